@@ -1,0 +1,82 @@
+/*
+ * miso_philox.h -- the counter-based RNG contract shared by the HIP kernels, the host
+ * library and the CPU checker (oracle/miso_oracle.c, counter mode).
+ *
+ * Why it exists: the reference draws from ONE global sequential stream
+ * (pysplicing/src/random.c:491 splicing_rng_default; in CPython, Python's `random`,
+ * pyrandom.c:163-184) whose consumption is data dependent (miso.c:65-80 draws only for
+ * reads with >= 2 compatible isoforms; miso.c:870 short-circuits the accept draw).  Thousands
+ * of events sampled concurrently cannot share such a stream, so every draw gets a fixed
+ * address instead:
+ *
+ *     Philox4x32-10( key = (seed_lo, seed_hi),
+ *                    ctr = (block, iteration, site | chain << 8, event_id) ) -> 4 x u32
+ *
+ *   site MISO_SITE_MH  (0): block 0 word 0        = accept uniform        (miso.c:870)
+ *                           word 2+2j, 3+2j       = the two uniforms of proposal normal j
+ *                                                   (random.c:1543-1551: u=(int)(2^27 u1)+u2)
+ *                           (words continue into block 1, 2, ... for K-1 > 1 normals)
+ *   site MISO_SITE_GIBBS (2): word r (block r/4, lane r%4) = the uniform of the r-th read that
+ *                           has >= 2 compatible isoforms, counted in read order (miso.c:69-80)
+ *   iteration = m for the main loop (miso.c:847), MISO_ITER_INIT for the set-up draws
+ *   (initial proposal miso.c:834 and initial assignment miso.c:841).
+ *
+ * A uniform is u32 * 2^-32, the same 32-bit resolution as the reference's stand-alone
+ * generator (random.c:382 splicing_rng_mt19937_get_real).
+ *
+ * Philox4x32-10: Salmon, Moraes, Dror, Shaw, "Parallel random numbers: as easy as 1, 2, 3",
+ * SC'11 -- constants and round function as published there.
+ */
+#ifndef MISO_PHILOX_H
+#define MISO_PHILOX_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define MISO_HD __host__ __device__ __forceinline__
+#else
+#define MISO_HD static inline
+#endif
+
+#define MISO_SITE_MH    0u
+#define MISO_SITE_GIBBS 2u
+#define MISO_ITER_INIT  0xFFFFFFFFu
+
+#define MISO_PHILOX_M0 0xD2511F53u
+#define MISO_PHILOX_M1 0xCD9E8D57u
+#define MISO_PHILOX_W0 0x9E3779B9u
+#define MISO_PHILOX_W1 0xBB67AE85u
+
+typedef struct { uint32_t v[4]; } miso_u32x4;
+
+MISO_HD miso_u32x4 miso_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                      uint32_t k0, uint32_t k1) {
+  miso_u32x4 out;
+  int r;
+  for (r = 0; r < 10; r++) {
+    uint64_t p0 = (uint64_t) MISO_PHILOX_M0 * c0;
+    uint64_t p1 = (uint64_t) MISO_PHILOX_M1 * c2;
+    uint32_t n0 = (uint32_t) (p1 >> 32) ^ c1 ^ k0;
+    uint32_t n2 = (uint32_t) (p0 >> 32) ^ c3 ^ k1;
+    c1 = (uint32_t) p1;
+    c3 = (uint32_t) p0;
+    c0 = n0;
+    c2 = n2;
+    k0 += MISO_PHILOX_W0;
+    k1 += MISO_PHILOX_W1;
+  }
+  out.v[0] = c0; out.v[1] = c1; out.v[2] = c2; out.v[3] = c3;
+  return out;
+}
+
+/* The addressed form used everywhere: one block of four words. */
+MISO_HD miso_u32x4 miso_draw_block(uint64_t seed, uint32_t event_id, uint32_t chain,
+                                   uint32_t iteration, uint32_t site, uint32_t block) {
+  return miso_philox4x32_10(block, iteration, site | (chain << 8), event_id,
+                            (uint32_t) seed, (uint32_t) (seed >> 32));
+}
+
+/* u32 -> [0,1) with 32-bit resolution; exact in double. */
+MISO_HD double miso_u01(uint32_t w) { return (double) w * (1.0 / 4294967296.0); }
+
+#endif /* MISO_PHILOX_H */
