@@ -1,0 +1,188 @@
+/*
+ * miso_amd.h -- C ABI of libmiso_amd.so: the MI355X-native MISO posterior sampler.
+ *
+ * This is the drop-in boundary for the one hot path of yarden/MISO: what the reference's
+ * CPython glue (pysplicing/src/pysplicing.c) binds in the C core for `createGene`, `MISO` and
+ * `MISOPaired`.  Plain pointers and sizes only; no Python, no torch, no HIP types.
+ *
+ *   reference symbol (file:line under /root/reference/pysplicing)   replaced by
+ *   ------------------------------------------------------------   ------------------------
+ *   splicing_create_gene        src/simulator.c:9                   miso_create_gene
+ *   splicing_gff_destroy2       src/gff.c:80                        miso_gene_destroy
+ *   splicing_gff_noiso_one      src/gff.c:684                       miso_gene_noiso
+ *   splicing_gff_isolength_one  src/gff.c:689                       miso_gene_isolength
+ *   splicing_miso               src/miso.c:638   (include/splicing.h:203)  miso_run
+ *   splicing_miso_paired        src/miso_paired.c:241 (splicing.h:216)     miso_run_paired
+ *   splicing_matchIso           src/solve.c:8                       miso_match_iso
+ *   splicing_matchIso_paired    src/solve.c:141                     miso_match_iso_paired
+ *   splicing_strerror           src/error.c:71                      miso_strerror
+ *   splicing_error handler hook src/pyerror.c:27-44                 miso_last_error
+ *
+ * The reference runs ONE event per call on one CPU core.  A GPU needs thousands of events in
+ * flight, so besides the per-event calls (a batch of one) the library exports a batch object:
+ * add events, upload once, launch, read results per event.  Events are independent
+ * (SURVEY.md section 8e): sharding a run over GPUs is a static split of the event list, each
+ * shard a batch on its own device; results do not depend on the split because every random
+ * draw is addressed by (seed, global event id, chain, iteration) -- include/miso_philox.h.
+ *
+ * Matrices are column-major as in the reference (include/splicing_matrix.h:67):
+ * samples[K x S] stores sample s at samples[s*K .. s*K+K-1]; class_templates[K x ncls] likewise.
+ * Error codes are the reference's (include/splicing_error.h:314-351).
+ *
+ * There is NO CPU fallback: every sampler entry point fails with MISO_ENODEVICE when no HIP
+ * device is usable.
+ */
+#ifndef MISO_AMD_H
+#define MISO_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes (splicing_error.h:314-351) ---- */
+#define MISO_SUCCESS 0
+#define MISO_FAILURE 1
+#define MISO_ENOMEM 2
+#define MISO_EINVAL 4
+#define MISO_UNIMPLEMENTED 12
+#define MISO_EINTERNAL 38
+#define MISO_ENODEVICE 60 /* new: no usable HIP device / HIP runtime error */
+
+/* ---- enums (splicing.h:59-62, 148-158; pysplicing/__init__.py:2-13) ---- */
+#define MISO_ALGO_REASSIGN 0
+#define MISO_ALGO_MARGINAL 1
+#define MISO_ALGO_CLASSES 2
+#define MISO_START_AUTO 0
+#define MISO_START_UNIFORM 1
+#define MISO_START_RANDOM 2
+#define MISO_START_GIVEN 3
+#define MISO_START_LINEAR 4
+#define MISO_STOP_FIXEDNO 0
+#define MISO_STOP_CONVERGENT_MEAN 1
+
+#define MISO_MAX_ISOFORMS 32
+
+/* splicing_miso_rundata_t (splicing.h:143-146), same field order */
+typedef struct miso_rundata {
+  int noIso, noIters, maxIters, noBurnIn, noLag, noAccepted, noRejected, noChains, noSamples;
+} miso_rundata_t;
+
+typedef struct miso_gene miso_gene_t;   /* one gene = the reference's splicing_gff_t handle */
+typedef struct miso_batch miso_batch_t;
+
+/* ---- errors ---- */
+const char *miso_strerror(int code);
+/* "Error at <file>:<line>: <reason>, <strerror>" of the calling thread's last failure
+   (the text pyerror.c:27-44 turns into the Python exception). */
+const char *miso_last_error(void);
+
+/* ---- device ---- */
+int miso_device_count(int *count);
+int miso_set_device(int device);
+
+/* ---- gene model ---- */
+/* exons: 2*n_exons ints (start,end; 1-based inclusive). isoforms: exon indices, each isoform
+   terminated by -1 (the flattening pyconvert.c:55-87 produces). strand: 0 +, 1 -, 2 unknown. */
+int miso_create_gene(const int *exons, int n_exons, const int *isoforms, int n_isoforms_flat,
+                     const char *id, const char *seqid, const char *source, int strand,
+                     miso_gene_t **gene);
+void miso_gene_destroy(miso_gene_t *gene);
+int miso_gene_noiso(const miso_gene_t *gene, int *noiso);
+int miso_gene_isolength(const miso_gene_t *gene, int *isolength /* noiso */);
+
+/* ---- problem construction on the host (input builder of the path) ---- */
+/* match: noiso x n_reads, 1.0 / 0.0 */
+int miso_match_iso(const miso_gene_t *gene, const int *position, const char *const *cigarstr,
+                   int n_reads, int overHang, int readLength, double *match);
+/* position/cigarstr hold 2*n_pairs mates (consecutive). match: noiso x n_pairs fragment
+   probabilities (0 = incompatible); fragmentLength: noiso x n_pairs (-1 = none), may be NULL */
+int miso_match_iso_paired(const miso_gene_t *gene, const int *position,
+                          const char *const *cigarstr, int n_positions, int readLength,
+                          int overHang, double normalMean, double normalVar, double numDevs,
+                          double *match, int *fragmentLength);
+
+/* ---- one event per call: splicing_miso / splicing_miso_paired ---- */
+/* Output sizes: samples noiso*S, logLik S with S = noChains*(noIterations-noBurnIn)/noLag;
+   class_templates noiso*n_reads (worst case), class_counts n_reads, assignment n_reads.
+   Any output pointer may be NULL.  seed: the one addition to the reference signature. */
+int miso_run(const miso_gene_t *gene, const int *position, const char *const *cigarstr,
+             int n_reads, int readLength, int overHang, int noChains, int noIterations,
+             int maxIterations, int noBurnIn, int noLag, const double *hyperp, int n_hyperp,
+             int algorithm, int start, int stop, uint64_t seed, double *samples, double *logLik,
+             double *class_templates, double *class_counts, int *n_classes, int *assignment,
+             miso_rundata_t *rundata);
+
+int miso_run_paired(const miso_gene_t *gene, const int *position, const char *const *cigarstr,
+                    int n_positions, int readLength, int overHang, int noChains,
+                    int noIterations, int maxIterations, int noBurnIn, int noLag,
+                    const double *hyperp, int n_hyperp, int start, int stop, double normalMean,
+                    double normalVar, double numDevs, uint64_t seed, double *samples,
+                    double *logLik, double *bin_class_templates, double *bin_class_counts,
+                    int *n_classes, int *assignment, miso_rundata_t *rundata);
+
+/* ---- many events per launch ---- */
+typedef struct miso_params {
+  int paired;                /* 0 single-end (splicing_miso), 1 paired-end (splicing_miso_paired) */
+  int readLength, overHang;
+  int noChains, noIterations, maxIterations, noBurnIn, noLag;
+  int algorithm, start, stop;
+  double normalMean, normalVar, numDevs; /* paired only */
+  int want_counts_trace;     /* tests: keep the per-iteration assignment counts of every chain */
+} miso_params_t;
+
+int miso_batch_create(const miso_params_t *params, miso_batch_t **batch);
+void miso_batch_destroy(miso_batch_t *batch);
+
+/* Adds one event built from alignments; hyperp NULL = all ones. *event_index = position in
+   the batch (also its offset from first_event_id in the RNG address). */
+int miso_batch_add_event(miso_batch_t *batch, const miso_gene_t *gene, const int *position,
+                         const char *const *cigarstr, int n_positions, const double *hyperp,
+                         int n_hyperp, int *event_index);
+
+/* Adds one event from an already built problem: match noiso x n_reads as miso_match_iso[_paired]
+   returns it (+ fragmentLength for paired), isoform lengths and exon counts (gff.c:583-657). */
+int miso_batch_add_problem(miso_batch_t *batch, int noiso, int n_reads, const double *match,
+                           const int *fragmentLength, const int *isolength, const int *noexons,
+                           const double *hyperp, int *event_index);
+
+int miso_batch_size(const miso_batch_t *batch, int *n_events);
+
+/* pack + copy to HBM (idempotent) */
+int miso_batch_upload(miso_batch_t *batch, int device);
+/* enqueue the sampler kernels for every event on the batch's stream; returns immediately */
+int miso_batch_launch(miso_batch_t *batch, uint64_t seed, uint32_t first_event_id);
+/* wait for the stream; *kernel_ms (may be NULL) = HIP-event time of the launches */
+int miso_batch_sync(miso_batch_t *batch, float *kernel_ms);
+/* copy results back to the host (after sync) */
+int miso_batch_download(miso_batch_t *batch);
+/* upload + launch + sync + download */
+int miso_batch_run(miso_batch_t *batch, int device, uint64_t seed, uint32_t first_event_id);
+
+int miso_batch_event_info(const miso_batch_t *batch, int event_index, int *noiso, int *n_reads,
+                          int *n_samples, int *n_classes);
+int miso_batch_get_result(const miso_batch_t *batch, int event_index, double *samples,
+                          double *logLik, double *class_templates, double *class_counts,
+                          int *assignment, miso_rundata_t *rundata);
+/* parity instrumentation: FNV-1a over every chain's per-iteration assignment counts
+   (counts_hash: noChains words) and, if want_counts_trace, the counts themselves
+   ((noIterations+1) x noChains x noiso int32, row m = counts the MH step of iteration m saw,
+   last row = final state). */
+int miso_batch_get_trace(const miso_batch_t *batch, int event_index, uint64_t *counts_hash,
+                         int32_t *counts_trace);
+
+/* bytes the kernels of the last launch moved by the reference algorithm's accounting
+   (SE (8K+20)N, PE (8K+28)N per chain-iteration + load/store) */
+int miso_batch_algorithmic_bytes(const miso_batch_t *batch, double *bytes);
+
+/* device-side self test of the arithmetic contract: evaluates miso_detmath / Philox on the GPU
+   for n inputs; out_* are host arrays of n doubles (used by tests/test_gpu_contract.py) */
+int miso_selftest_detmath(const double *x, int n, double *out_exp, double *out_log,
+                          double *out_sqrt, double *out_qnorm);
+int miso_selftest_philox(const uint32_t *ctr_key6, int n, uint32_t *out4);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MISO_AMD_H */

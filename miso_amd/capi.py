@@ -1,0 +1,264 @@
+"""ctypes binding of libmiso_amd.so (include/miso_amd.h).
+
+This is the only way Python reaches the sampler: there is no Python or CPU implementation of
+the path behind it.  Importing works without a GPU (so the symbol table can be checked);
+every sampler call raises ``InternalError`` when no HIP device is usable.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmiso_amd.so")
+
+MISO_SUCCESS, MISO_FAILURE, MISO_ENOMEM, MISO_EINVAL = 0, 1, 2, 4
+MISO_UNIMPLEMENTED, MISO_EINTERNAL, MISO_ENODEVICE = 12, 38, 60
+
+# pysplicing/pysplicing/__init__.py:2-13
+MISO_START_AUTO, MISO_START_UNIFORM, MISO_START_RANDOM, MISO_START_GIVEN, MISO_START_LINEAR = range(5)
+MISO_STOP_FIXEDNO, MISO_STOP_CONVERGENT_MEAN = 0, 1
+MISO_ALGO_REASSIGN, MISO_ALGO_MARGINAL, MISO_ALGO_CLASSES = 0, 1, 2
+
+
+class InternalError(Exception):
+    """pysplicing.InternalError (pysplicing.c:699-702)."""
+
+
+class RunData(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("noIso", "noIters", "maxIters", "noBurnIn", "noLag",
+                                       "noAccepted", "noRejected", "noChains", "noSamples")]
+
+
+class Params(C.Structure):
+    _fields_ = [("paired", C.c_int), ("readLength", C.c_int), ("overHang", C.c_int),
+                ("noChains", C.c_int), ("noIterations", C.c_int), ("maxIterations", C.c_int),
+                ("noBurnIn", C.c_int), ("noLag", C.c_int), ("algorithm", C.c_int),
+                ("start", C.c_int), ("stop", C.c_int), ("normalMean", C.c_double),
+                ("normalVar", C.c_double), ("numDevs", C.c_double),
+                ("want_counts_trace", C.c_int)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libmiso_amd.so; fail loudly if the HIP extension was not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "miso_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as "
+                "g; g.build()'` (hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        _lib.miso_last_error.restype = C.c_char_p
+        _lib.miso_strerror.restype = C.c_char_p
+        _lib.miso_batch_launch.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32]
+        _lib.miso_batch_run.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint32]
+    return _lib
+
+
+def check(rc):
+    """Raise like pyerror.c:27-44: MemoryError / NotImplementedError / InternalError."""
+    if rc == MISO_SUCCESS:
+        return
+    msg = lib().miso_last_error().decode(errors="replace")
+    if rc == MISO_ENOMEM:
+        raise MemoryError(msg)
+    if rc == MISO_UNIMPLEMENTED:
+        raise NotImplementedError(msg)
+    raise InternalError(msg)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _cigs(cigars):
+    arr = (C.c_char_p * max(len(cigars), 1))()
+    for i, c in enumerate(cigars):
+        arr[i] = c if isinstance(c, bytes) else c.encode()
+    return arr
+
+
+def device_count():
+    n = C.c_int(0)
+    check(lib().miso_device_count(C.byref(n)))
+    return n.value
+
+
+def set_device(d):
+    check(lib().miso_set_device(int(d)))
+
+
+class Gene:
+    """One gene: exons as (start, end) 1-based inclusive, isoforms as tuples of exon indices
+    (py2c_gene.py:10-21 builds exactly these for the reference's createGene)."""
+
+    def __init__(self, exons, isoforms, id="insilicogene", seqid="seq1", source="protein_coding",
+                 strand=2):
+        ex = np.asarray(exons, dtype=np.int32).reshape(-1)
+        flat = []
+        for iso in isoforms:
+            flat.extend(int(e) for e in iso)
+            flat.append(-1)
+        flat = np.asarray(flat, dtype=np.int32)
+        h = C.c_void_p()
+        check(lib().miso_create_gene(_p(ex), len(ex) // 2, _p(flat), len(flat), id.encode(),
+                                     seqid.encode(), source.encode(), int(strand), C.byref(h)))
+        self.handle = h
+
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h and _lib is not None:
+            _lib.miso_gene_destroy(h)
+
+    @property
+    def noiso(self):
+        n = C.c_int(0)
+        check(lib().miso_gene_noiso(self.handle, C.byref(n)))
+        return n.value
+
+    def isolength(self):
+        out = np.zeros(self.noiso, np.int32)
+        check(lib().miso_gene_isolength(self.handle, _p(out)))
+        return out
+
+    def match_iso(self, pos, cigars, read_len, overhang=1):
+        pos = np.asarray(pos, dtype=np.int32)
+        m = np.zeros((max(len(pos), 1), self.noiso))
+        check(lib().miso_match_iso(self.handle, _p(pos), _cigs(cigars), len(pos), overhang,
+                                   read_len, _p(m)))
+        return m[:len(pos)]
+
+    def match_iso_paired(self, pos, cigars, read_len, mean, var, num_devs=4.0, overhang=1):
+        pos = np.asarray(pos, dtype=np.int32)
+        n = len(pos) // 2
+        m = np.zeros((max(n, 1), self.noiso))
+        fl = np.zeros((max(n, 1), self.noiso), np.int32)
+        check(lib().miso_match_iso_paired(self.handle, _p(pos), _cigs(cigars), len(pos), read_len,
+                                          overhang, C.c_double(mean), C.c_double(var),
+                                          C.c_double(num_devs), _p(m), _p(fl)))
+        return m[:n], fl[:n]
+
+
+class EventResult:
+    def __init__(self, samples, loglik, templates, counts, assignment, rundata, counts_hash,
+                 counts_trace):
+        self.samples = samples              # [S, K]
+        self.loglik = loglik                # [S]
+        self.class_templates = templates    # [ncls, K]
+        self.class_counts = counts          # [ncls]
+        self.assignment = assignment        # [N]
+        self.rundata = rundata              # RunData
+        self.counts_hash = counts_hash      # [C] uint64
+        self.counts_trace = counts_trace    # [(M+1), C, K] or None
+
+    def as_tuple(self):
+        """The 6-tuple pysplicing.MISO returns (pysplicing.c:112-130, pyconvert.c:172-181)."""
+        rd = self.rundata
+        K = self.samples.shape[1] if self.samples.ndim == 2 else 0
+        return (tuple(tuple(float(v) for v in self.samples[:, k]) for k in range(K)),
+                tuple(float(v) for v in self.loglik),
+                tuple(tuple(float(v) for v in row) for row in self.class_templates),
+                tuple(float(v) for v in self.class_counts),
+                tuple(int(v) for v in self.assignment),
+                (rd.noIso, rd.noIters, rd.noBurnIn, rd.noLag, rd.noAccepted, rd.noRejected))
+
+
+class Batch:
+    """Many events, one launch (miso_batch_* in include/miso_amd.h)."""
+
+    def __init__(self, read_len, iters=5000, burn=500, lag=10, chains=6, overhang=1, paired=False,
+                 mean=0.0, var=0.0, num_devs=4.0, start=MISO_START_AUTO, stop=MISO_STOP_FIXEDNO,
+                 algo=MISO_ALGO_REASSIGN, max_iters=100000, counts_trace=False):
+        self.params = Params(int(paired), read_len, overhang, chains, iters, max_iters, burn, lag,
+                             algo, start, stop, mean, var, num_devs, int(counts_trace))
+        self.handle = C.c_void_p()
+        check(lib().miso_batch_create(C.byref(self.params), C.byref(self.handle)))
+
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h and _lib is not None:
+            _lib.miso_batch_destroy(h)
+
+    def add_event(self, gene, pos, cigars, hyper=None):
+        pos = np.asarray(pos, dtype=np.int32)
+        hy = None if hyper is None else np.asarray(hyper, dtype=np.float64)
+        idx = C.c_int(-1)
+        check(lib().miso_batch_add_event(self.handle, gene.handle, _p(pos), _cigs(cigars), len(pos),
+                                         _p(hy), 0 if hy is None else len(hy), C.byref(idx)))
+        return idx.value
+
+    def add_problem(self, match, isolen, noexons, fraglen=None, hyper=None):
+        """match: [N, K] (C-order) as Gene.match_iso returns it."""
+        match = np.ascontiguousarray(match, dtype=np.float64)
+        N, K = match.shape
+        isolen = np.asarray(isolen, dtype=np.int32)
+        noexons = np.asarray(noexons, dtype=np.int32)
+        fl = None if fraglen is None else np.ascontiguousarray(fraglen, dtype=np.int32)
+        hy = None if hyper is None else np.asarray(hyper, dtype=np.float64)
+        idx = C.c_int(-1)
+        check(lib().miso_batch_add_problem(self.handle, K, N, _p(match), _p(fl), _p(isolen),
+                                           _p(noexons), _p(hy), C.byref(idx)))
+        return idx.value
+
+    def __len__(self):
+        n = C.c_int(0)
+        check(lib().miso_batch_size(self.handle, C.byref(n)))
+        return n.value
+
+    def upload(self, device=0):
+        check(lib().miso_batch_upload(self.handle, int(device)))
+
+    def launch(self, seed=0, first_event_id=0):
+        check(lib().miso_batch_launch(self.handle, int(seed), int(first_event_id)))
+
+    def sync(self):
+        ms = C.c_float(0)
+        check(lib().miso_batch_sync(self.handle, C.byref(ms)))
+        return ms.value
+
+    def download(self):
+        check(lib().miso_batch_download(self.handle))
+
+    def run(self, device=0, seed=0, first_event_id=0):
+        check(lib().miso_batch_run(self.handle, int(device), int(seed), int(first_event_id)))
+
+    def algorithmic_bytes(self):
+        b = C.c_double(0)
+        check(lib().miso_batch_algorithmic_bytes(self.handle, C.byref(b)))
+        return b.value
+
+    def result(self, i, trace=False):
+        K, N, S, ncls = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        check(lib().miso_batch_event_info(self.handle, i, C.byref(K), C.byref(N), C.byref(S),
+                                          C.byref(ncls)))
+        K, N, S, ncls = K.value, N.value, S.value, ncls.value
+        samples = np.zeros((max(S, 1), K))
+        ll = np.zeros(max(S, 1))
+        ct = np.zeros((max(ncls, 1), K))
+        cc = np.zeros(max(ncls, 1))
+        ass = np.zeros(max(N, 1), np.int32)
+        rd = RunData()
+        check(lib().miso_batch_get_result(self.handle, i, _p(samples), _p(ll), _p(ct), _p(cc),
+                                          _p(ass), C.byref(rd)))
+        Cn, M = self.params.noChains, self.params.noIterations
+        h = np.zeros(Cn, np.uint64)
+        tr = np.zeros((M + 1, Cn, K), np.int32) if trace else None
+        check(lib().miso_batch_get_trace(self.handle, i, _p(h), _p(tr)))
+        return EventResult(samples[:S], ll[:S], ct[:ncls], cc[:ncls], ass[:N], rd, h, tr)
+
+
+def selftest_detmath(x):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    outs = [np.zeros_like(x) for _ in range(4)]
+    check(lib().miso_selftest_detmath(_p(x), len(x), *[_p(o) for o in outs]))
+    return outs
+
+
+def selftest_philox(ctr_key6):
+    a = np.ascontiguousarray(ctr_key6, dtype=np.uint32).reshape(-1, 6)
+    out = np.zeros((len(a), 4), np.uint32)
+    check(lib().miso_selftest_philox(_p(a), len(a), _p(out)))
+    return out

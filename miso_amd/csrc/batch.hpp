@@ -1,0 +1,44 @@
+// batch.hpp -- the batch object behind miso_batch_t (definition shared by runtime.hip / capi.hip)
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <vector>
+
+#include "device.hpp"
+#include "host.hpp"
+
+namespace miso {
+int device_count();
+void set_device(int d);
+miso_batch *batch_new(const miso_params_t &p);
+void selftest_detmath(const double *x, int n, double *e, double *l, double *s, double *q);
+void selftest_philox(const uint32_t *in6, int n, uint32_t *out4);
+}  // namespace miso
+
+struct miso_batch {
+  miso_params_t p{};
+  miso::FragmentDist fd;                 // paired only
+  std::vector<miso::PackedEvent> events;
+  // device
+  int device = -1;
+  bool uploaded = false, launched = false, downloaded = false;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  miso::DevEvent *d_events = nullptr;
+  unsigned char *d_in = nullptr, *d_out = nullptr;
+  double *d_fp = nullptr;
+  std::vector<miso::DevEvent> h_events;
+  std::vector<unsigned char> h_out;
+  uint64_t in_bytes = 0, out_bytes = 0;
+  float last_ms = 0.f;
+
+  int S() const { return p.noChains * (p.noIterations - p.noBurnIn) / p.noLag; }
+  ~miso_batch() { release(); }
+  void release();
+  void upload(int dev);
+  void launch(uint64_t seed, uint32_t first_event_id);
+  void sync(float *ms);
+  void download();
+};

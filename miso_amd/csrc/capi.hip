@@ -1,0 +1,304 @@
+// capi.hip -- the extern "C" surface declared in include/miso_amd.h.
+//
+// Error convention of the reference (splicing_error.h:548 SPLICING_CHECK, pyerror.c:27-44): every
+// entry point returns an int code; the text "Error at file:line: reason, strerror" of the last
+// failure is kept per thread for the binding to raise.
+#include <cstring>
+#include <memory>
+#include <new>
+#include <string>
+
+#include "batch.hpp"
+
+using namespace miso;
+
+struct miso_gene { Gene g; };
+
+namespace {
+thread_local std::string g_last_error;
+struct Rethrow { int code; };  // an inner entry point already recorded the error text
+
+template <class F> int guarded(F &&f) {
+  try {
+    f();
+    return MISO_SUCCESS;
+  } catch (const Rethrow &r) {
+    return r.code;
+  } catch (const Error &e) {
+    g_last_error = e.text;
+    return e.code;
+  } catch (const std::bad_alloc &) {
+    g_last_error = "Error at capi.hip:0: allocation failed, Out of memory";
+    return MISO_ENOMEM;
+  } catch (const std::exception &e) {
+    g_last_error = std::string("Error at capi.hip:0: ") + e.what() + ", Internal error, likely a bug";
+    return MISO_EINTERNAL;
+  }
+}
+
+void need(const void *p, const char *what) {
+  if (!p) MISO_FAIL(MISO_EINVAL, std::string(what) + " must not be NULL");
+}
+
+void fill_rundata(const miso_batch &b, int K, int accepted, miso_rundata_t *rd) {
+  rd->noIso = K; rd->noIters = b.p.noIterations; rd->maxIters = 0; rd->noBurnIn = b.p.noBurnIn;
+  rd->noLag = b.p.noLag; rd->noAccepted = accepted;
+  rd->noRejected = b.p.noChains * b.p.noIterations - accepted;
+  rd->noChains = b.p.noChains; rd->noSamples = b.S();
+}
+
+const PackedEvent &event_at(const miso_batch *b, int i) {
+  if (i < 0 || i >= static_cast<int>(b->events.size())) MISO_FAIL(MISO_EINVAL, "event index out of range");
+  return b->events[i];
+}
+}  // namespace
+
+extern "C" {
+
+const char *miso_strerror(int code) { return strerror_code(code); }
+const char *miso_last_error(void) { return g_last_error.c_str(); }
+
+int miso_device_count(int *count) {
+  return guarded([&] { need(count, "count"); *count = device_count(); });
+}
+int miso_set_device(int device) { return guarded([&] { set_device(device); }); }
+
+int miso_create_gene(const int *exons, int n_exons, const int *isoforms, int n_flat, const char *id,
+                     const char *seqid, const char *source, int strand, miso_gene_t **gene) {
+  return guarded([&] {
+    need(gene, "gene");
+    auto g = std::make_unique<miso_gene>();
+    g->g = make_gene(exons, n_exons, isoforms, n_flat, id, seqid, source, strand);
+    *gene = g.release();
+  });
+}
+void miso_gene_destroy(miso_gene_t *gene) { delete gene; }
+int miso_gene_noiso(const miso_gene_t *gene, int *noiso) {
+  return guarded([&] { need(gene, "gene"); need(noiso, "noiso"); *noiso = gene->g.K; });
+}
+int miso_gene_isolength(const miso_gene_t *gene, int *isolength) {
+  return guarded([&] {
+    need(gene, "gene"); need(isolength, "isolength");
+    std::memcpy(isolength, gene->g.isolen.data(), sizeof(int) * gene->g.K);
+  });
+}
+
+int miso_match_iso(const miso_gene_t *gene, const int *position, const char *const *cigarstr,
+                   int n_reads, int overHang, int readLength, double *match) {
+  return guarded([&] {
+    need(gene, "gene"); need(match, "match");
+    match_iso(gene->g, position, cigarstr, n_reads, overHang, readLength, match);
+  });
+}
+
+int miso_match_iso_paired(const miso_gene_t *gene, const int *position, const char *const *cigarstr,
+                          int n_positions, int readLength, int overHang, double normalMean,
+                          double normalVar, double numDevs, double *match, int *fragmentLength) {
+  return guarded([&] {
+    need(gene, "gene"); need(match, "match");
+    const FragmentDist fd = normal_fragment(normalMean, normalVar, numDevs, readLength);
+    match_iso_paired(gene->g, position, cigarstr, n_positions, readLength, overHang, fd, match,
+                     fragmentLength);
+  });
+}
+
+int miso_batch_create(const miso_params_t *params, miso_batch_t **batch) {
+  return guarded([&] { need(params, "params"); need(batch, "batch"); *batch = batch_new(*params); });
+}
+void miso_batch_destroy(miso_batch_t *batch) { delete batch; }
+
+int miso_batch_add_event(miso_batch_t *b, const miso_gene_t *gene, const int *position,
+                         const char *const *cigarstr, int n_positions, const double *hyperp,
+                         int n_hyperp, int *event_index) {
+  return guarded([&] {
+    need(b, "batch"); need(gene, "gene");
+    const Gene &g = gene->g;
+    if (hyperp && n_hyperp != g.K) MISO_FAIL(MISO_EINVAL, "Invalid hyperparameter vector length");
+    if (b->uploaded) MISO_FAIL(MISO_EINVAL, "batch already uploaded");
+    const int N = b->p.paired ? n_positions / 2 : n_positions;
+    std::vector<double> match(static_cast<size_t>(g.K) * (N > 0 ? N : 1));
+    std::vector<int> fraglen;
+    if (b->p.paired) {
+      fraglen.resize(match.size());
+      match_iso_paired(g, position, cigarstr, n_positions, b->p.readLength, b->p.overHang, b->fd,
+                       match.data(), fraglen.data());
+    } else {
+      match_iso(g, position, cigarstr, N, b->p.overHang, b->p.readLength, match.data());
+    }
+    b->events.push_back(pack_event(b->p, b->p.paired ? &b->fd : nullptr, g.K, N, match.data(),
+                                   b->p.paired ? fraglen.data() : nullptr, g.isolen.data(),
+                                   g.noexons.data(), hyperp));
+    if (event_index) *event_index = static_cast<int>(b->events.size()) - 1;
+  });
+}
+
+int miso_batch_add_problem(miso_batch_t *b, int noiso, int n_reads, const double *match,
+                           const int *fragmentLength, const int *isolength, const int *noexons,
+                           const double *hyperp, int *event_index) {
+  return guarded([&] {
+    need(b, "batch"); need(isolength, "isolength"); need(noexons, "noexons");
+    if (n_reads > 0) need(match, "match");
+    if (b->p.paired && n_reads > 0) need(fragmentLength, "fragmentLength");
+    if (b->uploaded) MISO_FAIL(MISO_EINVAL, "batch already uploaded");
+    b->events.push_back(pack_event(b->p, b->p.paired ? &b->fd : nullptr, noiso, n_reads, match,
+                                   fragmentLength, isolength, noexons, hyperp));
+    if (event_index) *event_index = static_cast<int>(b->events.size()) - 1;
+  });
+}
+
+int miso_batch_size(const miso_batch_t *b, int *n) {
+  return guarded([&] { need(b, "batch"); need(n, "n_events"); *n = static_cast<int>(b->events.size()); });
+}
+int miso_batch_upload(miso_batch_t *b, int device) {
+  return guarded([&] { need(b, "batch"); b->upload(device); });
+}
+int miso_batch_launch(miso_batch_t *b, uint64_t seed, uint32_t first_event_id) {
+  return guarded([&] { need(b, "batch"); b->launch(seed, first_event_id); });
+}
+int miso_batch_sync(miso_batch_t *b, float *ms) {
+  return guarded([&] { need(b, "batch"); b->sync(ms); });
+}
+int miso_batch_download(miso_batch_t *b) {
+  return guarded([&] { need(b, "batch"); b->download(); });
+}
+int miso_batch_run(miso_batch_t *b, int device, uint64_t seed, uint32_t first_event_id) {
+  return guarded([&] {
+    need(b, "batch");
+    b->upload(device); b->launch(seed, first_event_id); b->sync(nullptr); b->download();
+  });
+}
+
+int miso_batch_event_info(const miso_batch_t *b, int i, int *noiso, int *n_reads, int *n_samples,
+                          int *n_classes) {
+  return guarded([&] {
+    need(b, "batch");
+    const PackedEvent &e = event_at(b, i);
+    if (noiso) *noiso = e.K;
+    if (n_reads) *n_reads = e.N;
+    if (n_samples) *n_samples = b->S();
+    if (n_classes) *n_classes = static_cast<int>(e.class_counts.size());
+  });
+}
+
+int miso_batch_get_result(const miso_batch_t *b, int i, double *samples, double *logLik,
+                          double *class_templates, double *class_counts, int *assignment,
+                          miso_rundata_t *rundata) {
+  return guarded([&] {
+    need(b, "batch");
+    const PackedEvent &e = event_at(b, i);
+    if (!b->downloaded) MISO_FAIL(MISO_EINVAL, "results not downloaded yet");
+    const DevEvent &d = b->h_events[i];
+    const unsigned char *out = b->h_out.data();
+    const int S = b->S();
+    if (samples) std::memcpy(samples, out + d.off_samples, sizeof(double) * S * e.K);
+    if (logLik) std::memcpy(logLik, out + d.off_loglik, sizeof(double) * S);
+    if (class_templates)
+      std::memcpy(class_templates, e.class_templates.data(), sizeof(double) * e.class_templates.size());
+    if (class_counts)
+      std::memcpy(class_counts, e.class_counts.data(), sizeof(double) * e.class_counts.size());
+    if (assignment) {  // chain 0, final state (miso.c:943-946)
+      const uint8_t *da = out + d.off_drawass;
+      int r = 0;
+      for (int k = 0; k < e.N; k++) assignment[k] = e.fixed_ass[k] == -2 ? da[r++] : e.fixed_ass[k];
+    }
+    if (rundata) {
+      const ChainStats *st = reinterpret_cast<const ChainStats *>(out + d.off_stats);
+      int acc = 0;
+      for (int c = 0; c < b->p.noChains; c++) acc += st[c].accepted;
+      fill_rundata(*b, e.K, acc, rundata);
+    }
+  });
+}
+
+int miso_batch_get_trace(const miso_batch_t *b, int i, uint64_t *counts_hash, int32_t *counts_trace) {
+  return guarded([&] {
+    need(b, "batch");
+    const PackedEvent &e = event_at(b, i);
+    if (!b->downloaded) MISO_FAIL(MISO_EINVAL, "results not downloaded yet");
+    const DevEvent &d = b->h_events[i];
+    const unsigned char *out = b->h_out.data();
+    if (counts_hash) {
+      const ChainStats *st = reinterpret_cast<const ChainStats *>(out + d.off_stats);
+      for (int c = 0; c < b->p.noChains; c++) counts_hash[c] = st[c].counts_hash;
+    }
+    if (counts_trace) {
+      if (d.off_trace == NO_TRACE) MISO_FAIL(MISO_EINVAL, "batch was created without want_counts_trace");
+      std::memcpy(counts_trace, out + d.off_trace,
+                  sizeof(int32_t) * (static_cast<size_t>(b->p.noIterations) + 1) * b->p.noChains * e.K);
+    }
+  });
+}
+
+int miso_batch_algorithmic_bytes(const miso_batch_t *b, double *bytes) {
+  return guarded([&] {
+    need(b, "batch"); need(bytes, "bytes");
+    // per chain-iteration SE (8K+20)N, PE (8K+28)N; per event
+    // + 8KN (match load) + 8(K+1)S (samples + logLik store)
+    double total = 0.0;
+    const double CM = static_cast<double>(b->p.noChains) * b->p.noIterations;
+    for (const PackedEvent &e : b->events) {
+      const double per_it = (8.0 * e.K + (b->p.paired ? 28.0 : 20.0)) * e.N;
+      total += CM * per_it + 8.0 * e.K * e.N + 8.0 * (e.K + 1) * b->S();
+    }
+    *bytes = total;
+  });
+}
+
+// one event per call = a batch of one
+static int run_one(const miso_params_t &p, const miso_gene_t *gene, const int *position,
+                   const char *const *cigarstr, int n_positions, const double *hyperp, int n_hyperp,
+                   uint64_t seed, double *samples, double *logLik, double *templates, double *counts,
+                   int *n_classes, int *assignment, miso_rundata_t *rundata) {
+  return guarded([&] {
+    need(gene, "gene");
+    if (!hyperp || n_hyperp != gene->g.K) MISO_FAIL(MISO_EINVAL, "Invalid hyperparameter vector length");
+    std::unique_ptr<miso_batch> b(batch_new(p));
+    int rc = miso_batch_add_event(b.get(), gene, position, cigarstr, n_positions, hyperp, n_hyperp, nullptr);
+    if (rc) throw Rethrow{rc};
+    int dev = 0;
+    (void) hipGetDevice(&dev);
+    b->upload(dev); b->launch(seed, 0); b->sync(nullptr); b->download();
+    rc = miso_batch_get_result(b.get(), 0, samples, logLik, templates, counts, assignment, rundata);
+    if (rc) throw Rethrow{rc};
+    if (n_classes) *n_classes = static_cast<int>(b->events[0].class_counts.size());
+  });
+}
+
+int miso_run(const miso_gene_t *gene, const int *position, const char *const *cigarstr, int n_reads,
+             int readLength, int overHang, int noChains, int noIterations, int maxIterations,
+             int noBurnIn, int noLag, const double *hyperp, int n_hyperp, int algorithm, int start,
+             int stop, uint64_t seed, double *samples, double *logLik, double *class_templates,
+             double *class_counts, int *n_classes, int *assignment, miso_rundata_t *rundata) {
+  miso_params_t p{};
+  p.paired = 0; p.readLength = readLength; p.overHang = overHang; p.noChains = noChains;
+  p.noIterations = noIterations; p.maxIterations = maxIterations; p.noBurnIn = noBurnIn;
+  p.noLag = noLag; p.algorithm = algorithm; p.start = start; p.stop = stop;
+  return run_one(p, gene, position, cigarstr, n_reads, hyperp, n_hyperp, seed, samples, logLik,
+                 class_templates, class_counts, n_classes, assignment, rundata);
+}
+
+int miso_run_paired(const miso_gene_t *gene, const int *position, const char *const *cigarstr,
+                    int n_positions, int readLength, int overHang, int noChains, int noIterations,
+                    int maxIterations, int noBurnIn, int noLag, const double *hyperp, int n_hyperp,
+                    int start, int stop, double normalMean, double normalVar, double numDevs,
+                    uint64_t seed, double *samples, double *logLik, double *bin_class_templates,
+                    double *bin_class_counts, int *n_classes, int *assignment,
+                    miso_rundata_t *rundata) {
+  miso_params_t p{};
+  p.paired = 1; p.readLength = readLength; p.overHang = overHang; p.noChains = noChains;
+  p.noIterations = noIterations; p.maxIterations = maxIterations; p.noBurnIn = noBurnIn;
+  p.noLag = noLag; p.algorithm = MISO_ALGO_REASSIGN; p.start = start; p.stop = stop;
+  p.normalMean = normalMean; p.normalVar = normalVar; p.numDevs = numDevs;
+  return run_one(p, gene, position, cigarstr, n_positions, hyperp, n_hyperp, seed, samples, logLik,
+                 bin_class_templates, bin_class_counts, n_classes, assignment, rundata);
+}
+
+int miso_selftest_detmath(const double *x, int n, double *out_exp, double *out_log, double *out_sqrt,
+                          double *out_qnorm) {
+  return guarded([&] { selftest_detmath(x, n, out_exp, out_log, out_sqrt, out_qnorm); });
+}
+int miso_selftest_philox(const uint32_t *ctr_key6, int n, uint32_t *out4) {
+  return guarded([&] { selftest_philox(ctr_key6, n, out4); });
+}
+
+}  // extern "C"

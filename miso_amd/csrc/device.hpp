@@ -1,0 +1,60 @@
+// device.hpp -- HBM layout shared by the host runtime and the HIP kernels.
+#pragma once
+
+#include <cstdint>
+
+namespace miso {
+
+// Per-event constants, doubles, at DevEvent::off_consts:
+//   [0, K)      cst_k    single-end: log(effective length) (miso.c:136-138)
+//                        paired-end: assscores_k           (miso_paired.c:412-419)
+//   [K, 2K)     iscore_k single-end: -log(l_k)             (miso.c:781-783); paired: unused
+//   [2K, 3K)    hyper_k - 1                                  (miso.c:174)
+//   [3K + 0]    lgamma(sum hyper)   [3K + 1] sum lgamma(hyper_k)   (miso.c:172-178)
+//   [3K + 2]    sigma = 0.2/K^2     [3K + 3] proposal sd           (miso.c:328, 188)
+//   [3K + 4]    (2 pi sigma)^(-(K-1)/2)                            (miso.c:101)
+constexpr int CONST_EXTRA = 5;
+
+struct DevEvent {
+  int32_t K;
+  int32_t n_draw;      // reads with >= 2 compatible isoforms
+  int32_t n_reads;
+  int32_t base_bad;    // paired: a fixed read carries a non-finite score
+  int64_t base_sfix;   // paired: fixed reads' score sum, 2^-32 fixed point
+  // byte offsets into the input pool
+  uint64_t off_consts; // double[3K + CONST_EXTRA]
+  uint64_t off_base;   // int32[K]: reads with exactly one compatible isoform, per isoform
+  uint64_t off_draw;   // SE: uint32 mask[n_draw (padded to 4)]; PE: uint16 frag[n_draw x K]
+  uint64_t off_sfix;   // PE: int64[K x il], INT64_MIN = non-finite
+  // byte offsets into the output pool
+  uint64_t off_samples; // double[S x K]  (reference layout: K x S column-major)
+  uint64_t off_loglik;  // double[S]
+  uint64_t off_drawass; // uint8[n_draw]: chain 0's final pick for every drawing read
+  uint64_t off_stats;   // per chain: {uint64 counts_hash; int32 accepted; int32 pad}
+  uint64_t off_trace;   // int32[(M+1) x C x K] or ~0 when not requested
+};
+
+struct ChainStats {
+  uint64_t counts_hash;
+  int32_t accepted;
+  int32_t pad;
+};
+
+struct KernelArgs {
+  const DevEvent *events;
+  const unsigned char *in_pool;
+  unsigned char *out_pool;
+  const double *frag_prob;  // paired: normalised fragment-length probabilities [il]
+  int32_t il;
+  int32_t n_events;
+  int32_t C, M, B, lag;     // chains, iterations (incl. burn-in), burn-in, lag
+  int32_t start;            // MISO_START_AUTO / MISO_START_UNIFORM
+  uint32_t first_event_id;
+  uint64_t seed;
+};
+
+constexpr uint64_t NO_TRACE = ~0ull;
+constexpr uint16_t FRAG_NONE = 0xFFFF;
+constexpr int64_t SFIX_BAD = INT64_MIN;
+
+}  // namespace miso

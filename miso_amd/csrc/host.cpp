@@ -1,0 +1,326 @@
+// host.cpp -- gene model, alignment matching and event packing (host side of the path).
+//
+// Reference behaviour followed (paths under /root/reference/pysplicing/):
+//   make_gene          src/simulator.c:9-66, src/gff.c:583-657, 728-777
+//   parse_cigars       src/solve.c:220-306
+//   match_iso          src/solve.c:8-108
+//   normal_fragment    src/simulator.c:198-219 + src/util.c:17-32, normalised miso_paired.c:303-307
+//   match_iso_paired   src/solve.c:141-218, src/gff.c:855-898, 1041-1084
+//   pack_event         src/miso.c:762-786, src/miso_paired.c:386-419 (set-up quantities)
+#include "host.hpp"
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+
+#include "device.hpp"
+
+namespace miso {
+
+const char *strerror_code(int code) {
+  switch (code) {
+  case MISO_SUCCESS: return "No error";
+  case MISO_FAILURE: return "Failed";
+  case MISO_ENOMEM: return "Out of memory";
+  case MISO_EINVAL: return "Invalid value";
+  case MISO_UNIMPLEMENTED: return "Unimplemented function call";
+  case MISO_EINTERNAL: return "Internal error, likely a bug";
+  case MISO_ENODEVICE: return "No usable HIP device";
+  default: return "Unknown error";
+  }
+}
+
+Error::Error(int c, const std::string &reason, const char *file, int line) : code(c) {
+  const char *base = std::strrchr(file, '/');
+  text = std::string("Error at ") + (base ? base + 1 : file) + ":" + std::to_string(line) + ": " +
+         reason + ", " + strerror_code(c);
+}
+
+Gene make_gene(const int *exons, int n_exons, const int *isoforms, int n_flat, const char *id,
+               const char *seqid, const char *source, int strand) {
+  if (!exons || !isoforms || n_exons <= 0 || n_flat <= 0)
+    MISO_FAIL(MISO_EINVAL, "Gene needs at least one exon and one isoform");
+  if (isoforms[n_flat - 1] >= 0)
+    MISO_FAIL(MISO_EINVAL, "Isoform list must be terminated by -1");
+  Gene g;
+  g.id = id ? id : "insilicogene";
+  g.seqid = seqid ? seqid : "seq1";
+  g.source = source ? source : "protein_coding";
+  g.strand = strand;
+  g.exidx.push_back(0);
+  int len = 0, nex = 0;
+  for (int i = 0; i < n_flat; i++) {
+    const int e = isoforms[i];
+    if (e < 0) {
+      g.exidx.push_back(static_cast<int>(g.exstart.size()));
+      g.isolen.push_back(len);
+      g.noexons.push_back(nex);
+      len = nex = 0;
+      continue;
+    }
+    if (e >= n_exons) MISO_FAIL(MISO_EINVAL, "Isoform refers to an exon that does not exist");
+    g.exstart.push_back(exons[2 * e]);
+    g.exend.push_back(exons[2 * e + 1]);
+    len += exons[2 * e + 1] - exons[2 * e] + 1;
+    nex++;
+  }
+  g.K = static_cast<int>(g.isolen.size());
+  return g;
+}
+
+CigarTable parse_cigars(const char *const *cigar, int n, int maxReadLength) {
+  CigarTable t;
+  t.idx.reserve(n + 1);
+  t.len.reserve(n);
+  for (int i = 0; i < n; i++) {
+    const char *s = cigar[i];
+    int phase = 0;  // 0: leading clips allowed, 1: body, 2: trailing clips only
+    int covered = 0;
+    t.idx.push_back(static_cast<int>(t.ops.size()));
+    while (s && *s) {
+      char *end = nullptr;
+      long l = std::strtol(s, &end, 10);
+      const char op = *end;
+      const bool clip = (op == 'S' || op == 'H');
+      if (phase == 0 && !clip) phase = 1;
+      else if (phase == 1 && clip) phase = 2;
+      else if (phase == 2 && !clip)
+        MISO_FAIL(MISO_EINVAL,
+                  "Bad CIGAR string: `S' and 'H' may appear only at the beginning and the end");
+      switch (op) {
+      case 'M': case '=': case 'X': case 'S': case 'H': case 'D':
+        if (maxReadLength > 0 && covered + l > maxReadLength) l = maxReadLength - covered;
+        covered += static_cast<int>(l);
+        t.ops.push_back(static_cast<int>(l));
+        break;
+      case 'N': t.ops.push_back(static_cast<int>(-l)); break;
+      case 'I': break;
+      default:
+        MISO_FAIL(MISO_EINVAL, "Unsupported CIGAR string (`MNSHDI=X' are supported)");
+      }
+      s = end + 1;
+    }
+    t.len.push_back(covered);
+  }
+  t.idx.push_back(static_cast<int>(t.ops.size()));
+  return t;
+}
+
+void match_iso(const Gene &g, const int *pos, const char *const *cigar, int n, int overHang,
+               int readLength, double *match) {
+  if (overHang == 0) overHang = 1;
+  if (overHang < 1) MISO_FAIL(MISO_EINVAL, "Overhang length invalid. Must be positive");
+  if (readLength < 0) MISO_FAIL(MISO_EINVAL, "Read length cannot be negative");
+  const CigarTable ct = parse_cigars(cigar, n, readLength);
+  const int K = g.K;
+  for (int r = 0; r < n; r++) {
+    const int *ops = ct.ops.data() + ct.idx[r];
+    const int nops = ct.idx[r + 1] - ct.idx[r];
+    double *col = match + static_cast<size_t>(r) * K;
+    const bool usable = ct.len[r] >= readLength && nops > 0 && ops[0] >= overHang &&
+                        ops[nops - 1] >= overHang;
+    for (int k = 0; k < K; k++) {
+      col[k] = 0.0;
+      if (!usable) continue;
+      int p = pos[r], ex = g.exidx[k];
+      const int last = g.exidx[k + 1];
+      while (ex < last && (p < g.exstart[ex] || g.exend[ex] < p)) ex++;
+      if (ex >= last) continue;
+      bool ok = true;
+      for (int c = 0; c < nops && ok; c++) {
+        if (ops[c] > 0) {
+          if (p + ops[c] - 1 > g.exend[ex]) ok = false; else p += ops[c];
+        } else if (p != g.exend[ex] + 1) {
+          ok = false;
+        } else {
+          p -= ops[c];
+          ex++;
+          if (ex >= last || p != g.exstart[ex]) ok = false;
+        }
+      }
+      if (ok) col[k] = 1.0;
+    }
+  }
+}
+
+FragmentDist normal_fragment(double mean, double var, double numDevs, int minLength) {
+  const double sd = std::sqrt(var);
+  if (!(sd > 0)) MISO_FAIL(MISO_EINVAL, "Invalid `sigma' for normal");
+  FragmentDist fd;
+  fd.start = static_cast<int>(mean - sd * numDevs);
+  int end = static_cast<int>(mean + sd * numDevs);
+  if (fd.start < minLength) fd.start = minLength;
+  if (end < fd.start) end = fd.start;
+  fd.prob.resize(end - fd.start + 1);
+  const double inv_sqrt_2pi = 0.398942280401432677939946059934;
+  double sum = 0.0;
+  for (int i = fd.start, j = 0; i <= end; i++, j++) {
+    const double x = (i - mean) / sd;
+    fd.prob[j] = inv_sqrt_2pi * std::exp(-0.5 * x * x) / sd;
+  }
+  for (double v : fd.prob) sum += v;
+  const double scale = 1.0 / sum;
+  for (double &v : fd.prob) v *= scale;
+  return fd;
+}
+
+namespace {
+// position of genomic coordinate p inside isoform k (1-based), -1 when p is not in an exon
+int genomic_to_iso(const Gene &g, int k, int p) {
+  int before = 0;  // isoform bases in the exons left of the one containing p
+  for (int ex = g.exidx[k]; ex < g.exidx[k + 1]; ex++) {
+    if (g.exend[ex] < p) { before += g.exend[ex] - g.exstart[ex] + 1; continue; }
+    if (g.exstart[ex] <= p) return before + (p - g.exstart[ex]) + 1;
+    return -1;
+  }
+  return -1;
+}
+}  // namespace
+
+void match_iso_paired(const Gene &g, const int *pos, const char *const *cigar, int npos,
+                      int readLength, int overHang, const FragmentDist &fd, double *match,
+                      int *fraglen) {
+  const int K = g.K, n = npos / 2, il = static_cast<int>(fd.prob.size());
+  std::vector<double> mate(static_cast<size_t>(K) * (npos > 0 ? npos : 1));
+  match_iso(g, pos, cigar, npos, overHang, readLength, mate.data());
+  for (int r = 0; r < n; r++) {
+    for (int k = 0; k < K; k++) {
+      double v = 0.0;
+      int fl = -1;
+      if (mate[static_cast<size_t>(2 * r) * K + k] != 0 &&
+          mate[static_cast<size_t>(2 * r + 1) * K + k] != 0) {
+        const int frag =
+            genomic_to_iso(g, k, pos[2 * r + 1]) - genomic_to_iso(g, k, pos[2 * r]) + readLength;
+        if (frag >= fd.start && frag < fd.start + il) { v = fd.prob[frag - fd.start]; fl = frag; }
+      }
+      match[static_cast<size_t>(r) * K + k] = v;
+      if (fraglen) fraglen[static_cast<size_t>(r) * K + k] = fl;
+    }
+  }
+}
+
+void validate_params(const miso_params_t &p) {
+  // miso.c:674-717 / miso_paired.c:285-339, plus what this build does not restate
+  if (!p.paired) {
+    if (p.algorithm == MISO_ALGO_MARGINAL || p.algorithm == MISO_ALGO_CLASSES)
+      MISO_FAIL(MISO_UNIMPLEMENTED, "Only the REASSIGN algorithm runs on the GPU");
+    if (p.algorithm != MISO_ALGO_REASSIGN) MISO_FAIL(MISO_EINVAL, "`algorithm` is invalid");
+  }
+  if (p.start == MISO_START_GIVEN)
+    MISO_FAIL(MISO_EINVAL, "`start_psi' must be given when starting from a given PSI");
+  if (p.start == MISO_START_RANDOM || p.start == MISO_START_LINEAR)
+    MISO_FAIL(MISO_UNIMPLEMENTED, "Only START_AUTO and START_UNIFORM run on the GPU");
+  if (p.start < 0 || p.start > MISO_START_LINEAR) MISO_FAIL(MISO_EINVAL, "`start` is invalid");
+  const int ov = p.overHang == 0 ? 1 : p.overHang;
+  if (ov < 1 || ov >= p.readLength / 2)
+    MISO_FAIL(MISO_EINVAL, "Overhang length invalid. Must be between 0 and readLength/2");
+  if (p.noChains < 1) MISO_FAIL(MISO_EINVAL, "Number of chains must be at least one.");
+  if (p.stop == MISO_STOP_CONVERGENT_MEAN && p.noChains == 1)
+    MISO_FAIL(MISO_EINVAL, "Cannot access convergence with one chain only");
+  if (p.stop == MISO_STOP_CONVERGENT_MEAN)
+    MISO_FAIL(MISO_UNIMPLEMENTED, "Only STOP_FIXEDNO runs on the GPU");
+  if (p.stop != MISO_STOP_FIXEDNO) MISO_FAIL(MISO_EINVAL, "`stop` is invalid");
+  if (p.noLag < 1 || p.noBurnIn < 0 || p.noIterations < p.noBurnIn)
+    MISO_FAIL(MISO_EINVAL, "Invalid iteration / burn-in / lag combination");
+}
+
+PackedEvent pack_event(const miso_params_t &p, const FragmentDist *fd, int K, int N,
+                       const double *match, const int *fraglen, const int *isolen,
+                       const int *noexons, const double *hyper) {
+  if (K < 2) MISO_FAIL(MISO_EINVAL, "At least two isoforms are needed");
+  if (K > MISO_MAX_ISOFORMS) MISO_FAIL(MISO_UNIMPLEMENTED, "More than 32 isoforms");
+  if (p.paired && (!fd || !fraglen)) MISO_FAIL(MISO_EINTERNAL, "Paired event without fragments");
+  const int ov = p.overHang == 0 ? 1 : p.overHang;
+  PackedEvent e;
+  e.K = K; e.N = N; e.paired = p.paired != 0;
+  e.hyper.assign(K, 1.0);
+  if (hyper) e.hyper.assign(hyper, hyper + K);
+  e.base_count.assign(K, 0);
+  e.fixed_ass.assign(N, -1);
+
+  // --- constants ---
+  e.consts.assign(3 * K + CONST_EXTRA, 0.0);
+  const int il = p.paired ? static_cast<int>(fd->prob.size()) : 0;
+  std::vector<double> isoscore_tab;  // paired: il x K
+  if (!p.paired) {
+    for (int k = 0; k < K; k++) {
+      const int l = isolen[k] - p.readLength + 1 - 2 * (noexons[k] - 1) * (ov - 1);
+      const int eff = l > 0 ? l : 0;
+      e.consts[k] = std::log(static_cast<double>(eff));
+      e.consts[K + k] = -std::log(static_cast<double>(l));
+    }
+  } else {
+    isoscore_tab.resize(static_cast<size_t>(il) * K);
+    std::vector<double> ass(K, 0.0);
+    for (int j = 0; j < il; j++) {
+      for (int k = 0; k < K; k++) {
+        const double lp = isolen[k] - fd->start - j + 1 - 2 * (noexons[k] - 1) * (ov - 1);
+        isoscore_tab[static_cast<size_t>(k) * il + j] = -std::log(lp) + fd->prob[j];
+        if (lp > 0) ass[k] += lp;
+      }
+    }
+    for (int k = 0; k < K; k++) e.consts[k] = std::log(ass[k]);
+    e.sfix_table.resize(static_cast<size_t>(K) * il);
+    for (size_t i = 0; i < e.sfix_table.size(); i++) {
+      const double s = isoscore_tab[i];
+      e.sfix_table[i] = (std::isfinite(s) && std::fabs(s) < 1048576.0)
+                            ? static_cast<int64_t>(std::llrint(s * 4294967296.0))
+                            : SFIX_BAD;
+    }
+  }
+  double asum = 0.0, lgeach = 0.0;
+  for (int k = 0; k < K; k++) {
+    e.consts[2 * K + k] = e.hyper[k] - 1.0;
+    asum += e.hyper[k];
+    lgeach += std::lgamma(e.hyper[k]);
+  }
+  const double sigma = 0.2 / K / K;
+  e.consts[3 * K + 0] = std::lgamma(asum);
+  e.consts[3 * K + 1] = lgeach;
+  e.consts[3 * K + 2] = sigma;
+  e.consts[3 * K + 3] = (K - 1 == 1) ? sigma : std::sqrt(sigma);
+  e.consts[3 * K + 4] = std::pow(2 * M_PI * sigma, -0.5 * (K - 1));
+
+  // --- reads: classes for the header, fixed vs drawing reads for the device ---
+  std::map<std::vector<double>, double> cls;  // lexicographic order == matrix.pmt:546-562
+  std::vector<double> key(K);
+  for (int i = 0; i < N; i++) {
+    const double *col = match + static_cast<size_t>(i) * K;
+    uint32_t mask = 0;
+    int nv = 0, first = -1;
+    for (int k = 0; k < K; k++) {
+      if (col[k] != 0) { mask |= 1u << k; if (!nv) first = k; nv++; }
+      key[k] = p.paired ? static_cast<double>(col[k] != 0) : col[k];
+    }
+    cls[key] += 1.0;
+    if (nv == 0) continue;
+    if (nv == 1) {
+      e.fixed_ass[i] = first;
+      e.base_count[first]++;
+      if (p.paired) {
+        const int64_t v = e.sfix_table[static_cast<size_t>(first) * il +
+                                       (fraglen[static_cast<size_t>(i) * K + first] - fd->start)];
+        if (v == SFIX_BAD) e.base_bad = 1; else e.base_sfix += v;
+      }
+      continue;
+    }
+    e.fixed_ass[i] = -2;
+    if (!p.paired) {
+      e.draw_mask.push_back(mask);
+    } else {
+      for (int k = 0; k < K; k++) {
+        const int fl = fraglen[static_cast<size_t>(i) * K + k];
+        e.draw_frag.push_back(fl < 0 ? FRAG_NONE : static_cast<uint16_t>(fl - fd->start));
+      }
+    }
+    e.n_draw++;
+  }
+  for (const auto &kv : cls) {
+    e.class_templates.insert(e.class_templates.end(), kv.first.begin(), kv.first.end());
+    e.class_counts.push_back(kv.second);
+  }
+  return e;
+}
+
+}  // namespace miso

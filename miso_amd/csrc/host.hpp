@@ -1,0 +1,101 @@
+// host.hpp -- host-side model of the sampler path: gene, alignment matching, packed problems.
+//
+// Product code (libmiso_amd.so).  Independent of oracle/: the CPU checker has its own C
+// restatement; the two meet only in tests.
+#pragma once
+
+#include <cstdint>
+#include <exception>
+#include <string>
+#include <vector>
+
+#include "miso_amd.h"
+
+namespace miso {
+
+// ---- errors: the reference's convention (splicing_error.h:548 SPLICING_CHECK / pyerror.c) ----
+struct Error : std::exception {
+  int code;
+  std::string text;  // "Error at file:line: reason, strerror"
+  Error(int code, const std::string &reason, const char *file, int line);
+  const char *what() const noexcept override { return text.c_str(); }
+};
+#define MISO_FAIL(code, reason) throw ::miso::Error((code), (reason), __FILE__, __LINE__)
+
+const char *strerror_code(int code);
+
+// ---- gene model: one gene of the reference's splicing_gff_t (simulator.c:9-66) ----
+struct Gene {
+  int K = 0;                  // isoforms (mRNAs)
+  std::vector<int> exidx;     // K+1 offsets: isoform k owns exons [exidx[k], exidx[k+1])
+  std::vector<int> exstart;   // exon coordinates per isoform, in the order given
+  std::vector<int> exend;
+  std::vector<int> isolen;    // gff.c:583-619
+  std::vector<int> noexons;   // gff.c:624-657
+  std::string id, seqid, source;
+  int strand = 2;
+};
+
+Gene make_gene(const int *exons, int n_exons, const int *isoforms, int n_flat, const char *id,
+               const char *seqid, const char *source, int strand);
+
+// ---- alignments -> compatibility (solve.c:8-108, 141-306) ----
+struct CigarTable {
+  std::vector<int> ops;  // +len aligned block, -len skipped region
+  std::vector<int> idx;  // n+1 offsets
+  std::vector<int> len;  // reference-consuming length per read, clipped to readLength
+};
+CigarTable parse_cigars(const char *const *cigar, int n, int maxReadLength);
+
+void match_iso(const Gene &g, const int *pos, const char *const *cigar, int n, int overHang,
+               int readLength, double *match /* K x n */);
+
+struct FragmentDist {  // simulator.c:198-219, normalised as miso_paired.c:303-307
+  int start = 0;
+  std::vector<double> prob;
+};
+FragmentDist normal_fragment(double mean, double var, double numDevs, int minLength);
+
+void match_iso_paired(const Gene &g, const int *pos, const char *const *cigar, int npos,
+                      int readLength, int overHang, const FragmentDist &fd, double *match,
+                      int *fraglen /* may be null */);
+
+// ---- a packed event: everything the kernels need, nothing they do not ----
+//
+// The reference keeps match[K x N] doubles and walks all N reads every iteration.  Only reads
+// with >= 2 compatible isoforms ever consume a random number (miso.c:65-80); the others are
+// constants of the chain.  Packing therefore splits the reads into
+//   * "fixed" reads (0 or 1 compatible isoform): folded into base_count[k] (and, paired-end,
+//     into base_sfix), never touched again by the device;
+//   * "drawing" reads, kept in read order (their rank is their RNG address, miso_philox.h):
+//     single-end: one u32 bit mask per read (bit k = compatible with isoform k);
+//     paired-end: K u16 fragment-length indices per read (0xFFFF = incompatible).
+struct PackedEvent {
+  int K = 0, N = 0, n_draw = 0;
+  bool paired = false;
+  std::vector<double> hyper;            // K
+  std::vector<double> consts;           // 3K+5 doubles, layout in device.hpp
+  std::vector<int32_t> base_count;      // K
+  int64_t base_sfix = 0;                // paired: sum of fixed reads' scores, 2^-32 fixed point
+  int32_t base_bad = 0;                 // paired: a fixed read has a non-finite score
+  std::vector<uint32_t> draw_mask;      // single-end: n_draw
+  std::vector<uint16_t> draw_frag;      // paired-end: n_draw x K
+  std::vector<int64_t> sfix_table;      // paired-end: K x il fixed-point isoscores
+  std::vector<int32_t> fixed_ass;       // N: -1 / isoform for fixed reads, -2 for drawing reads
+  // header material for the caller (miso.c:762, miso_paired.c:386-391)
+  std::vector<double> class_templates;  // K x ncls
+  std::vector<double> class_counts;     // ncls
+};
+
+struct SamplerParams {
+  miso_params_t p{};
+  int n_samples() const { return p.noChains * (p.noIterations - p.noBurnIn) / p.noLag; }
+};
+
+void validate_params(const miso_params_t &p);
+
+PackedEvent pack_event(const miso_params_t &p, const FragmentDist *fd, int K, int N,
+                       const double *match, const int *fraglen, const int *isolen,
+                       const int *noexons, const double *hyper);
+
+}  // namespace miso

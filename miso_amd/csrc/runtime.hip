@@ -1,0 +1,191 @@
+// runtime.hip -- batch object: host packing -> HBM pools -> kernel launches -> results.
+//
+// One batch = the events one GPU samples in one go (the unit the reference hands to one worker
+// process, misopy/miso.py:165-187).  All events of a batch share the sampler parameters
+// (run_miso.py:68-73 passes the same settings for every event of a run).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+
+#include "batch.hpp"
+
+namespace miso {
+
+template <bool PE> __global__ void sampler_wave(const KernelArgs a);
+__global__ void selftest_detmath_kernel(const double *, int, double *, double *, double *, double *);
+__global__ void selftest_philox_kernel(const uint32_t *, int, uint32_t *);
+
+#define HIP_OK(call)                                                                       \
+  do {                                                                                     \
+    hipError_t e_ = (call);                                                                \
+    if (e_ != hipSuccess)                                                                  \
+      MISO_FAIL(MISO_ENODEVICE, std::string(#call) + ": " + hipGetErrorString(e_));        \
+  } while (0)
+
+int device_count() {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+void set_device(int d) { HIP_OK(hipSetDevice(d)); }
+
+static inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace miso
+
+using namespace miso;
+
+void miso_batch::release() {
+  if (device >= 0) (void) hipSetDevice(device);
+  if (d_events) (void) hipFree(d_events);
+  if (d_in) (void) hipFree(d_in);
+  if (d_out) (void) hipFree(d_out);
+  if (d_fp) (void) hipFree(d_fp);
+  if (ev0) (void) hipEventDestroy(ev0);
+  if (ev1) (void) hipEventDestroy(ev1);
+  if (stream) (void) hipStreamDestroy(stream);
+  d_events = nullptr; d_in = d_out = nullptr; d_fp = nullptr; ev0 = ev1 = nullptr; stream = nullptr;
+  uploaded = launched = downloaded = false;
+}
+
+void miso_batch::upload(int dev) {
+  if (uploaded && dev == device) return;
+  if (uploaded) release();
+  if (device_count() <= 0) MISO_FAIL(MISO_ENODEVICE, "no HIP device: the sampler has no CPU path");
+  device = dev;
+  HIP_OK(hipSetDevice(dev));
+  const int n = static_cast<int>(events.size());
+  const int C = p.noChains, M = p.noIterations, Sn = S();
+  h_events.assign(n, DevEvent{});
+  uint64_t in_off = 0, out_off = 0;
+  for (int i = 0; i < n; i++) {
+    const PackedEvent &e = events[i];
+    DevEvent &d = h_events[i];
+    d.K = e.K; d.n_draw = e.n_draw; d.n_reads = e.N; d.base_bad = e.base_bad;
+    d.base_sfix = e.base_sfix;
+    d.off_consts = in_off; in_off = align_up(in_off + e.consts.size() * 8, 16);
+    d.off_base = in_off; in_off = align_up(in_off + e.base_count.size() * 4, 16);
+    d.off_draw = in_off;
+    in_off = align_up(in_off + (e.paired ? e.draw_frag.size() * 2
+                                         : align_up(e.draw_mask.size(), 4) * 4), 16);
+    d.off_sfix = in_off; in_off = align_up(in_off + e.sfix_table.size() * 8, 16);
+    d.off_samples = out_off; out_off = align_up(out_off + static_cast<uint64_t>(Sn) * e.K * 8, 16);
+    d.off_loglik = out_off; out_off = align_up(out_off + static_cast<uint64_t>(Sn) * 8, 16);
+    d.off_drawass = out_off; out_off = align_up(out_off + static_cast<uint64_t>(e.n_draw), 16);
+    d.off_stats = out_off; out_off = align_up(out_off + sizeof(ChainStats) * C, 16);
+    if (p.want_counts_trace) {
+      d.off_trace = out_off;
+      out_off = align_up(out_off + static_cast<uint64_t>(M + 1) * C * e.K * 4, 16);
+    } else {
+      d.off_trace = NO_TRACE;
+    }
+  }
+  in_bytes = std::max<uint64_t>(in_off, 16);
+  out_bytes = std::max<uint64_t>(out_off, 16);
+  std::vector<unsigned char> h_in(in_bytes, 0);
+  for (int i = 0; i < n; i++) {
+    const PackedEvent &e = events[i];
+    const DevEvent &d = h_events[i];
+    std::memcpy(h_in.data() + d.off_consts, e.consts.data(), e.consts.size() * 8);
+    std::memcpy(h_in.data() + d.off_base, e.base_count.data(), e.base_count.size() * 4);
+    if (e.paired) std::memcpy(h_in.data() + d.off_draw, e.draw_frag.data(), e.draw_frag.size() * 2);
+    else std::memcpy(h_in.data() + d.off_draw, e.draw_mask.data(), e.draw_mask.size() * 4);
+    if (!e.sfix_table.empty())
+      std::memcpy(h_in.data() + d.off_sfix, e.sfix_table.data(), e.sfix_table.size() * 8);
+  }
+  HIP_OK(hipStreamCreate(&stream));
+  HIP_OK(hipEventCreate(&ev0));
+  HIP_OK(hipEventCreate(&ev1));
+  HIP_OK(hipMalloc(reinterpret_cast<void **>(&d_events), std::max<size_t>(n, 1) * sizeof(DevEvent)));
+  HIP_OK(hipMalloc(reinterpret_cast<void **>(&d_in), in_bytes));
+  HIP_OK(hipMalloc(reinterpret_cast<void **>(&d_out), out_bytes));
+  if (n) HIP_OK(hipMemcpy(d_events, h_events.data(), n * sizeof(DevEvent), hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(d_in, h_in.data(), in_bytes, hipMemcpyHostToDevice));
+  if (p.paired) {
+    HIP_OK(hipMalloc(reinterpret_cast<void **>(&d_fp), fd.prob.size() * 8));
+    HIP_OK(hipMemcpy(d_fp, fd.prob.data(), fd.prob.size() * 8, hipMemcpyHostToDevice));
+  }
+  uploaded = true;
+}
+
+void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
+  if (!uploaded) MISO_FAIL(MISO_EINVAL, "batch not uploaded");
+  HIP_OK(hipSetDevice(device));
+  const int n = static_cast<int>(events.size());
+  KernelArgs a{};
+  a.events = d_events; a.in_pool = d_in; a.out_pool = d_out; a.frag_prob = d_fp;
+  a.il = static_cast<int>(fd.prob.size()); a.n_events = n;
+  a.C = p.noChains; a.M = p.noIterations; a.B = p.noBurnIn; a.lag = p.noLag;
+  a.start = p.start; a.first_event_id = first_event_id; a.seed = seed;
+  HIP_OK(hipMemsetAsync(d_out, 0, out_bytes, stream));  // trailing sample columns stay 0 (miso.c:661)
+  HIP_OK(hipEventRecord(ev0, stream));
+  const long slots = static_cast<long>(n) * p.noChains;
+  if (slots > 0) {
+    const unsigned grid = static_cast<unsigned>((slots + 3) / 4);
+    const size_t lds = (p.paired ? align_up(fd.prob.size() * 8, 16) : 0) + 4 * 32 * sizeof(int);
+    if (p.paired) hipLaunchKernelGGL(sampler_wave<true>, dim3(grid), dim3(256), lds, stream, a);
+    else hipLaunchKernelGGL(sampler_wave<false>, dim3(grid), dim3(256), lds, stream, a);
+    HIP_OK(hipGetLastError());
+  }
+  HIP_OK(hipEventRecord(ev1, stream));
+  launched = true; downloaded = false;
+}
+
+void miso_batch::sync(float *ms) {
+  if (!launched) MISO_FAIL(MISO_EINVAL, "batch not launched");
+  HIP_OK(hipSetDevice(device));
+  HIP_OK(hipStreamSynchronize(stream));
+  HIP_OK(hipEventElapsedTime(&last_ms, ev0, ev1));
+  if (ms) *ms = last_ms;
+}
+
+void miso_batch::download() {
+  if (!launched) MISO_FAIL(MISO_EINVAL, "batch not launched");
+  HIP_OK(hipSetDevice(device));
+  h_out.resize(out_bytes);
+  HIP_OK(hipMemcpy(h_out.data(), d_out, out_bytes, hipMemcpyDeviceToHost));
+  downloaded = true;
+}
+
+namespace miso {
+
+miso_batch *batch_new(const miso_params_t &p) {
+  validate_params(p);
+  auto b = std::make_unique<miso_batch>();
+  b->p = p;
+  if (p.paired) b->fd = normal_fragment(p.normalMean, p.normalVar, p.numDevs, p.readLength);
+  return b.release();
+}
+
+void selftest_detmath(const double *x, int n, double *e, double *l, double *s, double *q) {
+  if (device_count() <= 0) MISO_FAIL(MISO_ENODEVICE, "no HIP device");
+  double *d[5];
+  for (auto &ptr : d) HIP_OK(hipMalloc(reinterpret_cast<void **>(&ptr), std::max(n, 1) * 8));
+  HIP_OK(hipMemcpy(d[0], x, n * 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(selftest_detmath_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, d[0], n, d[1],
+                     d[2], d[3], d[4]);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipDeviceSynchronize());
+  double *outs[4] = {e, l, s, q};
+  for (int i = 0; i < 4; i++) HIP_OK(hipMemcpy(outs[i], d[i + 1], n * 8, hipMemcpyDeviceToHost));
+  for (auto ptr : d) (void) hipFree(ptr);
+}
+
+void selftest_philox(const uint32_t *in6, int n, uint32_t *out4) {
+  if (device_count() <= 0) MISO_FAIL(MISO_ENODEVICE, "no HIP device");
+  uint32_t *din, *dout;
+  HIP_OK(hipMalloc(reinterpret_cast<void **>(&din), std::max(n, 1) * 24));
+  HIP_OK(hipMalloc(reinterpret_cast<void **>(&dout), std::max(n, 1) * 16));
+  HIP_OK(hipMemcpy(din, in6, n * 24, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(selftest_philox_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, din, n, dout);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipDeviceSynchronize());
+  HIP_OK(hipMemcpy(out4, dout, n * 16, hipMemcpyDeviceToHost));
+  (void) hipFree(din); (void) hipFree(dout);
+}
+
+}  // namespace miso

@@ -500,9 +500,10 @@ int orc_simulate_paired_reads(const orc_gene_t *g, const double *expr, int npair
 
 static const double *g_sort_m; static int g_sort_k; static int g_sort_bin;
 
-static int col_cmp(const void *pa, const void *pb) {
-  int a = *(const int *) pa, b = *(const int *) pb, i;
+/* matrix.pmt:546-577: lexicographic compare of two columns (exact values, or zero/non-zero) */
+static int col_cmp(int a, int b) {
   const double *ca = g_sort_m + (size_t) a * g_sort_k, *cb = g_sort_m + (size_t) b * g_sort_k;
+  int i;
   for (i = 0; i < g_sort_k; i++) {
     if (g_sort_bin) {
       if (ca[i] == 0 && cb[i] != 0) return -1;
@@ -512,16 +513,82 @@ static int col_cmp(const void *pa, const void *pb) {
       if (ca[i] > cb[i]) return 1;
     }
   }
-  /* equal columns: the reference's BSD qsort leaves their relative order unspecified; any
-     order yields the same classes, counts and per-isoform assignment counts.  Use the index. */
-  return (a > b) - (a < b);
+  return 0;
+}
+
+/*
+ * The reference sorts the column indices with an unstable quicksort (matrix.pmt:579-601 ->
+ * src/qsort.c, FreeBSD's libc qsort).  The order it leaves EQUAL columns in decides which read
+ * consumes which uniform of the stream (miso.c:59-83), so reproducing the reference bit for bit
+ * (per-read assignment, log-likelihood sums) needs the same permutation.  This is that sorting
+ * algorithm -- Bentley & McIlroy, "Engineering a Sort Function", Software P&E 23(11), 1993,
+ * program 7 (split-end partition, median of three / ninther pivot, insertion sort below 7
+ * elements) plus FreeBSD's "no swap happened -> insertion sort" shortcut -- written for an int
+ * index array.
+ */
+static void bm_swap(int *v, int i, int j) { int t = v[i]; v[i] = v[j]; v[j] = t; }
+
+static int bm_med3(const int *v, int a, int b, int c) {
+  return col_cmp(v[a], v[b]) < 0
+             ? (col_cmp(v[b], v[c]) < 0 ? b : (col_cmp(v[a], v[c]) < 0 ? c : a))
+             : (col_cmp(v[b], v[c]) > 0 ? b : (col_cmp(v[a], v[c]) < 0 ? a : c));
+}
+
+static void bm_insertion(int *v, int n) {
+  int m, l;
+  for (m = 1; m < n; m++)
+    for (l = m; l > 0 && col_cmp(v[l - 1], v[l]) > 0; l--) bm_swap(v, l, l - 1);
+}
+
+static void bm_qsort(int *v, int n) {
+  for (;;) {
+    int pa, pb, pc, pd, pl, pm, pn, d, r, i, swapped = 0, nl, nr;
+    if (n < 7) { bm_insertion(v, n); return; }
+    pm = n / 2;
+    if (n > 7) {
+      pl = 0; pn = n - 1;
+      if (n > 40) {
+        d = n / 8;
+        pl = bm_med3(v, pl, pl + d, pl + 2 * d);
+        pm = bm_med3(v, pm - d, pm, pm + d);
+        pn = bm_med3(v, pn - 2 * d, pn - d, pn);
+      }
+      pm = bm_med3(v, pl, pm, pn);
+    }
+    bm_swap(v, 0, pm);
+    pa = pb = 1;
+    pc = pd = n - 1;
+    for (;;) {
+      while (pb <= pc && (r = col_cmp(v[pb], v[0])) <= 0) {
+        if (r == 0) { swapped = 1; bm_swap(v, pa, pb); pa++; }
+        pb++;
+      }
+      while (pb <= pc && (r = col_cmp(v[pc], v[0])) >= 0) {
+        if (r == 0) { swapped = 1; bm_swap(v, pc, pd); pd--; }
+        pc--;
+      }
+      if (pb > pc) break;
+      bm_swap(v, pb, pc);
+      swapped = 1;
+      pb++; pc--;
+    }
+    if (!swapped) { bm_insertion(v, n); return; }
+    r = (pa < pb - pa) ? pa : pb - pa;               /* equal keys from the left end ... */
+    for (i = 0; i < r; i++) bm_swap(v, i, pb - r + i);
+    r = (pd - pc < n - pd - 1) ? pd - pc : n - pd - 1; /* ... and the right end to the middle */
+    for (i = 0; i < r; i++) bm_swap(v, pb + i, n - r + i);
+    nl = pb - pa; nr = pd - pc;
+    if (nl > 1) bm_qsort(v, nl);
+    if (nr > 1) { v += n - nr; n = nr; continue; }
+    return;
+  }
 }
 
 static void order_cols(const double *m, int K, int n, int bin, int *order) {
   int i;
   for (i = 0; i < n; i++) order[i] = i;
   g_sort_m = m; g_sort_k = K; g_sort_bin = bin;
-  qsort(order, n, sizeof(int), col_cmp);
+  bm_qsort(order, n);
 }
 
 /* run-length over the sorted columns; templates K x ncls col-major */
@@ -684,7 +751,7 @@ static double ldirichlet(const orc_state_t *S, const double *x) {
 static double score_joint(const orc_state_t *S, int chain, const double *psi) {
   int K = S->K, N = S->N, i;
   const int *ass = S->ass + (size_t) chain * N;
-  double logpsi[64], maxv, sum, readProb = 0.0, assProb = 0.0;
+  double logpsi[64] = { 0 }, maxv, sum, readProb = 0.0, assProb = 0.0;
   int32_t cnt[64];
   for (i = 0; i < K; i++)
     logpsi[i] = S->M->log(psi[i]) + (S->paired ? S->assscores[i] : S->logeff[i]);

@@ -1,0 +1,38 @@
+"""GPU: the arithmetic contract (include/miso_detmath.h, miso_philox.h) is bit-identical on
+device and host -- the premise of every bit-exact parity claim."""
+import numpy as np
+import pytest
+
+from miso_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+def test_detmath_device_equals_host(orc):
+    rng = np.random.default_rng(3)
+    x = np.concatenate([rng.uniform(-745, 710, 200000), rng.normal(0, 3, 200000),
+                        np.exp(rng.uniform(-700, 700, 200000)), rng.uniform(0, 1, 200000),
+                        [0.0, 1.0, 5e-324, 1e-310, np.inf, -np.inf, np.nan, -1.0, 0.5, 1e-17, 1 - 1e-16]])
+    e, l, s, q = capi.selftest_detmath(x)
+    for name, dev in (("exp", e), ("log", l), ("sqrt", s)):
+        f = getattr(orc.lib, "orc_det_" + name)
+        host = np.array([f(v) for v in x])
+        assert np.array_equal(dev.view(np.uint64), host.view(np.uint64)) or \
+            np.array_equal(dev[~np.isnan(host)].view(np.uint64), host[~np.isnan(host)].view(np.uint64)), name
+        assert (np.isnan(dev) == np.isnan(host)).all(), name
+    host = np.array([orc.lib.orc_qnorm_det(v) for v in x])
+    ok = ~np.isnan(host)
+    assert (np.isnan(q) == np.isnan(host)).all()
+    assert np.array_equal(q[ok].view(np.uint64), host[ok].view(np.uint64))
+
+
+def test_philox_device_equals_host(orc):
+    rng = np.random.default_rng(4)
+    a = rng.integers(0, 2**32, size=(5000, 6), dtype=np.uint64).astype(np.uint32)
+    a[0] = 0
+    a[1] = 0xFFFFFFFF
+    dev = capi.selftest_philox(a)
+    assert list(dev[0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert list(dev[1]) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    for i in range(0, 5000, 97):
+        assert (dev[i] == orc.philox(a[i, :4], a[i, 4:])).all()
