@@ -147,6 +147,21 @@ int miso_batch_add_problem(miso_batch_t *batch, int noiso, int n_reads, const do
                            const int *fragmentLength, const int *isolength, const int *noexons,
                            const double *hyperp, int *event_index);
 
+/* Synthetic reads for one gene (the module's simulateReads / simulatePairedReads,
+   pysplicing.c:280-330 -> simulator.c:68, 221): n_reads single-end reads, or n_reads PAIRS when
+   normalVar > 0.  position: n (2n paired) ints; cigar: n (2n) slots of cigar_stride bytes;
+   isoform (may be NULL): true isoform of every read.  Deterministic in sim_seed. */
+int miso_simulate_reads(const miso_gene_t *gene, const double *expression, int n_reads,
+                        int readLength, double normalMean, double normalVar, double numDevs,
+                        uint64_t sim_seed, int *isoform, int *position, char *cigar,
+                        int cigar_stride);
+
+/* miso_simulate_reads + miso_batch_add_event in one call (the batch's readLength / paired /
+   fragment parameters apply): bulk synthetic workloads without string traffic over the ABI. */
+int miso_batch_add_simulated(miso_batch_t *batch, const miso_gene_t *gene,
+                             const double *expression, int n_reads, uint64_t sim_seed,
+                             const double *hyperp, int n_hyperp, int *event_index);
+
 int miso_batch_size(const miso_batch_t *batch, int *n_events);
 
 /* pack + copy to HBM (idempotent) */

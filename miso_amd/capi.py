@@ -203,6 +203,16 @@ class Batch:
                                            _p(noexons), _p(hy), C.byref(idx)))
         return idx.value
 
+    def add_simulated(self, gene, expression, n_reads, sim_seed, hyper=None):
+        """Synthetic reads (miso_simulate_reads) -> add_event, all inside the library."""
+        ex = np.asarray(expression, dtype=np.float64)
+        hy = None if hyper is None else np.asarray(hyper, dtype=np.float64)
+        idx = C.c_int(-1)
+        check(lib().miso_batch_add_simulated(self.handle, gene.handle, _p(ex), int(n_reads),
+                                             C.c_uint64(sim_seed), _p(hy),
+                                             0 if hy is None else len(hy), C.byref(idx)))
+        return idx.value
+
     def __len__(self):
         n = C.c_int(0)
         check(lib().miso_batch_size(self.handle, C.byref(n)))
@@ -248,6 +258,22 @@ class Batch:
         tr = np.zeros((M + 1, Cn, K), np.int32) if trace else None
         check(lib().miso_batch_get_trace(self.handle, i, _p(h), _p(tr)))
         return EventResult(samples[:S], ll[:S], ct[:ncls], cc[:ncls], ass[:N], rd, h, tr)
+
+
+def simulate_reads(gene, expression, n_reads, read_len, sim_seed, mean=0.0, var=0.0, num_devs=4.0):
+    """pysplicing.simulateReads / simulatePairedReads (var > 0): returns (isoform, pos, cigars)."""
+    ex = np.asarray(expression, dtype=np.float64)
+    n = n_reads * (2 if var > 0 else 1)
+    stride = 64
+    iso = np.zeros(max(n, 1), np.int32)
+    pos = np.zeros(max(n, 1), np.int32)
+    buf = C.create_string_buffer(max(n, 1) * stride)
+    check(lib().miso_simulate_reads(gene.handle, _p(ex), int(n_reads), int(read_len),
+                                    C.c_double(mean), C.c_double(var), C.c_double(num_devs),
+                                    C.c_uint64(sim_seed), _p(iso), _p(pos), buf, stride))
+    raw = buf.raw
+    cig = [raw[i * stride:(i + 1) * stride].split(b"\0")[0] for i in range(n)]
+    return iso[:n], pos[:n], cig
 
 
 def selftest_detmath(x):

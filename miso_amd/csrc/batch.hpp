@@ -29,11 +29,21 @@ struct miso_batch {
   miso::DevEvent *d_events = nullptr;
   unsigned char *d_in = nullptr, *d_out = nullptr;
   double *d_fp = nullptr;
+  int32_t *d_slots = nullptr;     // [k2 events sorted by n_draw desc | all other events]
+  int n_k2 = 0, n_gen = 0;
+  int lanes_per_chain = 0;        // G of the last sampler_k2 launch (0 = none)
   std::vector<miso::DevEvent> h_events;
   std::vector<unsigned char> h_out;
   uint64_t in_bytes = 0, out_bytes = 0;
   float last_ms = 0.f;
 
+  int k2_first_event() const {  // the k2 event with the most drawing reads (list is sorted)
+    int best = -1;
+    for (size_t i = 0; i < events.size(); i++)
+      if (!events[i].paired && events[i].K == 2 && (best < 0 || events[i].n_draw > events[best].n_draw))
+        best = static_cast<int>(i);
+    return best;
+  }
   int S() const { return p.noChains * (p.noIterations - p.noBurnIn) / p.noLag; }
   ~miso_batch() { release(); }
   void release();

@@ -146,6 +146,42 @@ int miso_batch_add_problem(miso_batch_t *b, int noiso, int n_reads, const double
   });
 }
 
+int miso_simulate_reads(const miso_gene_t *gene, const double *expression, int n_reads,
+                        int readLength, double normalMean, double normalVar, double numDevs,
+                        uint64_t sim_seed, int *isoform, int *position, char *cigar,
+                        int cigar_stride) {
+  return guarded([&] {
+    need(gene, "gene"); need(expression, "expression"); need(position, "position"); need(cigar, "cigar");
+    const bool paired = normalVar > 0;
+    const SimReads r = paired
+        ? simulate_paired_reads(gene->g, expression, n_reads, readLength,
+                                normal_fragment(normalMean, normalVar, numDevs, readLength), sim_seed)
+        : simulate_reads(gene->g, expression, n_reads, readLength, sim_seed);
+    for (size_t i = 0; i < r.position.size(); i++) {
+      position[i] = r.position[i];
+      if (isoform) isoform[i] = r.isoform[i];
+      if (static_cast<int>(r.cigar[i].size()) >= cigar_stride) MISO_FAIL(MISO_EINVAL, "CIGAR string too long");
+      std::strcpy(cigar + i * static_cast<size_t>(cigar_stride), r.cigar[i].c_str());
+    }
+  });
+}
+
+int miso_batch_add_simulated(miso_batch_t *b, const miso_gene_t *gene, const double *expression,
+                             int n_reads, uint64_t sim_seed, const double *hyperp, int n_hyperp,
+                             int *event_index) {
+  return guarded([&] {
+    need(b, "batch"); need(gene, "gene"); need(expression, "expression");
+    const SimReads r = b->p.paired
+        ? simulate_paired_reads(gene->g, expression, n_reads, b->p.readLength, b->fd, sim_seed)
+        : simulate_reads(gene->g, expression, n_reads, b->p.readLength, sim_seed);
+    std::vector<const char *> cig(r.cigar.size());
+    for (size_t i = 0; i < cig.size(); i++) cig[i] = r.cigar[i].c_str();
+    const int rc = miso_batch_add_event(b, gene, r.position.data(), cig.data(),
+                                        static_cast<int>(r.position.size()), hyperp, n_hyperp, event_index);
+    if (rc) throw Rethrow{rc};
+  });
+}
+
 int miso_batch_size(const miso_batch_t *b, int *n) {
   return guarded([&] { need(b, "batch"); need(n, "n_events"); *n = static_cast<int>(b->events.size()); });
 }

@@ -46,6 +46,8 @@ struct KernelArgs {
   unsigned char *out_pool;
   const double *frag_prob;  // paired: normalised fragment-length probabilities [il]
   int32_t il;
+  const int32_t *slot_event;  // this launch's events (indices into `events`), n_slots of them
+  int32_t n_slots;
   int32_t n_events;
   int32_t C, M, B, lag;     // chains, iterations (incl. burn-in), burn-in, lag
   int32_t start;            // MISO_START_AUTO / MISO_START_UNIFORM

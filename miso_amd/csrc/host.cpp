@@ -200,6 +200,115 @@ void match_iso_paired(const Gene &g, const int *pos, const char *const *cigar, i
   }
 }
 
+namespace {
+struct SplitMix64 {  // Steele, Lea, Flood: "Fast splittable pseudorandom number generators", 2014
+  uint64_t s;
+  uint64_t next() {
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+  }
+  double u01() { return static_cast<double>(next() >> 11) * (1.0 / 9007199254740992.0); }
+};
+
+// isoform coordinate (1-based) -> genomic coordinate
+int iso_to_genomic(const Gene &g, int k, int p) {
+  for (int ex = g.exidx[k]; ex < g.exidx[k + 1]; ex++) {
+    const int len = g.exend[ex] - g.exstart[ex] + 1;
+    if (p <= len) return g.exstart[ex] + p - 1;
+    p -= len;
+  }
+  return -1;
+}
+
+std::string cigar_for(const Gene &g, int k, int start, int readLength) {
+  std::string out;
+  int ex = g.exidx[k], left = readLength, rs = start;
+  while (g.exend[ex] < rs) ex++;
+  while (g.exend[ex] < rs + left - 1) {
+    const int m = g.exend[ex] - rs + 1;
+    out += std::to_string(m) + "M" + std::to_string(g.exstart[ex + 1] - g.exend[ex] - 1) + "N";
+    left -= m;
+    rs = g.exstart[ex + 1];
+    ex++;
+  }
+  out += std::to_string(left) + "M";
+  return out;
+}
+
+int pick(const std::vector<double> &cum, double u) {
+  const double r = u * cum.back();
+  int w = 0;
+  while (w + 1 < static_cast<int>(cum.size()) && r > cum[w]) w++;
+  return w;
+}
+}  // namespace
+
+SimReads simulate_reads(const Gene &g, const double *expr, int n, int readLength, uint64_t seed) {
+  SplitMix64 rng{seed};
+  std::vector<int> eff(g.K);
+  std::vector<double> cum(g.K);
+  double acc = 0.0;
+  for (int k = 0; k < g.K; k++) {
+    const int l = g.isolen[k] - readLength + 1;
+    eff[k] = l > 0 ? l : 0;
+    acc += expr[k] * eff[k];
+    cum[k] = acc;
+  }
+  if (!(acc > 0)) MISO_FAIL(MISO_FAILURE, "No isoform is possible");
+  SimReads out;
+  out.isoform.resize(n); out.position.resize(n); out.cigar.resize(n);
+  for (int i = 0; i < n; i++) {
+    const int k = pick(cum, rng.u01());
+    const int p = 1 + static_cast<int>(rng.u01() * eff[k]);
+    out.isoform[i] = k;
+    out.position[i] = iso_to_genomic(g, k, p);
+    out.cigar[i] = cigar_for(g, k, out.position[i], readLength);
+  }
+  return out;
+}
+
+SimReads simulate_paired_reads(const Gene &g, const double *expr, int npairs, int readLength,
+                               const FragmentDist &fd, uint64_t seed) {
+  SplitMix64 rng{seed};
+  const int il = static_cast<int>(fd.prob.size());
+  // P(isoform) ~ expression x sum_f P(f) * #positions a fragment of length f has on it
+  std::vector<double> cum(g.K), fcum(il);
+  double acc = 0.0;
+  for (int k = 0; k < g.K; k++) {
+    double w = 0.0;
+    for (int j = 0; j < il; j++) {
+      const int slots = g.isolen[k] - (fd.start + j) + 1;
+      if (slots > 0) w += fd.prob[j] * slots;
+    }
+    acc += expr[k] * w;
+    cum[k] = acc;
+  }
+  if (!(acc > 0)) MISO_FAIL(MISO_FAILURE, "No isoform is possible");
+  SimReads out;
+  out.isoform.resize(2 * npairs); out.position.resize(2 * npairs); out.cigar.resize(2 * npairs);
+  for (int i = 0; i < npairs; i++) {
+    const int k = pick(cum, rng.u01());
+    double facc = 0.0;  // fragment length given the isoform: P(f) x #positions
+    for (int j = 0; j < il; j++) {
+      const int slots = g.isolen[k] - (fd.start + j) + 1;
+      facc += slots > 0 ? fd.prob[j] * slots : 0.0;
+      fcum[j] = facc;
+    }
+    const int frag = fd.start + pick(fcum, rng.u01());
+    const int slots = g.isolen[k] - frag + 1;
+    const int p = 1 + static_cast<int>(rng.u01() * slots);
+    const int p2 = p + frag - readLength;
+    for (int m = 0; m < 2; m++) {
+      out.isoform[2 * i + m] = k;
+      out.position[2 * i + m] = iso_to_genomic(g, k, m ? p2 : p);
+      out.cigar[2 * i + m] = cigar_for(g, k, out.position[2 * i + m], readLength);
+    }
+  }
+  return out;
+}
+
 void validate_params(const miso_params_t &p) {
   // miso.c:674-717 / miso_paired.c:285-339, plus what this build does not restate
   if (!p.paired) {

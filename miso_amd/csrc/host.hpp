@@ -60,6 +60,18 @@ void match_iso_paired(const Gene &g, const int *pos, const char *const *cigar, i
                       int readLength, int overHang, const FragmentDist &fd, double *match,
                       int *fraglen /* may be null */);
 
+// ---- synthetic reads (the module's simulateReads / simulatePairedReads: simulator.c:68-196,
+// 221-442).  Same sampling scheme -- isoform ~ expression x effective length, start uniform on the
+// isoform (paired: fragment length from the discretised normal), CIGAR from the exon structure --
+// driven by a private splitmix64 stream instead of the reference's global generator.
+struct SimReads {
+  std::vector<int> isoform, position;
+  std::vector<std::string> cigar;
+};
+SimReads simulate_reads(const Gene &g, const double *expr, int n, int readLength, uint64_t seed);
+SimReads simulate_paired_reads(const Gene &g, const double *expr, int npairs, int readLength,
+                               const FragmentDist &fd, uint64_t seed);
+
 // ---- a packed event: everything the kernels need, nothing they do not ----
 //
 // The reference keeps match[K x N] doubles and walks all N reads every iteration.  Only reads

@@ -131,10 +131,10 @@ __global__ __launch_bounds__(256) void sampler_wave(const KernelArgs a) {
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long slot = static_cast<long>(blockIdx.x) * 4 + wave;
-  if (slot >= static_cast<long>(a.n_events) * a.C) return;  // no block barrier below this line
+  if (slot >= static_cast<long>(a.n_slots) * a.C) return;  // no block barrier below this line
   int *lds_cnt = lds_cnt_all + wave * 32;
 
-  const int ev = static_cast<int>(slot / a.C);
+  const int ev = a.slot_event[slot / a.C];
   const uint32_t chain = static_cast<uint32_t>(slot % a.C);
   const DevEvent E = a.events[ev];
   const int K = E.K;

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 
@@ -15,6 +16,7 @@
 namespace miso {
 
 template <bool PE> __global__ void sampler_wave(const KernelArgs a);
+template <int G, int W> __global__ void sampler_k2(const KernelArgs a);
 __global__ void selftest_detmath_kernel(const double *, int, double *, double *, double *, double *);
 __global__ void selftest_philox_kernel(const uint32_t *, int, uint32_t *);
 
@@ -45,6 +47,8 @@ void miso_batch::release() {
   if (d_in) (void) hipFree(d_in);
   if (d_out) (void) hipFree(d_out);
   if (d_fp) (void) hipFree(d_fp);
+  if (d_slots) (void) hipFree(d_slots);
+  d_slots = nullptr;
   if (ev0) (void) hipEventDestroy(ev0);
   if (ev1) (void) hipEventDestroy(ev1);
   if (stream) (void) hipStreamDestroy(stream);
@@ -105,6 +109,16 @@ void miso_batch::upload(int dev) {
   HIP_OK(hipMalloc(reinterpret_cast<void **>(&d_out), out_bytes));
   if (n) HIP_OK(hipMemcpy(d_events, h_events.data(), n * sizeof(DevEvent), hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(d_in, h_in.data(), in_bytes, hipMemcpyHostToDevice));
+  // launch lists: two-isoform single-end events go to the lane-packed kernel, ordered by their
+  // number of drawing reads so the chains sharing a wavefront loop equally long
+  std::vector<int32_t> k2, gen;
+  for (int i = 0; i < n; i++) ((!p.paired && events[i].K == 2) ? k2 : gen).push_back(i);
+  std::stable_sort(k2.begin(), k2.end(),
+                   [&](int x, int y) { return events[x].n_draw > events[y].n_draw; });
+  n_k2 = static_cast<int>(k2.size()); n_gen = static_cast<int>(gen.size());
+  k2.insert(k2.end(), gen.begin(), gen.end());
+  HIP_OK(hipMalloc(reinterpret_cast<void **>(&d_slots), std::max<size_t>(n, 1) * sizeof(int32_t)));
+  if (n) HIP_OK(hipMemcpy(d_slots, k2.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
   if (p.paired) {
     HIP_OK(hipMalloc(reinterpret_cast<void **>(&d_fp), fd.prob.size() * 8));
     HIP_OK(hipMemcpy(d_fp, fd.prob.data(), fd.prob.size() * 8, hipMemcpyHostToDevice));
@@ -122,9 +136,43 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   a.C = p.noChains; a.M = p.noIterations; a.B = p.noBurnIn; a.lag = p.noLag;
   a.start = p.start; a.first_event_id = first_event_id; a.seed = seed;
   HIP_OK(hipMemsetAsync(d_out, 0, out_bytes, stream));  // trailing sample columns stay 0 (miso.c:661)
-  HIP_OK(hipEventRecord(ev0, stream));
-  const long slots = static_cast<long>(n) * p.noChains;
-  if (slots > 0) {
+  HIP_OK(hipEventRecord(ev0, stream));                  // events bracket the sampler kernel only
+  lanes_per_chain = 0;
+  if (n_k2 > 0) {
+    // Lanes per chain: enough wavefronts to cover every SIMD several times over (256 CUs x 4
+    // SIMDs; target >= 4 waves per SIMD), but no more lanes than a chain has draw quads.
+    const long chains = static_cast<long>(n_k2) * p.noChains;
+    int G = 64;
+    if (const char *env = std::getenv("MISO_LANES_PER_CHAIN")) {
+      G = std::atoi(env);
+    } else {
+      const long target_lanes = 4L * 1024 * 64;
+      while (G > 1 && chains * G > target_lanes) G >>= 1;
+      const int maxq = (events[k2_first_event()].n_draw + 3) / 4;
+      while (G > 1 && G / 2 >= std::max(maxq, 1)) G >>= 1;
+    }
+    if (G < 1 || G > 64 || (G & (G - 1))) MISO_FAIL(MISO_EINVAL, "MISO_LANES_PER_CHAIN must be a power of two <= 64");
+    lanes_per_chain = G;
+    a.slot_event = d_slots; a.n_slots = n_k2;
+    const unsigned grid = static_cast<unsigned>((chains * G + 255) / 256);
+    int W = 2;  // minimum waves per SIMD the kernel variant was register-allocated for
+    if (const char *env = std::getenv("MISO_K2_WAVES")) W = std::atoi(env);
+#define MISO_K2_LAUNCH(GG)                                                                        \
+  case GG:                                                                                        \
+    if (W == 4) hipLaunchKernelGGL((sampler_k2<GG, 4>), dim3(grid), dim3(256), 0, stream, a);      \
+    else if (W == 3) hipLaunchKernelGGL((sampler_k2<GG, 3>), dim3(grid), dim3(256), 0, stream, a); \
+    else hipLaunchKernelGGL((sampler_k2<GG, 2>), dim3(grid), dim3(256), 0, stream, a);             \
+    break;
+    switch (G) {
+      MISO_K2_LAUNCH(1) MISO_K2_LAUNCH(2) MISO_K2_LAUNCH(4) MISO_K2_LAUNCH(8)
+      MISO_K2_LAUNCH(16) MISO_K2_LAUNCH(32) MISO_K2_LAUNCH(64)
+    }
+#undef MISO_K2_LAUNCH
+    HIP_OK(hipGetLastError());
+  }
+  if (n_gen > 0) {
+    a.slot_event = d_slots + n_k2; a.n_slots = n_gen;
+    const long slots = static_cast<long>(n_gen) * p.noChains;
     const unsigned grid = static_cast<unsigned>((slots + 3) / 4);
     const size_t lds = (p.paired ? align_up(fd.prob.size() * 8, 16) : 0) + 4 * 32 * sizeof(int);
     if (p.paired) hipLaunchKernelGGL(sampler_wave<true>, dim3(grid), dim3(256), lds, stream, a);

@@ -1,0 +1,61 @@
+"""Synthetic alternative-splicing events for benchmarks, smoke tests and scale tests.
+
+Shapes follow SURVEY.md section 8(d): a skipped-exon event is three exons with isoforms
+[[0,1,2],[0,2]] (misopy/Gene.py:1042 se_event_to_gene), exon lengths U{50..300}, true psi
+~ U(0.05, 0.95), 1000 reads of 36 bp; K-isoform genes have K+1 exons and isoform k>0 skips
+exon k.  Everything is a pure function of the event's GLOBAL id, so any shard of a run
+(any GPU) builds exactly the events it owns.
+"""
+import numpy as np
+
+from . import capi
+
+GEN_SEED = 1234  # generator seed 1234 + event id
+
+
+def event_gene(event_id, K=2, min_len=50, max_len=300, gap=200):
+    """(exons, isoforms, expression) of synthetic event `event_id`."""
+    rng = np.random.default_rng(GEN_SEED + int(event_id))
+    lens = rng.integers(min_len, max_len + 1, size=K + 1)
+    exons, s = [], 1
+    for ln in lens:
+        exons.append((int(s), int(s + ln - 1)))
+        s += int(ln) + gap
+    isoforms = [list(range(K + 1))] + [[e for e in range(K + 1) if e != k] for k in range(1, K)]
+    if K == 2:
+        psi = rng.uniform(0.05, 0.95)
+        expr = np.array([psi, 1.0 - psi])
+    else:
+        expr = rng.dirichlet(np.ones(K))
+    return exons, isoforms, expr
+
+
+def build_batch(first_event_id, n_events, K=2, n_reads=1000, read_len=36, iters=7500, burn=2500,
+                lag=1, chains=1, paired=False, mean=250.0, var=900.0, counts_trace=False):
+    """Batch holding events [first_event_id, first_event_id + n_events)."""
+    kw = dict(min_len=400, max_len=800, gap=300) if paired else {}
+    b = capi.Batch(read_len, iters=iters, burn=burn, lag=lag, chains=chains, paired=paired,
+                   mean=mean if paired else 0.0, var=var if paired else 0.0,
+                   counts_trace=counts_trace)
+    for i in range(n_events):
+        gid = first_event_id + i
+        exons, isoforms, expr = event_gene(gid, K, **kw)
+        b.add_simulated(capi.Gene(exons, isoforms), expr, n_reads, GEN_SEED + gid)
+    return b
+
+
+def event_reads(event_id, K=2, n_reads=1000, read_len=36, paired=False, mean=250.0, var=900.0):
+    """The same reads build_batch gives event `event_id`, as (exons, isoforms, pos, cigars)."""
+    kw = dict(min_len=400, max_len=800, gap=300) if paired else {}
+    exons, isoforms, expr = event_gene(event_id, K, **kw)
+    g = capi.Gene(exons, isoforms)
+    _, pos, cig = capi.simulate_reads(g, expr, n_reads, read_len, GEN_SEED + int(event_id),
+                                      mean if paired else 0.0, var if paired else 0.0)
+    return exons, isoforms, pos, cig
+
+
+def shard_bounds(n_events, world_size, rank):
+    """Static contiguous split of the event list (misopy/cluster_utils.py:23-32 chunk_list)."""
+    base, extra = divmod(n_events, world_size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
