@@ -38,6 +38,41 @@
 #pragma clang fp contract(off)
 #endif
 
+/* Polynomial coefficients live in tables: on the device they sit in constant memory (scalar
+   loads into SGPRs when needed) instead of being hoisted into ~150 VGPRs by the compiler, which
+   would halve the occupancy of every kernel that calls these routines in a loop.  The tables are
+   not `const` on the device on purpose (a const table is folded back into immediates). */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MISO_TAB static __constant__ double
+#else
+#define MISO_TAB static const double
+#endif
+
+MISO_TAB miso_tab_exp[12] = { /* 1/13! ... 1/2! */
+  1.0 / 6227020800.0, 1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0,
+  1.0 / 40320.0, 1.0 / 5040.0, 1.0 / 720.0, 1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0, 0.5 };
+MISO_TAB miso_tab_log[12] = { /* 2/25 ... 2/3 */
+  2.0 / 25.0, 2.0 / 23.0, 2.0 / 21.0, 2.0 / 19.0, 2.0 / 17.0, 2.0 / 15.0, 2.0 / 13.0, 2.0 / 11.0,
+  2.0 / 9.0, 2.0 / 7.0, 2.0 / 5.0, 2.0 / 3.0 };
+/* AS241 PPND16 coefficient sets, highest degree first: a/b central, c/d intermediate, e/f tail */
+MISO_TAB miso_tab_qa[8] = { 2509.0809287301226727, 33430.575583588128105, 67265.770927008700853,
+  45921.953931549871457, 13731.693765509461125, 1971.5909503065514427, 133.14166789178437745,
+  3.387132872796366608 };
+MISO_TAB miso_tab_qb[8] = { 5226.495278852854561, 28729.085735721942674, 39307.89580009271061,
+  21213.794301586595867, 5394.1960214247511077, 687.1870074920579083, 42.313330701600911252, 1.0 };
+MISO_TAB miso_tab_qc[8] = { 7.7454501427834140764e-4, 0.0227238449892691845833,
+  0.24178072517745061177, 1.27045825245236838258, 3.64784832476320460504, 5.7694972214606914055,
+  4.6303378461565452959, 1.42343711074968357734 };
+MISO_TAB miso_tab_qd[8] = { 1.05075007164441684324e-9, 5.475938084995344946e-4,
+  0.0151986665636164571966, 0.14810397642748007459, 0.68976733498510000455,
+  1.6763848301838038494, 2.05319162663775882187, 1.0 };
+MISO_TAB miso_tab_qe[8] = { 2.01033439929228813265e-7, 2.71155556874348757815e-5,
+  0.0012426609473880784386, 0.026532189526576123093, 0.29656057182850489123,
+  1.7848265399172913358, 5.4637849111641143699, 6.6579046435011037772 };
+MISO_TAB miso_tab_qf[8] = { 2.04426310338993978564e-15, 1.4215117583164458887e-7,
+  1.8463183175100546818e-5, 7.868691311456132591e-4, 0.0148753612908506148525,
+  0.13692988092273580531, 0.59983220655588793769, 1.0 };
+
 MISO_DM uint64_t miso_d2u(double x) { uint64_t u; memcpy(&u, &x, 8); return u; }
 MISO_DM double miso_u2d(uint64_t u) { double x; memcpy(&x, &u, 8); return x; }
 MISO_DM double miso_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
@@ -45,36 +80,33 @@ MISO_DM double miso_fma(double a, double b, double c) { return __builtin_fma(a, 
 /* 2^n for n in [-1022, 1023] */
 MISO_DM double miso_pow2i(int n) { return miso_u2d((uint64_t) (n + 1023) << 52); }
 
+/* Both routines are written branch-free (special cases patched in by selects at the end): on the
+   GPU a data-dependent early return splits the caller into many small basic blocks, and the long
+   f64 dependency chains can then no longer be interleaved with independent work. */
 MISO_DM double miso_det_exp(double x) {
   const double LOG2E = 1.4426950408889634074;
   const double LN2_HI = 6.93147180369123816490e-01; /* low 21 bits of the mantissa zero */
   const double LN2_LO = 1.90821492927058770002e-10;
-  double kd, r, p;
-  int k, k1, k2;
-  if (x != x) return x;
-  if (x > 709.782712893384) return miso_u2d(0x7FF0000000000000ull);
-  if (x < -745.2) return 0.0;
-  kd = __builtin_floor(x * LOG2E + 0.5);
+  double xm, kd, r, p, res;
+  int k, k1, k2, i;
+  xm = (x != x) ? 0.0 : x;
+  xm = (xm > 710.0) ? 710.0 : xm;
+  xm = (xm < -746.0) ? -746.0 : xm;
+  kd = __builtin_floor(xm * LOG2E + 0.5);
   k = (int) kd;
-  r = miso_fma(-kd, LN2_HI, x);
+  r = miso_fma(-kd, LN2_HI, xm);
   r = miso_fma(-kd, LN2_LO, r);
-  p = 1.0 / 6227020800.0;               /* 1/13! */
-  p = miso_fma(p, r, 1.0 / 479001600.0); /* 1/12! */
-  p = miso_fma(p, r, 1.0 / 39916800.0);
-  p = miso_fma(p, r, 1.0 / 3628800.0);
-  p = miso_fma(p, r, 1.0 / 362880.0);
-  p = miso_fma(p, r, 1.0 / 40320.0);
-  p = miso_fma(p, r, 1.0 / 5040.0);
-  p = miso_fma(p, r, 1.0 / 720.0);
-  p = miso_fma(p, r, 1.0 / 120.0);
-  p = miso_fma(p, r, 1.0 / 24.0);
-  p = miso_fma(p, r, 1.0 / 6.0);
-  p = miso_fma(p, r, 0.5);
+  p = miso_tab_exp[0];
+  for (i = 1; i < 12; i++) p = miso_fma(p, r, miso_tab_exp[i]);
   p = miso_fma(p, r, 1.0);
   p = miso_fma(p, r, 1.0);
   k1 = k / 2;
   k2 = k - k1;
-  return p * miso_pow2i(k1) * miso_pow2i(k2);
+  res = p * miso_pow2i(k1) * miso_pow2i(k2);
+  res = (x > 709.782712893384) ? miso_u2d(0x7FF0000000000000ull) : res;
+  res = (x < -745.2) ? 0.0 : res;
+  res = (x != x) ? x : res;
+  return res;
 }
 
 MISO_DM double miso_det_log(double x) {
@@ -82,40 +114,29 @@ MISO_DM double miso_det_log(double x) {
   const double LN2_LO = 1.90821492927058770002e-10;
   const double SQRT2 = 1.41421356237309504880;
   uint64_t u;
-  int e;
-  double m, f, s, z, q, R, ed;
-  if (x != x) return x;
-  if (x < 0.0) return miso_u2d(0x7FF8000000000000ull);
-  if (x == 0.0) return miso_u2d(0xFFF0000000000000ull);
-  u = miso_d2u(x);
-  if (u == 0x7FF0000000000000ull) return x;
-  e = 0;
-  if ((u >> 52) == 0) { /* subnormal: scale by 2^54 */
-    x = x * 18014398509481984.0;
-    u = miso_d2u(x);
-    e = -54;
-  }
-  e += (int) (u >> 52) - 1023;
+  int e, i, sub, big;
+  double xs, m, f, s, z, q, R, ed, res;
+  sub = (miso_d2u(x) >> 52) == 0; /* +subnormal (or +0): scale by 2^54 */
+  xs = sub ? x * 18014398509481984.0 : x;
+  u = miso_d2u(xs);
+  e = (int) ((u >> 52) & 0x7FF) - 1023 + (sub ? -54 : 0);
   m = miso_u2d((u & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull);
-  if (m > SQRT2) { m = m * 0.5; e += 1; }
+  big = m > SQRT2;
+  m = big ? m * 0.5 : m;
+  e += big ? 1 : 0;
   f = m - 1.0;
   s = f / (2.0 + f);
   z = s * s;
-  q = 2.0 / 25.0;
-  q = miso_fma(q, z, 2.0 / 23.0);
-  q = miso_fma(q, z, 2.0 / 21.0);
-  q = miso_fma(q, z, 2.0 / 19.0);
-  q = miso_fma(q, z, 2.0 / 17.0);
-  q = miso_fma(q, z, 2.0 / 15.0);
-  q = miso_fma(q, z, 2.0 / 13.0);
-  q = miso_fma(q, z, 2.0 / 11.0);
-  q = miso_fma(q, z, 2.0 / 9.0);
-  q = miso_fma(q, z, 2.0 / 7.0);
-  q = miso_fma(q, z, 2.0 / 5.0);
-  q = miso_fma(q, z, 2.0 / 3.0);
+  q = miso_tab_log[0];
+  for (i = 1; i < 12; i++) q = miso_fma(q, z, miso_tab_log[i]);
   R = z * q;                      /* log(1+f) = 2s + s*R = f - s*(f - R) */
   ed = (double) e;
-  return miso_fma(ed, LN2_HI, f - (s * (f - R) - ed * LN2_LO));
+  res = miso_fma(ed, LN2_HI, f - (s * (f - R) - ed * LN2_LO));
+  res = (miso_d2u(x) == 0x7FF0000000000000ull) ? x : res;
+  res = (x == 0.0) ? miso_u2d(0xFFF0000000000000ull) : res;
+  res = (x < 0.0) ? miso_u2d(0x7FF8000000000000ull) : res;
+  res = (x != x) ? x : res;
+  return res;
 }
 
 MISO_DM double miso_det_sqrt(double x) {
@@ -152,46 +173,30 @@ MISO_DM double miso_det_sqrt(double x) {
 /* AS241 PPND16: lower-tail standard normal quantile. p in (0,1); p == 0 -> -inf, p == 1 -> +inf
    (as splicing_qnorm5, random.c:1392-1393). */
 MISO_DM double miso_det_qnorm(double p) {
-  double q, r, val;
+  double q, r, val, num, den;
+  int i;
   if (p != p) return p;
   if (p <= 0.0) return (p == 0.0) ? miso_u2d(0xFFF0000000000000ull) : miso_u2d(0x7FF8000000000000ull);
   if (p >= 1.0) return (p == 1.0) ? miso_u2d(0x7FF0000000000000ull) : miso_u2d(0x7FF8000000000000ull);
   q = p - 0.5;
   if ((q < 0 ? -q : q) <= 0.425) {
     r = 0.180625 - q * q;
-    val = q * (((((((r * 2509.0809287301226727 + 33430.575583588128105) * r +
-                    67265.770927008700853) * r + 45921.953931549871457) * r +
-                  13731.693765509461125) * r + 1971.5909503065514427) * r +
-                133.14166789178437745) * r + 3.387132872796366608) /
-          (((((((r * 5226.495278852854561 + 28729.085735721942674) * r +
-                39307.89580009271061) * r + 21213.794301586595867) * r +
-              5394.1960214247511077) * r + 687.1870074920579083) * r +
-            42.313330701600911252) * r + 1.0);
-    return val;
+    num = miso_tab_qa[0]; den = miso_tab_qb[0];
+    for (i = 1; i < 8; i++) { num = num * r + miso_tab_qa[i]; den = den * r + miso_tab_qb[i]; }
+    return q * num / den;
   }
   r = (q > 0) ? (1.0 - p) : p;
   r = miso_det_sqrt(-miso_det_log(r));
   if (r <= 5.0) {
     r = r - 1.6;
-    val = (((((((r * 7.7454501427834140764e-4 + 0.0227238449892691845833) * r +
-                0.24178072517745061177) * r + 1.27045825245236838258) * r +
-              3.64784832476320460504) * r + 5.7694972214606914055) * r +
-            4.6303378461565452959) * r + 1.42343711074968357734) /
-          (((((((r * 1.05075007164441684324e-9 + 5.475938084995344946e-4) * r +
-                0.0151986665636164571966) * r + 0.14810397642748007459) * r +
-              0.68976733498510000455) * r + 1.6763848301838038494) * r +
-            2.05319162663775882187) * r + 1.0);
+    num = miso_tab_qc[0]; den = miso_tab_qd[0];
+    for (i = 1; i < 8; i++) { num = num * r + miso_tab_qc[i]; den = den * r + miso_tab_qd[i]; }
   } else {
     r = r - 5.0;
-    val = (((((((r * 2.01033439929228813265e-7 + 2.71155556874348757815e-5) * r +
-                0.0012426609473880784386) * r + 0.026532189526576123093) * r +
-              0.29656057182850489123) * r + 1.7848265399172913358) * r +
-            5.4637849111641143699) * r + 6.6579046435011037772) /
-          (((((((r * 2.04426310338993978564e-15 + 1.4215117583164458887e-7) * r +
-                1.8463183175100546818e-5) * r + 7.868691311456132591e-4) * r +
-              0.0148753612908506148525) * r + 0.13692988092273580531) * r +
-            0.59983220655588793769) * r + 1.0);
+    num = miso_tab_qe[0]; den = miso_tab_qf[0];
+    for (i = 1; i < 8; i++) { num = num * r + miso_tab_qe[i]; den = den * r + miso_tab_qf[i]; }
   }
+  val = num / den;
   return (q < 0.0) ? -val : val;
 }
 

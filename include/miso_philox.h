@@ -53,6 +53,9 @@ MISO_HD miso_u32x4 miso_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uin
                                       uint32_t k0, uint32_t k1) {
   miso_u32x4 out;
   int r;
+#if defined(__clang__)
+#pragma unroll
+#endif
   for (r = 0; r < 10; r++) {
     uint64_t p0 = (uint64_t) MISO_PHILOX_M0 * c0;
     uint64_t p1 = (uint64_t) MISO_PHILOX_M1 * c2;

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmiso_amd.so")
+LIB_PATH = os.environ.get("MISO_AMD_LIB", os.path.join(_HERE, "libmiso_amd.so"))
 
 MISO_SUCCESS, MISO_FAILURE, MISO_ENOMEM, MISO_EINVAL = 0, 1, 2, 4
 MISO_UNIMPLEMENTED, MISO_EINTERNAL, MISO_ENODEVICE = 12, 38, 60

@@ -13,6 +13,7 @@ namespace miso {
 int device_count();
 void set_device(int d);
 miso_batch *batch_new(const miso_params_t &p);
+int choose_lanes_per_chain(long chains, int max_quads, int wave_slots);
 void selftest_detmath(const double *x, int n, double *e, double *l, double *s, double *q);
 void selftest_philox(const uint32_t *in6, int n, uint32_t *out4);
 }  // namespace miso
@@ -32,6 +33,7 @@ struct miso_batch {
   int32_t *d_slots = nullptr;     // [k2 events sorted by n_draw desc | all other events]
   int n_k2 = 0, n_gen = 0;
   int lanes_per_chain = 0;        // G of the last sampler_k2 launch (0 = none)
+  int wave_slots = 2048;          // resident sampler_k2 wavefronts on the device
   std::vector<miso::DevEvent> h_events;
   std::vector<unsigned char> h_out;
   uint64_t in_bytes = 0, out_bytes = 0;

@@ -2,22 +2,27 @@
 // BASELINE.json configs[1]), lane-packed for CDNA4.
 //
 // Why a second kernel: with K = 2 the per-iteration scalar math (propose + Metropolis-Hastings,
-// miso.c:449-552: ~11 f64 transcendentals and ~13 f64 divisions, one long dependency chain) costs
-// as much as the whole Gibbs sweep over ~500 ambiguous reads.  One wavefront per chain
-// (sampler_wave) spends 63/64 of those issue slots on redundant lanes.  Here a chain owns only
-// G lanes (G = 1..64, a power of two chosen by the host from the batch size):
-//   * the scalar math runs once per G lanes -> 64/G chains share every f64 instruction;
-//   * in the Gibbs step the G lanes stride over the chain's draw quads (one Philox4x32-10 block =
-//     the uniforms of four consecutive ambiguous reads), counting picks of isoform 0 with ONE u32
-//     compare per read: for two compatible isoforms the reference's test
-//         U * (psi0 + psi1) < psi0        (miso.c:69-73)
-//     is monotone in the 32-bit uniform, so it is replaced by  u < t  with the integer threshold
-//     t = #{u : fl(fl(u 2^-32) (psi0+psi1)) < psi0}, found exactly once per iteration;
-//   * a log2(G)-step cross-lane reduction gives the chain its count.
-// Everything that only depends on the CURRENT psi (log psi, normalised log psi*eff, the
-// proposal-density terms) is cached and swapped on acceptance: identical bits, half the
-// transcendentals.  No LDS, no barriers; chain state lives in VGPRs.  Reads with fewer than two
-// compatible isoforms never reach the device (host.hpp PackedEvent).
+// miso.c:449-552: ~11 f64 transcendentals and ~13 f64 divisions) costs as much as the whole Gibbs
+// sweep over ~500 ambiguous reads, and both are VALU-issue bound on gfx950 (f64 = 4 cycles per
+// wave instruction, measured).  One wavefront per chain (sampler_wave) wastes 63/64 of the scalar
+// issue slots.  Here a chain owns G lanes (G = 1..64, a power of two picked by the host):
+//
+//   * MH step, G >= 4: the FOUR lanes of every quad evaluate ONE transcendental routine on FOUR
+//     different arguments (log psi'_0 | log psi'_1 | logit psi'_0, then three exps, then three
+//     logs) and exchange results with DPP quad broadcasts: 5 routine calls per iteration instead
+//     of 11.  Every value is still produced by the same miso_detmath routine on the same input,
+//     so the bits are unchanged.  Terms that depend only on the CURRENT psi are cached and
+//     swapped on acceptance.
+//   * Gibbs step: the G lanes stride over the chain's draw quads (one Philox4x32-10 block = the
+//     uniforms of four consecutive ambiguous reads, two blocks in flight per trip).  With two
+//     compatible isoforms the reference's test  U * (psi0 + psi1) < psi0  (miso.c:69-73) is
+//     monotone in the 32-bit uniform, so it becomes ONE u32 compare against the threshold
+//     t = #{u : fl(fl(u 2^-32)(psi0+psi1)) < psi0}, found exactly once per iteration.  Round 0 of
+//     Philox is partly hoisted: the counter words (iteration, site|chain, event) are chain
+//     constants.
+//   * a log2(G)-step cross-lane add gives the chain its count.
+// No LDS, no barriers; chain state lives in VGPRs.  Reads with fewer than two compatible isoforms
+// never reach the device (host.hpp PackedEvent).
 #include <hip/hip_runtime.h>
 
 #include "device.hpp"
@@ -26,6 +31,14 @@
 #include "miso_philox.h"
 
 #pragma clang fp contract(off)
+
+#ifdef MISO_K2_PROFILE
+#define PROF_T(var) const uint64_t var = __builtin_readcyclecounter()
+#define PROF_ADD(acc, t0, t1) acc += (t1) - (t0)
+#else
+#define PROF_T(var)
+#define PROF_ADD(acc, t0, t1)
+#endif
 
 namespace miso {
 
@@ -40,6 +53,11 @@ struct PsiTerms {
   double pr;          // 1 / psi_0 / (1 - psi_0)                 (miso.c:105-110)
 };
 
+struct K2Consts {
+  double cst0, cst1, is0, is1, hm0, hm1, lg_sum, lg_each, sigma, sd, covar;
+};
+
+// scalar form (set-up, and the whole MH step when G < 4)
 __device__ __forceinline__ PsiTerms psi_terms(double x0, double x1, double cst0, double cst1) {
   PsiTerms t;
   t.x0 = x0; t.x1 = x1;
@@ -48,12 +66,7 @@ __device__ __forceinline__ PsiTerms psi_terms(double x0, double x1, double cst0,
   const double lp0 = t.lx0 + cst0, lp1 = t.lx1 + cst1;
   const bool m1 = lp1 > lp0;  // miso.c:137-140: maxv starts at entry 0
   const double maxv = m1 ? lp1 : lp0;
-  const double dmin = m1 ? lp0 - maxv : lp1 - maxv;
-  const double dmax = m1 ? lp1 - maxv : lp0 - maxv;
-  const double emin = miso_det_exp(dmin);
-  double emax = 1.0;                       // det_exp(+-0) == 1 exactly
-  if (!(dmax == 0.0)) emax = miso_det_exp(dmax);  // only when the maximum is not finite
-  const double ex0 = m1 ? emin : emax, ex1 = m1 ? emax : emin;
+  const double ex0 = miso_det_exp(lp0 - maxv), ex1 = miso_det_exp(lp1 - maxv);
   const double lse = miso_det_log((0.0 + ex0) + ex1) + maxv;
   t.lpn0 = lp0 - lse;
   t.lpn1 = lp1 - lse;
@@ -62,10 +75,6 @@ __device__ __forceinline__ PsiTerms psi_terms(double x0, double x1, double cst0,
   t.pr = 1.0 / (1.0 * x0) / ltheta;
   return t;
 }
-
-struct K2Consts {
-  double cst0, cst1, is0, is1, hm0, hm1, lg_sum, lg_each, sigma, sd, covar;
-};
 
 // miso.c:243-307 with the per-read sums taken from the counts
 __device__ __forceinline__ double joint(const PsiTerms &t, int c0, int c1, const K2Consts &c) {
@@ -79,39 +88,128 @@ __device__ __forceinline__ double joint(const PsiTerms &t, int c0, int c1, const
   return readProb + assProb + psiProb;
 }
 
-// miso.c:97-122 for len = 1: log density of theta under the logistic normal centred at mu
-__device__ __forceinline__ double prop_score(const PsiTerms &t, double mu, const K2Consts &c) {
-  const double tmp = t.lgt - mu;
-  const double expPart = 0.0 + (-0.5) * tmp * tmp / c.sigma;
-  const double pdf = c.covar * t.pr * miso_det_exp(expPart);
-  return miso_det_log(pdf);
+// miso.c:97-122 for len = 1: exponent of the logistic-normal density of theta around mu
+__device__ __forceinline__ double prop_exponent(double lgt, double mu, double sigma) {
+  const double tmp = lgt - mu;
+  return 0.0 + (-0.5) * tmp * tmp / sigma;
 }
 
 // #{u in [0, 2^32) : fl(fl(u * 2^-32) * T) < p0}  -- the reference's two-way draw as a threshold
+__device__ __forceinline__ bool k2_pred(int64_t u, double p0, double T) {
+  // the reference's test for uniform word u; u outside [0, 2^32) extends it monotonically
+  if (u < 0) return true;
+  if (u >= 4294967296ll) return false;
+  return static_cast<double>(static_cast<uint32_t>(u)) * (1.0 / 4294967296.0) * T < p0;
+}
+
 __device__ __forceinline__ uint64_t k2_threshold(double p0, double T) {
   double est = p0 / T * 4294967296.0;
-  if (!(est > 0.0)) est = 0.0;
-  if (est > 4294967296.0) est = 4294967296.0;
-  uint64_t t = static_cast<uint64_t>(est);
-  for (int g = 0; g < 64 && t > 0 &&
-                  !(static_cast<double>(static_cast<uint32_t>(t - 1)) * (1.0 / 4294967296.0) * T < p0); g++) t--;
-  for (int g = 0; g < 64 && t < 4294967296ull &&
-                  (static_cast<double>(static_cast<uint32_t>(t)) * (1.0 / 4294967296.0) * T < p0); g++) t++;
-  return t;
+  est = (est > 0.0) ? est : 0.0;  // also catches NaN
+  est = (est > 4294967296.0) ? 4294967296.0 : est;
+  const int64_t t0 = static_cast<int64_t>(est);
+  // The predicate is monotone in u and est is within one step of the boundary, so the threshold is
+  // t0 - 1 + (number of true tests among t0-1, t0, t0+1); the two outer tests guard that claim.
+  const int n = k2_pred(t0 - 1, p0, T) + k2_pred(t0, p0, T) + k2_pred(t0 + 1, p0, T);
+  int64_t t = t0 - 1 + n;
+  if (!k2_pred(t0 - 2, p0, T) || k2_pred(t0 + 2, p0, T)) {  // never taken for finite psi; exact fallback
+    t = t0 < 0 ? 0 : (t0 > 4294967296ll ? 4294967296ll : t0);
+    for (int g = 0; g < 4096 && t > 0 && !k2_pred(t - 1, p0, T); g++) t--;
+    for (int g = 0; g < 4096 && t < 4294967296ll && k2_pred(t, p0, T); g++) t++;
+  }
+  t = t < 0 ? 0 : t;
+  return static_cast<uint64_t>(t);
+}
+
+// value held by lane J of the caller's quad (v_mov_b32 with DPP quad_perm, full rate)
+template <int J> __device__ __forceinline__ double quad_bcast(double v) {
+  constexpr int ctrl = J | (J << 2) | (J << 4) | (J << 6);
+  const uint64_t u = miso_d2u(v);
+  const uint32_t lo = __builtin_amdgcn_mov_dpp(static_cast<int>(u), ctrl, 0xF, 0xF, true);
+  const uint32_t hi = __builtin_amdgcn_mov_dpp(static_cast<int>(u >> 32), ctrl, 0xF, 0xF, true);
+  return miso_u2d((static_cast<uint64_t>(hi) << 32) | lo);
+}
+
+// value held by an arbitrary lane (ds_bpermute): used when a chain's lanes are not quad aligned
+__device__ __forceinline__ double lane_bcast(double v, int src_lane) {
+  const uint64_t u = miso_d2u(v);
+  const uint32_t lo = __shfl(static_cast<int>(u), src_lane);
+  const uint32_t hi = __shfl(static_cast<int>(u >> 32), src_lane);
+  return miso_u2d((static_cast<uint64_t>(hi) << 32) | lo);
+}
+
+// Evaluate routine f on N arguments with NR lanes of the chain working in parallel: lane with
+// role r evaluates argument g*NR + r, results are broadcast back to every lane of the chain.
+// NR == 1 is the plain scalar form.  QUAD: the chain's lanes start on a quad boundary.
+template <int NR, bool QUAD, int N, class F>
+__device__ __forceinline__ void vec_eval(F f, const double (&in)[N], double (&out)[N], int role, int base) {
+#pragma unroll
+  for (int g = 0; g < (N + NR - 1) / NR; g++) {
+    double arg = in[g * NR];
+#pragma unroll
+    for (int r = 1; r < NR; r++)
+      if (g * NR + r < N) arg = (role == r) ? in[g * NR + r] : arg;
+    const double y = f(arg);
+    if (NR == 1) { out[g] = y; continue; }
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+      if (g * NR + r >= N) continue;
+      if (QUAD && NR == 4) {
+        out[g * NR + r] = r == 0 ? quad_bcast<0>(y) : r == 1 ? quad_bcast<1>(y) : r == 2 ? quad_bcast<2>(y) : quad_bcast<3>(y);
+      } else {
+        out[g * NR + r] = lane_bcast(y, base + r);
+      }
+    }
+  }
+}
+
+// Philox4x32-10 block (q, iter, site|chain, event) with round 0 split into chain / iteration
+// constants: identical output to miso_philox4x32_10.
+struct GibbsRng {
+  uint32_t p1lo, p1hi;  // M1 * (site | chain << 8)
+  uint32_t c3k1;        // event_id ^ k1
+  uint32_t k0, k1;
+};
+
+__device__ __forceinline__ miso_u32x4 philox_gibbs(const GibbsRng &g, uint32_t q, uint32_t n0_round0) {
+  const uint64_t p0 = static_cast<uint64_t>(MISO_PHILOX_M0) * q;
+  uint32_t c0 = n0_round0, c1 = g.p1lo, c2 = static_cast<uint32_t>(p0 >> 32) ^ g.c3k1,
+           c3 = static_cast<uint32_t>(p0);
+  uint32_t k0 = g.k0 + MISO_PHILOX_W0, k1 = g.k1 + MISO_PHILOX_W1;
+#pragma unroll
+  for (int r = 1; r < 10; r++) {
+    const uint64_t a = static_cast<uint64_t>(MISO_PHILOX_M0) * c0;
+    const uint64_t b = static_cast<uint64_t>(MISO_PHILOX_M1) * c2;
+    const uint32_t n0 = static_cast<uint32_t>(b >> 32) ^ c1 ^ k0;
+    const uint32_t n2 = static_cast<uint32_t>(a >> 32) ^ c3 ^ k1;
+    c1 = static_cast<uint32_t>(b); c3 = static_cast<uint32_t>(a); c0 = n0; c2 = n2;
+    k0 += MISO_PHILOX_W0; k1 += MISO_PHILOX_W1;
+  }
+  miso_u32x4 o;
+  o.v[0] = c0; o.v[1] = c1; o.v[2] = c2; o.v[3] = c3;
+  return o;
 }
 
 }  // namespace
 
-template <int G, int W>
-__global__ __launch_bounds__(256, W) void sampler_k2(const KernelArgs a) {
+template <int G>
+__global__ __launch_bounds__(256, 2) void sampler_k2(const KernelArgs a) {
+  constexpr int CPW = 64 / G;                      // chains per wavefront
+  constexpr int NR = G >= 4 ? 4 : G;               // lanes cooperating on the scalar math
+  constexpr bool QUAD = (G % 4) == 0;
+  constexpr bool POW2 = (G & (G - 1)) == 0;
   const int lane = threadIdx.x & 63;
-  const int sub = lane & (G - 1);
+  const int grp_raw = lane / G;
+  const bool lane_used = grp_raw < CPW;            // 64 % G lanes at the top of the wave idle
+  const int grp = lane_used ? grp_raw : CPW - 1;
+  const int base_lane = grp * G;
+  const int sub = lane_used ? lane - base_lane : 0;
+  const int role = sub % NR;
   const long n_chains = static_cast<long>(a.n_slots) * a.C;
-  const long wave_first = (static_cast<long>(blockIdx.x) * 256 + (threadIdx.x & ~63)) / G;
-  if (wave_first >= n_chains) return;  // whole wavefront idle
-  long slot = (static_cast<long>(blockIdx.x) * 256 + threadIdx.x) / G;
-  const bool live = slot < n_chains;   // dead groups shadow the last chain and store nothing
-  if (!live) slot = n_chains - 1;
+  const long wave_id = static_cast<long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (wave_id * CPW >= n_chains) return;  // whole wavefront idle
+  long slot = wave_id * CPW + grp;
+  const bool live = lane_used && slot < n_chains;  // dead lanes shadow a chain and store nothing
+  if (slot >= n_chains) slot = n_chains - 1;
 
   const int ev = a.slot_event[slot / a.C];
   const uint32_t chain = static_cast<uint32_t>(slot % a.C);
@@ -124,45 +222,89 @@ __global__ __launch_bounds__(256, W) void sampler_k2(const KernelArgs a) {
   c.hm0 = consts[4]; c.hm1 = consts[5]; c.lg_sum = consts[6]; c.lg_each = consts[7];
   c.sigma = consts[8]; c.sd = consts[9]; c.covar = consts[10];
   const int base0 = base[0], base1 = base[1];
-  const int n_draw = E.n_draw, n_quads = (n_draw + 3) >> 2;
-  int nq_wave = n_quads;  // loop bound must be wave-uniform: max over the wave's chains
-  for (int off = 32; off >= 1; off >>= 1) nq_wave = max(nq_wave, __shfl_xor(nq_wave, off));
+  const int n_draw = E.n_draw;
+  const int nfq = n_draw >> 2, rem = n_draw & 3;  // full draw quads, draws in the partial one
+  // trips of the Gibbs loop (two quads per lane per trip); must be wave-uniform
+  int trips = (nfq + 2 * G - 1) / (2 * G);
+  int any_rem = rem;
+  for (int off = 32; off >= 1; off >>= 1) {
+    trips = max(trips, __shfl_xor(trips, off));
+    any_rem |= __shfl_xor(any_rem, off);
+  }
 
   double *samples = reinterpret_cast<double *>(a.out_pool + E.off_samples);
   double *loglik = reinterpret_cast<double *>(a.out_pool + E.off_loglik);
-  uint32_t *drawass = reinterpret_cast<uint32_t *>(a.out_pool + E.off_drawass);
+  uint8_t *drawass = a.out_pool + E.off_drawass;
   int32_t *trace = (E.off_trace == NO_TRACE) ? nullptr
                                              : reinterpret_cast<int32_t *>(a.out_pool + E.off_trace);
   const uint32_t k0 = static_cast<uint32_t>(a.seed), k1 = static_cast<uint32_t>(a.seed >> 32);
   const uint32_t c2_gibbs = MISO_SITE_GIBBS | (chain << 8), c2_mh = MISO_SITE_MH | (chain << 8);
+  GibbsRng rng;
+  {
+    const uint64_t p1 = static_cast<uint64_t>(MISO_PHILOX_M1) * c2_gibbs;
+    rng.p1lo = static_cast<uint32_t>(p1); rng.p1hi = static_cast<uint32_t>(p1 >> 32);
+    rng.c3k1 = event_id ^ k1; rng.k0 = k0; rng.k1 = k1;
+  }
 
   int cnt0 = 0, cnt1 = 0;
   PsiTerms cur;
   double alpha = 0.0;
 
-  auto gibbs = [&](uint32_t iter, bool write_ass) {
+  // Gibbs step for the current psi (miso.c:30-91 restricted to two compatible isoforms)
+#ifdef MISO_K2_PROFILE
+  uint64_t pf_mh = 0, pf_thr = 0, pf_loop = 0, pf_red = 0, pf_rec = 0;
+#endif
+  auto gibbs = [&](uint32_t iter) {
+    PROF_T(g0);
     const uint64_t t = k2_threshold(cur.x0, (0.0 + cur.x0) + cur.x1);
-    const bool all = t >= 4294967296ull;
-    const uint32_t t32 = static_cast<uint32_t>(t);
+    const uint32_t tm = static_cast<uint32_t>(t - 1);  // u < t  <=>  t != 0 && u <= t - 1
+    const uint32_t n0r0 = rng.p1hi ^ iter ^ k0;
     int d0 = 0;
-    for (int q = sub; q < nq_wave; q += G) {
-      const miso_u32x4 u = miso_philox4x32_10(static_cast<uint32_t>(q), iter, c2_gibbs, event_id, k0, k1);
-      if (q < n_quads) {
-        const int rem = n_draw - 4 * q;  // >= 1 valid draws in this quad
-        const int p0 = all | (u.v[0] < t32), p1 = all | (u.v[1] < t32), p2 = all | (u.v[2] < t32),
-                  p3 = all | (u.v[3] < t32);
-        d0 += p0 + (rem > 1 ? p1 : 0) + (rem > 2 ? p2 : 0) + (rem > 3 ? p3 : 0);
-        if (write_ass)  // isoform index per read, one byte each: pick ? 0 : 1
-          drawass[q] = (p0 ? 0u : 1u) | (p1 ? 0u : 1u) << 8 | (p2 ? 0u : 1u) << 16 | (p3 ? 0u : 1u) << 24;
-      }
+    PROF_T(g1);
+    PROF_ADD(pf_thr, g0, g1);
+    for (int j = 0; j < trips; j++) {
+      const int qa = sub + (2 * j) * G, qb = qa + G;
+      const miso_u32x4 ua = philox_gibbs(rng, static_cast<uint32_t>(qa), n0r0);
+      const miso_u32x4 ub = philox_gibbs(rng, static_cast<uint32_t>(qb), n0r0);
+      const int ca = (ua.v[0] <= tm) + (ua.v[1] <= tm) + (ua.v[2] <= tm) + (ua.v[3] <= tm);
+      const int cb = (ub.v[0] <= tm) + (ub.v[1] <= tm) + (ub.v[2] <= tm) + (ub.v[3] <= tm);
+      d0 += (qa < nfq ? ca : 0) + (qb < nfq ? cb : 0);
     }
+    if (any_rem) {  // the partial quad, owned by one lane of the group
+      const miso_u32x4 u = philox_gibbs(rng, static_cast<uint32_t>(nfq), n0r0);
+      const int cp = (rem > 0 && u.v[0] <= tm) + (rem > 1 && u.v[1] <= tm) + (rem > 2 && u.v[2] <= tm);
+      d0 += (sub == (nfq % G)) ? cp : 0;
+    }
+    if (t == 0 || !lane_used) d0 = 0;
+    PROF_T(g2);
+    PROF_ADD(pf_loop, g1, g2);
+    if (POW2) {
 #pragma unroll
-    for (int off = G >> 1; off >= 1; off >>= 1) d0 += __shfl_xor(d0, off);
+      for (int off = G >> 1; off >= 1; off >>= 1) d0 += __shfl_xor(d0, off);
+    } else {
+      int tot = 0;
+#pragma unroll
+      for (int j = 0; j < G; j++) tot += __shfl(d0, base_lane + j);
+      d0 = tot;
+    }
     cnt0 = base0 + d0;
     cnt1 = base1 + (n_draw - d0);
+    PROF_T(g3);
+    PROF_ADD(pf_red, g2, g3);
   };
 
-  // alpha' = alpha + sd z, psi' = logit_inv(alpha') (miso.c:449-471); also hands back the accept word
+  // the per-read picks of one Gibbs step, written once for the caller (miso.c:943-946)
+  auto gibbs_write = [&](uint32_t iter) {
+    const uint64_t t = k2_threshold(cur.x0, (0.0 + cur.x0) + cur.x1);
+    const int nq = (n_draw + 3) >> 2;
+    for (int q = sub; q < nq; q += G) {
+      const miso_u32x4 u = miso_philox4x32_10(static_cast<uint32_t>(q), iter, c2_gibbs, event_id, k0, k1);
+      for (int j = 0; j < 4; j++)
+        if (4 * q + j < n_draw) drawass[4 * q + j] = (static_cast<uint64_t>(u.v[j]) < t) ? 0 : 1;
+    }
+  };
+
+  // alpha' = alpha + sd z, psi' = logit_inv(alpha') (miso.c:449-471); also the accept word
   auto propose = [&](uint32_t iter, double &alphaN, double &x0, double &x1, uint32_t &accept_word) {
     const miso_u32x4 b = miso_philox4x32_10(0u, iter, c2_mh, event_id, k0, k1);
     accept_word = b.v[0];
@@ -181,7 +323,8 @@ __global__ __launch_bounds__(256, W) void sampler_k2(const KernelArgs a) {
     alpha = aN;
     cur = psi_terms(x0, x1, c.cst0, c.cst1);
   }
-  gibbs(MISO_ITER_INIT, live && sub < G && chain == 0 && a.M == 0);
+  gibbs(MISO_ITER_INIT);
+  if (a.M == 0 && live && chain == 0) gibbs_write(MISO_ITER_INIT);
 
   uint64_t hash = 0xCBF29CE484222325ull;
   int accepted = 0, lagCounter = 0, noS = 0;
@@ -194,17 +337,47 @@ __global__ __launch_bounds__(256, W) void sampler_k2(const KernelArgs a) {
       int32_t *row = trace + (static_cast<size_t>(m) * a.C + chain) * 2;
       row[0] = cnt0; row[1] = cnt1;
     }
+    PROF_T(m0);
     double alphaN, x0, x1; uint32_t accept_word;
     propose(static_cast<uint32_t>(m), alphaN, x0, x1, accept_word);
-    const PsiTerms nw = psi_terms(x0, x1, c.cst0, c.cst1);
+    PsiTerms nw;
+    double ptoCS, ctoPS;
+    {
+      // NR lanes, one routine, NR arguments per call (see vec_eval)
+      auto f_log = [](double v) { return miso_det_log(v); };
+      auto f_exp = [](double v) { return miso_det_exp(v); };
+      const double ltheta = 1.0 - x0;
+      const double inB[3] = {x0, x1, x0 / ltheta};
+      double outB[3];
+      vec_eval<NR, QUAD>(f_log, inB, outB, role, base_lane);
+      nw.x0 = x0; nw.x1 = x1;
+      nw.lx0 = outB[0]; nw.lx1 = outB[1]; nw.lgt = outB[2];
+      nw.pr = 1.0 / (1.0 * x0) / ltheta;
+      const double lp0 = nw.lx0 + c.cst0, lp1 = nw.lx1 + c.cst1;
+      const double maxv = (lp1 > lp0) ? lp1 : lp0;  // miso.c:137-140: maxv starts at entry 0
+      const double inC[4] = {lp0 - maxv, lp1 - maxv,
+                             prop_exponent(cur.lgt, alphaN, c.sigma),   // theta = psi,  mu = alpha'
+                             prop_exponent(nw.lgt, alpha, c.sigma)};    // theta = psi', mu = alpha
+      double outC[4];
+      vec_eval<NR, QUAD>(f_exp, inC, outC, role, base_lane);
+      const double inD[3] = {(0.0 + outC[0]) + outC[1], c.covar * cur.pr * outC[2],
+                             c.covar * nw.pr * outC[3]};
+      double outD[3];
+      vec_eval<NR, QUAD>(f_log, inD, outD, role, base_lane);
+      const double lse = outD[0] + maxv;
+      ptoCS = outD[1];
+      ctoPS = outD[2];
+      nw.lpn0 = lp0 - lse;
+      nw.lpn1 = lp1 - lse;
+    }
     const double pp = joint(nw, cnt0, cnt1, c);
     const double pc = joint(cur, cnt0, cnt1, c);
-    const double ptoCS = prop_score(cur, alphaN, c);
-    const double ctoPS = prop_score(nw, alpha, c);
     const double acceptP = (m > 0) ? miso_det_exp(pp + ptoCS - (pc + ctoPS)) : miso_det_exp(pp - pc);
     const bool acc = (acceptP >= 1) || (miso_u01(accept_word) < acceptP);
     double cJS = pc;
     if (acc) { cur = nw; alpha = alphaN; cJS = pp; accepted++; }
+    PROF_T(m1);
+    PROF_ADD(pf_mh, m0, m1);
 
     if (m >= a.B) {  // miso.c:882-893
       if (lagCounter == a.lag - 1) {
@@ -219,8 +392,18 @@ __global__ __launch_bounds__(256, W) void sampler_k2(const KernelArgs a) {
         lagCounter++;
       }
     }
-    gibbs(static_cast<uint32_t>(m), live && chain == 0 && m == a.M - 1);
+    PROF_T(m2);
+    PROF_ADD(pf_rec, m1, m2);
+    gibbs(static_cast<uint32_t>(m));
   }
+#ifdef MISO_K2_PROFILE
+  if (writer && chain == 0 && a.M > 8) {  // smuggle the phase cycle counts out through the log scores
+    loglik[0] = static_cast<double>(pf_mh); loglik[1] = static_cast<double>(pf_thr);
+    loglik[2] = static_cast<double>(pf_loop); loglik[3] = static_cast<double>(pf_red);
+    loglik[4] = static_cast<double>(pf_rec);
+  }
+#endif
+  if (a.M > 0 && live && chain == 0) gibbs_write(static_cast<uint32_t>(a.M - 1));
   hash = (hash ^ static_cast<uint32_t>(cnt0)) * 0x100000001B3ull;
   hash = (hash ^ static_cast<uint32_t>(cnt1)) * 0x100000001B3ull;
   if (writer) {
@@ -235,15 +418,20 @@ __global__ __launch_bounds__(256, W) void sampler_k2(const KernelArgs a) {
   }
 }
 
-#define MISO_INSTANTIATE_K2(G) \
-  template __global__ void sampler_k2<G, 2>(const KernelArgs); \
-  template __global__ void sampler_k2<G, 3>(const KernelArgs); \
-  template __global__ void sampler_k2<G, 4>(const KernelArgs);
+#define MISO_INSTANTIATE_K2(G) template __global__ void sampler_k2<G>(const KernelArgs);
 MISO_INSTANTIATE_K2(1)
 MISO_INSTANTIATE_K2(2)
+MISO_INSTANTIATE_K2(3)
 MISO_INSTANTIATE_K2(4)
+MISO_INSTANTIATE_K2(5)
+MISO_INSTANTIATE_K2(6)
+MISO_INSTANTIATE_K2(7)
 MISO_INSTANTIATE_K2(8)
+MISO_INSTANTIATE_K2(9)
+MISO_INSTANTIATE_K2(10)
+MISO_INSTANTIATE_K2(12)
 MISO_INSTANTIATE_K2(16)
+MISO_INSTANTIATE_K2(21)
 MISO_INSTANTIATE_K2(32)
 MISO_INSTANTIATE_K2(64)
 

@@ -16,7 +16,7 @@
 namespace miso {
 
 template <bool PE> __global__ void sampler_wave(const KernelArgs a);
-template <int G, int W> __global__ void sampler_k2(const KernelArgs a);
+template <int G> __global__ void sampler_k2(const KernelArgs a);
 __global__ void selftest_detmath_kernel(const double *, int, double *, double *, double *, double *);
 __global__ void selftest_philox_kernel(const uint32_t *, int, uint32_t *);
 
@@ -36,6 +36,24 @@ int device_count() {
 void set_device(int d) { HIP_OK(hipSetDevice(d)); }
 
 static inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
+
+// Lanes per chain for sampler_k2.  Measured on MI355X (profiles/r01_k2_phase_cycles.txt): the
+// kernel is VALU-issue bound at two resident wavefronts per SIMD; the per-iteration scalar MH
+// step costs a wavefront ~9k cycles whatever G is, so fewer lanes per chain (more chains sharing
+// it) is better -- until the wavefronts no longer fit the device's resident slots and a second,
+// mostly empty round starts.  Hence: the smallest supported G whose wavefront count still fills
+// the slots once, i.e. the largest G with ceil(chains / (64 / G)) <= slots; G = 1 for batches that
+// overflow anyway; never more lanes than a chain has pairs of draw quads to stride over.
+int choose_lanes_per_chain(long chains, int max_quads, int wave_slots) {
+  static const int kG[] = {64, 32, 21, 16, 12, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1};
+  const int cap = std::max(1, max_quads / 2);
+  for (int G : kG) {
+    if (G > cap) continue;
+    const int cpw = 64 / G;
+    if ((chains + cpw - 1) / cpw <= wave_slots) return G;
+  }
+  return 1;
+}
 
 }  // namespace miso
 
@@ -101,6 +119,11 @@ void miso_batch::upload(int dev) {
     if (!e.sfix_table.empty())
       std::memcpy(h_in.data() + d.off_sfix, e.sfix_table.data(), e.sfix_table.size() * 8);
   }
+  {
+    hipDeviceProp_t prop;
+    HIP_OK(hipGetDeviceProperties(&prop, dev));
+    wave_slots = prop.multiProcessorCount * 4 * 2;  // CUs x SIMDs x resident sampler_k2 waves
+  }
   HIP_OK(hipStreamCreate(&stream));
   HIP_OK(hipEventCreate(&ev0));
   HIP_OK(hipEventCreate(&ev1));
@@ -139,33 +162,22 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   HIP_OK(hipEventRecord(ev0, stream));                  // events bracket the sampler kernel only
   lanes_per_chain = 0;
   if (n_k2 > 0) {
-    // Lanes per chain: enough wavefronts to cover every SIMD several times over (256 CUs x 4
-    // SIMDs; target >= 4 waves per SIMD), but no more lanes than a chain has draw quads.
     const long chains = static_cast<long>(n_k2) * p.noChains;
-    int G = 64;
-    if (const char *env = std::getenv("MISO_LANES_PER_CHAIN")) {
-      G = std::atoi(env);
-    } else {
-      const long target_lanes = 4L * 1024 * 64;
-      while (G > 1 && chains * G > target_lanes) G >>= 1;
-      const int maxq = (events[k2_first_event()].n_draw + 3) / 4;
-      while (G > 1 && G / 2 >= std::max(maxq, 1)) G >>= 1;
-    }
-    if (G < 1 || G > 64 || (G & (G - 1))) MISO_FAIL(MISO_EINVAL, "MISO_LANES_PER_CHAIN must be a power of two <= 64");
+    const int maxq = (events[k2_first_event()].n_draw + 3) / 4;
+    int G = 0;
+    if (const char *env = std::getenv("MISO_LANES_PER_CHAIN")) G = std::atoi(env);
+    else G = choose_lanes_per_chain(chains, maxq, wave_slots);
     lanes_per_chain = G;
     a.slot_event = d_slots; a.n_slots = n_k2;
-    const unsigned grid = static_cast<unsigned>((chains * G + 255) / 256);
-    int W = 2;  // minimum waves per SIMD the kernel variant was register-allocated for
-    if (const char *env = std::getenv("MISO_K2_WAVES")) W = std::atoi(env);
-#define MISO_K2_LAUNCH(GG)                                                                        \
-  case GG:                                                                                        \
-    if (W == 4) hipLaunchKernelGGL((sampler_k2<GG, 4>), dim3(grid), dim3(256), 0, stream, a);      \
-    else if (W == 3) hipLaunchKernelGGL((sampler_k2<GG, 3>), dim3(grid), dim3(256), 0, stream, a); \
-    else hipLaunchKernelGGL((sampler_k2<GG, 2>), dim3(grid), dim3(256), 0, stream, a);             \
-    break;
+    const int cpw = 64 / std::max(G, 1);
+    const unsigned grid = static_cast<unsigned>(((chains + cpw - 1) / cpw + 3) / 4);
+#define MISO_K2_LAUNCH(GG) \
+  case GG: hipLaunchKernelGGL((sampler_k2<GG>), dim3(grid), dim3(256), 0, stream, a); break;
     switch (G) {
-      MISO_K2_LAUNCH(1) MISO_K2_LAUNCH(2) MISO_K2_LAUNCH(4) MISO_K2_LAUNCH(8)
-      MISO_K2_LAUNCH(16) MISO_K2_LAUNCH(32) MISO_K2_LAUNCH(64)
+      MISO_K2_LAUNCH(1) MISO_K2_LAUNCH(2) MISO_K2_LAUNCH(3) MISO_K2_LAUNCH(4) MISO_K2_LAUNCH(5)
+      MISO_K2_LAUNCH(6) MISO_K2_LAUNCH(7) MISO_K2_LAUNCH(8) MISO_K2_LAUNCH(9) MISO_K2_LAUNCH(10)
+      MISO_K2_LAUNCH(12) MISO_K2_LAUNCH(16) MISO_K2_LAUNCH(21) MISO_K2_LAUNCH(32) MISO_K2_LAUNCH(64)
+    default: MISO_FAIL(MISO_EINVAL, "MISO_LANES_PER_CHAIN must be one of 1-10,12,16,21,32,64");
     }
 #undef MISO_K2_LAUNCH
     HIP_OK(hipGetLastError());

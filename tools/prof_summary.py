@@ -1,0 +1,48 @@
+"""Summarise rocprofv3 rocpd databases (kernel trace + PMC passes) into a text file for profiles/."""
+import glob, os, sqlite3, sys
+
+def q(db, sql):
+    con = sqlite3.connect(db)
+    try:
+        cur = con.execute(sql)
+        cols = [d[0] for d in cur.description]
+        return cols, cur.fetchall()
+    finally:
+        con.close()
+
+def main(prof_dir, out):
+    lines = []
+    tr = glob.glob(os.path.join(prof_dir, "trace", "*.db"))
+    if tr:
+        cols, rows = q(tr[0], "select name, count(*) as calls, sum(end-start) as total_ns, avg(end-start) as avg_ns, "
+                              "min(end-start) as min_ns, max(end-start) as max_ns from kernels group by name order by total_ns desc")
+        lines.append("== kernel trace (rocprofv3 --kernel-trace --stats) ==")
+        lines.append("%-60s %6s %14s %14s %14s %14s" % ("kernel", "calls", "total_ms", "avg_ms", "min_ms", "max_ms"))
+        for r in rows:
+            lines.append("%-60s %6d %14.3f %14.3f %14.3f %14.3f" % (r[0][:60], r[1], r[2]/1e6, r[3]/1e6, r[4]/1e6, r[5]/1e6))
+        cols, rows = q(tr[0], "select name, grid_x, workgroup_x, lds_size, scratch_size, vgpr_count, accum_vgpr_count, sgpr_count "
+                              "from kernels group by name") if True else (None, [])
+        lines.append("")
+        lines.append("%-60s %10s %6s %6s %8s %6s %6s %6s" % ("kernel", "grid", "wg", "lds", "scratch", "vgpr", "agpr", "sgpr"))
+        for r in rows:
+            lines.append("%-60s %10s %6s %6s %8s %6s %6s %6s" % ((r[0][:60],) + tuple(r[1:])))
+    for sub in sorted(glob.glob(os.path.join(prof_dir, "pmc_*"))):
+        if not os.path.isdir(sub):
+            continue
+        for db in glob.glob(os.path.join(sub, "*.db")):
+            try:
+                cols, rows = q(db, "select kernel_name, counter_name, count(*) as n, sum(value) as total, avg(value) as avg "
+                                   "from counters_collection group by kernel_name, counter_name order by kernel_name, counter_name")
+            except Exception as e:
+                lines.append("(%s: %s)" % (db, e)); continue
+            lines.append("")
+            lines.append("== PMC pass %s (rocprofv3 --pmc; value summed over XCDs/SEs per dispatch, avg over dispatches) ==" % os.path.basename(sub))
+            lines.append("%-50s %-24s %6s %22s" % ("kernel", "counter", "disp", "avg_per_dispatch"))
+            for r in rows:
+                lines.append("%-50s %-24s %6d %22.1f" % (r[0][:50], r[1], r[2], r[4]))
+    txt = "\n".join(lines) + "\n"
+    open(out, "w").write(txt)
+    print(txt)
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
