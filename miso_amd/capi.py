@@ -240,6 +240,15 @@ class Batch:
         check(lib().miso_batch_algorithmic_bytes(self.handle, C.byref(b)))
         return b.value
 
+    def classes(self, i):
+        """(templates [ncls, K], counts [ncls]) of event i: available before any GPU work."""
+        K, ncls = C.c_int(), C.c_int()
+        check(lib().miso_batch_event_info(self.handle, i, C.byref(K), None, None, C.byref(ncls)))
+        ct = np.zeros((max(ncls.value, 1), K.value))
+        cc = np.zeros(max(ncls.value, 1))
+        check(lib().miso_batch_get_result(self.handle, i, None, None, _p(ct), _p(cc), None, None))
+        return ct[:ncls.value], cc[:ncls.value]
+
     def result(self, i, trace=False):
         K, N, S, ncls = C.c_int(), C.c_int(), C.c_int(), C.c_int()
         check(lib().miso_batch_event_info(self.handle, i, C.byref(K), C.byref(N), C.byref(S),

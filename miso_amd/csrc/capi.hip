@@ -222,16 +222,18 @@ int miso_batch_get_result(const miso_batch_t *b, int i, double *samples, double 
   return guarded([&] {
     need(b, "batch");
     const PackedEvent &e = event_at(b, i);
+    // read classes are host-side set-up quantities (miso.c:762); everything else needs the run
+    if (class_templates)
+      std::memcpy(class_templates, e.class_templates.data(), sizeof(double) * e.class_templates.size());
+    if (class_counts)
+      std::memcpy(class_counts, e.class_counts.data(), sizeof(double) * e.class_counts.size());
+    if (!samples && !logLik && !assignment && !rundata) return;
     if (!b->downloaded) MISO_FAIL(MISO_EINVAL, "results not downloaded yet");
     const DevEvent &d = b->h_events[i];
     const unsigned char *out = b->h_out.data();
     const int S = b->S();
     if (samples) std::memcpy(samples, out + d.off_samples, sizeof(double) * S * e.K);
     if (logLik) std::memcpy(logLik, out + d.off_loglik, sizeof(double) * S);
-    if (class_templates)
-      std::memcpy(class_templates, e.class_templates.data(), sizeof(double) * e.class_templates.size());
-    if (class_counts)
-      std::memcpy(class_counts, e.class_counts.data(), sizeof(double) * e.class_counts.size());
     if (assignment) {  // chain 0, final state (miso.c:943-946)
       const uint8_t *da = out + d.off_drawass;
       int r = 0;

@@ -1,6 +1,6 @@
 // host.hpp -- host-side model of the sampler path: gene, alignment matching, packed problems.
 //
-// Product code (libmiso_amd.so).  Independent of oracle/: the CPU checker has its own C
+// Product code (libmiso_amd.so).  Independent of the CPU checker, which has its own C
 // restatement; the two meet only in tests.
 #pragma once
 

@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the REAL reference.
+
+Run in the authoring container only (needs /root/reference and `make -C oracle ref`):
+
+    python tests/golden/make_golden.py
+
+Each fixture is an .npz holding the inputs (gene, read positions, CIGARs, sampler parameters,
+MT19937 seed) and what the reference C core (oracle/_ref/libmiso_ref.so = the reference's own
+sources behind oracle/ref_shim.c) returned for them: match matrix, read classes, psi samples, log
+scores, final assignment, run data.  tests/test_oracle_golden.py replays the inputs through
+oracle/miso_oracle.c (stream mode) and demands identical bits, with or without the reference
+library being present.  Data only: no reference source text is stored.
+
+Also extracts the reference's own test data set (misopy/test-data/sam-data/c2c12.Atp2b1.sam +
+misopy/gff-events/mm9/genes/Atp2b1.mm9.gff, the inputs of misopy/test_miso.py:131-171) into
+plain arrays: read start (SAM POS, 1-based), CIGAR string, and the two mRNAs' exon lists.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from _libs import RefLib  # noqa: E402
+from _problems import expr_for, flat, se_gene  # noqa: E402
+
+REF_ROOT = "/root/reference/misopy"
+
+
+def save(name, **kw):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **kw)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+def pack_result(r):
+    return dict(match=r.match, class_templates=r.class_templates, class_counts=r.class_counts,
+                samples=r.samples, loglik=r.loglik, assignment=r.assignment, rundata=r.rundata)
+
+
+def iso_array(isoforms):
+    out = []
+    for iso in isoforms:
+        out.extend(iso)
+        out.append(-1)
+    return np.asarray(out, np.int32)
+
+
+def se_case(R, name, K, N, seed, iters, burn, lag, chains, overhang=1, read_len=36, **gene_kw):
+    exons, isoforms = se_gene(K, **gene_kw)
+    g = R.gene(flat(exons), isoforms)
+    R.rng_seed(seed)
+    stream = np.array([R.unif01() for _ in range(8)] + [R.normal01() for _ in range(8)])
+    R.rng_seed(seed)
+    rc, iso, pos, cig = R.simulate_reads(g, expr_for(K), N, read_len)
+    assert rc == 0
+    r = R.miso(g, pos, cig, read_len, iters=iters, burn=burn, lag=lag, chains=chains,
+               overhang=overhang)
+    assert r.rc == 0
+    save(name, kind="se", exons=np.asarray(exons, np.int32), isoforms=iso_array(isoforms),
+         expr=expr_for(K), seed=seed, read_len=read_len, overhang=overhang, iters=iters, burn=burn,
+         lag=lag, chains=chains, pos=pos, cigars=np.array(cig), sim_isoform=iso, rng_stream=stream,
+         **pack_result(r))
+
+
+def pe_case(R, name, K, N, seed, iters, burn, lag, chains, mean=250.0, var=900.0, read_len=36):
+    exons, isoforms = se_gene(K, exlen=500, gap=300)
+    g = R.gene(flat(exons), isoforms)
+    R.rng_seed(seed)
+    rc, iso, pos, cig = R.simulate_paired_reads(g, expr_for(K), N, read_len, mean, var)
+    assert rc == 0
+    rcm, m, fl = R.match_iso_paired(g, pos, cig, read_len, mean, var)
+    r = R.miso_paired(g, pos, cig, read_len, mean, var, iters=iters, burn=burn, lag=lag,
+                      chains=chains)
+    assert r.rc == 0 and rcm == 0
+    save(name, kind="pe", exons=np.asarray(exons, np.int32), isoforms=iso_array(isoforms),
+         expr=expr_for(K), seed=seed, read_len=read_len, overhang=1, iters=iters, burn=burn,
+         lag=lag, chains=chains, mean=mean, var=var, pos=pos, cigars=np.array(cig),
+         sim_isoform=iso, fraglen=fl, **pack_result(r))
+
+
+def cigar_edge_case(R):
+    """Hand-written alignments exercising solve.c:220-306 / 8-108: clips, =, X, D, I, skips that
+    do and do not match the annotation, overhang violations, short reads, reads off the gene."""
+    exons = [(101, 200), (301, 400), (501, 600)]
+    isoforms = [[0, 1, 2], [0, 2]]
+    g = R.gene(flat(exons), isoforms)
+    reads = [
+        (120, "36M"), (180, "21M100N15M"), (180, "21M300N15M"), (190, "11M100N25M"),
+        (199, "2M100N34M"), (350, "36M"), (380, "21M100N15M"), (120, "4S32M"), (120, "32M4S"),
+        (120, "2H34M"), (120, "10M2I26M"), (120, "10M2D24M"), (120, "30=6X"), (120, "20M"),
+        (50, "36M"), (590, "36M"), (180, "21M99N15M"), (181, "20M100N16M"), (165, "36M"),
+        (166, "35M100N1M"), (120, "36M10M"), (400, "1M100N35M"), (365, "36M"),
+    ]
+    pos = np.array([p for p, _ in reads], np.int32)
+    cig = [c.encode() for _, c in reads]
+    out = {}
+    for ov in (1, 4):
+        rc, m = R.match_iso(g, pos, cig, 36, overhang=ov)
+        assert rc == 0
+        out["match_ov%d" % ov] = m
+    R.rng_seed(9)
+    r = R.miso(g, pos, cig, 36, iters=300, burn=50, lag=2, chains=2, overhang=1)
+    assert r.rc == 0
+    save("cigar_edges", kind="se", exons=np.asarray(exons, np.int32), isoforms=iso_array(isoforms),
+         seed=9, read_len=36, overhang=1, iters=300, burn=50, lag=2, chains=2, pos=pos,
+         cigars=np.array(cig), **out, **pack_result(r))
+
+
+def atp2b1_case(R):
+    """The reference's own test inputs (misopy/test_miso.py:131-171), as arrays."""
+    gff = os.path.join(REF_ROOT, "gff-events/mm9/genes/Atp2b1.mm9.gff")
+    sam = os.path.join(REF_ROOT, "test-data/sam-data/c2c12.Atp2b1.sam")
+    mrnas, order = {}, []
+    for line in open(gff):
+        if line.startswith("#"):
+            continue
+        f = line.rstrip("\n").split("\t")
+        attrs = dict(kv.split("=", 1) for kv in f[8].split(";") if "=" in kv)
+        if f[2] == "mRNA":
+            mrnas[attrs["ID"]] = []
+            order.append(attrs["ID"])
+        elif f[2] == "exon":
+            mrnas[attrs["Parent"]].append((int(f[3]), int(f[4])))
+    parts = sorted({e for m in order for e in mrnas[m]})       # misopy/Gene.py: parts by start
+    isoforms = [sorted(parts.index(e) for e in mrnas[m]) for m in order]
+    pos, cig = [], []
+    for line in open(sam):
+        if line.startswith("@"):
+            continue
+        f = line.split("\t")
+        if f[5] == "*":
+            continue
+        pos.append(int(f[3]))
+        cig.append(f[5].encode())
+    pos = np.asarray(pos, np.int32)
+    g = R.gene(flat(parts), isoforms)
+    R.rng_seed(42)
+    r = R.miso(g, pos, cig, 36, iters=1000, burn=200, lag=4, chains=2, overhang=1)
+    assert r.rc == 0
+    save("atp2b1", kind="se", exons=np.asarray(parts, np.int32), isoforms=iso_array(isoforms),
+         mrna_ids=np.array(order), seed=42, read_len=36, overhang=1, iters=1000, burn=200, lag=4,
+         chains=2, pos=pos, cigars=np.array(cig), **pack_result(r))
+
+
+def main():
+    if not RefLib.available():
+        sys.exit("oracle/_ref/libmiso_ref.so missing: run `make -C oracle ref` first")
+    R = RefLib()
+    devnull = os.open(os.devnull, os.O_WRONLY)
+    saved = os.dup(1)
+    os.dup2(devnull, 1)  # the reference prints "no chains: %d" (miso.c:837)
+    try:
+        se_case(R, "se_k2", 2, 400, 42, 1000, 200, 2, 1)
+        se_case(R, "se_k2_default", 2, 300, 7, 1000, 100, 10, 6)
+        se_case(R, "se_k3", 3, 300, 11, 600, 100, 5, 3, overhang=4)
+        se_case(R, "se_k5", 5, 400, 13, 500, 100, 3, 2)
+        se_case(R, "se_k10", 10, 500, 17, 300, 60, 7, 2)
+        se_case(R, "se_k2_lagrem", 2, 100, 19, 207, 50, 10, 3)   # lag does not divide M-B (C8)
+        pe_case(R, "pe_k2", 2, 300, 23, 600, 100, 2, 2)
+        pe_case(R, "pe_k3", 3, 250, 29, 400, 50, 5, 3)
+        pe_case(R, "pe_k5", 5, 200, 31, 300, 50, 3, 1)
+        cigar_edge_case(R)
+        atp2b1_case(R)
+    finally:
+        os.dup2(saved, 1)
+    print("done")
+
+
+if __name__ == "__main__":
+    main()

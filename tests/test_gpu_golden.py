@@ -1,0 +1,87 @@
+"""GPU: the HIP path on the committed golden INPUTS (incl. the reference's own Atp2b1 test data),
+against the oracle's counter mode; plus the sampler entry points that mirror splicing_miso /
+splicing_miso_paired one event at a time."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import _golden
+import miso_amd
+from _libs import OrcLib
+from _problems import flat
+from miso_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", _golden.names())
+def test_golden_inputs_bit_exact(orc, name):
+    g = _golden.load(name)
+    paired = str(g["kind"]) == "pe"
+    G = miso_amd.Gene(g["exon_list"], g["isoform_list"])
+    og = orc.gene(flat(g["exon_list"]), g["isoform_list"])
+    kw = dict(iters=g["iters"], burn=g["burn"], lag=g["lag"], chains=g["chains"], overhang=g["overhang"])
+    if paired:
+        mean, var = float(g["mean"]), float(g["var"])
+        b = miso_amd.Batch(g["read_len"], paired=True, mean=mean, var=var, counts_trace=True, **kw)
+        cpu = orc.miso_paired(og, g["pos"], g["cigars"], g["read_len"], mean, var,
+                              mode=OrcLib.COUNTER, seed=11, event_id=77, trace=True, **kw)
+    else:
+        b = miso_amd.Batch(g["read_len"], counts_trace=True, **kw)
+        cpu = orc.miso(og, g["pos"], g["cigars"], g["read_len"], mode=OrcLib.COUNTER, seed=11,
+                       event_id=77, trace=True, **kw)
+    b.add_event(G, g["pos"], g["cigars"])
+    b.run(seed=11, first_event_id=77)
+    gpu = b.result(0, trace=True)
+    assert cpu.rc == 0
+    # set-up quantities equal the REAL reference's (golden), not just the oracle's
+    assert np.array_equal(gpu.class_templates, g["class_templates"])
+    assert np.array_equal(gpu.class_counts, g["class_counts"])
+    assert np.array_equal(gpu.counts_trace, cpu.trace["counts_trace"])
+    assert np.array_equal(gpu.counts_hash, cpu.trace["counts_hash"])
+    assert np.array_equal(gpu.samples, cpu.samples)
+    assert np.array_equal(gpu.loglik, cpu.loglik, equal_nan=True)
+    assert np.array_equal(gpu.assignment, cpu.assignment)
+    assert (gpu.rundata.noAccepted, gpu.rundata.noRejected) == (cpu.accepted, cpu.rejected)
+    # and the posterior agrees with the reference run stored in the fixture (different RNG):
+    # |delta mean psi| within 5 sigma of the two runs' Monte-Carlo error
+    filled = g["chains"] * ((g["iters"] - g["burn"]) // g["lag"])
+    a, r = gpu.samples[:filled], g["samples"][:filled]
+    ess = max(filled / 20.0, 4.0)  # conservative effective sample size
+    tol = 5 * np.sqrt((a.var(0) + r.var(0)) / ess) + 5e-3
+    assert (np.abs(a.mean(0) - r.mean(0)) < tol).all(), (a.mean(0), r.mean(0), tol)
+
+
+def test_per_event_entry_points(orc):
+    """miso_run / miso_run_paired: the splicing_miso signatures + seed, a batch of one."""
+    g = _golden.load("se_k3")
+    G = miso_amd.Gene(g["exon_list"], g["isoform_list"])
+    K, N, S = 3, len(g["pos"]), g["chains"] * (g["iters"] - g["burn"]) // g["lag"]
+    samples, ll = np.zeros(K * S), np.zeros(S)
+    ct, cc, ncls = np.zeros(K * N), np.zeros(N), C.c_int()
+    ass, rd = np.zeros(N, np.int32), capi.RunData()
+    pos = np.asarray(g["pos"], np.int32)
+    rc = capi.lib().miso_run(G.handle, capi._p(pos), capi._cigs(g["cigars"]), N, g["read_len"],
+                             g["overhang"], g["chains"], g["iters"], 100000, g["burn"], g["lag"],
+                             capi._p(np.ones(K)), K, 0, 0, 0, C.c_uint64(5), capi._p(samples),
+                             capi._p(ll), capi._p(ct), capi._p(cc), C.byref(ncls), capi._p(ass),
+                             C.byref(rd))
+    capi.check(rc)
+    og = orc.gene(flat(g["exon_list"]), g["isoform_list"])
+    cpu = orc.miso(og, g["pos"], g["cigars"], g["read_len"], iters=g["iters"], burn=g["burn"],
+                   lag=g["lag"], chains=g["chains"], overhang=g["overhang"], mode=OrcLib.COUNTER,
+                   seed=5, event_id=0)
+    assert np.array_equal(samples.reshape(S, K), cpu.samples) and np.array_equal(ll, cpu.loglik)
+    assert np.array_equal(ass, cpu.assignment) and ncls.value == len(g["class_counts"])
+    assert (rd.noIso, rd.noIters, rd.noBurnIn, rd.noLag, rd.noChains, rd.noSamples) == \
+        (K, g["iters"], g["burn"], g["lag"], g["chains"], S)
+    assert rd.noAccepted + rd.noRejected == g["chains"] * g["iters"]
+
+
+def test_error_paths_on_device(orc):
+    G = miso_amd.Gene([(1, 100), (201, 300), (401, 500)], [[0, 1, 2], [0, 2]])
+    rc = capi.lib().miso_run(G.handle, capi._p(np.array([10], np.int32)), capi._cigs([b"36Q"]), 1, 36,
+                             1, 1, 50, 100000, 10, 1, capi._p(np.ones(2)), 2, 0, 0, 0, C.c_uint64(1),
+                             None, None, None, None, None, None, None)
+    assert rc == capi.MISO_EINVAL and b"Unsupported CIGAR" in capi.lib().miso_last_error()

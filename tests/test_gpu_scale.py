@@ -1,0 +1,92 @@
+"""GPU, full BASELINE size: properties that do not need the oracle to run 40 000 events.
+
+* layout independence: the same batch sampled with different lanes-per-chain (different kernels /
+  wave mappings) gives the same checksum-of-checksums over every chain's per-iteration assignment
+  counts, and identical psi samples;
+* shard independence: events sampled as one batch or as two shards (different first_event_id,
+  the 8-GPU split) give identical results;
+* a spot check of a few events against the oracle at full iteration count;
+* sanity of the posterior against the simulated truth.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import miso_amd
+from _libs import OrcLib
+from _problems import flat
+from miso_amd import workload
+
+pytestmark = pytest.mark.gpu
+
+
+def _digest(b, n):
+    h = np.uint64(0xCBF29CE484222325)
+    means = np.zeros(n)
+    for i in range(n):
+        r = b.result(i)
+        for w in r.counts_hash:
+            h = (h ^ w) * np.uint64(0x100000001B3)
+        means[i] = r.samples[:, 0].mean()
+    return int(h), means
+
+
+def test_full_size_layout_and_shard_independence(orc):
+    E, kw = 40000, dict(n_reads=1000, iters=7500, burn=2500, lag=1, chains=1)
+    b = workload.build_batch(0, E, **kw)
+    old = os.environ.pop("MISO_LANES_PER_CHAIN", None)
+    try:
+        b.run(seed=42, first_event_id=0)
+        with np.errstate(over="ignore"):
+            ref_digest, means = _digest(b, E)
+        os.environ["MISO_LANES_PER_CHAIN"] = "8"
+        b.run(seed=42, first_event_id=0)
+        with np.errstate(over="ignore"):
+            d8, means8 = _digest(b, E)
+    finally:
+        os.environ.pop("MISO_LANES_PER_CHAIN", None)
+        if old is not None:
+            os.environ["MISO_LANES_PER_CHAIN"] = old
+    assert d8 == ref_digest and np.array_equal(means, means8)
+    # two shards == one batch (first_event_id carries the global id)
+    lo = workload.build_batch(0, 300, **kw)
+    hi = workload.build_batch(300, 300, **kw)
+    lo.run(seed=42, first_event_id=0)
+    hi.run(seed=42, first_event_id=300)
+    for i in (0, 7, 299):
+        assert np.array_equal(lo.result(i).samples, b.result(i).samples)
+        assert np.array_equal(hi.result(i).samples, b.result(300 + i).samples)
+        assert np.array_equal(hi.result(i).assignment, b.result(300 + i).assignment)
+    # spot check against the oracle at the full iteration count
+    for e in (1, 12345, 39999):
+        exons, isoforms, pos, cig = workload.event_reads(e)
+        g = orc.gene(flat(exons), isoforms)
+        cpu = orc.miso(g, pos, cig, 36, iters=7500, burn=2500, lag=1, chains=1, mode=OrcLib.COUNTER,
+                       seed=42, event_id=e, trace=True)
+        r = b.result(e)
+        assert np.array_equal(r.counts_hash, cpu.trace["counts_hash"])
+        assert np.array_equal(r.samples, cpu.samples) and np.array_equal(r.loglik, cpu.loglik)
+    # posterior means track the simulated truth (psi ~ U(0.05, 0.95), 1000 reads)
+    truth = np.array([workload.event_gene(e)[2][0] for e in range(0, E, 40)])
+    err = means[::40] - truth
+    assert abs(err.mean()) < 0.01 and np.sqrt((err ** 2).mean()) < 0.06, (err.mean(), err.std())
+
+
+def test_empty_and_degenerate_events():
+    """No reads, no compatible reads, one read, reads all of one class, 20 isoforms."""
+    G = miso_amd.Gene([(1, 100), (201, 300), (401, 500)], [[0, 1, 2], [0, 2]])
+    b = miso_amd.Batch(36, iters=200, burn=50, lag=5, chains=2, counts_trace=True)
+    b.add_event(G, [], [])
+    b.add_event(G, [1000, 2000], [b"36M", b"36M"])            # off the gene: all -1
+    b.add_event(G, [10], [b"36M"])                            # one ambiguous read
+    b.add_event(G, [210] * 9, [b"36M"] * 9)                   # inclusion-only reads, no draws
+    b.run(seed=3)
+    r0, r1, r2, r3 = (b.result(i, trace=True) for i in range(4))
+    assert r0.assignment.size == 0 and (r0.counts_trace == 0).all()
+    assert (r1.assignment == -1).all() and (r1.counts_trace == 0).all()
+    assert r2.counts_trace.sum(-1).min() == 1 == r2.counts_trace.sum(-1).max()
+    assert (r3.assignment == 0).all() and (r3.counts_trace[..., 0] == 9).all()
+    for r in (r0, r1, r2, r3):
+        assert np.isfinite(r.samples).all() and np.allclose(r.samples.sum(1), 1.0)
+    assert r3.samples[:, 0].mean() > 0.5                      # nine inclusion reads pull psi up

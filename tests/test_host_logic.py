@@ -1,0 +1,113 @@
+"""CPU: the product's host side (gene model, CIGAR matching, read classes, parameter checks,
+simulator) against the oracle and the golden vectors.  No GPU needed: this is the input builder
+of the path (solve.c:8-306) plus the boundary's error behaviour (pysplicing.c / pyerror.c)."""
+import numpy as np
+import pytest
+
+import _golden
+import miso_amd
+from miso_amd import capi, workload
+from _problems import flat
+
+
+@pytest.mark.parametrize("name", _golden.names("se"))
+def test_match_matrix_and_classes_vs_golden(name):
+    g = _golden.load(name)
+    G = miso_amd.Gene(g["exon_list"], g["isoform_list"])
+    m = G.match_iso(g["pos"], g["cigars"], g["read_len"], overhang=g["overhang"])
+    assert np.array_equal(m, g["match"])
+    b = miso_amd.Batch(g["read_len"], iters=g["iters"], burn=g["burn"], lag=g["lag"],
+                       chains=g["chains"], overhang=g["overhang"])
+    i = b.add_event(G, g["pos"], g["cigars"])
+    ct, cc = b.classes(i)
+    assert np.array_equal(ct, g["class_templates"]) and np.array_equal(cc, g["class_counts"])
+
+
+@pytest.mark.parametrize("name", _golden.names("pe"))
+def test_paired_match_and_binary_classes_vs_golden(name):
+    g = _golden.load(name)
+    G = miso_amd.Gene(g["exon_list"], g["isoform_list"])
+    m, fl = G.match_iso_paired(g["pos"], g["cigars"], g["read_len"], float(g["mean"]), float(g["var"]))
+    assert np.array_equal(m, g["match"]) and np.array_equal(fl, g["fraglen"])
+    b = miso_amd.Batch(g["read_len"], iters=g["iters"], burn=g["burn"], lag=g["lag"],
+                       chains=g["chains"], paired=True, mean=float(g["mean"]), var=float(g["var"]))
+    i = b.add_event(G, g["pos"], g["cigars"])
+    ct, cc = b.classes(i)
+    assert np.array_equal(ct, g["class_templates"]) and np.array_equal(cc, g["class_counts"])
+
+
+def test_cigar_edge_cases_vs_golden():
+    g = _golden.load("cigar_edges")
+    G = miso_amd.Gene(g["exon_list"], g["isoform_list"])
+    for ov in (1, 4):
+        assert np.array_equal(G.match_iso(g["pos"], g["cigars"], 36, overhang=ov), g["match_ov%d" % ov])
+
+
+def test_isoform_lengths(orc):
+    g = _golden.load("atp2b1")
+    G = miso_amd.Gene(g["exon_list"], g["isoform_list"])
+    og = orc.gene(flat(g["exon_list"]), g["isoform_list"])
+    assert G.noiso == 2 and (G.isolength() == orc.isolength(og)).all()
+
+
+@pytest.mark.parametrize("bad,msg", [
+    ([b"36Q"], "Unsupported CIGAR"), ([b"10M5S10M"], "Bad CIGAR string")])
+def test_bad_cigar_raises_like_the_reference(bad, msg):
+    G = miso_amd.Gene([(1, 100), (201, 300)], [[0, 1], [0]])
+    with pytest.raises(miso_amd.InternalError, match=msg):
+        G.match_iso([10], bad, 36)
+
+
+def test_parameter_errors():
+    # miso.c:674-717; what the GPU build does not implement raises NotImplementedError
+    with pytest.raises(miso_amd.InternalError, match="Overhang length invalid"):
+        miso_amd.Batch(36, overhang=18)
+    with pytest.raises(miso_amd.InternalError, match="at least one"):
+        miso_amd.Batch(36, chains=0)
+    with pytest.raises(miso_amd.InternalError, match="one chain only"):
+        miso_amd.Batch(36, chains=1, stop=capi.MISO_STOP_CONVERGENT_MEAN)
+    with pytest.raises(NotImplementedError):
+        miso_amd.Batch(36, chains=2, stop=capi.MISO_STOP_CONVERGENT_MEAN)
+    with pytest.raises(NotImplementedError):
+        miso_amd.Batch(36, algo=capi.MISO_ALGO_CLASSES)
+    with pytest.raises(miso_amd.InternalError, match="start_psi"):
+        miso_amd.Batch(36, start=capi.MISO_START_GIVEN)
+    G = miso_amd.Gene([(1, 100), (201, 300), (401, 500)], [[0, 1, 2], [0, 2]])
+    b = miso_amd.Batch(36)
+    with pytest.raises(miso_amd.InternalError, match="hyperparameter"):
+        b.add_event(G, [10], [b"36M"], hyper=[1.0, 1.0, 1.0])
+    with pytest.raises(miso_amd.InternalError):
+        miso_amd.Gene([(1, 100)], [[0, 3]])
+
+
+def test_product_simulator_is_deterministic_and_valid(orc):
+    """miso_simulate_reads: reads of isoform k are compatible with isoform k (checked with the
+    ORACLE's matcher), same seed -> same reads, batch ingestion == explicit ingestion."""
+    for K, paired in ((2, False), (5, False), (2, True), (3, True)):
+        kw = dict(min_len=400, max_len=800, gap=300) if paired else {}
+        exons, isoforms, expr = workload.event_gene(17, K, **kw)
+        G = miso_amd.Gene(exons, isoforms)
+        mean, var = (250.0, 900.0) if paired else (0.0, 0.0)
+        iso, pos, cig = capi.simulate_reads(G, expr, 200, 36, 99, mean, var)
+        iso2, pos2, cig2 = capi.simulate_reads(G, expr, 200, 36, 99, mean, var)
+        assert (pos == pos2).all() and cig == cig2
+        og = orc.gene(flat(exons), isoforms)
+        rc, m = orc.match_iso(og, pos, cig, 36)
+        assert rc == 0 and (m[np.arange(len(pos)), iso] == 1).all()
+        if paired:
+            rc, mp, fl = orc.match_iso_paired(og, pos, cig, 36, mean, var)
+            assert rc == 0 and (fl[np.arange(200), iso[::2]] >= 0).mean() > 0.99
+        b1 = miso_amd.Batch(36, paired=paired, mean=mean, var=var)
+        b2 = miso_amd.Batch(36, paired=paired, mean=mean, var=var)
+        b1.add_simulated(G, expr, 200, 99)
+        b2.add_event(G, pos, cig)
+        assert all(np.array_equal(x, y) for x, y in zip(b1.classes(0), b2.classes(0)))
+
+
+def test_workload_is_a_function_of_the_global_event_id():
+    a = workload.build_batch(5, 3, n_reads=50, iters=10, burn=2)
+    b = workload.build_batch(6, 1, n_reads=50, iters=10, burn=2)
+    assert all(np.array_equal(x, y) for x, y in zip(a.classes(1), b.classes(0)))
+    assert workload.shard_bounds(10, 4, 0) == (0, 3) and workload.shard_bounds(10, 4, 3) == (8, 10)
+    cover = [i for r in range(7) for i in range(*workload.shard_bounds(40, 7, r))]
+    assert cover == list(range(40))

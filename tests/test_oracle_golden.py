@@ -1,0 +1,88 @@
+"""CPU: the oracle (oracle/miso_oracle.c, stream mode) replays the golden vectors -- outputs of
+the REAL reference C core for fixed inputs and MT19937 seeds -- and must reproduce every bit:
+match matrix, read classes, psi samples, log scores, final assignment, accept counts."""
+import numpy as np
+import pytest
+
+import _golden
+from _problems import flat
+
+
+def _replay(orc, g):
+    gene = orc.gene(flat(g["exon_list"]), g["isoform_list"])
+    orc.rng_seed(g["seed"])
+    return gene
+
+
+@pytest.mark.parametrize("name", _golden.names("se"))
+def test_single_end_golden(orc, name):
+    g = _golden.load(name)
+    gene = _replay(orc, g)
+    if "expr" in g:  # the reads themselves came from the reference simulator on the same stream
+        rc, iso, pos, cig = orc.simulate_reads(gene, g["expr"], len(g["pos"]), g["read_len"])
+        assert rc == 0 and (pos == g["pos"]).all() and cig == g["cigars"]
+        assert (iso == g["sim_isoform"]).all()
+    r = orc.miso(gene, g["pos"], g["cigars"], g["read_len"], iters=g["iters"], burn=g["burn"],
+                 lag=g["lag"], chains=g["chains"], overhang=g["overhang"])
+    assert r.rc == 0
+    assert np.array_equal(r.match, g["match"])
+    assert np.array_equal(r.class_templates, g["class_templates"])
+    assert np.array_equal(r.class_counts, g["class_counts"])
+    assert np.array_equal(r.rundata, g["rundata"])
+    # columns past C*floor((M-B)/lag) are never written by the reference (C8: uninitialised there)
+    filled = g["chains"] * ((g["iters"] - g["burn"]) // g["lag"])
+    assert np.array_equal(r.samples[:filled], g["samples"][:filled])
+    assert np.array_equal(r.loglik[:filled], g["loglik"][:filled])
+    assert np.array_equal(r.assignment, g["assignment"])
+
+
+@pytest.mark.parametrize("name", _golden.names("pe"))
+def test_paired_end_golden(orc, name):
+    g = _golden.load(name)
+    gene = _replay(orc, g)
+    mean, var = float(g["mean"]), float(g["var"])
+    rc, iso, pos, cig = orc.simulate_paired_reads(gene, g["expr"], len(g["pos"]) // 2,
+                                                  g["read_len"], mean, var)
+    assert rc == 0 and (pos == g["pos"]).all() and cig == g["cigars"]
+    rc, m, fl = orc.match_iso_paired(gene, g["pos"], g["cigars"], g["read_len"], mean, var)
+    assert rc == 0 and np.array_equal(m, g["match"]) and np.array_equal(fl, g["fraglen"])
+    r = orc.miso_paired(gene, g["pos"], g["cigars"], g["read_len"], mean, var, iters=g["iters"],
+                        burn=g["burn"], lag=g["lag"], chains=g["chains"])
+    assert r.rc == 0
+    assert np.array_equal(r.match, g["match"])
+    assert np.array_equal(r.class_templates, g["class_templates"])
+    assert np.array_equal(r.class_counts, g["class_counts"])
+    assert np.array_equal(r.rundata, g["rundata"])
+    assert np.array_equal(r.samples, g["samples"])
+    assert np.array_equal(r.loglik, g["loglik"])
+    assert np.array_equal(r.assignment, g["assignment"])
+
+
+def test_rng_stream_golden(orc):
+    """MT19937 + inversion normal (random.c:301-448, 1543-1551): first draws after seeding."""
+    g = _golden.load("se_k2")
+    orc.rng_seed(g["seed"])
+    got = np.array([orc.unif01() for _ in range(8)] + [orc.normal01() for _ in range(8)])
+    assert np.array_equal(got, g["rng_stream"])
+
+
+def test_cigar_edges_golden(orc):
+    g = _golden.load("cigar_edges")
+    gene = orc.gene(flat(g["exon_list"]), g["isoform_list"])
+    for ov in (1, 4):
+        rc, m = orc.match_iso(gene, g["pos"], g["cigars"], g["read_len"], overhang=ov)
+        assert rc == 0 and np.array_equal(m, g["match_ov%d" % ov]), ov
+
+
+def test_lag_remainder_leaves_zero_columns(orc):
+    """C8: noSamples = C*(M-B)/lag in int arithmetic, trailing sample columns stay zero."""
+    g = _golden.load("se_k2_lagrem")
+    S = g["chains"] * (g["iters"] - g["burn"]) // g["lag"]
+    assert g["samples"].shape[0] == S == int(g["rundata"][8])
+    filled = g["chains"] * ((g["iters"] - g["burn"]) // g["lag"])
+    gene = orc.gene(flat(g["exon_list"]), g["isoform_list"])
+    orc.rng_seed(g["seed"])
+    orc.simulate_reads(gene, g["expr"], len(g["pos"]), g["read_len"])
+    r = orc.miso(gene, g["pos"], g["cigars"], g["read_len"], iters=g["iters"], burn=g["burn"],
+                 lag=g["lag"], chains=g["chains"])
+    assert filled < S and (r.samples[filled:] == 0).all() and (r.samples[:filled] != 0).all()

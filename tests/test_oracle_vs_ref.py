@@ -1,0 +1,85 @@
+"""CPU (authoring container, or wherever oracle/_ref/libmiso_ref.so travelled): the oracle against
+the LIVE reference on more shapes than the committed fixtures hold. Skipped without the library."""
+import os
+
+import numpy as np
+import pytest
+
+from _problems import expr_for, flat, se_gene
+
+
+@pytest.fixture(autouse=True)
+def _quiet_stdout():
+    """the reference prints 'no chains: %d' per call (miso.c:837)"""
+    yield
+
+
+def _same(rR, rO, chains, iters, burn, lag):
+    # columns past C*floor((M-B)/lag) are never written by the reference (quirk C8)
+    filled = chains * ((iters - burn) // lag)
+    for f in ("match", "class_templates", "class_counts", "rundata", "assignment"):
+        assert np.array_equal(getattr(rR, f), getattr(rO, f)), f
+    assert np.array_equal(rR.samples[:filled], rO.samples[:filled])
+    assert np.array_equal(rR.loglik[:filled], rO.loglik[:filled])
+
+
+def _pair(ref, orc, exons, isoforms):
+    return ref.gene(flat(exons), isoforms), orc.gene(flat(exons), isoforms)
+
+
+def test_stream_generators_identical(ref, orc):
+    for seed in (0, 1, 42, 2**31 + 5):
+        ref.rng_seed(seed)
+        orc.rng_seed(seed)
+        assert [ref.unif01() for _ in range(700)] == [orc.unif01() for _ in range(700)]
+        assert [ref.normal01() for _ in range(3000)] == [orc.normal01() for _ in range(3000)]
+        assert [ref.integer(1, 977) for _ in range(50)] == [orc.integer(1, 977) for _ in range(50)]
+
+
+@pytest.mark.parametrize("K,N,ov,chains,iters,burn,lag", [
+    (2, 1000, 1, 1, 1500, 500, 1), (2, 200, 3, 6, 500, 50, 10), (3, 500, 4, 3, 600, 100, 5),
+    (4, 64, 1, 2, 300, 30, 3), (7, 400, 2, 2, 300, 50, 4), (12, 600, 1, 1, 200, 40, 2)])
+def test_single_end_bit_exact(ref, orc, K, N, ov, chains, iters, burn, lag):
+    exons, isoforms = se_gene(K)
+    gR, gO = _pair(ref, orc, exons, isoforms)
+    ref.rng_seed(100 + K)
+    orc.rng_seed(100 + K)
+    a = ref.simulate_reads(gR, expr_for(K), N, 36)
+    b = orc.simulate_reads(gO, expr_for(K), N, 36)
+    assert a[0] == b[0] == 0 and (a[2] == b[2]).all() and a[3] == b[3]
+    rR = ref.miso(gR, a[2], a[3], 36, iters=iters, burn=burn, lag=lag, chains=chains, overhang=ov)
+    rO = orc.miso(gO, b[2], b[3], 36, iters=iters, burn=burn, lag=lag, chains=chains, overhang=ov)
+    assert rR.rc == rO.rc == 0
+    _same(rR, rO, chains, iters, burn, lag)
+
+
+@pytest.mark.parametrize("K,N,chains,iters,burn,lag,mean,var", [
+    (2, 500, 1, 600, 100, 1, 250.0, 900.0), (2, 200, 6, 300, 50, 10, 200.0, 400.0),
+    (3, 300, 2, 300, 50, 3, 250.0, 900.0), (6, 250, 2, 200, 40, 2, 300.0, 1600.0)])
+def test_paired_end_bit_exact(ref, orc, K, N, chains, iters, burn, lag, mean, var):
+    exons, isoforms = se_gene(K, exlen=500, gap=300)
+    gR, gO = _pair(ref, orc, exons, isoforms)
+    ref.rng_seed(200 + K)
+    orc.rng_seed(200 + K)
+    a = ref.simulate_paired_reads(gR, expr_for(K), N, 36, mean, var)
+    b = orc.simulate_paired_reads(gO, expr_for(K), N, 36, mean, var)
+    assert a[0] == b[0] == 0 and (a[2] == b[2]).all() and a[3] == b[3]
+    mR = ref.match_iso_paired(gR, a[2], a[3], 36, mean, var)
+    mO = orc.match_iso_paired(gO, b[2], b[3], 36, mean, var)
+    assert np.array_equal(mR[1], mO[1]) and np.array_equal(mR[2], mO[2])
+    rR = ref.miso_paired(gR, a[2], a[3], 36, mean, var, iters=iters, burn=burn, lag=lag, chains=chains)
+    rO = orc.miso_paired(gO, b[2], b[3], 36, mean, var, iters=iters, burn=burn, lag=lag, chains=chains)
+    assert rR.rc == rO.rc == 0
+    _same(rR, rO, chains, iters, burn, lag)
+
+
+def test_error_codes_match(ref, orc):
+    exons, isoforms = se_gene(2)
+    gR, gO = _pair(ref, orc, exons, isoforms)
+    pos, cig = np.array([10, 20], np.int32), [b"36M", b"36M"]
+    # overhang >= readLength/2, zero chains, wrong hyper length, bad CIGAR (miso.c:690-706, solve.c:245,296)
+    for kw in (dict(overhang=18), dict(chains=0), dict(hyper=[1.0, 1.0, 1.0])):
+        assert ref.miso(gR, pos, cig, 36, iters=10, burn=2, lag=1, **{"chains": 1, **kw}).rc == \
+            orc.miso(gO, pos, cig, 36, iters=10, burn=2, lag=1, **{"chains": 1, **kw}).rc == 4
+    for bad in ([b"36Q"], [b"10M5S10M"]):
+        assert ref.match_iso(gR, pos[:1], bad, 36)[0] == orc.match_iso(gO, pos[:1], bad, 36)[0] == 4
