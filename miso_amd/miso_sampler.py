@@ -1,0 +1,257 @@
+"""Host-side mirror of misopy/miso_sampler.py (the caller of the hot path), Python 3.
+
+Same class, method names, argument meaning, skip rules and `.miso` text format as the reference
+(`MISOSampler.run_sampler`, `output_miso_results`: miso_sampler.py:169-466; `py2c_gene`:
+py2c_gene.py:4-23; `count_isoform_assignments`: reads_utils.py:37-46), calling the MI355X
+`pysplicing` module instead of the CPython-2 one.  `run_sampler_batch` is the addition: many
+events per GPU launch (one `.miso` file each), which is what a GPU needs.
+
+The gene object only has to look like misopy.Gene.Gene as far as this module reads it:
+`label`, `chrom`, `strand`, `parts` (objects with `start`, `end`, `label`, `len`) and `isoforms`
+(objects with `parts`, `desc`, `genomic_start`, `genomic_end`).  `SimpleGene` provides exactly that.
+"""
+import os
+import random
+import sys
+import time
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+if _HERE not in sys.path:
+    sys.path.insert(0, _HERE)
+import pysplicing  # noqa: E402  (miso_amd/pysplicing)
+
+
+# ---------------------------------------------------------------------------------------------
+# a minimal gene model (stand-in for misopy/Gene.py:114-1131, which is not on the path)
+# ---------------------------------------------------------------------------------------------
+class Part:
+    def __init__(self, start, end, label=None):
+        self.start, self.end = int(start), int(end)
+        self.len = self.end - self.start + 1
+        self.label = label or "%d-%d" % (self.start, self.end)
+
+    def __eq__(self, other):
+        return (self.start, self.end) == (other.start, other.end)
+
+    def __hash__(self):
+        return hash((self.start, self.end))
+
+
+class Isoform:
+    def __init__(self, parts, label=None):
+        self.parts = list(parts)
+        self.desc = [p.label for p in self.parts]
+        self.label = label
+        self.genomic_start = min(p.start for p in self.parts)
+        self.genomic_end = max(p.end for p in self.parts)
+
+
+class SimpleGene:
+    """exons: (start, end) 1-based inclusive; isoforms: lists of exon indices (Gene.py:1042
+    se_event_to_gene builds [[0,1,2],[0,2]] for a skipped exon)."""
+
+    def __init__(self, exons, isoforms, label="gene", chrom=None, strand=None):
+        self.parts = [Part(s, e, "%s.%d" % (label, i)) for i, (s, e) in enumerate(exons)]
+        self.isoforms = [Isoform([self.parts[i] for i in iso]) for iso in isoforms]
+        self.label, self.chrom, self.strand = label, chrom, strand
+
+
+def py2c_gene(py_gene):
+    """py2c_gene.py:4-23: exon tuple = (part.start, part.end), isoform tuple = indices into parts."""
+    exon_lens = tuple((part.start, part.end) for part in py_gene.parts)
+    isoforms_desc = tuple(tuple(py_gene.parts.index(p) for p in iso.parts)
+                          for iso in py_gene.isoforms)
+    return pysplicing.createGene(exon_lens, isoforms_desc)
+
+
+def count_isoform_assignments(assignments):
+    """reads_utils.py:37-46."""
+    assignments = np.asarray(assignments)
+    num_isoforms = int(assignments.max())
+    return [(k, int((assignments == k).sum())) for k in range(num_isoforms + 1)]
+
+
+def get_single_end_sampler_params(num_isoforms, read_len, overhang_len=1):
+    """miso_sampler.py:146-166 (sigma_proposal is informational: the C core fixes it, miso.c:328)."""
+    return {"read_len": read_len, "overhang_len": overhang_len, "uniform_proposal": False,
+            "sigma_proposal": 0.05 * np.eye(max(num_isoforms - 1, 1))}
+
+
+def get_paired_end_sampler_params(num_isoforms, mean_frag_len, frag_variance, read_len,
+                                  overhang_len=1):
+    """miso_sampler.py:120-143."""
+    p = get_single_end_sampler_params(num_isoforms, read_len, overhang_len)
+    p.update(mean_frag_len=mean_frag_len, frag_variance=frag_variance)
+    return p
+
+
+class MISOSampler:
+    def __init__(self, params, paired_end=False, log_dir=None):
+        self.params = params
+        self.paired_end = paired_end
+        if self.paired_end:
+            if "mean_frag_len" not in params or "frag_variance" not in params:
+                raise Exception("Must set mean_frag_len and frag_variance when running in sampler "
+                                "on paired-end data.")
+            self.mean_frag_len = params["mean_frag_len"]
+            self.frag_variance = params["frag_variance"]
+        self.log_dir = log_dir
+
+    # -- one event per call: miso_sampler.py:199-373 ------------------------------------------
+    def run_sampler(self, num_iters, reads, gene, hyperparameters, params, output_file,
+                    num_chains=6, burn_in=1000, lag=2, prior_params=None,
+                    algorithm=pysplicing.MISO_ALGO_CLASSES,
+                    start_cond=pysplicing.MISO_START_AUTO, stop_cond=pysplicing.MISO_STOP_FIXEDNO,
+                    verbose=True, seed=None):
+        prepared = self._prepare(reads, gene, output_file, prior_params, verbose)
+        if prepared is None:
+            return None
+        c_gene, read_positions, read_cigars, prior_params, output_file = prepared
+        self.params.update(iters=num_iters, burn_in=burn_in, lag=lag)
+        t1 = time.time()
+        kw = {} if seed is None else {"seed": seed}
+        if self.paired_end:
+            res = pysplicing.MISOPaired(c_gene, 0, read_positions, read_cigars,
+                                        int(self.params["read_len"]), float(self.mean_frag_len),
+                                        float(self.frag_variance), 4.0,  # num_sds: miso_sampler.py:289
+                                        int(num_iters), int(burn_in), int(lag), prior_params,
+                                        int(self.params["overhang_len"]), int(num_chains),
+                                        start_cond, stop_cond, **kw)
+        else:
+            # the reference forces REASSIGN whatever `algorithm` says (miso_sampler.py:322-323)
+            res = pysplicing.MISO(c_gene, 0, read_positions, read_cigars,
+                                  int(self.params["read_len"]), int(num_iters), int(burn_in),
+                                  int(lag), prior_params, int(self.params["overhang_len"]),
+                                  int(num_chains), start_cond, stop_cond,
+                                  pysplicing.MISO_ALGO_REASSIGN, **kw)
+        done = self._finish(res, gene, output_file, num_iters, burn_in, lag, verbose)
+        if verbose and done:
+            print("Event took %.2f seconds" % (time.time() - t1))
+        return done
+
+    # -- many events per launch (no reference counterpart) ------------------------------------
+    def run_sampler_batch(self, num_iters, events, num_chains=6, burn_in=1000, lag=2,
+                          start_cond=pysplicing.MISO_START_AUTO,
+                          stop_cond=pysplicing.MISO_STOP_FIXEDNO, seed=None, first_event_id=0,
+                          verbose=False):
+        """events: list of (reads, gene, output_file[, prior_params]); same per-event skip rules as
+        run_sampler.  Returns the list of written file names (None for skipped events)."""
+        todo, slots = [], []
+        for i, ev in enumerate(events):
+            reads, gene, output_file = ev[:3]
+            prep = self._prepare(reads, gene, output_file, ev[3] if len(ev) > 3 else None, verbose)
+            if prep is not None:
+                todo.append((prep[0], prep[1], prep[2], prep[3]))
+                slots.append((i, gene, prep[4]))
+        written = [None] * len(events)
+        if not todo:
+            return written
+        self.params.update(iters=num_iters, burn_in=burn_in, lag=lag)
+        kw = dict(seed=seed if seed is not None else random.getrandbits(64),
+                  first_event_id=first_event_id)
+        if self.paired_end:
+            results = pysplicing.MISOPairedBatch(tuple(todo), int(self.params["read_len"]),
+                                                 float(self.mean_frag_len), float(self.frag_variance),
+                                                 4.0, int(num_iters), int(burn_in), int(lag),
+                                                 int(self.params["overhang_len"]), int(num_chains),
+                                                 start_cond, stop_cond, **kw)
+        else:
+            results = pysplicing.MISOBatch(tuple(todo), int(self.params["read_len"]), int(num_iters),
+                                           int(burn_in), int(lag), int(self.params["overhang_len"]),
+                                           int(num_chains), start_cond, stop_cond,
+                                           pysplicing.MISO_ALGO_REASSIGN, **kw)
+        for (i, gene, out), res in zip(slots, results):
+            written[i] = self._finish(res, gene, out, num_iters, burn_in, lag, verbose)
+        return written
+
+    # -- shared pieces -------------------------------------------------------------------------
+    def _prepare(self, reads, gene, output_file, prior_params, verbose):
+        num_isoforms = len(gene.isoforms)
+        self.num_isoforms = num_isoforms
+        if prior_params is None:
+            prior_params = (1.0,) * num_isoforms
+        read_positions, read_cigars = reads[0], reads[1]
+        self.num_reads = len(read_positions)
+        if self.num_reads == 0:                                    # miso_sampler.py:229-231
+            if verbose:
+                print("No reads for gene: %s" % gene.label)
+            return None
+        output_file = output_file + ".miso"
+        if os.path.isfile(os.path.normpath(output_file)):          # miso_sampler.py:233-238
+            if verbose:
+                print("Output filename %s exists, not running MISO." % output_file)
+            return None
+        if num_isoforms == 1:                                      # miso_sampler.py:270-275
+            if verbose:
+                print("Gene %s has only one isoform; skipping..." % gene.label)
+            return None
+        c_gene = py2c_gene(gene)
+        read_positions = tuple(int(r) + 1 for r in read_positions)  # 0-based -> 1-based (:284)
+        read_cigars = tuple(c.decode() if isinstance(c, bytes) else c for c in read_cigars)
+        return c_gene, read_positions, read_cigars, tuple(float(x) for x in prior_params), output_file
+
+    def _finish(self, miso_results, gene, output_file, num_iters, burn_in, lag, verbose):
+        psi_vectors = np.transpose(np.array(miso_results[0]))
+        kept_log_scores = np.transpose(np.array(miso_results[1]))
+        reads_data = (miso_results[2], miso_results[3])
+        assignments = np.array(miso_results[4])
+        run_stats = miso_results[5]
+        if np.all(assignments == -1):                              # miso_sampler.py:352-354
+            if verbose:
+                print("All reads incompatible with annotation, skipping...")
+            return None
+        accepted, rejected = run_stats[4], run_stats[5]
+        percent_acceptance = float(accepted) / (accepted + rejected) * 100
+        self.output_miso_results(output_file, gene, reads_data, assignments, psi_vectors,
+                                 kept_log_scores, num_iters, burn_in, lag, percent_acceptance, "drift")
+        return output_file
+
+    def output_miso_results(self, output_file, gene, reads_data, assignments, psi_vectors,
+                            kept_log_scores, num_iters, burn_in, lag, percent_acceptance,
+                            proposal_type):
+        """miso_sampler.py:376-466, byte for byte the same layout."""
+        os.makedirs(os.path.dirname(os.path.abspath(output_file)), exist_ok=True)
+        iso_delim = "_"
+        if isinstance(gene.isoforms[0].desc, list):
+            str_isoforms = "[" + ",".join("'" + iso_delim.join(iso.desc) + "'" for iso in gene.isoforms) + "]"
+        else:
+            str_isoforms = "[" + ",".join("'" + iso.desc + "'" for iso in gene.isoforms) + "]"
+        exon_lens = ",".join("('%s',%d)" % (p.label, p.len) for p in gene.parts)
+        read_classes, read_class_counts = reads_data
+        read_counts_list = []
+        for class_num, class_type in enumerate(read_classes):
+            class_str = str(tuple(int(c) for c in class_type)).replace(" ", "")
+            read_counts_list.append("%s:%s" % (class_str, "%s" % int(read_class_counts[class_num])))
+        read_counts_str = ",".join(read_counts_list)
+        assigned_counts_str = ",".join("%d:%d" % (c[0], c[1]) for c in count_isoform_assignments(assignments))
+        mRNA_start_coords = ",".join(str(iso.genomic_start) for iso in gene.isoforms)
+        mRNA_end_coords = ",".join(str(iso.genomic_end) for iso in gene.isoforms)
+        chrom = gene.chrom if gene.chrom is not None else "NA"
+        strand = gene.strand if gene.strand is not None else "NA"
+        header = "#isoforms=%s\texon_lens=%s\titers=%d\tburn_in=%d\tlag=%d\t" \
+                 "percent_accept=%.2f\tproposal_type=%s\t" \
+                 "counts=%s\tassigned_counts=%s\tchrom=%s\tstrand=%s\tmRNA_starts=%s\tmRNA_ends=%s\n" \
+                 % (str_isoforms, exon_lens, num_iters, burn_in, lag, percent_acceptance, proposal_type,
+                    read_counts_str, assigned_counts_str, chrom, strand, mRNA_start_coords,
+                    mRNA_end_coords)
+        with open(output_file, "w") as output:
+            output.write(header)
+            output.write("%s\n" % "\t".join(["sampled_psi", "log_score"]))
+            for psi_sample, curr_log_score in zip(psi_vectors, kept_log_scores):
+                psi_sample_str = ",".join("%.4f" % psi for psi in psi_sample)
+                output.write("%s\t%.2f\n" % (psi_sample_str, curr_log_score))
+
+
+def load_samples(miso_file):
+    """samples_utils.py:130-180 (the reader summarize_miso uses): (samples [S, K], header dict,
+    log scores)."""
+    with open(miso_file) as f:
+        header = f.readline().rstrip("\n")
+        f.readline()
+        rows = [ln.rstrip("\n").split("\t") for ln in f if ln.strip()]
+    fields = dict(kv.split("=", 1) for kv in header[1:].split("\t"))
+    samples = np.array([[float(x) for x in r[0].split(",")] for r in rows])
+    scores = np.array([float(r[1]) for r in rows])
+    return samples, fields, scores
