@@ -45,6 +45,18 @@ def _cpu_worker(args):
     return time.perf_counter() - t0
 
 
+def usable_cores():
+    """Host cores this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(a):
     """Reference C sampler on the host cores: P processes (the reference's own parallelism is
     processes, misopy/miso.py:165-187), a bounded sample of the bench's own events."""
@@ -52,7 +64,7 @@ def cpu_baseline(a):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from _libs import RefLib
     kind = "reference" if RefLib.available() else "port"
-    cores = len(os.sched_getaffinity(0))
+    cores = usable_cores()
     per_proc = a.cpu_events
     jobs = [(kind, list(range(p * per_proc, (p + 1) * per_proc)), a.K, a.reads, a.read_len,
              a.iters, a.burn, a.lag, a.chains) for p in range(cores)]
@@ -85,7 +97,7 @@ def main():
     ap.add_argument("--chains", type=int, default=1)
     ap.add_argument("--paired", action="store_true")
     ap.add_argument("--seed", type=int, default=42)
-    ap.add_argument("--cpu-events", type=int, default=8, help="reference events per host process")
+    ap.add_argument("--cpu-events", type=int, default=12, help="reference events per host process")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
