@@ -32,6 +32,7 @@ struct miso_batch {
   double *d_fp = nullptr;
   int32_t *d_slots = nullptr;     // [k2 events sorted by n_draw desc | all other events]
   int n_k2 = 0, n_gen = 0;
+  int gen_kmax = 2, gen_maxq = 1;  // over the general-kernel events
   int lanes_per_chain = 0;        // G of the last sampler_k2 launch (0 = none)
   int wave_slots = 2048;          // resident sampler_k2 wavefronts on the device
   std::vector<miso::DevEvent> h_events;

@@ -17,6 +17,8 @@ namespace miso {
 
 template <bool PE> __global__ void sampler_wave(const KernelArgs a);
 template <int G> __global__ void sampler_k2(const KernelArgs a);
+template <int G, bool PE> __global__ void sampler_grp(const KernelArgs a);
+static inline int grp_slice_bytes(int ks) { return 10 * ks * 8 + 2 * ks * 4; }
 __global__ void selftest_detmath_kernel(const double *, int, double *, double *, double *, double *);
 __global__ void selftest_philox_kernel(const uint32_t *, int, uint32_t *);
 
@@ -138,6 +140,14 @@ void miso_batch::upload(int dev) {
   for (int i = 0; i < n; i++) ((!p.paired && events[i].K == 2) ? k2 : gen).push_back(i);
   std::stable_sort(k2.begin(), k2.end(),
                    [&](int x, int y) { return events[x].n_draw > events[y].n_draw; });
+  // the general kernel's wavefronts loop to their largest K and longest draw list: group alike
+  std::stable_sort(gen.begin(), gen.end(), [&](int x, int y) {
+    return events[x].K != events[y].K ? events[x].K > events[y].K : events[x].n_draw > events[y].n_draw; });
+  gen_kmax = 2; gen_maxq = 1;
+  for (int i : gen) {
+    gen_kmax = std::max(gen_kmax, events[i].K);
+    gen_maxq = std::max(gen_maxq, (events[i].n_draw + 3) / 4);
+  }
   n_k2 = static_cast<int>(k2.size()); n_gen = static_cast<int>(gen.size());
   k2.insert(k2.end(), gen.begin(), gen.end());
   HIP_OK(hipMalloc(reinterpret_cast<void **>(&d_slots), std::max<size_t>(n, 1) * sizeof(int32_t)));
@@ -184,11 +194,45 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   }
   if (n_gen > 0) {
     a.slot_event = d_slots + n_k2; a.n_slots = n_gen;
-    const long slots = static_cast<long>(n_gen) * p.noChains;
-    const unsigned grid = static_cast<unsigned>((slots + 3) / 4);
-    const size_t lds = (p.paired ? align_up(fd.prob.size() * 8, 16) : 0) + 4 * 32 * sizeof(int);
-    if (p.paired) hipLaunchKernelGGL(sampler_wave<true>, dim3(grid), dim3(256), lds, stream, a);
-    else hipLaunchKernelGGL(sampler_wave<false>, dim3(grid), dim3(256), lds, stream, a);
+    const long chains = static_cast<long>(n_gen) * p.noChains;
+    const size_t fp_bytes = p.paired ? align_up(fd.prob.size() * 8, 16) : 0;
+    // lanes per chain: as for sampler_k2, bounded by the LDS a workgroup's chains need
+    int G = 64;
+    const char *env = std::getenv("MISO_GENERAL_LANES");
+    if (env) {
+      G = std::atoi(env);
+    } else {
+      // largest lane group whose wavefronts fill the resident slots once (see
+      // choose_lanes_per_chain); smaller groups only when the batch overflows the device anyway
+      for (int g : {32, 16, 8, 4, 2}) {
+        const int cpw = 64 / g;
+        const size_t lds = fp_bytes + 4 * static_cast<size_t>(cpw) * grp_slice_bytes(gen_kmax);
+        if (g > std::max(2, gen_maxq) || lds > 64 * 1024) continue;
+        G = g;
+        if ((chains + cpw - 1) / cpw <= wave_slots) break;
+      }
+    }
+    a.kstride = gen_kmax;
+    if (G == 64) {
+      const unsigned grid = static_cast<unsigned>((chains + 3) / 4);
+      const size_t lds = fp_bytes + 4 * 32 * sizeof(int);
+      if (p.paired) hipLaunchKernelGGL(sampler_wave<true>, dim3(grid), dim3(256), lds, stream, a);
+      else hipLaunchKernelGGL(sampler_wave<false>, dim3(grid), dim3(256), lds, stream, a);
+    } else {
+      const int cpw = 64 / G;
+      const unsigned grid = static_cast<unsigned>(((chains + cpw - 1) / cpw + 3) / 4);
+      const size_t lds = fp_bytes + 4 * static_cast<size_t>(cpw) * grp_slice_bytes(gen_kmax);
+#define MISO_GRP_LAUNCH(GG)                                                                          \
+  case GG:                                                                                           \
+    if (p.paired) hipLaunchKernelGGL((sampler_grp<GG, true>), dim3(grid), dim3(256), lds, stream, a); \
+    else hipLaunchKernelGGL((sampler_grp<GG, false>), dim3(grid), dim3(256), lds, stream, a);         \
+    break;
+      switch (G) {
+        MISO_GRP_LAUNCH(2) MISO_GRP_LAUNCH(4) MISO_GRP_LAUNCH(8) MISO_GRP_LAUNCH(16) MISO_GRP_LAUNCH(32)
+      default: MISO_FAIL(MISO_EINVAL, "MISO_GENERAL_LANES must be 2, 4, 8, 16, 32 or 64");
+      }
+#undef MISO_GRP_LAUNCH
+    }
     HIP_OK(hipGetLastError());
   }
   HIP_OK(hipEventRecord(ev1, stream));

@@ -79,3 +79,54 @@ def test_many_events_one_launch(orc):
         assert (gpu.samples == cpu.samples).all(), i
         assert np.array_equal(gpu.loglik, cpu.loglik, equal_nan=True), i
         assert (gpu.assignment == cpu.assignment).all(), i
+
+
+@pytest.mark.parametrize("paired", [False, True])
+def test_general_kernel_variants_agree(orc, paired):
+    """sampler_grp with 2..32 lanes per chain and sampler_wave (64) are the same function."""
+    import os
+    specs = [(3, 300), (5, 257), (8, 400), (3, 5), (12, 350), (4, 0), (6, 64)]
+    kw = dict(iters=150, burn=30, lag=2, chains=3)
+    b = miso_amd.Batch(36, paired=paired, mean=250.0 if paired else 0.0, var=900.0 if paired else 0.0,
+                       counts_trace=True, **kw)
+    keep = []
+    for i, (K, N) in enumerate(specs):
+        if paired:
+            exons, isoforms, g, pos, cig = simulate_pe(orc, K, max(N, 1), seed=400 + i)
+            pos, cig = pos[:2 * N], cig[:2 * N]
+        else:
+            exons, isoforms, g, pos, cig = simulate_se(orc, K, max(N, 1), seed=400 + i)
+            pos, cig = pos[:N], cig[:N]
+        b.add_event(miso_amd.Gene(exons, isoforms), pos, cig)
+        keep.append((g, pos, cig))
+    old = os.environ.pop("MISO_GENERAL_LANES", None)
+    try:
+        ref = None
+        for lanes in ("64", "2", "4", "8", "16", "32", None):
+            if lanes is None:
+                os.environ.pop("MISO_GENERAL_LANES", None)
+            else:
+                os.environ["MISO_GENERAL_LANES"] = lanes
+            b.run(seed=21, first_event_id=3)
+            got = [b.result(i, trace=True) for i in range(len(specs))]
+            if ref is None:
+                ref = got
+                continue
+            for x, y in zip(ref, got):
+                assert np.array_equal(x.counts_trace, y.counts_trace), lanes
+                assert np.array_equal(x.samples, y.samples), lanes
+                assert np.array_equal(x.loglik, y.loglik, equal_nan=True), lanes
+                assert np.array_equal(x.assignment, y.assignment), lanes
+                assert x.rundata.noAccepted == y.rundata.noAccepted, lanes
+    finally:
+        os.environ.pop("MISO_GENERAL_LANES", None)
+        if old is not None:
+            os.environ["MISO_GENERAL_LANES"] = old
+    for i, (g, pos, cig) in enumerate(keep):   # and the wave kernel's answer is the oracle's
+        if paired:
+            cpu = orc.miso_paired(g, pos, cig, 36, 250.0, 900.0, mode=OrcLib.COUNTER, seed=21,
+                                  event_id=3 + i, trace=True, **kw)
+        else:
+            cpu = orc.miso(g, pos, cig, 36, mode=OrcLib.COUNTER, seed=21, event_id=3 + i, trace=True, **kw)
+        assert np.array_equal(ref[i].counts_trace, cpu.trace["counts_trace"]), i
+        assert np.array_equal(ref[i].samples, cpu.samples), i
