@@ -29,6 +29,7 @@
 #include <math.h>
 
 #if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
 #define MISO_DM __host__ __device__ __forceinline__
 #else
 #define MISO_DM static inline

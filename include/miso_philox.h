@@ -33,6 +33,7 @@
 #include <stdint.h>
 
 #if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
 #define MISO_HD __host__ __device__ __forceinline__
 #else
 #define MISO_HD static inline
@@ -78,6 +79,13 @@ MISO_HD miso_u32x4 miso_draw_block(uint64_t seed, uint32_t event_id, uint32_t ch
   return miso_philox4x32_10(block, iteration, site | (chain << 8), event_id,
                             (uint32_t) seed, (uint32_t) (seed >> 32));
 }
+
+/* Paired-end fragment scores (miso_paired.c:157-163) are summed in fixed point so that the sum does
+   not depend on the order of the reads: value * 2^MISO_SFIX_BITS rounded to nearest, int32 per
+   table entry (|value| < 31), MISO_SFIX_BAD = non-finite / not representable. */
+#define MISO_SFIX_BITS 26
+#define MISO_SFIX_SCALE 67108864.0 /* 2^26 */
+#define MISO_SFIX_BAD INT32_MIN
 
 /* u32 -> [0,1) with 32-bit resolution; exact in double. */
 MISO_HD double miso_u01(uint32_t w) { return (double) w * (1.0 / 4294967296.0); }

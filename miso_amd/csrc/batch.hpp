@@ -13,7 +13,7 @@ namespace miso {
 int device_count();
 void set_device(int d);
 miso_batch *batch_new(const miso_params_t &p);
-int choose_lanes_per_chain(long chains, int max_quads, int wave_slots);
+int choose_lanes_per_chain(long chains, int max_quads, int wave_slots, int max_cpw);
 void selftest_detmath(const double *x, int n, double *e, double *l, double *s, double *q);
 void selftest_philox(const uint32_t *in6, int n, uint32_t *out4);
 }  // namespace miso
@@ -43,7 +43,7 @@ struct miso_batch {
   int k2_first_event() const {  // the k2 event with the most drawing reads (list is sorted)
     int best = -1;
     for (size_t i = 0; i < events.size(); i++)
-      if (!events[i].paired && events[i].K == 2 && (best < 0 || events[i].n_draw > events[best].n_draw))
+      if (events[i].K == 2 && (best < 0 || events[i].n_draw > events[best].n_draw))
         best = static_cast<int>(i);
     return best;
   }

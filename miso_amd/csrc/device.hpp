@@ -20,12 +20,12 @@ struct DevEvent {
   int32_t n_draw;      // reads with >= 2 compatible isoforms
   int32_t n_reads;
   int32_t base_bad;    // paired: a fixed read carries a non-finite score
-  int64_t base_sfix;   // paired: fixed reads' score sum, 2^-32 fixed point
+  int64_t base_sfix;   // paired: fixed reads' score sum, 2^-26 fixed point (miso_philox.h)
   // byte offsets into the input pool
   uint64_t off_consts; // double[3K + CONST_EXTRA]
   uint64_t off_base;   // int32[K]: reads with exactly one compatible isoform, per isoform
   uint64_t off_draw;   // SE: uint32 mask[n_draw (padded to 4)]; PE: uint16 frag[n_draw x K]
-  uint64_t off_sfix;   // PE: int64[K x il], INT64_MIN = non-finite
+  uint64_t off_sfix;   // PE: int32[K x il] fixed-point scores, MISO_SFIX_BAD = non-finite
   // byte offsets into the output pool
   uint64_t off_samples; // double[S x K]  (reference layout: K x S column-major)
   uint64_t off_loglik;  // double[S]
@@ -58,6 +58,6 @@ struct KernelArgs {
 
 constexpr uint64_t NO_TRACE = ~0ull;
 constexpr uint16_t FRAG_NONE = 0xFFFF;
-constexpr int64_t SFIX_BAD = INT64_MIN;
+constexpr int32_t SFIX_BAD = INT32_MIN;  // == MISO_SFIX_BAD
 
 }  // namespace miso

@@ -15,6 +15,7 @@
 #include <map>
 
 #include "device.hpp"
+#include "miso_philox.h"
 
 namespace miso {
 
@@ -373,8 +374,8 @@ PackedEvent pack_event(const miso_params_t &p, const FragmentDist *fd, int K, in
     e.sfix_table.resize(static_cast<size_t>(K) * il);
     for (size_t i = 0; i < e.sfix_table.size(); i++) {
       const double s = isoscore_tab[i];
-      e.sfix_table[i] = (std::isfinite(s) && std::fabs(s) < 1048576.0)
-                            ? static_cast<int64_t>(std::llrint(s * 4294967296.0))
+      e.sfix_table[i] = (std::isfinite(s) && std::fabs(s) < 31.0)
+                            ? static_cast<int32_t>(std::llrint(s * MISO_SFIX_SCALE))
                             : SFIX_BAD;
     }
   }
@@ -408,7 +409,7 @@ PackedEvent pack_event(const miso_params_t &p, const FragmentDist *fd, int K, in
       e.fixed_ass[i] = first;
       e.base_count[first]++;
       if (p.paired) {
-        const int64_t v = e.sfix_table[static_cast<size_t>(first) * il +
+        const int32_t v = e.sfix_table[static_cast<size_t>(first) * il +
                                        (fraglen[static_cast<size_t>(i) * K + first] - fd->start)];
         if (v == SFIX_BAD) e.base_bad = 1; else e.base_sfix += v;
       }

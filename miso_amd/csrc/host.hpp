@@ -88,11 +88,11 @@ struct PackedEvent {
   std::vector<double> hyper;            // K
   std::vector<double> consts;           // 3K+5 doubles, layout in device.hpp
   std::vector<int32_t> base_count;      // K
-  int64_t base_sfix = 0;                // paired: sum of fixed reads' scores, 2^-32 fixed point
+  int64_t base_sfix = 0;                // paired: sum of fixed reads' scores, 2^-26 fixed point
   int32_t base_bad = 0;                 // paired: a fixed read has a non-finite score
   std::vector<uint32_t> draw_mask;      // single-end: n_draw
   std::vector<uint16_t> draw_frag;      // paired-end: n_draw x K
-  std::vector<int64_t> sfix_table;      // paired-end: K x il fixed-point isoscores
+  std::vector<int32_t> sfix_table;      // paired-end: K x il fixed-point isoscores
   std::vector<int32_t> fixed_ass;       // N: -1 / isoform for fixed reads, -2 for drawing reads
   // header material for the caller (miso.c:762, miso_paired.c:386-391)
   std::vector<double> class_templates;  // K x ncls

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void sampler_wave(const KernelArgs a) {
 
   const uint32_t *masks = reinterpret_cast<const uint32_t *>(a.in_pool + E.off_draw);
   const uint16_t *frags = reinterpret_cast<const uint16_t *>(a.in_pool + E.off_draw);
-  const int64_t *sfix = reinterpret_cast<const int64_t *>(a.in_pool + E.off_sfix);
+  const int32_t *sfix = reinterpret_cast<const int32_t *>(a.in_pool + E.off_sfix);
   double *samples = reinterpret_cast<double *>(a.out_pool + E.off_samples);
   double *loglik = reinterpret_cast<double *>(a.out_pool + E.off_loglik);
   uint8_t *drawass = a.out_pool + E.off_drawass;
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void sampler_wave(const KernelArgs a) {
           }
         }
         if (PE && sel[j] >= 0) {
-          const int64_t v = sfix[static_cast<size_t>(sel[j]) * a.il + fsel];
+          const int32_t v = sfix[static_cast<size_t>(sel[j]) * a.il + fsel];
           if (v == SFIX_BAD) bad = 1; else acc += v;
         }
         if (write_ass && sel[j] >= 0) drawass[r] = static_cast<uint8_t>(sel[j]);
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void sampler_wave(const KernelArgs a) {
     propose(alpha, alphaN, psiN, accept_word, c, K, lane, a.seed, event_id, chain,
             static_cast<uint32_t>(m));
     const double rp = PE ? (rbad ? miso_u2d(0x7FF8000000000000ull)
-                                 : static_cast<double>(rfix) * (1.0 / 4294967296.0))
+                                 : static_cast<double>(rfix) * (1.0 / MISO_SFIX_SCALE))
                          : 0.0;
     const double pp = joint_score<PE>(psiN, cnt, rp, c, K, lane);
     const double pc = joint_score<PE>(psi, cnt, rp, c, K, lane);

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void sampler_grp(const KernelArgs a) {
 
   const uint32_t *masks = reinterpret_cast<const uint32_t *>(a.in_pool + E.off_draw);
   const uint16_t *frags = reinterpret_cast<const uint16_t *>(a.in_pool + E.off_draw);
-  const int64_t *sfix = reinterpret_cast<const int64_t *>(a.in_pool + E.off_sfix);
+  const int32_t *sfix = reinterpret_cast<const int32_t *>(a.in_pool + E.off_sfix);
   double *samples = reinterpret_cast<double *>(a.out_pool + E.off_samples);
   double *loglik = reinterpret_cast<double *>(a.out_pool + E.off_loglik);
   uint8_t *drawass = a.out_pool + E.off_drawass;
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void sampler_grp(const KernelArgs a) {
         if (sel >= 0) {
           atomicAdd(&S.cnt[sel], 1);
           if (PE) {
-            const int64_t v = sfix[static_cast<size_t>(sel) * a.il + fsel];
+            const int32_t v = sfix[static_cast<size_t>(sel) * a.il + fsel];
             if (v == SFIX_BAD) bad = 1; else acc += v;
           }
           if (write_ass) drawass[r] = static_cast<uint8_t>(sel);
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256, 2) void sampler_grp(const KernelArgs a) {
       }
     propose(S.alpha, S.alphaN, S.psiN, static_cast<uint32_t>(m), accept_word);
     const double rp = PE ? (rbad ? miso_u2d(0x7FF8000000000000ull)
-                                 : static_cast<double>(rfix) * (1.0 / 4294967296.0))
+                                 : static_cast<double>(rfix) * (1.0 / MISO_SFIX_SCALE))
                          : 0.0;
     const double pp = joint(S.psiN, rp);
     const double pc = joint(S.psi, rp);

@@ -77,10 +77,12 @@ __device__ __forceinline__ PsiTerms psi_terms(double x0, double x1, double cst0,
 }
 
 // miso.c:243-307 with the per-read sums taken from the counts
-__device__ __forceinline__ double joint(const PsiTerms &t, int c0, int c1, const K2Consts &c) {
+template <bool PE>
+__device__ __forceinline__ double joint(const PsiTerms &t, int c0, int c1, const K2Consts &c, double readProbPE) {
   double readProb = 0.0, assProb = 0.0, psiProb = 0.0;
-  if (c0 != 0) { readProb = readProb + static_cast<double>(c0) * c.is0; assProb = assProb + static_cast<double>(c0) * t.lpn0; }
-  if (c1 != 0) { readProb = readProb + static_cast<double>(c1) * c.is1; assProb = assProb + static_cast<double>(c1) * t.lpn1; }
+  if (c0 != 0) { if (!PE) readProb = readProb + static_cast<double>(c0) * c.is0; assProb = assProb + static_cast<double>(c0) * t.lpn0; }
+  if (c1 != 0) { if (!PE) readProb = readProb + static_cast<double>(c1) * c.is1; assProb = assProb + static_cast<double>(c1) * t.lpn1; }
+  if (PE) readProb = readProbPE;  // miso_paired.c:157-163, summed in 2^-26 fixed point
   psiProb = psiProb + c.hm0 * t.lx0;
   psiProb = psiProb + c.hm1 * t.lx1;
   psiProb = psiProb + c.lg_sum;
@@ -191,8 +193,14 @@ __device__ __forceinline__ miso_u32x4 philox_gibbs(const GibbsRng &g, uint32_t q
 
 }  // namespace
 
-template <int G>
+template <int G, bool PE>
 __global__ __launch_bounds__(256, 2) void sampler_k2(const KernelArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_k2[];
+  double *lds_fp = reinterpret_cast<double *>(smem_k2);  // PE: fragment-length probabilities
+  if (PE) {
+    for (int i = threadIdx.x; i < a.il; i += blockDim.x) lds_fp[i] = a.frag_prob[i];
+    __syncthreads();                               // the only block-level barrier
+  }
   constexpr int CPW = 64 / G;                      // chains per wavefront
   constexpr int NR = G >= 4 ? 4 : G;               // lanes cooperating on the scalar math
   constexpr bool QUAD = (G % 4) == 0;
@@ -247,14 +255,71 @@ __global__ __launch_bounds__(256, 2) void sampler_k2(const KernelArgs a) {
   }
 
   int cnt0 = 0, cnt1 = 0;
+  int64_t rfix = 0; int rbad = 0;   // PE: fixed-point sum of the assigned reads' fragment scores
+  const uint4 *fragq = reinterpret_cast<const uint4 *>(a.in_pool + E.off_draw);  // PE: 4 reads x (f0 | f1 << 16)
+  // PE: the event's fixed-point score table (2 x il int32) sits in the chain's LDS slice: a per-read
+  // gather from L2 would cost more than the whole rest of the Gibbs step
+  int32_t *lds_tab = reinterpret_cast<int32_t *>(smem_k2 + ((a.il * 8 + 15) & ~15)) +
+                     (static_cast<size_t>(threadIdx.x >> 6) * CPW + grp) * (2 * a.il);
+  if (PE) {
+    const int32_t *sfix = reinterpret_cast<const int32_t *>(a.in_pool + E.off_sfix);
+    for (int i = sub; i < 2 * a.il; i += G) lds_tab[i] = sfix[i];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  }
   PsiTerms cur;
   double alpha = 0.0;
+
+  // paired-end pick of one read (miso_paired.c:11-22, 64-68): weights psi_k * fragProb(frag_k)
+  auto pe_pick = [&](uint32_t ff, uint32_t uword, int64_t &acc, int &bad) {
+    const uint32_t f0 = ff & 0xFFFFu, f1 = ff >> 16;
+    const double c0 = 0.0 + cur.x0 * lds_fp[f0];
+    const double T = c0 + cur.x1 * lds_fp[f1];
+    const bool p0 = miso_u01(uword) * T < c0;
+    const int32_t v = lds_tab[p0 ? f0 : a.il + f1];
+    if (v == SFIX_BAD) bad = 1; else acc += v;
+    return p0;
+  };
 
   // Gibbs step for the current psi (miso.c:30-91 restricted to two compatible isoforms)
 #ifdef MISO_K2_PROFILE
   uint64_t pf_mh = 0, pf_thr = 0, pf_loop = 0, pf_red = 0, pf_rec = 0;
 #endif
   auto gibbs = [&](uint32_t iter) {
+    if (PE) {
+      const uint32_t n0r0 = rng.p1hi ^ iter ^ k0;
+      const int nq = (n_draw + 3) >> 2;
+      int d0 = 0, bad = 0; int64_t acc = 0;
+      for (int j = 0; j < 2 * trips + 1; j++) {
+        const int q = sub + j * G;
+        const miso_u32x4 u = philox_gibbs(rng, static_cast<uint32_t>(q), n0r0);
+        if (q < nq && lane_used) {
+          const uint4 f = fragq[q];
+          const int left = n_draw - 4 * q;
+          d0 += pe_pick(f.x, u.v[0], acc, bad);
+          if (left > 1) d0 += pe_pick(f.y, u.v[1], acc, bad);
+          if (left > 2) d0 += pe_pick(f.z, u.v[2], acc, bad);
+          if (left > 3) d0 += pe_pick(f.w, u.v[3], acc, bad);
+        }
+      }
+      if (POW2) {
+#pragma unroll
+        for (int off = G >> 1; off >= 1; off >>= 1) {
+          d0 += __shfl_xor(d0, off); acc += __shfl_xor(acc, off); bad |= __shfl_xor(bad, off);
+        }
+      } else {
+        int tot = 0, tb = 0; int64_t ta = 0;
+#pragma unroll
+        for (int j = 0; j < G; j++) {
+          tot += __shfl(d0, base_lane + j); ta += __shfl(acc, base_lane + j); tb |= __shfl(bad, base_lane + j);
+        }
+        d0 = tot; acc = ta; bad = tb;
+      }
+      cnt0 = base0 + d0;
+      cnt1 = base1 + (n_draw - d0);
+      rfix = E.base_sfix + acc;
+      rbad = bad | E.base_bad;
+      return;
+    }
     PROF_T(g0);
     const uint64_t t = k2_threshold(cur.x0, (0.0 + cur.x0) + cur.x1);
     const uint32_t tm = static_cast<uint32_t>(t - 1);  // u < t  <=>  t != 0 && u <= t - 1
@@ -295,12 +360,18 @@ __global__ __launch_bounds__(256, 2) void sampler_k2(const KernelArgs a) {
 
   // the per-read picks of one Gibbs step, written once for the caller (miso.c:943-946)
   auto gibbs_write = [&](uint32_t iter) {
-    const uint64_t t = k2_threshold(cur.x0, (0.0 + cur.x0) + cur.x1);
+    const uint64_t t = PE ? 0 : k2_threshold(cur.x0, (0.0 + cur.x0) + cur.x1);
     const int nq = (n_draw + 3) >> 2;
     for (int q = sub; q < nq; q += G) {
       const miso_u32x4 u = miso_philox4x32_10(static_cast<uint32_t>(q), iter, c2_gibbs, event_id, k0, k1);
-      for (int j = 0; j < 4; j++)
-        if (4 * q + j < n_draw) drawass[4 * q + j] = (static_cast<uint64_t>(u.v[j]) < t) ? 0 : 1;
+      const uint4 f = PE ? fragq[q] : make_uint4(0, 0, 0, 0);
+      const uint32_t ff[4] = {f.x, f.y, f.z, f.w};
+      for (int j = 0; j < 4; j++) {
+        if (4 * q + j >= n_draw) continue;
+        int64_t dummy = 0; int db = 0;
+        const bool p0 = PE ? pe_pick(ff[j], u.v[j], dummy, db) : (static_cast<uint64_t>(u.v[j]) < t);
+        drawass[4 * q + j] = p0 ? 0 : 1;
+      }
     }
   };
 
@@ -370,8 +441,11 @@ __global__ __launch_bounds__(256, 2) void sampler_k2(const KernelArgs a) {
       nw.lpn0 = lp0 - lse;
       nw.lpn1 = lp1 - lse;
     }
-    const double pp = joint(nw, cnt0, cnt1, c);
-    const double pc = joint(cur, cnt0, cnt1, c);
+    const double rp = PE ? (rbad ? miso_u2d(0x7FF8000000000000ull)
+                                 : static_cast<double>(rfix) * (1.0 / MISO_SFIX_SCALE))
+                         : 0.0;
+    const double pp = joint<PE>(nw, cnt0, cnt1, c, rp);
+    const double pc = joint<PE>(cur, cnt0, cnt1, c, rp);
     const double acceptP = (m > 0) ? miso_det_exp(pp + ptoCS - (pc + ctoPS)) : miso_det_exp(pp - pc);
     const bool acc = (acceptP >= 1) || (miso_u01(accept_word) < acceptP);
     double cJS = pc;
@@ -418,7 +492,9 @@ __global__ __launch_bounds__(256, 2) void sampler_k2(const KernelArgs a) {
   }
 }
 
-#define MISO_INSTANTIATE_K2(G) template __global__ void sampler_k2<G>(const KernelArgs);
+#define MISO_INSTANTIATE_K2(G)                                      \
+  template __global__ void sampler_k2<G, false>(const KernelArgs); \
+  template __global__ void sampler_k2<G, true>(const KernelArgs);
 MISO_INSTANTIATE_K2(1)
 MISO_INSTANTIATE_K2(2)
 MISO_INSTANTIATE_K2(3)

@@ -16,7 +16,7 @@
 namespace miso {
 
 template <bool PE> __global__ void sampler_wave(const KernelArgs a);
-template <int G> __global__ void sampler_k2(const KernelArgs a);
+template <int G, bool PE> __global__ void sampler_k2(const KernelArgs a);
 template <int G, bool PE> __global__ void sampler_grp(const KernelArgs a);
 static inline int grp_slice_bytes(int ks) { return 10 * ks * 8 + 2 * ks * 4; }
 __global__ void selftest_detmath_kernel(const double *, int, double *, double *, double *, double *);
@@ -46,15 +46,20 @@ static inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a
 // mostly empty round starts.  Hence: the smallest supported G whose wavefront count still fills
 // the slots once, i.e. the largest G with ceil(chains / (64 / G)) <= slots; G = 1 for batches that
 // overflow anyway; never more lanes than a chain has pairs of draw quads to stride over.
-int choose_lanes_per_chain(long chains, int max_quads, int wave_slots) {
+int choose_lanes_per_chain(long chains, int max_quads, int wave_slots, int max_cpw) {
   static const int kG[] = {64, 32, 21, 16, 12, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1};
   const int cap = std::max(1, max_quads / 2);
+  const bool pow2_only = max_cpw < 64;   // paired-end reduces three values per step: measured, the
+  int last = 64;                         // shuffle-loop reduction of odd group sizes does not pay
   for (int G : kG) {
-    if (G > cap) continue;
     const int cpw = 64 / G;
+    if (cpw > max_cpw) break;            // paired-end: per-chain LDS tables bound the chains per wave
+    if (pow2_only && (G & (G - 1))) continue;
+    last = G;
+    if (G > cap) continue;
     if ((chains + cpw - 1) / cpw <= wave_slots) return G;
   }
-  return 1;
+  return last;
 }
 
 }  // namespace miso
@@ -96,7 +101,7 @@ void miso_batch::upload(int dev) {
     d.off_draw = in_off;
     in_off = align_up(in_off + (e.paired ? e.draw_frag.size() * 2
                                          : align_up(e.draw_mask.size(), 4) * 4), 16);
-    d.off_sfix = in_off; in_off = align_up(in_off + e.sfix_table.size() * 8, 16);
+    d.off_sfix = in_off; in_off = align_up(in_off + e.sfix_table.size() * 4, 16);
     d.off_samples = out_off; out_off = align_up(out_off + static_cast<uint64_t>(Sn) * e.K * 8, 16);
     d.off_loglik = out_off; out_off = align_up(out_off + static_cast<uint64_t>(Sn) * 8, 16);
     d.off_drawass = out_off; out_off = align_up(out_off + static_cast<uint64_t>(e.n_draw), 16);
@@ -119,7 +124,7 @@ void miso_batch::upload(int dev) {
     if (e.paired) std::memcpy(h_in.data() + d.off_draw, e.draw_frag.data(), e.draw_frag.size() * 2);
     else std::memcpy(h_in.data() + d.off_draw, e.draw_mask.data(), e.draw_mask.size() * 4);
     if (!e.sfix_table.empty())
-      std::memcpy(h_in.data() + d.off_sfix, e.sfix_table.data(), e.sfix_table.size() * 8);
+      std::memcpy(h_in.data() + d.off_sfix, e.sfix_table.data(), e.sfix_table.size() * 4);
   }
   {
     hipDeviceProp_t prop;
@@ -134,10 +139,10 @@ void miso_batch::upload(int dev) {
   HIP_OK(hipMalloc(reinterpret_cast<void **>(&d_out), out_bytes));
   if (n) HIP_OK(hipMemcpy(d_events, h_events.data(), n * sizeof(DevEvent), hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(d_in, h_in.data(), in_bytes, hipMemcpyHostToDevice));
-  // launch lists: two-isoform single-end events go to the lane-packed kernel, ordered by their
+  // launch lists: two-isoform events (single- or paired-end) go to sampler_k2, ordered by their
   // number of drawing reads so the chains sharing a wavefront loop equally long
   std::vector<int32_t> k2, gen;
-  for (int i = 0; i < n; i++) ((!p.paired && events[i].K == 2) ? k2 : gen).push_back(i);
+  for (int i = 0; i < n; i++) ((events[i].K == 2) ? k2 : gen).push_back(i);
   std::stable_sort(k2.begin(), k2.end(),
                    [&](int x, int y) { return events[x].n_draw > events[y].n_draw; });
   // the general kernel's wavefronts loop to their largest K and longest draw list: group alike
@@ -176,13 +181,20 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     const int maxq = (events[k2_first_event()].n_draw + 3) / 4;
     int G = 0;
     if (const char *env = std::getenv("MISO_LANES_PER_CHAIN")) G = std::atoi(env);
-    else G = choose_lanes_per_chain(chains, maxq, wave_slots);
+    const size_t k2_fp = p.paired ? align_up(fd.prob.size() * 8, 16) : 0;
+    const size_t k2_tab = p.paired ? 2 * fd.prob.size() * 4 : 0;   // per chain: int32[2 x il]
+    const int max_cpw = p.paired ? std::max<int>(1, static_cast<int>((60 * 1024 - k2_fp) / (4 * k2_tab))) : 64;
+    if (!G) G = choose_lanes_per_chain(chains, maxq, wave_slots, max_cpw);
     lanes_per_chain = G;
     a.slot_event = d_slots; a.n_slots = n_k2;
     const int cpw = 64 / std::max(G, 1);
     const unsigned grid = static_cast<unsigned>(((chains + cpw - 1) / cpw + 3) / 4);
-#define MISO_K2_LAUNCH(GG) \
-  case GG: hipLaunchKernelGGL((sampler_k2<GG>), dim3(grid), dim3(256), 0, stream, a); break;
+    const size_t k2_lds = k2_fp + 4 * static_cast<size_t>(cpw) * k2_tab;
+#define MISO_K2_LAUNCH(GG)                                                                           \
+  case GG:                                                                                          \
+    if (p.paired) hipLaunchKernelGGL((sampler_k2<GG, true>), dim3(grid), dim3(256), k2_lds, stream, a); \
+    else hipLaunchKernelGGL((sampler_k2<GG, false>), dim3(grid), dim3(256), 0, stream, a);           \
+    break;
     switch (G) {
       MISO_K2_LAUNCH(1) MISO_K2_LAUNCH(2) MISO_K2_LAUNCH(3) MISO_K2_LAUNCH(4) MISO_K2_LAUNCH(5)
       MISO_K2_LAUNCH(6) MISO_K2_LAUNCH(7) MISO_K2_LAUNCH(8) MISO_K2_LAUNCH(9) MISO_K2_LAUNCH(10)

@@ -13,7 +13,7 @@
  *                     log/exp/qnorm from include/miso_detmath.h, joint score summed from
  *                     per-isoform counts (single-end: miso.c:265-271 / 152-156 summed per read
  *                     equal sum_k count_k*score_k up to rounding) and, paired-end, the per-read
- *                     fragment score summed in 2^-32 fixed point (order independent).
+ *                     fragment score summed in 2^-26 fixed point (order independent, miso_philox.h).
  */
 #include "miso_oracle.h"
 
@@ -641,7 +641,7 @@ typedef struct {
   double *psi, *psiNew, *alpha, *alphaNew; /* K x C, (K-1) x C */
 } orc_state_t;
 
-#define SFIX_BAD INT64_MIN
+#define SFIX_BAD ((int64_t) MISO_SFIX_BAD)
 
 /* miso.c:219-241 + 462-468 (logit_inv and the last component) */
 static void logit_inv_col(const orc_state_t *S, const double *alpha, double *psi) {
@@ -782,7 +782,7 @@ static double score_joint(const orc_state_t *S, int chain, const double *psi) {
         int64_t v = S->sfix[(size_t) i * K + ass[i]];
         if (v == SFIX_BAD) bad = 1; else acc += v;
       }
-      readProb = bad ? NAN : (double) acc * (1.0 / 4294967296.0);
+      readProb = bad ? NAN : (double) acc * (1.0 / MISO_SFIX_SCALE);
     } else {
       for (i = 0; i < K; i++) if (cnt[i] != 0) readProb = readProb + (double) cnt[i] * S->isoscores[i];
     }
@@ -1049,14 +1049,14 @@ int orc_miso_paired(const orc_gene_t *g, const int *pos, const char **cigar, int
   S.paired = 1; S.fs = fs; S.il = il;
   S.match = match; S.order = order; S.fraglen = fraglen; S.pisoscores = pisoscores;
   S.assscores = assscores;
-  if (S.counter) { /* fixed-point per-read scores: llrint(S * 2^32) */
+  if (S.counter) { /* fixed-point per-read scores: llrint(S * 2^MISO_SFIX_BITS) */
     sfix = malloc(sizeof(int64_t) * (size_t) K * (N > 0 ? N : 1));
     for (i = 0; i < N; i++) for (j = 0; j < K; j++) {
       int fl = fraglen[(size_t) i * K + j];
       int64_t v = SFIX_BAD;
       if (fl >= 0) {
         double s = pisoscores[(size_t) j * il + (fl - fs)];
-        if (isfinite(s) && fabs(s) < 1048576.0) v = (int64_t) llrint(s * 4294967296.0);
+        if (isfinite(s) && fabs(s) < 31.0) v = (int64_t) llrint(s * MISO_SFIX_SCALE);
       }
       sfix[(size_t) i * K + j] = v;
     }
