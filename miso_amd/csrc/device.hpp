@@ -25,6 +25,10 @@ struct DevEvent {
   uint64_t off_consts; // double[3K + CONST_EXTRA]
   uint64_t off_base;   // int32[K]: reads with exactly one compatible isoform, per isoform
   uint64_t off_draw;   // SE: uint32 mask[n_draw (padded to 4)]; PE: uint16 frag[n_draw x K]
+  uint64_t off_cls;    // SE: uint8 class id per drawing read (padded to 4), or ~0 when not available
+  uint64_t off_clsmask;// SE: uint32 mask per drawing-read class
+  int32_t n_dcls;      // SE: number of drawing-read classes (0 = use the masks)
+  int32_t pad0;
   uint64_t off_sfix;   // PE: int32[K x il] fixed-point scores, MISO_SFIX_BAD = non-finite
   // byte offsets into the output pool
   uint64_t off_samples; // double[S x K]  (reference layout: K x S column-major)
@@ -57,6 +61,7 @@ struct KernelArgs {
 };
 
 constexpr uint64_t NO_TRACE = ~0ull;
+constexpr int MAX_DRAW_CLASSES = 32;  // single-end: per-class integer thresholds up to this many classes
 constexpr uint16_t FRAG_NONE = 0xFFFF;
 constexpr int32_t SFIX_BAD = INT32_MIN;  // == MISO_SFIX_BAD
 

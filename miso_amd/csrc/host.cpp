@@ -418,6 +418,12 @@ PackedEvent pack_event(const miso_params_t &p, const FragmentDist *fd, int K, in
     e.fixed_ass[i] = -2;
     if (!p.paired) {
       e.draw_mask.push_back(mask);
+      if (e.dcls_mask.size() <= MAX_DRAW_CLASSES) {   // read classes of the drawing reads
+        size_t c = 0;
+        while (c < e.dcls_mask.size() && e.dcls_mask[c] != mask) c++;
+        if (c == e.dcls_mask.size()) e.dcls_mask.push_back(mask);
+        e.draw_cls.push_back(static_cast<uint8_t>(c));
+      }
     } else {
       for (int k = 0; k < K; k++) {
         const int fl = fraglen[static_cast<size_t>(i) * K + k];
@@ -426,6 +432,7 @@ PackedEvent pack_event(const miso_params_t &p, const FragmentDist *fd, int K, in
     }
     e.n_draw++;
   }
+  if (e.dcls_mask.size() > MAX_DRAW_CLASSES) { e.dcls_mask.clear(); e.draw_cls.clear(); }
   for (const auto &kv : cls) {
     e.class_templates.insert(e.class_templates.end(), kv.first.begin(), kv.first.end());
     e.class_counts.push_back(kv.second);

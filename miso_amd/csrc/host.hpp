@@ -91,6 +91,9 @@ struct PackedEvent {
   int64_t base_sfix = 0;                // paired: sum of fixed reads' scores, 2^-26 fixed point
   int32_t base_bad = 0;                 // paired: a fixed read has a non-finite score
   std::vector<uint32_t> draw_mask;      // single-end: n_draw
+  std::vector<uint32_t> dcls_mask;      // single-end: distinct masks among the drawing reads ...
+  std::vector<uint8_t> draw_cls;        // ... and each drawing read's index into them (empty when
+                                        // there are more than MISO_MAX_DRAW_CLASSES of them)
   std::vector<uint16_t> draw_frag;      // paired-end: n_draw x K
   std::vector<int32_t> sfix_table;      // paired-end: K x il fixed-point isoscores
   std::vector<int32_t> fixed_ass;       // N: -1 / isoform for fixed reads, -2 for drawing reads

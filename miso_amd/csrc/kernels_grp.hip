@@ -40,6 +40,8 @@ __device__ __forceinline__ double seq_sum(const double *v, int n) {
 struct Slice {            // one chain's LDS slice; every array has `ks` entries
   double *psi, *alpha, *psiN, *alphaN, *ta, *tb, *tc, *cst, *isc, *hm1;
   int *cnt, *bas;  // picks of the drawing reads; reads with a single compatible isoform
+  uint32_t *cmask; // SE class path: mask of every drawing-read class [MAX_DRAW_CLASSES]
+  uint64_t *thr;   // SE class path: integer thresholds [MAX_DRAW_CLASSES x (ks - 1)]
 };
 
 __device__ __forceinline__ Slice carve(unsigned char *base, int ks) {
@@ -49,15 +51,43 @@ __device__ __forceinline__ Slice carve(unsigned char *base, int ks) {
   s.tb = d + 5 * ks; s.tc = d + 6 * ks; s.cst = d + 7 * ks; s.isc = d + 8 * ks; s.hm1 = d + 9 * ks;
   s.cnt = reinterpret_cast<int *>(d + 10 * ks);
   s.bas = s.cnt + ks;
+  s.thr = reinterpret_cast<uint64_t *>(reinterpret_cast<unsigned char *>(d) + 10 * ks * 8 + 2 * ks * 4);
+  s.cmask = reinterpret_cast<uint32_t *>(s.thr + MAX_DRAW_CLASSES * (ks - 1));
   return s;
 }
 
 struct Scalars { double lg_sum, lg_each, sigma, sd, covar; };
 
+// The reference's draw compares rnd = fl(fl(u 2^-32) T) with a cumulative weight c: `rnd < c` when two
+// isoforms are compatible, `!(rnd > c)` otherwise (miso.c:69-79).  Both are monotone in the 32-bit
+// word u, so each becomes an integer threshold: the number of words for which the test holds.
+template <bool LE> __device__ __forceinline__ bool thr_pred(int64_t u, double c, double T) {
+  if (u < 0) return true;
+  if (u >= 4294967296ll) return false;
+  const double rnd = static_cast<double>(static_cast<uint32_t>(u)) * (1.0 / 4294967296.0) * T;
+  return LE ? !(rnd > c) : (rnd < c);
+}
+template <bool LE> __device__ __forceinline__ uint64_t draw_threshold(double c, double T) {
+  double est = c / T * 4294967296.0;
+  est = (est > 0.0) ? est : 0.0;
+  est = (est > 4294967296.0) ? 4294967296.0 : est;
+  const int64_t t0 = static_cast<int64_t>(est);
+  const int n = thr_pred<LE>(t0 - 1, c, T) + thr_pred<LE>(t0, c, T) + thr_pred<LE>(t0 + 1, c, T);
+  int64_t t = t0 - 1 + n;
+  if (!thr_pred<LE>(t0 - 2, c, T) || thr_pred<LE>(t0 + 2, c, T)) {  // exact fallback, not taken in practice
+    t = t0 < 0 ? 0 : (t0 > 4294967296ll ? 4294967296ll : t0);
+    for (int g = 0; g < 4096 && t > 0 && !thr_pred<LE>(t - 1, c, T); g++) t--;
+    for (int g = 0; g < 4096 && t < 4294967296ll && thr_pred<LE>(t, c, T); g++) t++;
+  }
+  return static_cast<uint64_t>(t < 0 ? 0 : t);
+}
+
 }  // namespace
 
 // bytes of LDS one chain needs for isoform stride ks (ks even)
-__host__ __device__ inline int grp_slice_bytes(int ks) { return 10 * ks * 8 + 2 * ks * 4; }
+__host__ __device__ inline int grp_slice_bytes(int ks) {
+  return 10 * ks * 8 + 2 * ks * 4 + MAX_DRAW_CLASSES * (ks - 1) * 8 + MAX_DRAW_CLASSES * 4;
+}
 
 template <int G, bool PE>
 __global__ __launch_bounds__(256, 2) void sampler_grp(const KernelArgs a) {
@@ -99,6 +129,17 @@ __global__ __launch_bounds__(256, 2) void sampler_grp(const KernelArgs a) {
       S.alpha[k] = 0.0; S.psi[k] = 0.0; S.cnt[k] = 0; S.bas[k] = base[k];
     }
   }
+  // single-end class path: usable when every chain of the wavefront has a class table
+  const uint8_t *clsq = a.in_pool + E.off_cls;
+  const int n_dcls = PE ? 0 : E.n_dcls;
+  int ncw = n_dcls;
+  bool cls_ok = !PE && (n_dcls > 0 || E.n_draw == 0);
+  for (int off = 32; off >= 1; off >>= 1) { ncw = max(ncw, __shfl_xor(ncw, off)); }
+  cls_ok = __all(cls_ok);
+  if (cls_ok) {
+    const uint32_t *gm = reinterpret_cast<const uint32_t *>(a.in_pool + E.off_clsmask);
+    for (int c0 = 0; c0 < ncw; c0 += G) { const int cc = c0 + sub; if (cc < n_dcls) S.cmask[cc] = gm[cc]; }
+  }
   wave_sync();
   Scalars c;
   c.lg_sum = consts[3 * K + 0]; c.lg_each = consts[3 * K + 1]; c.sigma = consts[3 * K + 2];
@@ -119,6 +160,54 @@ __global__ __launch_bounds__(256, 2) void sampler_grp(const KernelArgs a) {
   auto gibbs = [&](uint32_t iter, bool write_ass) {
     for (int k0 = 0; k0 < Kw; k0 += G) { const int k = k0 + sub; if (k < K) S.cnt[k] = 0; }
     wave_sync();
+    if (!PE && cls_ok) {
+      // thresholds of every drawing-read class for the current psi: one class per lane
+      const int tw = ks - 1;
+      for (int c0 = 0; c0 < ncw; c0 += G) {
+        const int cc = c0 + sub;
+        if (cc < n_dcls) {
+          const uint32_t m = S.cmask[cc];
+          const int nv = __popc(m);
+          double T = 0.0;
+          for (int k = 0; k < K; k++) if ((m >> k) & 1u) T = T + S.psi[k];
+          double cum = 0.0; uint64_t run = 0; int j = 0;
+          for (int k = 0; k < K && j < nv - 1; k++) {
+            if (!((m >> k) & 1u)) continue;
+            cum = cum + S.psi[k];
+            const uint64_t t = (nv == 2) ? draw_threshold<false>(cum, T) : draw_threshold<true>(cum, T);
+            run = t > run ? t : run;          // first j with u < t_j  ==  #{j : u >= running max}
+            S.thr[cc * tw + j] = run;
+            j++;
+          }
+        }
+      }
+      wave_sync();
+      const uint32_t *cq = reinterpret_cast<const uint32_t *>(clsq);
+      for (int q0 = 0; q0 < nqw; q0 += G) {
+        const int q = q0 + sub;
+        const bool active = q < n_quads;
+        const miso_u32x4 u = miso_draw_block(a.seed, event_id, chain, iter, MISO_SITE_GIBBS,
+                                             static_cast<uint32_t>(q));
+        const uint32_t c4 = active ? cq[q] : 0u;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int r = 4 * q + j;
+          if (!(active && r < n_draw)) continue;
+          const int cc = (c4 >> (8 * j)) & 0xFF;
+          uint32_t m = S.cmask[cc];
+          const int nvm1 = __popc(m) - 1;
+          const uint64_t uw = u.v[j];
+          int w = 0;
+          for (int i = 0; i < nvm1; i++) w += (uw >= S.thr[cc * tw + i]) ? 1 : 0;
+          for (int i = 0; i < w; i++) m &= m - 1;   // drop the w lowest compatible isoforms
+          const int sel = __ffs(m) - 1;
+          atomicAdd(&S.cnt[sel], 1);
+          if (write_ass) drawass[r] = static_cast<uint8_t>(sel);
+        }
+      }
+      wave_sync();
+      return;
+    }
     int64_t acc = 0; int bad = 0;
     const bool small = Kw <= 8;
     double ps[8];

@@ -18,7 +18,9 @@ namespace miso {
 template <bool PE> __global__ void sampler_wave(const KernelArgs a);
 template <int G, bool PE> __global__ void sampler_k2(const KernelArgs a);
 template <int G, bool PE> __global__ void sampler_grp(const KernelArgs a);
-static inline int grp_slice_bytes(int ks) { return 10 * ks * 8 + 2 * ks * 4; }
+static inline int grp_slice_bytes(int ks) {  // must match kernels_grp.hip
+  return 10 * ks * 8 + 2 * ks * 4 + MAX_DRAW_CLASSES * (ks - 1) * 8 + MAX_DRAW_CLASSES * 4;
+}
 __global__ void selftest_detmath_kernel(const double *, int, double *, double *, double *, double *);
 __global__ void selftest_philox_kernel(const uint32_t *, int, uint32_t *);
 
@@ -101,6 +103,9 @@ void miso_batch::upload(int dev) {
     d.off_draw = in_off;
     in_off = align_up(in_off + (e.paired ? e.draw_frag.size() * 2
                                          : align_up(e.draw_mask.size(), 4) * 4), 16);
+    d.n_dcls = static_cast<int32_t>(e.dcls_mask.size());
+    d.off_cls = in_off; in_off = align_up(in_off + align_up(e.draw_cls.size(), 4), 16);
+    d.off_clsmask = in_off; in_off = align_up(in_off + e.dcls_mask.size() * 4, 16);
     d.off_sfix = in_off; in_off = align_up(in_off + e.sfix_table.size() * 4, 16);
     d.off_samples = out_off; out_off = align_up(out_off + static_cast<uint64_t>(Sn) * e.K * 8, 16);
     d.off_loglik = out_off; out_off = align_up(out_off + static_cast<uint64_t>(Sn) * 8, 16);
@@ -123,6 +128,10 @@ void miso_batch::upload(int dev) {
     std::memcpy(h_in.data() + d.off_base, e.base_count.data(), e.base_count.size() * 4);
     if (e.paired) std::memcpy(h_in.data() + d.off_draw, e.draw_frag.data(), e.draw_frag.size() * 2);
     else std::memcpy(h_in.data() + d.off_draw, e.draw_mask.data(), e.draw_mask.size() * 4);
+    if (!e.draw_cls.empty()) {
+      std::memcpy(h_in.data() + d.off_cls, e.draw_cls.data(), e.draw_cls.size());
+      std::memcpy(h_in.data() + d.off_clsmask, e.dcls_mask.data(), e.dcls_mask.size() * 4);
+    }
     if (!e.sfix_table.empty())
       std::memcpy(h_in.data() + d.off_sfix, e.sfix_table.data(), e.sfix_table.size() * 4);
   }
@@ -224,6 +233,10 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
         if ((chains + cpw - 1) / cpw <= wave_slots) break;
       }
     }
+    // a forced (or odd) choice never exceeds the LDS budget: fewer chains per wavefront instead
+    while (G < 64 && (G < 2 || (G & (G - 1)) ||
+                      fp_bytes + 4 * static_cast<size_t>(64 / G) * grp_slice_bytes(gen_kmax) > 64 * 1024))
+      G = (G < 2) ? 2 : ((G & (G - 1)) ? 64 : G * 2);
     a.kstride = gen_kmax;
     if (G == 64) {
       const unsigned grid = static_cast<unsigned>((chains + 3) / 4);
