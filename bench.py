@@ -111,7 +111,7 @@ def main():
 
     from miso_amd import capi, workload
     dist = None
-    if world > 1:
+    if world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ):  # launched by torchrun
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
