@@ -53,6 +53,7 @@ struct KernelArgs {
   const int32_t *slot_event;  // this launch's events (indices into `events`), n_slots of them
   int32_t n_slots;
   int32_t kstride;          // sampler_grp: isoform stride of the per-chain LDS slices
+  int32_t qstride;          // sampler_grp: draw quads per chain the LDS slice can stage (0 = none)
   int32_t n_events;
   int32_t C, M, B, lag;     // chains, iterations (incl. burn-in), burn-in, lag
   int32_t start;            // MISO_START_AUTO / MISO_START_UNIFORM

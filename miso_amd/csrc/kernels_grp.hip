@@ -23,6 +23,14 @@
 
 #pragma clang fp contract(off)
 
+#ifdef MISO_K2_PROFILE
+#define GPROF_T(var) const uint64_t var = __builtin_readcyclecounter()
+#define GPROF_ADD(acc, t0, t1) acc += (t1) - (t0)
+#else
+#define GPROF_T(var)
+#define GPROF_ADD(acc, t0, t1)
+#endif
+
 namespace miso {
 
 namespace {
@@ -41,7 +49,9 @@ struct Slice {            // one chain's LDS slice; every array has `ks` entries
   double *psi, *alpha, *psiN, *alphaN, *ta, *tb, *tc, *cst, *isc, *hm1;
   int *cnt, *bas;  // picks of the drawing reads; reads with a single compatible isoform
   uint32_t *cmask; // SE class path: mask of every drawing-read class [MAX_DRAW_CLASSES]
-  uint64_t *thr;   // SE class path: integer thresholds [MAX_DRAW_CLASSES x (ks - 1)]
+  uint64_t *thr;   // SE class path: integer thresholds [MAX_DRAW_CLASSES x (ks - 1)], unused = 2^32
+  uint64_t *vl;    // SE class path: the class's compatible isoforms, one per byte, ascending [MAX_DRAW_CLASSES]
+  uint32_t *cq;    // SE class path: class id of every drawing read, four per word [qstride]
 };
 
 __device__ __forceinline__ Slice carve(unsigned char *base, int ks) {
@@ -52,7 +62,9 @@ __device__ __forceinline__ Slice carve(unsigned char *base, int ks) {
   s.cnt = reinterpret_cast<int *>(d + 10 * ks);
   s.bas = s.cnt + ks;
   s.thr = reinterpret_cast<uint64_t *>(reinterpret_cast<unsigned char *>(d) + 10 * ks * 8 + 2 * ks * 4);
-  s.cmask = reinterpret_cast<uint32_t *>(s.thr + MAX_DRAW_CLASSES * (ks - 1));
+  s.vl = s.thr + MAX_DRAW_CLASSES * (ks - 1);
+  s.cmask = reinterpret_cast<uint32_t *>(s.vl + MAX_DRAW_CLASSES);
+  s.cq = s.cmask + MAX_DRAW_CLASSES;
   return s;
 }
 
@@ -85,8 +97,9 @@ template <bool LE> __device__ __forceinline__ uint64_t draw_threshold(double c, 
 }  // namespace
 
 // bytes of LDS one chain needs for isoform stride ks (ks even)
-__host__ __device__ inline int grp_slice_bytes(int ks) {
-  return 10 * ks * 8 + 2 * ks * 4 + MAX_DRAW_CLASSES * (ks - 1) * 8 + MAX_DRAW_CLASSES * 4;
+__host__ __device__ inline int grp_slice_bytes(int ks, int qs) {
+  return 10 * ks * 8 + 2 * ks * 4 + MAX_DRAW_CLASSES * (ks - 1) * 8 + MAX_DRAW_CLASSES * 8 +
+         MAX_DRAW_CLASSES * 4 + ((qs + 1) & ~1) * 4;
 }
 
 template <int G, bool PE>
@@ -108,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void sampler_grp(const KernelArgs a) {
   const bool live = slot < n_chains;
   if (!live) slot = n_chains - 1;           // shadow a real chain, store nothing
   const int ks = a.kstride;
-  const Slice S = carve(smem + fp_bytes + (static_cast<size_t>(wave) * CPW + grp) * grp_slice_bytes(ks), ks);
+  const Slice S = carve(smem + fp_bytes + (static_cast<size_t>(wave) * CPW + grp) * grp_slice_bytes(ks, a.qstride), ks);
 
   const int ev = a.slot_event[slot / a.C];
   const uint32_t chain = static_cast<uint32_t>(slot % a.C);
@@ -119,6 +132,10 @@ __global__ __launch_bounds__(256, 2) void sampler_grp(const KernelArgs a) {
     Kw = max(Kw, __shfl_xor(Kw, off));
     nqw = max(nqw, __shfl_xor(nqw, off));
   }
+  // tell the compiler these bounds are wave-uniform: otherwise every loop over them becomes a
+  // divergent loop with exec masking and an LDS wait per step (measured: 8x slower read loop)
+  Kw = __builtin_amdgcn_readfirstlane(Kw);
+  nqw = __builtin_amdgcn_readfirstlane(nqw);
   const uint32_t event_id = a.first_event_id + static_cast<uint32_t>(ev);
   const double *consts = reinterpret_cast<const double *>(a.in_pool + E.off_consts);
   const int *base = reinterpret_cast<const int *>(a.in_pool + E.off_base);
@@ -133,12 +150,24 @@ __global__ __launch_bounds__(256, 2) void sampler_grp(const KernelArgs a) {
   const uint8_t *clsq = a.in_pool + E.off_cls;
   const int n_dcls = PE ? 0 : E.n_dcls;
   int ncw = n_dcls;
-  bool cls_ok = !PE && (n_dcls > 0 || E.n_draw == 0);
+  bool cls_ok = !PE && (n_dcls > 0 || E.n_draw == 0) && ((E.n_draw + 3) >> 2) <= a.qstride;
   for (int off = 32; off >= 1; off >>= 1) { ncw = max(ncw, __shfl_xor(ncw, off)); }
   cls_ok = __all(cls_ok);
+  ncw = __builtin_amdgcn_readfirstlane(ncw);
   if (cls_ok) {
     const uint32_t *gm = reinterpret_cast<const uint32_t *>(a.in_pool + E.off_clsmask);
-    for (int c0 = 0; c0 < ncw; c0 += G) { const int cc = c0 + sub; if (cc < n_dcls) S.cmask[cc] = gm[cc]; }
+    for (int c0 = 0; c0 < ncw; c0 += G) {
+      const int cc = c0 + sub;
+      if (cc < n_dcls) {
+        const uint32_t m = gm[cc];
+        uint64_t v = 0; int j = 0;
+        for (int k = 0; k < K && j < 8; k++) if ((m >> k) & 1u) { v |= static_cast<uint64_t>(k) << (8 * j); j++; }
+        S.cmask[cc] = m; S.vl[cc] = v;
+      }
+    }
+    // the class ids stay in LDS for the whole run: the read loop never waits on global memory
+    const uint32_t *gq = reinterpret_cast<const uint32_t *>(clsq);
+    for (int q0 = 0; q0 < nqw; q0 += G) { const int q = q0 + sub; if (q < ((E.n_draw + 3) >> 2)) S.cq[q] = gq[q]; }
   }
   wave_sync();
   Scalars c;
@@ -156,8 +185,12 @@ __global__ __launch_bounds__(256, 2) void sampler_grp(const KernelArgs a) {
   const int n_draw = E.n_draw, n_quads = (n_draw + 3) >> 2;
   int64_t rfix = 0; int rbad = 0;
 
+#ifdef MISO_K2_PROFILE
+  uint64_t gp_thr = 0, gp_loop = 0, gp_mh = 0;
+#endif
   // ---- Gibbs step for the chain's current psi (in S.psi) ----
   auto gibbs = [&](uint32_t iter, bool write_ass) {
+    GPROF_T(t0);
     for (int k0 = 0; k0 < Kw; k0 += G) { const int k = k0 + sub; if (k < K) S.cnt[k] = 0; }
     wave_sync();
     if (!PE && cls_ok) {
@@ -179,33 +212,52 @@ __global__ __launch_bounds__(256, 2) void sampler_grp(const KernelArgs a) {
             S.thr[cc * tw + j] = run;
             j++;
           }
+          for (; j < tw; j++) S.thr[cc * tw + j] = 4294967296ull;  // never reached by a 32-bit word
         }
       }
       wave_sync();
-      const uint32_t *cq = reinterpret_cast<const uint32_t *>(clsq);
+      GPROF_T(t1);
+      GPROF_ADD(gp_thr, t0, t1);
+      const uint32_t *cq = S.cq;
+      const int tww = Kw - 1;   // wave-uniform number of thresholds to test (<= 7)
       for (int q0 = 0; q0 < nqw; q0 += G) {
         const int q = q0 + sub;
         const bool active = q < n_quads;
         const miso_u32x4 u = miso_draw_block(a.seed, event_id, chain, iter, MISO_SITE_GIBBS,
                                              static_cast<uint32_t>(q));
         const uint32_t c4 = active ? cq[q] : 0u;
+        int sel4[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {      // straight-line: all LDS reads of the quad issue together
+          const int cc = (c4 >> (8 * j)) & 0xFF;
+          const uint64_t *row = S.thr + cc * tw;
+          const uint64_t vl = S.vl[cc];
+          const uint64_t uw = u.v[j];
+          int w = 0;
+          if (tww <= 7) {      // K <= 8: fixed, fully unrolled scan; isoform list packed in one word
+#pragma unroll
+            for (int i = 0; i < 7; i++) if (i < tww) w += (uw >= row[i]) ? 1 : 0;
+            sel4[j] = static_cast<int>((vl >> (8 * w)) & 0xFF);
+          } else {             // more isoforms: scan the class's thresholds, then walk its mask
+            uint32_t m = S.cmask[cc];
+            const int nvm1 = __popc(m) - 1;
+            for (int i = 0; i < nvm1; i++) w += (uw >= row[i]) ? 1 : 0;
+            for (int i = 0; i < w; i++) m &= m - 1;
+            sel4[j] = __ffs(m) - 1;
+          }
+        }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           const int r = 4 * q + j;
-          if (!(active && r < n_draw)) continue;
-          const int cc = (c4 >> (8 * j)) & 0xFF;
-          uint32_t m = S.cmask[cc];
-          const int nvm1 = __popc(m) - 1;
-          const uint64_t uw = u.v[j];
-          int w = 0;
-          for (int i = 0; i < nvm1; i++) w += (uw >= S.thr[cc * tw + i]) ? 1 : 0;
-          for (int i = 0; i < w; i++) m &= m - 1;   // drop the w lowest compatible isoforms
-          const int sel = __ffs(m) - 1;
-          atomicAdd(&S.cnt[sel], 1);
-          if (write_ass) drawass[r] = static_cast<uint8_t>(sel);
+          if (active && r < n_draw) {
+            atomicAdd(&S.cnt[sel4[j]], 1);
+            if (write_ass) drawass[r] = static_cast<uint8_t>(sel4[j]);
+          }
         }
       }
       wave_sync();
+      GPROF_T(t2);
+      GPROF_ADD(gp_loop, t1, t2);
       return;
     }
     int64_t acc = 0; int bad = 0;
@@ -396,6 +448,7 @@ __global__ __launch_bounds__(256, 2) void sampler_grp(const KernelArgs a) {
         const int k = k0 + sub;
         if (k < K) trace[(static_cast<size_t>(m) * a.C + chain) * K + k] = count_of(k);
       }
+    GPROF_T(m0);
     propose(S.alpha, S.alphaN, S.psiN, static_cast<uint32_t>(m), accept_word);
     const double rp = PE ? (rbad ? miso_u2d(0x7FF8000000000000ull)
                                  : static_cast<double>(rfix) * (1.0 / MISO_SFIX_SCALE))
@@ -416,6 +469,8 @@ __global__ __launch_bounds__(256, 2) void sampler_grp(const KernelArgs a) {
       cJS = pp; accepted++;
     }
     wave_sync();
+    GPROF_T(m1);
+    GPROF_ADD(gp_mh, m0, m1);
     if (m >= a.B) {  // miso.c:882-893
       if (lagCounter == a.lag - 1) {
         if (live) {
@@ -432,6 +487,11 @@ __global__ __launch_bounds__(256, 2) void sampler_grp(const KernelArgs a) {
     gibbs(static_cast<uint32_t>(m), live && chain == 0 && m == a.M - 1);
   }
   for (int k = 0; k < K; k++) hash = (hash ^ static_cast<uint32_t>(count_of(k))) * 0x100000001B3ull;
+#ifdef MISO_K2_PROFILE
+  if (live && sub == 0 && chain == 0 && a.M > 8) {
+    loglik[0] = static_cast<double>(gp_mh); loglik[1] = static_cast<double>(gp_thr); loglik[2] = static_cast<double>(gp_loop);
+  }
+#endif
   if (live) {
     if (trace)
       for (int k0 = 0; k0 < Kw; k0 += G) {

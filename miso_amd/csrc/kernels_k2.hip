@@ -239,6 +239,8 @@ __global__ __launch_bounds__(256, 2) void sampler_k2(const KernelArgs a) {
     trips = max(trips, __shfl_xor(trips, off));
     any_rem |= __shfl_xor(any_rem, off);
   }
+  trips = __builtin_amdgcn_readfirstlane(trips);     // wave-uniform by construction: say so
+  any_rem = __builtin_amdgcn_readfirstlane(any_rem);
 
   double *samples = reinterpret_cast<double *>(a.out_pool + E.off_samples);
   double *loglik = reinterpret_cast<double *>(a.out_pool + E.off_loglik);
