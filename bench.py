@@ -82,6 +82,21 @@ def cpu_baseline(a):
             "value_1core": round(per_proc / (sum(times) / len(times)), 3)}
 
 
+def measured_traffic(kernel, a):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/traffic.json, written by tools/prof_summary.py from separate FETCH_SIZE / WRITE_SIZE
+    runs of this same command; FETCH_SIZE doubled per MI355X_MICROARCH.md).  None when no profile
+    of exactly this workload is committed."""
+    try:
+        table = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    except (OSError, ValueError):
+        return None
+    key = "%s|events=%d|K=%d|reads=%d|iters=%d|chains=%d|paired=%d" % (
+        kernel, a.events, a.K, a.reads, a.iters, a.chains, int(a.paired))
+    rec = table.get(key)
+    return None if rec is None else rec["hbm_bytes_per_launch"]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -173,8 +188,8 @@ def main():
                        "parallelism": "static event shard x%d, no collective" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": None,
-                         "kernel": "sampler_wave", "kernel_ms": round(avg_ms, 3),
+                         "traffic": measured_traffic(batch.last_kernels(), a),
+                         "kernel": batch.last_kernels(), "kernel_ms": round(avg_ms, 3),
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "algorithmic bytes = what the reference algorithm streams "
                                  "(SURVEY 8d: (8K+20)N per chain-iteration); the kernel keeps the "

@@ -187,6 +187,9 @@ int miso_batch_get_result(const miso_batch_t *batch, int event_index, double *sa
 int miso_batch_get_trace(const miso_batch_t *batch, int event_index, uint64_t *counts_hash,
                          int32_t *counts_trace);
 
+/* names of the kernels the last launch used (for profiles): e.g. "sampler_k2<3, false>" */
+int miso_batch_last_kernels(const miso_batch_t *batch, char *buf, int buflen);
+
 /* bytes the kernels of the last launch moved by the reference algorithm's accounting
    (SE (8K+20)N, PE (8K+28)N per chain-iteration + load/store) */
 int miso_batch_algorithmic_bytes(const miso_batch_t *batch, double *bytes);

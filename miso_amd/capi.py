@@ -235,6 +235,11 @@ class Batch:
     def run(self, device=0, seed=0, first_event_id=0):
         check(lib().miso_batch_run(self.handle, int(device), int(seed), int(first_event_id)))
 
+    def last_kernels(self):
+        buf = C.create_string_buffer(256)
+        check(lib().miso_batch_last_kernels(self.handle, buf, 256))
+        return buf.value.decode()
+
     def algorithmic_bytes(self):
         b = C.c_double(0)
         check(lib().miso_batch_algorithmic_bytes(self.handle, C.byref(b)))

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <string>
 #include <vector>
 
 #include "device.hpp"
@@ -34,6 +35,7 @@ struct miso_batch {
   int n_k2 = 0, n_gen = 0;
   int gen_kmax = 2, gen_maxq = 1;  // over the general-kernel events
   int lanes_per_chain = 0;        // G of the last sampler_k2 launch (0 = none)
+  std::string last_kernels;       // names of the kernels of the last launch, comma separated
   int wave_slots = 2048;          // resident sampler_k2 wavefronts on the device
   std::vector<miso::DevEvent> h_events;
   std::vector<unsigned char> h_out;

@@ -267,6 +267,14 @@ int miso_batch_get_trace(const miso_batch_t *b, int i, uint64_t *counts_hash, in
   });
 }
 
+int miso_batch_last_kernels(const miso_batch_t *b, char *buf, int buflen) {
+  return guarded([&] {
+    need(b, "batch"); need(buf, "buf");
+    if (buflen <= static_cast<int>(b->last_kernels.size())) MISO_FAIL(MISO_EINVAL, "buffer too small");
+    std::strcpy(buf, b->last_kernels.c_str());
+  });
+}
+
 int miso_batch_algorithmic_bytes(const miso_batch_t *b, double *bytes) {
   return guarded([&] {
     need(b, "batch"); need(bytes, "bytes");

@@ -139,29 +139,50 @@ __device__ __forceinline__ double lane_bcast(double v, int src_lane) {
   return miso_u2d((static_cast<uint64_t>(hi) << 32) | lo);
 }
 
-// Evaluate routine f on N arguments with NR lanes of the chain working in parallel: lane with
-// role r evaluates argument g*NR + r, results are broadcast back to every lane of the chain.
-// NR == 1 is the plain scalar form.  QUAD: the chain's lanes start on a quad boundary.
-template <int NR, bool QUAD, int N, class F>
-__device__ __forceinline__ void vec_eval(F f, const double (&in)[N], double (&out)[N], int role, int base) {
-#pragma unroll
-  for (int g = 0; g < (N + NR - 1) / NR; g++) {
-    double arg = in[g * NR];
-#pragma unroll
-    for (int r = 1; r < NR; r++)
-      if (g * NR + r < N) arg = (role == r) ? in[g * NR + r] : arg;
-    const double y = f(arg);
-    if (NR == 1) { out[g] = y; continue; }
-#pragma unroll
-    for (int r = 0; r < NR; r++) {
-      if (g * NR + r >= N) continue;
-      if (QUAD && NR == 4) {
-        out[g * NR + r] = r == 0 ? quad_bcast<0>(y) : r == 1 ? quad_bcast<1>(y) : r == 2 ? quad_bcast<2>(y) : quad_bcast<3>(y);
-      } else {
-        out[g * NR + r] = lane_bcast(y, base + r);
-      }
-    }
+// Evaluate routine f on 3 or 4 arguments with NR lanes of the chain working in parallel: the lane
+// with role r evaluates argument r, results are broadcast back to every lane of the chain
+// (NR == 1: plain scalar calls).  QUAD: the chain's lanes start on a quad boundary (DPP broadcast).
+// Written with scalars only -- argument arrays end up on the stack (scratch) in some instantiations.
+template <int NR, bool QUAD, int R> __device__ __forceinline__ double role_bcast(double y, int base) {
+  if (QUAD && NR == 4) return quad_bcast<R>(y);
+  return lane_bcast(y, base + R);
+}
+
+template <int NR, bool QUAD, class F>
+__device__ __forceinline__ void vec_eval3(F f, double a0, double a1, double a2, double &o0, double &o1,
+                                          double &o2, int role, int base) {
+  if (NR == 1) { o0 = f(a0); o1 = f(a1); o2 = f(a2); return; }
+  if (NR == 2) {
+    const double y = f(role == 1 ? a1 : a0);
+    o0 = role_bcast<NR, QUAD, 0>(y, base); o1 = role_bcast<NR, QUAD, 1>(y, base);
+    o2 = f(a2);
+    return;
   }
+  const double y = f(role == 1 ? a1 : (role == 2 ? a2 : a0));
+  o0 = role_bcast<NR, QUAD, 0>(y, base); o1 = role_bcast<NR, QUAD, 1>(y, base);
+  o2 = role_bcast<NR, QUAD, 2>(y, base);
+}
+
+template <int NR, bool QUAD, class F>
+__device__ __forceinline__ void vec_eval4(F f, double a0, double a1, double a2, double a3, double &o0,
+                                          double &o1, double &o2, double &o3, int role, int base) {
+  if (NR == 1) { o0 = f(a0); o1 = f(a1); o2 = f(a2); o3 = f(a3); return; }
+  if (NR == 2) {
+    const double y = f(role == 1 ? a1 : a0), z = f(role == 1 ? a3 : a2);
+    o0 = role_bcast<NR, QUAD, 0>(y, base); o1 = role_bcast<NR, QUAD, 1>(y, base);
+    o2 = role_bcast<NR, QUAD, 0>(z, base); o3 = role_bcast<NR, QUAD, 1>(z, base);
+    return;
+  }
+  if (NR == 3) {
+    const double y = f(role == 1 ? a1 : (role == 2 ? a2 : a0));
+    o0 = role_bcast<NR, QUAD, 0>(y, base); o1 = role_bcast<NR, QUAD, 1>(y, base);
+    o2 = role_bcast<NR, QUAD, 2>(y, base);
+    o3 = f(a3);
+    return;
+  }
+  const double y = f(role == 1 ? a1 : (role == 2 ? a2 : (role == 3 ? a3 : a0)));
+  o0 = role_bcast<NR, QUAD, 0>(y, base); o1 = role_bcast<NR, QUAD, 1>(y, base);
+  o2 = role_bcast<NR, QUAD, 2>(y, base); o3 = role_bcast<NR, QUAD, 3>(y, base);
 }
 
 // Philox4x32-10 block (q, iter, site|chain, event) with round 0 split into chain / iteration
@@ -194,7 +215,7 @@ __device__ __forceinline__ miso_u32x4 philox_gibbs(const GibbsRng &g, uint32_t q
 }  // namespace
 
 template <int G, bool PE>
-__global__ __launch_bounds__(256, 2) void sampler_k2(const KernelArgs a) {
+__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void sampler_k2(const KernelArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_k2[];
   double *lds_fp = reinterpret_cast<double *>(smem_k2);  // PE: fragment-length probabilities
   if (PE) {
@@ -272,13 +293,15 @@ __global__ __launch_bounds__(256, 2) void sampler_k2(const KernelArgs a) {
   double alpha = 0.0;
 
   // paired-end pick of one read (miso_paired.c:11-22, 64-68): weights psi_k * fragProb(frag_k)
-  auto pe_pick = [&](uint32_t ff, uint32_t uword, int64_t &acc, int &bad) {
+  auto pe_pick = [&](uint32_t ff, uint32_t uword, int64_t &acc, int &bad) __attribute__((always_inline)) {
     const uint32_t f0 = ff & 0xFFFFu, f1 = ff >> 16;
     const double c0 = 0.0 + cur.x0 * lds_fp[f0];
     const double T = c0 + cur.x1 * lds_fp[f1];
     const bool p0 = miso_u01(uword) * T < c0;
     const int32_t v = lds_tab[p0 ? f0 : a.il + f1];
-    if (v == SFIX_BAD) bad = 1; else acc += v;
+    const bool isbad = v == SFIX_BAD;
+    bad |= isbad ? 1 : 0;
+    acc += isbad ? 0 : v;
     return p0;
   };
 
@@ -420,26 +443,21 @@ __global__ __launch_bounds__(256, 2) void sampler_k2(const KernelArgs a) {
       auto f_log = [](double v) { return miso_det_log(v); };
       auto f_exp = [](double v) { return miso_det_exp(v); };
       const double ltheta = 1.0 - x0;
-      const double inB[3] = {x0, x1, x0 / ltheta};
-      double outB[3];
-      vec_eval<NR, QUAD>(f_log, inB, outB, role, base_lane);
-      nw.x0 = x0; nw.x1 = x1;
-      nw.lx0 = outB[0]; nw.lx1 = outB[1]; nw.lgt = outB[2];
+      double lgtN;
+      vec_eval3<NR, QUAD>(f_log, x0, x1, x0 / ltheta, nw.lx0, nw.lx1, lgtN, role, base_lane);
+      nw.x0 = x0; nw.x1 = x1; nw.lgt = lgtN;
       nw.pr = 1.0 / (1.0 * x0) / ltheta;
       const double lp0 = nw.lx0 + c.cst0, lp1 = nw.lx1 + c.cst1;
       const double maxv = (lp1 > lp0) ? lp1 : lp0;  // miso.c:137-140: maxv starts at entry 0
-      const double inC[4] = {lp0 - maxv, lp1 - maxv,
-                             prop_exponent(cur.lgt, alphaN, c.sigma),   // theta = psi,  mu = alpha'
-                             prop_exponent(nw.lgt, alpha, c.sigma)};    // theta = psi', mu = alpha
-      double outC[4];
-      vec_eval<NR, QUAD>(f_exp, inC, outC, role, base_lane);
-      const double inD[3] = {(0.0 + outC[0]) + outC[1], c.covar * cur.pr * outC[2],
-                             c.covar * nw.pr * outC[3]};
-      double outD[3];
-      vec_eval<NR, QUAD>(f_log, inD, outD, role, base_lane);
-      const double lse = outD[0] + maxv;
-      ptoCS = outD[1];
-      ctoPS = outD[2];
+      double ex0, ex1, xp, xc;
+      vec_eval4<NR, QUAD>(f_exp, lp0 - maxv, lp1 - maxv,
+                          prop_exponent(cur.lgt, alphaN, c.sigma),   // theta = psi,  mu = alpha'
+                          prop_exponent(nw.lgt, alpha, c.sigma),     // theta = psi', mu = alpha
+                          ex0, ex1, xp, xc, role, base_lane);
+      double ls;
+      vec_eval3<NR, QUAD>(f_log, (0.0 + ex0) + ex1, c.covar * cur.pr * xp, c.covar * nw.pr * xc, ls, ptoCS,
+                          ctoPS, role, base_lane);
+      const double lse = ls + maxv;
       nw.lpn0 = lp0 - lse;
       nw.lpn1 = lp1 - lse;
     }

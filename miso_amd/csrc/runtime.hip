@@ -186,6 +186,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   HIP_OK(hipMemsetAsync(d_out, 0, out_bytes, stream));  // trailing sample columns stay 0 (miso.c:661)
   HIP_OK(hipEventRecord(ev0, stream));                  // events bracket the sampler kernel only
   lanes_per_chain = 0;
+  last_kernels.clear();
   if (n_k2 > 0) {
     const long chains = static_cast<long>(n_k2) * p.noChains;
     const int maxq = (events[k2_first_event()].n_draw + 3) / 4;
@@ -196,6 +197,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     const int max_cpw = p.paired ? std::max<int>(1, static_cast<int>((60 * 1024 - k2_fp) / (4 * k2_tab))) : 64;
     if (!G) G = choose_lanes_per_chain(chains, maxq, wave_slots, max_cpw);
     lanes_per_chain = G;
+    last_kernels = "sampler_k2<" + std::to_string(G) + (p.paired ? ", true>" : ", false>");
     a.slot_event = d_slots; a.n_slots = n_k2;
     const int cpw = 64 / std::max(G, 1);
     const unsigned grid = static_cast<unsigned>(((chains + cpw - 1) / cpw + 3) / 4);
@@ -241,6 +243,9 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
                       fp_bytes + 4 * static_cast<size_t>(64 / G) * grp_slice_bytes(gen_kmax, qs) > 64 * 1024))
       G = (G < 2) ? 2 : ((G & (G - 1)) ? 64 : G * 2);
     a.kstride = gen_kmax; a.qstride = qs;
+    last_kernels += std::string(last_kernels.empty() ? "" : ",") +
+                    (G == 64 ? std::string("sampler_wave<") : "sampler_grp<" + std::to_string(G) + ", ") +
+                    (p.paired ? "true>" : "false>");
     if (G == 64) {
       const unsigned grid = static_cast<unsigned>((chains + 3) / 4);
       const size_t lds = fp_bytes + 4 * 32 * sizeof(int);

@@ -43,6 +43,42 @@ def main(prof_dir, out):
     txt = "\n".join(lines) + "\n"
     open(out, "w").write(txt)
     print(txt)
+    update_traffic(prof_dir)
+
+
+def update_traffic(prof_dir):
+    """profiles/traffic.json: HBM bytes per launch of the sampler kernel of this profiled bench run.
+    FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE is doubled (gfx950 counts 64 B per 128 B request,
+    MI355X_MICROARCH.md section HBM); WRITE_SIZE is taken as reported (uncalibrated there)."""
+    import json
+    try:
+        bench = json.loads(open(os.path.join(prof_dir, "bench_trace.json")).read().strip().split("\n")[-1])
+        fdb = glob.glob(os.path.join(prof_dir, "pmc_fetch", "*.db"))[0]
+        wdb = glob.glob(os.path.join(prof_dir, "pmc_write", "*.db"))[0]
+    except (OSError, ValueError, IndexError):
+        return
+    def avg(db, counter):
+        _, rows = q(db, "select kernel_name, avg(value) from counters_collection where counter_name='%s' "
+                        "and kernel_name like '%%sampler_%%' group by kernel_name order by avg(value) desc" % counter)
+        return rows[0][1] if rows else None
+    fetch_kb, write_kb = avg(fdb, "FETCH_SIZE"), avg(wdb, "WRITE_SIZE")
+    if fetch_kb is None or write_kb is None:
+        return
+    c = bench["config"]
+    key = "%s|events=%d|K=%d|reads=%d|iters=%d|chains=%d|paired=%d" % (
+        bench["roofline"]["kernel"], c["events_per_gpu"], c["K"], c["reads"], c["iters"], c["chains"],
+        int("paired-end" in c["workload"]))
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")
+    try:
+        table = json.load(open(path))
+    except (OSError, ValueError):
+        table = {}
+    table[key] = {"fetch_size_kb": fetch_kb, "write_size_kb": write_kb,
+                  "hbm_bytes_per_launch": 2 * fetch_kb * 1024 + write_kb * 1024,
+                  "source": os.path.basename(prof_dir.rstrip("/")),
+                  "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"]}
+    json.dump(table, open(path, "w"), indent=1, sort_keys=True)
+    print("traffic:", key, table[key])
 
 if __name__ == "__main__":
     main(sys.argv[1], sys.argv[2])
