@@ -54,6 +54,7 @@ struct KernelArgs {
   int32_t n_slots;
   int32_t kstride;          // sampler_grp: isoform stride of the per-chain LDS slices
   int32_t qstride;          // sampler_grp: draw quads per chain the LDS slice can stage (0 = none)
+  int32_t tstride;          // sampler_grp PE: score-table entries per chain staged in LDS (0 = none)
   int32_t n_events;
   int32_t C, M, B, lag;     // chains, iterations (incl. burn-in), burn-in, lag
   int32_t start;            // MISO_START_AUTO / MISO_START_UNIFORM

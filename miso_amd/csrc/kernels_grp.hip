@@ -52,6 +52,7 @@ struct Slice {            // one chain's LDS slice; every array has `ks` entries
   uint64_t *thr;   // SE class path: integer thresholds [MAX_DRAW_CLASSES x (ks - 1)], unused = 2^32
   uint64_t *vl;    // SE class path: the class's compatible isoforms, one per byte, ascending [MAX_DRAW_CLASSES]
   uint32_t *cq;    // SE class path: class id of every drawing read, four per word [qstride]
+  int32_t *stab;   // PE: the event's fixed-point score table [tstride] (when it fits)
 };
 
 __device__ __forceinline__ Slice carve(unsigned char *base, int ks) {
@@ -65,10 +66,46 @@ __device__ __forceinline__ Slice carve(unsigned char *base, int ks) {
   s.vl = s.thr + MAX_DRAW_CLASSES * (ks - 1);
   s.cmask = reinterpret_cast<uint32_t *>(s.vl + MAX_DRAW_CLASSES);
   s.cq = s.cmask + MAX_DRAW_CLASSES;
+  s.stab = nullptr;
   return s;
 }
 
 struct Scalars { double lg_sum, lg_each, sigma, sd, covar; };
+
+// One read's pick by direct evaluation of the reference's scan (miso.c:11-22, 69-80; paired-end
+// miso_paired.c:11-22, 64-75) for at most KK isoforms, fully unrolled, everything in registers.
+template <int KK, bool PE>
+__device__ __forceinline__ int pick_direct(const double (&ps)[8], uint32_t mask, const uint16_t *fr_row,
+                                           int K, const double *lds_fp, bool on, uint32_t uword,
+                                           uint16_t &fsel) {
+  double w[KK]; uint16_t fr[KK]; bool val[KK];
+  double T = 0.0; int nv = 0;
+#pragma unroll
+  for (int k = 0; k < KK; k++) {
+    fr[k] = FRAG_NONE;
+    if (PE) {
+      if (on && k < K) fr[k] = fr_row[k];
+      val[k] = fr[k] != FRAG_NONE;
+      w[k] = ps[k] * lds_fp[val[k] ? fr[k] : 0];
+    } else {
+      val[k] = on && ((mask >> k) & 1u);
+      w[k] = ps[k];
+    }
+    if (val[k]) { T = T + w[k]; nv++; }
+  }
+  const double rnd = miso_u01(uword) * T;
+  double cum = 0.0; int idx = 0, sel = -1;
+#pragma unroll
+  for (int k = 0; k < KK; k++) {
+    if (val[k]) {
+      cum = cum + w[k];
+      const bool stop = (nv == 2) ? (idx == 0 ? (rnd < cum) : true) : !(rnd > cum);
+      idx++;
+      if (sel < 0 && (stop || idx == nv)) { sel = k; fsel = fr[k]; }
+    }
+  }
+  return sel;
+}
 
 // The reference's draw compares rnd = fl(fl(u 2^-32) T) with a cumulative weight c: `rnd < c` when two
 // isoforms are compatible, `!(rnd > c)` otherwise (miso.c:69-79).  Both are monotone in the 32-bit
@@ -97,9 +134,9 @@ template <bool LE> __device__ __forceinline__ uint64_t draw_threshold(double c, 
 }  // namespace
 
 // bytes of LDS one chain needs for isoform stride ks (ks even)
-__host__ __device__ inline int grp_slice_bytes(int ks, int qs) {
+__host__ __device__ inline int grp_slice_bytes(int ks, int qs, int ts) {
   return 10 * ks * 8 + 2 * ks * 4 + MAX_DRAW_CLASSES * (ks - 1) * 8 + MAX_DRAW_CLASSES * 8 +
-         MAX_DRAW_CLASSES * 4 + ((qs + 1) & ~1) * 4;
+         MAX_DRAW_CLASSES * 4 + ((qs + 1) & ~1) * 4 + ((ts + 1) & ~1) * 4;
 }
 
 template <int G, bool PE>
@@ -121,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void sampler_grp(const KernelArgs a) {
   const bool live = slot < n_chains;
   if (!live) slot = n_chains - 1;           // shadow a real chain, store nothing
   const int ks = a.kstride;
-  const Slice S = carve(smem + fp_bytes + (static_cast<size_t>(wave) * CPW + grp) * grp_slice_bytes(ks, a.qstride), ks);
+  const Slice S = carve(smem + fp_bytes + (static_cast<size_t>(wave) * CPW + grp) * grp_slice_bytes(ks, a.qstride, a.tstride), ks);
 
   const int ev = a.slot_event[slot / a.C];
   const uint32_t chain = static_cast<uint32_t>(slot % a.C);
@@ -177,6 +214,12 @@ __global__ __launch_bounds__(256, 2) void sampler_grp(const KernelArgs a) {
   const uint32_t *masks = reinterpret_cast<const uint32_t *>(a.in_pool + E.off_draw);
   const uint16_t *frags = reinterpret_cast<const uint16_t *>(a.in_pool + E.off_draw);
   const int32_t *sfix = reinterpret_cast<const int32_t *>(a.in_pool + E.off_sfix);
+  if (PE && a.tstride > 0) {  // score table into the chain's slice: no per-read gather from L2
+    int32_t *stab = reinterpret_cast<int32_t *>(S.cq + ((a.qstride + 1) & ~1));
+    for (int i = sub; i < K * a.il; i += G) stab[i] = sfix[i];
+    sfix = stab;
+    wave_sync();
+  }
   double *samples = reinterpret_cast<double *>(a.out_pool + E.off_samples);
   double *loglik = reinterpret_cast<double *>(a.out_pool + E.off_loglik);
   uint8_t *drawass = a.out_pool + E.off_drawass;
@@ -280,34 +323,16 @@ __global__ __launch_bounds__(256, 2) void sampler_grp(const KernelArgs a) {
         const int r = 4 * q + j;
         const bool on = active && r < n_draw;
         int sel = -1; uint16_t fsel = 0;
-        if (small) {   // K <= 8: psi and the read's weights stay in registers
-          double w[8]; uint16_t fr[8]; double T = 0.0; int nv = 0;
-#pragma unroll
-          for (int k = 0; k < 8; k++) {
-            w[k] = 0.0; fr[k] = FRAG_NONE;
-            bool valid;
-            if (PE) {
-              fr[k] = (on && k < K) ? frags[static_cast<size_t>(r) * K + k] : FRAG_NONE;
-              valid = fr[k] != FRAG_NONE;
-              if (valid) w[k] = ps[k] * lds_fp[fr[k]];
-            } else {
-              valid = on && ((m4[j] >> k) & 1u);
-              if (valid) w[k] = ps[k];
-            }
-            if (valid) { T = T + w[k]; nv++; }       // pass 1 (miso.c:11-22)
-            else fr[k] = FRAG_NONE, w[k] = -1.0;     // marks "not compatible"
-          }
-          const double rnd = miso_u01(u.v[j]) * T;
-          double cum = 0.0; int idx = 0;
-#pragma unroll
-          for (int k = 0; k < 8; k++) {               // pass 2 (miso.c:69-80)
-            const bool valid = w[k] >= 0.0;
-            if (valid) {
-              cum = cum + w[k];
-              const bool stop = (nv == 2) ? (idx == 0 ? (rnd < cum) : true) : !(rnd > cum);
-              idx++;
-              if (sel < 0 && (stop || idx == nv)) { sel = k; fsel = fr[k]; }
-            }
+        if (small) {   // K <= 8: exact unroll for the wavefront's isoform count
+          const uint16_t *row = frags + static_cast<size_t>(r) * K;
+          switch (Kw) {
+          case 2: sel = pick_direct<2, PE>(ps, m4[j], row, K, lds_fp, on, u.v[j], fsel); break;
+          case 3: sel = pick_direct<3, PE>(ps, m4[j], row, K, lds_fp, on, u.v[j], fsel); break;
+          case 4: sel = pick_direct<4, PE>(ps, m4[j], row, K, lds_fp, on, u.v[j], fsel); break;
+          case 5: sel = pick_direct<5, PE>(ps, m4[j], row, K, lds_fp, on, u.v[j], fsel); break;
+          case 6: sel = pick_direct<6, PE>(ps, m4[j], row, K, lds_fp, on, u.v[j], fsel); break;
+          case 7: sel = pick_direct<7, PE>(ps, m4[j], row, K, lds_fp, on, u.v[j], fsel); break;
+          default: sel = pick_direct<8, PE>(ps, m4[j], row, K, lds_fp, on, u.v[j], fsel); break;
           }
         } else {
           double T = 0.0; int nv = 0;   // pass 1: total weight, ascending k (miso.c:11-22)

@@ -18,9 +18,9 @@ namespace miso {
 template <bool PE> __global__ void sampler_wave(const KernelArgs a);
 template <int G, bool PE> __global__ void sampler_k2(const KernelArgs a);
 template <int G, bool PE> __global__ void sampler_grp(const KernelArgs a);
-static inline int grp_slice_bytes(int ks, int qs) {  // must match kernels_grp.hip
+static inline int grp_slice_bytes(int ks, int qs, int ts) {  // must match kernels_grp.hip
   return 10 * ks * 8 + 2 * ks * 4 + MAX_DRAW_CLASSES * (ks - 1) * 8 + MAX_DRAW_CLASSES * 8 +
-         MAX_DRAW_CLASSES * 4 + ((qs + 1) & ~1) * 4;
+         MAX_DRAW_CLASSES * 4 + ((qs + 1) & ~1) * 4 + ((ts + 1) & ~1) * 4;
 }
 __global__ void selftest_detmath_kernel(const double *, int, double *, double *, double *, double *);
 __global__ void selftest_philox_kernel(const uint32_t *, int, uint32_t *);
@@ -222,6 +222,9 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     const size_t fp_bytes = p.paired ? align_up(fd.prob.size() * 8, 16) : 0;
     // single-end: stage every drawing read's class id in LDS when that leaves room for >= 2 chains
     const int qs = (!p.paired && gen_maxq <= 2048) ? gen_maxq : 0;
+    // paired-end: the per-event score table (K x il int32) joins the slice when >= 4 chains still fit
+    int ts = p.paired ? gen_kmax * static_cast<int>(fd.prob.size()) : 0;
+    if (ts && fp_bytes + 4 * 4 * static_cast<size_t>(grp_slice_bytes(gen_kmax, 0, ts)) > 64 * 1024) ts = 0;
     // lanes per chain: as for sampler_k2, bounded by the LDS a workgroup's chains need
     int G = 64;
     const char *env = std::getenv("MISO_GENERAL_LANES");
@@ -232,7 +235,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       // choose_lanes_per_chain); smaller groups only when the batch overflows the device anyway
       for (int g : {32, 16, 8, 4, 2}) {
         const int cpw = 64 / g;
-        const size_t lds = fp_bytes + 4 * static_cast<size_t>(cpw) * grp_slice_bytes(gen_kmax, qs);
+        const size_t lds = fp_bytes + 4 * static_cast<size_t>(cpw) * grp_slice_bytes(gen_kmax, qs, ts);
         if (g > std::max(2, gen_maxq) || lds > 64 * 1024) continue;
         G = g;
         if ((chains + cpw - 1) / cpw <= wave_slots) break;
@@ -240,9 +243,9 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     }
     // a forced (or odd) choice never exceeds the LDS budget: fewer chains per wavefront instead
     while (G < 64 && (G < 2 || (G & (G - 1)) ||
-                      fp_bytes + 4 * static_cast<size_t>(64 / G) * grp_slice_bytes(gen_kmax, qs) > 64 * 1024))
+                      fp_bytes + 4 * static_cast<size_t>(64 / G) * grp_slice_bytes(gen_kmax, qs, ts) > 64 * 1024))
       G = (G < 2) ? 2 : ((G & (G - 1)) ? 64 : G * 2);
-    a.kstride = gen_kmax; a.qstride = qs;
+    a.kstride = gen_kmax; a.qstride = qs; a.tstride = ts;
     last_kernels += std::string(last_kernels.empty() ? "" : ",") +
                     (G == 64 ? std::string("sampler_wave<") : "sampler_grp<" + std::to_string(G) + ", ") +
                     (p.paired ? "true>" : "false>");
@@ -254,7 +257,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     } else {
       const int cpw = 64 / G;
       const unsigned grid = static_cast<unsigned>(((chains + cpw - 1) / cpw + 3) / 4);
-      const size_t lds = fp_bytes + 4 * static_cast<size_t>(cpw) * grp_slice_bytes(gen_kmax, qs);
+      const size_t lds = fp_bytes + 4 * static_cast<size_t>(cpw) * grp_slice_bytes(gen_kmax, qs, ts);
 #define MISO_GRP_LAUNCH(GG)                                                                          \
   case GG:                                                                                           \
     if (p.paired) hipLaunchKernelGGL((sampler_grp<GG, true>), dim3(grid), dim3(256), lds, stream, a); \
