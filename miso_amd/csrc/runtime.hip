@@ -221,7 +221,9 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     const long chains = static_cast<long>(n_gen) * p.noChains;
     const size_t fp_bytes = p.paired ? align_up(fd.prob.size() * 8, 16) : 0;
     // single-end: stage every drawing read's class id in LDS when that leaves room for >= 2 chains
-    const int qs = (!p.paired && gen_maxq <= 2048) ? gen_maxq : 0;
+    // MISO_NO_CLASS_PATH=1 (tests): force the direct mask path of sampler_grp
+    const bool no_cls = std::getenv("MISO_NO_CLASS_PATH") != nullptr;
+    const int qs = (!p.paired && !no_cls && gen_maxq <= 2048) ? gen_maxq : 0;
     // paired-end: the per-event score table (K x il int32) joins the slice when >= 4 chains still fit
     int ts = p.paired ? gen_kmax * static_cast<int>(fd.prob.size()) : 0;
     if (ts && fp_bytes + 4 * 4 * static_cast<size_t>(grp_slice_bytes(gen_kmax, 0, ts)) > 64 * 1024) ts = 0;

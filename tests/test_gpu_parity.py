@@ -102,9 +102,13 @@ def test_general_kernel_variants_agree(orc, paired):
     old = os.environ.pop("MISO_GENERAL_LANES", None)
     try:
         ref = None
-        for lanes in ("64", "2", "4", "8", "16", "32", None):
+        for lanes in ("64", "2", "4", "8", "16", "32", None, "8-nocls"):
+            os.environ.pop("MISO_NO_CLASS_PATH", None)
             if lanes is None:
                 os.environ.pop("MISO_GENERAL_LANES", None)
+            elif lanes.endswith("-nocls"):
+                os.environ["MISO_GENERAL_LANES"] = lanes.split("-")[0]
+                os.environ["MISO_NO_CLASS_PATH"] = "1"
             else:
                 os.environ["MISO_GENERAL_LANES"] = lanes
             b.run(seed=21, first_event_id=3)
@@ -120,6 +124,7 @@ def test_general_kernel_variants_agree(orc, paired):
                 assert x.rundata.noAccepted == y.rundata.noAccepted, lanes
     finally:
         os.environ.pop("MISO_GENERAL_LANES", None)
+        os.environ.pop("MISO_NO_CLASS_PATH", None)
         if old is not None:
             os.environ["MISO_GENERAL_LANES"] = old
     for i, (g, pos, cig) in enumerate(keep):   # and the wave kernel's answer is the oracle's
@@ -130,3 +135,66 @@ def test_general_kernel_variants_agree(orc, paired):
             cpu = orc.miso(g, pos, cig, 36, mode=OrcLib.COUNTER, seed=21, event_id=3 + i, trace=True, **kw)
         assert np.array_equal(ref[i].counts_trace, cpu.trace["counts_trace"]), i
         assert np.array_equal(ref[i].samples, cpu.samples), i
+
+
+@pytest.mark.parametrize("paired", [False, True])
+@pytest.mark.parametrize("K", [2, 4])
+def test_options_hyper_start_overhang(orc, K, paired):
+    """Non-default options of the reference signature: Dirichlet hyper-parameters != 1
+    (miso.c:165-182), START_UNIFORM (miso.c:372-387), overhang > 1 (miso.c:781)."""
+    hyper = list(np.linspace(0.7, 2.5, K))
+    kw = dict(iters=300, burn=60, lag=3, chains=2, overhang=3, start=1)
+    if paired:
+        exons, isoforms, g, pos, cig = simulate_pe(orc, K, 300, seed=500 + K)
+        b = miso_amd.Batch(36, paired=True, mean=250.0, var=900.0, counts_trace=True, **kw)
+        cpu = orc.miso_paired(g, pos, cig, 36, 250.0, 900.0, hyper=hyper, mode=OrcLib.COUNTER, seed=8,
+                              event_id=2, trace=True, **kw)
+    else:
+        exons, isoforms, g, pos, cig = simulate_se(orc, K, 400, seed=500 + K)
+        b = miso_amd.Batch(36, counts_trace=True, **kw)
+        cpu = orc.miso(g, pos, cig, 36, hyper=hyper, mode=OrcLib.COUNTER, seed=8, event_id=2,
+                       trace=True, **kw)
+    b.add_event(miso_amd.Gene(exons, isoforms), pos, cig, hyper=hyper)
+    b.run(seed=8, first_event_id=2)
+    _compare(b.result(0, trace=True), cpu, 2)
+
+
+def test_many_read_classes_fall_back_to_masks(orc):
+    """More than 32 distinct compatibility masks among the drawing reads: the class-threshold path
+    does not apply, the direct mask path must give the oracle's answer."""
+    K = 7
+    exons = [(1 + 300 * i, 200 + 300 * i) for i in range(K + 1)]
+    rng = np.random.default_rng(5)
+    isoforms = [sorted(set([0, K]) | set(int(e) for e in rng.choice(np.arange(1, K), size=rng.integers(2, K - 1), replace=False)))
+                for _ in range(K)]
+    g = orc.gene([c for e in exons for c in e], isoforms)
+    orc.rng_seed(77)
+    rc, iso, pos, cig = orc.simulate_reads(g, np.ones(K) / K, 1500, 36)
+    assert rc == 0
+    probe = orc.miso(g, pos, cig, 36, iters=5, burn=1, lag=1, chains=1)
+    kw = dict(iters=200, burn=40, lag=2, chains=2)
+    b = miso_amd.Batch(36, counts_trace=True, **kw)
+    b.add_event(miso_amd.Gene(exons, isoforms), pos, cig)
+    b.run(seed=13, first_event_id=1)
+    cpu = orc.miso(g, pos, cig, 36, mode=OrcLib.COUNTER, seed=13, event_id=1, trace=True, **kw)
+    _compare(b.result(0, trace=True), cpu, 2)
+    assert len(probe.class_counts) >= 8
+
+
+def test_large_event_and_thirty_two_isoforms(orc):
+    """An event with 60 000 reads (draw list far beyond one trip per lane) and a 32-isoform gene."""
+    exons, isoforms, g, pos, cig = simulate_se(orc, 2, 60000, seed=900)
+    b = miso_amd.Batch(36, iters=60, burn=10, lag=1, chains=1, counts_trace=True)
+    b.add_event(miso_amd.Gene(exons, isoforms), pos, cig)
+    exons32, isoforms32, g32, pos32, cig32 = simulate_se(orc, 32, 500, seed=901, exlen=60, gap=50)
+    b.add_event(miso_amd.Gene(exons32, isoforms32), pos32, cig32)
+    b.run(seed=3, first_event_id=0)
+    cpu = orc.miso(g, pos, cig, 36, iters=60, burn=10, lag=1, chains=1, mode=OrcLib.COUNTER, seed=3,
+                   event_id=0, trace=True)
+    _compare(b.result(0, trace=True), cpu, 1)
+    cpu32 = orc.miso(g32, pos32, cig32, 36, iters=60, burn=10, lag=1, chains=1, mode=OrcLib.COUNTER,
+                     seed=3, event_id=1, trace=True)
+    _compare(b.result(1, trace=True), cpu32, 1)
+    with pytest.raises(NotImplementedError):
+        e33, i33, *_ = simulate_se(orc, 33, 10, seed=902, exlen=60, gap=50)
+        miso_amd.Batch(36).add_event(miso_amd.Gene(e33, i33), pos32[:5], cig32[:5])
