@@ -114,6 +114,8 @@ def main():
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--cpu-events", type=int, default=12, help="reference events per host process")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--summarize", action="store_true",
+                    help="also time the device-side posterior summaries (outside the timed region)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -166,6 +168,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    summary_ms = None
+    if a.summarize:
+        t1 = time.perf_counter()
+        batch.summarize(0.95)
+        summary_ms = 1e3 * (time.perf_counter() - t1)
+
     if rank == 0:
         total_events = a.events * world * a.steps
         value = total_events / elapsed
@@ -197,6 +205,7 @@ def main():
                                  "claim -- see DESIGN.md"},
             "cpu_baseline": cpu,
             "host_build_s": round(t_build, 2),
+            "summary_ms": None if summary_ms is None else round(summary_ms, 3),
         }
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -187,6 +187,15 @@ int miso_batch_get_result(const miso_batch_t *batch, int event_index, double *sa
 int miso_batch_get_trace(const miso_batch_t *batch, int event_index, uint64_t *counts_hash,
                          int32_t *counts_trace);
 
+/* Posterior summaries on the device, from the samples of the last launch (after miso_batch_sync;
+   no miso_batch_download needed): what summarize_miso computes per event
+   (misopy/credible_intervals.py:4-72): per isoform the mean of psi and the Chen-Shao credible
+   interval = order statistics int(round(alpha/2 n)) - 1 and int(round((1-alpha/2) n)) - 1 of the
+   sorted samples, alpha = 1 - confidence_level.  mean / ci_low / ci_high: noiso doubles each. */
+int miso_batch_summarize(miso_batch_t *batch, double confidence_level);
+int miso_batch_get_summary(const miso_batch_t *batch, int event_index, double *mean, double *ci_low,
+                           double *ci_high);
+
 /* names of the kernels the last launch used (for profiles): e.g. "sampler_k2<3, false>" */
 int miso_batch_last_kernels(const miso_batch_t *batch, char *buf, int buflen);
 

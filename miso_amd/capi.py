@@ -55,6 +55,7 @@ def lib():
         _lib.miso_strerror.restype = C.c_char_p
         _lib.miso_batch_launch.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32]
         _lib.miso_batch_run.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint32]
+        _lib.miso_batch_summarize.argtypes = [C.c_void_p, C.c_double]
     return _lib
 
 
@@ -234,6 +235,18 @@ class Batch:
 
     def run(self, device=0, seed=0, first_event_id=0):
         check(lib().miso_batch_run(self.handle, int(device), int(seed), int(first_event_id)))
+
+    def summarize(self, confidence_level=0.95):
+        """Device-side posterior means and credible intervals of every event (no sample download)."""
+        check(lib().miso_batch_summarize(self.handle, C.c_double(confidence_level)))
+
+    def summary(self, i):
+        """(mean[K], ci_low[K], ci_high[K]) of event i after summarize()."""
+        K = C.c_int()
+        check(lib().miso_batch_event_info(self.handle, i, C.byref(K), None, None, None))
+        m, lo, hi = (np.zeros(K.value) for _ in range(3))
+        check(lib().miso_batch_get_summary(self.handle, i, _p(m), _p(lo), _p(hi)))
+        return m, lo, hi
 
     def last_kernels(self):
         buf = C.create_string_buffer(256)

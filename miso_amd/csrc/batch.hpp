@@ -39,6 +39,9 @@ struct miso_batch {
   int wave_slots = 2048;          // resident sampler_k2 wavefronts on the device
   std::vector<miso::DevEvent> h_events;
   std::vector<unsigned char> h_out;
+  std::vector<double> h_summary;        // per event: K x {mean, ci_low, ci_high}
+  std::vector<uint64_t> h_sum_off;      // offsets (in doubles) into h_summary
+  bool summarized = false;
   uint64_t in_bytes = 0, out_bytes = 0;
   float last_ms = 0.f;
 
@@ -56,4 +59,5 @@ struct miso_batch {
   void launch(uint64_t seed, uint32_t first_event_id);
   void sync(float *ms);
   void download();
+  void summarize(double confidence_level);
 };

@@ -267,6 +267,24 @@ int miso_batch_get_trace(const miso_batch_t *b, int i, uint64_t *counts_hash, in
   });
 }
 
+int miso_batch_summarize(miso_batch_t *b, double confidence_level) {
+  return guarded([&] { need(b, "batch"); b->summarize(confidence_level); });
+}
+
+int miso_batch_get_summary(const miso_batch_t *b, int i, double *mean, double *ci_low, double *ci_high) {
+  return guarded([&] {
+    need(b, "batch");
+    const PackedEvent &e = event_at(b, i);
+    if (!b->summarized) MISO_FAIL(MISO_EINVAL, "miso_batch_summarize has not run");
+    const double *s = b->h_summary.data() + b->h_sum_off[i];
+    for (int k = 0; k < e.K; k++) {
+      if (mean) mean[k] = s[3 * k];
+      if (ci_low) ci_low[k] = s[3 * k + 1];
+      if (ci_high) ci_high[k] = s[3 * k + 2];
+    }
+  });
+}
+
 int miso_batch_last_kernels(const miso_batch_t *b, char *buf, int buflen) {
   return guarded([&] {
     need(b, "batch"); need(buf, "buf");

@@ -17,6 +17,7 @@ namespace miso {
 
 template <bool PE> __global__ void sampler_wave(const KernelArgs a);
 template <int G, bool PE> __global__ void sampler_k2(const KernelArgs a);
+__global__ void summarize_kernel(const DevEvent *, const unsigned char *, int, int, int, int, const uint64_t *, double *);
 template <int G, bool PE> __global__ void sampler_grp(const KernelArgs a);
 static inline int grp_slice_bytes(int ks, int qs, int ts) {  // must match kernels_grp.hip
   return 10 * ks * 8 + 2 * ks * 4 + MAX_DRAW_CLASSES * (ks - 1) * 8 + MAX_DRAW_CLASSES * 8 +
@@ -274,7 +275,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     HIP_OK(hipGetLastError());
   }
   HIP_OK(hipEventRecord(ev1, stream));
-  launched = true; downloaded = false;
+  launched = true; downloaded = false; summarized = false;
 }
 
 void miso_batch::sync(float *ms) {
@@ -283,6 +284,36 @@ void miso_batch::sync(float *ms) {
   HIP_OK(hipStreamSynchronize(stream));
   HIP_OK(hipEventElapsedTime(&last_ms, ev0, ev1));
   if (ms) *ms = last_ms;
+}
+
+// Posterior mean and Chen-Shao credible interval of every isoform, computed where the samples are
+// (credible_intervals.py:31-55: order statistics int(round(alpha/2 n)) - 1 and
+// int(round((1 - alpha/2) n)) - 1, Python-2 rounding = half away from zero).
+void miso_batch::summarize(double confidence_level) {
+  if (!launched) MISO_FAIL(MISO_EINVAL, "batch not launched");
+  HIP_OK(hipSetDevice(device));
+  const int n = static_cast<int>(events.size()), Sn = S();
+  const double alpha = 1 - confidence_level;
+  const int lo = static_cast<int>(std::floor((alpha / 2) * Sn + 0.5)) - 1;
+  const int hi = static_cast<int>(std::floor((1 - alpha / 2) * Sn + 0.5)) - 1;
+  if (!(lo > 0 && hi > 0 && hi < Sn))   // the reference asserts both indices > 0
+    MISO_FAIL(MISO_EINVAL, "Too few samples for a credible interval");
+  h_sum_off.assign(n, 0);
+  uint64_t off = 0; int kmax = 1;
+  for (int i = 0; i < n; i++) { h_sum_off[i] = off; off += 3 * events[i].K; kmax = std::max(kmax, events[i].K); }
+  h_summary.assign(off, 0.0);
+  if (n == 0) { summarized = true; return; }
+  uint64_t *d_off = nullptr; double *d_sum = nullptr;
+  HIP_OK(hipMalloc(reinterpret_cast<void **>(&d_off), n * sizeof(uint64_t)));
+  HIP_OK(hipMalloc(reinterpret_cast<void **>(&d_sum), off * sizeof(double)));
+  HIP_OK(hipMemcpyAsync(d_off, h_sum_off.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+  hipLaunchKernelGGL(summarize_kernel, dim3(n, kmax), dim3(256), 0, stream, d_events, d_out, n, Sn, lo, hi,
+                     d_off, d_sum);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipMemcpyAsync(h_summary.data(), d_sum, off * sizeof(double), hipMemcpyDeviceToHost, stream));
+  HIP_OK(hipStreamSynchronize(stream));
+  (void) hipFree(d_off); (void) hipFree(d_sum);
+  summarized = true;
 }
 
 void miso_batch::download() {

@@ -21,6 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 if _HERE not in sys.path:
     sys.path.insert(0, _HERE)
 import pysplicing  # noqa: E402  (miso_amd/pysplicing)
+import summary  # noqa: E402  (miso_amd/summary.py)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -135,9 +136,11 @@ class MISOSampler:
     def run_sampler_batch(self, num_iters, events, num_chains=6, burn_in=1000, lag=2,
                           start_cond=pysplicing.MISO_START_AUTO,
                           stop_cond=pysplicing.MISO_STOP_FIXEDNO, seed=None, first_event_id=0,
-                          verbose=False):
+                          verbose=False, summary_file=None, confidence_level=0.95):
         """events: list of (reads, gene, output_file[, prior_params]); same per-event skip rules as
-        run_sampler.  Returns the list of written file names (None for skipped events)."""
+        run_sampler.  Returns the list of written file names (None for skipped events).
+        summary_file: also write the `summarize_miso` table (samples_utils.py:263-329) for the
+        events of this batch, from means / credible intervals computed on the device."""
         todo, slots = [], []
         for i, ev in enumerate(events):
             reads, gene, output_file = ev[:3]
@@ -151,6 +154,8 @@ class MISOSampler:
         self.params.update(iters=num_iters, burn_in=burn_in, lag=lag)
         kw = dict(seed=seed if seed is not None else random.getrandbits(64),
                   first_event_id=first_event_id)
+        if summary_file is not None:
+            kw["summary"] = confidence_level
         if self.paired_end:
             results = pysplicing.MISOPairedBatch(tuple(todo), int(self.params["read_len"]),
                                                  float(self.mean_frag_len), float(self.frag_variance),
@@ -162,8 +167,14 @@ class MISOSampler:
                                            int(burn_in), int(lag), int(self.params["overhang_len"]),
                                            int(num_chains), start_cond, stop_cond,
                                            pysplicing.MISO_ALGO_REASSIGN, **kw)
+        rows = []
         for (i, gene, out), res in zip(slots, results):
             written[i] = self._finish(res, gene, out, num_iters, burn_in, lag, verbose)
+            if summary_file is not None and written[i] is not None:
+                name = os.path.basename(written[i])[:-len(".miso")]
+                rows.append((name,) + tuple(res[6]) + (read_header(written[i]),))
+        if summary_file is not None:
+            summary.write_summary(summary_file, rows)
         return written
 
     # -- shared pieces -------------------------------------------------------------------------
@@ -242,6 +253,13 @@ class MISOSampler:
             for psi_sample, curr_log_score in zip(psi_vectors, kept_log_scores):
                 psi_sample_str = ",".join("%.4f" % psi for psi in psi_sample)
                 output.write("%s\t%.2f\n" % (psi_sample_str, curr_log_score))
+
+
+def read_header(miso_file):
+    """The `#key=value<TAB>...` first line of a .miso file as a dict."""
+    with open(miso_file) as f:
+        header = f.readline().rstrip("\n")
+    return dict(kv.split("=", 1) for kv in header[1:].split("\t"))
 
 
 def load_samples(miso_file):

@@ -356,13 +356,29 @@ static PyObject *py_miso_paired(PyObject *self, PyObject *args, PyObject *kw) {
 
 /* ---- MISOBatch / MISOPairedBatch: many events, one launch ---- */
 
+/* summary=<confidence level>: each result gains a 7th element (means, ci_low, ci_high), computed
+   on the device from the samples (what summarize_miso derives later from the .miso file,
+   credible_intervals.py:4-72) */
+static PyObject *summary_tuple(miso_batch_t *b, int idx) {
+  int K, rc; double m[MISO_MAX_ISOFORMS], lo[MISO_MAX_ISOFORMS], hi[MISO_MAX_ISOFORMS];
+  if ((rc = miso_batch_event_info(b, idx, &K, NULL, NULL, NULL))) return raise_miso(rc);
+  if ((rc = miso_batch_get_summary(b, idx, m, lo, hi))) return raise_miso(rc);
+  return Py_BuildValue("(NNN)", from_doubles(m, K), from_doubles(lo, K), from_doubles(hi, K));
+}
+
 static PyObject *batch_common(PyObject *events, miso_params_t *p, PyObject *seedobj,
-                              unsigned int first_event_id) {
+                              unsigned int first_event_id, PyObject *summaryobj) {
+  double conf = 0;
   miso_batch_t *b = NULL; PyObject *out = NULL; Py_ssize_t i, n; int rc;
   unsigned long long seed;
   if (!PyTuple_Check(events)) { PyErr_SetString(PyExc_TypeError, "Need a tuple"); return NULL; }
   if (seedobj && seedobj != Py_None) { seed = PyLong_AsUnsignedLongLongMask(seedobj); if (PyErr_Occurred()) return NULL; }
   else if (default_seed(&seed)) return NULL;
+  if (summaryobj && summaryobj != Py_None) {
+    conf = PyFloat_AsDouble(summaryobj);
+    if (PyErr_Occurred()) return NULL;
+    if (!(conf > 0 && conf < 1)) { PyErr_SetString(PyExc_ValueError, "summary must be a confidence level in (0, 1)"); return NULL; }
+  }
   if ((rc = miso_batch_create(p, &b))) return raise_miso(rc);
   n = PyTuple_Size(events);
   for (i = 0; i < n; i++) {
@@ -375,9 +391,16 @@ static PyObject *batch_common(PyObject *events, miso_params_t *p, PyObject *seed
                   PyTuple_Size(ev) == 4 ? PyTuple_GET_ITEM(ev, 3) : NULL)) goto fail;
   }
   if (n > 0 && run_batch(b, seed, first_event_id)) goto fail;
+  if (n > 0 && conf > 0 && (rc = miso_batch_summarize(b, conf))) { raise_miso(rc); goto fail; }
   out = PyList_New(n);
   for (i = 0; out && i < n; i++) {
     PyObject *r = result_tuple(b, (int) i);
+    if (r && conf > 0) {
+      PyObject *s = summary_tuple(b, (int) i), *r7 = NULL;
+      PyObject *one = s ? PyTuple_Pack(1, s) : NULL;
+      if (one) r7 = PySequence_Concat(r, one);
+      Py_XDECREF(one); Py_XDECREF(s); Py_DECREF(r); r = r7;
+    }
     if (!r) { Py_CLEAR(out); break; }
     PyList_SET_ITEM(out, i, r);
   }
@@ -388,32 +411,32 @@ fail:
 
 static PyObject *py_miso_batch(PyObject *self, PyObject *args, PyObject *kw) {
   static char *kwlist[] = {"events", "readLength", "noIterations", "noBurnIn", "noLag", "overhang",
-                           "no_chains", "start", "stop", "algo", "seed", "first_event_id", NULL};
-  PyObject *events, *seedobj = NULL;
+                           "no_chains", "start", "stop", "algo", "seed", "first_event_id", "summary", NULL};
+  PyObject *events, *seedobj = NULL, *summaryobj = NULL;
   int readLength, iters = 5000, burn = 500, lag = 10, overhang = 1, chains = 6;
   int start = MISO_START_AUTO, stop = MISO_STOP_FIXEDNO, algo = MISO_ALGO_REASSIGN;
   unsigned int first = 0; miso_params_t p;
-  if (!PyArg_ParseTupleAndKeywords(args, kw, "Oi|iiiiiiii$OI", kwlist, &events, &readLength, &iters,
+  if (!PyArg_ParseTupleAndKeywords(args, kw, "Oi|iiiiiiii$OIO", kwlist, &events, &readLength, &iters,
                                    &burn, &lag, &overhang, &chains, &start, &stop, &algo, &seedobj,
-                                   &first)) return NULL;
+                                   &first, &summaryobj)) return NULL;
   fill_params(&p, 0, readLength, overhang, chains, iters, burn, lag, algo, start, stop, 0, 0, 0);
-  return batch_common(events, &p, seedobj, first);
+  return batch_common(events, &p, seedobj, first, summaryobj);
 }
 
 static PyObject *py_miso_paired_batch(PyObject *self, PyObject *args, PyObject *kw) {
   static char *kwlist[] = {"events", "readLength", "normalMean", "normalVar", "numDevs",
                            "noIterations", "noBurnIn", "noLag", "overhang", "no_chains", "start",
-                           "stop", "seed", "first_event_id", NULL};
-  PyObject *events, *seedobj = NULL;
+                           "stop", "seed", "first_event_id", "summary", NULL};
+  PyObject *events, *seedobj = NULL, *summaryobj = NULL;
   int readLength, iters = 5000, burn = 500, lag = 10, overhang = 1, chains = 6;
   int start = MISO_START_AUTO, stop = MISO_STOP_FIXEDNO;
   double mean, var, devs; unsigned int first = 0; miso_params_t p;
-  if (!PyArg_ParseTupleAndKeywords(args, kw, "Oiddd|iiiiiii$OI", kwlist, &events, &readLength, &mean,
+  if (!PyArg_ParseTupleAndKeywords(args, kw, "Oiddd|iiiiiii$OIO", kwlist, &events, &readLength, &mean,
                                    &var, &devs, &iters, &burn, &lag, &overhang, &chains, &start,
-                                   &stop, &seedobj, &first)) return NULL;
+                                   &stop, &seedobj, &first, &summaryobj)) return NULL;
   fill_params(&p, 1, readLength, overhang, chains, iters, burn, lag, MISO_ALGO_REASSIGN, start, stop,
               mean, var, devs);
-  return batch_common(events, &p, seedobj, first);
+  return batch_common(events, &p, seedobj, first, summaryobj);
 }
 
 /* ---- simulateReads / simulatePairedReads (pysplicing.c:280-330, 462-520) ---- */
