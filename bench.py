@@ -114,6 +114,9 @@ def main():
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--cpu-events", type=int, default=12, help="reference events per host process")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--compare", action="store_true",
+                    help="also sample a second RNA-seq sample of the same events and time the device-side "
+                         "Bayes factors (BASELINE configs[4]; outside the timed region)")
     ap.add_argument("--summarize", action="store_true",
                     help="also time the device-side posterior summaries (outside the timed region)")
     a = ap.parse_args()
@@ -174,6 +177,18 @@ def main():
         batch.summarize(0.95)
         summary_ms = 1e3 * (time.perf_counter() - t1)
 
+    compare_ms = None
+    if a.compare:
+        other = workload.build_batch(first + (1 << 24), a.events, K=a.K, n_reads=a.reads,
+                                     read_len=a.read_len, iters=a.iters, burn=a.burn, lag=a.lag,
+                                     chains=a.chains, paired=a.paired)
+        other.upload(local_rank)
+        other.launch(seed=a.seed ^ 0x5851F42D4C957F2D, first_event_id=first)
+        other.sync()
+        t1 = time.perf_counter()
+        batch.compare(other, 0.3)
+        compare_ms = 1e3 * (time.perf_counter() - t1)
+
     if rank == 0:
         total_events = a.events * world * a.steps
         value = total_events / elapsed
@@ -206,6 +221,7 @@ def main():
             "cpu_baseline": cpu,
             "host_build_s": round(t_build, 2),
             "summary_ms": None if summary_ms is None else round(summary_ms, 3),
+            "compare_ms": None if compare_ms is None else round(compare_ms, 3),
         }
         print(json.dumps(out), flush=True)
     if dist is not None:

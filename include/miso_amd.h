@@ -196,6 +196,16 @@ int miso_batch_summarize(miso_batch_t *batch, double confidence_level);
 int miso_batch_get_summary(const miso_batch_t *batch, int event_index, double *mean, double *ci_low,
                            double *ci_high);
 
+/* Two-sample comparison on the device (compare_miso, misopy/hypothesis_test.py:89-179, 348-380):
+   `sample1` and `sample2` hold the SAME events in the same order (one batch per RNA-seq sample),
+   both launched on the same device.  Per event and isoform: index-paired delta = psi1 - psi2;
+   mean|delta| <= 0.009 or constant delta -> Bayes factor 0 (posterior peaked on the null);
+   otherwise Gaussian KDE of delta with covariance factor `smoothing` (reference: 0.3) evaluated at
+   0, BF = 1 / density, 1e12 if the density is 0, capped at 1e12.  Results are stored in sample1. */
+int miso_batch_compare(miso_batch_t *sample1, miso_batch_t *sample2, double smoothing);
+int miso_batch_get_comparison(const miso_batch_t *sample1, int event_index, double *mean1, double *mean2,
+                              double *bayes_factor, double *density_at_0);   /* noiso doubles each */
+
 /* names of the kernels the last launch used (for profiles): e.g. "sampler_k2<3, false>" */
 int miso_batch_last_kernels(const miso_batch_t *batch, char *buf, int buflen);
 

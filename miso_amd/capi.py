@@ -56,6 +56,7 @@ def lib():
         _lib.miso_batch_launch.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32]
         _lib.miso_batch_run.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint32]
         _lib.miso_batch_summarize.argtypes = [C.c_void_p, C.c_double]
+        _lib.miso_batch_compare.argtypes = [C.c_void_p, C.c_void_p, C.c_double]
     return _lib
 
 
@@ -247,6 +248,18 @@ class Batch:
         m, lo, hi = (np.zeros(K.value) for _ in range(3))
         check(lib().miso_batch_get_summary(self.handle, i, _p(m), _p(lo), _p(hi)))
         return m, lo, hi
+
+    def compare(self, other, smoothing=0.3):
+        """Two-sample comparison with `other` (same events, same order) on the device."""
+        check(lib().miso_batch_compare(self.handle, other.handle, C.c_double(smoothing)))
+
+    def comparison(self, i):
+        """(mean1[K], mean2[K], bayes_factor[K], density_at_0[K]) of event i after compare()."""
+        K = C.c_int()
+        check(lib().miso_batch_event_info(self.handle, i, C.byref(K), None, None, None))
+        m1, m2, bf, dens = (np.zeros(K.value) for _ in range(4))
+        check(lib().miso_batch_get_comparison(self.handle, i, _p(m1), _p(m2), _p(bf), _p(dens)))
+        return m1, m2, bf, dens
 
     def last_kernels(self):
         buf = C.create_string_buffer(256)

@@ -42,6 +42,8 @@ struct miso_batch {
   std::vector<double> h_summary;        // per event: K x {mean, ci_low, ci_high}
   std::vector<uint64_t> h_sum_off;      // offsets (in doubles) into h_summary
   bool summarized = false;
+  std::vector<double> h_compare;        // per event: K x {mean1, mean2, bayes factor, posterior density at 0}
+  bool compared = false;
   uint64_t in_bytes = 0, out_bytes = 0;
   float last_ms = 0.f;
 
@@ -60,4 +62,5 @@ struct miso_batch {
   void sync(float *ms);
   void download();
   void summarize(double confidence_level);
+  void compare(miso_batch &other, double smoothing);
 };

@@ -285,6 +285,28 @@ int miso_batch_get_summary(const miso_batch_t *b, int i, double *mean, double *c
   });
 }
 
+int miso_batch_compare(miso_batch_t *a, miso_batch_t *b, double smoothing) {
+  return guarded([&] { need(a, "batch"); need(b, "batch"); a->compare(*b, smoothing); });
+}
+
+int miso_batch_get_comparison(const miso_batch_t *b, int i, double *mean1, double *mean2, double *bayes_factor,
+                              double *density0) {
+  return guarded([&] {
+    need(b, "batch");
+    const PackedEvent &e = event_at(b, i);
+    if (!b->compared) MISO_FAIL(MISO_EINVAL, "miso_batch_compare has not run");
+    size_t off = 0;
+    for (int j = 0; j < i; j++) off += 4 * static_cast<size_t>(b->events[j].K);
+    const double *s = b->h_compare.data() + off;
+    for (int k = 0; k < e.K; k++) {
+      if (mean1) mean1[k] = s[4 * k];
+      if (mean2) mean2[k] = s[4 * k + 1];
+      if (bayes_factor) bayes_factor[k] = s[4 * k + 2];
+      if (density0) density0[k] = s[4 * k + 3];
+    }
+  });
+}
+
 int miso_batch_last_kernels(const miso_batch_t *b, char *buf, int buflen) {
   return guarded([&] {
     need(b, "batch"); need(buf, "buf");

@@ -17,6 +17,8 @@ namespace miso {
 
 template <bool PE> __global__ void sampler_wave(const KernelArgs a);
 template <int G, bool PE> __global__ void sampler_k2(const KernelArgs a);
+__global__ void compare_kernel(const DevEvent *, const unsigned char *, const DevEvent *, const unsigned char *, int, int,
+                               double, const uint64_t *, double *);
 __global__ void summarize_kernel(const DevEvent *, const unsigned char *, int, int, int, int, const uint64_t *, double *);
 template <int G, bool PE> __global__ void sampler_grp(const KernelArgs a);
 static inline int grp_slice_bytes(int ks, int qs, int ts) {  // must match kernels_grp.hip
@@ -275,7 +277,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     HIP_OK(hipGetLastError());
   }
   HIP_OK(hipEventRecord(ev1, stream));
-  launched = true; downloaded = false; summarized = false;
+  launched = true; downloaded = false; summarized = false; compared = false;
 }
 
 void miso_batch::sync(float *ms) {
@@ -314,6 +316,39 @@ void miso_batch::summarize(double confidence_level) {
   HIP_OK(hipStreamSynchronize(stream));
   (void) hipFree(d_off); (void) hipFree(d_sum);
   summarized = true;
+}
+
+// Two-sample comparison of this batch (sample 1) with `other` (sample 2), event by event and
+// index-paired (hypothesis_test.py:89-179): both must hold the same events in the same order.
+void miso_batch::compare(miso_batch &other, double smoothing) {
+  if (!launched || !other.launched) MISO_FAIL(MISO_EINVAL, "batch not launched");
+  if (device != other.device) MISO_FAIL(MISO_EINVAL, "Batches to compare live on different devices");
+  if (events.size() != other.events.size() || S() != other.S())
+    MISO_FAIL(MISO_EINVAL, "Batches to compare differ in events or samples per event");
+  if (!(smoothing > 0)) MISO_FAIL(MISO_EINVAL, "Invalid smoothing parameter");
+  const int n = static_cast<int>(events.size()), Sn = S();
+  if (Sn < 2) MISO_FAIL(MISO_EINVAL, "Too few samples to compare");
+  std::vector<uint64_t> off(n);
+  uint64_t tot = 0; int kmax = 1;
+  for (int i = 0; i < n; i++) {
+    if (events[i].K != other.events[i].K) MISO_FAIL(MISO_EINVAL, "Events to compare differ in isoforms");
+    off[i] = tot; tot += 4 * events[i].K; kmax = std::max(kmax, events[i].K);
+  }
+  h_compare.assign(tot, 0.0);
+  if (n == 0) { compared = true; return; }
+  HIP_OK(hipSetDevice(device));
+  HIP_OK(hipStreamSynchronize(other.stream));
+  uint64_t *d_off = nullptr; double *d_cmp = nullptr;
+  HIP_OK(hipMalloc(reinterpret_cast<void **>(&d_off), n * sizeof(uint64_t)));
+  HIP_OK(hipMalloc(reinterpret_cast<void **>(&d_cmp), tot * sizeof(double)));
+  HIP_OK(hipMemcpyAsync(d_off, off.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+  hipLaunchKernelGGL(compare_kernel, dim3(n, kmax), dim3(256), 0, stream, d_events, d_out, other.d_events,
+                     other.d_out, n, Sn, smoothing, d_off, d_cmp);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipMemcpyAsync(h_compare.data(), d_cmp, tot * sizeof(double), hipMemcpyDeviceToHost, stream));
+  HIP_OK(hipStreamSynchronize(stream));
+  (void) hipFree(d_off); (void) hipFree(d_cmp);
+  compared = true;
 }
 
 void miso_batch::download() {

@@ -22,6 +22,7 @@ if _HERE not in sys.path:
     sys.path.insert(0, _HERE)
 import pysplicing  # noqa: E402  (miso_amd/pysplicing)
 import summary  # noqa: E402  (miso_amd/summary.py)
+import compare  # noqa: E402  (miso_amd/compare.py)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -175,6 +176,45 @@ class MISOSampler:
                 rows.append((name,) + tuple(res[6]) + (read_header(written[i]),))
         if summary_file is not None:
             summary.write_summary(summary_file, rows)
+        return written
+
+    # -- two RNA-seq samples over the same events + Bayes factors (compare_miso) ----------------
+    def run_comparison_batch(self, num_iters, events1, events2, comparison_file, num_chains=6,
+                             burn_in=1000, lag=2, seed=None, seed2=None, first_event_id=0,
+                             confidence_level=0.95, smoothing=0.3, verbose=False):
+        """events1[i] and events2[i] = (reads, gene, output_file[, prior_params]) describe the SAME
+        event in sample 1 and sample 2.  Samples both on the GPU, writes every .miso file and the
+        `.miso_bf` table of hypothesis_test.py:186-345 with Bayes factors computed on the device.
+        Events skipped in either sample (no reads, one isoform, output exists) are left out, as
+        compare_miso leaves out events missing from one directory (hypothesis_test.py:262-264)."""
+        if len(events1) != len(events2):
+            raise ValueError("the two samples must list the same events")
+        keep = []
+        for i, (e1, e2) in enumerate(zip(events1, events2)):
+            p1 = self._prepare(e1[0], e1[1], e1[2], e1[3] if len(e1) > 3 else None, verbose)
+            p2 = self._prepare(e2[0], e2[1], e2[2], e2[3] if len(e2) > 3 else None, verbose)
+            if p1 is not None and p2 is not None:
+                keep.append((i, e1[1], p1, p2))
+        written = [None] * len(events1)
+        rows = []
+        if keep:
+            self.params.update(iters=num_iters, burn_in=burn_in, lag=lag)
+            kw = dict(seed=seed if seed is not None else random.getrandbits(64), seed2=seed2,
+                      first_event_id=first_event_id, summary=confidence_level, smoothing=smoothing)
+            if self.paired_end:
+                kw["paired"] = (float(self.mean_frag_len), float(self.frag_variance), 4.0)
+            r1, r2, cmp = pysplicing.MISOCompareBatch(
+                tuple(p[2][:4] for p in keep), tuple(p[3][:4] for p in keep),
+                int(self.params["read_len"]), int(num_iters), int(burn_in), int(lag),
+                int(self.params["overhang_len"]), int(num_chains), **kw)
+            for (i, gene, p1, p2), a, b, c in zip(keep, r1, r2, cmp):
+                f1 = self._finish(a, gene, p1[4], num_iters, burn_in, lag, verbose)
+                f2 = self._finish(b, gene, p2[4], num_iters, burn_in, lag, verbose)
+                written[i] = (f1, f2)
+                if f1 is not None and f2 is not None:
+                    name = os.path.basename(f1)[:-len(".miso")]
+                    rows.append((name, a[6], b[6], c[2], read_header(f1), read_header(f2)))
+        compare.write_comparison(comparison_file, rows)
         return written
 
     # -- shared pieces -------------------------------------------------------------------------

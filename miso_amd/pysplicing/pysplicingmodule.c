@@ -366,32 +366,38 @@ static PyObject *summary_tuple(miso_batch_t *b, int idx) {
   return Py_BuildValue("(NNN)", from_doubles(m, K), from_doubles(lo, K), from_doubles(hi, K));
 }
 
-static PyObject *batch_common(PyObject *events, miso_params_t *p, PyObject *seedobj,
-                              unsigned int first_event_id, PyObject *summaryobj) {
-  double conf = 0;
-  miso_batch_t *b = NULL; PyObject *out = NULL; Py_ssize_t i, n; int rc;
-  unsigned long long seed;
+static int parse_level(PyObject *obj, double *conf) {
+  *conf = 0;
+  if (!obj || obj == Py_None) return 0;
+  *conf = PyFloat_AsDouble(obj);
+  if (PyErr_Occurred()) return -1;
+  if (!(*conf > 0 && *conf < 1)) { PyErr_SetString(PyExc_ValueError, "summary must be a confidence level in (0, 1)"); return -1; }
+  return 0;
+}
+
+/* a new batch holding `events` = ((gff, readpos, readcigar[, hyperp]), ...) */
+static miso_batch_t *fill_batch(PyObject *events, miso_params_t *p) {
+  miso_batch_t *b = NULL; Py_ssize_t i, n; int rc;
   if (!PyTuple_Check(events)) { PyErr_SetString(PyExc_TypeError, "Need a tuple"); return NULL; }
-  if (seedobj && seedobj != Py_None) { seed = PyLong_AsUnsignedLongLongMask(seedobj); if (PyErr_Occurred()) return NULL; }
-  else if (default_seed(&seed)) return NULL;
-  if (summaryobj && summaryobj != Py_None) {
-    conf = PyFloat_AsDouble(summaryobj);
-    if (PyErr_Occurred()) return NULL;
-    if (!(conf > 0 && conf < 1)) { PyErr_SetString(PyExc_ValueError, "summary must be a confidence level in (0, 1)"); return NULL; }
-  }
-  if ((rc = miso_batch_create(p, &b))) return raise_miso(rc);
+  if ((rc = miso_batch_create(p, &b))) { raise_miso(rc); return NULL; }
   n = PyTuple_Size(events);
   for (i = 0; i < n; i++) {
     PyObject *ev = PyTuple_GET_ITEM(events, i);
     if (!PyTuple_Check(ev) || PyTuple_Size(ev) < 3 || PyTuple_Size(ev) > 4) {
       PyErr_SetString(PyExc_TypeError, "each event must be (gff, readpos, readcigar[, hyperp])");
-      goto fail;
+      miso_batch_destroy(b); return NULL;
     }
     if (add_event(b, PyTuple_GET_ITEM(ev, 0), PyTuple_GET_ITEM(ev, 1), PyTuple_GET_ITEM(ev, 2),
-                  PyTuple_Size(ev) == 4 ? PyTuple_GET_ITEM(ev, 3) : NULL)) goto fail;
+                  PyTuple_Size(ev) == 4 ? PyTuple_GET_ITEM(ev, 3) : NULL)) { miso_batch_destroy(b); return NULL; }
   }
-  if (n > 0 && run_batch(b, seed, first_event_id)) goto fail;
-  if (n > 0 && conf > 0 && (rc = miso_batch_summarize(b, conf))) { raise_miso(rc); goto fail; }
+  return b;
+}
+
+/* list of the 6-tuples of a finished batch; 7-tuples with the summary when conf > 0 */
+static PyObject *results_list(miso_batch_t *b, Py_ssize_t n, double conf) {
+  Py_ssize_t i; int rc;
+  PyObject *out;
+  if (n > 0 && conf > 0 && (rc = miso_batch_summarize(b, conf))) return raise_miso(rc);
   out = PyList_New(n);
   for (i = 0; out && i < n; i++) {
     PyObject *r = result_tuple(b, (int) i);
@@ -404,8 +410,74 @@ static PyObject *batch_common(PyObject *events, miso_params_t *p, PyObject *seed
     if (!r) { Py_CLEAR(out); break; }
     PyList_SET_ITEM(out, i, r);
   }
-fail:
+  return out;
+}
+
+static PyObject *batch_common(PyObject *events, miso_params_t *p, PyObject *seedobj,
+                              unsigned int first_event_id, PyObject *summaryobj) {
+  double conf; miso_batch_t *b; PyObject *out = NULL; Py_ssize_t n;
+  unsigned long long seed;
+  if (seedobj && seedobj != Py_None) { seed = PyLong_AsUnsignedLongLongMask(seedobj); if (PyErr_Occurred()) return NULL; }
+  else if (default_seed(&seed)) return NULL;
+  if (parse_level(summaryobj, &conf)) return NULL;
+  if (!(b = fill_batch(events, p))) return NULL;
+  n = PyTuple_Size(events);
+  if (n == 0 || !run_batch(b, seed, first_event_id)) out = results_list(b, n, conf);
   miso_batch_destroy(b);
+  return out;
+}
+
+/* ---- MISOCompareBatch: two RNA-seq samples over the same events, Bayes factors on the GPU ----
+   (compare_miso: misopy/hypothesis_test.py:89-179, 348-380) */
+
+static PyObject *py_miso_compare_batch(PyObject *self, PyObject *args, PyObject *kw) {
+  static char *kwlist[] = {"events1", "events2", "readLength", "noIterations", "noBurnIn", "noLag",
+                           "overhang", "no_chains", "start", "stop", "seed", "seed2", "first_event_id",
+                           "summary", "smoothing", "paired", NULL};
+  PyObject *ev1, *ev2, *seedobj = NULL, *seed2obj = NULL, *summaryobj = NULL, *pairedobj = NULL;
+  PyObject *r1 = NULL, *r2 = NULL, *cmp = NULL, *out = NULL;
+  int readLength, iters = 5000, burn = 500, lag = 10, overhang = 1, chains = 6;
+  int start = MISO_START_AUTO, stop = MISO_STOP_FIXEDNO, rc;
+  unsigned int first = 0; double smoothing = 0.3, conf = 0.95, mean = 0, var = 0, devs = 0;
+  unsigned long long seed, seed2; Py_ssize_t i, n;
+  miso_params_t p; miso_batch_t *b1 = NULL, *b2 = NULL;
+  if (!PyArg_ParseTupleAndKeywords(args, kw, "OOi|iiiiiii$OOIOdO", kwlist, &ev1, &ev2, &readLength, &iters,
+                                   &burn, &lag, &overhang, &chains, &start, &stop, &seedobj, &seed2obj,
+                                   &first, &summaryobj, &smoothing, &pairedobj)) return NULL;
+  if (seedobj && seedobj != Py_None) { seed = PyLong_AsUnsignedLongLongMask(seedobj); if (PyErr_Occurred()) return NULL; }
+  else if (default_seed(&seed)) return NULL;
+  /* the two samples must not share random numbers: identical draws would correlate the chains */
+  if (seed2obj && seed2obj != Py_None) { seed2 = PyLong_AsUnsignedLongLongMask(seed2obj); if (PyErr_Occurred()) return NULL; }
+  else seed2 = seed ^ 0x5851F42D4C957F2DULL;
+  if (seed2 == seed) { PyErr_SetString(PyExc_ValueError, "seed2 must differ from seed"); return NULL; }
+  if (summaryobj && summaryobj != Py_None && parse_level(summaryobj, &conf)) return NULL;
+  if (pairedobj && pairedobj != Py_None &&
+      !PyArg_ParseTuple(pairedobj, "ddd;paired must be (normalMean, normalVar, numDevs)", &mean, &var, &devs)) return NULL;
+  fill_params(&p, pairedobj && pairedobj != Py_None, readLength, overhang, chains, iters, burn, lag,
+              MISO_ALGO_REASSIGN, start, stop, mean, var, devs);
+  if (!PyTuple_Check(ev1) || !PyTuple_Check(ev2)) { PyErr_SetString(PyExc_TypeError, "Need a tuple"); return NULL; }
+  n = PyTuple_Size(ev1);
+  if (PyTuple_Size(ev2) != n) { PyErr_SetString(PyExc_ValueError, "the two samples must list the same events"); return NULL; }
+  if (!(b1 = fill_batch(ev1, &p))) goto done;
+  if (!(b2 = fill_batch(ev2, &p))) goto done;
+  if (n > 0 && (run_batch(b1, seed, first) || run_batch(b2, seed2, first))) goto done;
+  if (!(r1 = results_list(b1, n, conf)) || !(r2 = results_list(b2, n, conf))) goto done;
+  if (n > 0 && (rc = miso_batch_compare(b1, b2, smoothing))) { raise_miso(rc); goto done; }
+  if (!(cmp = PyList_New(n))) goto done;
+  for (i = 0; i < n; i++) {
+    int K; double m1[MISO_MAX_ISOFORMS], m2[MISO_MAX_ISOFORMS], bf[MISO_MAX_ISOFORMS], d0[MISO_MAX_ISOFORMS];
+    PyObject *t;
+    if ((rc = miso_batch_event_info(b1, (int) i, &K, NULL, NULL, NULL)) ||
+        (rc = miso_batch_get_comparison(b1, (int) i, m1, m2, bf, d0))) { raise_miso(rc); goto done; }
+    t = Py_BuildValue("(NNNN)", from_doubles(m1, K), from_doubles(m2, K), from_doubles(bf, K), from_doubles(d0, K));
+    if (!t) goto done;
+    PyList_SET_ITEM(cmp, i, t);
+  }
+  out = Py_BuildValue("(OOO)", r1, r2, cmp);
+done:
+  Py_XDECREF(r1); Py_XDECREF(r2); Py_XDECREF(cmp);
+  if (b1) miso_batch_destroy(b1);
+  if (b2) miso_batch_destroy(b2);
   return out;
 }
 
@@ -501,6 +573,7 @@ static PyMethodDef methods[] = {
   {"MISOPaired", (PyCFunction) py_miso_paired, METH_VARARGS | METH_KEYWORDS, "Run MISO on a single gene, paired-end reads (GPU)"},
   {"MISOBatch", (PyCFunction) py_miso_batch, METH_VARARGS | METH_KEYWORDS, "Run MISO on many genes in one GPU launch"},
   {"MISOPairedBatch", (PyCFunction) py_miso_paired_batch, METH_VARARGS | METH_KEYWORDS, "Paired-end MISOBatch"},
+  {"MISOCompareBatch", (PyCFunction) py_miso_compare_batch, METH_VARARGS | METH_KEYWORDS, "Two samples over the same events: results, summaries and Bayes factors"},
   {"noIso", py_no_iso, METH_VARARGS, "Number of isoforms"},
   {"isoLength", py_iso_length, METH_VARARGS, "Length of the isoforms"},
   {"simulateReads", (PyCFunction) py_simulate_reads, METH_VARARGS | METH_KEYWORDS, "Simulate single-end reads"},
