@@ -236,8 +236,8 @@ int miso_batch_get_result(const miso_batch_t *b, int i, double *samples, double 
     if (logLik) std::memcpy(logLik, out + d.off_loglik, sizeof(double) * S);
     if (assignment) {  // chain 0, final state (miso.c:943-946)
       const uint8_t *da = out + d.off_drawass;
-      int r = 0;
-      for (int k = 0; k < e.N; k++) assignment[k] = e.fixed_ass[k] == -2 ? da[r++] : e.fixed_ass[k];
+      for (int k = 0; k < e.N; k++) assignment[k] = e.fixed_ass[k];
+      for (int r = 0; r < e.n_draw; r++) assignment[e.draw_index[r]] = da[r];
     }
     if (rundata) {
       const ChainStats *st = reinterpret_cast<const ChainStats *>(out + d.off_stats);

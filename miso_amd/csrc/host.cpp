@@ -416,14 +416,9 @@ PackedEvent pack_event(const miso_params_t &p, const FragmentDist *fd, int K, in
       continue;
     }
     e.fixed_ass[i] = -2;
+    e.draw_index.push_back(i);
     if (!p.paired) {
       e.draw_mask.push_back(mask);
-      if (e.dcls_mask.size() <= MAX_DRAW_CLASSES) {   // read classes of the drawing reads
-        size_t c = 0;
-        while (c < e.dcls_mask.size() && e.dcls_mask[c] != mask) c++;
-        if (c == e.dcls_mask.size()) e.dcls_mask.push_back(mask);
-        e.draw_cls.push_back(static_cast<uint8_t>(c));
-      }
     } else {
       for (int k = 0; k < K; k++) {
         const int fl = fraglen[static_cast<size_t>(i) * K + k];
@@ -432,7 +427,34 @@ PackedEvent pack_event(const miso_params_t &p, const FragmentDist *fd, int K, in
     }
     e.n_draw++;
   }
-  if (e.dcls_mask.size() > MAX_DRAW_CLASSES) { e.dcls_mask.clear(); e.draw_cls.clear(); }
+  if (!p.paired && e.n_draw > 0) {
+    // draw order: by column (isoform 0 most significant, 0 < 1), ties by read index
+    auto key = [K](uint32_t m) { uint32_t r = 0; for (int k = 0; k < K; k++) r = (r << 1) | ((m >> k) & 1u); return r; };
+    std::vector<int32_t> perm(e.n_draw);
+    for (int r = 0; r < e.n_draw; r++) perm[r] = r;
+    std::stable_sort(perm.begin(), perm.end(), [&](int32_t x, int32_t y) { return key(e.draw_mask[x]) < key(e.draw_mask[y]); });
+    std::vector<int32_t> idx(e.n_draw); std::vector<uint32_t> msk(e.n_draw);
+    for (int r = 0; r < e.n_draw; r++) { idx[r] = e.draw_index[perm[r]]; msk[r] = e.draw_mask[perm[r]]; }
+    e.draw_index.swap(idx); e.draw_mask.swap(msk);
+    for (int r = 0; r < e.n_draw; r++)
+      if (r == 0 || e.draw_mask[r] != e.draw_mask[r - 1]) { e.dcls_mask.push_back(e.draw_mask[r]); e.dcls_start.push_back(r); }
+    e.dcls_start.push_back(e.n_draw);
+    if (e.dcls_mask.size() > MAX_DRAW_CLASSES) {
+      e.dcls_mask.clear(); e.dcls_start.clear();
+    } else {
+      // one unit = the words of one Philox block (draws 4q .. 4q+3) that belong to one class
+      for (size_t c = 0; c < e.dcls_mask.size(); c++) {
+        e.max_cls_size = std::max(e.max_cls_size, __builtin_popcount(e.dcls_mask[c]));
+        for (int r = e.dcls_start[c]; r < e.dcls_start[c + 1];) {
+          const int q = r >> 2, end = std::min(e.dcls_start[c + 1], 4 * q + 4);
+          uint32_t wm = 0;
+          for (; r < end; r++) wm |= 1u << (r & 3);
+          e.draw_units.push_back(static_cast<uint32_t>(q) | wm << 20 | static_cast<uint32_t>(c) << 24);
+        }
+      }
+      if (e.n_draw > (1 << 22)) { e.dcls_mask.clear(); e.dcls_start.clear(); e.draw_units.clear(); }
+    }
+  }
   for (const auto &kv : cls) {
     e.class_templates.insert(e.class_templates.end(), kv.first.begin(), kv.first.end());
     e.class_counts.push_back(kv.second);

@@ -90,10 +90,17 @@ struct PackedEvent {
   std::vector<int32_t> base_count;      // K
   int64_t base_sfix = 0;                // paired: sum of fixed reads' scores, 2^-26 fixed point
   int32_t base_bad = 0;                 // paired: a fixed read has a non-finite score
+  // The drawing reads (>= 2 compatible isoforms) in DRAW ORDER: draw r uses Gibbs word r of the
+  // iteration.  Paired-end: input order.  Single-end: stable order by compatibility column, columns
+  // compared lexicographically like the reference's own read order (matrix.pmt:546-562), so that
+  // the reads of one class are consecutive.
+  std::vector<int32_t> draw_index;      // n_draw: read index of draw r
   std::vector<uint32_t> draw_mask;      // single-end: n_draw
-  std::vector<uint32_t> dcls_mask;      // single-end: distinct masks among the drawing reads ...
-  std::vector<uint8_t> draw_cls;        // ... and each drawing read's index into them (empty when
-                                        // there are more than MISO_MAX_DRAW_CLASSES of them)
+  std::vector<uint32_t> dcls_mask;      // single-end: distinct masks among the drawing reads, in draw order
+  std::vector<int32_t> dcls_start;      // ... first draw of each class (+ n_draw at the end)
+  std::vector<uint32_t> draw_units;     // ... work units of the class kernel: q | wordmask << 20 | class << 24
+                                        // (all three empty with more than MAX_DRAW_CLASSES classes)
+  int max_cls_size = 0;                 // ... most isoforms any drawing class is compatible with
   std::vector<uint16_t> draw_frag;      // paired-end: n_draw x K
   std::vector<int32_t> sfix_table;      // paired-end: K x il fixed-point isoscores
   std::vector<int32_t> fixed_ass;       // N: -1 / isoform for fixed reads, -2 for drawing reads

@@ -12,7 +12,11 @@
 //   * Gibbs: the chain's lanes stride over its draw quads (one Philox4x32-10 block = four reads);
 //     SE reads carry a u32 compatibility mask, PE reads K u16 fragment indices into the
 //     fragment-probability table staged in LDS; picks are counted with LDS atomics on the chain's
-//     slice; the PE fragment score is accumulated in 2^-32 fixed point and reduced over the lanes.
+//     slice; the PE fragment score is accumulated in 2^-26 fixed point and reduced over the lanes;
+//   * single-end Gibbs, class path: the drawing reads are ordered by compatibility class (host.hpp),
+//     so a class's pick thresholds are integers computed once per iteration and a read costs one
+//     Philox word and (class size - 1) compare+add into register counters -- no per-read LDS
+//     traffic, no atomics (class_units below).
 // Same arithmetic, same order, same RNG addresses as sampler_wave and the CPU checker.
 #include <hip/hip_runtime.h>
 
@@ -48,25 +52,31 @@ __device__ __forceinline__ double seq_sum(const double *v, int n) {
 struct Slice {            // one chain's LDS slice; every array has `ks` entries
   double *psi, *alpha, *psiN, *alphaN, *ta, *tb, *tc, *cst, *isc, *hm1;
   int *cnt, *bas;  // picks of the drawing reads; reads with a single compatible isoform
-  uint32_t *cmask; // SE class path: mask of every drawing-read class [MAX_DRAW_CLASSES]
-  uint64_t *thr;   // SE class path: integer thresholds [MAX_DRAW_CLASSES x (ks - 1)], unused = 2^32
-  uint64_t *vl;    // SE class path: the class's compatible isoforms, one per byte, ascending [MAX_DRAW_CLASSES]
-  uint32_t *cq;    // SE class path: class id of every drawing read, four per word [qstride]
+  // SE class path (only when qstride > 0), per drawing-read class c < MAX_DRAW_CLASSES:
+  uint32_t *thr;   //   low words of the cumulative integer thresholds [c x (ks - 1)]
+  int *cum;        //   reads of the class whose word is below threshold j [c x (ks - 1)]
+  uint32_t *cmask; //   compatibility mask
+  int *csize;      //   number of reads
+  uint32_t *alw;   //   bit j: threshold j is 2^32 (every word is below it)
+  uint32_t *units; //   work units: q | wordmask << 20 | class << 24 [qstride]
   int32_t *stab;   // PE: the event's fixed-point score table [tstride] (when it fits)
 };
 
-__device__ __forceinline__ Slice carve(unsigned char *base, int ks) {
+
+__device__ __forceinline__ Slice carve(unsigned char *base, int ks, int qs) {
   Slice s;
   double *d = reinterpret_cast<double *>(base);
   s.psi = d; s.alpha = d + ks; s.psiN = d + 2 * ks; s.alphaN = d + 3 * ks; s.ta = d + 4 * ks;
   s.tb = d + 5 * ks; s.tc = d + 6 * ks; s.cst = d + 7 * ks; s.isc = d + 8 * ks; s.hm1 = d + 9 * ks;
   s.cnt = reinterpret_cast<int *>(d + 10 * ks);
   s.bas = s.cnt + ks;
-  s.thr = reinterpret_cast<uint64_t *>(reinterpret_cast<unsigned char *>(d) + 10 * ks * 8 + 2 * ks * 4);
-  s.vl = s.thr + MAX_DRAW_CLASSES * (ks - 1);
-  s.cmask = reinterpret_cast<uint32_t *>(s.vl + MAX_DRAW_CLASSES);
-  s.cq = s.cmask + MAX_DRAW_CLASSES;
-  s.stab = nullptr;
+  s.thr = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(d) + 10 * ks * 8 + 2 * ks * 4);
+  s.cum = reinterpret_cast<int *>(s.thr + MAX_DRAW_CLASSES * (ks - 1));
+  s.cmask = reinterpret_cast<uint32_t *>(s.cum + MAX_DRAW_CLASSES * (ks - 1));
+  s.csize = reinterpret_cast<int *>(s.cmask + MAX_DRAW_CLASSES);
+  s.alw = reinterpret_cast<uint32_t *>(s.csize + MAX_DRAW_CLASSES);
+  s.units = s.alw + MAX_DRAW_CLASSES;
+  s.stab = reinterpret_cast<int32_t *>(reinterpret_cast<unsigned char *>(s.thr) + grp_cls_bytes(ks, qs));
   return s;
 }
 
@@ -131,13 +141,50 @@ template <bool LE> __device__ __forceinline__ uint64_t draw_threshold(double c, 
   return static_cast<uint64_t>(t < 0 ? 0 : t);
 }
 
+// The single-end class path's read loop.  The chain's G lanes stride over its work units (the words
+// of one Philox block that belong to one class); a lane keeps the thresholds T[] of its current
+// class and the counters cj[j] = #{words seen below T[j]} in registers and touches LDS only when
+// its class changes.  TW >= the wavefront's largest (class size - 1), compile-time for the unroll.
+template <int TW, int G>
+__device__ __forceinline__ void class_units(const uint32_t *units, const uint32_t *thr, int *cum, int tw,
+                                            int nuw, int n_units, int sub, uint64_t seed,
+                                            uint32_t event_id, uint32_t chain, uint32_t iter) {
+  uint32_t T[TW]; int cj[TW];
+#pragma unroll
+  for (int j = 0; j < TW; j++) { T[j] = 0; cj[j] = 0; }
+  int cur = -1;
+  for (int i0 = 0; i0 < nuw; i0 += G) {
+    const int i = i0 + sub;
+    const bool active = i < n_units;
+    const uint32_t un = active ? units[i] : 0u;
+    const uint32_t wm = (un >> 20) & 0xFu;
+    const int c = active ? static_cast<int>(un >> 24) : cur;
+    const miso_u32x4 u = miso_draw_block(seed, event_id, chain, iter, MISO_SITE_GIBBS, un & 0xFFFFFu);
+    if (c != cur) {
+      if (cur >= 0) {
+#pragma unroll
+        for (int j = 0; j < TW; j++) if (j < tw && cj[j]) atomicAdd(&cum[cur * tw + j], cj[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < TW; j++) { T[j] = (j < tw) ? thr[c * tw + j] : 0u; cj[j] = 0; }
+      cur = c;
+    }
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      const uint32_t uw = ((wm >> w) & 1u) ? u.v[w] : 0xFFFFFFFFu;   // never below a 32-bit threshold
+#pragma unroll
+      for (int j = 0; j < TW; j++) cj[j] += (uw < T[j]) ? 1 : 0;
+    }
+  }
+  if (cur >= 0) {
+#pragma unroll
+    for (int j = 0; j < TW; j++) if (j < tw && cj[j]) atomicAdd(&cum[cur * tw + j], cj[j]);
+  }
+}
+
 }  // namespace
 
-// bytes of LDS one chain needs for isoform stride ks (ks even)
-__host__ __device__ inline int grp_slice_bytes(int ks, int qs, int ts) {
-  return 10 * ks * 8 + 2 * ks * 4 + MAX_DRAW_CLASSES * (ks - 1) * 8 + MAX_DRAW_CLASSES * 8 +
-         MAX_DRAW_CLASSES * 4 + ((qs + 1) & ~1) * 4 + ((ts + 1) & ~1) * 4;
-}
+
 
 template <int G, bool PE>
 __global__ __launch_bounds__(256, 2) void sampler_grp(const KernelArgs a) {
@@ -158,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void sampler_grp(const KernelArgs a) {
   const bool live = slot < n_chains;
   if (!live) slot = n_chains - 1;           // shadow a real chain, store nothing
   const int ks = a.kstride;
-  const Slice S = carve(smem + fp_bytes + (static_cast<size_t>(wave) * CPW + grp) * grp_slice_bytes(ks, a.qstride, a.tstride), ks);
+  const Slice S = carve(smem + fp_bytes + (static_cast<size_t>(wave) * CPW + grp) * grp_slice_bytes(ks, a.qstride, a.tstride), ks, a.qstride);
 
   const int ev = a.slot_event[slot / a.C];
   const uint32_t chain = static_cast<uint32_t>(slot % a.C);
@@ -184,27 +231,28 @@ __global__ __launch_bounds__(256, 2) void sampler_grp(const KernelArgs a) {
     }
   }
   // single-end class path: usable when every chain of the wavefront has a class table
-  const uint8_t *clsq = a.in_pool + E.off_cls;
   const int n_dcls = PE ? 0 : E.n_dcls;
-  int ncw = n_dcls;
-  bool cls_ok = !PE && (n_dcls > 0 || E.n_draw == 0) && ((E.n_draw + 3) >> 2) <= a.qstride;
-  for (int off = 32; off >= 1; off >>= 1) { ncw = max(ncw, __shfl_xor(ncw, off)); }
+  const int n_units = PE ? 0 : E.n_units;
+  int ncw = n_dcls, nuw = n_units, tww = PE ? 0 : E.max_cls - 1;
+  bool cls_ok = !PE && a.qstride > 0 && (n_dcls > 0 || E.n_draw == 0) && n_units <= a.qstride;
+  for (int off = 32; off >= 1; off >>= 1) {
+    ncw = max(ncw, __shfl_xor(ncw, off));
+    nuw = max(nuw, __shfl_xor(nuw, off));
+    tww = max(tww, __shfl_xor(tww, off));
+  }
   cls_ok = __all(cls_ok);
   ncw = __builtin_amdgcn_readfirstlane(ncw);
+  nuw = __builtin_amdgcn_readfirstlane(nuw);
+  tww = __builtin_amdgcn_readfirstlane(tww);
   if (cls_ok) {
     const uint32_t *gm = reinterpret_cast<const uint32_t *>(a.in_pool + E.off_clsmask);
     for (int c0 = 0; c0 < ncw; c0 += G) {
       const int cc = c0 + sub;
-      if (cc < n_dcls) {
-        const uint32_t m = gm[cc];
-        uint64_t v = 0; int j = 0;
-        for (int k = 0; k < K && j < 8; k++) if ((m >> k) & 1u) { v |= static_cast<uint64_t>(k) << (8 * j); j++; }
-        S.cmask[cc] = m; S.vl[cc] = v;
-      }
+      if (cc < n_dcls) { S.cmask[cc] = gm[2 * cc]; S.csize[cc] = static_cast<int>(gm[2 * cc + 1]); }
     }
-    // the class ids stay in LDS for the whole run: the read loop never waits on global memory
-    const uint32_t *gq = reinterpret_cast<const uint32_t *>(clsq);
-    for (int q0 = 0; q0 < nqw; q0 += G) { const int q = q0 + sub; if (q < ((E.n_draw + 3) >> 2)) S.cq[q] = gq[q]; }
+    // the work units stay in LDS for the whole run: the read loop never waits on global memory
+    const uint32_t *gu = reinterpret_cast<const uint32_t *>(a.in_pool + E.off_cls);
+    for (int i0 = 0; i0 < nuw; i0 += G) { const int i = i0 + sub; if (i < n_units) S.units[i] = gu[i]; }
   }
   wave_sync();
   Scalars c;
@@ -215,7 +263,7 @@ __global__ __launch_bounds__(256, 2) void sampler_grp(const KernelArgs a) {
   const uint16_t *frags = reinterpret_cast<const uint16_t *>(a.in_pool + E.off_draw);
   const int32_t *sfix = reinterpret_cast<const int32_t *>(a.in_pool + E.off_sfix);
   if (PE && a.tstride > 0) {  // score table into the chain's slice: no per-read gather from L2
-    int32_t *stab = reinterpret_cast<int32_t *>(S.cq + ((a.qstride + 1) & ~1));
+    int32_t *stab = S.stab;
     for (int i = sub; i < K * a.il; i += G) stab[i] = sfix[i];
     sfix = stab;
     wave_sync();
@@ -236,8 +284,8 @@ __global__ __launch_bounds__(256, 2) void sampler_grp(const KernelArgs a) {
     GPROF_T(t0);
     for (int k0 = 0; k0 < Kw; k0 += G) { const int k = k0 + sub; if (k < K) S.cnt[k] = 0; }
     wave_sync();
-    if (!PE && cls_ok) {
-      // thresholds of every drawing-read class for the current psi: one class per lane
+    if (!PE && cls_ok && !__any(write_ass)) {
+      // integer thresholds of every drawing-read class for the current psi: one class per lane
       const int tw = ks - 1;
       for (int c0 = 0; c0 < ncw; c0 += G) {
         const int cc = c0 + sub;
@@ -245,56 +293,49 @@ __global__ __launch_bounds__(256, 2) void sampler_grp(const KernelArgs a) {
           const uint32_t m = S.cmask[cc];
           const int nv = __popc(m);
           double T = 0.0;
-          for (int k = 0; k < K; k++) if ((m >> k) & 1u) T = T + S.psi[k];
-          double cum = 0.0; uint64_t run = 0; int j = 0;
-          for (int k = 0; k < K && j < nv - 1; k++) {
-            if (!((m >> k) & 1u)) continue;
-            cum = cum + S.psi[k];
+          for (uint32_t mm = m; mm; mm &= mm - 1) T = T + S.psi[__ffs(mm) - 1];
+          double cum = 0.0; uint64_t run = 0; uint32_t alw = 0; int j = 0;
+          for (uint32_t mm = m; j < nv - 1; mm &= mm - 1, j++) {
+            cum = cum + S.psi[__ffs(mm) - 1];
             const uint64_t t = (nv == 2) ? draw_threshold<false>(cum, T) : draw_threshold<true>(cum, T);
-            run = t > run ? t : run;          // first j with u < t_j  ==  #{j : u >= running max}
-            S.thr[cc * tw + j] = run;
-            j++;
+            run = t > run ? t : run;          // first j with u < t_j  ==  first j with u < running max
+            S.thr[cc * tw + j] = static_cast<uint32_t>(run);
+            alw |= static_cast<uint32_t>(run >> 32) << j;
+            S.cum[cc * tw + j] = 0;
           }
-          for (; j < tw; j++) S.thr[cc * tw + j] = 4294967296ull;  // never reached by a 32-bit word
+          for (; j < tw; j++) { S.thr[cc * tw + j] = 0u; S.cum[cc * tw + j] = 0; }
+          S.alw[cc] = alw;
         }
       }
       wave_sync();
       GPROF_T(t1);
       GPROF_ADD(gp_thr, t0, t1);
-      const uint32_t *cq = S.cq;
-      const int tww = Kw - 1;   // wave-uniform number of thresholds to test (<= 7)
-      for (int q0 = 0; q0 < nqw; q0 += G) {
-        const int q = q0 + sub;
-        const bool active = q < n_quads;
-        const miso_u32x4 u = miso_draw_block(a.seed, event_id, chain, iter, MISO_SITE_GIBBS,
-                                             static_cast<uint32_t>(q));
-        const uint32_t c4 = active ? cq[q] : 0u;
-        int sel4[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {      // straight-line: all LDS reads of the quad issue together
-          const int cc = (c4 >> (8 * j)) & 0xFF;
-          const uint64_t *row = S.thr + cc * tw;
-          const uint64_t vl = S.vl[cc];
-          const uint64_t uw = u.v[j];
-          int w = 0;
-          if (tww <= 7) {      // K <= 8: fixed, fully unrolled scan; isoform list packed in one word
-#pragma unroll
-            for (int i = 0; i < 7; i++) if (i < tww) w += (uw >= row[i]) ? 1 : 0;
-            sel4[j] = static_cast<int>((vl >> (8 * w)) & 0xFF);
-          } else {             // more isoforms: scan the class's thresholds, then walk its mask
-            uint32_t m = S.cmask[cc];
-            const int nvm1 = __popc(m) - 1;
-            for (int i = 0; i < nvm1; i++) w += (uw >= row[i]) ? 1 : 0;
-            for (int i = 0; i < w; i++) m &= m - 1;
-            sel4[j] = __ffs(m) - 1;
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const int r = 4 * q + j;
-          if (active && r < n_draw) {
-            atomicAdd(&S.cnt[sel4[j]], 1);
-            if (write_ass) drawass[r] = static_cast<uint8_t>(sel4[j]);
+#define MISO_UNITS(TW) class_units<TW, G>(S.units, S.thr, S.cum, tw, nuw, n_units, sub, a.seed, event_id, chain, iter)
+      if (tww <= 1) MISO_UNITS(1);
+      else if (tww == 2) MISO_UNITS(2);
+      else if (tww == 3) MISO_UNITS(3);
+      else if (tww == 4) MISO_UNITS(4);
+      else if (tww == 5) MISO_UNITS(5);
+      else if (tww == 6) MISO_UNITS(6);
+      else if (tww == 7) MISO_UNITS(7);
+      else if (tww <= 9) MISO_UNITS(9);
+      else if (tww <= 12) MISO_UNITS(12);
+      else if (tww <= 16) MISO_UNITS(16);
+      else if (tww <= 23) MISO_UNITS(23);
+      else MISO_UNITS(31);
+#undef MISO_UNITS
+      wave_sync();
+      // cumulative counts -> picks per isoform: member j of the class got C_j - C_(j-1) reads
+      for (int c0 = 0; c0 < ncw; c0 += G) {
+        const int cc = c0 + sub;
+        if (cc < n_dcls) {
+          const uint32_t m = S.cmask[cc], alw = S.alw[cc];
+          const int nv = __popc(m), nc = S.csize[cc];
+          int prev = 0, j = 0;
+          for (uint32_t mm = m; mm; mm &= mm - 1, j++) {
+            const int Cj = (j == nv - 1 || ((alw >> j) & 1u)) ? nc : S.cum[cc * tw + j];
+            if (Cj != prev) atomicAdd(&S.cnt[__ffs(mm) - 1], Cj - prev);
+            prev = Cj;
           }
         }
       }

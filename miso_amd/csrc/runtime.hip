@@ -21,10 +21,6 @@ __global__ void compare_kernel(const DevEvent *, const unsigned char *, const De
                                double, const uint64_t *, double *);
 __global__ void summarize_kernel(const DevEvent *, const unsigned char *, int, int, int, int, const uint64_t *, double *);
 template <int G, bool PE> __global__ void sampler_grp(const KernelArgs a);
-static inline int grp_slice_bytes(int ks, int qs, int ts) {  // must match kernels_grp.hip
-  return 10 * ks * 8 + 2 * ks * 4 + MAX_DRAW_CLASSES * (ks - 1) * 8 + MAX_DRAW_CLASSES * 8 +
-         MAX_DRAW_CLASSES * 4 + ((qs + 1) & ~1) * 4 + ((ts + 1) & ~1) * 4;
-}
 __global__ void selftest_detmath_kernel(const double *, int, double *, double *, double *, double *);
 __global__ void selftest_philox_kernel(const uint32_t *, int, uint32_t *);
 
@@ -108,8 +104,10 @@ void miso_batch::upload(int dev) {
     in_off = align_up(in_off + (e.paired ? e.draw_frag.size() * 2
                                          : align_up(e.draw_mask.size(), 4) * 4), 16);
     d.n_dcls = static_cast<int32_t>(e.dcls_mask.size());
-    d.off_cls = in_off; in_off = align_up(in_off + align_up(e.draw_cls.size(), 4), 16);
-    d.off_clsmask = in_off; in_off = align_up(in_off + e.dcls_mask.size() * 4, 16);
+    d.n_units = static_cast<int32_t>(e.draw_units.size());
+    d.max_cls = e.max_cls_size;
+    d.off_cls = in_off; in_off = align_up(in_off + e.draw_units.size() * 4, 16);
+    d.off_clsmask = in_off; in_off = align_up(in_off + e.dcls_mask.size() * 8, 16);
     d.off_sfix = in_off; in_off = align_up(in_off + e.sfix_table.size() * 4, 16);
     d.off_samples = out_off; out_off = align_up(out_off + static_cast<uint64_t>(Sn) * e.K * 8, 16);
     d.off_loglik = out_off; out_off = align_up(out_off + static_cast<uint64_t>(Sn) * 8, 16);
@@ -132,9 +130,13 @@ void miso_batch::upload(int dev) {
     std::memcpy(h_in.data() + d.off_base, e.base_count.data(), e.base_count.size() * 4);
     if (e.paired) std::memcpy(h_in.data() + d.off_draw, e.draw_frag.data(), e.draw_frag.size() * 2);
     else std::memcpy(h_in.data() + d.off_draw, e.draw_mask.data(), e.draw_mask.size() * 4);
-    if (!e.draw_cls.empty()) {
-      std::memcpy(h_in.data() + d.off_cls, e.draw_cls.data(), e.draw_cls.size());
-      std::memcpy(h_in.data() + d.off_clsmask, e.dcls_mask.data(), e.dcls_mask.size() * 4);
+    if (!e.draw_units.empty()) {
+      std::memcpy(h_in.data() + d.off_cls, e.draw_units.data(), e.draw_units.size() * 4);
+      uint32_t *cm = reinterpret_cast<uint32_t *>(h_in.data() + d.off_clsmask);
+      for (size_t c = 0; c < e.dcls_mask.size(); c++) {
+        cm[2 * c] = e.dcls_mask[c];
+        cm[2 * c + 1] = static_cast<uint32_t>(e.dcls_start[c + 1] - e.dcls_start[c]);
+      }
     }
     if (!e.sfix_table.empty())
       std::memcpy(h_in.data() + d.off_sfix, e.sfix_table.data(), e.sfix_table.size() * 4);
@@ -161,10 +163,11 @@ void miso_batch::upload(int dev) {
   // the general kernel's wavefronts loop to their largest K and longest draw list: group alike
   std::stable_sort(gen.begin(), gen.end(), [&](int x, int y) {
     return events[x].K != events[y].K ? events[x].K > events[y].K : events[x].n_draw > events[y].n_draw; });
-  gen_kmax = 2; gen_maxq = 1;
+  gen_kmax = 2; gen_maxq = 1; gen_maxu = 0;
   for (int i : gen) {
     gen_kmax = std::max(gen_kmax, events[i].K);
     gen_maxq = std::max(gen_maxq, (events[i].n_draw + 3) / 4);
+    gen_maxu = std::max(gen_maxu, static_cast<int>(events[i].draw_units.size()));
   }
   n_k2 = static_cast<int>(k2.size()); n_gen = static_cast<int>(gen.size());
   k2.insert(k2.end(), gen.begin(), gen.end());
@@ -226,7 +229,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     // single-end: stage every drawing read's class id in LDS when that leaves room for >= 2 chains
     // MISO_NO_CLASS_PATH=1 (tests): force the direct mask path of sampler_grp
     const bool no_cls = std::getenv("MISO_NO_CLASS_PATH") != nullptr;
-    const int qs = (!p.paired && !no_cls && gen_maxq <= 2048) ? gen_maxq : 0;
+    const int qs = (!p.paired && !no_cls && gen_maxu > 0 && gen_maxu <= 2048 + MAX_DRAW_CLASSES) ? gen_maxu : 0;
     // paired-end: the per-event score table (K x il int32) joins the slice when >= 4 chains still fit
     int ts = p.paired ? gen_kmax * static_cast<int>(fd.prob.size()) : 0;
     if (ts && fp_bytes + 4 * 4 * static_cast<size_t>(grp_slice_bytes(gen_kmax, 0, ts)) > 64 * 1024) ts = 0;

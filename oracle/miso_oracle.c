@@ -625,6 +625,7 @@ typedef struct {
   int count_sums;        /* use count-based score sums */
   const double *match;   /* K x N */
   const int *order;      /* N (stream mode draw order) */
+  int *corder;           /* N (counter mode draw order, single-end): see counter_order() */
   const double *hyper;   /* K */
   double lg_sum, lg_each; /* lgamma(sum a), sum lgamma(a_k): miso.c:165-182 */
   double sigma, sd, covarConst;
@@ -696,16 +697,40 @@ static int count_valid(const double *col, int K, int *first) {
   return nv;
 }
 
+/* Counter-mode draw order of the single-end sampler: reads ordered by their compatibility column,
+   columns compared lexicographically as splicing_order_matches does (matrix.pmt:546-562), ties by
+   read index (the reference's qsort is unstable there; a contract needs a definite order).  The
+   r-th read of this order with >= 2 compatible isoforms uses Gibbs word r.  Paired-end: input order. */
+static const double *co_match; static int co_K;
+static int co_cmp(const void *a, const void *b) {
+  int x = *(const int *) a, y = *(const int *) b, k;
+  const double *cx = co_match + (size_t) x * co_K, *cy = co_match + (size_t) y * co_K;
+  for (k = 0; k < co_K; k++) {
+    int bx = cx[k] != 0, by = cy[k] != 0;
+    if (bx != by) return bx - by;
+  }
+  return (x > y) - (x < y);
+}
+static void counter_order(orc_state_t *S) {
+  int i;
+  S->corder = malloc(sizeof(int) * (size_t) (S->N > 0 ? S->N : 1));
+  for (i = 0; i < S->N; i++) S->corder[i] = i;
+  if (!S->paired) { co_match = S->match; co_K = S->K; qsort(S->corder, (size_t) S->N, sizeof(int), co_cmp); }
+}
+
 static void reassign(orc_state_t *S, uint32_t iter) {
   int k, i, K = S->K, N = S->N;
   for (k = 0; k < S->C; k++) {
     const double *psi = S->psi + k * K;
     int *ass = S->ass + (size_t) k * N;
     if (S->counter) {
-      uint32_t rank = 0; miso_u32x4 blk; uint32_t have = 0xFFFFFFFFu;
+      uint32_t rank = 0; miso_u32x4 blk; uint32_t have = 0xFFFFFFFFu; int ii;
       memset(&blk, 0, sizeof(blk));
-      for (i = 0; i < N; i++) {
-        const double *col = S->match + (size_t) i * K;
+      if (!S->corder) counter_order(S);
+      for (ii = 0; ii < N; ii++) {
+        const double *col;
+        i = S->corder[ii];
+        col = S->match + (size_t) i * K;
         int first = -1, nv = count_valid(col, K, &first);
         if (nv == 0) ass[i] = -1;
         else if (nv == 1) ass[i] = first;
@@ -936,7 +961,7 @@ static void fill_common(orc_state_t *S, const orc_gene_t *g, const orc_opts_t *o
 }
 
 static void free_common(orc_state_t *S) {
-  free(S->ass); free(S->psi); free(S->psiNew); free(S->alpha); free(S->alphaNew);
+  free(S->ass); free(S->psi); free(S->psiNew); free(S->alpha); free(S->alphaNew); free(S->corder);
 }
 
 /* ------------------------------------------------------------------------------------ */

@@ -1,0 +1,13 @@
+#!/bin/bash
+# Profile build of the library (-DMISO_K2_PROFILE: s_memtime phase counters written into loglik[0..]).
+set -e
+cd "$(dirname "$0")/.."
+mkdir -p tools/_build
+F="-DMISO_K2_PROFILE -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -Iinclude -Imiso_amd/csrc -Wno-unused-result"
+for f in runtime kernels kernels_k2 kernels_grp kernels_summary capi; do
+  /opt/rocm/bin/hipcc $F -c miso_amd/csrc/$f.hip -o tools/_build/$f.o &
+done
+/opt/rocm/bin/hipcc $F -x hip -c miso_amd/csrc/host.cpp -o tools/_build/host.o &
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC tools/_build/*.o -o tools/_build/libmiso_prof.so
+rm -f tools/_build/*.o
