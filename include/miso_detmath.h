@@ -49,6 +49,23 @@
 #define MISO_TAB static const double
 #endif
 
+/* Device code reads a table through MISO_TAB_REF: the pointer passes through an empty volatile
+   asm, so the compiler can neither fold the loads nor hoist them out of the sampler's iteration
+   loop -- hoisting all 72 coefficients at once spills SGPRs into VGPR lanes, and the reloads land
+   in the hot read loop.  Scalar loads from the constant cache at each use are far cheaper. */
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const double __attribute__((address_space(4))) *miso_ctab_t;
+static __device__ __forceinline__ miso_ctab_t miso_tab_fresh(miso_ctab_t p) {
+  __asm__ volatile("" : "+s"(p));
+  return p;
+}
+#define MISO_TAB_REF(t) miso_tab_fresh((miso_ctab_t) (t))
+#define MISO_TAB_PTR miso_ctab_t
+#else
+#define MISO_TAB_REF(t) (t)
+#define MISO_TAB_PTR const double *
+#endif
+
 MISO_TAB miso_tab_exp[12] = { /* 1/13! ... 1/2! */
   1.0 / 6227020800.0, 1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0,
   1.0 / 40320.0, 1.0 / 5040.0, 1.0 / 720.0, 1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0, 0.5 };
@@ -97,8 +114,11 @@ MISO_DM double miso_det_exp(double x) {
   k = (int) kd;
   r = miso_fma(-kd, LN2_HI, xm);
   r = miso_fma(-kd, LN2_LO, r);
-  p = miso_tab_exp[0];
-  for (i = 1; i < 12; i++) p = miso_fma(p, r, miso_tab_exp[i]);
+  {
+    MISO_TAB_PTR te = MISO_TAB_REF(miso_tab_exp);
+    p = te[0];
+    for (i = 1; i < 12; i++) p = miso_fma(p, r, te[i]);
+  }
   p = miso_fma(p, r, 1.0);
   p = miso_fma(p, r, 1.0);
   k1 = k / 2;
@@ -128,8 +148,11 @@ MISO_DM double miso_det_log(double x) {
   f = m - 1.0;
   s = f / (2.0 + f);
   z = s * s;
-  q = miso_tab_log[0];
-  for (i = 1; i < 12; i++) q = miso_fma(q, z, miso_tab_log[i]);
+  {
+    MISO_TAB_PTR tl = MISO_TAB_REF(miso_tab_log);
+    q = tl[0];
+    for (i = 1; i < 12; i++) q = miso_fma(q, z, tl[i]);
+  }
   R = z * q;                      /* log(1+f) = 2s + s*R = f - s*(f - R) */
   ed = (double) e;
   res = miso_fma(ed, LN2_HI, f - (s * (f - R) - ed * LN2_LO));
@@ -182,20 +205,32 @@ MISO_DM double miso_det_qnorm(double p) {
   q = p - 0.5;
   if ((q < 0 ? -q : q) <= 0.425) {
     r = 0.180625 - q * q;
-    num = miso_tab_qa[0]; den = miso_tab_qb[0];
-    for (i = 1; i < 8; i++) { num = num * r + miso_tab_qa[i]; den = den * r + miso_tab_qb[i]; }
+    {
+      MISO_TAB_PTR tn = MISO_TAB_REF(miso_tab_qa);
+      MISO_TAB_PTR td = MISO_TAB_REF(miso_tab_qb);
+      num = tn[0]; den = td[0];
+      for (i = 1; i < 8; i++) { num = num * r + tn[i]; den = den * r + td[i]; }
+    }
     return q * num / den;
   }
   r = (q > 0) ? (1.0 - p) : p;
   r = miso_det_sqrt(-miso_det_log(r));
   if (r <= 5.0) {
     r = r - 1.6;
-    num = miso_tab_qc[0]; den = miso_tab_qd[0];
-    for (i = 1; i < 8; i++) { num = num * r + miso_tab_qc[i]; den = den * r + miso_tab_qd[i]; }
+    {
+      MISO_TAB_PTR tn = MISO_TAB_REF(miso_tab_qc);
+      MISO_TAB_PTR td = MISO_TAB_REF(miso_tab_qd);
+      num = tn[0]; den = td[0];
+      for (i = 1; i < 8; i++) { num = num * r + tn[i]; den = den * r + td[i]; }
+    }
   } else {
     r = r - 5.0;
-    num = miso_tab_qe[0]; den = miso_tab_qf[0];
-    for (i = 1; i < 8; i++) { num = num * r + miso_tab_qe[i]; den = den * r + miso_tab_qf[i]; }
+    {
+      MISO_TAB_PTR tn = MISO_TAB_REF(miso_tab_qe);
+      MISO_TAB_PTR td = MISO_TAB_REF(miso_tab_qf);
+      num = tn[0]; den = td[0];
+      for (i = 1; i < 8; i++) { num = num * r + tn[i]; den = den * r + td[i]; }
+    }
   }
   val = num / den;
   return (q < 0.0) ? -val : val;

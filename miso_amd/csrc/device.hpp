@@ -25,12 +25,12 @@ struct DevEvent {
   uint64_t off_consts; // double[3K + CONST_EXTRA]
   uint64_t off_base;   // int32[K]: reads with exactly one compatible isoform, per isoform
   uint64_t off_draw;   // SE: uint32 mask[n_draw (padded to 4)]; PE: uint16 frag[n_draw x K]
-  uint64_t off_cls;    // SE: uint32 work units of the class path: q | wordmask << 20 | class << 24
-  uint64_t off_clsmask;// SE: per drawing-read class {uint32 mask, int32 reads}
+  uint64_t off_cls;    // SE: class table, CLS_WORDS uint32 per drawing-read class + a sentinel row
+  uint64_t off_clsmask;// SE: uint16 (class << 8 | member) per threshold of the class path
   int32_t n_dcls;      // SE: number of drawing-read classes (0 = use the masks)
-  int32_t n_units;     // SE: number of work units
+  int32_t n_units;     // SE: number of work units (Philox blocks x classes touching them)
   int32_t max_cls;     // SE: most isoforms any drawing class is compatible with
-  int32_t pad0;
+  int32_t n_pairs;     // SE: sum over classes of (isoforms - 1)
   uint64_t off_sfix;   // PE: int32[K x il] fixed-point scores, MISO_SFIX_BAD = non-finite
   // byte offsets into the output pool
   uint64_t off_samples; // double[S x K]  (reference layout: K x S column-major)
@@ -55,7 +55,7 @@ struct KernelArgs {
   const int32_t *slot_event;  // this launch's events (indices into `events`), n_slots of them
   int32_t n_slots;
   int32_t kstride;          // sampler_grp: isoform stride of the per-chain LDS slices
-  int32_t qstride;          // sampler_grp: SE work units per chain the LDS slice can stage (0 = no class path)
+  int32_t cstride;          // sampler_grp: SE drawing-read classes per chain in the LDS slice (0 = no class path)
   int32_t tstride;          // sampler_grp PE: score-table entries per chain staged in LDS (0 = none)
   int32_t n_events;
   int32_t C, M, B, lag;     // chains, iterations (incl. burn-in), burn-in, lag
@@ -68,17 +68,22 @@ constexpr uint64_t NO_TRACE = ~0ull;
 constexpr int MAX_DRAW_CLASSES = 32;  // single-end: per-class integer thresholds up to this many classes
 
 // LDS bytes of one chain's slice in sampler_grp (layout: kernels_grp.hip `carve`): isoform stride ks
-// (even), qs staged single-end work units (0 = no class path), ts paired-end score entries.
+// (even), cs single-end drawing-read classes (0 = no class path), ts paired-end score entries.
 #ifdef __HIPCC__
 #define MISO_DEVHOST __host__ __device__
 #else
 #define MISO_DEVHOST
 #endif
-MISO_DEVHOST inline int grp_cls_bytes(int ks, int qs) {
-  return qs > 0 ? MAX_DRAW_CLASSES * (ks - 1) * 8 + MAX_DRAW_CLASSES * 12 + ((qs + 1) & ~1) * 4 : 0;
+// class table row: {mask, first unit, first unit - first block, head | tail << 4 word masks};
+// after the sentinel row: A_k = reads of the classes whose last isoform is <= k, k < K
+constexpr int CLS_WORDS = 4;
+MISO_DEVHOST inline int grp_cls_bytes(int ks, int cs) {
+  return cs > 0 ? cs * (ks - 1) * 4 + ((cs * (ks - 1)) & 1) * 4 + (CLS_WORDS * (cs + 1) + ks + (ks & 1)) * 4 +
+                      ((cs * (ks - 1) * 2 + 7) & ~7)
+                : 0;
 }
-MISO_DEVHOST inline int grp_slice_bytes(int ks, int qs, int ts) {
-  return 10 * ks * 8 + 2 * ks * 4 + grp_cls_bytes(ks, qs) + ((ts + 1) & ~1) * 4;
+MISO_DEVHOST inline int grp_slice_bytes(int ks, int cs, int ts) {
+  return 15 * ks * 8 + 32 + (3 * ks + (ks & 1)) * 4 + grp_cls_bytes(ks, cs) + ((ts + 1) & ~1) * 4;
 }
 constexpr uint16_t FRAG_NONE = 0xFFFF;
 constexpr int32_t SFIX_BAD = INT32_MIN;  // == MISO_SFIX_BAD

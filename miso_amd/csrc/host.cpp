@@ -427,7 +427,7 @@ PackedEvent pack_event(const miso_params_t &p, const FragmentDist *fd, int K, in
     }
     e.n_draw++;
   }
-  if (!p.paired && e.n_draw > 0) {
+  if (!p.paired) {
     // draw order: by column (isoform 0 most significant, 0 < 1), ties by read index
     auto key = [K](uint32_t m) { uint32_t r = 0; for (int k = 0; k < K; k++) r = (r << 1) | ((m >> k) & 1u); return r; };
     std::vector<int32_t> perm(e.n_draw);
@@ -442,17 +442,29 @@ PackedEvent pack_event(const miso_params_t &p, const FragmentDist *fd, int K, in
     if (e.dcls_mask.size() > MAX_DRAW_CLASSES) {
       e.dcls_mask.clear(); e.dcls_start.clear();
     } else {
-      // one unit = the words of one Philox block (draws 4q .. 4q+3) that belong to one class
+      // one unit = the words of one Philox block (draws 4q .. 4q+3) that belong to one class; a
+      // class's units are consecutive blocks, so the table only needs where they start
       for (size_t c = 0; c < e.dcls_mask.size(); c++) {
-        e.max_cls_size = std::max(e.max_cls_size, __builtin_popcount(e.dcls_mask[c]));
-        for (int r = e.dcls_start[c]; r < e.dcls_start[c + 1];) {
-          const int q = r >> 2, end = std::min(e.dcls_start[c + 1], 4 * q + 4);
-          uint32_t wm = 0;
-          for (; r < end; r++) wm |= 1u << (r & 3);
-          e.draw_units.push_back(static_cast<uint32_t>(q) | wm << 20 | static_cast<uint32_t>(c) << 24);
-        }
+        const int nv = __builtin_popcount(e.dcls_mask[c]);
+        const int r0 = e.dcls_start[c], r1 = e.dcls_start[c + 1];
+        const int q0 = r0 >> 2, q1 = (r1 - 1) >> 2;
+        const uint32_t head = (0xFu << (r0 & 3)) & 0xFu, tail = 0xFu >> (3 - ((r1 - 1) & 3));
+        e.max_cls_size = std::max(e.max_cls_size, nv);
+        const uint32_t row[CLS_WORDS] = {e.dcls_mask[c], static_cast<uint32_t>(e.n_units),
+                                         static_cast<uint32_t>(e.n_units - q0), head | tail << 4};
+        e.dcls_tab.insert(e.dcls_tab.end(), row, row + CLS_WORDS);
+        e.n_units += q1 - q0 + 1;
+        for (int k = 0, j = 0; j < nv - 1; k++)   // every member but the last
+          if ((e.dcls_mask[c] >> k) & 1u) { e.dcls_pairs.push_back(static_cast<uint16_t>(c << 8 | k)); j++; }
       }
-      if (e.n_draw > (1 << 22)) { e.dcls_mask.clear(); e.dcls_start.clear(); e.draw_units.clear(); }
+      const uint32_t last[CLS_WORDS] = {0u, static_cast<uint32_t>(e.n_units), 0u, 0xFFu};
+      e.dcls_tab.insert(e.dcls_tab.end(), last, last + CLS_WORDS);
+      for (int k = 0; k < K; k++) {   // A_k: every read of a class whose last isoform is <= k picks <= k
+        uint32_t ak = 0;
+        for (size_t c = 0; c < e.dcls_mask.size(); c++)
+          if (31 - __builtin_clz(e.dcls_mask[c]) <= k) ak += static_cast<uint32_t>(e.dcls_start[c + 1] - e.dcls_start[c]);
+        e.dcls_tab.push_back(ak);
+      }
     }
   }
   for (const auto &kv : cls) {

@@ -98,8 +98,10 @@ struct PackedEvent {
   std::vector<uint32_t> draw_mask;      // single-end: n_draw
   std::vector<uint32_t> dcls_mask;      // single-end: distinct masks among the drawing reads, in draw order
   std::vector<int32_t> dcls_start;      // ... first draw of each class (+ n_draw at the end)
-  std::vector<uint32_t> draw_units;     // ... work units of the class kernel: q | wordmask << 20 | class << 24
-                                        // (all three empty with more than MAX_DRAW_CLASSES classes)
+  std::vector<uint32_t> dcls_tab;       // ... device class table, CLS_WORDS per class + sentinel (device.hpp)
+  std::vector<uint16_t> dcls_pairs;     // ... (class << 8 | isoform) for every class member but its last
+                                        // (all four empty with more than MAX_DRAW_CLASSES classes)
+  int n_units = 0;                      // ... work units: (Philox block, class) incidences
   int max_cls_size = 0;                 // ... most isoforms any drawing class is compatible with
   std::vector<uint16_t> draw_frag;      // paired-end: n_draw x K
   std::vector<int32_t> sfix_table;      // paired-end: K x il fixed-point isoscores

@@ -5,18 +5,25 @@
 // benefit of a single chain.  Here a chain owns G lanes (G = 2..32) and a wavefront carries 64/G
 // chains, so that step is shared 64/G ways, exactly as in sampler_k2 -- but for any K <= 32 and for
 // the paired-end model:
-//   * per-chain vectors (psi, alpha, proposals, scratch, per-isoform constants, counts) live in an
-//     LDS slice of the chain; lane `sub` of the chain owns isoforms sub, sub+G, ...: transcendentals
-//     run lane-parallel, the reference's left-to-right sums are re-read from LDS by every lane
-//     (broadcast reads), so all lanes of a chain hold identical scalars;
-//   * Gibbs: the chain's lanes stride over its draw quads (one Philox4x32-10 block = four reads);
-//     SE reads carry a u32 compatibility mask, PE reads K u16 fragment indices into the
-//     fragment-probability table staged in LDS; picks are counted with LDS atomics on the chain's
-//     slice; the PE fragment score is accumulated in 2^-26 fixed point and reduced over the lanes;
-//   * single-end Gibbs, class path: the drawing reads are ordered by compatibility class (host.hpp),
-//     so a class's pick thresholds are integers computed once per iteration and a read costs one
-//     Philox word and (class size - 1) compare+add into register counters -- no per-read LDS
-//     traffic, no atomics (class_units below).
+//   * per-chain vectors (psi, alpha, proposals, cached logs, per-isoform constants, counts) live in
+//     an LDS slice of the chain; the reference's left-to-right sums are re-read from LDS by every
+//     lane (broadcast reads), so all lanes of a chain hold identical scalars;
+//   * Metropolis-Hastings step = SIX transcendental passes per iteration instead of one per call
+//     site: every pass evaluates one function (qnorm, exp, log, exp, log, exp) on all the arguments
+//     that are ready, one argument per lane -- the log psi'_k of the joint score next to the
+//     log(psi'_k / psi'_K) of the proposal density, the softmax exponentials next to the two
+//     Gaussian kernels, the log-sum-exp next to the two proposal densities.  Everything that
+//     depends only on the CURRENT psi (its logs, log-sum-exp, Jacobian) is cached across
+//     iterations and swapped in on acceptance.  Values and summation orders are those of
+//     miso.c:97-163, 243-307, 449-552 (same as sampler_wave and the CPU checker);
+//   * single-end Gibbs, class path: the drawing reads are ordered by compatibility class
+//     (host.hpp), so a class's pick thresholds are integers computed once per iteration (one
+//     (class, member) pair per lane) and a read costs one Philox word and K - 1 compare+add into
+//     register counters indexed by ISOFORM (D_k = reads whose pick is isoform <= k), which need
+//     no flushing when the class changes -- no per-read LDS traffic, no atomics (class_units);
+//   * paired-end Gibbs: K u16 fragment indices per read into the fragment-probability table staged
+//     in LDS; picks are counted with LDS atomics on the chain's slice; the fragment score is
+//     accumulated in 2^-26 fixed point and reduced over the lanes.
 // Same arithmetic, same order, same RNG addresses as sampler_wave and the CPU checker.
 #include <hip/hip_runtime.h>
 
@@ -24,6 +31,7 @@
 #include "miso_amd.h"
 #include "miso_detmath.h"
 #include "miso_philox.h"
+#include "gibbs_rng.hpp"
 
 #pragma clang fp contract(off)
 
@@ -49,34 +57,38 @@ __device__ __forceinline__ double seq_sum(const double *v, int n) {
   return acc;
 }
 
-struct Slice {            // one chain's LDS slice; every array has `ks` entries
-  double *psi, *alpha, *psiN, *alphaN, *ta, *tb, *tc, *cst, *isc, *hm1;
+struct Slice {            // one chain's LDS slice; every per-isoform array has `ks` entries
+  double *psi, *alpha, *lp, *tb, *lr;        // current state and its cache: log psi, log psi + cst, log(psi_k / psi_K')
+  double *psiN, *alphaN, *lpN, *tbN, *lrN;   // the proposal's
+  double *tc, *u2;                           // scratch (tc doubles as the first Gaussian-term buffer)
+  double *cst, *isc, *hm1;                   // per-isoform constants (device.hpp)
+  double *sx;                                // 4 scalars
   int *cnt, *bas;  // picks of the drawing reads; reads with a single compatible isoform
-  // SE class path (only when qstride > 0), per drawing-read class c < MAX_DRAW_CLASSES:
-  uint32_t *thr;   //   low words of the cumulative integer thresholds [c x (ks - 1)]
-  int *cum;        //   reads of the class whose word is below threshold j [c x (ks - 1)]
-  uint32_t *cmask; //   compatibility mask
-  int *csize;      //   number of reads
-  uint32_t *alw;   //   bit j: threshold j is 2^32 (every word is below it)
-  uint32_t *units; //   work units: q | wordmask << 20 | class << 24 [qstride]
+  int *dl;         // SE class path: D_k = drawing reads that picked an isoform <= k
+  // SE class path (only when cstride > 0), per drawing-read class c:
+  uint32_t *thr;   //   thr[c][k] = words below it pick an isoform <= k [c x (ks - 1)]
+  uint32_t *ctab;  //   CLS_WORDS words per class + one sentinel row, then A_k (host.hpp dcls_tab)
+  uint16_t *pairs; //   (class << 8 | isoform) of every threshold to compute
   int32_t *stab;   // PE: the event's fixed-point score table [tstride] (when it fits)
 };
 
-
-__device__ __forceinline__ Slice carve(unsigned char *base, int ks, int qs) {
+__device__ __forceinline__ Slice carve(unsigned char *base, int ks, int cs) {
   Slice s;
   double *d = reinterpret_cast<double *>(base);
-  s.psi = d; s.alpha = d + ks; s.psiN = d + 2 * ks; s.alphaN = d + 3 * ks; s.ta = d + 4 * ks;
-  s.tb = d + 5 * ks; s.tc = d + 6 * ks; s.cst = d + 7 * ks; s.isc = d + 8 * ks; s.hm1 = d + 9 * ks;
-  s.cnt = reinterpret_cast<int *>(d + 10 * ks);
+  s.psi = d; s.alpha = d + ks; s.lp = d + 2 * ks; s.tb = d + 3 * ks; s.lr = d + 4 * ks;
+  s.psiN = d + 5 * ks; s.alphaN = d + 6 * ks; s.lpN = d + 7 * ks; s.tbN = d + 8 * ks; s.lrN = d + 9 * ks;
+  s.tc = d + 10 * ks; s.u2 = d + 11 * ks;
+  s.cst = d + 12 * ks; s.isc = d + 13 * ks; s.hm1 = d + 14 * ks;
+  s.sx = d + 15 * ks;
+  s.cnt = reinterpret_cast<int *>(s.sx + 4);
   s.bas = s.cnt + ks;
-  s.thr = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(d) + 10 * ks * 8 + 2 * ks * 4);
-  s.cum = reinterpret_cast<int *>(s.thr + MAX_DRAW_CLASSES * (ks - 1));
-  s.cmask = reinterpret_cast<uint32_t *>(s.cum + MAX_DRAW_CLASSES * (ks - 1));
-  s.csize = reinterpret_cast<int *>(s.cmask + MAX_DRAW_CLASSES);
-  s.alw = reinterpret_cast<uint32_t *>(s.csize + MAX_DRAW_CLASSES);
-  s.units = s.alw + MAX_DRAW_CLASSES;
-  s.stab = reinterpret_cast<int32_t *>(reinterpret_cast<unsigned char *>(s.thr) + grp_cls_bytes(ks, qs));
+  s.dl = s.bas + ks;
+  unsigned char *c = reinterpret_cast<unsigned char *>(s.dl + ks + (ks & 1));
+  const int tw = ks - 1;
+  s.thr = reinterpret_cast<uint32_t *>(c);
+  s.ctab = s.thr + cs * tw + ((cs * tw) & 1);
+  s.pairs = reinterpret_cast<uint16_t *>(s.ctab + CLS_WORDS * (cs + 1) + ks + (ks & 1));
+  s.stab = reinterpret_cast<int32_t *>(c + grp_cls_bytes(ks, cs));
   return s;
 }
 
@@ -126,65 +138,78 @@ template <bool LE> __device__ __forceinline__ bool thr_pred(int64_t u, double c,
   const double rnd = static_cast<double>(static_cast<uint32_t>(u)) * (1.0 / 4294967296.0) * T;
   return LE ? !(rnd > c) : (rnd < c);
 }
-template <bool LE> __device__ __forceinline__ uint64_t draw_threshold(double c, double T) {
-  double est = c / T * 4294967296.0;
-  est = (est > 0.0) ? est : 0.0;
+// `est` only seeds the search (any value gives the exact threshold; a good one makes it short)
+template <bool LE> __device__ __forceinline__ uint64_t draw_threshold(double c, double T, double est) {
+  est = (est > 0.0) ? est : 0.0;                      // also maps NaN to 0
   est = (est > 4294967296.0) ? 4294967296.0 : est;
   const int64_t t0 = static_cast<int64_t>(est);
   const int n = thr_pred<LE>(t0 - 1, c, T) + thr_pred<LE>(t0, c, T) + thr_pred<LE>(t0 + 1, c, T);
   int64_t t = t0 - 1 + n;
-  if (!thr_pred<LE>(t0 - 2, c, T) || thr_pred<LE>(t0 + 2, c, T)) {  // exact fallback, not taken in practice
-    t = t0 < 0 ? 0 : (t0 > 4294967296ll ? 4294967296ll : t0);
+  if (!thr_pred<LE>(t0 - 2, c, T) || thr_pred<LE>(t0 + 2, c, T)) {  // exact fallback, rarely taken
+    t = t0;
     for (int g = 0; g < 4096 && t > 0 && !thr_pred<LE>(t - 1, c, T); g++) t--;
     for (int g = 0; g < 4096 && t < 4294967296ll && thr_pred<LE>(t, c, T); g++) t++;
   }
   return static_cast<uint64_t>(t < 0 ? 0 : t);
 }
 
-// The single-end class path's read loop.  The chain's G lanes stride over its work units (the words
-// of one Philox block that belong to one class); a lane keeps the thresholds T[] of its current
-// class and the counters cj[j] = #{words seen below T[j]} in registers and touches LDS only when
-// its class changes.  TW >= the wavefront's largest (class size - 1), compile-time for the unroll.
+// The single-end class path's read loop.  The chain's G lanes stride over its work units (unit i =
+// the words of one Philox block that belong to one class; classes are consecutive, so units are
+// implicit: class c owns units [ustart_c, ustart_(c+1)), unit i covers block i - qd_c, all four words
+// except in the class's first / last unit).  A lane keeps the thresholds T[k] of its current class
+// in registers and counts D[k] += (word < T[k]): isoform-indexed, so nothing is flushed when the
+// class changes; the next class's row is prefetched while the current one is being consumed.
+// TW = the wavefront's K - 1, rounded up to an instantiated value.
 template <int TW, int G>
-__device__ __forceinline__ void class_units(const uint32_t *units, const uint32_t *thr, int *cum, int tw,
-                                            int nuw, int n_units, int sub, uint64_t seed,
-                                            uint32_t event_id, uint32_t chain, uint32_t iter) {
-  uint32_t T[TW]; int cj[TW];
+__device__ __forceinline__ void class_units(const uint32_t *ctab, const uint32_t *thr, int tw, int ncls,
+                                            int nuw, int n_units, int sub, const GibbsRng &rng,
+                                            uint32_t n0r0, int (&D)[TW]) {
+  uint32_t T[TW], NT[TW];
 #pragma unroll
-  for (int j = 0; j < TW; j++) { T[j] = 0; cj[j] = 0; }
-  int cur = -1;
+  for (int j = 0; j < TW; j++) { T[j] = 0; D[j] = 0; NT[j] = (j < tw) ? thr[j] : 0u; }
+  int cur = -1, ust = 0, uend = 0, qd = 0;
+  uint32_t hmtm = 0xFFu;
+  int n_ust = static_cast<int>(ctab[1]), n_uend = static_cast<int>(ctab[CLS_WORDS + 1]),
+      n_qd = static_cast<int>(ctab[2]);
+  uint32_t n_hm = ctab[3];
   for (int i0 = 0; i0 < nuw; i0 += G) {
     const int i = i0 + sub;
     const bool active = i < n_units;
-    const uint32_t un = active ? units[i] : 0u;
-    const uint32_t wm = (un >> 20) & 0xFu;
-    const int c = active ? static_cast<int>(un >> 24) : cur;
-    const miso_u32x4 u = miso_draw_block(seed, event_id, chain, iter, MISO_SITE_GIBBS, un & 0xFFFFFu);
-    if (c != cur) {
-      if (cur >= 0) {
+    if (active && i >= uend) {
+      cur++;
+      if (i >= n_uend) {   // the lane's stride jumped over whole classes (classes of fewer than G units)
+        do { cur++; n_uend = static_cast<int>(ctab[CLS_WORDS * (cur + 1) + 1]); } while (i >= n_uend);
+        n_ust = static_cast<int>(ctab[CLS_WORDS * cur + 1]);
+        n_qd = static_cast<int>(ctab[CLS_WORDS * cur + 2]);
+        n_hm = ctab[CLS_WORDS * cur + 3];
 #pragma unroll
-        for (int j = 0; j < TW; j++) if (j < tw && cj[j]) atomicAdd(&cum[cur * tw + j], cj[j]);
+        for (int j = 0; j < TW; j++) NT[j] = (j < tw) ? thr[cur * tw + j] : 0u;
       }
+      ust = n_ust; uend = n_uend; qd = n_qd; hmtm = n_hm;
 #pragma unroll
-      for (int j = 0; j < TW; j++) { T[j] = (j < tw) ? thr[c * tw + j] : 0u; cj[j] = 0; }
-      cur = c;
+      for (int j = 0; j < TW; j++) T[j] = NT[j];
+      const int nx = min(cur + 1, ncls - 1);
+      n_ust = static_cast<int>(ctab[CLS_WORDS * nx + 1]);
+      n_uend = static_cast<int>(ctab[CLS_WORDS * (nx + 1) + 1]);
+      n_qd = static_cast<int>(ctab[CLS_WORDS * nx + 2]);
+      n_hm = ctab[CLS_WORDS * nx + 3];
+#pragma unroll
+      for (int j = 0; j < TW; j++) NT[j] = (j < tw) ? thr[nx * tw + j] : 0u;
     }
+    uint32_t wm = active ? 0xFu : 0u;
+    if (i == ust) wm &= hmtm;
+    if (i == uend - 1) wm &= hmtm >> 4;
+    const miso_u32x4 u = philox_gibbs(rng, static_cast<uint32_t>(active ? i - qd : 0), n0r0);
 #pragma unroll
     for (int w = 0; w < 4; w++) {
       const uint32_t uw = ((wm >> w) & 1u) ? u.v[w] : 0xFFFFFFFFu;   // never below a 32-bit threshold
 #pragma unroll
-      for (int j = 0; j < TW; j++) cj[j] += (uw < T[j]) ? 1 : 0;
+      for (int j = 0; j < TW; j++) D[j] += (uw < T[j]) ? 1 : 0;
     }
-  }
-  if (cur >= 0) {
-#pragma unroll
-    for (int j = 0; j < TW; j++) if (j < tw && cj[j]) atomicAdd(&cum[cur * tw + j], cj[j]);
   }
 }
 
 }  // namespace
-
-
 
 template <int G, bool PE>
 __global__ __launch_bounds__(256, 2) void sampler_grp(const KernelArgs a) {
@@ -204,8 +229,9 @@ __global__ __launch_bounds__(256, 2) void sampler_grp(const KernelArgs a) {
   long slot = wave_id * CPW + grp;
   const bool live = slot < n_chains;
   if (!live) slot = n_chains - 1;           // shadow a real chain, store nothing
-  const int ks = a.kstride;
-  const Slice S = carve(smem + fp_bytes + (static_cast<size_t>(wave) * CPW + grp) * grp_slice_bytes(ks, a.qstride, a.tstride), ks, a.qstride);
+  const int ks = a.kstride, cs = a.cstride;
+  Slice S = carve(smem + fp_bytes + (static_cast<size_t>(wave) * CPW + grp) * grp_slice_bytes(ks, cs, a.tstride),
+                  ks, cs);
 
   const int ev = a.slot_event[slot / a.C];
   const uint32_t chain = static_cast<uint32_t>(slot % a.C);
@@ -227,32 +253,32 @@ __global__ __launch_bounds__(256, 2) void sampler_grp(const KernelArgs a) {
     const int k = k0 + sub;
     if (k < K) {
       S.cst[k] = consts[k]; S.isc[k] = consts[K + k]; S.hm1[k] = consts[2 * K + k];
-      S.alpha[k] = 0.0; S.psi[k] = 0.0; S.cnt[k] = 0; S.bas[k] = base[k];
+      S.alpha[k] = 0.0; S.psi[k] = 0.0; S.cnt[k] = 0; S.bas[k] = base[k]; S.dl[k] = 0;
     }
   }
   // single-end class path: usable when every chain of the wavefront has a class table
   const int n_dcls = PE ? 0 : E.n_dcls;
   const int n_units = PE ? 0 : E.n_units;
-  int ncw = n_dcls, nuw = n_units, tww = PE ? 0 : E.max_cls - 1;
-  bool cls_ok = !PE && a.qstride > 0 && (n_dcls > 0 || E.n_draw == 0) && n_units <= a.qstride;
+  const int n_pairs = PE ? 0 : E.n_pairs;
+  int ncw = n_dcls, nuw = n_units, npw = n_pairs, tww = K - 1;
+  bool cls_ok = !PE && cs > 0 && (n_dcls > 0 || E.n_draw == 0) && n_dcls <= cs;
   for (int off = 32; off >= 1; off >>= 1) {
     ncw = max(ncw, __shfl_xor(ncw, off));
     nuw = max(nuw, __shfl_xor(nuw, off));
+    npw = max(npw, __shfl_xor(npw, off));
     tww = max(tww, __shfl_xor(tww, off));
   }
   cls_ok = __all(cls_ok);
   ncw = __builtin_amdgcn_readfirstlane(ncw);
   nuw = __builtin_amdgcn_readfirstlane(nuw);
+  npw = __builtin_amdgcn_readfirstlane(npw);
   tww = __builtin_amdgcn_readfirstlane(tww);
-  if (cls_ok) {
-    const uint32_t *gm = reinterpret_cast<const uint32_t *>(a.in_pool + E.off_clsmask);
-    for (int c0 = 0; c0 < ncw; c0 += G) {
-      const int cc = c0 + sub;
-      if (cc < n_dcls) { S.cmask[cc] = gm[2 * cc]; S.csize[cc] = static_cast<int>(gm[2 * cc + 1]); }
-    }
-    // the work units stay in LDS for the whole run: the read loop never waits on global memory
-    const uint32_t *gu = reinterpret_cast<const uint32_t *>(a.in_pool + E.off_cls);
-    for (int i0 = 0; i0 < nuw; i0 += G) { const int i = i0 + sub; if (i < n_units) S.units[i] = gu[i]; }
+  if (cls_ok) {   // the class tables stay in LDS for the whole run
+    const uint32_t *gt = reinterpret_cast<const uint32_t *>(a.in_pool + E.off_cls);
+    const uint16_t *gp = reinterpret_cast<const uint16_t *>(a.in_pool + E.off_clsmask);
+    for (int i = sub; i < CLS_WORDS * (n_dcls + 1); i += G) S.ctab[i] = gt[i];
+    for (int k = sub; k < K; k += G) S.ctab[CLS_WORDS * (cs + 1) + k] = gt[CLS_WORDS * (n_dcls + 1) + k];   // A_k
+    for (int i = sub; i < n_pairs; i += G) S.pairs[i] = gp[i];
   }
   wave_sync();
   Scalars c;
@@ -263,9 +289,8 @@ __global__ __launch_bounds__(256, 2) void sampler_grp(const KernelArgs a) {
   const uint16_t *frags = reinterpret_cast<const uint16_t *>(a.in_pool + E.off_draw);
   const int32_t *sfix = reinterpret_cast<const int32_t *>(a.in_pool + E.off_sfix);
   if (PE && a.tstride > 0) {  // score table into the chain's slice: no per-read gather from L2
-    int32_t *stab = S.stab;
-    for (int i = sub; i < K * a.il; i += G) stab[i] = sfix[i];
-    sfix = stab;
+    for (int i = sub; i < K * a.il; i += G) S.stab[i] = sfix[i];
+    sfix = S.stab;
     wave_sync();
   }
   double *samples = reinterpret_cast<double *>(a.out_pool + E.off_samples);
@@ -275,6 +300,7 @@ __global__ __launch_bounds__(256, 2) void sampler_grp(const KernelArgs a) {
                                              : reinterpret_cast<int32_t *>(a.out_pool + E.off_trace);
   const int n_draw = E.n_draw, n_quads = (n_draw + 3) >> 2;
   int64_t rfix = 0; int rbad = 0;
+  const GibbsRng rng = gibbs_rng_init(a.seed, event_id, chain);
 
 #ifdef MISO_K2_PROFILE
   uint64_t gp_thr = 0, gp_loop = 0, gp_mh = 0;
@@ -284,65 +310,87 @@ __global__ __launch_bounds__(256, 2) void sampler_grp(const KernelArgs a) {
     GPROF_T(t0);
     for (int k0 = 0; k0 < Kw; k0 += G) { const int k = k0 + sub; if (k < K) S.cnt[k] = 0; }
     wave_sync();
+    bool slow = false;   // a non-final threshold of 2^32 cannot be held in 32 bits: direct path this time
     if (!PE && cls_ok && !__any(write_ass)) {
-      // integer thresholds of every drawing-read class for the current psi: one class per lane
+      // integer thresholds of every drawing-read class for the current psi: one (class, member)
+      // pair per lane
       const int tw = ks - 1;
+      for (int p0 = 0; p0 < npw; p0 += G) {
+        const int p = p0 + sub;
+        if (p < n_pairs) {
+          const uint32_t pr = S.pairs[p];
+          const int cc = static_cast<int>(pr >> 8), kp = static_cast<int>(pr & 0xFFu);
+          const uint32_t m = S.ctab[CLS_WORDS * cc];
+          double T = 0.0, cumw = 0.0;
+          for (uint32_t mm = m; mm; mm &= mm - 1) {   // ascending isoforms, as miso.c:11-22
+            const int kk = __ffs(mm) - 1;
+            T = T + S.psi[kk];
+            if (kk == kp) cumw = T;
+          }
+          const double est = cumw * (4294967296.0 / T);
+          const uint64_t t = (__popc(m) == 2) ? draw_threshold<false>(cumw, T, est) : draw_threshold<true>(cumw, T, est);
+          S.thr[cc * tw + kp] = static_cast<uint32_t>(t);
+          slow |= (t >> 32) != 0;
+        }
+      }
+      wave_sync();
+      // per class: running maximum over its members (first j with u < t_j == first j with
+      // u < max(t_0..t_j)), spread over the isoform axis: thr[c][k] = threshold of the last member
+      // <= k, 0 before the first member and from the last member on (those reads are in A_k)
       for (int c0 = 0; c0 < ncw; c0 += G) {
         const int cc = c0 + sub;
         if (cc < n_dcls) {
-          const uint32_t m = S.cmask[cc];
-          const int nv = __popc(m);
-          double T = 0.0;
-          for (uint32_t mm = m; mm; mm &= mm - 1) T = T + S.psi[__ffs(mm) - 1];
-          double cum = 0.0; uint64_t run = 0; uint32_t alw = 0; int j = 0;
-          for (uint32_t mm = m; j < nv - 1; mm &= mm - 1, j++) {
-            cum = cum + S.psi[__ffs(mm) - 1];
-            const uint64_t t = (nv == 2) ? draw_threshold<false>(cum, T) : draw_threshold<true>(cum, T);
-            run = t > run ? t : run;          // first j with u < t_j  ==  first j with u < running max
-            S.thr[cc * tw + j] = static_cast<uint32_t>(run);
-            alw |= static_cast<uint32_t>(run >> 32) << j;
-            S.cum[cc * tw + j] = 0;
+          const uint32_t m = S.ctab[CLS_WORDS * cc];
+          const int kmax = 31 - __clz(static_cast<int>(m));
+          uint32_t run = 0, val = 0;
+          for (int k = 0; k < K - 1; k++) {
+            if (k >= kmax) val = 0u;
+            else if ((m >> k) & 1u) { const uint32_t t = S.thr[cc * tw + k]; run = t > run ? t : run; val = run; }
+            S.thr[cc * tw + k] = val;
           }
-          for (; j < tw; j++) { S.thr[cc * tw + j] = 0u; S.cum[cc * tw + j] = 0; }
-          S.alw[cc] = alw;
         }
       }
+      for (int k0 = 0; k0 < Kw; k0 += G) { const int k = k0 + sub; if (k < K) S.dl[k] = 0; }
       wave_sync();
       GPROF_T(t1);
       GPROF_ADD(gp_thr, t0, t1);
-#define MISO_UNITS(TW) class_units<TW, G>(S.units, S.thr, S.cum, tw, nuw, n_units, sub, a.seed, event_id, chain, iter)
-      if (tww <= 1) MISO_UNITS(1);
-      else if (tww == 2) MISO_UNITS(2);
-      else if (tww == 3) MISO_UNITS(3);
-      else if (tww == 4) MISO_UNITS(4);
-      else if (tww == 5) MISO_UNITS(5);
-      else if (tww == 6) MISO_UNITS(6);
-      else if (tww == 7) MISO_UNITS(7);
-      else if (tww <= 9) MISO_UNITS(9);
-      else if (tww <= 12) MISO_UNITS(12);
-      else if (tww <= 16) MISO_UNITS(16);
-      else if (tww <= 23) MISO_UNITS(23);
-      else MISO_UNITS(31);
+      slow = __any(slow);
+      if (!slow) {
+        const uint32_t n0r0 = rng.p1hi ^ iter ^ rng.k0;
+#define MISO_UNITS(TW)                                                                               \
+  {                                                                                                  \
+    int D[TW];                                                                                       \
+    class_units<TW, G>(S.ctab, S.thr, tw, n_dcls, nuw, n_units, sub, rng, n0r0, D);                  \
+    _Pragma("unroll") for (int j = 0; j < TW; j++) if (j < tw && D[j]) atomicAdd(&S.dl[j], D[j]);   \
+  }
+        if (tww <= 2) MISO_UNITS(2)
+        else if (tww == 3) MISO_UNITS(3)
+        else if (tww == 4) MISO_UNITS(4)
+        else if (tww == 5) MISO_UNITS(5)
+        else if (tww == 6) MISO_UNITS(6)
+        else if (tww == 7) MISO_UNITS(7)
+        else if (tww <= 9) MISO_UNITS(9)
+        else if (tww <= 12) MISO_UNITS(12)
+        else if (tww <= 16) MISO_UNITS(16)
+        else if (tww <= 23) MISO_UNITS(23)
+        else MISO_UNITS(31)
 #undef MISO_UNITS
-      wave_sync();
-      // cumulative counts -> picks per isoform: member j of the class got C_j - C_(j-1) reads
-      for (int c0 = 0; c0 < ncw; c0 += G) {
-        const int cc = c0 + sub;
-        if (cc < n_dcls) {
-          const uint32_t m = S.cmask[cc], alw = S.alw[cc];
-          const int nv = __popc(m), nc = S.csize[cc];
-          int prev = 0, j = 0;
-          for (uint32_t mm = m; mm; mm &= mm - 1, j++) {
-            const int Cj = (j == nv - 1 || ((alw >> j) & 1u)) ? nc : S.cum[cc * tw + j];
-            if (Cj != prev) atomicAdd(&S.cnt[__ffs(mm) - 1], Cj - prev);
-            prev = Cj;
+        wave_sync();
+        // D_k (+ the reads of classes that end at or before k) -> picks per isoform
+        const uint32_t *A = S.ctab + CLS_WORDS * (cs + 1);
+        for (int k0 = 0; k0 < Kw; k0 += G) {
+          const int k = k0 + sub;
+          if (k < K) {
+            const int hi = (k < K - 1) ? S.dl[k] + static_cast<int>(A[k]) : n_draw;
+            const int lo = (k > 0) ? S.dl[k - 1] + static_cast<int>(A[k - 1]) : 0;
+            S.cnt[k] = hi - lo;
           }
         }
+        wave_sync();
+        GPROF_T(t2);
+        GPROF_ADD(gp_loop, t1, t2);
+        return;
       }
-      wave_sync();
-      GPROF_T(t2);
-      GPROF_ADD(gp_loop, t1, t2);
-      return;
     }
     int64_t acc = 0; int bad = 0;
     const bool small = Kw <= 8;
@@ -422,7 +470,7 @@ __global__ __launch_bounds__(256, 2) void sampler_grp(const KernelArgs a) {
   };
   auto count_of = [&](int k) { return S.bas[k] + S.cnt[k]; };
 
-  // ---- alpha' = alpha + sd z ; psi' = logit_inv(alpha')  (miso.c:449-471) ----
+  // ---- alpha' = alpha + sd z ; psi' = logit_inv(alpha')  (miso.c:449-471): passes 1 (qnorm) and 2 (exp) ----
   auto propose = [&](double *alpha_in, double *alpha_out, double *psi_out,
                      uint32_t iter, uint32_t &accept_word) {
     {
@@ -438,62 +486,57 @@ __global__ __launch_bounds__(256, 2) void sampler_grp(const KernelArgs a) {
         const double z = miso_det_norm_from_unif(miso_u01(b.v[w & 3]), miso_u01(b.v[(w & 3) + 1]));
         const double an = alpha_in[k] + c.sd * z;
         alpha_out[k] = an;
-        S.ta[k] = miso_det_exp(an);
+        S.tc[k] = miso_det_exp(an);
       }
     }
     wave_sync();
-    const double sumexp = seq_sum(S.ta, K - 1) + 1.0;
-    for (int k0 = 0; k0 < Kw; k0 += G) { const int k = k0 + sub; if (k < K - 1) psi_out[k] = S.ta[k] / sumexp; }
+    const double sumexp = seq_sum(S.tc, K - 1) + 1.0;
+    for (int k0 = 0; k0 < Kw; k0 += G) { const int k = k0 + sub; if (k < K - 1) psi_out[k] = S.tc[k] / sumexp; }
     wave_sync();
     const double sumpsi = seq_sum(psi_out, K - 1);
     if (sub == 0) psi_out[K - 1] = 1 - sumpsi;
     wave_sync();
   };
 
-  // ---- joint log score of x under the current counts (miso.c:243-307; PE miso_paired.c:133-174) ----
-  auto joint = [&](double *x, double readProbPE) {
-    for (int k0 = 0; k0 < Kw; k0 += G) {
-      const int k = k0 + sub;
-      if (k < K) { const double lx = miso_det_log(x[k]); S.ta[k] = lx; S.tb[k] = lx + S.cst[k]; }
+  // ---- the psi-only part of both scores, cached per state: lp = log x, tb = lp + cst, lr =
+  // log(x_k / x_K') with x_K' = 1 - x_0 - x_1 ... (miso.c:104-109), and the Jacobian 1/(prod x_i x_K').
+  // ONE log pass over 2K-1 arguments. ----
+  auto log_pass = [&](const double *x, double *lp, double *tb, double *lr, double &jac) {
+    double ltheta = 1.0, prod = 1.0;
+    for (int i = 0; i < K - 1; i++) { const double t = x[i]; ltheta = ltheta - t; prod = prod * t; }
+    jac = 1.0 / prod / ltheta;
+    for (int s0 = 0; s0 < 2 * Kw - 1; s0 += G) {
+      const int s = s0 + sub;
+      if (s < 2 * K - 1) {
+        const bool first = s < K;
+        const int k = first ? s : s - K;
+        const double xv = x[k];
+        const double r = miso_det_log(first ? xv : xv / ltheta);
+        if (first) { lp[k] = r; tb[k] = r + S.cst[k]; } else { lr[k] = r; }
+      }
     }
     wave_sync();
-    double maxv = S.tb[0];
-    for (int k = 1; k < K; k++) { const double v = S.tb[k]; if (v > maxv) maxv = v; }
-    for (int k0 = 0; k0 < Kw; k0 += G) { const int k = k0 + sub; if (k < K) S.tc[k] = miso_det_exp(S.tb[k] - maxv); }
-    wave_sync();
-    const double lse = miso_det_log(seq_sum(S.tc, K)) + maxv;
+  };
+  auto max_of = [&](const double *tb) {
+    double maxv = tb[0];
+    for (int k = 1; k < K; k++) { const double v = tb[k]; if (v > maxv) maxv = v; }
+    return maxv;
+  };
+  // ---- joint log score from cached logs and the current counts (miso.c:243-307; PE miso_paired.c:133-174) ----
+  auto joint_sums = [&](const double *lp, const double *tb, double lse, double readProbPE) {
     double readProb = 0.0, assProb = 0.0, psiProb = 0.0;
     for (int k = 0; k < K; k++) {
       const int ck = count_of(k);
       if (ck != 0) {
         if (!PE) readProb = readProb + static_cast<double>(ck) * S.isc[k];
-        assProb = assProb + static_cast<double>(ck) * (S.tb[k] - lse);
+        assProb = assProb + static_cast<double>(ck) * (tb[k] - lse);
       }
     }
     if (PE) readProb = readProbPE;
-    for (int k = 0; k < K; k++) psiProb = psiProb + S.hm1[k] * S.ta[k];
+    for (int k = 0; k < K; k++) psiProb = psiProb + S.hm1[k] * lp[k];
     psiProb = psiProb + c.lg_sum;
     psiProb = psiProb - c.lg_each;
-    wave_sync();  // scratch is reused by the next call
     return readProb + assProb + psiProb;
-  };
-
-  // ---- log density of theta under the logistic normal centred at mu (miso.c:97-122) ----
-  auto prop_score = [&](double *theta, double *mu) {
-    double ltheta = 1.0, prod = 1.0;
-    for (int i = 0; i < K - 1; i++) { const double t = theta[i]; ltheta = ltheta - t; prod = prod * t; }
-    prod = 1.0 / prod / ltheta;
-    for (int k0 = 0; k0 < Kw; k0 += G) {
-      const int k = k0 + sub;
-      if (k < K - 1) {
-        const double tmp = miso_det_log(theta[k] / ltheta) - mu[k];
-        S.ta[k] = (-0.5) * tmp * tmp / c.sigma;
-      }
-    }
-    wave_sync();
-    const double expPart = seq_sum(S.ta, K - 1);
-    wave_sync();
-    return miso_det_log(c.covar * prod * miso_det_exp(expPart));
   };
 
   // ---- initial state: miso.c:330-447 (START_AUTO / START_UNIFORM), then miso.c:834, 841 ----
@@ -502,6 +545,15 @@ __global__ __launch_bounds__(256, 2) void sampler_grp(const KernelArgs a) {
   wave_sync();
   uint32_t accept_word = 0;
   propose(S.alpha, S.alpha, S.psi, MISO_ITER_INIT, accept_word);
+  double jac = 0.0, lse = 0.0;    // of the current psi
+  {
+    log_pass(S.psi, S.lp, S.tb, S.lr, jac);
+    const double maxv = max_of(S.tb);
+    for (int k0 = 0; k0 < Kw; k0 += G) { const int k = k0 + sub; if (k < K) S.tc[k] = miso_det_exp(S.tb[k] - maxv); }
+    wave_sync();
+    lse = miso_det_log(seq_sum(S.tc, K)) + maxv;
+    wave_sync();
+  }
   gibbs(MISO_ITER_INIT, live && chain == 0 && a.M == 0);
 
   uint64_t hash = 0xCBF29CE484222325ull;
@@ -515,26 +567,63 @@ __global__ __launch_bounds__(256, 2) void sampler_grp(const KernelArgs a) {
         if (k < K) trace[(static_cast<size_t>(m) * a.C + chain) * K + k] = count_of(k);
       }
     GPROF_T(m0);
-    propose(S.alpha, S.alphaN, S.psiN, static_cast<uint32_t>(m), accept_word);
+    propose(S.alpha, S.alphaN, S.psiN, static_cast<uint32_t>(m), accept_word);     // passes 1, 2
+    double jacN;
+    log_pass(S.psiN, S.lpN, S.tbN, S.lrN, jacN);                                      // pass 3
+    const double maxN = max_of(S.tbN);
+    // Gaussian parts of the two proposal densities (miso.c:110-117): proposal -> current uses the
+    // current psi's log ratios against alpha', current -> proposal the proposal's against alpha
+    for (int k0 = 0; k0 < Kw; k0 += G) {
+      const int k = k0 + sub;
+      if (k < K - 1) {
+        const double t1 = S.lr[k] - S.alphaN[k];
+        S.tc[k] = (-0.5) * t1 * t1 / c.sigma;
+        const double t2 = S.lrN[k] - S.alpha[k];
+        S.u2[k] = (-0.5) * t2 * t2 / c.sigma;
+      }
+    }
+    wave_sync();
+    const double e1 = seq_sum(S.tc, K - 1), e2 = seq_sum(S.u2, K - 1);
+    wave_sync();
+    for (int s0 = 0; s0 < Kw + 2; s0 += G) {                                        // pass 4: exp
+      const int s = s0 + sub;
+      if (s < K + 2) {
+        const double arg = s < K ? S.tbN[s] - maxN : (s == K ? e1 : e2);
+        const double r = miso_det_exp(arg);
+        if (s < K) S.tc[s] = r; else S.sx[s - K] = r;
+      }
+    }
+    wave_sync();
+    {                                                                               // pass 5: log
+      const double sumtc = seq_sum(S.tc, K);
+      const double x1 = S.sx[0], x2 = S.sx[1];
+      wave_sync();
+      for (int s0 = 0; s0 < 3; s0 += G) {
+        const int s = s0 + sub;
+        if (s < 3) S.sx[s] = miso_det_log(s == 0 ? sumtc : (s == 1 ? c.covar * jac * x1 : c.covar * jacN * x2));
+      }
+      wave_sync();
+    }
+    const double lseN = S.sx[0] + maxN, ptoCS = S.sx[1], ctoPS = S.sx[2];
     const double rp = PE ? (rbad ? miso_u2d(0x7FF8000000000000ull)
                                  : static_cast<double>(rfix) * (1.0 / MISO_SFIX_SCALE))
                          : 0.0;
-    const double pp = joint(S.psiN, rp);
-    const double pc = joint(S.psi, rp);
-    const double ptoCS = prop_score(S.psi, S.alphaN);
-    const double ctoPS = prop_score(S.psiN, S.alpha);
-    const double acceptP = (m > 0) ? miso_det_exp(pp + ptoCS - (pc + ctoPS)) : miso_det_exp(pp - pc);
+    const double pp = joint_sums(S.lpN, S.tbN, lseN, rp);
+    const double pc = joint_sums(S.lp, S.tb, lse, rp);
+    const double acceptP = (m > 0) ? miso_det_exp(pp + ptoCS - (pc + ctoPS)) : miso_det_exp(pp - pc);  // pass 6
     const bool acc = (acceptP >= 1) || (miso_u01(accept_word) < acceptP);
     double cJS = pc;
-    if (acc) {
-      for (int k0 = 0; k0 < Kw; k0 += G) {
-        const int k = k0 + sub;
-        if (k < K) S.psi[k] = S.psiN[k];
-        if (k < K - 1) S.alpha[k] = S.alphaN[k];
-      }
+    wave_sync();
+    if (acc) {   // the proposal and its cache become the current state: swap the slice's pointers
+      double *t;
+      t = S.psi; S.psi = S.psiN; S.psiN = t;
+      t = S.alpha; S.alpha = S.alphaN; S.alphaN = t;
+      t = S.lp; S.lp = S.lpN; S.lpN = t;
+      t = S.tb; S.tb = S.tbN; S.tbN = t;
+      t = S.lr; S.lr = S.lrN; S.lrN = t;
+      jac = jacN; lse = lseN;
       cJS = pp; accepted++;
     }
-    wave_sync();
     GPROF_T(m1);
     GPROF_ADD(gp_mh, m0, m1);
     if (m >= a.B) {  // miso.c:882-893

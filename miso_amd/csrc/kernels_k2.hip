@@ -29,6 +29,7 @@
 #include "miso_amd.h"
 #include "miso_detmath.h"
 #include "miso_philox.h"
+#include "gibbs_rng.hpp"
 
 #pragma clang fp contract(off)
 
@@ -185,33 +186,6 @@ __device__ __forceinline__ void vec_eval4(F f, double a0, double a1, double a2, 
   o2 = role_bcast<NR, QUAD, 2>(y, base); o3 = role_bcast<NR, QUAD, 3>(y, base);
 }
 
-// Philox4x32-10 block (q, iter, site|chain, event) with round 0 split into chain / iteration
-// constants: identical output to miso_philox4x32_10.
-struct GibbsRng {
-  uint32_t p1lo, p1hi;  // M1 * (site | chain << 8)
-  uint32_t c3k1;        // event_id ^ k1
-  uint32_t k0, k1;
-};
-
-__device__ __forceinline__ miso_u32x4 philox_gibbs(const GibbsRng &g, uint32_t q, uint32_t n0_round0) {
-  const uint64_t p0 = static_cast<uint64_t>(MISO_PHILOX_M0) * q;
-  uint32_t c0 = n0_round0, c1 = g.p1lo, c2 = static_cast<uint32_t>(p0 >> 32) ^ g.c3k1,
-           c3 = static_cast<uint32_t>(p0);
-  uint32_t k0 = g.k0 + MISO_PHILOX_W0, k1 = g.k1 + MISO_PHILOX_W1;
-#pragma unroll
-  for (int r = 1; r < 10; r++) {
-    const uint64_t a = static_cast<uint64_t>(MISO_PHILOX_M0) * c0;
-    const uint64_t b = static_cast<uint64_t>(MISO_PHILOX_M1) * c2;
-    const uint32_t n0 = static_cast<uint32_t>(b >> 32) ^ c1 ^ k0;
-    const uint32_t n2 = static_cast<uint32_t>(a >> 32) ^ c3 ^ k1;
-    c1 = static_cast<uint32_t>(b); c3 = static_cast<uint32_t>(a); c0 = n0; c2 = n2;
-    k0 += MISO_PHILOX_W0; k1 += MISO_PHILOX_W1;
-  }
-  miso_u32x4 o;
-  o.v[0] = c0; o.v[1] = c1; o.v[2] = c2; o.v[3] = c3;
-  return o;
-}
-
 }  // namespace
 
 template <int G, bool PE>
@@ -270,12 +244,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                                              : reinterpret_cast<int32_t *>(a.out_pool + E.off_trace);
   const uint32_t k0 = static_cast<uint32_t>(a.seed), k1 = static_cast<uint32_t>(a.seed >> 32);
   const uint32_t c2_gibbs = MISO_SITE_GIBBS | (chain << 8), c2_mh = MISO_SITE_MH | (chain << 8);
-  GibbsRng rng;
-  {
-    const uint64_t p1 = static_cast<uint64_t>(MISO_PHILOX_M1) * c2_gibbs;
-    rng.p1lo = static_cast<uint32_t>(p1); rng.p1hi = static_cast<uint32_t>(p1 >> 32);
-    rng.c3k1 = event_id ^ k1; rng.k0 = k0; rng.k1 = k1;
-  }
+  const GibbsRng rng = gibbs_rng_init(a.seed, event_id, chain);
 
   int cnt0 = 0, cnt1 = 0;
   int64_t rfix = 0; int rbad = 0;   // PE: fixed-point sum of the assigned reads' fragment scores

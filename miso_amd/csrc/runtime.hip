@@ -104,10 +104,11 @@ void miso_batch::upload(int dev) {
     in_off = align_up(in_off + (e.paired ? e.draw_frag.size() * 2
                                          : align_up(e.draw_mask.size(), 4) * 4), 16);
     d.n_dcls = static_cast<int32_t>(e.dcls_mask.size());
-    d.n_units = static_cast<int32_t>(e.draw_units.size());
+    d.n_units = e.n_units;
     d.max_cls = e.max_cls_size;
-    d.off_cls = in_off; in_off = align_up(in_off + e.draw_units.size() * 4, 16);
-    d.off_clsmask = in_off; in_off = align_up(in_off + e.dcls_mask.size() * 8, 16);
+    d.n_pairs = static_cast<int32_t>(e.dcls_pairs.size());
+    d.off_cls = in_off; in_off = align_up(in_off + e.dcls_tab.size() * 4, 16);
+    d.off_clsmask = in_off; in_off = align_up(in_off + e.dcls_pairs.size() * 2, 16);
     d.off_sfix = in_off; in_off = align_up(in_off + e.sfix_table.size() * 4, 16);
     d.off_samples = out_off; out_off = align_up(out_off + static_cast<uint64_t>(Sn) * e.K * 8, 16);
     d.off_loglik = out_off; out_off = align_up(out_off + static_cast<uint64_t>(Sn) * 8, 16);
@@ -130,13 +131,10 @@ void miso_batch::upload(int dev) {
     std::memcpy(h_in.data() + d.off_base, e.base_count.data(), e.base_count.size() * 4);
     if (e.paired) std::memcpy(h_in.data() + d.off_draw, e.draw_frag.data(), e.draw_frag.size() * 2);
     else std::memcpy(h_in.data() + d.off_draw, e.draw_mask.data(), e.draw_mask.size() * 4);
-    if (!e.draw_units.empty()) {
-      std::memcpy(h_in.data() + d.off_cls, e.draw_units.data(), e.draw_units.size() * 4);
-      uint32_t *cm = reinterpret_cast<uint32_t *>(h_in.data() + d.off_clsmask);
-      for (size_t c = 0; c < e.dcls_mask.size(); c++) {
-        cm[2 * c] = e.dcls_mask[c];
-        cm[2 * c + 1] = static_cast<uint32_t>(e.dcls_start[c + 1] - e.dcls_start[c]);
-      }
+    if (!e.dcls_tab.empty()) {
+      std::memcpy(h_in.data() + d.off_cls, e.dcls_tab.data(), e.dcls_tab.size() * 4);
+      if (!e.dcls_pairs.empty())
+        std::memcpy(h_in.data() + d.off_clsmask, e.dcls_pairs.data(), e.dcls_pairs.size() * 2);
     }
     if (!e.sfix_table.empty())
       std::memcpy(h_in.data() + d.off_sfix, e.sfix_table.data(), e.sfix_table.size() * 4);
@@ -163,11 +161,12 @@ void miso_batch::upload(int dev) {
   // the general kernel's wavefronts loop to their largest K and longest draw list: group alike
   std::stable_sort(gen.begin(), gen.end(), [&](int x, int y) {
     return events[x].K != events[y].K ? events[x].K > events[y].K : events[x].n_draw > events[y].n_draw; });
-  gen_kmax = 2; gen_maxq = 1; gen_maxu = 0;
+  gen_kmax = 2; gen_maxq = 1; gen_maxu = 0; gen_nocls = false;
   for (int i : gen) {
     gen_kmax = std::max(gen_kmax, events[i].K);
     gen_maxq = std::max(gen_maxq, (events[i].n_draw + 3) / 4);
-    gen_maxu = std::max(gen_maxu, static_cast<int>(events[i].draw_units.size()));
+    gen_maxu = std::max(gen_maxu, static_cast<int>(events[i].dcls_mask.size()));
+    if (!events[i].paired && events[i].n_draw > 0 && events[i].dcls_mask.empty()) gen_nocls = true;
   }
   n_k2 = static_cast<int>(k2.size()); n_gen = static_cast<int>(gen.size());
   k2.insert(k2.end(), gen.begin(), gen.end());
@@ -226,34 +225,40 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     a.slot_event = d_slots + n_k2; a.n_slots = n_gen;
     const long chains = static_cast<long>(n_gen) * p.noChains;
     const size_t fp_bytes = p.paired ? align_up(fd.prob.size() * 8, 16) : 0;
-    // single-end: stage every drawing read's class id in LDS when that leaves room for >= 2 chains
-    // MISO_NO_CLASS_PATH=1 (tests): force the direct mask path of sampler_grp
+    // a workgroup may use half of the CU's 160 KB of LDS (two workgroups per CU)
+    constexpr size_t LDS_MAX = 80 * 1024;
+    // single-end: per-class thresholds and counters join the slice (class path) when every event
+    // has a class table; MISO_NO_CLASS_PATH=1 (tests): force the direct mask path of sampler_grp
     const bool no_cls = std::getenv("MISO_NO_CLASS_PATH") != nullptr;
-    const int qs = (!p.paired && !no_cls && gen_maxu > 0 && gen_maxu <= 2048 + MAX_DRAW_CLASSES) ? gen_maxu : 0;
+    int qs = (!p.paired && !no_cls && !gen_nocls && gen_maxu > 0) ? gen_maxu : 0;
+    if (qs && 4 * 2 * static_cast<size_t>(grp_slice_bytes(gen_kmax, qs, 0)) > LDS_MAX) qs = 0;
     // paired-end: the per-event score table (K x il int32) joins the slice when >= 4 chains still fit
     int ts = p.paired ? gen_kmax * static_cast<int>(fd.prob.size()) : 0;
-    if (ts && fp_bytes + 4 * 4 * static_cast<size_t>(grp_slice_bytes(gen_kmax, 0, ts)) > 64 * 1024) ts = 0;
+    if (ts && fp_bytes + 4 * 4 * static_cast<size_t>(grp_slice_bytes(gen_kmax, 0, ts)) > LDS_MAX) ts = 0;
     // lanes per chain: as for sampler_k2, bounded by the LDS a workgroup's chains need
     int G = 64;
     const char *env = std::getenv("MISO_GENERAL_LANES");
     if (env) {
       G = std::atoi(env);
     } else {
-      // largest lane group whose wavefronts fill the resident slots once (see
-      // choose_lanes_per_chain); smaller groups only when the batch overflows the device anyway
-      for (int g : {32, 16, 8, 4, 2}) {
+      // the per-iteration scalar step costs the same per wavefront whatever G is, so pack as many
+      // chains per wavefront as still fills the device: the smallest G whose wavefronts occupy
+      // every resident slot; a batch too small for that takes the largest G (most wavefronts)
+      bool found = false;
+      for (int g : {2, 4, 8, 16, 32}) {
         const int cpw = 64 / g;
         const size_t lds = fp_bytes + 4 * static_cast<size_t>(cpw) * grp_slice_bytes(gen_kmax, qs, ts);
-        if (g > std::max(2, gen_maxq) || lds > 64 * 1024) continue;
-        G = g;
-        if ((chains + cpw - 1) / cpw <= wave_slots) break;
+        if (lds > LDS_MAX) continue;
+        if (!found || g <= std::max(2, gen_maxq)) G = g;
+        found = true;
+        if ((chains + cpw - 1) / cpw >= wave_slots) break;
       }
     }
     // a forced (or odd) choice never exceeds the LDS budget: fewer chains per wavefront instead
     while (G < 64 && (G < 2 || (G & (G - 1)) ||
-                      fp_bytes + 4 * static_cast<size_t>(64 / G) * grp_slice_bytes(gen_kmax, qs, ts) > 64 * 1024))
+                      fp_bytes + 4 * static_cast<size_t>(64 / G) * grp_slice_bytes(gen_kmax, qs, ts) > LDS_MAX))
       G = (G < 2) ? 2 : ((G & (G - 1)) ? 64 : G * 2);
-    a.kstride = gen_kmax; a.qstride = qs; a.tstride = ts;
+    a.kstride = gen_kmax; a.cstride = qs; a.tstride = ts;
     last_kernels += std::string(last_kernels.empty() ? "" : ",") +
                     (G == 64 ? std::string("sampler_wave<") : "sampler_grp<" + std::to_string(G) + ", ") +
                     (p.paired ? "true>" : "false>");
@@ -268,8 +273,15 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       const size_t lds = fp_bytes + 4 * static_cast<size_t>(cpw) * grp_slice_bytes(gen_kmax, qs, ts);
 #define MISO_GRP_LAUNCH(GG)                                                                          \
   case GG:                                                                                           \
-    if (p.paired) hipLaunchKernelGGL((sampler_grp<GG, true>), dim3(grid), dim3(256), lds, stream, a); \
-    else hipLaunchKernelGGL((sampler_grp<GG, false>), dim3(grid), dim3(256), lds, stream, a);         \
+    if (p.paired) {                                                                                  \
+      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sampler_grp<GG, true>),             \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds))); \
+      hipLaunchKernelGGL((sampler_grp<GG, true>), dim3(grid), dim3(256), lds, stream, a);            \
+    } else {                                                                                         \
+      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sampler_grp<GG, false>),            \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds))); \
+      hipLaunchKernelGGL((sampler_grp<GG, false>), dim3(grid), dim3(256), lds, stream, a);           \
+    }                                                                                                \
     break;
       switch (G) {
         MISO_GRP_LAUNCH(2) MISO_GRP_LAUNCH(4) MISO_GRP_LAUNCH(8) MISO_GRP_LAUNCH(16) MISO_GRP_LAUNCH(32)
