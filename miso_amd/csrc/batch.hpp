@@ -33,8 +33,15 @@ struct miso_batch {
   double *d_fp = nullptr;
   int32_t *d_slots = nullptr;     // [k2 events sorted by n_draw desc | all other events]
   int n_k2 = 0, n_gen = 0;
-  int gen_kmax = 2, gen_maxq = 1, gen_maxu = 0;  // over the general-kernel events (gen_maxu: drawing-read classes)
-  bool gen_nocls = false;         // some general single-end event has no class table (> MAX_DRAW_CLASSES classes)
+  // the other events, grouped by isoform-count class (sampler_grp<G, PE, KC> holds K in (KC_prev, KC])
+  struct GenRun {
+    int first = 0, count = 0;     // slice of d_slots (after the n_k2 two-isoform events)
+    int kc = 4;                   // 4, 8, 12, 16 or 32
+    int kmax = 2, maxq = 1;       // most isoforms, most draw quads
+    int maxcls = 0;               // most drawing-read classes (single-end)
+    bool nocls = false;           // some single-end event has no class table (> MAX_DRAW_CLASSES classes)
+  };
+  std::vector<GenRun> gen_runs;
   int lanes_per_chain = 0;        // G of the last sampler_k2 launch (0 = none)
   std::string last_kernels;       // names of the kernels of the last launch, comma separated
   int wave_slots = 2048;          // resident sampler_k2 wavefronts on the device

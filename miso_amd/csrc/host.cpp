@@ -427,6 +427,8 @@ PackedEvent pack_event(const miso_params_t &p, const FragmentDist *fd, int K, in
     }
     e.n_draw++;
   }
+  if (p.paired)   // whole quads of reads on the device: pad with incompatible reads
+    while ((e.draw_frag.size() / K) % 4) e.draw_frag.insert(e.draw_frag.end(), K, FRAG_NONE);
   if (!p.paired) {
     // draw order: by column (isoform 0 most significant, 0 < 1), ties by read index
     auto key = [K](uint32_t m) { uint32_t r = 0; for (int k = 0; k < K; k++) r = (r << 1) | ((m >> k) & 1u); return r; };

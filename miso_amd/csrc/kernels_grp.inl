@@ -1,4 +1,7 @@
-// kernels_grp.hip -- lane-packed sampler for any isoform count and for paired-end reads.
+// kernels_grp.inl -- lane-packed sampler for any isoform count and for paired-end reads.
+// (template code; kernels_grp_c*.hip instantiate it per isoform-count class KC = 4, 8, 12, 16, 32:
+// a kernel only carries the unrolled loop variants of its class, so the wide variants' register
+// pressure does not leak into the narrow ones; runtime.hip launches each class's events separately)
 //
 // sampler_wave (kernels.hip) gives one wavefront to one chain; its per-iteration scalar step
 // (miso.c:449-552: O(K) transcendentals in one dependency chain) keeps 64 lanes busy for the
@@ -209,10 +212,78 @@ __device__ __forceinline__ void class_units(const uint32_t *ctab, const uint32_t
   }
 }
 
+// The paired-end read loop when every chain of the wavefront has exactly KK isoforms.  A lane takes
+// the quad of reads 4q .. 4q+3: their 4 KK fragment indices are one contiguous block of 2 KK dwords,
+// fetched with wide loads ONE TRIP AHEAD so the L2 latency overlaps the previous quad's arithmetic;
+// weights psi_k fp[f] from the LDS tables, pick by the reference's scan (miso_paired.c:11-22,
+// 64-75), score from the chain's LDS table.  Reads beyond n_draw are padded with FRAG_NONE (host).
+template <int KK, int G>
+__device__ __forceinline__ void pe_quads(const uint16_t *frags, const double *psi, const double *lds_fp,
+                                         const int32_t *stab, int il, int *cnt, uint8_t *drawass,
+                                         bool write_ass, int nqw, int n_quads, int n_draw, int sub,
+                                         const GibbsRng &rng, uint32_t n0r0, int64_t &acc_out, int &bad_out) {
+  constexpr int ND = 2 * KK;   // dwords per quad
+  double ps[KK];
+#pragma unroll
+  for (int k = 0; k < KK; k++) ps[k] = psi[k];
+  const uint32_t *fq = reinterpret_cast<const uint32_t *>(frags);
+  uint32_t nxt[ND];
+  {
+    const int q = sub;
+#pragma unroll
+    for (int i = 0; i < ND; i++) nxt[i] = (q < n_quads) ? fq[static_cast<size_t>(q) * ND + i] : 0xFFFFFFFFu;
+  }
+  int64_t acc = 0; int bad = 0;
+  for (int q0 = 0; q0 < nqw; q0 += G) {
+    const int q = q0 + sub;
+    uint32_t cur[ND];
+#pragma unroll
+    for (int i = 0; i < ND; i++) cur[i] = nxt[i];
+    {
+      const int qn = q + G;
+#pragma unroll
+      for (int i = 0; i < ND; i++) nxt[i] = (qn < n_quads) ? fq[static_cast<size_t>(qn) * ND + i] : 0xFFFFFFFFu;
+    }
+    const miso_u32x4 u = philox_gibbs(rng, static_cast<uint32_t>(q), n0r0);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      uint32_t fr[KK]; double w[KK]; bool val[KK];
+      double T = 0.0; int nv = 0;
+#pragma unroll
+      for (int k = 0; k < KK; k++) {
+        const int idx = j * KK + k;
+        fr[k] = (cur[idx >> 1] >> (16 * (idx & 1))) & 0xFFFFu;
+        val[k] = fr[k] != FRAG_NONE;
+        w[k] = ps[k] * lds_fp[val[k] ? fr[k] : 0];
+        if (val[k]) { T = T + w[k]; nv++; }
+      }
+      const double rnd = miso_u01(u.v[j]) * T;
+      double cum = 0.0; int idx = 0, sel = -1; uint32_t fsel = 0;
+#pragma unroll
+      for (int k = 0; k < KK; k++) {
+        if (val[k]) {
+          cum = cum + w[k];
+          const bool stop = (nv == 2) ? (idx == 0 ? (rnd < cum) : true) : !(rnd > cum);
+          idx++;
+          if (sel < 0 && (stop || idx == nv)) { sel = k; fsel = fr[k]; }
+        }
+      }
+      if (sel >= 0) {
+        atomicAdd(&cnt[sel], 1);
+        const int32_t v = stab[sel * il + static_cast<int>(fsel)];
+        if (v == SFIX_BAD) bad = 1; else acc += v;
+        if (write_ass) drawass[4 * q + j] = static_cast<uint8_t>(sel);
+      }
+    }
+  }
+  acc_out = acc; bad_out = bad;
+}
+
 }  // namespace
 
-template <int G, bool PE>
+template <int G, bool PE, int KC>
 __global__ __launch_bounds__(256, 2) void sampler_grp(const KernelArgs a) {
+  constexpr int KLO = KC == 4 ? 3 : (KC == 8 ? 5 : (KC == 12 ? 9 : (KC == 16 ? 13 : 17)));   // the class holds K in [KLO, KC]
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int CPW = 64 / G;
   const int fp_bytes = PE ? ((a.il * 8 + 15) & ~15) : 0;
@@ -301,6 +372,8 @@ __global__ __launch_bounds__(256, 2) void sampler_grp(const KernelArgs a) {
   const int n_draw = E.n_draw, n_quads = (n_draw + 3) >> 2;
   int64_t rfix = 0; int rbad = 0;
   const GibbsRng rng = gibbs_rng_init(a.seed, event_id, chain);
+  // paired-end fast path: one isoform count for the whole wavefront
+  const bool pe_fast = PE && KC <= 16 && Kw >= KLO && __all(K == Kw);
 
 #ifdef MISO_K2_PROFILE
   uint64_t gp_thr = 0, gp_loop = 0, gp_mh = 0;
@@ -363,17 +436,11 @@ __global__ __launch_bounds__(256, 2) void sampler_grp(const KernelArgs a) {
     class_units<TW, G>(S.ctab, S.thr, tw, n_dcls, nuw, n_units, sub, rng, n0r0, D);                  \
     _Pragma("unroll") for (int j = 0; j < TW; j++) if (j < tw && D[j]) atomicAdd(&S.dl[j], D[j]);   \
   }
-        if (tww <= 2) MISO_UNITS(2)
-        else if (tww == 3) MISO_UNITS(3)
-        else if (tww == 4) MISO_UNITS(4)
-        else if (tww == 5) MISO_UNITS(5)
-        else if (tww == 6) MISO_UNITS(6)
-        else if (tww == 7) MISO_UNITS(7)
-        else if (tww <= 9) MISO_UNITS(9)
-        else if (tww <= 12) MISO_UNITS(12)
-        else if (tww <= 16) MISO_UNITS(16)
-        else if (tww <= 23) MISO_UNITS(23)
-        else MISO_UNITS(31)
+        if constexpr (KC == 4) { if (tww <= 2) MISO_UNITS(2) else MISO_UNITS(3) }
+        else if constexpr (KC == 8) { if (tww <= 4) MISO_UNITS(4) else if (tww == 5) MISO_UNITS(5) else if (tww == 6) MISO_UNITS(6) else MISO_UNITS(7) }
+        else if constexpr (KC == 12) { if (tww <= 9) MISO_UNITS(9) else MISO_UNITS(11) }
+        else if constexpr (KC == 16) { MISO_UNITS(15) }
+        else { if (tww <= 23) MISO_UNITS(23) else MISO_UNITS(31) }
 #undef MISO_UNITS
         wave_sync();
         // D_k (+ the reads of classes that end at or before k) -> picks per isoform
@@ -393,7 +460,22 @@ __global__ __launch_bounds__(256, 2) void sampler_grp(const KernelArgs a) {
       }
     }
     int64_t acc = 0; int bad = 0;
-    const bool small = Kw <= 8;
+    if (PE && pe_fast) {
+      const uint32_t n0r0 = rng.p1hi ^ iter ^ rng.k0;
+#define MISO_PEQ(KK) pe_quads<KK, G>(frags, S.psi, lds_fp, sfix, a.il, S.cnt, drawass, write_ass, nqw, n_quads, n_draw, sub, rng, n0r0, acc, bad);
+      if constexpr (KC == 4) { if (Kw == 3) MISO_PEQ(3) else MISO_PEQ(4) }
+      else if constexpr (KC == 8) { if (Kw == 5) MISO_PEQ(5) else if (Kw == 6) MISO_PEQ(6) else if (Kw == 7) MISO_PEQ(7) else MISO_PEQ(8) }
+      else if constexpr (KC == 12) { if (Kw == 9) MISO_PEQ(9) else if (Kw == 10) MISO_PEQ(10) else if (Kw == 11) MISO_PEQ(11) else MISO_PEQ(12) }
+      else if constexpr (KC == 16) { if (Kw == 13) MISO_PEQ(13) else if (Kw == 14) MISO_PEQ(14) else if (Kw == 15) MISO_PEQ(15) else MISO_PEQ(16) }
+#undef MISO_PEQ
+      wave_sync();
+#pragma unroll
+      for (int off = G >> 1; off >= 1; off >>= 1) { acc += __shfl_xor(acc, off); bad |= __shfl_xor(bad, off); }
+      rfix = E.base_sfix + acc;
+      rbad = bad | E.base_bad;
+      return;
+    }
+    const bool small = KC <= 8;
     double ps[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) ps[k] = (small && k < K) ? S.psi[k] : 0.0;
@@ -412,16 +494,16 @@ __global__ __launch_bounds__(256, 2) void sampler_grp(const KernelArgs a) {
         const int r = 4 * q + j;
         const bool on = active && r < n_draw;
         int sel = -1; uint16_t fsel = 0;
-        if (small) {   // K <= 8: exact unroll for the wavefront's isoform count
+        if constexpr (KC <= 8) {   // K <= 8: exact unroll for the wavefront's isoform count
           const uint16_t *row = frags + static_cast<size_t>(r) * K;
-          switch (Kw) {
-          case 2: sel = pick_direct<2, PE>(ps, m4[j], row, K, lds_fp, on, u.v[j], fsel); break;
-          case 3: sel = pick_direct<3, PE>(ps, m4[j], row, K, lds_fp, on, u.v[j], fsel); break;
-          case 4: sel = pick_direct<4, PE>(ps, m4[j], row, K, lds_fp, on, u.v[j], fsel); break;
-          case 5: sel = pick_direct<5, PE>(ps, m4[j], row, K, lds_fp, on, u.v[j], fsel); break;
-          case 6: sel = pick_direct<6, PE>(ps, m4[j], row, K, lds_fp, on, u.v[j], fsel); break;
-          case 7: sel = pick_direct<7, PE>(ps, m4[j], row, K, lds_fp, on, u.v[j], fsel); break;
-          default: sel = pick_direct<8, PE>(ps, m4[j], row, K, lds_fp, on, u.v[j], fsel); break;
+          if constexpr (KC == 4) {
+            if (Kw <= 3) sel = pick_direct<3, PE>(ps, m4[j], row, K, lds_fp, on, u.v[j], fsel);
+            else sel = pick_direct<4, PE>(ps, m4[j], row, K, lds_fp, on, u.v[j], fsel);
+          } else {
+            if (Kw <= 5) sel = pick_direct<5, PE>(ps, m4[j], row, K, lds_fp, on, u.v[j], fsel);
+            else if (Kw == 6) sel = pick_direct<6, PE>(ps, m4[j], row, K, lds_fp, on, u.v[j], fsel);
+            else if (Kw == 7) sel = pick_direct<7, PE>(ps, m4[j], row, K, lds_fp, on, u.v[j], fsel);
+            else sel = pick_direct<8, PE>(ps, m4[j], row, K, lds_fp, on, u.v[j], fsel);
           }
         } else {
           double T = 0.0; int nv = 0;   // pass 1: total weight, ascending k (miso.c:11-22)
@@ -659,14 +741,5 @@ __global__ __launch_bounds__(256, 2) void sampler_grp(const KernelArgs a) {
     }
   }
 }
-
-#define MISO_INSTANTIATE_GRP(G) \
-  template __global__ void sampler_grp<G, false>(const KernelArgs); \
-  template __global__ void sampler_grp<G, true>(const KernelArgs);
-MISO_INSTANTIATE_GRP(2)
-MISO_INSTANTIATE_GRP(4)
-MISO_INSTANTIATE_GRP(8)
-MISO_INSTANTIATE_GRP(16)
-MISO_INSTANTIATE_GRP(32)
 
 }  // namespace miso

@@ -1,0 +1,13 @@
+// sampler_grp for events with 13-16 isoforms (see kernels_grp.inl)
+#include "kernels_grp.inl"
+
+namespace miso {
+#define MISO_INSTANTIATE_GRP(G) \
+  template __global__ void sampler_grp<G, false, 16>(const KernelArgs); \
+  template __global__ void sampler_grp<G, true, 16>(const KernelArgs);
+MISO_INSTANTIATE_GRP(2)
+MISO_INSTANTIATE_GRP(4)
+MISO_INSTANTIATE_GRP(8)
+MISO_INSTANTIATE_GRP(16)
+MISO_INSTANTIATE_GRP(32)
+}  // namespace miso

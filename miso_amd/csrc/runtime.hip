@@ -20,7 +20,7 @@ template <int G, bool PE> __global__ void sampler_k2(const KernelArgs a);
 __global__ void compare_kernel(const DevEvent *, const unsigned char *, const DevEvent *, const unsigned char *, int, int,
                                double, const uint64_t *, double *);
 __global__ void summarize_kernel(const DevEvent *, const unsigned char *, int, int, int, int, const uint64_t *, double *);
-template <int G, bool PE> __global__ void sampler_grp(const KernelArgs a);
+template <int G, bool PE, int KC> __global__ void sampler_grp(const KernelArgs a);
 __global__ void selftest_detmath_kernel(const double *, int, double *, double *, double *, double *);
 __global__ void selftest_philox_kernel(const uint32_t *, int, uint32_t *);
 
@@ -161,12 +161,20 @@ void miso_batch::upload(int dev) {
   // the general kernel's wavefronts loop to their largest K and longest draw list: group alike
   std::stable_sort(gen.begin(), gen.end(), [&](int x, int y) {
     return events[x].K != events[y].K ? events[x].K > events[y].K : events[x].n_draw > events[y].n_draw; });
-  gen_kmax = 2; gen_maxq = 1; gen_maxu = 0; gen_nocls = false;
-  for (int i : gen) {
-    gen_kmax = std::max(gen_kmax, events[i].K);
-    gen_maxq = std::max(gen_maxq, (events[i].n_draw + 3) / 4);
-    gen_maxu = std::max(gen_maxu, static_cast<int>(events[i].dcls_mask.size()));
-    if (!events[i].paired && events[i].n_draw > 0 && events[i].dcls_mask.empty()) gen_nocls = true;
+  gen_runs.clear();
+  for (size_t j = 0; j < gen.size(); j++) {
+    const PackedEvent &e = events[gen[j]];
+    const int kc = e.K <= 4 ? 4 : (e.K <= 8 ? 8 : (e.K <= 12 ? 12 : (e.K <= 16 ? 16 : 32)));
+    if (gen_runs.empty() || gen_runs.back().kc != kc) {
+      GenRun r; r.first = static_cast<int>(j); r.kc = kc;
+      gen_runs.push_back(r);
+    }
+    GenRun &r = gen_runs.back();
+    r.count++;
+    r.kmax = std::max(r.kmax, e.K);
+    r.maxq = std::max(r.maxq, (e.n_draw + 3) / 4);
+    r.maxcls = std::max(r.maxcls, static_cast<int>(e.dcls_mask.size()));
+    if (!e.paired && e.n_draw > 0 && e.dcls_mask.empty()) r.nocls = true;
   }
   n_k2 = static_cast<int>(k2.size()); n_gen = static_cast<int>(gen.size());
   k2.insert(k2.end(), gen.begin(), gen.end());
@@ -221,37 +229,40 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
 #undef MISO_K2_LAUNCH
     HIP_OK(hipGetLastError());
   }
-  if (n_gen > 0) {
-    a.slot_event = d_slots + n_k2; a.n_slots = n_gen;
-    const long chains = static_cast<long>(n_gen) * p.noChains;
+  for (const GenRun &run : gen_runs) {
+    a.slot_event = d_slots + n_k2 + run.first; a.n_slots = run.count;
+    const int gen_kmax = run.kmax, gen_maxq = run.maxq;
+    const long chains = static_cast<long>(run.count) * p.noChains;
     const size_t fp_bytes = p.paired ? align_up(fd.prob.size() * 8, 16) : 0;
     // a workgroup may use half of the CU's 160 KB of LDS (two workgroups per CU)
     constexpr size_t LDS_MAX = 80 * 1024;
-    // single-end: per-class thresholds and counters join the slice (class path) when every event
-    // has a class table; MISO_NO_CLASS_PATH=1 (tests): force the direct mask path of sampler_grp
+    // single-end: per-class thresholds join the slice (class path) when every event has a class
+    // table; MISO_NO_CLASS_PATH=1 (tests): force the direct mask path of sampler_grp
     const bool no_cls = std::getenv("MISO_NO_CLASS_PATH") != nullptr;
-    int qs = (!p.paired && !no_cls && !gen_nocls && gen_maxu > 0) ? gen_maxu : 0;
+    int qs = (!p.paired && !no_cls && !run.nocls && run.maxcls > 0) ? run.maxcls : 0;
     if (qs && 4 * 2 * static_cast<size_t>(grp_slice_bytes(gen_kmax, qs, 0)) > LDS_MAX) qs = 0;
     // paired-end: the per-event score table (K x il int32) joins the slice when >= 4 chains still fit
     int ts = p.paired ? gen_kmax * static_cast<int>(fd.prob.size()) : 0;
     if (ts && fp_bytes + 4 * 4 * static_cast<size_t>(grp_slice_bytes(gen_kmax, 0, ts)) > LDS_MAX) ts = 0;
-    // lanes per chain: as for sampler_k2, bounded by the LDS a workgroup's chains need
+    // lanes per chain: bounded by the LDS a workgroup's chains need
     int G = 64;
     const char *env = std::getenv("MISO_GENERAL_LANES");
     if (env) {
       G = std::atoi(env);
     } else {
-      // the per-iteration scalar step costs the same per wavefront whatever G is, so pack as many
-      // chains per wavefront as still fills the device: the smallest G whose wavefronts occupy
-      // every resident slot; a batch too small for that takes the largest G (most wavefronts)
+      // single-end: the per-iteration scalar step costs the same per wavefront whatever G is, so
+      // pack as many chains per wavefront as still fills the device: the smallest G whose
+      // wavefronts occupy every resident slot; a batch too small for that takes the largest G.
+      // paired-end: the read loop waits on memory and more wavefronts hide it: largest G up to 16.
       bool found = false;
       for (int g : {2, 4, 8, 16, 32}) {
+        if (p.paired && g > 16 && found) break;
         const int cpw = 64 / g;
         const size_t lds = fp_bytes + 4 * static_cast<size_t>(cpw) * grp_slice_bytes(gen_kmax, qs, ts);
         if (lds > LDS_MAX) continue;
         if (!found || g <= std::max(2, gen_maxq)) G = g;
         found = true;
-        if ((chains + cpw - 1) / cpw >= wave_slots) break;
+        if (!p.paired && (chains + cpw - 1) / cpw >= wave_slots) break;
       }
     }
     // a forced (or odd) choice never exceeds the LDS budget: fewer chains per wavefront instead
@@ -260,8 +271,10 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       G = (G < 2) ? 2 : ((G & (G - 1)) ? 64 : G * 2);
     a.kstride = gen_kmax; a.cstride = qs; a.tstride = ts;
     last_kernels += std::string(last_kernels.empty() ? "" : ",") +
-                    (G == 64 ? std::string("sampler_wave<") : "sampler_grp<" + std::to_string(G) + ", ") +
-                    (p.paired ? "true>" : "false>");
+                    (G == 64 ? std::string("sampler_wave<")
+                             : "sampler_grp<" + std::to_string(G) + ", ") +
+                    (p.paired ? "true" : "false") +
+                    (G == 64 ? std::string(">") : ", " + std::to_string(run.kc) + ">");
     if (G == 64) {
       const unsigned grid = static_cast<unsigned>((chains + 3) / 4);
       const size_t lds = fp_bytes + 4 * 32 * sizeof(int);
@@ -271,23 +284,34 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       const int cpw = 64 / G;
       const unsigned grid = static_cast<unsigned>(((chains + cpw - 1) / cpw + 3) / 4);
       const size_t lds = fp_bytes + 4 * static_cast<size_t>(cpw) * grp_slice_bytes(gen_kmax, qs, ts);
-#define MISO_GRP_LAUNCH(GG)                                                                          \
-  case GG:                                                                                           \
-    if (p.paired) {                                                                                  \
-      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sampler_grp<GG, true>),             \
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds))); \
-      hipLaunchKernelGGL((sampler_grp<GG, true>), dim3(grid), dim3(256), lds, stream, a);            \
-    } else {                                                                                         \
-      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sampler_grp<GG, false>),            \
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds))); \
-      hipLaunchKernelGGL((sampler_grp<GG, false>), dim3(grid), dim3(256), lds, stream, a);           \
-    }                                                                                                \
+#define MISO_GRP_LAUNCH_K(GG, KC)                                                                          \
+  {                                                                                                        \
+    if (p.paired) {                                                                                        \
+      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sampler_grp<GG, true, KC>),               \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));      \
+      hipLaunchKernelGGL((sampler_grp<GG, true, KC>), dim3(grid), dim3(256), lds, stream, a);              \
+    } else {                                                                                               \
+      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sampler_grp<GG, false, KC>),              \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));      \
+      hipLaunchKernelGGL((sampler_grp<GG, false, KC>), dim3(grid), dim3(256), lds, stream, a);             \
+    }                                                                                                      \
+  }
+#define MISO_GRP_LAUNCH(GG)                                    \
+  case GG:                                                     \
+    switch (run.kc) {                                          \
+    case 4: MISO_GRP_LAUNCH_K(GG, 4) break;                    \
+    case 8: MISO_GRP_LAUNCH_K(GG, 8) break;                    \
+    case 12: MISO_GRP_LAUNCH_K(GG, 12) break;                  \
+    case 16: MISO_GRP_LAUNCH_K(GG, 16) break;                  \
+    default: MISO_GRP_LAUNCH_K(GG, 32) break;                  \
+    }                                                          \
     break;
       switch (G) {
         MISO_GRP_LAUNCH(2) MISO_GRP_LAUNCH(4) MISO_GRP_LAUNCH(8) MISO_GRP_LAUNCH(16) MISO_GRP_LAUNCH(32)
       default: MISO_FAIL(MISO_EINVAL, "MISO_GENERAL_LANES must be 2, 4, 8, 16, 32 or 64");
       }
 #undef MISO_GRP_LAUNCH
+#undef MISO_GRP_LAUNCH_K
     }
     HIP_OK(hipGetLastError());
   }

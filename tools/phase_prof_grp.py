@@ -8,7 +8,7 @@ E, iters = int(os.environ.get("EVENTS", 8192)), 1500
 Ks = [int(k) for k in os.environ.get("KS", "3").split(",")]
 Gs = [int(g) for g in os.environ.get("GS", "16").split(",")]
 for K in Ks:
-    b = workload.build_batch(0, E, K=K, iters=iters, burn=500)
+    b = workload.build_batch(0, E, K=K, iters=iters, burn=500, paired=bool(int(os.environ.get("PAIRED", "0"))))
     b.upload(0)
     for G in Gs:
         os.environ["MISO_GENERAL_LANES"] = str(G)
