@@ -130,6 +130,12 @@ typedef struct miso_params {
   int algorithm, start, stop;
   double normalMean, normalVar, numDevs; /* paired only */
   int want_counts_trace;     /* tests: keep the per-iteration assignment counts of every chain */
+  int device_match;          /* 1: miso_batch_add_event only parses the CIGAR strings; the
+                                compatibility of every read with every isoform (solve.c:8-108,
+                                141-218) is computed by one GPU kernel for the whole batch at
+                                miso_batch_upload.  Read classes (miso_batch_event_info's
+                                n_classes, class templates) are then available after the upload.
+                                0: on the host, at miso_batch_add_event */
 } miso_params_t;
 
 int miso_batch_create(const miso_params_t *params, miso_batch_t **batch);
@@ -205,6 +211,12 @@ int miso_batch_get_summary(const miso_batch_t *batch, int event_index, double *m
 int miso_batch_compare(miso_batch_t *sample1, miso_batch_t *sample2, double smoothing);
 int miso_batch_get_comparison(const miso_batch_t *sample1, int event_index, double *mean1, double *mean2,
                               double *bayes_factor, double *density_at_0);   /* noiso doubles each */
+
+/* device_match batches: kernel time of the matching launch done by miso_batch_upload, and (tests:
+   want_counts_trace batches only) the kernel's output for event i in the layout of
+   miso_match_iso[_paired]: match noiso x n_reads, fragmentLength likewise or NULL. */
+int miso_batch_last_match_ms(const miso_batch_t *batch, float *ms);
+int miso_batch_get_match(const miso_batch_t *batch, int event_index, double *match, int *fragmentLength);
 
 /* names of the kernels the last launch used (for profiles): e.g. "sampler_k2<3, false>" */
 int miso_batch_last_kernels(const miso_batch_t *batch, char *buf, int buflen);

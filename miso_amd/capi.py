@@ -36,7 +36,7 @@ class Params(C.Structure):
                 ("noBurnIn", C.c_int), ("noLag", C.c_int), ("algorithm", C.c_int),
                 ("start", C.c_int), ("stop", C.c_int), ("normalMean", C.c_double),
                 ("normalVar", C.c_double), ("numDevs", C.c_double),
-                ("want_counts_trace", C.c_int)]
+                ("want_counts_trace", C.c_int), ("device_match", C.c_int)]
 
 
 _lib = None
@@ -173,9 +173,10 @@ class Batch:
 
     def __init__(self, read_len, iters=5000, burn=500, lag=10, chains=6, overhang=1, paired=False,
                  mean=0.0, var=0.0, num_devs=4.0, start=MISO_START_AUTO, stop=MISO_STOP_FIXEDNO,
-                 algo=MISO_ALGO_REASSIGN, max_iters=100000, counts_trace=False):
+                 algo=MISO_ALGO_REASSIGN, max_iters=100000, counts_trace=False, device_match=False):
         self.params = Params(int(paired), read_len, overhang, chains, iters, max_iters, burn, lag,
-                             algo, start, stop, mean, var, num_devs, int(counts_trace))
+                             algo, start, stop, mean, var, num_devs, int(counts_trace),
+                             int(device_match))
         self.handle = C.c_void_p()
         check(lib().miso_batch_create(C.byref(self.params), C.byref(self.handle)))
 
@@ -260,6 +261,21 @@ class Batch:
         m1, m2, bf, dens = (np.zeros(K.value) for _ in range(4))
         check(lib().miso_batch_get_comparison(self.handle, i, _p(m1), _p(m2), _p(bf), _p(dens)))
         return m1, m2, bf, dens
+
+    def match_ms(self):
+        ms = C.c_float(0)
+        check(lib().miso_batch_last_match_ms(self.handle, C.byref(ms)))
+        return ms.value
+
+    def device_match_of(self, i):
+        """(match [N, K], fraglen [N, K] or None) as the GPU computed them (device_match +
+        counts_trace batches, after upload)."""
+        K, N = C.c_int(), C.c_int()
+        check(lib().miso_batch_event_info(self.handle, i, C.byref(K), C.byref(N), None, None))
+        m = np.zeros((N.value, K.value))
+        fl = np.zeros((N.value, K.value), np.int32) if self.params.paired else None
+        check(lib().miso_batch_get_match(self.handle, i, _p(m), _p(fl)))
+        return m, fl
 
     def last_kernels(self):
         buf = C.create_string_buffer(256)

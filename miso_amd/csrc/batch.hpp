@@ -42,6 +42,20 @@ struct miso_batch {
     bool nocls = false;           // some single-end event has no class table (> MAX_DRAW_CLASSES classes)
   };
   std::vector<GenRun> gen_runs;
+  // device_match: events whose compatibility is still to be computed (kernels_match.hip)
+  struct Pending {
+    int event = 0;               // index into `events` (a placeholder until resolved)
+    miso::Gene gene;
+    std::vector<int> pos;
+    miso::CigarTable ct;
+    std::vector<double> hyper;   // empty = all ones
+  };
+  std::vector<Pending> pending;
+  float match_ms = 0.f;          // kernel time of the last resolve
+  // tests (want_counts_trace): the kernel's raw outputs, per resolved event
+  std::vector<std::vector<uint32_t>> kept_masks;   // single-end: N masks
+  std::vector<std::vector<uint16_t>> kept_frags;   // paired-end: N x K fragment indices
+  void resolve_pending();        // runs match_kernel for all pending events, packs them
   int lanes_per_chain = 0;        // G of the last sampler_k2 launch (0 = none)
   std::string last_kernels;       // names of the kernels of the last launch, comma separated
   int wave_slots = 2048;          // resident sampler_k2 wavefronts on the device

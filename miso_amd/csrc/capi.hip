@@ -116,6 +116,24 @@ int miso_batch_add_event(miso_batch_t *b, const miso_gene_t *gene, const int *po
     if (hyperp && n_hyperp != g.K) MISO_FAIL(MISO_EINVAL, "Invalid hyperparameter vector length");
     if (b->uploaded) MISO_FAIL(MISO_EINVAL, "batch already uploaded");
     const int N = b->p.paired ? n_positions / 2 : n_positions;
+    if (b->p.device_match) {   // row f1: parse now (errors surface here), match on the GPU at upload
+      if (g.K < 2) MISO_FAIL(MISO_EINVAL, "At least two isoforms are needed");
+      if (g.K > MISO_MAX_ISOFORMS) MISO_FAIL(MISO_UNIMPLEMENTED, "More than 32 isoforms");
+      if (b->p.overHang < 0) MISO_FAIL(MISO_EINVAL, "Overhang length invalid. Must be positive");
+      if (b->p.readLength < 0) MISO_FAIL(MISO_EINVAL, "Read length cannot be negative");
+      miso_batch::Pending pe;
+      pe.event = static_cast<int>(b->events.size());
+      pe.gene = g;
+      pe.pos.assign(position, position + (b->p.paired ? 2 * N : N));
+      pe.ct = parse_cigars(cigarstr, b->p.paired ? 2 * N : N, b->p.readLength);
+      if (hyperp) pe.hyper.assign(hyperp, hyperp + g.K);
+      b->pending.push_back(std::move(pe));
+      PackedEvent ph;
+      ph.K = g.K; ph.N = N; ph.paired = b->p.paired != 0;
+      b->events.push_back(std::move(ph));
+      if (event_index) *event_index = static_cast<int>(b->events.size()) - 1;
+      return;
+    }
     std::vector<double> match(static_cast<size_t>(g.K) * (N > 0 ? N : 1));
     std::vector<int> fraglen;
     if (b->p.paired) {
@@ -303,6 +321,32 @@ int miso_batch_get_comparison(const miso_batch_t *b, int i, double *mean1, doubl
       if (mean2) mean2[k] = s[4 * k + 1];
       if (bayes_factor) bayes_factor[k] = s[4 * k + 2];
       if (density0) density0[k] = s[4 * k + 3];
+    }
+  });
+}
+
+int miso_batch_last_match_ms(const miso_batch_t *b, float *ms) {
+  return guarded([&] { need(b, "batch"); need(ms, "ms"); *ms = b->match_ms; });
+}
+
+int miso_batch_get_match(const miso_batch_t *b, int i, double *match, int *fragmentLength) {
+  return guarded([&] {
+    need(b, "batch"); need(match, "match");
+    const PackedEvent &e = event_at(b, i);
+    if (!b->p.device_match || !b->p.want_counts_trace || !b->uploaded)
+      MISO_FAIL(MISO_EINVAL, "device match outputs are kept only for uploaded device_match batches with want_counts_trace");
+    const size_t n = static_cast<size_t>(e.N) * e.K;
+    if (e.paired) {
+      const std::vector<uint16_t> &f = b->kept_frags.at(i);
+      for (size_t j = 0; j < n; j++) {
+        const bool ok = f[j] != FRAG_NONE;
+        match[j] = ok ? b->fd.prob[f[j]] : 0.0;
+        if (fragmentLength) fragmentLength[j] = ok ? b->fd.start + f[j] : -1;
+      }
+    } else {
+      const std::vector<uint32_t> &m = b->kept_masks.at(i);
+      for (int r = 0; r < e.N; r++)
+        for (int k = 0; k < e.K; k++) match[static_cast<size_t>(r) * e.K + k] = (m[r] >> k) & 1u ? 1.0 : 0.0;
     }
   });
 }

@@ -40,6 +40,16 @@ struct DevEvent {
   uint64_t off_trace;   // int32[(M+1) x C x K] or ~0 when not requested
 };
 
+// one event of match_kernel (kernels_match.hip)
+struct MatchEvent {
+  int32_t K;
+  int32_t n_reads;     // reads (single-end) or pairs (paired-end)
+  int32_t exidx_off;   // K + 1 exon offsets of the event, relative to ex_off
+  int32_t ex_off;      // the event's exon coordinates
+  int32_t read_off;    // first read (mate) of the event in the batch-wide read arrays
+  int32_t out_off;     // first output slot: masks[out_off + r] / frags[(out_off + r) * K + k]
+};
+
 struct ChainStats {
   uint64_t counts_hash;
   int32_t accepted;

@@ -341,6 +341,35 @@ PackedEvent pack_event(const miso_params_t &p, const FragmentDist *fd, int K, in
   if (K < 2) MISO_FAIL(MISO_EINVAL, "At least two isoforms are needed");
   if (K > MISO_MAX_ISOFORMS) MISO_FAIL(MISO_UNIMPLEMENTED, "More than 32 isoforms");
   if (p.paired && (!fd || !fraglen)) MISO_FAIL(MISO_EINTERNAL, "Paired event without fragments");
+  // the packed form only needs which isoforms a read is compatible with (and, paired-end, the
+  // fragment length in each); a caller-made single-end matrix with values other than 0/1 keeps
+  // its values for the header's read classes
+  std::vector<uint32_t> masks(N > 0 ? N : 1, 0u);
+  std::vector<uint16_t> frags;
+  bool binary = true;
+  if (p.paired) frags.assign(static_cast<size_t>(N) * K, FRAG_NONE);
+  for (int i = 0; i < N; i++) {
+    uint32_t m = 0;
+    for (int k = 0; k < K; k++) {
+      const size_t j = static_cast<size_t>(i) * K + k;
+      if (match[j] != 0) {
+        m |= 1u << k;
+        if (p.paired) frags[j] = static_cast<uint16_t>(fraglen[j] - fd->start);
+      }
+      if (!p.paired && match[j] != 0.0 && match[j] != 1.0) binary = false;
+    }
+    masks[i] = m;
+  }
+  return pack_event_masks(p, fd, K, N, masks.data(), p.paired ? frags.data() : nullptr,
+                          (p.paired || binary) ? nullptr : match, isolen, noexons, hyper);
+}
+
+PackedEvent pack_event_masks(const miso_params_t &p, const FragmentDist *fd, int K, int N,
+                             const uint32_t *masks, const uint16_t *frags, const double *se_values,
+                             const int *isolen, const int *noexons, const double *hyper) {
+  if (K < 2) MISO_FAIL(MISO_EINVAL, "At least two isoforms are needed");
+  if (K > MISO_MAX_ISOFORMS) MISO_FAIL(MISO_UNIMPLEMENTED, "More than 32 isoforms");
+  if (p.paired && (!fd || (N > 0 && !frags))) MISO_FAIL(MISO_EINTERNAL, "Paired event without fragments");
   const int ov = p.overHang == 0 ? 1 : p.overHang;
   PackedEvent e;
   e.K = K; e.N = N; e.paired = p.paired != 0;
@@ -393,50 +422,81 @@ PackedEvent pack_event(const miso_params_t &p, const FragmentDist *fd, int K, in
   e.consts[3 * K + 4] = std::pow(2 * M_PI * sigma, -0.5 * (K - 1));
 
   // --- reads: classes for the header, fixed vs drawing reads for the device ---
-  std::map<std::vector<double>, double> cls;  // lexicographic order == matrix.pmt:546-562
-  std::vector<double> key(K);
+  // Read classes for the header (miso.c:762 / miso_paired.c:386-391), in the lexicographic column
+  // order of matrix.pmt:546-562.  Columns of 0/1 (always, for matches built from alignments; the
+  // paired-end classes are binarised by definition) are keyed by their bit pattern, isoform 0 most
+  // significant; anything else (a caller-made single-end matrix) takes the general map.
+  std::map<std::vector<double>, double> cls;
+  std::vector<std::pair<uint32_t, double>> bcls;   // (bit-reversed mask, count), small
+  const bool binary = se_values == nullptr;
+  auto reversed = [K](uint32_t m) { uint32_t r = 0; for (int k = 0; k < K; k++) r = (r << 1) | ((m >> k) & 1u); return r; };
+  uint32_t last_mask = ~0u; size_t last_cls = 0;
   for (int i = 0; i < N; i++) {
-    const double *col = match + static_cast<size_t>(i) * K;
-    uint32_t mask = 0;
-    int nv = 0, first = -1;
-    for (int k = 0; k < K; k++) {
-      if (col[k] != 0) { mask |= 1u << k; if (!nv) first = k; nv++; }
-      key[k] = p.paired ? static_cast<double>(col[k] != 0) : col[k];
+    const uint32_t mask = masks[i];
+    const int nv = __builtin_popcount(mask);
+    if (binary) {
+      if (mask != last_mask) {   // reads of one class tend to come in runs
+        const uint32_t rev = reversed(mask);
+        size_t c = 0;
+        while (c < bcls.size() && bcls[c].first != rev) c++;
+        if (c == bcls.size()) bcls.emplace_back(rev, 0.0);
+        last_mask = mask; last_cls = c;
+      }
+      bcls[last_cls].second += 1.0;
+    } else {
+      cls[std::vector<double>(se_values + static_cast<size_t>(i) * K, se_values + static_cast<size_t>(i + 1) * K)] += 1.0;
     }
-    cls[key] += 1.0;
     if (nv == 0) continue;
     if (nv == 1) {
+      const int first = __builtin_ctz(mask);
       e.fixed_ass[i] = first;
       e.base_count[first]++;
       if (p.paired) {
-        const int32_t v = e.sfix_table[static_cast<size_t>(first) * il +
-                                       (fraglen[static_cast<size_t>(i) * K + first] - fd->start)];
+        const int32_t v = e.sfix_table[static_cast<size_t>(first) * il + frags[static_cast<size_t>(i) * K + first]];
         if (v == SFIX_BAD) e.base_bad = 1; else e.base_sfix += v;
       }
       continue;
     }
     e.fixed_ass[i] = -2;
     e.draw_index.push_back(i);
-    if (!p.paired) {
-      e.draw_mask.push_back(mask);
-    } else {
-      for (int k = 0; k < K; k++) {
-        const int fl = fraglen[static_cast<size_t>(i) * K + k];
-        e.draw_frag.push_back(fl < 0 ? FRAG_NONE : static_cast<uint16_t>(fl - fd->start));
-      }
-    }
+    if (!p.paired) e.draw_mask.push_back(mask);
+    else e.draw_frag.insert(e.draw_frag.end(), frags + static_cast<size_t>(i) * K, frags + static_cast<size_t>(i + 1) * K);
     e.n_draw++;
   }
   if (p.paired)   // whole quads of reads on the device: pad with incompatible reads
     while ((e.draw_frag.size() / K) % 4) e.draw_frag.insert(e.draw_frag.end(), K, FRAG_NONE);
   if (!p.paired) {
     // draw order: by column (isoform 0 most significant, 0 < 1), ties by read index
-    auto key = [K](uint32_t m) { uint32_t r = 0; for (int k = 0; k < K; k++) r = (r << 1) | ((m >> k) & 1u); return r; };
-    std::vector<int32_t> perm(e.n_draw);
-    for (int r = 0; r < e.n_draw; r++) perm[r] = r;
-    std::stable_sort(perm.begin(), perm.end(), [&](int32_t x, int32_t y) { return key(e.draw_mask[x]) < key(e.draw_mask[y]); });
+    // (a stable counting sort over the distinct masks: usually a handful, at most n_draw)
+    std::vector<std::pair<uint32_t, uint32_t>> dm;   // (reversed mask, mask) of the distinct drawing masks
+    std::vector<int32_t> cid(e.n_draw);
+    {
+      uint32_t lm = ~0u; int32_t lc = 0;
+      for (int r = 0; r < e.n_draw; r++) {
+        const uint32_t m = e.draw_mask[r];
+        if (m != lm) {
+          size_t c = 0;
+          while (c < dm.size() && dm[c].second != m) c++;
+          if (c == dm.size()) dm.emplace_back(reversed(m), m);
+          lm = m; lc = static_cast<int32_t>(c);
+        }
+        cid[r] = lc;
+      }
+    }
+    std::vector<int32_t> rank(dm.size()), start(dm.size() + 1, 0);
+    {
+      std::vector<int32_t> by(dm.size());
+      for (size_t c = 0; c < dm.size(); c++) by[c] = static_cast<int32_t>(c);
+      std::sort(by.begin(), by.end(), [&](int32_t x, int32_t y) { return dm[x].first < dm[y].first; });
+      for (size_t j = 0; j < by.size(); j++) rank[by[j]] = static_cast<int32_t>(j);
+    }
+    for (int r = 0; r < e.n_draw; r++) start[rank[cid[r]] + 1]++;
+    for (size_t c = 0; c < dm.size(); c++) start[c + 1] += start[c];
     std::vector<int32_t> idx(e.n_draw); std::vector<uint32_t> msk(e.n_draw);
-    for (int r = 0; r < e.n_draw; r++) { idx[r] = e.draw_index[perm[r]]; msk[r] = e.draw_mask[perm[r]]; }
+    for (int r = 0; r < e.n_draw; r++) {
+      const int32_t at = start[rank[cid[r]]]++;
+      idx[at] = e.draw_index[r]; msk[at] = e.draw_mask[r];
+    }
     e.draw_index.swap(idx); e.draw_mask.swap(msk);
     for (int r = 0; r < e.n_draw; r++)
       if (r == 0 || e.draw_mask[r] != e.draw_mask[r - 1]) { e.dcls_mask.push_back(e.draw_mask[r]); e.dcls_start.push_back(r); }
@@ -467,6 +527,13 @@ PackedEvent pack_event(const miso_params_t &p, const FragmentDist *fd, int K, in
           if (31 - __builtin_clz(e.dcls_mask[c]) <= k) ak += static_cast<uint32_t>(e.dcls_start[c + 1] - e.dcls_start[c]);
         e.dcls_tab.push_back(ak);
       }
+    }
+  }
+  if (binary) {
+    std::sort(bcls.begin(), bcls.end());
+    for (const auto &kv : bcls) {
+      for (int k = 0; k < K; k++) e.class_templates.push_back((kv.first >> (K - 1 - k)) & 1u ? 1.0 : 0.0);
+      e.class_counts.push_back(kv.second);
     }
   }
   for (const auto &kv : cls) {

@@ -18,6 +18,8 @@ struct Error : std::exception {
   int code;
   std::string text;  // "Error at file:line: reason, strerror"
   Error(int code, const std::string &reason, const char *file, int line);
+  struct Formatted {};
+  Error(int c, const std::string &formatted_text, Formatted) : code(c), text(formatted_text) {}  // re-raise
   const char *what() const noexcept override { return text.c_str(); }
 };
 #define MISO_FAIL(code, reason) throw ::miso::Error((code), (reason), __FILE__, __LINE__)
@@ -121,5 +123,11 @@ void validate_params(const miso_params_t &p);
 PackedEvent pack_event(const miso_params_t &p, const FragmentDist *fd, int K, int N,
                        const double *match, const int *fraglen, const int *isolen,
                        const int *noexons, const double *hyper);
+// the same from what the packing really needs: per read the u32 compatibility mask, paired-end the
+// K u16 fragment-length indices (FRAG_NONE = incompatible); se_values (single-end, optional): the
+// match matrix when it holds values other than 0/1, for the header's read classes only
+PackedEvent pack_event_masks(const miso_params_t &p, const FragmentDist *fd, int K, int N,
+                             const uint32_t *masks, const uint16_t *frags, const double *se_values,
+                             const int *isolen, const int *noexons, const double *hyper);
 
 }  // namespace miso

@@ -6,10 +6,14 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <string>
+#include <thread>
 
 #include "batch.hpp"
 
@@ -19,6 +23,8 @@ template <bool PE> __global__ void sampler_wave(const KernelArgs a);
 template <int G, bool PE> __global__ void sampler_k2(const KernelArgs a);
 __global__ void compare_kernel(const DevEvent *, const unsigned char *, const DevEvent *, const unsigned char *, int, int,
                                double, const uint64_t *, double *);
+__global__ void match_kernel(const MatchEvent *, const int2 *, const int *, const int *, const int *, const int *,
+                             const int *, const int *, const int *, int, int, int, int, int, uint32_t *, uint16_t *);
 __global__ void summarize_kernel(const DevEvent *, const unsigned char *, int, int, int, int, const uint64_t *, double *);
 template <int G, bool PE, int KC> __global__ void sampler_grp(const KernelArgs a);
 __global__ void selftest_detmath_kernel(const double *, int, double *, double *, double *, double *);
@@ -83,12 +89,154 @@ void miso_batch::release() {
   uploaded = launched = downloaded = false;
 }
 
+// Row f1: the compatibility of every pending event's reads with its isoforms, in one launch.
+// Inputs: the genes' exon tables and the host-parsed CIGAR blocks; outputs: u32 masks (single-end)
+// or u16 fragment indices (paired-end), from which the events are packed exactly as the host path
+// packs them (the same pack_event, fed with the match matrix those outputs stand for).
+void miso_batch::resolve_pending() {
+  if (pending.empty()) return;
+  const bool timing = std::getenv("MISO_TIMING") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+    return std::chrono::duration<double>(b - a).count(); };
+  const auto T0 = now();
+  const int n = static_cast<int>(pending.size());
+  const bool pe = p.paired != 0;
+  const int mates = pe ? 2 : 1;
+  const int ov = p.overHang == 0 ? 1 : p.overHang;
+  std::vector<MatchEvent> mev(n);
+  std::vector<int2> blocks;
+  std::vector<int> h_exidx, h_exstart, h_exend, h_pos, h_opidx, h_ops, h_len;
+  // offsets first, then the copies in parallel
+  std::vector<size_t> o_xi(n + 1, 0), o_ex(n + 1, 0), o_rd(n + 1, 0), o_op(n + 1, 0), o_out(n + 1, 0);
+  std::vector<size_t> frag_off(n, 0);
+  size_t out_frags = 0;
+  for (int i = 0; i < n; i++) {
+    const Pending &q = pending[i];
+    const int N = events[q.event].N;
+    const size_t K = static_cast<size_t>(q.gene.K);
+    o_xi[i + 1] = o_xi[i] + q.gene.exidx.size();
+    o_ex[i + 1] = o_ex[i] + q.gene.exstart.size();
+    o_rd[i + 1] = o_rd[i] + static_cast<size_t>(mates) * N;
+    o_op[i + 1] = o_op[i] + q.ct.ops.size();
+    // frags[(out_off + r) * K + k]: out_off in units of the event's own K, so round up
+    const size_t slot = pe ? (out_frags + K - 1) / K : o_out[i];
+    frag_off[i] = slot * K;
+    if (pe) out_frags = frag_off[i] + static_cast<size_t>(N) * K;
+    o_out[i + 1] = o_out[i] + N;
+    MatchEvent &m = mev[i];
+    m.K = q.gene.K; m.n_reads = N;
+    m.exidx_off = static_cast<int32_t>(o_xi[i]); m.ex_off = static_cast<int32_t>(o_ex[i]);
+    m.read_off = static_cast<int32_t>(o_rd[i]); m.out_off = static_cast<int32_t>(slot);
+    for (int r0 = 0; r0 < N; r0 += 256) blocks.push_back(make_int2(i, r0));
+  }
+  if (o_op[n] > 0x7FFFFFF0u || o_rd[n] > 0x7FFFFFF0u || out_frags > 0x7FFFFFF0u)
+    MISO_FAIL(MISO_EINVAL, "Batch too large for one match launch");
+  const size_t out_slots = o_out[n];
+  h_exidx.resize(o_xi[n]); h_exstart.resize(o_ex[n]); h_exend.resize(o_ex[n]);
+  h_pos.resize(o_rd[n]); h_len.resize(o_rd[n]); h_opidx.resize(o_rd[n] + 1); h_ops.resize(o_op[n]);
+  const int nthreads = std::max(1, std::min<int>(16, static_cast<int>(std::thread::hardware_concurrency())));
+  auto parallel = [&](auto &&fn) {
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nthreads; t++) pool.emplace_back([&fn, t] { fn(t); });
+    fn(0);
+    for (auto &th : pool) th.join();
+  };
+  parallel([&](int t) {
+    for (int i = t; i < n; i += nthreads) {
+      const Pending &q = pending[i];
+      std::copy(q.gene.exidx.begin(), q.gene.exidx.end(), h_exidx.begin() + o_xi[i]);
+      std::copy(q.gene.exstart.begin(), q.gene.exstart.end(), h_exstart.begin() + o_ex[i]);
+      std::copy(q.gene.exend.begin(), q.gene.exend.end(), h_exend.begin() + o_ex[i]);
+      std::copy(q.pos.begin(), q.pos.end(), h_pos.begin() + o_rd[i]);
+      std::copy(q.ct.len.begin(), q.ct.len.end(), h_len.begin() + o_rd[i]);
+      std::copy(q.ct.ops.begin(), q.ct.ops.end(), h_ops.begin() + o_op[i]);
+      const int base = static_cast<int>(o_op[i]);
+      const size_t nr = o_rd[i + 1] - o_rd[i];
+      for (size_t r = 0; r < nr; r++) h_opidx[o_rd[i] + r] = base + q.ct.idx[r];
+    }
+  });
+  h_opidx[o_rd[n]] = static_cast<int>(o_op[n]);
+  const auto T1 = now();
+  std::vector<uint32_t> h_masks(pe ? 0 : out_slots);
+  std::vector<uint16_t> h_frags(pe ? out_frags : 0);
+  if (!blocks.empty()) {
+    auto up = [&](const void *src, size_t bytes) {
+      void *d = nullptr;
+      HIP_OK(hipMalloc(&d, std::max<size_t>(bytes, 16)));
+      if (bytes) HIP_OK(hipMemcpy(d, src, bytes, hipMemcpyHostToDevice));
+      return d;
+    };
+    void *d_ev = up(mev.data(), mev.size() * sizeof(MatchEvent));
+    void *d_bl = up(blocks.data(), blocks.size() * sizeof(int2));
+    void *d_xi = up(h_exidx.data(), h_exidx.size() * 4), *d_xs = up(h_exstart.data(), h_exstart.size() * 4);
+    void *d_xe = up(h_exend.data(), h_exend.size() * 4), *d_po = up(h_pos.data(), h_pos.size() * 4);
+    void *d_oi = up(h_opidx.data(), h_opidx.size() * 4), *d_op = up(h_ops.data(), h_ops.size() * 4);
+    void *d_le = up(h_len.data(), h_len.size() * 4);
+    void *d_out = nullptr;
+    const size_t out_bytes_m = pe ? h_frags.size() * 2 : h_masks.size() * 4;
+    HIP_OK(hipMalloc(&d_out, std::max<size_t>(out_bytes_m, 16)));
+    hipEvent_t t0, t1;
+    HIP_OK(hipEventCreate(&t0)); HIP_OK(hipEventCreate(&t1));
+    HIP_OK(hipEventRecord(t0, nullptr));
+    hipLaunchKernelGGL(match_kernel, dim3(static_cast<unsigned>(blocks.size())), dim3(256), 0, nullptr,
+                       static_cast<const MatchEvent *>(d_ev), static_cast<const int2 *>(d_bl),
+                       static_cast<const int *>(d_xi), static_cast<const int *>(d_xs),
+                       static_cast<const int *>(d_xe), static_cast<const int *>(d_po),
+                       static_cast<const int *>(d_oi), static_cast<const int *>(d_op),
+                       static_cast<const int *>(d_le), p.readLength, ov, pe ? 1 : 0, fd.start,
+                       static_cast<int>(fd.prob.size()), static_cast<uint32_t *>(d_out),
+                       static_cast<uint16_t *>(d_out));
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipEventRecord(t1, nullptr));
+    HIP_OK(hipMemcpy(pe ? static_cast<void *>(h_frags.data()) : static_cast<void *>(h_masks.data()), d_out,
+                     out_bytes_m, hipMemcpyDeviceToHost));
+    HIP_OK(hipEventElapsedTime(&match_ms, t0, t1));
+    (void) hipEventDestroy(t0); (void) hipEventDestroy(t1);
+    for (void *d : {d_ev, d_bl, d_xi, d_xs, d_xe, d_po, d_oi, d_op, d_le, d_out}) (void) hipFree(d);
+  }
+  const auto T2 = now();
+  if (p.want_counts_trace) { kept_masks.resize(events.size()); kept_frags.resize(events.size()); }
+  // pack on the host cores (a few, the cgroup may allow far fewer than the machine has)
+  std::vector<std::string> errors(nthreads);
+  std::vector<int> codes(nthreads, 0);
+  parallel([&](int t) {
+    try {
+      for (int i = t; i < n; i += nthreads) {
+        const Pending &q = pending[i];
+        const int K = q.gene.K, N = mev[i].n_reads;
+        const uint32_t *mk = pe ? nullptr : h_masks.data() + mev[i].out_off;
+        const uint16_t *f = pe ? h_frags.data() + frag_off[i] : nullptr;
+        std::vector<uint32_t> pm;
+        if (pe) {   // a pair's mask = the isoforms with a fragment length inside the distribution
+          pm.assign(std::max(N, 1), 0u);
+          for (int r = 0; r < N; r++)
+            for (int k = 0; k < K; k++) if (f[static_cast<size_t>(r) * K + k] != FRAG_NONE) pm[r] |= 1u << k;
+          mk = pm.data();
+        }
+        if (p.want_counts_trace) {
+          if (pe) kept_frags[q.event].assign(f, f + static_cast<size_t>(N) * K);
+          else kept_masks[q.event].assign(mk, mk + N);
+        }
+        events[q.event] = pack_event_masks(p, pe ? &fd : nullptr, K, N, mk, f, nullptr, q.gene.isolen.data(),
+                                           q.gene.noexons.data(), q.hyper.empty() ? nullptr : q.hyper.data());
+      }
+    } catch (const Error &e) { codes[t] = e.code; errors[t] = e.text; }
+  });
+  for (int t = 0; t < nthreads; t++) if (codes[t]) throw Error(codes[t], errors[t], Error::Formatted{});
+  pending.clear();
+  if (timing)
+    std::fprintf(stderr, "[miso] resolve: flatten %.3f s, device (alloc+copies+kernel %.3f ms) %.3f s, pack (%d threads) %.3f s\n",
+                 secs(T0, T1), match_ms, secs(T1, T2), nthreads, secs(T2, now()));
+}
+
 void miso_batch::upload(int dev) {
   if (uploaded && dev == device) return;
   if (uploaded) release();
   if (device_count() <= 0) MISO_FAIL(MISO_ENODEVICE, "no HIP device: the sampler has no CPU path");
   device = dev;
   HIP_OK(hipSetDevice(dev));
+  resolve_pending();
   const int n = static_cast<int>(events.size());
   const int C = p.noChains, M = p.noIterations, Sn = S();
   h_events.assign(n, DevEvent{});

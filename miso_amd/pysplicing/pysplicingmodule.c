@@ -301,6 +301,7 @@ static void fill_params(miso_params_t *p, int paired, int readLength, int overha
   p->noIterations = iters; p->maxIterations = 100000 /* pysplicing.c:43 */; p->noBurnIn = burn;
   p->noLag = lag; p->algorithm = algo; p->start = start; p->stop = stop;
   p->normalMean = mean; p->normalVar = var; p->numDevs = devs;
+  p->device_match = 1;   /* read x isoform compatibility on the GPU too (solve.c:8-108, 141-218) */
 }
 
 /* ---- MISO (pysplicing.c:41-131) ---- */

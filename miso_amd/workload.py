@@ -31,12 +31,13 @@ def event_gene(event_id, K=2, min_len=50, max_len=300, gap=200):
 
 
 def build_batch(first_event_id, n_events, K=2, n_reads=1000, read_len=36, iters=7500, burn=2500,
-                lag=1, chains=1, paired=False, mean=250.0, var=900.0, counts_trace=False):
+                lag=1, chains=1, paired=False, mean=250.0, var=900.0, counts_trace=False,
+                device_match=False):
     """Batch holding events [first_event_id, first_event_id + n_events)."""
     kw = dict(min_len=400, max_len=800, gap=300) if paired else {}
     b = capi.Batch(read_len, iters=iters, burn=burn, lag=lag, chains=chains, paired=paired,
                    mean=mean if paired else 0.0, var=var if paired else 0.0,
-                   counts_trace=counts_trace)
+                   counts_trace=counts_trace, device_match=device_match)
     for i in range(n_events):
         gid = first_event_id + i
         exons, isoforms, expr = event_gene(gid, K, **kw)
