@@ -1,0 +1,495 @@
+// alnio.cpp -- BAM / SAM reader behind include/miso_alnio.h.
+//
+// The reference reaches alignments through pysam, one Python object per read
+// (misopy/sam_utils.py:139-186, 207-442).  Here a file is decoded once into columns:
+//   BAM : mmap, walk the BGZF block headers (BSIZE), inflate all blocks in parallel straight into
+//         one buffer (each block knows its ISIZE), then one serial pass over the records
+//         (SAM spec v1, section 4.2);
+//   SAM : one pass over the text.
+// and indexed in memory by (reference, position) with a prefix maximum of the end coordinates, so
+// an event's fetch is a binary search + a short scan (no .bai needed, unsorted input accepted).
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cerrno>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <string_view>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include "miso_alnio.h"
+#include "miso_amd.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) {
+  g_err = msg;
+  return code;
+}
+
+const char kCigarOps[] = "MIDNSHP=X";
+
+}  // namespace
+
+struct miso_alnfile {
+  bool is_bam = false;
+  std::vector<std::string> ref_names;
+  std::vector<int64_t> ref_len;
+  std::unordered_map<std::string, int> ref_index;
+  // columns, file order
+  std::vector<int32_t> ref_id, pos, end, flag, l_seq;
+  std::vector<uint64_t> cigar_off{0}, name_off{0};
+  std::vector<uint32_t> cigar;
+  std::vector<char> names;
+  // index: records with a reference, ordered by (ref, pos, file order)
+  std::vector<int64_t> order;
+  std::vector<int64_t> ref_begin;   // n_refs + 1 offsets into `order`
+  std::vector<int32_t> pmax_end;    // running maximum of `end` inside each reference's segment
+
+  int64_t n() const { return static_cast<int64_t>(pos.size()); }
+
+  void push(int32_t rid, int32_t p, int32_t fl, int32_t lseq, const uint32_t *cg, size_t ncg,
+            const char *name, size_t lname) {
+    int64_t reflen = 0;
+    for (size_t i = 0; i < ncg; i++) {
+      const uint32_t op = cg[i] & 15u;
+      if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) reflen += cg[i] >> 4;
+    }
+    // htslib bam_endpos: unmapped or no reference-consuming op -> pos + 1
+    const int32_t e = ((fl & 4) || reflen == 0) ? p + 1 : static_cast<int32_t>(p + reflen);
+    ref_id.push_back(rid); pos.push_back(p); end.push_back(e); flag.push_back(fl);
+    l_seq.push_back(lseq);
+    cigar.insert(cigar.end(), cg, cg + ncg);
+    cigar_off.push_back(cigar.size());
+    names.insert(names.end(), name, name + lname);
+    name_off.push_back(names.size());
+  }
+
+  void build_index() {
+    const int nref = static_cast<int>(ref_names.size());
+    order.clear();
+    for (int64_t i = 0; i < n(); i++)
+      if (ref_id[i] >= 0 && ref_id[i] < nref) order.push_back(i);
+    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {
+      if (ref_id[a] != ref_id[b]) return ref_id[a] < ref_id[b];
+      return pos[a] < pos[b];
+    });
+    ref_begin.assign(nref + 1, 0);
+    for (int64_t i : order) ref_begin[ref_id[i] + 1]++;
+    for (int r = 0; r < nref; r++) ref_begin[r + 1] += ref_begin[r];
+    pmax_end.resize(order.size());
+    for (int r = 0; r < nref; r++) {
+      int32_t m = INT32_MIN;
+      for (int64_t j = ref_begin[r]; j < ref_begin[r + 1]; j++) {
+        m = std::max(m, end[order[j]]);
+        pmax_end[j] = m;
+      }
+    }
+  }
+
+  template <class F> void for_overlaps(int ref, int64_t start, int64_t stop, F &&f) const {
+    if (ref < 0 || ref + 1 >= static_cast<int>(ref_begin.size())) return;
+    const int64_t lo = ref_begin[ref], hi = ref_begin[ref + 1];
+    // first record whose running max end exceeds `start`: nothing before it can overlap
+    const int64_t first = std::upper_bound(pmax_end.begin() + lo, pmax_end.begin() + hi, start,
+                                           [](int64_t s, int32_t e) { return s < e; }) -
+                          pmax_end.begin();
+    for (int64_t j = first; j < hi; j++) {
+      const int64_t i = order[j];
+      if (pos[i] >= stop) break;
+      if (end[i] > start) f(i);
+    }
+  }
+};
+
+namespace {
+
+struct Mapped {
+  const unsigned char *p = nullptr;
+  size_t len = 0;
+  int fd = -1;
+  ~Mapped() {
+    if (p && len) munmap(const_cast<unsigned char *>(p), len);
+    if (fd >= 0) close(fd);
+  }
+};
+
+inline uint32_t rd32(const unsigned char *p) { uint32_t v; std::memcpy(&v, p, 4); return v; }
+inline uint16_t rd16(const unsigned char *p) { uint16_t v; std::memcpy(&v, p, 2); return v; }
+
+struct Block { size_t in_off, in_len, out_off, out_len; };
+
+int inflate_all(const Mapped &m, int n_threads, std::vector<unsigned char> &out) {
+  std::vector<Block> blocks;
+  size_t off = 0, total = 0;
+  while (off < m.len) {
+    if (m.len - off < 18 || m.p[off] != 31 || m.p[off + 1] != 139 || m.p[off + 2] != 8 ||
+        !(m.p[off + 3] & 4))
+      return fail(MISO_EINVAL, "not a BGZF block at offset " + std::to_string(off));
+    const size_t xlen = rd16(m.p + off + 10);
+    size_t x = off + 12, bsize = 0;
+    const size_t xend = x + xlen;
+    if (xend > m.len) return fail(MISO_EINVAL, "truncated BGZF header");
+    while (x + 4 <= xend) {
+      const size_t slen = rd16(m.p + x + 2);
+      if (m.p[x] == 'B' && m.p[x + 1] == 'C' && slen == 2) bsize = static_cast<size_t>(rd16(m.p + x + 4)) + 1;
+      x += 4 + slen;
+    }
+    if (bsize < xlen + 20 || off + bsize > m.len) return fail(MISO_EINVAL, "bad BGZF block size");
+    const size_t isize = rd32(m.p + off + bsize - 4);
+    blocks.push_back({off + 12 + xlen, bsize - xlen - 20, total, isize});
+    total += isize;
+    off += bsize;
+  }
+  try { out.resize(total); } catch (...) { return fail(MISO_ENOMEM, "out of memory inflating the BAM file"); }
+  std::atomic<size_t> next{0};
+  std::atomic<int> bad{0};
+  auto work = [&] {
+    z_stream zs;
+    for (;;) {
+      const size_t b = next.fetch_add(1);
+      if (b >= blocks.size() || bad.load()) return;
+      const Block &k = blocks[b];
+      if (k.out_len == 0) continue;
+      std::memset(&zs, 0, sizeof zs);
+      if (inflateInit2(&zs, -15) != Z_OK) { bad = 1; return; }
+      zs.next_in = const_cast<unsigned char *>(m.p + k.in_off);
+      zs.avail_in = static_cast<uInt>(k.in_len);
+      zs.next_out = out.data() + k.out_off;
+      zs.avail_out = static_cast<uInt>(k.out_len);
+      const int rc = inflate(&zs, Z_FINISH);
+      inflateEnd(&zs);
+      if (rc != Z_STREAM_END || zs.avail_out != 0) { bad = 1; return; }
+    }
+  };
+  const int T = std::max(1, std::min<int>(n_threads, static_cast<int>(blocks.size())));
+  std::vector<std::thread> th;
+  for (int t = 1; t < T; t++) th.emplace_back(work);
+  work();
+  for (auto &t : th) t.join();
+  if (bad.load()) return fail(MISO_EINVAL, "corrupt BGZF block (inflate failed)");
+  return 0;
+}
+
+int parse_bam(const std::vector<unsigned char> &d, miso_alnfile &f) {
+  const size_t n = d.size();
+  size_t o = 0;
+  auto need = [&](size_t k) { return o + k <= n; };
+  if (!need(12) || std::memcmp(d.data(), "BAM\1", 4) != 0) return fail(MISO_EINVAL, "missing BAM magic");
+  const uint32_t l_text = rd32(d.data() + 4);
+  o = 8 + static_cast<size_t>(l_text);
+  if (!need(4)) return fail(MISO_EINVAL, "truncated BAM header");
+  const uint32_t n_ref = rd32(d.data() + o); o += 4;
+  for (uint32_t r = 0; r < n_ref; r++) {
+    if (!need(4)) return fail(MISO_EINVAL, "truncated BAM reference list");
+    const uint32_t l_name = rd32(d.data() + o); o += 4;
+    if (!need(static_cast<size_t>(l_name) + 4) || l_name == 0) return fail(MISO_EINVAL, "truncated BAM reference list");
+    std::string name(reinterpret_cast<const char *>(d.data() + o), l_name - 1);
+    o += l_name;
+    f.ref_len.push_back(static_cast<int32_t>(rd32(d.data() + o))); o += 4;
+    f.ref_index.emplace(name, static_cast<int>(f.ref_names.size()));
+    f.ref_names.push_back(std::move(name));
+  }
+  std::vector<uint32_t> tmp;
+  while (o < n) {
+    if (!need(4)) return fail(MISO_EINVAL, "truncated BAM record");
+    const uint32_t bs = rd32(d.data() + o); o += 4;
+    if (bs < 32 || !need(bs)) return fail(MISO_EINVAL, "truncated BAM record");
+    const unsigned char *r = d.data() + o;
+    const int32_t rid = static_cast<int32_t>(rd32(r)), p = static_cast<int32_t>(rd32(r + 4));
+    const uint32_t l_name = r[8];
+    const uint32_t n_cig = rd16(r + 12), fl = rd16(r + 14);
+    const int32_t l_seq = static_cast<int32_t>(rd32(r + 16));
+    if (32 + static_cast<size_t>(l_name) + 4 * static_cast<size_t>(n_cig) > bs || l_name == 0)
+      return fail(MISO_EINVAL, "malformed BAM record");
+    const char *name = reinterpret_cast<const char *>(r + 32);
+    tmp.resize(n_cig);  // the cigar may be unaligned inside the record
+    if (n_cig) std::memcpy(tmp.data(), r + 32 + l_name, 4 * static_cast<size_t>(n_cig));
+    f.push(rid, p, static_cast<int32_t>(fl), l_seq, tmp.data(), n_cig, name, l_name - 1);
+    o += bs;
+  }
+  return 0;
+}
+
+int parse_sam(const unsigned char *p, size_t len, miso_alnfile &f) {
+  const char *s = reinterpret_cast<const char *>(p), *e = s + len;
+  std::vector<uint32_t> cg;
+  size_t lineno = 0;
+  while (s < e) {
+    const char *nl = static_cast<const char *>(std::memchr(s, '\n', e - s));
+    const char *le = nl ? nl : e;
+    const char *next = nl ? nl + 1 : e;
+    if (le > s && le[-1] == '\r') le--;
+    lineno++;
+    if (le == s) { s = next; continue; }
+    if (*s == '@') {
+      if (le - s >= 3 && s[1] == 'S' && s[2] == 'Q') {
+        std::string name; int64_t ln = 0;
+        const char *q = s;
+        while (q < le) {
+          const char *t = static_cast<const char *>(std::memchr(q, '\t', le - q));
+          const char *fe = t ? t : le;
+          if (fe - q > 3 && q[0] == 'S' && q[1] == 'N' && q[2] == ':') name.assign(q + 3, fe);
+          if (fe - q > 3 && q[0] == 'L' && q[1] == 'N' && q[2] == ':') ln = std::strtoll(std::string(q + 3, fe).c_str(), nullptr, 10);
+          q = t ? t + 1 : le;
+        }
+        if (!name.empty() && !f.ref_index.count(name)) {
+          f.ref_index.emplace(name, static_cast<int>(f.ref_names.size()));
+          f.ref_names.push_back(name);
+          f.ref_len.push_back(ln);
+        }
+      }
+      s = next;
+      continue;
+    }
+    const char *fld[11]; size_t fl_len[11]; int nf = 0;
+    const char *q = s;
+    while (nf < 11) {
+      const char *t = static_cast<const char *>(std::memchr(q, '\t', le - q));
+      fld[nf] = q; fl_len[nf] = (t ? t : le) - q; nf++;
+      if (!t) break;
+      q = t + 1;
+    }
+    if (nf < 11) return fail(MISO_EINVAL, "SAM line " + std::to_string(lineno) + ": fewer than 11 fields");
+    const int32_t flag = static_cast<int32_t>(std::strtol(std::string(fld[1], fl_len[1]).c_str(), nullptr, 10));
+    const std::string rname(fld[2], fl_len[2]);
+    int32_t rid = -1;
+    if (rname != "*") {
+      auto it = f.ref_index.find(rname);
+      if (it == f.ref_index.end()) {  // header-less SAM: references in order of appearance
+        rid = static_cast<int32_t>(f.ref_names.size());
+        f.ref_index.emplace(rname, rid);
+        f.ref_names.push_back(rname);
+        f.ref_len.push_back(0);
+      } else {
+        rid = it->second;
+      }
+    }
+    const int32_t pos1 = static_cast<int32_t>(std::strtol(std::string(fld[3], fl_len[3]).c_str(), nullptr, 10));
+    cg.clear();
+    if (!(fl_len[5] == 1 && fld[5][0] == '*')) {
+      const char *c = fld[5], *ce = c + fl_len[5];
+      while (c < ce) {
+        uint64_t v = 0; bool digits = false;
+        while (c < ce && *c >= '0' && *c <= '9') { v = v * 10 + (*c - '0'); c++; digits = true; }
+        const char *opp = (c < ce) ? std::strchr(kCigarOps, *c) : nullptr;
+        if (!digits || !opp || *c == '\0' || v >= (1u << 28))
+          return fail(MISO_EINVAL, "SAM line " + std::to_string(lineno) + ": bad CIGAR");
+        cg.push_back(static_cast<uint32_t>(v << 4) | static_cast<uint32_t>(opp - kCigarOps));
+        c++;
+      }
+    }
+    const int32_t l_seq = (fl_len[9] == 1 && fld[9][0] == '*') ? 0 : static_cast<int32_t>(fl_len[9]);
+    f.push(rid, pos1 - 1, flag, l_seq, cg.data(), cg.size(), fld[0], fl_len[0]);
+    s = next;
+  }
+  return 0;
+}
+
+int usable_threads() {
+  long n = sysconf(_SC_NPROCESSORS_ONLN);
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min<long>(n, CPU_COUNT(&set));
+  return static_cast<int>(std::max<long>(1, std::min<long>(n, 64)));
+}
+
+void append_cigar_string(const miso_alnfile &f, int64_t i, std::string &out) {
+  char buf[16];
+  for (uint64_t c = f.cigar_off[i]; c < f.cigar_off[i + 1]; c++) {
+    const uint32_t v = f.cigar[c], op = v & 15u;
+    const int k = std::snprintf(buf, sizeof buf, "%u", v >> 4);
+    out.append(buf, k);
+    out.push_back(op < 9 ? kCigarOps[op] : '?');
+  }
+  out.push_back('\0');
+}
+
+// misopy/sam_utils.py:195-204: endswith /1 /2 #1 #2 -> drop the last THREE characters (sic)
+std::string_view strip_mate_id(std::string_view name) {
+  const size_t n = name.size();
+  if (n >= 2 && (name[n - 2] == '/' || name[n - 2] == '#') && (name[n - 1] == '1' || name[n - 1] == '2'))
+    return name.substr(0, n >= 3 ? n - 3 : 0);
+  return name;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *miso_aln_last_error(void) { return g_err.c_str(); }
+
+int miso_aln_open(const char *path, int n_threads, miso_alnfile_t **out) {
+  if (!path || !out) return fail(MISO_EINVAL, "miso_aln_open: null argument");
+  *out = nullptr;
+  Mapped m;
+  m.fd = open(path, O_RDONLY);
+  if (m.fd < 0) return fail(MISO_FAILURE, std::string("cannot open ") + path + ": " + std::strerror(errno));
+  struct stat st;
+  if (fstat(m.fd, &st) != 0) return fail(MISO_FAILURE, std::string("cannot stat ") + path);
+  m.len = static_cast<size_t>(st.st_size);
+  if (m.len) {
+    void *p = mmap(nullptr, m.len, PROT_READ, MAP_PRIVATE, m.fd, 0);
+    if (p == MAP_FAILED) { m.len = 0; return fail(MISO_FAILURE, std::string("cannot map ") + path); }
+    m.p = static_cast<const unsigned char *>(p);
+  }
+  miso_alnfile *f = nullptr;
+  try {
+    f = new miso_alnfile();
+    int rc;
+    if (m.len >= 2 && m.p[0] == 31 && m.p[1] == 139) {
+      f->is_bam = true;
+      std::vector<unsigned char> data;
+      rc = inflate_all(m, n_threads > 0 ? n_threads : usable_threads(), data);
+      if (rc == 0) rc = parse_bam(data, *f);
+    } else {
+      rc = parse_sam(m.p, m.len, *f);
+    }
+    if (rc != 0) { delete f; return rc; }
+    f->build_index();
+  } catch (const std::bad_alloc &) {
+    delete f;
+    return fail(MISO_ENOMEM, "out of memory reading the alignment file");
+  }
+  *out = f;
+  return 0;
+}
+
+void miso_aln_close(miso_alnfile_t *f) { delete f; }
+
+int miso_aln_columns(const miso_alnfile_t *f, miso_aln_columns_t *c) {
+  if (!f || !c) return fail(MISO_EINVAL, "miso_aln_columns: null argument");
+  c->n = f->n();
+  c->ref_id = f->ref_id.data(); c->pos = f->pos.data(); c->end = f->end.data();
+  c->flag = f->flag.data(); c->l_seq = f->l_seq.data();
+  c->cigar_off = f->cigar_off.data(); c->cigar = f->cigar.data();
+  c->name_off = f->name_off.data(); c->names = f->names.data();
+  return 0;
+}
+
+int miso_aln_n_refs(const miso_alnfile_t *f) { return f ? static_cast<int>(f->ref_names.size()) : 0; }
+
+const char *miso_aln_ref_name(const miso_alnfile_t *f, int ref) {
+  if (!f || ref < 0 || ref >= static_cast<int>(f->ref_names.size())) return nullptr;
+  return f->ref_names[ref].c_str();
+}
+
+int64_t miso_aln_ref_length(const miso_alnfile_t *f, int ref) {
+  if (!f || ref < 0 || ref >= static_cast<int>(f->ref_len.size())) return -1;
+  return f->ref_len[ref];
+}
+
+int miso_aln_ref_id(const miso_alnfile_t *f, const char *name) {
+  if (!f || !name) return -1;
+  auto it = f->ref_index.find(name);
+  return it == f->ref_index.end() ? -1 : it->second;
+}
+
+int miso_aln_is_bam(const miso_alnfile_t *f) { return f && f->is_bam ? 1 : 0; }
+
+int miso_aln_fetch(const miso_alnfile_t *f, int ref, int64_t start, int64_t end, int64_t *idx,
+                   int64_t cap, int64_t *n) {
+  if (!f || !n) return fail(MISO_EINVAL, "miso_aln_fetch: null argument");
+  int64_t k = 0;
+  f->for_overlaps(ref, start, end, [&](int64_t i) {
+    if (idx && k < cap) idx[k] = i;
+    k++;
+  });
+  *n = k;
+  return 0;
+}
+
+int miso_aln_parse_reads(const miso_alnfile_t *f, int ref, int64_t start, int64_t end, int paired,
+                         int strand_rule, int target_strand, int given_read_len,
+                         int32_t *positions, int64_t pos_cap, char *cigar_buf, int64_t cigar_cap,
+                         int64_t *n_reads, int64_t *cigar_bytes, int64_t *n_strand_discarded) {
+  if (!f || !n_reads || !cigar_bytes) return fail(MISO_EINVAL, "miso_aln_parse_reads: null argument");
+  if (strand_rule != MISO_STRAND_UNSTRANDED && strand_rule != MISO_STRAND_FIRSTSTRAND)
+    return fail(MISO_EINVAL, "miso_aln_parse_reads: unknown strand rule");
+  std::vector<int32_t> pos_out;
+  std::string cig_out;
+  int64_t kept = 0, discarded = 0;
+  const bool check_strand = strand_rule == MISO_STRAND_FIRSTSTRAND && target_strand != 0;  // sam_utils.py:385-390
+  auto minus = [&](int64_t i) { return (f->flag[i] & 16) != 0; };
+  auto has_cigar = [&](int64_t i) { return f->cigar_off[i + 1] > f->cigar_off[i]; };
+  try {
+    if (!paired) {
+      f->for_overlaps(ref, start, end, [&](int64_t i) {
+        if (!has_cigar(i)) return;                                           // sam_utils.py:419
+        if (given_read_len > 0 && f->l_seq[i] != given_read_len) return;     // :423-426
+        if (check_strand) {                                                  // :353-358
+          const char s = minus(i) ? '-' : '+';
+          if (s != static_cast<char>(target_strand)) { discarded++; return; }
+        }
+        pos_out.push_back(f->pos[i]);
+        append_cigar_string(*f, i, cig_out);
+        kept++;
+      });
+    } else {
+      // pair_sam_reads (sam_utils.py:207-300), names in order of first appearance
+      struct Group { int64_t r[2]; int count; };
+      std::vector<Group> groups;
+      std::unordered_map<std::string_view, size_t> by_name;
+      f->for_overlaps(ref, start, end, [&](int64_t i) {
+        const int fl = f->flag[i];
+        // QC fail, unmapped, mate unmapped or not paired: never enters the pairing (:225-230)
+        if ((fl & 0x200) || (fl & 0x4) || (fl & 0x8) || !(fl & 0x1)) return;
+        const std::string_view name = strip_mate_id(
+            std::string_view(f->names.data() + f->name_off[i], f->name_off[i + 1] - f->name_off[i]));
+        auto it = by_name.find(name);
+        if (it == by_name.end()) {
+          by_name.emplace(name, groups.size());
+          groups.push_back({{i, -1}, 1});
+          return;
+        }
+        Group &g = groups[it->second];
+        if (g.count < 2) g.r[g.count] = i;
+        g.count++;
+        if (g.count == 2 && strand_rule == MISO_STRAND_FIRSTSTRAND) {        // :236-248
+          if ((f->flag[g.r[0]] & 0x40) && minus(g.r[0])) std::swap(g.r[0], g.r[1]);
+          if ((f->flag[g.r[0]] & 0x80) && minus(g.r[0])) std::swap(g.r[0], g.r[1]);
+        }
+      });
+      for (const Group &g : groups) {
+        if (g.count != 2) continue;                                          // :255-261
+        const int64_t a = g.r[0], b = g.r[1];
+        if (minus(a) == minus(b)) continue;                                  // :264-271 same strand
+        if (check_strand) {                                                  // :337-346
+          bool ok = false;
+          if (target_strand == '+') ok = !minus(a);
+          else if (target_strand == '-') ok = minus(b);
+          if (!ok) { discarded++; continue; }
+        }
+        if (!has_cigar(a) || !has_cigar(b)) continue;                        // :394-395
+        if (given_read_len > 0 && (f->l_seq[a] != given_read_len || f->l_seq[b] != given_read_len))
+          continue;                                                          // :399-404
+        pos_out.push_back(f->pos[a]);
+        pos_out.push_back(f->pos[b]);
+        append_cigar_string(*f, a, cig_out);
+        append_cigar_string(*f, b, cig_out);
+        kept++;
+      }
+    }
+  } catch (const std::bad_alloc &) {
+    return fail(MISO_ENOMEM, "out of memory collecting the reads of an event");
+  }
+  *n_reads = kept;
+  *cigar_bytes = static_cast<int64_t>(cig_out.size());
+  if (n_strand_discarded) *n_strand_discarded = discarded;
+  if (positions) std::memcpy(positions, pos_out.data(), 4 * static_cast<size_t>(std::min<int64_t>(pos_cap, pos_out.size())));
+  if (cigar_buf) std::memcpy(cigar_buf, cig_out.data(), static_cast<size_t>(std::min<int64_t>(cigar_cap, cig_out.size())));
+  return 0;
+}
+
+}  // extern "C"

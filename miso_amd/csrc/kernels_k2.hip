@@ -33,6 +33,10 @@
 
 #pragma clang fp contract(off)
 
+#ifndef MISO_K2_UQ
+#define MISO_K2_UQ 2   // Philox blocks in flight per lane in the single-end read loop
+#endif
+
 #ifdef MISO_K2_PROFILE
 #define PROF_T(var) const uint64_t var = __builtin_readcyclecounter()
 #define PROF_ADD(acc, t0, t1) acc += (t1) - (t0)
@@ -227,8 +231,9 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   const int base0 = base[0], base1 = base[1];
   const int n_draw = E.n_draw;
   const int nfq = n_draw >> 2, rem = n_draw & 3;  // full draw quads, draws in the partial one
-  // trips of the Gibbs loop (two quads per lane per trip); must be wave-uniform
-  int trips = (nfq + 2 * G - 1) / (2 * G);
+  // trips of the Gibbs loop (UQ quads per lane per trip); must be wave-uniform
+  constexpr int UQ = PE ? 2 : MISO_K2_UQ;
+  int trips = (nfq + UQ * G - 1) / (UQ * G);
   int any_rem = rem;
   for (int off = 32; off >= 1; off >>= 1) {
     trips = max(trips, __shfl_xor(trips, off));
@@ -322,12 +327,17 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     PROF_T(g1);
     PROF_ADD(pf_thr, g0, g1);
     for (int j = 0; j < trips; j++) {
-      const int qa = sub + (2 * j) * G, qb = qa + G;
-      const miso_u32x4 ua = philox_gibbs(rng, static_cast<uint32_t>(qa), n0r0);
-      const miso_u32x4 ub = philox_gibbs(rng, static_cast<uint32_t>(qb), n0r0);
-      const int ca = (ua.v[0] <= tm) + (ua.v[1] <= tm) + (ua.v[2] <= tm) + (ua.v[3] <= tm);
-      const int cb = (ub.v[0] <= tm) + (ub.v[1] <= tm) + (ub.v[2] <= tm) + (ub.v[3] <= tm);
-      d0 += (qa < nfq ? ca : 0) + (qb < nfq ? cb : 0);
+      // UQ independent Philox blocks in flight per lane: the 9 dependent rounds of one block leave
+      // the multiplier pipe idle between rounds; interleaved blocks fill it
+      miso_u32x4 u[UQ];
+#pragma unroll
+      for (int i = 0; i < UQ; i++)
+        u[i] = philox_gibbs(rng, static_cast<uint32_t>(sub + (UQ * j + i) * G), n0r0);
+#pragma unroll
+      for (int i = 0; i < UQ; i++) {
+        const int ci = (u[i].v[0] <= tm) + (u[i].v[1] <= tm) + (u[i].v[2] <= tm) + (u[i].v[3] <= tm);
+        d0 += (sub + (UQ * j + i) * G < nfq) ? ci : 0;
+      }
     }
     if (any_rem) {  // the partial quad, owned by one lane of the group
       const miso_u32x4 u = philox_gibbs(rng, static_cast<uint32_t>(nfq), n0r0);

@@ -1,0 +1,171 @@
+"""misopy/miso.py (`miso --run`) for Python 3 and GPUs.
+
+    python -m miso_amd.miso --run INDEXED_GFF_DIR ALIGNMENTS.bam --output-dir OUT --read-len 36 \
+           [--paired-end MEAN SD] [--overhang-len N] [--settings-filename F] [--event-type T]
+           [-p N_GPUS] [--seed S]
+
+The reference's GenesDispatcher (miso.py:69-337) splits the gene list into `num_processors`
+chunks (cluster_utils.chunk_list) and runs `run_miso.py --compute-genes-from-file` on each in its
+own process, one CPU core per process.  Here a chunk is a GPU: `-p N` = number of GPUs of this
+node (default: all visible), one child process per GPU, each sampling its contiguous chunk as GPU
+batches; no communication between them.  Every event keeps its GLOBAL index in the Philox counter
+(`--first-event-id`), so the .miso files do not depend on N.  Cluster submission (`--use-cluster`,
+SGE), `--prefilter` (bedtools) are outside the path and not provided.
+"""
+import os
+import subprocess
+import sys
+import time
+
+from . import gff_utils
+from .settings import Settings
+
+
+def chunk_list(seq, num):
+    """cluster_utils.py:23-32."""
+    avg = len(seq) / float(num)
+    out = []
+    last = 0.0
+    while last < len(seq):
+        out.append(seq[int(last):int(last + avg)])
+        last += avg
+    return out
+
+
+def visible_gpus():
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import pysplicing
+    return int(pysplicing.deviceCount())
+
+
+class GenesDispatcher(object):
+    """miso.py:69-337, with GPUs for processors."""
+
+    def __init__(self, gff_dir, bam_filename, output_dir, read_len, overhang_len,
+                 settings_fname=None, paired_end=None, gene_ids=None, num_proc=None,
+                 event_type=None, seed=None):
+        self.gff_dir, self.bam_filename, self.output_dir = gff_dir, bam_filename, output_dir
+        if not os.path.isfile(self.bam_filename):
+            raise IOError("BAM file %s not found." % self.bam_filename)
+        self.read_len = read_len
+        self.overhang_len = 1            # "For now setting overhang to 1 always" (miso.py:100-102)
+        self.settings_fname, self.paired_end = settings_fname, paired_end
+        self.event_type, self.seed = event_type, seed
+        self.num_processors = int(num_proc) if num_proc is not None else max(1, visible_gpus())
+        self.batch_logs_dir = os.path.join(output_dir, "batch-logs")
+        self.batch_genes_dir = os.path.join(output_dir, "batch-genes")
+        os.makedirs(self.batch_logs_dir, exist_ok=True)
+        os.makedirs(self.batch_genes_dir, exist_ok=True)
+        self.gene_ids_to_gff_index = gff_utils.get_gene_ids_to_gff_index(gff_dir)
+        self.gene_ids = list(gene_ids) if gene_ids is not None else \
+            list(self.gene_ids_to_gff_index.keys())
+        if len(self.gene_ids) == 0:
+            raise ValueError("No genes to run on. Did you pass me the wrong path to your index "
+                             "GFF directory? Or perhaps your indexed GFF directory is empty?")
+
+    def output_batch_files(self):
+        """miso.py:152-186: batch-<n>_genes.txt, two columns: gene ID, indexed file."""
+        batches = []
+        first = 0
+        for batch_num, ids in enumerate(chunk_list(self.gene_ids, self.num_processors)):
+            fname = os.path.join(self.batch_genes_dir, "batch-%d_genes.txt" % batch_num)
+            with open(fname, "w") as out:
+                for gene_id in ids:
+                    if gene_id not in self.gene_ids_to_gff_index:
+                        print("Skipping: %s" % gene_id)
+                        continue
+                    out.write("%s\t%s\n" % (gene_id, self.gene_ids_to_gff_index[gene_id]))
+            batches.append((fname, len(ids), first))
+            first += len(ids)
+        return batches
+
+    def run(self):
+        batches = self.output_batch_files()
+        print("Preparing to run %d batches of jobs..." % len(batches))
+        procs = []
+        for batch_num, (fname, size, first) in enumerate(batches):
+            if size == 0:
+                continue
+            cmd = [sys.executable, "-m", "miso_amd.run_miso", "--compute-genes-from-file", fname,
+                   self.bam_filename, self.output_dir, "--read-len", str(self.read_len),
+                   "--device", str(batch_num), "--first-event-id", str(first)]
+            if self.paired_end is not None:
+                cmd += ["--paired-end", "%.1f" % float(self.paired_end[0]),
+                        "%.1f" % float(self.paired_end[1])]
+            else:
+                cmd += ["--overhang-len", str(self.overhang_len)]
+            if self.settings_fname is not None:
+                cmd += ["--settings-filename", self.settings_fname]
+            if self.event_type is not None:
+                cmd += ["--event-type", self.event_type]
+            if self.seed is not None:
+                cmd += ["--seed", str(self.seed)]
+            log = os.path.join(self.batch_logs_dir, "batch-%d-%s.log"
+                               % (batch_num, time.strftime("%m-%d-%y_%H:%M:%S")))
+            print("Running batch of %d genes on GPU %d.." % (size, batch_num))
+            env = dict(os.environ)
+            root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+            env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+            procs.append((batch_num, subprocess.Popen(cmd, stdout=open(log, "a"),
+                                                      stderr=subprocess.STDOUT, env=env), log))
+        failed = 0
+        for batch_num, p, log in procs:
+            p.wait()
+            if p.returncode != 0:
+                failed += 1
+                print("WARNING: batch %d might have failed (exit %d), see %s"
+                      % (batch_num, p.returncode, log))
+        return failed
+
+
+def compute_all_genes_psi(gff_dir, bam_filename, read_len, output_dir, overhang_len=1,
+                          paired_end=None, settings_fname=None, num_proc=None, event_type=None,
+                          seed=None):
+    """miso.py:340-420."""
+    print("Computing Psi values...")
+    print("  - GFF index: %s" % gff_dir)
+    print("  - BAM: %s" % bam_filename)
+    print("  - Read length: %d" % read_len)
+    print("  - Output directory: %s" % output_dir)
+    os.makedirs(output_dir, exist_ok=True)
+    return GenesDispatcher(gff_dir, bam_filename, output_dir, read_len, overhang_len,
+                           settings_fname=settings_fname, paired_end=paired_end, num_proc=num_proc,
+                           event_type=event_type, seed=seed).run()
+
+
+def main(argv=None):
+    import argparse
+    ap = argparse.ArgumentParser(description="MISO (Mixture of Isoforms model) on MI355X")
+    ap.add_argument("--run", nargs=2, metavar=("INDEXED_GFF_DIR", "BAM"))
+    ap.add_argument("--event-type", default=None)
+    ap.add_argument("--settings-filename", default=None)
+    ap.add_argument("--read-len", type=int, default=None)
+    ap.add_argument("--paired-end", nargs=2, default=None, metavar=("MEAN", "SD"))
+    ap.add_argument("--overhang-len", type=int, default=None)
+    ap.add_argument("--output-dir", default=None)
+    ap.add_argument("-p", dest="num_proc", type=int, default=None, help="number of GPUs")
+    ap.add_argument("--seed", type=int, default=None)
+    a = ap.parse_args(argv)
+    settings_filename = None if a.settings_filename is None else \
+        os.path.abspath(os.path.expanduser(a.settings_filename))
+    Settings.load(settings_filename)
+    if a.run is None:
+        ap.print_help()
+        return 0
+    if a.output_dir is None:
+        print("Error: need --output-dir to compute Psi values.")
+        return 1
+    if a.read_len is None:
+        print("Error: need --read-len to compute Psi values.")
+        return 1
+    gff_dir, bam = (os.path.abspath(os.path.expanduser(p)) for p in a.run)
+    failed = compute_all_genes_psi(gff_dir, bam, a.read_len,
+                                   os.path.abspath(os.path.expanduser(a.output_dir)),
+                                   overhang_len=a.overhang_len or 1, paired_end=a.paired_end,
+                                   settings_fname=settings_filename, num_proc=a.num_proc,
+                                   event_type=a.event_type, seed=a.seed)
+    return 1 if failed else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,201 @@
+"""misopy/run_miso.py for Python 3 and for a GPU: compute Psi for a set of genes / events.
+
+The reference loops `for gene: fetch reads -> MISOSampler.run_sampler` (run_miso.py:34-206), one
+C call per event on one CPU core.  A GPU wants thousands of events per launch, so the same steps
+are split in two: `collect_gene_events` does everything the reference does per gene up to the
+sampler call (index lookup, the read-length sanity check, transcript bounds, fetch, strand /
+read-length filters, mate pairing, the minimum-read filter, output path), and
+`compute_gene_psi` hands the whole list to `MISOSampler.run_sampler_batch` -- one batch per
+launch, one `.miso` file per event, byte layout as in the reference.
+
+    python -m miso_amd.run_miso --compute-gene-psi GENE_IDS INDEXED.pickle BAM OUT --read-len 36
+    python -m miso_amd.run_miso --compute-genes-from-file GENES.txt BAM OUT --read-len 36 \
+           [--paired-end MEAN SD] [--overhang-len N] [--settings-filename F] [--device D]
+           [--seed S] [--first-event-id I]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+from . import gff_utils, sam_utils
+from .settings import Settings
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+if _HERE not in sys.path:
+    sys.path.insert(0, _HERE)
+import miso_sampler as miso  # noqa: E402  (flat import: it shares `pysplicing` with its tests)
+
+
+def collect_gene_events(gene_entries, bamfile, output_dir, read_len, overhang_len,
+                        paired_end=None, event_type=None, verbose=True):
+    """run_miso.py:98-206 up to (not including) sampler.run_sampler, for many genes.
+    gene_entries: iterable of (gene_id, indexed_gff_filename).
+    Returns (events, info): events = [(reads, gene_obj, output_filename)] for
+    MISOSampler.run_sampler_batch, info = per gene status strings (for logs / tests)."""
+    settings = Settings.get()
+    min_event_reads = Settings.get_min_event_reads()
+    strand_rule = Settings.get_strand_param()
+    filter_reads = settings.get("filter_reads", True)               # run_miso.py:91-94
+    events, info = [], {}
+    loaded = {}
+    for gene_id, gff_index_filename in gene_entries:
+        if not os.path.exists(gff_index_filename):
+            print("Error: No GFF %s" % gff_index_filename)
+            info[gene_id] = "no index"
+            continue
+        if gff_index_filename not in loaded:
+            loaded = {gff_index_filename: gff_utils.load_indexed_gff_file(gff_index_filename)}
+        gff_genes = loaded[gff_index_filename]
+        if gene_id not in gff_genes:
+            info[gene_id] = "not in index"
+            continue
+        gene_info = gff_genes[gene_id]
+        gene_obj = gene_info['gene_object']
+        # Sanity check: if the isoforms are all shorter than the read, skip (run_miso.py:110-115)
+        if all(l < read_len for l in gene_obj.iso_lens):
+            if verbose:
+                print("All isoforms of %s shorter than %d, so skipping" % (gene_id, read_len))
+            info[gene_id] = "isoforms shorter than reads"
+            continue
+        tx_start, tx_end = gff_utils.get_inclusive_txn_bounds(gene_info['hierarchy'][gene_id])
+        chrom = sam_utils.resolve_chrom(bamfile, gene_obj.chrom)
+        try:
+            reads, num_raw_reads = bamfile.parse_reads(
+                chrom, tx_start, tx_end, paired_end=bool(paired_end), strand_rule=strand_rule,
+                target_strand=gene_obj.strand, given_read_len=read_len)
+        except ValueError:
+            if verbose:
+                print("Cannot fetch reads in region: %s:%d-%d" % (chrom, tx_start, tx_end))
+            reads, num_raw_reads = ((), ()), 0
+        if filter_reads and num_raw_reads < min_event_reads:
+            if verbose:
+                print("Only %d reads in gene, skipping (needed >= %d reads)"
+                      % (num_raw_reads, min_event_reads))
+            info[gene_id] = "only %d reads" % num_raw_reads
+            continue
+        if event_type is not None:
+            chrom_dir = os.path.join(output_dir, event_type, gene_obj.chrom)
+        else:
+            chrom_dir = os.path.join(output_dir, gene_obj.chrom)
+        miso_basename = os.path.basename(gff_index_filename)
+        if not miso_basename.endswith(".pickle"):
+            raise ValueError("Error: Invalid index file %s" % gff_index_filename)
+        output_filename = os.path.join(chrom_dir, miso_basename[:-len(".pickle")])
+        events.append((reads, gene_obj, output_filename))
+        info[gene_id] = "%d reads" % num_raw_reads
+    return events, info
+
+
+def compute_gene_psi(gene_ids, gff_index_filename, bam_filename, output_dir, read_len,
+                     overhang_len, paired_end=None, event_type=None, verbose=True, bamfile=None,
+                     seed=None, first_event_id=0, device=None, gene_entries=None,
+                     max_events_per_launch=65536):
+    """run_miso.py:34-206.  `gene_entries` (list of (gene_id, index file)) generalises the
+    reference's (gene_ids, one index file) so a whole batch file is one GPU batch."""
+    os.makedirs(output_dir, exist_ok=True)
+    if gene_entries is None:
+        gene_entries = [(g, gff_index_filename) for g in gene_ids]
+    print("Computing Psi for %d genes..." % len(gene_entries))
+    print("  - BAM: %s" % bam_filename)
+    print("  - Outputting to: %s" % output_dir)
+    if paired_end:
+        print("  - Paired-end mode: ", paired_end)
+    settings_params = Settings.get_sampler_params()
+    burn_in, lag = settings_params["burn_in"], settings_params["lag"]
+    num_iters, num_chains = settings_params["num_iters"], settings_params["num_chains"]
+    if device is not None:
+        os.environ["MISO_DEVICE"] = str(int(device))               # read by pysplicing per launch
+    t0 = time.time()
+    own = bamfile is None
+    if own:
+        bamfile = sam_utils.load_bam_reads(bam_filename)
+    events, info = collect_gene_events(gene_entries, bamfile, output_dir, read_len, overhang_len,
+                                       paired_end=paired_end, event_type=event_type,
+                                       verbose=verbose)
+    t1 = time.time()
+    written = []
+    if paired_end:
+        mean_frag_len = int(paired_end[0])
+        frag_variance = np.power(int(paired_end[1]), 2)             # run_miso.py:80-83
+    for lo in range(0, len(events), max_events_per_launch):
+        chunk = events[lo:lo + max_events_per_launch]
+        # sampler parameters as in run_miso.py:151-171 (num_isoforms only sizes an unused matrix)
+        if paired_end:
+            params = miso.get_paired_end_sampler_params(2, mean_frag_len, frag_variance, read_len,
+                                                        overhang_len=overhang_len)
+        else:
+            params = miso.get_single_end_sampler_params(2, read_len, overhang_len)
+        sampler = miso.MISOSampler(params, paired_end=bool(paired_end), log_dir=output_dir)
+        written += sampler.run_sampler_batch(num_iters, chunk, num_chains=num_chains,
+                                             burn_in=burn_in, lag=lag, seed=seed,
+                                             first_event_id=first_event_id + lo, verbose=verbose)
+    t2 = time.time()
+    if verbose:
+        print("Collected %d events in %.2f s, sampled in %.2f s"
+              % (len(events), t1 - t0, t2 - t1))
+    if own:
+        bamfile.close()
+    return written, info
+
+
+def read_genes_file(genes_filename):
+    """Two-column, tab-delimited: gene ID, indexed GFF file (run_miso.py:236-250)."""
+    entries = []
+    with open(genes_filename) as genes_in:
+        for line in genes_in:
+            if not line.strip():
+                continue
+            gene_id, gff_filename = line.strip().split("\t")
+            entries.append((gene_id, gff_filename))
+    return entries
+
+
+def main(argv=None):
+    import argparse
+    ap = argparse.ArgumentParser(description="MISO (Mixture of Isoforms model) on MI355X")
+    ap.add_argument("--compute-gene-psi", nargs=4, metavar=("GENE_IDS", "INDEX", "BAM", "OUT"))
+    ap.add_argument("--compute-genes-from-file", nargs=3, metavar=("GENES_FILE", "BAM", "OUT"))
+    ap.add_argument("--paired-end", nargs=2, type=float, metavar=("MEAN", "SD"))
+    ap.add_argument("--read-len", type=int)
+    ap.add_argument("--overhang-len", type=int)
+    ap.add_argument("--event-type", default=None)
+    ap.add_argument("--settings-filename", default=None)
+    ap.add_argument("--device", type=int, default=None, help="HIP device of this process")
+    ap.add_argument("--seed", type=int, default=None)
+    ap.add_argument("--first-event-id", type=int, default=0,
+                    help="global index of this shard's first event (results do not depend on sharding)")
+    a = ap.parse_args(argv)
+    Settings.load(a.settings_filename)
+    if a.read_len is None:
+        print("Error: must provide --read-len.")
+        return 1
+    overhang_len = a.overhang_len if a.overhang_len is not None else 1
+    paired_end = tuple(a.paired_end) if a.paired_end else None
+    if a.compute_genes_from_file:
+        genes_filename, bam_filename, output_dir = (os.path.abspath(os.path.expanduser(p))
+                                                    for p in a.compute_genes_from_file)
+        for p in (genes_filename, bam_filename):
+            if not os.path.isfile(p):
+                print("Error: %s does not exist." % p)
+                return 1
+        entries = read_genes_file(genes_filename)
+        compute_gene_psi(None, None, bam_filename, output_dir, a.read_len, overhang_len,
+                         paired_end=paired_end, event_type=a.event_type, gene_entries=entries,
+                         seed=a.seed, first_event_id=a.first_event_id, device=a.device)
+        print("Processed %d genes" % len(entries))
+    elif a.compute_gene_psi:
+        gene_ids = a.compute_gene_psi[0].split(",")
+        gff_filename, bam_filename, output_dir = (os.path.abspath(os.path.expanduser(p))
+                                                  for p in a.compute_gene_psi[1:])
+        compute_gene_psi(gene_ids, gff_filename, bam_filename, output_dir, a.read_len,
+                         overhang_len, paired_end=paired_end, event_type=a.event_type,
+                         seed=a.seed, first_event_id=a.first_event_id, device=a.device)
+    else:
+        ap.print_help()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,374 @@
+"""Python-3 mirror of misopy/sam_utils.py for the path in front of the sampler.
+
+The reference goes through pysam (third-party, absent here).  `Samfile` below is backed by the
+native reader of libmiso_amd.so (include/miso_alnio.h, csrc/alnio.cpp: BAM/BGZF inflated in
+parallel or SAM text, indexed in memory) and offers what the reference uses of pysam:
+`.references`, `.fetch(chrom, start, end)` and reads with `qname, flag, pos, cigar, rlen,
+is_paired, is_read1, is_read2, is_reverse, is_unmapped, mate_is_unmapped, is_qcfail`.
+
+Two ways to the sampler's inputs:
+  * `sam_parse_reads(reads, ...)` -- the reference's function, line by line, over read objects
+    (sam_utils.py:363-442 with pair_sam_reads :207-300 and read_matches_strand :320-360);
+  * `Samfile.parse_reads(chrom, start, end, ...)` -- the same rules evaluated natively for one
+    event in one call (miso_aln_parse_reads), which is what the batch runner uses.
+`tests/test_frontend.py` checks that the two agree.
+"""
+import ctypes as C
+import os
+from collections import OrderedDict
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.environ.get("MISO_AMD_LIB", os.path.join(_HERE, "libmiso_amd.so"))
+
+STRAND_RULES = {None: 0, "fr-unstranded": 0, "fr-firststrand": 1}
+
+# Global variable containing CIGAR types for conversion (sam_utils.py:303); '=' and 'X' (BAM ops
+# 7, 8) are an IndexError in the reference, here they keep their SAM letters, which the sampler's
+# CIGAR parser accepts (solve.c:249-299)
+CIGAR_TYPES = ('M', 'I', 'D', 'N', 'S', 'H', 'P', '=', 'X')
+
+
+class _Columns(C.Structure):
+    _fields_ = [("n", C.c_int64), ("ref_id", C.POINTER(C.c_int32)), ("pos", C.POINTER(C.c_int32)),
+                ("end", C.POINTER(C.c_int32)), ("flag", C.POINTER(C.c_int32)),
+                ("l_seq", C.POINTER(C.c_int32)), ("cigar_off", C.POINTER(C.c_uint64)),
+                ("cigar", C.POINTER(C.c_uint32)), ("name_off", C.POINTER(C.c_uint64)),
+                ("names", C.POINTER(C.c_char))]
+
+
+_lib = None
+
+
+def _native():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise ImportError("miso_amd: %s is missing -- build it with "
+                              "`python __graft_entry__.py`" % _LIB_PATH)
+        L = C.CDLL(_LIB_PATH)
+        L.miso_aln_last_error.restype = C.c_char_p
+        L.miso_aln_ref_name.restype = C.c_char_p
+        L.miso_aln_ref_name.argtypes = [C.c_void_p, C.c_int]
+        L.miso_aln_ref_length.restype = C.c_int64
+        L.miso_aln_ref_length.argtypes = [C.c_void_p, C.c_int]
+        L.miso_aln_ref_id.argtypes = [C.c_void_p, C.c_char_p]
+        L.miso_aln_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.miso_aln_close.argtypes = [C.c_void_p]
+        L.miso_aln_columns.argtypes = [C.c_void_p, C.POINTER(_Columns)]
+        L.miso_aln_n_refs.argtypes = [C.c_void_p]
+        L.miso_aln_is_bam.argtypes = [C.c_void_p]
+        L.miso_aln_fetch.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p,
+                                     C.c_int64, C.POINTER(C.c_int64)]
+        L.miso_aln_parse_reads.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int,
+                                           C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64,
+                                           C.c_void_p, C.c_int64, C.POINTER(C.c_int64),
+                                           C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        msg = _native().miso_aln_last_error().decode(errors="replace")
+        if rc == 2:
+            raise MemoryError(msg)
+        raise IOError(msg)
+
+
+class AlignedRead(object):
+    """What the reference reads of a pysam.AlignedRead."""
+    __slots__ = ("qname", "flag", "pos", "cigar", "rlen", "aend", "tid")
+
+    def __init__(self, qname, flag, pos, cigar, rlen, aend=None, tid=-1):
+        self.qname, self.flag, self.pos, self.cigar, self.rlen = qname, flag, pos, cigar, rlen
+        self.aend, self.tid = aend, tid
+
+    is_paired = property(lambda self: bool(self.flag & 0x1))
+    is_unmapped = property(lambda self: bool(self.flag & 0x4))
+    mate_is_unmapped = property(lambda self: bool(self.flag & 0x8))
+    is_reverse = property(lambda self: bool(self.flag & 0x10))
+    is_read1 = property(lambda self: bool(self.flag & 0x40))
+    is_read2 = property(lambda self: bool(self.flag & 0x80))
+    is_qcfail = property(lambda self: bool(self.flag & 0x200))
+
+    def __repr__(self):
+        return "AlignedRead(%s, flag=%d, pos=%d, cigar=%s)" % (self.qname, self.flag, self.pos,
+                                                             sam_cigar_to_str(self.cigar))
+
+
+class Samfile(object):
+    """pysam.Samfile as far as misopy uses it (sam_utils.py:139-186), over the native reader."""
+
+    def __init__(self, filename, mode="rb", template=None, threads=0):
+        self.filename = filename
+        self._h = C.c_void_p()
+        _check(_native().miso_aln_open(os.fsencode(filename), int(threads), C.byref(self._h)))
+        L = _native()
+        self.references = tuple(L.miso_aln_ref_name(self._h, i).decode()
+                                for i in range(L.miso_aln_n_refs(self._h)))
+        self.lengths = tuple(L.miso_aln_ref_length(self._h, i) for i in range(len(self.references)))
+        self._ref_index = {name: i for i, name in enumerate(self.references)}
+        cols = _Columns()
+        _check(L.miso_aln_columns(self._h, C.byref(cols)))
+        n = self.mapped_plus_unmapped = int(cols.n)
+
+        def view(ptr, count, dtype):
+            if count == 0:
+                return np.zeros(0, dtype)
+            return np.ctypeslib.as_array(ptr, shape=(count,)).view(dtype)
+        self.ref_id = view(cols.ref_id, n, np.int32)
+        self.pos = view(cols.pos, n, np.int32)
+        self.end = view(cols.end, n, np.int32)
+        self.flag = view(cols.flag, n, np.int32)
+        self.l_seq = view(cols.l_seq, n, np.int32)
+        self.cigar_off = view(cols.cigar_off, n + 1, np.uint64)
+        self.name_off = view(cols.name_off, n + 1, np.uint64)
+        self.cigar = view(cols.cigar, int(self.cigar_off[-1]), np.uint32)
+        self.names = C.string_at(cols.names, int(self.name_off[-1])) if n else b""
+        self.is_bam = bool(L.miso_aln_is_bam(self._h))
+
+    def close(self):
+        if self._h:
+            _native().miso_aln_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return self.mapped_plus_unmapped
+
+    def read(self, i):
+        """Record i (file order) as an AlignedRead."""
+        c0, c1 = int(self.cigar_off[i]), int(self.cigar_off[i + 1])
+        cigar = None if c1 == c0 else [(int(v) & 15, int(v) >> 4) for v in self.cigar[c0:c1]]
+        name = self.names[int(self.name_off[i]):int(self.name_off[i + 1])].decode()
+        return AlignedRead(name, int(self.flag[i]), int(self.pos[i]), cigar, int(self.l_seq[i]),
+                           int(self.end[i]), int(self.ref_id[i]))
+
+    def __iter__(self):
+        return (self.read(i) for i in range(len(self)))
+
+    def gettid(self, chrom):
+        return self._ref_index.get(chrom, -1)
+
+    def fetch_indices(self, chrom, start, end):
+        tid = self.gettid(chrom)
+        if tid < 0:
+            raise ValueError("invalid reference `%s`" % chrom)   # what pysam raises
+        if start > end:
+            raise ValueError("invalid region: start (%d) > end (%d)" % (start, end))
+        n = C.c_int64()
+        L = _native()
+        _check(L.miso_aln_fetch(self._h, tid, start, end, None, 0, C.byref(n)))
+        idx = np.zeros(n.value, np.int64)
+        if n.value:
+            _check(L.miso_aln_fetch(self._h, tid, start, end, idx.ctypes.data, n.value, C.byref(n)))
+        return idx
+
+    def fetch(self, chrom, start, end):
+        """bamfile.fetch(chrom, start, end): reads overlapping the 0-based half-open region."""
+        return [self.read(int(i)) for i in self.fetch_indices(chrom, start, end)]
+
+    def parse_reads(self, chrom, start, end, paired_end=False, strand_rule=None,
+                    target_strand=None, given_read_len=None):
+        """fetch + sam_parse_reads natively: ((positions, cigars), num_reads) of one event."""
+        if strand_rule == "fr-secondstrand":
+            raise Exception("fr-secondstrand currently unsupported.")      # sam_utils.py:331
+        if strand_rule not in STRAND_RULES:
+            raise Exception("Unknown strandedness rule.")                   # sam_utils.py:348, 360
+        rule = STRAND_RULES[strand_rule]
+        tid = self.gettid(chrom)
+        if tid < 0:
+            raise ValueError("invalid reference `%s`" % chrom)
+        ts = ord(target_strand[0]) if target_strand else 0
+        L = _native()
+        n, nb, nd = C.c_int64(), C.c_int64(), C.c_int64()
+        args = (self._h, tid, start, end, 1 if paired_end else 0, rule, ts,
+                int(given_read_len) if given_read_len is not None else 0)
+        _check(L.miso_aln_parse_reads(*args, None, 0, None, 0, C.byref(n), C.byref(nb), C.byref(nd)))
+        npos = n.value * (2 if paired_end else 1)
+        pos = np.zeros(npos, np.int32)
+        buf = C.create_string_buffer(max(nb.value, 1))
+        if npos:
+            _check(L.miso_aln_parse_reads(*args, pos.ctypes.data, npos, buf, nb.value, C.byref(n),
+                                          C.byref(nb), C.byref(nd)))
+        cigars = tuple(buf.raw[:nb.value].decode().split("\0")[:-1]) if nb.value else ()
+        self.last_strand_discarded = nd.value
+        return (tuple(int(p) for p in pos), cigars), int(n.value)
+
+
+def load_bam_reads(bam_filename, template=None):
+    """sam_utils.py:139-150."""
+    print("Loading BAM filename from: %s" % bam_filename)
+    bam_filename = os.path.abspath(os.path.expanduser(bam_filename))
+    return Samfile(bam_filename, "rb", template=template)
+
+
+def resolve_chrom(bamfile, chrom):
+    """sam_utils.py:160-168: drop a leading 'chr' when the file's references do not carry it."""
+    if chrom in bamfile.references:
+        return chrom
+    chrom_parts = chrom.split("chr")
+    return chrom_parts[0] if len(chrom_parts) <= 1 else chrom_parts[1]
+
+
+def fetch_bam_reads_in_gene(bamfile, chrom, start, end, gene=None):
+    """sam_utils.py:153-186."""
+    gene_reads = []
+    chrom = resolve_chrom(bamfile, chrom)
+    try:
+        gene_reads = bamfile.fetch(chrom, start, end)
+    except ValueError:
+        print("Cannot fetch reads in region: %s:%d-%d" % (chrom, start, end))
+    return gene_reads
+
+
+def flag_to_strand(flag):
+    """sam_utils.py:189-196."""
+    return "-" if flag & 16 else "+"
+
+
+def strip_mate_id(read_name):
+    """sam_utils.py:199-213 -- including its off-by-one: THREE characters are dropped."""
+    if read_name.endswith("/1") or read_name.endswith("/2") or \
+       read_name.endswith("#1") or read_name.endswith("#2"):
+        read_name = read_name[0:-3]
+    return read_name
+
+
+def pair_sam_reads(samfile, filter_reads=True, return_unpaired=False, strand_rule=None,
+                   verbose=False):
+    """sam_utils.py:216-300.  Pairs keep the order in which their names first appear (the
+    reference iterates a Python-2 dict: its order is arbitrary)."""
+    paired_reads = OrderedDict()
+    unpaired_reads = {}
+    for read in samfile:
+        curr_name = strip_mate_id(read.qname)
+        if filter_reads:
+            if read.is_qcfail or read.is_unmapped or read.mate_is_unmapped or (not read.is_paired):
+                unpaired_reads[curr_name] = read
+                continue
+        paired_reads.setdefault(curr_name, []).append(read)
+        if len(paired_reads[curr_name]) == 2:
+            if strand_rule == "fr-firststrand":
+                if paired_reads[curr_name][0].is_read1 and paired_reads[curr_name][0].is_reverse:
+                    paired_reads[curr_name] = paired_reads[curr_name][::-1]
+                if paired_reads[curr_name][0].is_read2 and paired_reads[curr_name][0].is_reverse:
+                    paired_reads[curr_name] = paired_reads[curr_name][::-1]
+    to_delete = []
+    num_unpaired = 0
+    num_total = 0
+    for read_name, read in paired_reads.items():
+        if len(read) != 2:
+            unpaired_reads[read_name] = read
+            num_unpaired += 1
+            to_delete.append(read_name)
+            continue
+        left_read, right_read = read[0], read[1]
+        if flag_to_strand(left_read.flag) == flag_to_strand(right_read.flag):
+            to_delete.append(read_name)
+            continue
+        if left_read.pos > right_read.pos and verbose:
+            print("WARNING: %s left mate starts later than right mate" % left_read.qname)
+        num_total += 1
+    for del_key in to_delete:
+        del paired_reads[del_key]
+    if verbose:
+        print("Filtered out %d read pairs that were on same strand." % len(to_delete))
+        print("Filtered out %d reads that had no paired mate." % num_unpaired)
+        print("  - Total read pairs: %d" % num_total)
+    if not return_unpaired:
+        return paired_reads
+    return paired_reads, unpaired_reads
+
+
+def sam_cigar_to_str(sam_cigar):
+    """sam_utils.py:305-322."""
+    cigar_str = ""
+    if sam_cigar is None:
+        return cigar_str
+    for c in sam_cigar:
+        cigar_str += "%d%s" % (c[1], CIGAR_TYPES[c[0]])
+    return cigar_str
+
+
+def read_matches_strand(read, target_strand, strand_rule, paired_end=None):
+    """sam_utils.py:325-370."""
+    if strand_rule == "fr-unstranded":
+        return True
+    if strand_rule == "fr-secondstrand":
+        raise Exception("fr-secondstrand currently unsupported.")
+    matches = False
+    if paired_end is not None:
+        read1, read2 = read
+        if strand_rule == "fr-firststrand":
+            if target_strand == "+":
+                return flag_to_strand(read1.flag) == "+"
+            elif target_strand == "-":
+                return flag_to_strand(read2.flag) == "-"
+            # any other target strand: the reference falls through and returns None
+            return None
+        else:
+            raise Exception("Unknown strandedness rule.")
+    else:
+        if strand_rule == "fr-firststrand":
+            matches = (flag_to_strand(read.flag) == target_strand)
+        else:
+            raise Exception("Unknown strandedness rule.")
+    return matches
+
+
+def sam_parse_reads(samfile, paired_end=False, strand_rule=None, target_strand=None,
+                    given_read_len=None, verbose=False):
+    """sam_utils.py:373-452: (positions, cigar strings) for the sampler + number of reads."""
+    read_positions = []
+    read_cigars = []
+    num_reads = 0
+    check_strand = True
+    if (strand_rule is None) or (strand_rule == "fr-unstranded") or (target_strand is None):
+        check_strand = False
+    num_strand_discarded = 0
+    if paired_end:
+        paired_reads = pair_sam_reads(samfile, strand_rule=strand_rule, verbose=verbose)
+        for read_id, read_info in paired_reads.items():
+            if check_strand:
+                if not read_matches_strand(read_info, target_strand, strand_rule,
+                                           paired_end=paired_end):
+                    num_strand_discarded += 1
+                    continue
+            read1, read2 = read_info
+            if (read1.cigar is None) or (read2.cigar is None):
+                continue
+            if given_read_len is not None:
+                if (read1.rlen != given_read_len) or (read2.rlen != given_read_len):
+                    continue
+            read_positions.append(int(read1.pos))
+            read_positions.append(int(read2.pos))
+            read_cigars.append(sam_cigar_to_str(read1.cigar))
+            read_cigars.append(sam_cigar_to_str(read2.cigar))
+            num_reads += 1
+    else:
+        for read in samfile:
+            if read.cigar is None:
+                continue
+            if given_read_len is not None:
+                if read.rlen != given_read_len:
+                    continue
+            if check_strand:
+                if not read_matches_strand(read, target_strand, strand_rule,
+                                           paired_end=paired_end):
+                    num_strand_discarded += 1
+                    continue
+            read_positions.append(int(read.pos))
+            read_cigars.append(sam_cigar_to_str(read.cigar))
+            num_reads += 1
+    if check_strand and verbose:
+        print("No. reads discarded due to strand violation: %d" % num_strand_discarded)
+    reads = (tuple(read_positions), tuple(read_cigars))
+    return reads, num_reads

@@ -1,0 +1,276 @@
+"""CPU: the front end -- GFF3 -> genes, SAM/BAM -> reads of an event, the
+indexer and the batch collector -- against the reference's own test data set
+(tests/golden/data: misopy/gff-events/mm9/genes/Atp2b1.mm9.gff and
+misopy/test-data/sam-data/c2c12.Atp2b1.sam, the inputs of misopy/test_miso.py:131-171), the
+golden arrays extracted from it (tests/golden/atp2b1.npz) and brute-force restatements."""
+import gzip
+import os
+import random
+
+import numpy as np
+import pytest
+
+from _bam import sam_to_bam
+from _golden import load as load_golden
+
+from miso_amd import gene_utils, gff_utils, index_gff, run_miso, sam_utils
+from miso_amd.settings import Settings
+
+DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "data")
+GFF = os.path.join(DATA, "Atp2b1.mm9.gff")
+
+
+@pytest.fixture(scope="module")
+def sam_text():
+    with gzip.open(os.path.join(DATA, "c2c12.Atp2b1.sam.gz"), "rt") as f:
+        return f.read()
+
+
+@pytest.fixture(scope="module")
+def sam_path(tmp_path_factory, sam_text):
+    p = tmp_path_factory.mktemp("aln") / "c2c12.Atp2b1.sam"
+    p.write_text(sam_text)
+    return str(p)
+
+
+@pytest.fixture(scope="module")
+def bam_path(tmp_path_factory, sam_text):
+    p = str(tmp_path_factory.mktemp("aln") / "c2c12.Atp2b1.bam")
+    sam_to_bam(sam_text, p, block=20000)     # ~60 BGZF blocks: the parallel inflate path
+    return p
+
+
+# ---- GFF -> gene ------------------------------------------------------------------------------
+def test_gene_from_gff_matches_golden_structure():
+    g = load_golden("atp2b1")
+    genes = gene_utils.load_genes_from_gff(GFF, suppress_warnings=True)
+    assert list(genes) == ["ENSMUSG00000019943"]
+    gene = genes["ENSMUSG00000019943"]["gene_object"]
+    assert (gene.chrom, gene.strand) == ("10", "+")
+    assert [iso.label for iso in gene.isoforms] == list(g["mrna_ids"])
+    for iso, idx in zip(gene.isoforms, g["isoform_list"]):
+        want = [g["exon_list"][i] for i in idx]
+        assert [(p.start, p.end) for p in iso.parts] == want
+    # parts = every exon of every transcript, shared exons once per transcript (Gene.py:992-1000)
+    assert len(gene.parts) == sum(len(iso.parts) for iso in gene.isoforms)
+    assert list(gene.iso_lens) == [1364, 4755]
+    tx = gff_utils.get_inclusive_txn_bounds(genes["ENSMUSG00000019943"]["hierarchy"]["ENSMUSG00000019943"])
+    assert tx == (98377804, 98486420)
+
+
+def test_py2c_gene_resolves_shared_exons_to_the_first_equal_part():
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(DATA), "..", "..", "miso_amd"))
+    genes = gene_utils.load_genes_from_gff(GFF, suppress_warnings=True)
+    gene = genes["ENSMUSG00000019943"]["gene_object"]
+    # py2c_gene.py:10-21 semantics without the extension: indices via list.index / Exon.__eq__
+    iso2 = [gene.parts.index(p) for p in gene.isoforms[1].parts]
+    shared = [(p.start, p.end) for p in gene.isoforms[0].parts]
+    for i, p in zip(iso2, gene.isoforms[1].parts):
+        if (p.start, p.end) in shared:
+            assert i < len(gene.isoforms[0].parts)       # points into transcript 1's copy
+        assert (gene.parts[i].start, gene.parts[i].end) == (p.start, p.end)
+
+
+def test_gff_reader_details(tmp_path):
+    p = tmp_path / "t.gff"
+    p.write_text("##gff-version 3\n# comment\n\n"
+                 "chr1\tsrc\tgene\t100\t900\t.\t-\t.\tID=g%201;Name=a,b\n"
+                 "chr1\tsrc\tmRNA\t900\t100\t.\t-\t.\tID=t1;Parent=g%201\n"          # swapped coords
+                 "chr1\tsrc\texon\t100\t200\t.\t-\t.\tParent=t1\n"                     # default exon ID
+                 "chr1\tsrc\texon\t300\t400\t.\t-\t.\tID=e2;Parent=t1;bad\n")
+    db = gff_utils.GFFDatabase(str(p), suppress_warnings=True)
+    assert db.genes[0].get_id() == "g 1" and db.genes[0].attributes["Name"] == ["a", "b"]
+    assert (db.mRNAs[0].start, db.mRNAs[0].end) == (100, 900)
+    assert db.exons[0].get_id() == "t1@100@200@-"
+    genes = gene_utils.load_genes_from_gff(str(p), suppress_warnings=True)
+    gene = genes["g 1"]["gene_object"]
+    assert [p_.label for p_ in gene.parts] == ["t1@100@200@-", "e2"] and gene.strand == "-"
+    with pytest.raises(gff_utils.FormatError):
+        list(gff_utils.Reader(iter(["a\tb\tc\n"])))
+
+
+# ---- SAM / BAM reader -------------------------------------------------------------------------
+def test_sam_reader_matches_golden_arrays(sam_path):
+    g = load_golden("atp2b1")
+    f = sam_utils.Samfile(sam_path)
+    assert not f.is_bam and "10" in f.references and f.lengths[f.gettid("10")] == 129993255
+    (pos, cig), n = f.parse_reads("10", 0, 1 << 30)
+    assert n == len(g["pos"]) == 3589
+    assert np.array_equal(np.asarray(pos) + 1, g["pos"])            # golden positions are 1-based
+    assert list(cig) == [c.decode() for c in g["cigars"]]
+
+
+def test_bam_equals_sam(sam_path, bam_path):
+    a, b = sam_utils.Samfile(sam_path), sam_utils.Samfile(bam_path, threads=4)
+    assert b.is_bam and a.references == b.references and a.lengths == b.lengths
+    for col in ("ref_id", "pos", "end", "flag", "l_seq", "cigar_off", "cigar", "name_off"):
+        assert np.array_equal(getattr(a, col), getattr(b, col)), col
+    assert a.names == b.names
+    r = b.read(5)
+    assert r.cigar is not None and sam_utils.sam_cigar_to_str(r.cigar) and r.rlen == 36
+
+
+def test_fetch_equals_brute_force(bam_path):
+    f = sam_utils.Samfile(bam_path)
+    tid = f.gettid("10")
+    rng = random.Random(3)
+    lo, hi = int(f.pos.min()), int(f.end.max())
+    for _ in range(200):
+        s = rng.randint(lo - 1000, hi + 1000)
+        e = s + rng.choice([0, 1, 50, 5000, 200000])
+        want = np.nonzero((f.ref_id == tid) & (f.pos < e) & (f.end > s))[0]
+        got = f.fetch_indices("10", s, e)
+        assert sorted(got.tolist()) == want.tolist()
+        assert np.all(np.diff(f.pos[got]) >= 0)
+    with pytest.raises(ValueError):
+        f.fetch("nope", 0, 10)
+    assert sam_utils.fetch_bam_reads_in_gene(f, "chr10", lo, lo + 100) != []    # 'chr' stripped
+    assert sam_utils.fetch_bam_reads_in_gene(f, "chrZ", 0, 10) == []
+
+
+def test_unsorted_input_and_corrupt_files(tmp_path, sam_text):
+    lines = sam_text.splitlines()
+    head = [l for l in lines if l.startswith("@")]
+    body = [l for l in lines if not l.startswith("@")]
+    random.Random(1).shuffle(body)
+    p = tmp_path / "shuffled.bam"
+    sam_to_bam("\n".join(head + body) + "\n", str(p), block=7000)
+    f = sam_utils.Samfile(str(p))
+    (pos, cig), n = f.parse_reads("10", 98377804, 98486420)
+    assert n > 3000 and list(pos) == sorted(pos)
+    raw = p.read_bytes()
+    bad = tmp_path / "bad.bam"
+    bad.write_bytes(raw[:len(raw) // 2])
+    with pytest.raises(IOError):
+        sam_utils.Samfile(str(bad))
+    bad.write_bytes(raw[:100] + bytes(50) + raw[150:])
+    with pytest.raises(IOError):
+        sam_utils.Samfile(str(bad))
+    with pytest.raises(IOError):
+        sam_utils.Samfile(str(tmp_path / "missing.bam"))
+    bad.write_text("r1\t0\tchr1\t5\n")
+    with pytest.raises(IOError):
+        sam_utils.Samfile(str(bad))
+    empty = tmp_path / "empty.sam"
+    empty.write_text("@SQ\tSN:chr1\tLN:100\n")
+    e = sam_utils.Samfile(str(empty))
+    assert len(e) == 0 and e.parse_reads("chr1", 0, 100) == (((), ()), 0)
+
+
+# ---- read filters, pairing, strand rules: native path vs the line-by-line mirror ---------------
+def synthetic_pairs(seed, n=300):
+    rng = random.Random(seed)
+    lines = ["@SQ\tSN:chr1\tLN:100000"]
+    for i in range(n):
+        name = "r%d" % i
+        p1 = rng.randint(100, 5000)
+        p2 = p1 + rng.randint(0, 400)
+        rev1 = rng.random() < 0.5
+        rev2 = (not rev1) if rng.random() < 0.9 else rev1                 # some same-strand pairs
+        first_is_1 = rng.random() < 0.5
+        f1 = 0x1 | (0x10 if rev1 else 0) | (0x20 if rev2 else 0) | (0x40 if first_is_1 else 0x80)
+        f2 = 0x1 | (0x10 if rev2 else 0) | (0x20 if rev1 else 0) | (0x80 if first_is_1 else 0x40)
+        kind = rng.random()
+        if kind < 0.05:
+            f1 |= 0x200                                                   # QC fail
+        elif kind < 0.10:
+            f2 |= 0x8                                                     # mate unmapped
+        elif kind < 0.15:
+            f1 &= ~0x1                                                    # not paired
+        suffix = rng.choice([("", ""), ("/1", "/2"), ("#1", "#2")])
+        l1 = 36 if rng.random() < 0.9 else 30
+        cig1 = "%dM" % l1 if rng.random() < 0.8 else "10M200N%dM" % (l1 - 10)
+        cig2 = "36M" if rng.random() < 0.95 else "*"
+        recs = [(name + suffix[0], f1, p1, cig1, l1), (name + suffix[1], f2, p2, cig2, 36)]
+        if kind > 0.95:
+            recs.append((name + suffix[0], f1, p1 + 3, cig1, l1))         # a third alignment
+        if kind > 0.90 and kind <= 0.95:
+            recs = recs[:1]                                               # mate missing
+        for nm, fl, ps, cg, ln in recs:
+            lines.append("\t".join([nm, str(fl), "chr1", str(ps), "255", cg, "=", "1", "0",
+                                    "A" * ln, "I" * ln]))
+    return "\n".join(lines) + "\n"
+
+
+@pytest.mark.parametrize("paired", [False, True])
+@pytest.mark.parametrize("rule,target", [(None, None), ("fr-unstranded", "+"), ("fr-firststrand", "+"),
+                                         ("fr-firststrand", "-"), ("fr-firststrand", None),
+                                         ("fr-firststrand", "?")])
+@pytest.mark.parametrize("rlen", [None, 36])
+def test_native_parse_reads_equals_reference_logic(tmp_path, paired, rule, target, rlen):
+    p = tmp_path / "pairs.sam"
+    p.write_text(synthetic_pairs(11))
+    f = sam_utils.Samfile(str(p))
+    paired = (250, 30) if paired else None       # what run_miso.py passes: None or (mean, sd)
+    for (s, e) in [(4990, 5001), (1000, 3000), (0, 100000)]:
+        native, n_native = f.parse_reads("chr1", s, e, paired_end=paired, strand_rule=rule,
+                                         target_strand=target, given_read_len=rlen)
+        mirror, n_mirror = sam_utils.sam_parse_reads(f.fetch("chr1", s, e), paired_end=paired,
+                                                     strand_rule=rule, target_strand=target,
+                                                     given_read_len=rlen)
+        assert n_native == n_mirror
+        assert native == mirror
+    assert n_native > 0 or target == "?"
+
+
+def test_strand_rules_of_the_reference_test_suite():
+    """misopy/test_miso.py:80-127 (test_strandedness), same assertions."""
+    f_read = sam_utils.AlignedRead("f", 0, 0, [(0, 36)], 36)
+    r_read = sam_utils.AlignedRead("r", 16, 0, [(0, 36)], 36)
+    m = sam_utils.read_matches_strand
+    for read in (f_read, r_read):
+        for target in "+-":
+            assert m(read, target, "fr-unstranded") is True
+    assert m(f_read, "+", "fr-firststrand") is True
+    assert m(f_read, "-", "fr-firststrand") is False
+    assert m(r_read, "+", "fr-firststrand") is False
+    assert m(r_read, "-", "fr-firststrand") is True
+    pe = (300, 10)
+    assert m((f_read, r_read), "+", "fr-firststrand", paired_end=pe) is True
+    assert m((f_read, r_read), "-", "fr-firststrand", paired_end=pe) is True
+    with pytest.raises(Exception):
+        m(f_read, "+", "fr-secondstrand")
+    assert sam_utils.strip_mate_id("read7/1") == "read" and sam_utils.strip_mate_id("read7") == "read7"
+    assert sam_utils.flag_to_strand(16) == "-" and sam_utils.flag_to_strand(99) == "+"
+
+
+# ---- index + collector ---------------------------------------------------------------------------
+def test_index_and_collect(tmp_path, bam_path):
+    idx = str(tmp_path / "indexed")
+    index_gff.index_gff(GFF, idx)
+    pick = os.path.join(idx, "chr10", "ENSMUSG00000019943.pickle")
+    assert os.path.isfile(pick) and os.path.isfile(os.path.join(idx, "genes.gff"))
+    m = gff_utils.get_gene_ids_to_gff_index(idx)
+    assert list(m.items()) == [("ENSMUSG00000019943", pick)]
+    os.remove(os.path.join(idx, gff_utils.INDEX_MAP_BASENAME))          # directory-scan fallback
+    assert dict(gff_utils.get_gene_ids_to_gff_index(idx)) == dict(m)
+    index_gff.index_gff(GFF, idx)                                         # already indexed: no-op
+    Settings.load(None)
+    bam = sam_utils.Samfile(bam_path)
+    out = str(tmp_path / "out")
+    events, info = run_miso.collect_gene_events(m.items(), bam, out, 36, 1, verbose=False)
+    assert len(events) == 1 and info["ENSMUSG00000019943"].endswith("reads")
+    (pos, cig), gene, fname = events[0]
+    assert fname == os.path.join(out, "10", "ENSMUSG00000019943") and len(pos) == len(cig) > 3000
+    assert gene.label == "ENSMUSG00000019943"
+    # the read-length and minimum-read filters of run_miso.py:110-115, 139-147
+    assert run_miso.collect_gene_events(m.items(), bam, out, 5000, 1, verbose=False)[0] == []
+    ev, info = run_miso.collect_gene_events(m.items(), bam, out, 40, 1, verbose=False)
+    assert ev == [] and info["ENSMUSG00000019943"] == "only 0 reads"
+    c = index_gff.compress_event_name("ENSMUSG00000019943")
+    assert c.startswith("misocomp_") and c == index_gff.compress_event_name("ENSMUSG00000019943")
+
+
+def test_settings(tmp_path):
+    Settings.load(None)
+    assert Settings.get_sampler_params() == {"num_chains": 6, "burn_in": 500, "lag": 10, "num_iters": 5000}
+    assert Settings.get_min_event_reads() == 20 and Settings.get_strand_param() == "fr-unstranded"
+    p = tmp_path / "s.txt"
+    p.write_text("[data]\nfilter_results = True\nmin_event_reads = 5\nstrand = fr-firststrand\n"
+                 "[cluster]\ncluster_command = long\n[sampler]\nburn_in = 10\nlag = 2\nnum_iters = 100\n")
+    Settings.load(str(p))
+    assert Settings.get_sampler_params() == {"num_chains": 6, "burn_in": 10, "lag": 2, "num_iters": 100}
+    assert Settings.get_min_event_reads() == 5 and Settings.get_strand_param() == "fr-firststrand"
+    assert Settings.get()["cluster_command"] == "long"
+    Settings.load(None)
