@@ -46,7 +46,7 @@ def sam_to_bam(sam_text, bam_path, block=20000):
             recs.append(line.split("\t"))
     rid = {n: i for i, (n, _) in enumerate(refs)}
     text = ("\n".join(header) + "\n").encode()
-    raw = b"BAM\x01" + struct.pack("<i", len(text)) + text + struct.pack("<i", len(refs))
+    raw = bytearray(b"BAM\x01") + struct.pack("<i", len(text)) + text + struct.pack("<i", len(refs))
     for n, ln in refs:
         raw += struct.pack("<i", len(n) + 1) + n.encode() + b"\0" + struct.pack("<i", ln)
     for f in recs:
@@ -65,5 +65,5 @@ def sam_to_bam(sam_text, bam_path, block=20000):
         raw += struct.pack("<i", len(body)) + body
     with open(bam_path, "wb") as out:
         for i in range(0, len(raw), block):
-            out.write(bgzf_block(raw[i:i + block]))
+            out.write(bgzf_block(bytes(raw[i:i + block])))
         out.write(bgzf_block(b""))   # EOF marker block
