@@ -50,6 +50,15 @@
 
 typedef struct { uint32_t v[4]; } miso_u32x4;
 
+/* a ^ b ^ c.  gfx950 has no v_xor3_b32 but a three-input boolean op, v_bitop3_b32 (truth table
+ * 0x96 = parity); hipcc does not form it from two xors, and Philox spends 4 xors per round next to
+ * 2 multiplies, so the device code asks for it by name.  Same bits everywhere. */
+#if defined(__HIP_DEVICE_COMPILE__) && defined(__gfx950__)
+#define MISO_XOR3(a, b, c) __builtin_amdgcn_bitop3_b32((a), (b), (c), 0x96)
+#else
+#define MISO_XOR3(a, b, c) ((a) ^ (b) ^ (c))
+#endif
+
 MISO_HD miso_u32x4 miso_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                       uint32_t k0, uint32_t k1) {
   miso_u32x4 out;
@@ -60,8 +69,8 @@ MISO_HD miso_u32x4 miso_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uin
   for (r = 0; r < 10; r++) {
     uint64_t p0 = (uint64_t) MISO_PHILOX_M0 * c0;
     uint64_t p1 = (uint64_t) MISO_PHILOX_M1 * c2;
-    uint32_t n0 = (uint32_t) (p1 >> 32) ^ c1 ^ k0;
-    uint32_t n2 = (uint32_t) (p0 >> 32) ^ c3 ^ k1;
+    uint32_t n0 = MISO_XOR3((uint32_t) (p1 >> 32), c1, k0);
+    uint32_t n2 = MISO_XOR3((uint32_t) (p0 >> 32), c3, k1);
     c1 = (uint32_t) p1;
     c3 = (uint32_t) p0;
     c0 = n0;

@@ -33,8 +33,8 @@ __device__ __forceinline__ miso_u32x4 philox_gibbs(const GibbsRng &g, uint32_t q
   for (int r = 1; r < 10; r++) {
     const uint64_t a = static_cast<uint64_t>(MISO_PHILOX_M0) * c0;
     const uint64_t b = static_cast<uint64_t>(MISO_PHILOX_M1) * c2;
-    const uint32_t n0 = static_cast<uint32_t>(b >> 32) ^ c1 ^ k0;
-    const uint32_t n2 = static_cast<uint32_t>(a >> 32) ^ c3 ^ k1;
+    const uint32_t n0 = MISO_XOR3(static_cast<uint32_t>(b >> 32), c1, k0);
+    const uint32_t n2 = MISO_XOR3(static_cast<uint32_t>(a >> 32), c3, k1);
     c1 = static_cast<uint32_t>(b); c3 = static_cast<uint32_t>(a); c0 = n0; c2 = n2;
     k0 += MISO_PHILOX_W0; k1 += MISO_PHILOX_W1;
   }
