@@ -40,8 +40,10 @@ struct miso_batch {
     int kmax = 2, maxq = 1;       // most isoforms, most draw quads
     int maxcls = 0;               // most drawing-read classes (single-end)
     bool nocls = false;           // some single-end event has no class table (> MAX_DRAW_CLASSES classes)
+    int tuned_G = 0;              // lanes per chain picked by the first launch's trial runs
   };
   std::vector<GenRun> gen_runs;
+  int tuned_k2_G = 0;             // ditto for the two-isoform kernel
   // device_match: events whose compatibility is still to be computed (kernels_match.hip)
   struct Pending {
     int event = 0;               // index into `events` (a placeholder until resolved)

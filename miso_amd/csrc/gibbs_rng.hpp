@@ -24,11 +24,18 @@ __device__ __forceinline__ GibbsRng gibbs_rng_init(uint64_t seed, uint32_t event
 }
 
 // per iteration: n0_round0 = g.p1hi ^ iter ^ g.k0
+// REKEY: the nine round keys are wave-uniform, so hipcc hoists all 18 into SGPRs; in the register-
+// heavy general kernel they are then spilled to VGPR lanes and fetched back with a v_readlane + s_nop
+// per round INSIDE the read loop.  An opaque copy of the key makes them loop-variant: they are
+// rebuilt per block with scalar adds, which issue beside the vector work.
+template <bool REKEY = false>
 __device__ __forceinline__ miso_u32x4 philox_gibbs(const GibbsRng &g, uint32_t q, uint32_t n0_round0) {
   const uint64_t p0 = static_cast<uint64_t>(MISO_PHILOX_M0) * q;
   uint32_t c0 = n0_round0, c1 = g.p1lo, c2 = static_cast<uint32_t>(p0 >> 32) ^ g.c3k1,
            c3 = static_cast<uint32_t>(p0);
-  uint32_t k0 = g.k0 + MISO_PHILOX_W0, k1 = g.k1 + MISO_PHILOX_W1;
+  uint32_t gk0 = g.k0, gk1 = g.k1;
+  if (REKEY) asm volatile("" : "+s"(gk0), "+s"(gk1));
+  uint32_t k0 = gk0 + MISO_PHILOX_W0, k1 = gk1 + MISO_PHILOX_W1;
 #pragma unroll
   for (int r = 1; r < 10; r++) {
     const uint64_t a = static_cast<uint64_t>(MISO_PHILOX_M0) * c0;

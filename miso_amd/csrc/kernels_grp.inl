@@ -46,6 +46,10 @@
 #define GPROF_ADD(acc, t0, t1)
 #endif
 
+#ifndef MISO_GRP_ILP_MAX_TW
+#define MISO_GRP_ILP_MAX_TW 3   // single-end class path: two Philox blocks in flight per lane up to K = 4 (measured: +3% at K=3, a loss from K=5)
+#endif
+
 namespace miso {
 
 namespace {
@@ -163,24 +167,28 @@ template <bool LE> __device__ __forceinline__ uint64_t draw_threshold(double c, 
 // in registers and counts D[k] += (word < T[k]): isoform-indexed, so nothing is flushed when the
 // class changes; the next class's row is prefetched while the current one is being consumed.
 // TW = the wavefront's K - 1, rounded up to an instantiated value.
-template <int TW, int G>
-__device__ __forceinline__ void class_units(const uint32_t *ctab, const uint32_t *thr, int tw, int ncls,
-                                            int nuw, int n_units, int sub, const GibbsRng &rng,
-                                            uint32_t n0r0, int (&D)[TW]) {
+// One strided walk over a chain's work units: the class the current unit belongs to, that class's
+// thresholds in registers, and the next class's row prefetched.
+template <int TW> struct UnitWalker {
   uint32_t T[TW], NT[TW];
+  int cur, ust, uend, qd;
+  uint32_t hmtm;
+  int n_ust, n_uend, n_qd;
+  uint32_t n_hm;
+
+  __device__ __forceinline__ void init(const uint32_t *ctab, const uint32_t *thr, int tw) {
 #pragma unroll
-  for (int j = 0; j < TW; j++) { T[j] = 0; D[j] = 0; NT[j] = (j < tw) ? thr[j] : 0u; }
-  int cur = -1, ust = 0, uend = 0, qd = 0;
-  uint32_t hmtm = 0xFFu;
-  int n_ust = static_cast<int>(ctab[1]), n_uend = static_cast<int>(ctab[CLS_WORDS + 1]),
-      n_qd = static_cast<int>(ctab[2]);
-  uint32_t n_hm = ctab[3];
-  for (int i0 = 0; i0 < nuw; i0 += G) {
-    const int i = i0 + sub;
-    const bool active = i < n_units;
+    for (int j = 0; j < TW; j++) { T[j] = 0; NT[j] = (j < tw) ? thr[j] : 0u; }
+    cur = -1; ust = 0; uend = 0; qd = 0; hmtm = 0xFFu;
+    n_ust = static_cast<int>(ctab[1]); n_uend = static_cast<int>(ctab[CLS_WORDS + 1]);
+    n_qd = static_cast<int>(ctab[2]); n_hm = ctab[3];
+  }
+  // make unit i the current one (i only grows); returns the word mask of the unit
+  __device__ __forceinline__ uint32_t seek(const uint32_t *ctab, const uint32_t *thr, int tw, int ncls,
+                                           int i, bool active) {
     if (active && i >= uend) {
       cur++;
-      if (i >= n_uend) {   // the lane's stride jumped over whole classes (classes of fewer than G units)
+      if (i >= n_uend) {   // the stride jumped over whole classes (classes of fewer units than the stride)
         do { cur++; n_uend = static_cast<int>(ctab[CLS_WORDS * (cur + 1) + 1]); } while (i >= n_uend);
         n_ust = static_cast<int>(ctab[CLS_WORDS * cur + 1]);
         n_qd = static_cast<int>(ctab[CLS_WORDS * cur + 2]);
@@ -202,7 +210,9 @@ __device__ __forceinline__ void class_units(const uint32_t *ctab, const uint32_t
     uint32_t wm = active ? 0xFu : 0u;
     if (i == ust) wm &= hmtm;
     if (i == uend - 1) wm &= hmtm >> 4;
-    const miso_u32x4 u = philox_gibbs(rng, static_cast<uint32_t>(active ? i - qd : 0), n0r0);
+    return wm;
+  }
+  __device__ __forceinline__ void count(const miso_u32x4 &u, uint32_t wm, int (&D)[TW]) const {
 #pragma unroll
     for (int w = 0; w < 4; w++) {
       const uint32_t uw = ((wm >> w) & 1u) ? u.v[w] : 0xFFFFFFFFu;   // never below a 32-bit threshold
@@ -210,6 +220,41 @@ __device__ __forceinline__ void class_units(const uint32_t *ctab, const uint32_t
       for (int j = 0; j < TW; j++) D[j] += (uw < T[j]) ? 1 : 0;
     }
   }
+};
+
+// NW walkers per lane (units sub + G (NW m + w), m = 0, 1, ..): NW independent Philox blocks are in
+// flight per trip.  One block's nine dependent rounds leave the multiplier idle between rounds and a
+// batch of 40 000 chains only gives ~2.4 wavefronts per SIMD to fill the gaps, so for small K (few
+// compares per word) a second block per lane is what hides the latency; for large K the TW
+// compare-adds per word already do and the second walker's registers are not worth it.
+template <int TW, int G, int NW>
+__device__ __forceinline__ void class_units_nw(const uint32_t *ctab, const uint32_t *thr, int tw, int ncls,
+                                               int nuw, int n_units, int sub, const GibbsRng &rng,
+                                               uint32_t n0r0, int (&D)[TW]) {
+  UnitWalker<TW> W[NW];
+#pragma unroll
+  for (int w = 0; w < NW; w++) W[w].init(ctab, thr, tw);
+#pragma unroll
+  for (int j = 0; j < TW; j++) D[j] = 0;
+  for (int i0 = 0; i0 < nuw; i0 += NW * G) {
+    uint32_t wm[NW]; miso_u32x4 u[NW];
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+      const int i = i0 + w * G + sub;
+      const bool active = i < n_units;
+      wm[w] = W[w].seek(ctab, thr, tw, ncls, i, active);
+      u[w] = philox_gibbs<true>(rng, static_cast<uint32_t>(active ? i - W[w].qd : 0), n0r0);
+    }
+#pragma unroll
+    for (int w = 0; w < NW; w++) W[w].count(u[w], wm[w], D);
+  }
+}
+
+template <int TW, int G>
+__device__ __forceinline__ void class_units(const uint32_t *ctab, const uint32_t *thr, int tw, int ncls,
+                                            int nuw, int n_units, int sub, const GibbsRng &rng,
+                                            uint32_t n0r0, int (&D)[TW]) {
+  class_units_nw<TW, G, (TW <= MISO_GRP_ILP_MAX_TW) ? 2 : 1>(ctab, thr, tw, ncls, nuw, n_units, sub, rng, n0r0, D);
 }
 
 // The paired-end read loop when every chain of the wavefront has exactly KK isoforms.  A lane takes
@@ -244,7 +289,7 @@ __device__ __forceinline__ void pe_quads(const uint16_t *frags, const double *ps
 #pragma unroll
       for (int i = 0; i < ND; i++) nxt[i] = (qn < n_quads) ? fq[static_cast<size_t>(qn) * ND + i] : 0xFFFFFFFFu;
     }
-    const miso_u32x4 u = philox_gibbs(rng, static_cast<uint32_t>(q), n0r0);
+    const miso_u32x4 u = philox_gibbs<true>(rng, static_cast<uint32_t>(q), n0r0);
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       uint32_t fr[KK]; double w[KK]; bool val[KK];
@@ -282,7 +327,10 @@ __device__ __forceinline__ void pe_quads(const uint16_t *frags, const double *ps
 }  // namespace
 
 template <int G, bool PE, int KC>
-__global__ __launch_bounds__(256, 2) void sampler_grp(const KernelArgs a) {
+#ifndef MISO_GRP_MINBLOCKS
+#define MISO_GRP_MINBLOCKS 3   // measured: K=3 89.7k -> 114.4k events/s going from 2 to 3 (register budget 168)
+#endif
+__global__ __launch_bounds__(256, KC <= 8 ? MISO_GRP_MINBLOCKS : 2) void sampler_grp(const KernelArgs a) {
   constexpr int KLO = KC == 4 ? 3 : (KC == 8 ? 5 : (KC == 12 ? 9 : (KC == 16 ? 13 : 17)));   // the class holds K in [KLO, KC]
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int CPW = 64 / G;

@@ -309,7 +309,7 @@ void miso_batch::upload(int dev) {
   // the general kernel's wavefronts loop to their largest K and longest draw list: group alike
   std::stable_sort(gen.begin(), gen.end(), [&](int x, int y) {
     return events[x].K != events[y].K ? events[x].K > events[y].K : events[x].n_draw > events[y].n_draw; });
-  gen_runs.clear();
+  gen_runs.clear(); tuned_k2_G = 0;
   for (size_t j = 0; j < gen.size(); j++) {
     const PackedEvent &e = events[gen[j]];
     const int kc = e.K <= 4 ? 4 : (e.K <= 8 ? 8 : (e.K <= 12 ? 12 : (e.K <= 16 ? 16 : 32)));
@@ -345,28 +345,22 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   a.C = p.noChains; a.M = p.noIterations; a.B = p.noBurnIn; a.lag = p.noLag;
   a.start = p.start; a.first_event_id = first_event_id; a.seed = seed;
   HIP_OK(hipMemsetAsync(d_out, 0, out_bytes, stream));  // trailing sample columns stay 0 (miso.c:661)
-  HIP_OK(hipEventRecord(ev0, stream));                  // events bracket the sampler kernel only
   lanes_per_chain = 0;
   last_kernels.clear();
-  if (n_k2 > 0) {
+
+  // ---- two-isoform events: sampler_k2<G> ----
+  const size_t k2_fp = p.paired ? align_up(fd.prob.size() * 8, 16) : 0;
+  const size_t k2_tab = p.paired ? 2 * fd.prob.size() * 4 : 0;   // per chain: int32[2 x il]
+  auto launch_k2 = [&](KernelArgs ka, int G) {
     const long chains = static_cast<long>(n_k2) * p.noChains;
-    const int maxq = (events[k2_first_event()].n_draw + 3) / 4;
-    int G = 0;
-    if (const char *env = std::getenv("MISO_LANES_PER_CHAIN")) G = std::atoi(env);
-    const size_t k2_fp = p.paired ? align_up(fd.prob.size() * 8, 16) : 0;
-    const size_t k2_tab = p.paired ? 2 * fd.prob.size() * 4 : 0;   // per chain: int32[2 x il]
-    const int max_cpw = p.paired ? std::max<int>(1, static_cast<int>((60 * 1024 - k2_fp) / (4 * k2_tab))) : 64;
-    if (!G) G = choose_lanes_per_chain(chains, maxq, wave_slots, max_cpw);
-    lanes_per_chain = G;
-    last_kernels = "sampler_k2<" + std::to_string(G) + (p.paired ? ", true>" : ", false>");
-    a.slot_event = d_slots; a.n_slots = n_k2;
+    ka.slot_event = d_slots; ka.n_slots = n_k2;
     const int cpw = 64 / std::max(G, 1);
     const unsigned grid = static_cast<unsigned>(((chains + cpw - 1) / cpw + 3) / 4);
     const size_t k2_lds = k2_fp + 4 * static_cast<size_t>(cpw) * k2_tab;
 #define MISO_K2_LAUNCH(GG)                                                                           \
   case GG:                                                                                          \
-    if (p.paired) hipLaunchKernelGGL((sampler_k2<GG, true>), dim3(grid), dim3(256), k2_lds, stream, a); \
-    else hipLaunchKernelGGL((sampler_k2<GG, false>), dim3(grid), dim3(256), 0, stream, a);           \
+    if (p.paired) hipLaunchKernelGGL((sampler_k2<GG, true>), dim3(grid), dim3(256), k2_lds, stream, ka); \
+    else hipLaunchKernelGGL((sampler_k2<GG, false>), dim3(grid), dim3(256), 0, stream, ka);           \
     break;
     switch (G) {
       MISO_K2_LAUNCH(1) MISO_K2_LAUNCH(2) MISO_K2_LAUNCH(3) MISO_K2_LAUNCH(4) MISO_K2_LAUNCH(5)
@@ -376,72 +370,51 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     }
 #undef MISO_K2_LAUNCH
     HIP_OK(hipGetLastError());
-  }
-  for (const GenRun &run : gen_runs) {
-    a.slot_event = d_slots + n_k2 + run.first; a.n_slots = run.count;
-    const int gen_kmax = run.kmax, gen_maxq = run.maxq;
-    const long chains = static_cast<long>(run.count) * p.noChains;
-    const size_t fp_bytes = p.paired ? align_up(fd.prob.size() * 8, 16) : 0;
-    // a workgroup may use half of the CU's 160 KB of LDS (two workgroups per CU)
-    constexpr size_t LDS_MAX = 80 * 1024;
+  };
+
+  // ---- more than two isoforms: sampler_grp<G, PE, KC> per isoform-count class ----
+  // a workgroup may use half of the CU's 160 KB of LDS (two workgroups per CU)
+  constexpr size_t LDS_MAX = 80 * 1024;
+  const size_t fp_bytes = p.paired ? align_up(fd.prob.size() * 8, 16) : 0;
+  struct GrpShape { int qs, ts; };
+  auto grp_shape = [&](const GenRun &run) {
     // single-end: per-class thresholds join the slice (class path) when every event has a class
     // table; MISO_NO_CLASS_PATH=1 (tests): force the direct mask path of sampler_grp
     const bool no_cls = std::getenv("MISO_NO_CLASS_PATH") != nullptr;
     int qs = (!p.paired && !no_cls && !run.nocls && run.maxcls > 0) ? run.maxcls : 0;
-    if (qs && 4 * 2 * static_cast<size_t>(grp_slice_bytes(gen_kmax, qs, 0)) > LDS_MAX) qs = 0;
+    if (qs && 4 * 2 * static_cast<size_t>(grp_slice_bytes(run.kmax, qs, 0)) > LDS_MAX) qs = 0;
     // paired-end: the per-event score table (K x il int32) joins the slice when >= 4 chains still fit
-    int ts = p.paired ? gen_kmax * static_cast<int>(fd.prob.size()) : 0;
-    if (ts && fp_bytes + 4 * 4 * static_cast<size_t>(grp_slice_bytes(gen_kmax, 0, ts)) > LDS_MAX) ts = 0;
-    // lanes per chain: bounded by the LDS a workgroup's chains need
-    int G = 64;
-    const char *env = std::getenv("MISO_GENERAL_LANES");
-    if (env) {
-      G = std::atoi(env);
-    } else {
-      // single-end: the per-iteration scalar step costs the same per wavefront whatever G is, so
-      // pack as many chains per wavefront as still fills the device: the smallest G whose
-      // wavefronts occupy every resident slot; a batch too small for that takes the largest G.
-      // paired-end: the read loop waits on memory and more wavefronts hide it: largest G up to 16.
-      bool found = false;
-      for (int g : {2, 4, 8, 16, 32}) {
-        if (p.paired && g > 16 && found) break;
-        const int cpw = 64 / g;
-        const size_t lds = fp_bytes + 4 * static_cast<size_t>(cpw) * grp_slice_bytes(gen_kmax, qs, ts);
-        if (lds > LDS_MAX) continue;
-        if (!found || g <= std::max(2, gen_maxq)) G = g;
-        found = true;
-        if (!p.paired && (chains + cpw - 1) / cpw >= wave_slots) break;
-      }
-    }
-    // a forced (or odd) choice never exceeds the LDS budget: fewer chains per wavefront instead
-    while (G < 64 && (G < 2 || (G & (G - 1)) ||
-                      fp_bytes + 4 * static_cast<size_t>(64 / G) * grp_slice_bytes(gen_kmax, qs, ts) > LDS_MAX))
-      G = (G < 2) ? 2 : ((G & (G - 1)) ? 64 : G * 2);
-    a.kstride = gen_kmax; a.cstride = qs; a.tstride = ts;
-    last_kernels += std::string(last_kernels.empty() ? "" : ",") +
-                    (G == 64 ? std::string("sampler_wave<")
-                             : "sampler_grp<" + std::to_string(G) + ", ") +
-                    (p.paired ? "true" : "false") +
-                    (G == 64 ? std::string(">") : ", " + std::to_string(run.kc) + ">");
+    int ts = p.paired ? run.kmax * static_cast<int>(fd.prob.size()) : 0;
+    if (ts && fp_bytes + 4 * 4 * static_cast<size_t>(grp_slice_bytes(run.kmax, 0, ts)) > LDS_MAX) ts = 0;
+    return GrpShape{qs, ts};
+  };
+  auto grp_fits = [&](const GenRun &run, const GrpShape &sh, int G) {
+    return G >= 2 && G <= 32 && !(G & (G - 1)) &&
+           fp_bytes + 4 * static_cast<size_t>(64 / G) * grp_slice_bytes(run.kmax, sh.qs, sh.ts) <= LDS_MAX;
+  };
+  auto launch_grp = [&](KernelArgs ka, const GenRun &run, const GrpShape &sh, int G) {
+    const long chains = static_cast<long>(run.count) * p.noChains;
+    ka.slot_event = d_slots + n_k2 + run.first; ka.n_slots = run.count;
+    ka.kstride = run.kmax; ka.cstride = sh.qs; ka.tstride = sh.ts;
     if (G == 64) {
       const unsigned grid = static_cast<unsigned>((chains + 3) / 4);
       const size_t lds = fp_bytes + 4 * 32 * sizeof(int);
-      if (p.paired) hipLaunchKernelGGL(sampler_wave<true>, dim3(grid), dim3(256), lds, stream, a);
-      else hipLaunchKernelGGL(sampler_wave<false>, dim3(grid), dim3(256), lds, stream, a);
+      if (p.paired) hipLaunchKernelGGL(sampler_wave<true>, dim3(grid), dim3(256), lds, stream, ka);
+      else hipLaunchKernelGGL(sampler_wave<false>, dim3(grid), dim3(256), lds, stream, ka);
     } else {
       const int cpw = 64 / G;
       const unsigned grid = static_cast<unsigned>(((chains + cpw - 1) / cpw + 3) / 4);
-      const size_t lds = fp_bytes + 4 * static_cast<size_t>(cpw) * grp_slice_bytes(gen_kmax, qs, ts);
+      const size_t lds = fp_bytes + 4 * static_cast<size_t>(cpw) * grp_slice_bytes(run.kmax, sh.qs, sh.ts);
 #define MISO_GRP_LAUNCH_K(GG, KC)                                                                          \
   {                                                                                                        \
     if (p.paired) {                                                                                        \
       HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sampler_grp<GG, true, KC>),               \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));      \
-      hipLaunchKernelGGL((sampler_grp<GG, true, KC>), dim3(grid), dim3(256), lds, stream, a);              \
+      hipLaunchKernelGGL((sampler_grp<GG, true, KC>), dim3(grid), dim3(256), lds, stream, ka);             \
     } else {                                                                                               \
       HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sampler_grp<GG, false, KC>),              \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));      \
-      hipLaunchKernelGGL((sampler_grp<GG, false, KC>), dim3(grid), dim3(256), lds, stream, a);             \
+      hipLaunchKernelGGL((sampler_grp<GG, false, KC>), dim3(grid), dim3(256), lds, stream, ka);            \
     }                                                                                                      \
   }
 #define MISO_GRP_LAUNCH(GG)                                    \
@@ -462,6 +435,117 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
 #undef MISO_GRP_LAUNCH_K
     }
     HIP_OK(hipGetLastError());
+  };
+
+  // Lanes per chain, measured: the best split depends on how the batch's wavefronts fill the SIMDs
+  // (chains, isoforms, reads, LDS per workgroup), so the first launch of a large single-end batch
+  // with more than two isoforms times a few iterations of the rule of thumb's choice and of the next
+  // larger ones on the batch itself and keeps the fastest (K=5: 58k -> 81k events/s) (the trial launches record nothing: burn-in = their length; what they leave in the
+  // output pool is rewritten by the real launch).  MISO_NO_AUTOTUNE=1 keeps the rule of thumb.
+  const bool tune = std::getenv("MISO_NO_AUTOTUNE") == nullptr && p.noIterations >= 400;
+  auto fastest = [&](const std::vector<int> &cand, auto &&trial) {
+    // per-iteration cost = slope between a short and a longer trial (set-up, launch and code-object
+    // load cancel); ~200 iterations per candidate
+    auto timed = [&](int iters, int g) {
+      KernelArgs t = a;
+      t.M = iters; t.B = iters;
+      float ms = 0;
+      HIP_OK(hipEventRecord(ev0, stream));
+      trial(t, g);
+      HIP_OK(hipEventRecord(ev1, stream));
+      HIP_OK(hipEventSynchronize(ev1));
+      HIP_OK(hipEventElapsedTime(&ms, ev0, ev1));
+      return ms;
+    };
+    int best = cand[0]; float best_slope = 0;
+    for (size_t i = 0; i < cand.size(); i++) {
+      timed(4, cand[i]);
+      const float t0 = timed(32, cand[i]), t1 = timed(160, cand[i]);
+      const float slope = t1 - t0;
+      if (i == 0 || slope < best_slope) { best = cand[i]; best_slope = slope; }
+    }
+    return best;
+  };
+
+  int k2_G = 0;
+  if (n_k2 > 0) {
+    const long chains = static_cast<long>(n_k2) * p.noChains;
+    const int maxq = (events[k2_first_event()].n_draw + 3) / 4;
+    const int max_cpw = p.paired ? std::max<int>(1, static_cast<int>((60 * 1024 - k2_fp) / (4 * k2_tab))) : 64;
+    if (const char *env = std::getenv("MISO_LANES_PER_CHAIN")) k2_G = std::atoi(env);
+    else if (tuned_k2_G) k2_G = tuned_k2_G;
+    else {
+      k2_G = choose_lanes_per_chain(chains, maxq, wave_slots, max_cpw);
+      if (tune && chains >= 4096 && std::getenv("MISO_AUTOTUNE_K2") != nullptr) {   // the rule is the measured optimum
+        static const int kG[] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 16, 21, 32, 64};
+        std::vector<int> cand{k2_G};
+        for (int i = 0; i < 15; i++)
+          if (kG[i] == k2_G) {
+            for (int j : {i - 1, i + 1, i + 2})
+              if (j >= 0 && j < 15 && 64 / kG[j] <= max_cpw && !(p.paired && (kG[j] & (kG[j] - 1))) &&
+                  kG[j] <= std::max(1, maxq))
+                cand.push_back(kG[j]);
+          }
+        if (cand.size() > 1) k2_G = fastest(cand, [&](const KernelArgs &t, int g) { launch_k2(t, g); });
+        tuned_k2_G = k2_G;
+      }
+    }
+  }
+  std::vector<int> grp_G(gen_runs.size(), 64);
+  std::vector<GrpShape> grp_sh(gen_runs.size());
+  for (size_t ri = 0; ri < gen_runs.size(); ri++) {
+    GenRun &run = gen_runs[ri];
+    const GrpShape sh = grp_sh[ri] = grp_shape(run);
+    const long chains = static_cast<long>(run.count) * p.noChains;
+    int G = 64;
+    if (const char *env = std::getenv("MISO_GENERAL_LANES")) {
+      G = std::atoi(env);
+    } else if (run.tuned_G) {
+      G = run.tuned_G;
+    } else {
+      // rule of thumb.  single-end: the per-iteration scalar step costs the same per wavefront
+      // whatever G is, so pack as many chains per wavefront as still fills the device: the smallest
+      // G whose wavefronts occupy every resident slot; a batch too small for that takes the largest.
+      // paired-end: the read loop waits on memory and more wavefronts hide it: largest G up to 16.
+      bool found = false;
+      for (int g : {2, 4, 8, 16, 32}) {
+        if (p.paired && g > 16 && found) break;
+        if (!grp_fits(run, sh, g)) continue;
+        const int cpw = 64 / g;
+        if (!found || g <= std::max(2, run.maxq)) G = g;
+        found = true;
+        if (!p.paired && (chains + cpw - 1) / cpw >= wave_slots) break;
+      }
+      if (tune && chains >= 2048 && G != 64) {
+        std::vector<int> cand{G};
+        // the rule errs on the small side (tail effect when the wavefronts do not fit one round)
+        for (int g : {G * 2, G * 4})
+          if (!p.paired && grp_fits(run, sh, g) && g <= std::max(2, 2 * run.maxq)) cand.push_back(g);
+        if (cand.size() > 1)
+          G = fastest(cand, [&](const KernelArgs &t, int g) { launch_grp(t, run, sh, g); });
+        run.tuned_G = G;
+      }
+    }
+    // a forced (or odd) choice never exceeds the LDS budget: fewer chains per wavefront instead
+    while (G < 64 && !grp_fits(run, sh, G)) G = (G < 2) ? 2 : ((G & (G - 1)) ? 64 : G * 2);
+    grp_G[ri] = G;
+  }
+
+  HIP_OK(hipEventRecord(ev0, stream));                  // events bracket the sampler kernels only
+  if (n_k2 > 0) {
+    lanes_per_chain = k2_G;
+    last_kernels = "sampler_k2<" + std::to_string(k2_G) + (p.paired ? ", true>" : ", false>");
+    launch_k2(a, k2_G);
+  }
+  for (size_t ri = 0; ri < gen_runs.size(); ri++) {
+    const GenRun &run = gen_runs[ri];
+    const int G = grp_G[ri];
+    last_kernels += std::string(last_kernels.empty() ? "" : ",") +
+                    (G == 64 ? std::string("sampler_wave<")
+                             : "sampler_grp<" + std::to_string(G) + ", ") +
+                    (p.paired ? "true" : "false") +
+                    (G == 64 ? std::string(">") : ", " + std::to_string(run.kc) + ">");
+    launch_grp(a, run, grp_sh[ri], G);
   }
   HIP_OK(hipEventRecord(ev1, stream));
   launched = true; downloaded = false; summarized = false; compared = false;
