@@ -112,7 +112,8 @@ def main():
     ap.add_argument("--chains", type=int, default=1)
     ap.add_argument("--paired", action="store_true")
     ap.add_argument("--seed", type=int, default=42)
-    ap.add_argument("--cpu-events", type=int, default=12, help="reference events per host process")
+    ap.add_argument("--cpu-events", type=int, default=150,
+                    help="reference events per host process (~12 s of CPU work per core at the default shape)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-match", action="store_true",
                     help="compute the read x isoform compatibility on the host instead of the GPU (row f1)")

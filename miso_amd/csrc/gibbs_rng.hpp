@@ -34,7 +34,10 @@ __device__ __forceinline__ miso_u32x4 philox_gibbs(const GibbsRng &g, uint32_t q
   uint32_t c0 = n0_round0, c1 = g.p1lo, c2 = static_cast<uint32_t>(p0 >> 32) ^ g.c3k1,
            c3 = static_cast<uint32_t>(p0);
   uint32_t gk0 = g.k0, gk1 = g.k1;
-  if (REKEY) asm volatile("" : "+s"(gk0), "+s"(gk1));
+  if (REKEY) {   // the key is the launch's seed: uniform, but only readfirstlane proves it to the compiler
+    gk0 = __builtin_amdgcn_readfirstlane(gk0); gk1 = __builtin_amdgcn_readfirstlane(gk1);
+    asm volatile("" : "+s"(gk0), "+s"(gk1));
+  }
   uint32_t k0 = gk0 + MISO_PHILOX_W0, k1 = gk1 + MISO_PHILOX_W1;
 #pragma unroll
   for (int r = 1; r < 10; r++) {

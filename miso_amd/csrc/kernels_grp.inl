@@ -262,8 +262,11 @@ __device__ __forceinline__ void class_units(const uint32_t *ctab, const uint32_t
 // fetched with wide loads ONE TRIP AHEAD so the L2 latency overlaps the previous quad's arithmetic;
 // weights psi_k fp[f] from the LDS tables, pick by the reference's scan (miso_paired.c:11-22,
 // 64-75), score from the chain's LDS table.  Reads beyond n_draw are padded with FRAG_NONE (host).
+// Exec-masked formulation (data-dependent branches skip the isoforms a read is not compatible with):
+// slower than the branch-free one below up to ~6 isoforms (K=3 +4%, K=5 +5%), faster beyond
+// (K=10: 9.7k vs 7.1k events/s) where the selects of the branch-free form outnumber the work saved.
 template <int KK, int G>
-__device__ __forceinline__ void pe_quads(const uint16_t *frags, const double *psi, const double *lds_fp,
+__device__ __forceinline__ void pe_quads_masked(const uint16_t *frags, const double *psi, const double *lds_fp,
                                          const int32_t *stab, int il, int *cnt, uint8_t *drawass,
                                          bool write_ass, int nqw, int n_quads, int n_draw, int sub,
                                          const GibbsRng &rng, uint32_t n0r0, int64_t &acc_out, int &bad_out) {
@@ -314,13 +317,96 @@ __device__ __forceinline__ void pe_quads(const uint16_t *frags, const double *ps
         }
       }
       if (sel >= 0) {
-        atomicAdd(&cnt[sel], 1);
+        atomicAdd(&cnt[sel], 1);   // with many isoforms one LDS atomic beats KK register updates
         const int32_t v = stab[sel * il + static_cast<int>(fsel)];
         if (v == SFIX_BAD) bad = 1; else acc += v;
         if (write_ass) drawass[4 * q + j] = static_cast<uint8_t>(sel);
       }
     }
   }
+  acc_out = acc; bad_out = bad;
+}
+
+
+template <int KK, int G, bool WRITE>
+__device__ __forceinline__ void pe_quads(const uint16_t *frags, const double *psi, const double *lds_fp,
+                                         const int32_t *stab, int il, int *cnt, uint8_t *drawass,
+                                         bool write_ass, int nqw, int n_quads, int n_draw, int sub,
+                                         const GibbsRng &rng, uint32_t n0r0, int64_t &acc_out, int &bad_out) {
+  // Written without data-dependent branches: the first version had ~10 per read (guarded loads,
+  // `if (valid)` in the scan), each a scheduling barrier with its own s_waitcnt, and the loop ran at
+  // LDS / L2 latency.  Invalid isoforms contribute +0.0 to the sums (bit-neutral: every weight is
+  // >= +0), out-of-range quads are loaded from a clamped address and masked.
+  constexpr int ND = 2 * KK;   // dwords per quad
+  double ps[KK];
+#pragma unroll
+  for (int k = 0; k < KK; k++) ps[k] = psi[k];
+  const uint32_t *fq = reinterpret_cast<const uint32_t *>(frags);
+  const int q_last = max(n_quads - 1, 0);
+  uint32_t nxt[ND];
+  {
+    const int q = sub;
+    const uint32_t *src = fq + static_cast<size_t>(min(q, q_last)) * ND;
+#pragma unroll
+    for (int i = 0; i < ND; i++) { const uint32_t v = src[i]; nxt[i] = (q < n_quads) ? v : 0xFFFFFFFFu; }
+  }
+  int64_t acc = 0; int bad = 0;
+  int cl[KK];   // this lane's picks per isoform: registers, not one LDS atomic per read (the G lanes of
+#pragma unroll  // a chain hit the same K counters, which the LDS serialises)
+  for (int k = 0; k < KK; k++) cl[k] = 0;
+  for (int q0 = 0; q0 < nqw; q0 += G) {
+    const int q = q0 + sub;
+    uint32_t cur[ND];
+#pragma unroll
+    for (int i = 0; i < ND; i++) cur[i] = nxt[i];
+    {
+      const int qn = q + G;
+      const uint32_t *src = fq + static_cast<size_t>(min(qn, q_last)) * ND;
+#pragma unroll
+      for (int i = 0; i < ND; i++) { const uint32_t v = src[i]; nxt[i] = (qn < n_quads) ? v : 0xFFFFFFFFu; }
+    }
+    const miso_u32x4 u = philox_gibbs<true>(rng, static_cast<uint32_t>(q), n0r0);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      uint32_t fr[KK]; double w[KK]; bool val[KK];
+      double T = 0.0; int nv = 0;
+#pragma unroll
+      for (int k = 0; k < KK; k++) {
+        const int idx = j * KK + k;
+        fr[k] = (cur[idx >> 1] >> (16 * (idx & 1))) & 0xFFFFu;
+        val[k] = fr[k] != FRAG_NONE;
+        const double fpv = lds_fp[val[k] ? fr[k] : 0u];   // unconditional gather, masked below
+        const double wk = ps[k] * fpv;
+        w[k] = val[k] ? wk : 0.0;
+        T = T + w[k];
+        nv += val[k] ? 1 : 0;
+      }
+      const double rnd = miso_u01(u.v[j]) * T;
+      double cum = 0.0; int idx = 0, sel = -1, lastv = -1;
+#pragma unroll
+      for (int k = 0; k < KK; k++) {   // the reference's scan (miso_paired.c:64-75) over the valid isoforms
+        cum = cum + w[k];
+        // bitwise, not short-circuit: `&&` on f64 compares comes back as branches
+        const bool two = nv == 2, first = idx == 0, lt = rnd < cum, ngt = !(rnd > cum);
+        const bool stop = val[k] & ((two & (lt | !first)) | (!two & ngt));
+        sel = ((sel < 0) & stop) ? k : sel;
+        lastv = val[k] ? k : lastv;
+        idx += val[k] ? 1 : 0;
+      }
+      sel = (sel < 0) ? lastv : sel;   // ran off the end: the last valid isoform
+      uint32_t fsel = 0;
+#pragma unroll
+      for (int k = 0; k < KK; k++) { fsel = (sel == k) ? fr[k] : fsel; cl[k] += (sel == k) ? 1 : 0; }
+      const bool picked = sel >= 0;
+      const int32_t v = stab[picked ? sel * il + static_cast<int>(fsel) : 0];
+      const bool isbad = v == SFIX_BAD;
+      bad |= (picked & isbad) ? 1 : 0;
+      acc += (picked & !isbad) ? v : 0;
+      if (WRITE) { if (write_ass && picked) drawass[4 * q + j] = static_cast<uint8_t>(sel); }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < KK; k++) if (cl[k]) atomicAdd(&cnt[k], cl[k]);
   acc_out = acc; bad_out = bad;
 }
 
@@ -543,7 +629,12 @@ __global__ __launch_bounds__(256, KC <= 8 ? MISO_GRP_MINBLOCKS : 2) void sampler
     int64_t acc = 0; int bad = 0;
     if (PE && pe_fast) {
       const uint32_t n0r0 = rng.p1hi ^ iter ^ rng.k0;
-#define MISO_PEQ(KK) pe_quads<KK, G>(frags, S.psi, lds_fp, sfix, a.il, S.cnt, drawass, write_ass, nqw, n_quads, n_draw, sub, rng, n0r0, acc, bad);
+#define MISO_PEQ(KK)                                                                                  \
+  {                                                                                                   \
+    if constexpr ((KK) > 6) pe_quads_masked<KK, G>(frags, S.psi, lds_fp, sfix, a.il, S.cnt, drawass, write_ass, nqw, n_quads, n_draw, sub, rng, n0r0, acc, bad); \
+    else if (__any(write_ass)) pe_quads<KK, G, true>(frags, S.psi, lds_fp, sfix, a.il, S.cnt, drawass, write_ass, nqw, n_quads, n_draw, sub, rng, n0r0, acc, bad); \
+    else pe_quads<KK, G, false>(frags, S.psi, lds_fp, sfix, a.il, S.cnt, drawass, write_ass, nqw, n_quads, n_draw, sub, rng, n0r0, acc, bad); \
+  }
       if constexpr (KC == 4) { if (Kw == 3) MISO_PEQ(3) else MISO_PEQ(4) }
       else if constexpr (KC == 8) { if (Kw == 5) MISO_PEQ(5) else if (Kw == 6) MISO_PEQ(6) else if (Kw == 7) MISO_PEQ(7) else MISO_PEQ(8) }
       else if constexpr (KC == 12) { if (Kw == 9) MISO_PEQ(9) else if (Kw == 10) MISO_PEQ(10) else if (Kw == 11) MISO_PEQ(11) else MISO_PEQ(12) }
