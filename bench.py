@@ -38,11 +38,23 @@ def _cpu_worker(args):
         exons, isoforms, pos, cig = workload.event_reads(e, K, n_reads, read_len)
         g = L.gene([c for ex in exons for c in ex], isoforms)
         probs.append((g, pos, cig))
+    import numpy as np
+    stats = []
     t0 = time.perf_counter()
     for g, pos, cig in probs:
         r = L.miso(g, pos, cig, read_len, iters=iters, burn=burn, lag=lag, chains=chains)
         assert r.rc == 0
-    return time.perf_counter() - t0
+        stats.append(r.samples)
+    dt = time.perf_counter() - t0
+    # posterior mean and Chen-Shao 95 % bounds of isoform 0 (credible_intervals.py:31-55), outside
+    # the timed region: what the GPU's numbers are compared with (|delta psi| in BASELINE's metric)
+    out = []
+    for e, smp in zip(ev_ids, stats):
+        x = np.sort(np.asarray(smp)[:, 0])
+        n = len(x)
+        out.append((e, float(x.mean()), float(x[int(round(0.025 * n)) - 1]),
+                    float(x[int(round(0.975 * n)) - 1]), float(x.std(ddof=1))))
+    return dt, out
 
 
 def usable_cores():
@@ -71,8 +83,10 @@ def cpu_baseline(a):
     ctx = mp.get_context("fork")
     t0 = time.perf_counter()
     with ctx.Pool(cores) as pool:
-        times = pool.map(_cpu_worker, jobs)
+        res = pool.map(_cpu_worker, jobs)
     wall = time.perf_counter() - t0
+    times = [r[0] for r in res]
+    cpu_baseline.psi = [row for r in res for row in r[1]]   # (event, mean, lo, hi, sd) of isoform 0
     busy = max(times)
     return {"value": round(cores * per_proc / busy, 3), "unit": "events/s", "cores": cores,
             "kind": kind,
@@ -194,6 +208,26 @@ def main():
         batch.compare(other, 0.3)
         compare_ms = 1e3 * (time.perf_counter() - t1)
 
+    delta = None
+    if rank == 0 and cpu is not None and getattr(cpu_baseline, "psi", None):
+        # BASELINE's "|delta psi| vs ref": the GPU's posterior summaries (computed on the device) of
+        # the very events the reference just sampled on the host, different random streams
+        import numpy as np
+        batch.summarize(0.95)
+        rows = [r for r in cpu_baseline.psi if r[0] < a.events]
+        d_mean, d_lo, d_hi, z = [], [], [], []
+        for e, m, lo, hi, sd in rows:
+            gm, glo, ghi = batch.summary(e)
+            d_mean.append(abs(gm[0] - m)); d_lo.append(abs(glo[0] - lo)); d_hi.append(abs(ghi[0] - hi))
+            z.append(abs(gm[0] - m) / max(sd, 1e-12))
+        delta = {"events": len(rows), "mean_abs_dpsi": round(float(np.mean(d_mean)), 6),
+                 "max_abs_dpsi": round(float(np.max(d_mean)), 6),
+                 "mean_abs_dci_low": round(float(np.mean(d_lo)), 6),
+                 "mean_abs_dci_high": round(float(np.mean(d_hi)), 6),
+                 "max_dpsi_in_posterior_sd": round(float(np.max(z)), 4),
+                 "note": "isoform 0, GPU (device-side mean / Chen-Shao 95%% bounds) vs the real "
+                         "reference C core on the same events; independent random streams, so the "
+                         "difference is Monte-Carlo error of two %d-sample chains" % (a.iters - a.burn)}
     if rank == 0:
         total_events = a.events * world * a.steps
         value = total_events / elapsed
@@ -224,6 +258,7 @@ def main():
                                  "event on chip, so frac can exceed 1 and is NOT an HBM-utilisation "
                                  "claim -- see DESIGN.md"},
             "cpu_baseline": cpu,
+            "delta_psi_vs_reference": delta,
             "host_build_s": round(t_build, 2), "upload_s": round(t_up, 3),
             "match_kernel_ms": round(batch.match_ms(), 3),
             "summary_ms": None if summary_ms is None else round(summary_ms, 3),

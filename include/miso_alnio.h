@@ -92,6 +92,18 @@ int miso_aln_parse_reads(const miso_alnfile_t *f, int ref, int64_t start, int64_
                          int32_t *positions, int64_t pos_cap, char *cigar_buf, int64_t cigar_cap,
                          int64_t *n_reads, int64_t *cigar_bytes, int64_t *n_strand_discarded);
 
+/* One event straight from the file into a sampler batch (miso_amd.h): miso_aln_parse_reads with the
+ * batch's single-end / paired-end mode, positions made 1-based (misopy/miso_sampler.py:284), then
+ * miso_batch_add_event -- no per-read work in the host language.  *n_reads = reads (pairs) found;
+ * the event is added only when 0 < *n_reads and *n_reads >= min_reads (run_miso.py:139-147), else
+ * *event_index = -1 and the call still succeeds.  Errors as miso_batch_add_event (bad CIGAR, ...). */
+struct miso_batch;
+struct miso_gene;
+int miso_batch_add_event_aln(struct miso_batch *batch, const struct miso_gene *gene,
+                             const miso_alnfile_t *f, int ref, int64_t start, int64_t end,
+                             int strand_rule, int target_strand, int given_read_len, int64_t min_reads,
+                             const double *hyperp, int n_hyperp, int64_t *n_reads, int *event_index);
+
 const char *miso_aln_last_error(void);
 
 #ifdef __cplusplus

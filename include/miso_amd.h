@@ -186,6 +186,18 @@ int miso_batch_event_info(const miso_batch_t *batch, int event_index, int *noiso
 int miso_batch_get_result(const miso_batch_t *batch, int event_index, double *samples,
                           double *logLik, double *class_templates, double *class_counts,
                           int *assignment, miso_rundata_t *rundata);
+
+/* The `.miso` files of many events at once (misopy/miso_sampler.py:444-464, output_miso_results):
+ * for each j < n, paths[j] receives headers[j] (the caller's "#isoforms=...\n" line), the column
+ * line "sampled_psi\tlog_score\n" and one row per kept sample, "%.4f,%.4f,...\t%.2f\n", with the
+ * digits Python's % operator prints (nan for NaN).  The rows are formatted and written by n_threads
+ * host threads (<= 0: all cores): at 5000 rows per event the reference's Python loop is the slowest
+ * step of a whole-genome run once sampling takes milliseconds.  Needs downloaded results. */
+int miso_batch_write_miso_files(const miso_batch_t *batch, int n, const int *event_index,
+                                const char *const *paths, const char *const *headers, int n_threads);
+/* tests: the writer's number formatter on its own ("%.2f" / "%.4f"), NUL-terminated strings `stride`
+ * bytes apart */
+int miso_selftest_format(const double *x, int n, int decimals, char *out, int stride);
 /* parity instrumentation: FNV-1a over every chain's per-iteration assignment counts
    (counts_hash: noChains words) and, if want_counts_trace, the counts themselves
    ((noIterations+1) x noChains x noiso int32, row m = counts the MH step of iteration m saw,

@@ -262,6 +262,49 @@ class Batch:
         check(lib().miso_batch_get_comparison(self.handle, i, _p(m1), _p(m2), _p(bf), _p(dens)))
         return m1, m2, bf, dens
 
+    def add_event_aln(self, gene, alnfile, chrom, start, end, strand_rule=0, target_strand=None,
+                      read_len=None, min_reads=0, hyper=None):
+        """One event straight from an open alignment file (sam_utils.Samfile) -- fetch, pairing and
+        filters run natively (miso_batch_add_event_aln).  Returns (event index or -1, reads found)."""
+        hy = None if hyper is None else np.asarray(hyper, dtype=np.float64)
+        tid = alnfile.gettid(chrom)
+        if tid < 0:
+            return -1, 0
+        idx, n = C.c_int(-1), C.c_int64(0)
+        L = lib()
+        L.miso_batch_add_event_aln.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64,
+                                               C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64,
+                                               C.c_void_p, C.c_int, C.POINTER(C.c_int64),
+                                               C.POINTER(C.c_int)]
+        check(L.miso_batch_add_event_aln(self.handle, gene.handle, alnfile._h, tid, int(start),
+                                         int(end), int(strand_rule),
+                                         ord(target_strand[0]) if target_strand else 0,
+                                         int(read_len) if read_len else 0, int(min_reads), _p(hy),
+                                         0 if hy is None else len(hy), C.byref(n), C.byref(idx)))
+        return idx.value, n.value
+
+    def result_lite(self, i):
+        """(class_templates, class_counts, assignment, rundata) of event i -- no sample copy."""
+        K, N, ncls = C.c_int(), C.c_int(), C.c_int()
+        check(lib().miso_batch_event_info(self.handle, i, C.byref(K), C.byref(N), None, C.byref(ncls)))
+        ct = np.zeros((max(ncls.value, 1), K.value))
+        cc = np.zeros(max(ncls.value, 1))
+        ass = np.zeros(max(N.value, 1), np.int32)
+        rd = RunData()
+        check(lib().miso_batch_get_result(self.handle, i, None, None, _p(ct), _p(cc), _p(ass),
+                                          C.byref(rd)))
+        return ct[:ncls.value], cc[:ncls.value], ass[:N.value], rd
+
+    def write_miso_files(self, indices, paths, headers, threads=0):
+        """The `.miso` files of the given events, rows formatted and written natively."""
+        n = len(indices)
+        if n == 0:
+            return
+        idx = np.asarray(indices, dtype=np.int32)
+        pa = (C.c_char_p * n)(*[os.fsencode(p) for p in paths])
+        hd = (C.c_char_p * n)(*[h.encode() for h in headers])
+        check(lib().miso_batch_write_miso_files(self.handle, n, _p(idx), pa, hd, int(threads)))
+
     def match_ms(self):
         ms = C.c_float(0)
         check(lib().miso_batch_last_match_ms(self.handle, C.byref(ms)))

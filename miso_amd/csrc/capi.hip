@@ -3,12 +3,19 @@
 // Error convention of the reference (splicing_error.h:548 SPLICING_CHECK, pyerror.c:27-44): every
 // entry point returns an int code; the text "Error at file:line: reason, strerror" of the last
 // failure is kept per thread for the binding to raise.
+#include <atomic>
+#include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "batch.hpp"
+#include "miso_alnio.h"
 
 using namespace miso;
 
@@ -52,6 +59,66 @@ const PackedEvent &event_at(const miso_batch *b, int i) {
   return b->events[i];
 }
 }  // namespace
+
+// ---- the sample rows of `.miso` files, written natively (misopy/miso_sampler.py:456-464) ----
+namespace {
+
+// "%.*f" of a finite x with |x| < 2^31 / 10^D, exactly as printf rounds it (to nearest, ties to even
+// on the EXACT binary value): scale, round, and fall back to snprintf when the scaled value is so
+// close to a tie that the multiplication's rounding could have moved it across.
+template <int D> inline char *fmt_fixed(char *o, double x) {
+  constexpr double P = D == 4 ? 10000.0 : 100.0;
+  if (!(x == x)) { std::memcpy(o, "nan", 3); return o + 3; }          // Python prints nan, never -nan
+  const double ax = x < 0 ? -x : x;
+  if (ax < 200000.0) {
+    const double t = ax * P, r = std::floor(t + 0.5), d = t + 0.5 - r;
+    if (d > 1e-6 && d < 1.0 - 1e-6) {
+      uint64_t v = static_cast<uint64_t>(r);
+      const bool neg = (x < 0 || (x == 0 && std::signbit(x)));        // "-0.00" like printf
+      char tmp[24]; int n = 0;
+      for (int i = 0; i < D; i++) { tmp[n++] = static_cast<char>('0' + v % 10); v /= 10; }
+      tmp[n++] = '.';
+      do { tmp[n++] = static_cast<char>('0' + v % 10); v /= 10; } while (v);
+      if (neg) *o++ = '-';
+      while (n) *o++ = tmp[--n];
+      return o;
+    }
+  }
+  return o + std::snprintf(o, 336, D == 4 ? "%.4f" : "%.2f", x);   // 1e308 has 309 digits
+}
+
+void write_miso_file(const miso_batch *b, int i, const char *path, const char *header) {
+  const PackedEvent &e = event_at(b, i);
+  const DevEvent &d = b->h_events[i];
+  const unsigned char *out = b->h_out.data();
+  const int S = b->S(), K = e.K;
+  const double *samples = reinterpret_cast<const double *>(out + d.off_samples);   // K x S, column-major
+  const double *loglik = reinterpret_cast<const double *>(out + d.off_loglik);
+  std::string buf;
+  buf.reserve(std::strlen(header) + 32 + static_cast<size_t>(S) * (8 * K + 16));
+  buf.append(header);
+  buf.append("sampled_psi\tlog_score\n");
+  std::vector<char> rowbuf(static_cast<size_t>(K + 1) * 336 + 8);
+  char *row = rowbuf.data();
+  for (int s = 0; s < S; s++) {
+    char *o = row;
+    for (int k = 0; k < K; k++) {
+      if (k) *o++ = ',';
+      o = fmt_fixed<4>(o, samples[static_cast<size_t>(s) * K + k]);
+    }
+    *o++ = '\t';
+    o = fmt_fixed<2>(o, loglik[s]);
+    *o++ = '\n';
+    buf.append(row, o - row);
+  }
+  FILE *f = std::fopen(path, "w");
+  if (!f) MISO_FAIL(MISO_FAILURE, std::string("cannot open ") + path + " for writing");
+  const size_t w = std::fwrite(buf.data(), 1, buf.size(), f);
+  if (std::fclose(f) != 0 || w != buf.size()) MISO_FAIL(MISO_FAILURE, std::string("short write to ") + path);
+}
+
+}  // namespace
+
 
 extern "C" {
 
@@ -263,6 +330,86 @@ int miso_batch_get_result(const miso_batch_t *b, int i, double *samples, double 
       for (int c = 0; c < b->p.noChains; c++) acc += st[c].accepted;
       fill_rundata(*b, e.K, acc, rundata);
     }
+  });
+}
+
+int miso_batch_add_event_aln(miso_batch_t *b, const miso_gene_t *gene, const miso_alnfile_t *f, int ref,
+                             int64_t start, int64_t end, int strand_rule, int target_strand,
+                             int given_read_len, int64_t min_reads, const double *hyperp, int n_hyperp,
+                             int64_t *n_reads, int *event_index) {
+  if (event_index) *event_index = -1;
+  int64_t n = 0, nb = 0;
+  int rc = guarded([&] {
+    need(b, "batch"); need(gene, "gene"); need(f, "alignment file");
+    const int paired = b->p.paired ? 1 : 0;
+    if (miso_aln_parse_reads(f, ref, start, end, paired, strand_rule, target_strand, given_read_len,
+                             nullptr, 0, nullptr, 0, &n, &nb, nullptr))
+      MISO_FAIL(MISO_EINVAL, std::string("alignment reader: ") + miso_aln_last_error());
+  });
+  if (rc) return rc;
+  if (n_reads) *n_reads = n;
+  if (n == 0 || n < min_reads) return MISO_SUCCESS;   // the caller's skip rules (run_miso.py:139-147)
+  std::vector<int32_t> pos;
+  std::vector<char> cig;
+  std::vector<const char *> cptr;
+  rc = guarded([&] {
+    const int paired = b->p.paired ? 1 : 0;
+    const int64_t npos = n * (paired ? 2 : 1);
+    pos.resize(npos); cig.resize(nb + 1);
+    int64_t n2 = 0, nb2 = 0;
+    if (miso_aln_parse_reads(f, ref, start, end, paired, strand_rule, target_strand, given_read_len,
+                             pos.data(), npos, cig.data(), nb, &n2, &nb2, nullptr) || n2 != n || nb2 != nb)
+      MISO_FAIL(MISO_EINTERNAL, "alignment reader changed its answer");
+    for (auto &p : pos) p += 1;                        // 0-based -> 1-based (miso_sampler.py:284)
+    cptr.reserve(npos);
+    const char *c = cig.data();
+    for (int64_t i = 0; i < npos; i++) { cptr.push_back(c); c += std::strlen(c) + 1; }
+  });
+  if (rc) return rc;
+  return miso_batch_add_event(b, gene, pos.data(), cptr.data(), static_cast<int>(pos.size()), hyperp,
+                              n_hyperp, event_index);
+}
+
+int miso_selftest_format(const double *x, int n, int decimals, char *out, int stride) {
+  return guarded([&] {
+    need(x, "x"); need(out, "out");
+    if ((decimals != 2 && decimals != 4) || stride < 344) MISO_FAIL(MISO_EINVAL, "decimals must be 2 or 4, stride >= 344");
+    for (int i = 0; i < n; i++) {
+      char *o = out + static_cast<size_t>(i) * stride;
+      char *e = decimals == 4 ? fmt_fixed<4>(o, x[i]) : fmt_fixed<2>(o, x[i]);
+      *e = '\0';
+    }
+  });
+}
+
+int miso_batch_write_miso_files(const miso_batch_t *b, int n, const int *event_index,
+                                const char *const *paths, const char *const *headers, int n_threads) {
+  return guarded([&] {
+    need(b, "batch");
+    if (n < 0 || (n > 0 && (!event_index || !paths || !headers))) MISO_FAIL(MISO_EINVAL, "null argument");
+    if (!b->downloaded) MISO_FAIL(MISO_EINVAL, "results not downloaded yet");
+    for (int j = 0; j < n; j++) { (void) event_at(b, event_index[j]); need(paths[j], "path"); need(headers[j], "header"); }
+    int T = n_threads > 0 ? n_threads : static_cast<int>(std::thread::hardware_concurrency());
+    T = std::max(1, std::min(T, std::min(n, 64)));
+    std::atomic<int> next{0};
+    std::mutex mu; std::string first_error; int first_code = 0;
+    auto work = [&] {
+      for (;;) {
+        const int j = next.fetch_add(1);
+        if (j >= n) return;
+        try {
+          write_miso_file(b, event_index[j], paths[j], headers[j]);
+        } catch (const Error &err) {
+          std::lock_guard<std::mutex> g(mu);
+          if (!first_code) { first_code = err.code; first_error = err.text; }
+        }
+      }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; t++) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+    if (first_code) { g_last_error = first_error; throw Rethrow{first_code}; }
   });
 }
 

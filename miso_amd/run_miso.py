@@ -29,7 +29,7 @@ import miso_sampler as miso  # noqa: E402  (flat import: it shares `pysplicing` 
 
 
 def collect_gene_events(gene_entries, bamfile, output_dir, read_len, overhang_len,
-                        paired_end=None, event_type=None, verbose=True):
+                        paired_end=None, event_type=None, verbose=True, native=False):
     """run_miso.py:98-206 up to (not including) sampler.run_sampler, for many genes.
     gene_entries: iterable of (gene_id, indexed_gff_filename).
     Returns (events, info): events = [(reads, gene_obj, output_filename)] for
@@ -61,6 +61,25 @@ def collect_gene_events(gene_entries, bamfile, output_dir, read_len, overhang_le
             continue
         tx_start, tx_end = gff_utils.get_inclusive_txn_bounds(gene_info['hierarchy'][gene_id])
         chrom = sam_utils.resolve_chrom(bamfile, gene_obj.chrom)
+        if event_type is not None:
+            chrom_dir = os.path.join(output_dir, event_type, gene_obj.chrom)
+        else:
+            chrom_dir = os.path.join(output_dir, gene_obj.chrom)
+        miso_basename = os.path.basename(gff_index_filename)
+        if not miso_basename.endswith(".pickle"):
+            raise ValueError("Error: Invalid index file %s" % gff_index_filename)
+        output_filename = os.path.join(chrom_dir, miso_basename[:-len(".pickle")])
+        if native:
+            # the reads stay in the file: fetch, pairing, filters and the minimum-read rule are
+            # applied natively when the sampler adds the event to its batch
+            if strand_rule == "fr-secondstrand":
+                raise Exception("fr-secondstrand currently unsupported.")     # sam_utils.py:331
+            region = miso.AlnRegion(bamfile, chrom, tx_start, tx_end, strand_rule=strand_rule,
+                                    target_strand=gene_obj.strand, read_len=read_len,
+                                    min_reads=min_event_reads if filter_reads else 0)
+            events.append((region, gene_obj, output_filename))
+            info[gene_id] = "region %s:%d-%d" % (chrom, tx_start, tx_end)
+            continue
         try:
             reads, num_raw_reads = bamfile.parse_reads(
                 chrom, tx_start, tx_end, paired_end=bool(paired_end), strand_rule=strand_rule,
@@ -75,14 +94,6 @@ def collect_gene_events(gene_entries, bamfile, output_dir, read_len, overhang_le
                       % (num_raw_reads, min_event_reads))
             info[gene_id] = "only %d reads" % num_raw_reads
             continue
-        if event_type is not None:
-            chrom_dir = os.path.join(output_dir, event_type, gene_obj.chrom)
-        else:
-            chrom_dir = os.path.join(output_dir, gene_obj.chrom)
-        miso_basename = os.path.basename(gff_index_filename)
-        if not miso_basename.endswith(".pickle"):
-            raise ValueError("Error: Invalid index file %s" % gff_index_filename)
-        output_filename = os.path.join(chrom_dir, miso_basename[:-len(".pickle")])
         events.append((reads, gene_obj, output_filename))
         info[gene_id] = "%d reads" % num_raw_reads
     return events, info
@@ -91,7 +102,7 @@ def collect_gene_events(gene_entries, bamfile, output_dir, read_len, overhang_le
 def compute_gene_psi(gene_ids, gff_index_filename, bam_filename, output_dir, read_len,
                      overhang_len, paired_end=None, event_type=None, verbose=True, bamfile=None,
                      seed=None, first_event_id=0, device=None, gene_entries=None,
-                     max_events_per_launch=65536):
+                     max_events_per_launch=32768):
     """run_miso.py:34-206.  `gene_entries` (list of (gene_id, index file)) generalises the
     reference's (gene_ids, one index file) so a whole batch file is one GPU batch."""
     os.makedirs(output_dir, exist_ok=True)
@@ -113,7 +124,7 @@ def compute_gene_psi(gene_ids, gff_index_filename, bam_filename, output_dir, rea
         bamfile = sam_utils.load_bam_reads(bam_filename)
     events, info = collect_gene_events(gene_entries, bamfile, output_dir, read_len, overhang_len,
                                        paired_end=paired_end, event_type=event_type,
-                                       verbose=verbose)
+                                       verbose=verbose, native=True)
     t1 = time.time()
     written = []
     if paired_end:

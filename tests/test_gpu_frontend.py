@@ -78,3 +78,65 @@ def test_miso_run_cli_on_reference_test_data(tmp_path, fmt):
              "--settings-filename", str(settings), "-p", "1", "--seed", "32"])
     assert r.returncode == 0
     assert np.array_equal(miso_sampler.load_samples(miso_file)[0], samples)
+
+
+def test_native_writer_and_region_path_equal_the_python_path(tmp_path):
+    """One event three ways -- run_sampler (Python row loop, miso_sampler.py:456-464),
+    run_sampler_batch with explicit reads and run_sampler_batch with the reads still in the
+    alignment file (AlnRegion) -- must give byte-identical .miso files."""
+    import miso_sampler
+    from miso_amd import gene_utils, sam_utils
+    with gzip.open(os.path.join(DATA, "c2c12.Atp2b1.sam.gz"), "rt") as f:
+        sam_text = f.read()
+    aln = str(tmp_path / "reads.bam")
+    sam_to_bam(sam_text, aln)
+    bam = sam_utils.Samfile(aln)
+    gene = gene_utils.load_genes_from_gff(os.path.join(DATA, "Atp2b1.mm9.gff"),
+                                          suppress_warnings=True)["ENSMUSG00000019943"]["gene_object"]
+    reads, n = bam.parse_reads("10", 98377804, 98486420, given_read_len=36)
+    assert n > 3000
+
+    def sampler():
+        return miso_sampler.MISOSampler(miso_sampler.get_single_end_sampler_params(2, 36))
+    a = sampler().run_sampler(600, reads, gene, None, None, str(tmp_path / "a" / "g"), num_chains=3,
+                              burn_in=100, lag=5, verbose=False, seed=5)
+    b = sampler().run_sampler_batch(600, [(reads, gene, str(tmp_path / "b" / "g"))], num_chains=3,
+                                    burn_in=100, lag=5, seed=5)[0]
+    region = miso_sampler.AlnRegion(bam, "10", 98377804, 98486420, read_len=36, min_reads=20)
+    c = sampler().run_sampler_batch(600, [(region, gene, str(tmp_path / "c" / "g")),
+                                          (miso_sampler.AlnRegion(bam, "10", 5, 10, read_len=36, min_reads=20),
+                                           gene, str(tmp_path / "c" / "empty")),
+                                          (miso_sampler.AlnRegion(bam, "nope", 5, 10), gene,
+                                           str(tmp_path / "c" / "nochrom"))],
+                                    num_chains=3, burn_in=100, lag=5, seed=5)
+    assert a and b and c[0] and c[1] is None and c[2] is None
+    ref = open(a, "rb").read()
+    assert open(b, "rb").read() == ref
+    assert open(c[0], "rb").read() == ref
+    assert ref.count(b"\n") == 2 + 3 * (600 - 100) // 5
+
+
+def test_native_writer_many_isoforms_paired(tmp_path):
+    """Paired-end, 5 isoforms, several events: native rows == the rows Python formats from the
+    samples pysplicing returns."""
+    import miso_sampler
+    import pysplicing
+    from miso_amd import workload
+    events = []
+    for e in range(3):
+        exons, isoforms, pos, cig = workload.event_reads(e, K=5, n_reads=300, paired=True)
+        gene = miso_sampler.SimpleGene(exons, isoforms, label="g%d" % e, chrom="1", strand="+")
+        reads = (tuple(int(p) - 1 for p in pos), tuple(c.decode() for c in cig))
+        events.append((reads, gene, str(tmp_path / ("e%d" % e))))
+    s = miso_sampler.MISOSampler(miso_sampler.get_paired_end_sampler_params(5, 250.0, 900.0, 36),
+                                 paired_end=True)
+    written = s.run_sampler_batch(400, events, num_chains=2, burn_in=100, lag=3, seed=9)
+    assert all(written)
+    direct = pysplicing.MISOPairedBatch(
+        tuple((miso_sampler.py2c_gene(g), tuple(p + 1 for p in r[0]), r[1], (1.0,) * 5)
+              for r, g, _ in events), 36, 250.0, 900.0, 4.0, 400, 100, 3, 1, 2, seed=9)
+    for e, res in enumerate(direct):
+        psi = np.transpose(np.array(res[0]))
+        rows = ["%s\t%.2f" % (",".join("%.4f" % v for v in p), ll) for p, ll in zip(psi, res[1])]
+        got = open(written[e]).read().split("\n")
+        assert got[2:-1] == rows

@@ -111,3 +111,31 @@ def test_workload_is_a_function_of_the_global_event_id():
     assert workload.shard_bounds(10, 4, 0) == (0, 3) and workload.shard_bounds(10, 4, 3) == (8, 10)
     cover = [i for r in range(7) for i in range(*workload.shard_bounds(40, 7, r))]
     assert cover == list(range(40))
+
+
+def test_miso_file_number_formatting_equals_python():
+    """miso_batch_write_miso_files prints "%.4f" / "%.2f" (miso_sampler.py:458-464) with a fast path;
+    every digit must equal Python's % operator, ties and near-ties included."""
+    import ctypes as C
+    L = capi.lib()
+    rng = np.random.default_rng(1)
+
+    def mismatches(x, d):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        buf = C.create_string_buffer(344 * len(x))
+        assert L.miso_selftest_format(x.ctypes.data_as(C.c_void_p), len(x), d, buf, 344) == 0
+        raw = buf.raw
+        fmt = "%%.%df" % d
+        return [(v, raw[344 * i:344 * (i + 1)].split(b"\0")[0].decode(), fmt % v)
+                for i, v in enumerate(x) if raw[344 * i:344 * (i + 1)].split(b"\0")[0].decode() != fmt % v]
+
+    ties4 = (np.arange(0, 10000) + 0.5) / 10000.0
+    psi = np.concatenate([rng.uniform(0, 1, 100000), np.arange(0, 10001) / 10000.0, ties4,
+                          np.nextafter(ties4, 1), np.nextafter(ties4, 0),
+                          [0.0, -0.0, 1.0, np.nan, np.inf, -np.inf, 1e-310, 0.99995, 5e-5, 4.9999999e-5]])
+    assert mismatches(psi, 4) == []
+    ties2 = (np.arange(-5000, 5000) + 0.5) / 100.0
+    ll = np.concatenate([-rng.uniform(0, 20000, 100000), rng.normal(0, 1, 1000) * 1e6, ties2,
+                         np.nextafter(ties2, 1e9), np.nextafter(ties2, -1e9),
+                         [-0.004, -0.005, 0.005, 1e15, -1e300, np.nan, -np.inf, 199999.995, 200000.0]])
+    assert mismatches(ll, 2) == []
