@@ -410,15 +410,17 @@ int miso_aln_fetch(const miso_alnfile_t *f, int ref, int64_t start, int64_t end,
   return 0;
 }
 
-int miso_aln_parse_reads(const miso_alnfile_t *f, int ref, int64_t start, int64_t end, int paired,
-                         int strand_rule, int target_strand, int given_read_len,
-                         int32_t *positions, int64_t pos_cap, char *cigar_buf, int64_t cigar_cap,
-                         int64_t *n_reads, int64_t *cigar_bytes, int64_t *n_strand_discarded) {
-  if (!f || !n_reads || !cigar_bytes) return fail(MISO_EINVAL, "miso_aln_parse_reads: null argument");
+}  // extern "C"
+
+// one pass, growing buffers: what miso_batch_add_event_aln (capi.hip) uses directly
+int miso_aln_collect_reads(const miso_alnfile_t *f, int ref, int64_t start, int64_t end, int paired,
+                           int strand_rule, int target_strand, int given_read_len,
+                           std::vector<int32_t> &pos_out, std::string &cig_out, int64_t *n_reads,
+                           int64_t *n_strand_discarded) {
+  if (!f || !n_reads) return fail(MISO_EINVAL, "miso_aln_parse_reads: null argument");
   if (strand_rule != MISO_STRAND_UNSTRANDED && strand_rule != MISO_STRAND_FIRSTSTRAND)
     return fail(MISO_EINVAL, "miso_aln_parse_reads: unknown strand rule");
-  std::vector<int32_t> pos_out;
-  std::string cig_out;
+  pos_out.clear(); cig_out.clear();
   int64_t kept = 0, discarded = 0;
   const bool check_strand = strand_rule == MISO_STRAND_FIRSTSTRAND && target_strand != 0;  // sam_utils.py:385-390
   auto minus = [&](int64_t i) { return (f->flag[i] & 16) != 0; };
@@ -485,11 +487,24 @@ int miso_aln_parse_reads(const miso_alnfile_t *f, int ref, int64_t start, int64_
     return fail(MISO_ENOMEM, "out of memory collecting the reads of an event");
   }
   *n_reads = kept;
-  *cigar_bytes = static_cast<int64_t>(cig_out.size());
   if (n_strand_discarded) *n_strand_discarded = discarded;
+  return 0;
+}
+
+
+extern "C" int miso_aln_parse_reads(const miso_alnfile_t *f, int ref, int64_t start, int64_t end, int paired,
+                                    int strand_rule, int target_strand, int given_read_len,
+                                    int32_t *positions, int64_t pos_cap, char *cigar_buf, int64_t cigar_cap,
+                                    int64_t *n_reads, int64_t *cigar_bytes, int64_t *n_strand_discarded) {
+  if (!f || !n_reads || !cigar_bytes) return fail(MISO_EINVAL, "miso_aln_parse_reads: null argument");
+  thread_local std::vector<int32_t> pos_out;
+  thread_local std::string cig_out;
+  const int rc = miso_aln_collect_reads(f, ref, start, end, paired, strand_rule, target_strand,
+                                        given_read_len, pos_out, cig_out, n_reads, n_strand_discarded);
+  if (rc) return rc;
+  *cigar_bytes = static_cast<int64_t>(cig_out.size());
   if (positions) std::memcpy(positions, pos_out.data(), 4 * static_cast<size_t>(std::min<int64_t>(pos_cap, pos_out.size())));
   if (cigar_buf) std::memcpy(cigar_buf, cig_out.data(), static_cast<size_t>(std::min<int64_t>(cigar_cap, cig_out.size())));
   return 0;
 }
 
-}  // extern "C"

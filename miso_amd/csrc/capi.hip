@@ -17,6 +17,12 @@
 #include "batch.hpp"
 #include "miso_alnio.h"
 
+// alnio.cpp: one event's reads into growing buffers (the C entry point wraps it)
+int miso_aln_collect_reads(const miso_alnfile_t *f, int ref, int64_t start, int64_t end, int paired,
+                           int strand_rule, int target_strand, int given_read_len,
+                           std::vector<int32_t> &pos_out, std::string &cig_out, int64_t *n_reads,
+                           int64_t *n_strand_discarded);
+
 using namespace miso;
 
 struct miso_gene { Gene g; };
@@ -338,34 +344,23 @@ int miso_batch_add_event_aln(miso_batch_t *b, const miso_gene_t *gene, const mis
                              int given_read_len, int64_t min_reads, const double *hyperp, int n_hyperp,
                              int64_t *n_reads, int *event_index) {
   if (event_index) *event_index = -1;
-  int64_t n = 0, nb = 0;
+  int64_t n = 0;
+  thread_local std::vector<int32_t> pos;
+  thread_local std::string cig;
+  thread_local std::vector<const char *> cptr;
   int rc = guarded([&] {
     need(b, "batch"); need(gene, "gene"); need(f, "alignment file");
-    const int paired = b->p.paired ? 1 : 0;
-    if (miso_aln_parse_reads(f, ref, start, end, paired, strand_rule, target_strand, given_read_len,
-                             nullptr, 0, nullptr, 0, &n, &nb, nullptr))
+    if (miso_aln_collect_reads(f, ref, start, end, b->p.paired ? 1 : 0, strand_rule, target_strand,
+                               given_read_len, pos, cig, &n, nullptr))
       MISO_FAIL(MISO_EINVAL, std::string("alignment reader: ") + miso_aln_last_error());
   });
   if (rc) return rc;
   if (n_reads) *n_reads = n;
   if (n == 0 || n < min_reads) return MISO_SUCCESS;   // the caller's skip rules (run_miso.py:139-147)
-  std::vector<int32_t> pos;
-  std::vector<char> cig;
-  std::vector<const char *> cptr;
-  rc = guarded([&] {
-    const int paired = b->p.paired ? 1 : 0;
-    const int64_t npos = n * (paired ? 2 : 1);
-    pos.resize(npos); cig.resize(nb + 1);
-    int64_t n2 = 0, nb2 = 0;
-    if (miso_aln_parse_reads(f, ref, start, end, paired, strand_rule, target_strand, given_read_len,
-                             pos.data(), npos, cig.data(), nb, &n2, &nb2, nullptr) || n2 != n || nb2 != nb)
-      MISO_FAIL(MISO_EINTERNAL, "alignment reader changed its answer");
-    for (auto &p : pos) p += 1;                        // 0-based -> 1-based (miso_sampler.py:284)
-    cptr.reserve(npos);
-    const char *c = cig.data();
-    for (int64_t i = 0; i < npos; i++) { cptr.push_back(c); c += std::strlen(c) + 1; }
-  });
-  if (rc) return rc;
+  for (auto &p : pos) p += 1;                          // 0-based -> 1-based (miso_sampler.py:284)
+  cptr.clear();
+  const char *c = cig.data();
+  for (size_t i = 0; i < pos.size(); i++) { cptr.push_back(c); c += std::strlen(c) + 1; }
   return miso_batch_add_event(b, gene, pos.data(), cptr.data(), static_cast<int>(pos.size()), hyperp,
                               n_hyperp, event_index);
 }
