@@ -104,6 +104,9 @@ int miso_batch_add_event_aln(struct miso_batch *batch, const struct miso_gene *g
                              int strand_rule, int target_strand, int given_read_len, int64_t min_reads,
                              const double *hyperp, int n_hyperp, int64_t *n_reads, int *event_index);
 
+/* host threads the library uses by default: affinity mask capped by the cgroup CPU quota, <= 64 */
+int miso_usable_threads(void);
+
 const char *miso_aln_last_error(void);
 
 #ifdef __cplusplus

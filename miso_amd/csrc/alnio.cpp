@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cerrno>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -183,7 +184,7 @@ int inflate_all(const Mapped &m, int n_threads, std::vector<unsigned char> &out)
   return 0;
 }
 
-int parse_bam(const std::vector<unsigned char> &d, miso_alnfile &f) {
+int parse_bam(const std::vector<unsigned char> &d, miso_alnfile &f, int n_threads) {
   const size_t n = d.size();
   size_t o = 0;
   auto need = [&](size_t k) { return o + k <= n; };
@@ -202,24 +203,51 @@ int parse_bam(const std::vector<unsigned char> &d, miso_alnfile &f) {
     f.ref_index.emplace(name, static_cast<int>(f.ref_names.size()));
     f.ref_names.push_back(std::move(name));
   }
-  std::vector<uint32_t> tmp;
+  // pass 1 (serial, a few ns per record): where every record starts, and the running totals of CIGAR
+  // operations and name bytes, so that pass 2 can fill preallocated columns from all threads
+  std::vector<size_t> rec;
   while (o < n) {
     if (!need(4)) return fail(MISO_EINVAL, "truncated BAM record");
-    const uint32_t bs = rd32(d.data() + o); o += 4;
-    if (bs < 32 || !need(bs)) return fail(MISO_EINVAL, "truncated BAM record");
-    const unsigned char *r = d.data() + o;
-    const int32_t rid = static_cast<int32_t>(rd32(r)), p = static_cast<int32_t>(rd32(r + 4));
-    const uint32_t l_name = r[8];
-    const uint32_t n_cig = rd16(r + 12), fl = rd16(r + 14);
-    const int32_t l_seq = static_cast<int32_t>(rd32(r + 16));
+    const uint32_t bs = rd32(d.data() + o);
+    if (bs < 32 || o + 4 + static_cast<size_t>(bs) > n) return fail(MISO_EINVAL, "truncated BAM record");
+    const unsigned char *r = d.data() + o + 4;
+    const uint32_t l_name = r[8], n_cig = rd16(r + 12);
     if (32 + static_cast<size_t>(l_name) + 4 * static_cast<size_t>(n_cig) > bs || l_name == 0)
       return fail(MISO_EINVAL, "malformed BAM record");
-    const char *name = reinterpret_cast<const char *>(r + 32);
-    tmp.resize(n_cig);  // the cigar may be unaligned inside the record
-    if (n_cig) std::memcpy(tmp.data(), r + 32 + l_name, 4 * static_cast<size_t>(n_cig));
-    f.push(rid, p, static_cast<int32_t>(fl), l_seq, tmp.data(), n_cig, name, l_name - 1);
-    o += bs;
+    rec.push_back(o + 4);
+    f.cigar_off.push_back(f.cigar_off.back() + n_cig);
+    f.name_off.push_back(f.name_off.back() + (l_name - 1));
+    o += 4 + static_cast<size_t>(bs);
   }
+  const size_t N = rec.size();
+  f.ref_id.resize(N); f.pos.resize(N); f.end.resize(N); f.flag.resize(N); f.l_seq.resize(N);
+  f.cigar.resize(f.cigar_off.back());
+  f.names.resize(f.name_off.back());
+  auto fill = [&](size_t lo, size_t hi) {
+    for (size_t i = lo; i < hi; i++) {
+      const unsigned char *r = d.data() + rec[i];
+      const int32_t p = static_cast<int32_t>(rd32(r + 4));
+      const uint32_t l_name = r[8], n_cig = rd16(r + 12), fl = rd16(r + 14);
+      uint32_t *cg = f.cigar.data() + f.cigar_off[i];
+      if (n_cig) std::memcpy(cg, r + 32 + l_name, 4 * static_cast<size_t>(n_cig));   // unaligned in the record
+      int64_t reflen = 0;
+      for (uint32_t c = 0; c < n_cig; c++) {
+        const uint32_t op = cg[c] & 15u;
+        if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) reflen += cg[c] >> 4;
+      }
+      f.ref_id[i] = static_cast<int32_t>(rd32(r));
+      f.pos[i] = p;
+      f.end[i] = ((fl & 4) || reflen == 0) ? p + 1 : static_cast<int32_t>(p + reflen);   // bam_endpos
+      f.flag[i] = static_cast<int32_t>(fl);
+      f.l_seq[i] = static_cast<int32_t>(rd32(r + 16));
+      std::memcpy(f.names.data() + f.name_off[i], r + 32, l_name - 1);
+    }
+  };
+  const size_t T = std::max<size_t>(1, std::min<size_t>(static_cast<size_t>(n_threads), N / 65536 + 1));
+  std::vector<std::thread> th;
+  for (size_t t = 1; t < T; t++) th.emplace_back(fill, N * t / T, N * (t + 1) / T);
+  fill(0, N / T);
+  for (auto &t : th) t.join();
   return 0;
 }
 
@@ -298,12 +326,25 @@ int parse_sam(const unsigned char *p, size_t len, miso_alnfile &f) {
   return 0;
 }
 
-int usable_threads() {
+}  // namespace
+
+// host threads this process may really use: affinity mask capped by the cgroup CPU quota
+extern "C" int miso_usable_threads(void) {
   long n = sysconf(_SC_NPROCESSORS_ONLN);
   cpu_set_t set;
   if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min<long>(n, CPU_COUNT(&set));
+  if (FILE *fp = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char quota[32]; long period = 0;
+    if (std::fscanf(fp, "%31s %ld", quota, &period) == 2 && std::strcmp(quota, "max") != 0 && period > 0)
+      n = std::min<long>(n, std::max<long>(1, std::atol(quota) / period));
+    std::fclose(fp);
+  }
   return static_cast<int>(std::max<long>(1, std::min<long>(n, 64)));
 }
+
+namespace {
+
+int usable_threads() { return miso_usable_threads(); }
 
 void append_cigar_string(const miso_alnfile &f, int64_t i, std::string &out) {
   char buf[16];
@@ -351,13 +392,26 @@ int miso_aln_open(const char *path, int n_threads, miso_alnfile_t **out) {
     if (m.len >= 2 && m.p[0] == 31 && m.p[1] == 139) {
       f->is_bam = true;
       std::vector<unsigned char> data;
-      rc = inflate_all(m, n_threads > 0 ? n_threads : usable_threads(), data);
-      if (rc == 0) rc = parse_bam(data, *f);
+      const int T = n_threads > 0 ? n_threads : usable_threads();
+      const bool timing = std::getenv("MISO_TIMING") != nullptr;
+      const auto t0 = std::chrono::steady_clock::now();
+      rc = inflate_all(m, T, data);
+      const auto t1 = std::chrono::steady_clock::now();
+      if (rc == 0) rc = parse_bam(data, *f, T);
+      const auto t2 = std::chrono::steady_clock::now();
+      if (timing)
+        std::fprintf(stderr, "miso_aln_open: %d threads, inflate %.3f s (%.0f MB), records %.3f s\n", T,
+                     std::chrono::duration<double>(t1 - t0).count(), data.size() / 1e6,
+                     std::chrono::duration<double>(t2 - t1).count());
     } else {
       rc = parse_sam(m.p, m.len, *f);
     }
     if (rc != 0) { delete f; return rc; }
+    const auto t3 = std::chrono::steady_clock::now();
     f->build_index();
+    if (std::getenv("MISO_TIMING"))
+      std::fprintf(stderr, "miso_aln_open: index %.3f s\n",
+                   std::chrono::duration<double>(std::chrono::steady_clock::now() - t3).count());
   } catch (const std::bad_alloc &) {
     delete f;
     return fail(MISO_ENOMEM, "out of memory reading the alignment file");

@@ -17,6 +17,7 @@
 #include "batch.hpp"
 #include "miso_alnio.h"
 
+extern "C" int miso_usable_threads(void);   // alnio.cpp: affinity mask capped by the cgroup quota
 // alnio.cpp: one event's reads into growing buffers (the C entry point wraps it)
 int miso_aln_collect_reads(const miso_alnfile_t *f, int ref, int64_t start, int64_t end, int paired,
                            int strand_rule, int target_strand, int given_read_len,
@@ -384,7 +385,7 @@ int miso_batch_write_miso_files(const miso_batch_t *b, int n, const int *event_i
     if (n < 0 || (n > 0 && (!event_index || !paths || !headers))) MISO_FAIL(MISO_EINVAL, "null argument");
     if (!b->downloaded) MISO_FAIL(MISO_EINVAL, "results not downloaded yet");
     for (int j = 0; j < n; j++) { (void) event_at(b, event_index[j]); need(paths[j], "path"); need(headers[j], "header"); }
-    int T = n_threads > 0 ? n_threads : static_cast<int>(std::thread::hardware_concurrency());
+    int T = n_threads > 0 ? n_threads : miso_usable_threads();
     T = std::max(1, std::min(T, std::min(n, 64)));
     std::atomic<int> next{0};
     std::mutex mu; std::string first_error; int first_code = 0;

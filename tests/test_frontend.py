@@ -274,3 +274,37 @@ def test_settings(tmp_path):
     assert Settings.get_min_event_reads() == 5 and Settings.get_strand_param() == "fr-firststrand"
     assert Settings.get()["cluster_command"] == "long"
     Settings.load(None)
+
+
+def test_dispatcher_chunks_like_the_reference(tmp_path, bam_path, monkeypatch):
+    """miso.py:152-186 / cluster_utils.py:23-32: contiguous chunks of the gene list, one per GPU,
+    each knowing the global index of its first event (results independent of the split)."""
+    from miso_amd import miso as miso_cli
+    idx = str(tmp_path / "indexed")
+    genes = tmp_path / "many.gff"
+    lines = ["##gff-version 3"]
+    for g in range(11):
+        s = 1000 + 10000 * g
+        lines += ["chr1\tx\tgene\t%d\t%d\t.\t+\t.\tID=g%02d" % (s, s + 900, g),
+                  "chr1\tx\tmRNA\t%d\t%d\t.\t+\t.\tID=g%02d.A;Parent=g%02d" % (s, s + 900, g, g),
+                  "chr1\tx\texon\t%d\t%d\t.\t+\t.\tID=g%02d.A.1;Parent=g%02d.A" % (s, s + 100, g, g),
+                  "chr1\tx\texon\t%d\t%d\t.\t+\t.\tID=g%02d.A.2;Parent=g%02d.A" % (s + 800, s + 900, g, g),
+                  "chr1\tx\tmRNA\t%d\t%d\t.\t+\t.\tID=g%02d.B;Parent=g%02d" % (s, s + 900, g, g),
+                  "chr1\tx\texon\t%d\t%d\t.\t+\t.\tID=g%02d.B.1;Parent=g%02d.B" % (s, s + 100, g, g),
+                  "chr1\tx\texon\t%d\t%d\t.\t+\t.\tID=g%02d.B.2;Parent=g%02d.B" % (s + 400, s + 500, g, g),
+                  "chr1\tx\texon\t%d\t%d\t.\t+\t.\tID=g%02d.B.3;Parent=g%02d.B" % (s + 800, s + 900, g, g)]
+    genes.write_text("\n".join(lines) + "\n")
+    index_gff.index_gff(str(genes), idx)
+    assert miso_cli.chunk_list(list(range(11)), 4) == [[0, 1], [2, 3, 4], [5, 6, 7], [8, 9, 10]]
+    assert miso_cli.chunk_list(list(range(3)), 1) == [[0, 1, 2]]
+    d = miso_cli.GenesDispatcher(idx, bam_path, str(tmp_path / "out"), 36, 1, num_proc=4, seed=3)
+    batches = d.output_batch_files()
+    assert [(n, first) for _, n, first in batches] == [(2, 0), (3, 2), (3, 5), (3, 8)]
+    seen = []
+    for fname, n, first in batches:
+        entries = run_miso.read_genes_file(fname)
+        assert len(entries) == n and all(os.path.isfile(p) for _, p in entries)
+        seen += [g for g, _ in entries]
+    assert seen == ["g%02d" % g for g in range(11)]
+    with pytest.raises(IOError):
+        miso_cli.GenesDispatcher(idx, str(tmp_path / "no.bam"), str(tmp_path / "o2"), 36, 1, num_proc=1)
