@@ -349,9 +349,11 @@ int usable_threads() { return miso_usable_threads(); }
 void append_cigar_string(const miso_alnfile &f, int64_t i, std::string &out) {
   char buf[16];
   for (uint64_t c = f.cigar_off[i]; c < f.cigar_off[i + 1]; c++) {
-    const uint32_t v = f.cigar[c], op = v & 15u;
-    const int k = std::snprintf(buf, sizeof buf, "%u", v >> 4);
-    out.append(buf, k);
+    uint32_t v = f.cigar[c] >> 4;
+    const uint32_t op = f.cigar[c] & 15u;
+    int k = 0;
+    do { buf[k++] = static_cast<char>('0' + v % 10); v /= 10; } while (v);
+    while (k) out.push_back(buf[--k]);
     out.push_back(op < 9 ? kCigarOps[op] : '?');
   }
   out.push_back('\0');
