@@ -442,7 +442,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   // with more than two isoforms times a few iterations of the rule of thumb's choice and of the next
   // larger ones on the batch itself and keeps the fastest (K=5: 58k -> 81k events/s) (the trial launches record nothing: burn-in = their length; what they leave in the
   // output pool is rewritten by the real launch).  MISO_NO_AUTOTUNE=1 keeps the rule of thumb.
-  const bool tune = std::getenv("MISO_NO_AUTOTUNE") == nullptr && p.noIterations >= 400;
+  const bool tune = std::getenv("MISO_NO_AUTOTUNE") == nullptr && p.noIterations >= 2000;   // ~400 trial iterations: <= 20 % of a one-shot run
   auto fastest = [&](const std::vector<int> &cand, auto &&trial) {
     // per-iteration cost = slope between a short and a longer trial (set-up, launch and code-object
     // load cancel); ~200 iterations per candidate
