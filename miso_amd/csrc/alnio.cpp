@@ -251,7 +251,9 @@ int parse_bam(const std::vector<unsigned char> &d, miso_alnfile &f, int n_thread
   return 0;
 }
 
-int parse_sam(const unsigned char *p, size_t len, miso_alnfile &f) {
+// strict: a reference name missing from the header is an error for this chunk (the caller then falls
+// back to one serial pass, which numbers header-less references in order of appearance)
+int parse_sam(const unsigned char *p, size_t len, miso_alnfile &f, bool strict = false) {
   const char *s = reinterpret_cast<const char *>(p), *e = s + len;
   std::vector<uint32_t> cg;
   size_t lineno = 0;
@@ -296,6 +298,7 @@ int parse_sam(const unsigned char *p, size_t len, miso_alnfile &f) {
     int32_t rid = -1;
     if (rname != "*") {
       auto it = f.ref_index.find(rname);
+      if (it == f.ref_index.end() && strict) return fail(MISO_FAILURE, "reference not in the header");
       if (it == f.ref_index.end()) {  // header-less SAM: references in order of appearance
         rid = static_cast<int32_t>(f.ref_names.size());
         f.ref_index.emplace(rname, rid);
@@ -326,6 +329,68 @@ int parse_sam(const unsigned char *p, size_t len, miso_alnfile &f) {
   return 0;
 }
 
+
+// SAM text on all cores: the header serially, then the records in chunks cut at line ends, each into
+// its own columns, concatenated in file order.
+int parse_sam_parallel(const unsigned char *p, size_t len, miso_alnfile &f, int n_threads) {
+  const char *s = reinterpret_cast<const char *>(p), *e = s + len;
+  const char *body = s;
+  while (body < e && *body == '@') {
+    const char *nl = static_cast<const char *>(std::memchr(body, '\n', e - body));
+    body = nl ? nl + 1 : e;
+  }
+  const size_t body_len = static_cast<size_t>(e - body);
+  const int T = static_cast<int>(std::max<size_t>(1, std::min<size_t>(static_cast<size_t>(n_threads), body_len >> 22)));
+  if (T <= 1) return parse_sam(p, len, f);
+  int rc = parse_sam(p, static_cast<size_t>(body - s), f);   // header only
+  if (rc) return rc;
+  std::vector<const char *> cut(T + 1, e);
+  cut[0] = body;
+  for (int t = 1; t < T; t++) {
+    const char *q = body + body_len * t / T;
+    const char *nl = static_cast<const char *>(std::memchr(q, '\n', e - q));
+    cut[t] = nl ? nl + 1 : e;
+  }
+  std::vector<miso_alnfile> part(T);
+  std::vector<int> prc(T, 0);
+  std::vector<std::string> perr(T);
+  auto work = [&](int t) {
+    part[t].ref_names = f.ref_names; part[t].ref_len = f.ref_len; part[t].ref_index = f.ref_index;
+    prc[t] = parse_sam(reinterpret_cast<const unsigned char *>(cut[t]), static_cast<size_t>(cut[t + 1] - cut[t]),
+                       part[t], true);
+    if (prc[t]) perr[t] = g_err;
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < T; t++) th.emplace_back(work, t);
+  work(0);
+  for (auto &x : th) x.join();
+  for (int t = 0; t < T; t++) {
+    if (prc[t] == MISO_FAILURE) {   // a reference the header does not list: serial pass
+      f = miso_alnfile();
+      return parse_sam(p, len, f);
+    }
+    if (prc[t]) return fail(prc[t], perr[t] + " (line numbers count from the start of a " +
+                                    std::to_string(T) + "-way split)");
+  }
+  size_t n = 0, nc = 0, nn = 0;
+  for (auto &q : part) { n += q.pos.size(); nc += q.cigar.size(); nn += q.names.size(); }
+  f.ref_id.reserve(n); f.pos.reserve(n); f.end.reserve(n); f.flag.reserve(n); f.l_seq.reserve(n);
+  f.cigar.reserve(nc); f.names.reserve(nn); f.cigar_off.reserve(n + 1); f.name_off.reserve(n + 1);
+  for (auto &q : part) {
+    f.ref_id.insert(f.ref_id.end(), q.ref_id.begin(), q.ref_id.end());
+    f.pos.insert(f.pos.end(), q.pos.begin(), q.pos.end());
+    f.end.insert(f.end.end(), q.end.begin(), q.end.end());
+    f.flag.insert(f.flag.end(), q.flag.begin(), q.flag.end());
+    f.l_seq.insert(f.l_seq.end(), q.l_seq.begin(), q.l_seq.end());
+    const uint64_t c0 = f.cigar.size(), n0 = f.names.size();
+    f.cigar.insert(f.cigar.end(), q.cigar.begin(), q.cigar.end());
+    f.names.insert(f.names.end(), q.names.begin(), q.names.end());
+    for (size_t i = 1; i < q.cigar_off.size(); i++) f.cigar_off.push_back(c0 + q.cigar_off[i]);
+    for (size_t i = 1; i < q.name_off.size(); i++) f.name_off.push_back(n0 + q.name_off[i]);
+    q = miso_alnfile();
+  }
+  return 0;
+}
 }  // namespace
 
 // host threads this process may really use: affinity mask capped by the cgroup CPU quota
@@ -406,7 +471,7 @@ int miso_aln_open(const char *path, int n_threads, miso_alnfile_t **out) {
                      std::chrono::duration<double>(t1 - t0).count(), data.size() / 1e6,
                      std::chrono::duration<double>(t2 - t1).count());
     } else {
-      rc = parse_sam(m.p, m.len, *f);
+      rc = parse_sam_parallel(m.p, m.len, *f, n_threads > 0 ? n_threads : usable_threads());
     }
     if (rc != 0) { delete f; return rc; }
     const auto t3 = std::chrono::steady_clock::now();

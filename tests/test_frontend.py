@@ -308,3 +308,26 @@ def test_dispatcher_chunks_like_the_reference(tmp_path, bam_path, monkeypatch):
     assert seen == ["g%02d" % g for g in range(11)]
     with pytest.raises(IOError):
         miso_cli.GenesDispatcher(idx, str(tmp_path / "no.bam"), str(tmp_path / "o2"), 36, 1, num_proc=1)
+
+
+def test_parallel_sam_parse_equals_serial(tmp_path, sam_text):
+    lines = sam_text.splitlines()
+    head = [l for l in lines if l.startswith("@")]
+    body = [l for l in lines if not l.startswith("@")]
+    big = tmp_path / "big.sam"
+    with open(big, "w") as f:
+        f.write("\n".join(head) + "\n")
+        for rep in range(40):                                 # ~22 MB: several 4 MB chunks per thread
+            f.write("\n".join(body) + "\n")
+    a = sam_utils.Samfile(str(big), threads=1)
+    b = sam_utils.Samfile(str(big), threads=5)
+    assert len(a) == len(b) == 40 * len(body)
+    for col in ("ref_id", "pos", "end", "flag", "l_seq", "cigar_off", "cigar", "name_off"):
+        assert np.array_equal(getattr(a, col), getattr(b, col)), col
+    assert a.names == b.names and a.references == b.references
+    # a reference the header does not list: the parallel path hands over to the serial one
+    with open(big, "a") as f:
+        f.write("late\t0\tchrUn\t5\t255\t36M\t*\t0\t0\t%s\t%s\n" % ("A" * 36, "I" * 36))
+    c = sam_utils.Samfile(str(big), threads=5)
+    assert len(c) == len(a) + 1 and c.references[-1] == "chrUn"
+    assert c.fetch("chrUn", 0, 100)[0].qname == "late"
