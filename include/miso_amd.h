@@ -171,6 +171,11 @@ int miso_batch_add_simulated(miso_batch_t *batch, const miso_gene_t *gene,
 int miso_batch_size(const miso_batch_t *batch, int *n_events);
 
 /* pack + copy to HBM (idempotent) */
+/* The random stream of an event is addressed by (seed, event id): by default first_event_id (a launch
+ * argument) + the event's index in the batch.  A caller that drops events between numbering and
+ * batching (skip rules) pins the id here instead, so results do not depend on batch composition,
+ * chunk size or the number of GPUs.  Before miso_batch_upload. */
+int miso_batch_set_event_id(miso_batch_t *batch, int event_index, uint32_t event_id);
 int miso_batch_upload(miso_batch_t *batch, int device);
 /* enqueue the sampler kernels for every event on the batch's stream; returns immediately */
 int miso_batch_launch(miso_batch_t *batch, uint64_t seed, uint32_t first_event_id);

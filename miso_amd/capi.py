@@ -193,6 +193,10 @@ class Batch:
                                          _p(hy), 0 if hy is None else len(hy), C.byref(idx)))
         return idx.value
 
+    def set_event_id(self, idx, event_id):
+        """Pin event idx's id in the Philox counter (default: first_event_id + idx)."""
+        check(lib().miso_batch_set_event_id(self.handle, int(idx), C.c_uint32(int(event_id) & 0xFFFFFFFF)))
+
     def add_problem(self, match, isolen, noexons, fraglen=None, hyper=None):
         """match: [N, K] (C-order) as Gene.match_iso returns it."""
         match = np.ascontiguousarray(match, dtype=np.float64)

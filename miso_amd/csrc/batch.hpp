@@ -23,6 +23,7 @@ struct miso_batch {
   miso_params_t p{};
   miso::FragmentDist fd;                 // paired only
   std::vector<miso::PackedEvent> events;
+  std::vector<int64_t> event_ids;        // per event: explicit Philox event id, -1 = first_event_id + index
   // device
   int device = -1;
   bool uploaded = false, launched = false, downloaded = false;

@@ -277,6 +277,15 @@ int miso_batch_add_simulated(miso_batch_t *b, const miso_gene_t *gene, const dou
 int miso_batch_size(const miso_batch_t *b, int *n) {
   return guarded([&] { need(b, "batch"); need(n, "n_events"); *n = static_cast<int>(b->events.size()); });
 }
+int miso_batch_set_event_id(miso_batch_t *b, int event_index, uint32_t event_id) {
+  return guarded([&] {
+    need(b, "batch");
+    (void) event_at(b, event_index);
+    if (b->uploaded) MISO_FAIL(MISO_EINVAL, "batch already uploaded");
+    if (b->event_ids.size() < b->events.size()) b->event_ids.resize(b->events.size(), -1);
+    b->event_ids[event_index] = static_cast<int64_t>(event_id);
+  });
+}
 int miso_batch_upload(miso_batch_t *b, int device) {
   return guarded([&] { need(b, "batch"); b->upload(device); });
 }

@@ -31,6 +31,8 @@ struct DevEvent {
   int32_t n_units;     // SE: number of work units (Philox blocks x classes touching them)
   int32_t max_cls;     // SE: most isoforms any drawing class is compatible with
   int32_t n_pairs;     // SE: sum over classes of (isoforms - 1)
+  uint32_t explicit_id;// the event's id in the Philox counter when has_id (else first_event_id + index)
+  int32_t has_id;
   uint64_t off_sfix;   // PE: int32[K x il] fixed-point scores, MISO_SFIX_BAD = non-finite
   // byte offsets into the output pool
   uint64_t off_samples; // double[S x K]  (reference layout: K x S column-major)

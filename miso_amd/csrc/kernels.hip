@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void sampler_wave(const KernelArgs a) {
   const uint32_t chain = static_cast<uint32_t>(slot % a.C);
   const DevEvent E = a.events[ev];
   const int K = E.K;
-  const uint32_t event_id = a.first_event_id + static_cast<uint32_t>(ev);
+  const uint32_t event_id = E.has_id ? E.explicit_id : a.first_event_id + static_cast<uint32_t>(ev);
   const double *consts = reinterpret_cast<const double *>(a.in_pool + E.off_consts);
   const int *base = reinterpret_cast<const int *>(a.in_pool + E.off_base);
 

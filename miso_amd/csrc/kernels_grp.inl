@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256, KC <= 8 ? MISO_GRP_MINBLOCKS : 2) void sampler
   // divergent loop with exec masking and an LDS wait per step (measured: 8x slower read loop)
   Kw = __builtin_amdgcn_readfirstlane(Kw);
   nqw = __builtin_amdgcn_readfirstlane(nqw);
-  const uint32_t event_id = a.first_event_id + static_cast<uint32_t>(ev);
+  const uint32_t event_id = E.has_id ? E.explicit_id : a.first_event_id + static_cast<uint32_t>(ev);
   const double *consts = reinterpret_cast<const double *>(a.in_pool + E.off_consts);
   const int *base = reinterpret_cast<const int *>(a.in_pool + E.off_base);
   for (int k0 = 0; k0 < Kw; k0 += G) {

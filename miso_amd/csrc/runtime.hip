@@ -246,6 +246,9 @@ void miso_batch::upload(int dev) {
     DevEvent &d = h_events[i];
     d.K = e.K; d.n_draw = e.n_draw; d.n_reads = e.N; d.base_bad = e.base_bad;
     d.base_sfix = e.base_sfix;
+    if (i < static_cast<int>(event_ids.size()) && event_ids[i] >= 0) {
+      d.has_id = 1; d.explicit_id = static_cast<uint32_t>(event_ids[i]);
+    }
     d.off_consts = in_off; in_off = align_up(in_off + e.consts.size() * 8, 16);
     d.off_base = in_off; in_off = align_up(in_off + e.base_count.size() * 4, 16);
     d.off_draw = in_off;

@@ -11,6 +11,7 @@ from collections import OrderedDict, defaultdict
 from urllib.parse import unquote as url_unquote
 
 INDEX_MAP_BASENAME = "genes_to_filenames.json"
+BUNDLE_BASENAME = "genes_bundle.pickle"
 
 
 class FormatError(Exception):

@@ -22,6 +22,8 @@ if _HERE not in sys.path:
     sys.path.insert(0, _HERE)
 import pysplicing  # noqa: E402  (miso_amd/pysplicing)
 import capi  # noqa: E402  (miso_amd/capi.py: the batch object behind run_sampler_batch)
+
+capi.InternalError = pysplicing.InternalError   # one exception type for callers of this module
 import summary  # noqa: E402  (miso_amd/summary.py)
 import compare  # noqa: E402  (miso_amd/compare.py)
 
@@ -159,14 +161,26 @@ class MISOSampler:
                           start_cond=pysplicing.MISO_START_AUTO,
                           stop_cond=pysplicing.MISO_STOP_FIXEDNO, seed=None, first_event_id=0,
                           verbose=False, summary_file=None, confidence_level=0.95, threads=0):
-        """events: list of (reads, gene, output_file[, prior_params]); `reads` is the reference's
-        (positions 0-based, cigars) pair or an AlnRegion.  Same per-event skip rules as run_sampler
+        """events: list of (reads, gene, output_file[, prior_params[, event_id]]); `reads` is the
+        reference's (positions 0-based, cigars) pair or an AlnRegion; event_id pins the event's
+        random stream (default: first_event_id + its position among the events actually sampled).  Same per-event skip rules as run_sampler
         (no reads, output exists, one isoform, all reads incompatible).  One GPU batch; the `.miso`
         files are formatted and written by native threads (miso_batch_write_miso_files) -- at 5000
         rows per event Python's row loop would take longer than everything else together.
         Returns the list of written file names (None for skipped events).
         summary_file: also write the `summarize_miso` table (samples_utils.py:263-329) for the
-        events of this batch, from means / credible intervals computed on the device."""
+        events of this batch, from means / credible intervals computed on the device.
+        = prepare_batch (host: skip rules, reads into the batch) + finish_batch (GPU + files); a caller
+        with several batches can overlap one's finish with the next one's prepare (run_miso.py)."""
+        state = self.prepare_batch(num_iters, events, num_chains=num_chains, burn_in=burn_in, lag=lag,
+                                   start_cond=start_cond, stop_cond=stop_cond, verbose=verbose)
+        return self.finish_batch(state, seed=seed, first_event_id=first_event_id, verbose=verbose,
+                                 summary_file=summary_file, confidence_level=confidence_level,
+                                 threads=threads)
+
+    def prepare_batch(self, num_iters, events, num_chains=6, burn_in=1000, lag=2,
+                      start_cond=pysplicing.MISO_START_AUTO, stop_cond=pysplicing.MISO_STOP_FIXEDNO,
+                      verbose=False):
         self.params.update(iters=num_iters, burn_in=burn_in, lag=lag)
         batch = capi.Batch(int(self.params["read_len"]), iters=int(num_iters), burn=int(burn_in),
                            lag=int(lag), chains=int(num_chains),
@@ -211,7 +225,14 @@ class MISOSampler:
             else:
                 pos = np.asarray(reads[0], dtype=np.int64) + 1            # 0-based -> 1-based (:284)
                 idx = batch.add_event(c_gene, pos.astype(np.int32), list(reads[1]), hyper)
+            if len(ev) > 4 and ev[4] is not None:
+                batch.set_event_id(idx, ev[4])          # the event's global number (see run_miso.py)
             slots.append((i, idx, gene, out))
+        return (batch, slots, written, int(num_iters), int(burn_in), int(lag))
+
+    def finish_batch(self, state, seed=None, first_event_id=0, verbose=False, summary_file=None,
+                     confidence_level=0.95, threads=0):
+        batch, slots, written, num_iters, burn_in, lag = state
         if not slots:
             return written
         dev = int(os.environ.get("MISO_DEVICE", os.environ.get("LOCAL_RANK", "0")))

@@ -32,7 +32,7 @@ def collect_gene_events(gene_entries, bamfile, output_dir, read_len, overhang_le
                         paired_end=None, event_type=None, verbose=True, native=False):
     """run_miso.py:98-206 up to (not including) sampler.run_sampler, for many genes.
     gene_entries: iterable of (gene_id, indexed_gff_filename).
-    Returns (events, info): events = [(reads, gene_obj, output_filename)] for
+    Returns (events, info): events = [(reads, gene_obj, output_filename, None, index in gene_entries)] for
     MISOSampler.run_sampler_batch, info = per gene status strings (for logs / tests)."""
     settings = Settings.get()
     min_event_reads = Settings.get_min_event_reads()
@@ -40,14 +40,22 @@ def collect_gene_events(gene_entries, bamfile, output_dir, read_len, overhang_le
     filter_reads = settings.get("filter_reads", True)               # run_miso.py:91-94
     events, info = [], {}
     loaded = {}
-    for gene_id, gff_index_filename in gene_entries:
-        if not os.path.exists(gff_index_filename):
-            print("Error: No GFF %s" % gff_index_filename)
-            info[gene_id] = "no index"
-            continue
-        if gff_index_filename not in loaded:
-            loaded = {gff_index_filename: gff_utils.load_indexed_gff_file(gff_index_filename)}
-        gff_genes = loaded[gff_index_filename]
+    bundles = {}      # index root -> {gene_id: gene_info} from genes_bundle.pickle (or None)
+    for entry_no, (gene_id, gff_index_filename) in enumerate(gene_entries):
+        root = os.path.dirname(os.path.dirname(gff_index_filename))
+        if root not in bundles:
+            bpath = os.path.join(root, gff_utils.BUNDLE_BASENAME)
+            bundles[root] = gff_utils.load_indexed_gff_file(bpath) if os.path.isfile(bpath) else None
+        if bundles[root] is not None and gene_id in bundles[root]:
+            gff_genes = {gene_id: bundles[root][gene_id]}
+        else:
+            if not os.path.exists(gff_index_filename):
+                print("Error: No GFF %s" % gff_index_filename)
+                info[gene_id] = "no index"
+                continue
+            if gff_index_filename not in loaded:
+                loaded = {gff_index_filename: gff_utils.load_indexed_gff_file(gff_index_filename)}
+            gff_genes = loaded[gff_index_filename]
         if gene_id not in gff_genes:
             info[gene_id] = "not in index"
             continue
@@ -77,7 +85,7 @@ def collect_gene_events(gene_entries, bamfile, output_dir, read_len, overhang_le
             region = miso.AlnRegion(bamfile, chrom, tx_start, tx_end, strand_rule=strand_rule,
                                     target_strand=gene_obj.strand, read_len=read_len,
                                     min_reads=min_event_reads if filter_reads else 0)
-            events.append((region, gene_obj, output_filename))
+            events.append((region, gene_obj, output_filename, None, entry_no))
             info[gene_id] = "region %s:%d-%d" % (chrom, tx_start, tx_end)
             continue
         try:
@@ -94,7 +102,7 @@ def collect_gene_events(gene_entries, bamfile, output_dir, read_len, overhang_le
                       % (num_raw_reads, min_event_reads))
             info[gene_id] = "only %d reads" % num_raw_reads
             continue
-        events.append((reads, gene_obj, output_filename))
+        events.append((reads, gene_obj, output_filename, None, entry_no))
         info[gene_id] = "%d reads" % num_raw_reads
     return events, info
 
@@ -102,7 +110,7 @@ def collect_gene_events(gene_entries, bamfile, output_dir, read_len, overhang_le
 def compute_gene_psi(gene_ids, gff_index_filename, bam_filename, output_dir, read_len,
                      overhang_len, paired_end=None, event_type=None, verbose=True, bamfile=None,
                      seed=None, first_event_id=0, device=None, gene_entries=None,
-                     max_events_per_launch=32768):
+                     max_events_per_launch=8192):
     """run_miso.py:34-206.  `gene_entries` (list of (gene_id, index file)) generalises the
     reference's (gene_ids, one index file) so a whole batch file is one GPU batch."""
     os.makedirs(output_dir, exist_ok=True)
@@ -130,18 +138,31 @@ def compute_gene_psi(gene_ids, gff_index_filename, bam_filename, output_dir, rea
     if paired_end:
         mean_frag_len = int(paired_end[0])
         frag_variance = np.power(int(paired_end[1]), 2)             # run_miso.py:80-83
-    for lo in range(0, len(events), max_events_per_launch):
-        chunk = events[lo:lo + max_events_per_launch]
-        # sampler parameters as in run_miso.py:151-171 (num_isoforms only sizes an unused matrix)
-        if paired_end:
-            params = miso.get_paired_end_sampler_params(2, mean_frag_len, frag_variance, read_len,
-                                                        overhang_len=overhang_len)
-        else:
-            params = miso.get_single_end_sampler_params(2, read_len, overhang_len)
-        sampler = miso.MISOSampler(params, paired_end=bool(paired_end), log_dir=output_dir)
-        written += sampler.run_sampler_batch(num_iters, chunk, num_chains=num_chains,
-                                             burn_in=burn_in, lag=lag, seed=seed,
-                                             first_event_id=first_event_id + lo, verbose=verbose)
+    # batches in flight: while one is on the GPU and its files are being written (native code, GIL
+    # released), the next one's reads are moved from the alignment file into a new batch
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(1) as finisher:
+        pending = None
+        for lo in range(0, len(events), max_events_per_launch):
+            chunk = events[lo:lo + max_events_per_launch]
+            # sampler parameters as in run_miso.py:151-171 (num_isoforms only sizes an unused matrix)
+            if paired_end:
+                params = miso.get_paired_end_sampler_params(2, mean_frag_len, frag_variance, read_len,
+                                                            overhang_len=overhang_len)
+            else:
+                params = miso.get_single_end_sampler_params(2, read_len, overhang_len)
+            sampler = miso.MISOSampler(params, paired_end=bool(paired_end), log_dir=output_dir)
+            # every event keeps the number it has in the caller's gene list: skipped genes, chunking
+            # and the number of GPUs do not change anybody's random stream
+            chunk = [ev[:4] + (first_event_id + ev[4],) for ev in chunk]
+            state = sampler.prepare_batch(num_iters, chunk, num_chains=num_chains, burn_in=burn_in,
+                                          lag=lag, verbose=verbose)
+            if pending is not None:
+                written += pending.result()
+            pending = finisher.submit(sampler.finish_batch, state, seed=seed,
+                                      first_event_id=first_event_id + lo, verbose=verbose)
+        if pending is not None:
+            written += pending.result()
     t2 = time.time()
     if verbose:
         print("Collected %d events in %.2f s, sampled in %.2f s"

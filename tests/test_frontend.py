@@ -251,7 +251,8 @@ def test_index_and_collect(tmp_path, bam_path):
     out = str(tmp_path / "out")
     events, info = run_miso.collect_gene_events(m.items(), bam, out, 36, 1, verbose=False)
     assert len(events) == 1 and info["ENSMUSG00000019943"].endswith("reads")
-    (pos, cig), gene, fname = events[0]
+    (pos, cig), gene, fname = events[0][:3]
+    assert events[0][3] is None and events[0][4] == 0          # no prior; its number in the gene list
     assert fname == os.path.join(out, "10", "ENSMUSG00000019943") and len(pos) == len(cig) > 3000
     assert gene.label == "ENSMUSG00000019943"
     # the read-length and minimum-read filters of run_miso.py:110-115, 139-147

@@ -140,3 +140,28 @@ def test_native_writer_many_isoforms_paired(tmp_path):
         rows = ["%s\t%.2f" % (",".join("%.4f" % v for v in p), ll) for p, ll in zip(psi, res[1])]
         got = open(written[e]).read().split("\n")
         assert got[2:-1] == rows
+
+
+def test_event_ids_pin_the_random_stream(tmp_path):
+    """An event numbered g gives the same file whether it runs alone (first_event_id = g), inside a
+    batch next to others, or after events that the skip rules dropped."""
+    import miso_sampler
+    from miso_amd import workload
+    evs = []
+    for e in range(3):
+        exons, isoforms, pos, cig = workload.event_reads(e, K=2 + e, n_reads=200)
+        gene = miso_sampler.SimpleGene(exons, isoforms, label="g%d" % e)
+        evs.append(((tuple(int(p) - 1 for p in pos), tuple(c.decode() for c in cig)), gene))
+
+    def sampler():
+        return miso_sampler.MISOSampler(miso_sampler.get_single_end_sampler_params(2, 36))
+    kw = dict(num_chains=2, burn_in=50, lag=2, seed=4)
+    alone = [sampler().run_sampler_batch(250, [(r, g, str(tmp_path / "a" / ("e%d" % i)))], first_event_id=10 * i + 7, **kw)[0]
+             for i, (r, g) in enumerate(evs)]
+    empty = (((), ()), evs[0][1], str(tmp_path / "b" / "skipped"), None, 3)
+    together = sampler().run_sampler_batch(
+        250, [empty] + [(r, g, str(tmp_path / "b" / ("e%d" % i)), None, 10 * i + 7) for i, (r, g) in enumerate(evs)],
+        first_event_id=1000, **kw)
+    assert together[0] is None
+    for a, b in zip(alone, together[1:]):
+        assert open(a, "rb").read() == open(b, "rb").read()

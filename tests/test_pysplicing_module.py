@@ -175,3 +175,32 @@ def test_run_sampler_end_to_end_on_reference_test_data(tmp_path, orc):
     assert written[3] is None and all(w and os.path.exists(w) for w in written[:3])
     a, b = (miso_sampler.load_samples(w)[0] for w in written[:2])
     assert not np.array_equal(a, b)        # different event ids -> different streams
+
+
+@pytest.mark.gpu
+def test_legacy_test_pysplicing_script_shape():
+    """misopy/legacy_test_pysplicing.py:9-21, call for call (3 exons, isoforms (0,1),(0,2),(0,1,2),
+    expression (.2,.3,.5), 2000 reads of 33 bp, MISO(…, 5000, 500, 10, (1,1,1)))."""
+    gene = pysplicing.createGene(((1, 100), (201, 300), (401, 500)), ((0, 1), (0, 2), (0, 1, 2)))
+    assert pysplicing.noIso(gene) == (3,)                      # one entry per gene of the handle
+    assert pysplicing.isoLength(gene) == ((200, 200, 300),)
+    reads = pysplicing.simulateReads(gene, 0, (0.2, 0.3, 0.5), 2000, 33, seed=7)
+    assert len(reads[1]) == len(reads[2]) == 2000 and isinstance(reads[1], tuple)
+    results = pysplicing.MISO(gene, 0, reads[1], reads[2], 33, 5000, 500, 10, (1.0, 1.0, 1.0), seed=11)
+    samples, loglik, templates, counts, assignment, rundata = results
+    S = 6 * (5000 - 500) // 10                       # default 6 chains (pysplicing.c:62-66)
+    assert len(samples) == 3 and all(len(row) == S for row in samples) and len(loglik) == S
+    assert len(assignment) == 2000 and rundata[:4] == (3, 5000, 500, 10)
+    assert sum(counts) == 2000
+    psi = np.array(samples).mean(axis=1)
+    assert abs(psi.sum() - 1) < 1e-9
+    assert np.all(np.abs(psi - np.array([0.2, 0.3, 0.5])) < 0.06)
+
+
+def test_batch_path_raises_the_module_exception(tmp_path):
+    """A bad CIGAR in run_sampler_batch surfaces as pysplicing.InternalError, like run_sampler's."""
+    gene = miso_sampler.SimpleGene([(1, 100), (201, 300), (401, 500)], [[0, 1, 2], [0, 2]])
+    s = miso_sampler.MISOSampler(miso_sampler.get_single_end_sampler_params(2, 36))
+    with pytest.raises(pysplicing.InternalError, match="CIGAR"):
+        s.run_sampler_batch(100, [(((10, 20), ("36M", "3Q")), gene, str(tmp_path / "x"))],
+                            num_chains=1, burn_in=10, lag=1, seed=1)
