@@ -130,7 +130,7 @@ struct Mapped {
 inline uint32_t rd32(const unsigned char *p) { uint32_t v; std::memcpy(&v, p, 4); return v; }
 inline uint16_t rd16(const unsigned char *p) { uint16_t v; std::memcpy(&v, p, 2); return v; }
 
-struct Block { size_t in_off, in_len, out_off, out_len; };
+struct Block { size_t in_off, in_len, out_off, out_len; uint32_t crc; };
 
 int inflate_all(const Mapped &m, int n_threads, std::vector<unsigned char> &out) {
   std::vector<Block> blocks;
@@ -150,7 +150,7 @@ int inflate_all(const Mapped &m, int n_threads, std::vector<unsigned char> &out)
     }
     if (bsize < xlen + 20 || off + bsize > m.len) return fail(MISO_EINVAL, "bad BGZF block size");
     const size_t isize = rd32(m.p + off + bsize - 4);
-    blocks.push_back({off + 12 + xlen, bsize - xlen - 20, total, isize});
+    blocks.push_back({off + 12 + xlen, bsize - xlen - 20, total, isize, rd32(m.p + off + bsize - 8)});
     total += isize;
     off += bsize;
   }
@@ -173,6 +173,8 @@ int inflate_all(const Mapped &m, int n_threads, std::vector<unsigned char> &out)
       const int rc = inflate(&zs, Z_FINISH);
       inflateEnd(&zs);
       if (rc != Z_STREAM_END || zs.avail_out != 0) { bad = 1; return; }
+      // the block's CRC32 sits before ISIZE: a flipped bit that still inflates must not pass
+      if (crc32(crc32(0L, Z_NULL, 0), out.data() + k.out_off, static_cast<uInt>(k.out_len)) != k.crc) { bad = 1; return; }
     }
   };
   const int T = std::max(1, std::min<int>(n_threads, static_cast<int>(blocks.size())));
@@ -180,7 +182,7 @@ int inflate_all(const Mapped &m, int n_threads, std::vector<unsigned char> &out)
   for (int t = 1; t < T; t++) th.emplace_back(work);
   work();
   for (auto &t : th) t.join();
-  if (bad.load()) return fail(MISO_EINVAL, "corrupt BGZF block (inflate failed)");
+  if (bad.load()) return fail(MISO_EINVAL, "corrupt BGZF block (inflate or CRC32 failed)");
   return 0;
 }
 
@@ -624,8 +626,8 @@ extern "C" int miso_aln_parse_reads(const miso_alnfile_t *f, int ref, int64_t st
                                         given_read_len, pos_out, cig_out, n_reads, n_strand_discarded);
   if (rc) return rc;
   *cigar_bytes = static_cast<int64_t>(cig_out.size());
-  if (positions) std::memcpy(positions, pos_out.data(), 4 * static_cast<size_t>(std::min<int64_t>(pos_cap, pos_out.size())));
-  if (cigar_buf) std::memcpy(cigar_buf, cig_out.data(), static_cast<size_t>(std::min<int64_t>(cigar_cap, cig_out.size())));
+  if (positions && !pos_out.empty()) std::memcpy(positions, pos_out.data(), 4 * static_cast<size_t>(std::min<int64_t>(pos_cap, pos_out.size())));
+  if (cigar_buf && !cig_out.empty()) std::memcpy(cigar_buf, cig_out.data(), static_cast<size_t>(std::min<int64_t>(cigar_cap, cig_out.size())));
   return 0;
 }
 

@@ -8,6 +8,7 @@ for f in runtime kernels kernels_k2 kernels_grp_c4 kernels_grp_c8 kernels_grp_c1
   /opt/rocm/bin/hipcc $F -c miso_amd/csrc/$f.hip -o tools/_build/$f.o &
 done
 /opt/rocm/bin/hipcc $F -x hip -c miso_amd/csrc/host.cpp -o tools/_build/host.o &
+g++ -O2 -std=c++17 -fPIC -Iinclude -Imiso_amd/csrc -c miso_amd/csrc/alnio.cpp -o tools/_build/alnio.o &
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC tools/_build/*.o -o tools/_build/libmiso_prof.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC tools/_build/*.o -o tools/_build/libmiso_prof.so -lz -lpthread
 rm -f tools/_build/*.o
