@@ -288,16 +288,31 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       const uint32_t n0r0 = rng.p1hi ^ iter ^ k0;
       const int nq = (n_draw + 3) >> 2;
       int d0 = 0, bad = 0; int64_t acc = 0;
+      // No data-dependent branches: a quad beyond the chain's reads is loaded from a clamped address
+      // and its reads are masked, so the four reads' LDS gathers are all in flight at once (the
+      // guarded form waited on each read's tables separately: 16 s_waitcnt per quad) and the round
+      // keys are rebuilt per block instead of spilled (gibbs_rng.hpp).
+      const int q_last = max(nq - 1, 0);
+      const double x0 = cur.x0, x1 = cur.x1;
       for (int j = 0; j < 2 * trips + 1; j++) {
         const int q = sub + j * G;
-        const miso_u32x4 u = philox_gibbs(rng, static_cast<uint32_t>(q), n0r0);
-        if (q < nq && lane_used) {
-          const uint4 f = fragq[q];
-          const int left = n_draw - 4 * q;
-          d0 += pe_pick(f.x, u.v[0], acc, bad);
-          if (left > 1) d0 += pe_pick(f.y, u.v[1], acc, bad);
-          if (left > 2) d0 += pe_pick(f.z, u.v[2], acc, bad);
-          if (left > 3) d0 += pe_pick(f.w, u.v[3], acc, bad);
+        const miso_u32x4 u = philox_gibbs<true>(rng, static_cast<uint32_t>(q), n0r0);
+        const uint4 f = fragq[min(q, q_last)];
+        const int left = (q < nq && lane_used) ? n_draw - 4 * q : 0;   // reads of this quad that exist
+        const uint32_t ff[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const bool valid = left > r;
+          const uint32_t fv = valid ? ff[r] : 0u;
+          const uint32_t f0 = fv & 0xFFFFu, f1 = fv >> 16;
+          const double c0 = 0.0 + x0 * lds_fp[f0];               // miso_paired.c:11-22, 64-68
+          const double T = c0 + x1 * lds_fp[f1];
+          const bool p0 = miso_u01(u.v[r]) * T < c0;
+          const int32_t v = lds_tab[p0 ? f0 : a.il + f1];
+          const bool isbad = v == SFIX_BAD;
+          bad |= (valid & isbad) ? 1 : 0;
+          acc += (valid & !isbad) ? v : 0;
+          d0 += (valid & p0) ? 1 : 0;
         }
       }
       if (POW2) {
