@@ -43,7 +43,8 @@ class GenesDispatcher(object):
 
     def __init__(self, gff_dir, bam_filename, output_dir, read_len, overhang_len,
                  settings_fname=None, paired_end=None, gene_ids=None, num_proc=None,
-                 event_type=None, seed=None):
+                 event_type=None, seed=None, summarize=False, compare_bam=None,
+                 labels=("sample1", "sample2")):
         self.gff_dir, self.bam_filename, self.output_dir = gff_dir, bam_filename, output_dir
         if not os.path.isfile(self.bam_filename):
             raise IOError("BAM file %s not found." % self.bam_filename)
@@ -51,6 +52,9 @@ class GenesDispatcher(object):
         self.overhang_len = 1            # "For now setting overhang to 1 always" (miso.py:100-102)
         self.settings_fname, self.paired_end = settings_fname, paired_end
         self.event_type, self.seed = event_type, seed
+        self.summarize, self.compare_bam, self.labels = summarize, compare_bam, labels
+        if compare_bam is not None and not os.path.isfile(compare_bam):
+            raise IOError("BAM file %s not found." % compare_bam)
         self.num_processors = int(num_proc) if num_proc is not None else max(1, visible_gpus())
         self.batch_logs_dir = os.path.join(output_dir, "batch-logs")
         self.batch_genes_dir = os.path.join(output_dir, "batch-genes")
@@ -83,12 +87,34 @@ class GenesDispatcher(object):
         batches = self.output_batch_files()
         print("Preparing to run %d batches of jobs..." % len(batches))
         procs = []
+        parts = []
+        if self.compare_bam is not None:
+            out1, out2 = (os.path.join(self.output_dir, l) for l in self.labels)
+            cmp_name = "%s_vs_%s" % self.labels
+            table = os.path.join(self.output_dir, cmp_name, "bayes-factors", cmp_name + ".miso_bf")
+        elif self.summarize:
+            label = os.path.basename(os.path.normpath(self.output_dir))
+            table = os.path.join(self.output_dir, "summary", label + ".miso_summary")
+        else:
+            table = None
+        if table is not None:
+            os.makedirs(os.path.dirname(table), exist_ok=True)
         for batch_num, (fname, size, first) in enumerate(batches):
             if size == 0:
                 continue
-            cmd = [sys.executable, "-m", "miso_amd.run_miso", "--compute-genes-from-file", fname,
-                   self.bam_filename, self.output_dir, "--read-len", str(self.read_len),
-                   "--device", str(batch_num), "--first-event-id", str(first)]
+            part = None if table is None else "%s.gpu%d" % (table, batch_num)
+            if part:
+                parts.append(part)
+            if self.compare_bam is not None:
+                cmd = [sys.executable, "-m", "miso_amd.run_miso", "--compare-genes-from-file", fname,
+                       self.bam_filename, self.compare_bam, out1, out2, part]
+            else:
+                cmd = [sys.executable, "-m", "miso_amd.run_miso", "--compute-genes-from-file", fname,
+                       self.bam_filename, self.output_dir]
+                if part:
+                    cmd += ["--summary-file", part]
+            cmd += ["--read-len", str(self.read_len), "--device", str(batch_num),
+                    "--first-event-id", str(first)]
             if self.paired_end is not None:
                 cmd += ["--paired-end", "%.1f" % float(self.paired_end[0]),
                         "%.1f" % float(self.paired_end[1])]
@@ -115,12 +141,17 @@ class GenesDispatcher(object):
                 failed += 1
                 print("WARNING: batch %d might have failed (exit %d), see %s"
                       % (batch_num, p.returncode, log))
+        if table is not None:
+            from .run_miso import merge_tables
+            merge_tables(parts, table)
+            print("Wrote %s" % table)
         return failed
 
 
 def compute_all_genes_psi(gff_dir, bam_filename, read_len, output_dir, overhang_len=1,
                           paired_end=None, settings_fname=None, num_proc=None, event_type=None,
-                          seed=None):
+                          seed=None, summarize=False, compare_bam=None,
+                          labels=("sample1", "sample2")):
     """miso.py:340-420."""
     print("Computing Psi values...")
     print("  - GFF index: %s" % gff_dir)
@@ -130,7 +161,8 @@ def compute_all_genes_psi(gff_dir, bam_filename, read_len, output_dir, overhang_
     os.makedirs(output_dir, exist_ok=True)
     return GenesDispatcher(gff_dir, bam_filename, output_dir, read_len, overhang_len,
                            settings_fname=settings_fname, paired_end=paired_end, num_proc=num_proc,
-                           event_type=event_type, seed=seed).run()
+                           event_type=event_type, seed=seed, summarize=summarize,
+                           compare_bam=compare_bam, labels=labels).run()
 
 
 def main(argv=None):
@@ -145,6 +177,13 @@ def main(argv=None):
     ap.add_argument("--output-dir", default=None)
     ap.add_argument("-p", dest="num_proc", type=int, default=None, help="number of GPUs")
     ap.add_argument("--seed", type=int, default=None)
+    ap.add_argument("--summarize", action="store_true",
+                    help="also write OUT/summary/<OUT>.miso_summary (summarize_miso's table) from "
+                         "posterior means / credible intervals computed on the GPU during the run")
+    ap.add_argument("--compare", metavar="BAM2", default=None,
+                    help="second RNA-seq sample: sample both, write OUT/<label1>/, OUT/<label2>/ and the "
+                         "compare_miso table OUT/<l1>_vs_<l2>/bayes-factors/<l1>_vs_<l2>.miso_bf")
+    ap.add_argument("--labels", nargs=2, default=("sample1", "sample2"))
     a = ap.parse_args(argv)
     settings_filename = None if a.settings_filename is None else \
         os.path.abspath(os.path.expanduser(a.settings_filename))
@@ -163,7 +202,10 @@ def main(argv=None):
                                    os.path.abspath(os.path.expanduser(a.output_dir)),
                                    overhang_len=a.overhang_len or 1, paired_end=a.paired_end,
                                    settings_fname=settings_filename, num_proc=a.num_proc,
-                                   event_type=a.event_type, seed=a.seed)
+                                   event_type=a.event_type, seed=a.seed, summarize=a.summarize,
+                                   compare_bam=None if a.compare is None else
+                                   os.path.abspath(os.path.expanduser(a.compare)),
+                                   labels=tuple(a.labels))
     return 1 if failed else 0
 
 

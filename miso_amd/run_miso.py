@@ -110,7 +110,7 @@ def collect_gene_events(gene_entries, bamfile, output_dir, read_len, overhang_le
 def compute_gene_psi(gene_ids, gff_index_filename, bam_filename, output_dir, read_len,
                      overhang_len, paired_end=None, event_type=None, verbose=True, bamfile=None,
                      seed=None, first_event_id=0, device=None, gene_entries=None,
-                     max_events_per_launch=8192):
+                     max_events_per_launch=8192, summary_file=None):
     """run_miso.py:34-206.  `gene_entries` (list of (gene_id, index file)) generalises the
     reference's (gene_ids, one index file) so a whole batch file is one GPU batch."""
     os.makedirs(output_dir, exist_ok=True)
@@ -141,6 +141,7 @@ def compute_gene_psi(gene_ids, gff_index_filename, bam_filename, output_dir, rea
     # batches in flight: while one is on the GPU and its files are being written (native code, GIL
     # released), the next one's reads are moved from the alignment file into a new batch
     from concurrent.futures import ThreadPoolExecutor
+    summary_parts = []
     with ThreadPoolExecutor(1) as finisher:
         pending = None
         for lo in range(0, len(events), max_events_per_launch):
@@ -159,10 +160,16 @@ def compute_gene_psi(gene_ids, gff_index_filename, bam_filename, output_dir, rea
                                           lag=lag, verbose=verbose)
             if pending is not None:
                 written += pending.result()
+            part = None if summary_file is None else "%s.part%06d" % (summary_file, lo)
+            if part:
+                summary_parts.append(part)
             pending = finisher.submit(sampler.finish_batch, state, seed=seed,
-                                      first_event_id=first_event_id + lo, verbose=verbose)
+                                      first_event_id=first_event_id + lo, verbose=verbose,
+                                      summary_file=part)
         if pending is not None:
             written += pending.result()
+    if summary_file is not None:
+        merge_tables(summary_parts, summary_file)
     t2 = time.time()
     if verbose:
         print("Collected %d events in %.2f s, sampled in %.2f s"
@@ -170,6 +177,70 @@ def compute_gene_psi(gene_ids, gff_index_filename, bam_filename, output_dir, rea
     if own:
         bamfile.close()
     return written, info
+
+
+def merge_tables(parts, filename, remove=True):
+    """Concatenate tab-separated tables that share a header line (per-batch / per-GPU parts)."""
+    os.makedirs(os.path.dirname(os.path.abspath(filename)), exist_ok=True)
+    header_done = False
+    with open(filename, "w") as out:
+        for part in parts:
+            if not os.path.isfile(part):
+                continue
+            with open(part) as f:
+                header = f.readline()
+                if not header_done:
+                    out.write(header)
+                    header_done = True
+                for line in f:
+                    out.write(line)
+            if remove:
+                os.remove(part)
+    return filename
+
+
+def compare_gene_psi(gene_entries, bam1_filename, bam2_filename, output_dir1, output_dir2,
+                     comparison_file, read_len, overhang_len, paired_end=None, event_type=None,
+                     verbose=True, seed=None, first_event_id=0, device=None,
+                     max_events_per_launch=4096):
+    """Two RNA-seq samples over the same genes in one go (BASELINE configs[4]): both samples are
+    sampled on this GPU, their `.miso` files written like two `miso --run`s would, and the
+    `.miso_bf` table of `compare_miso` (hypothesis_test.py:186-345) comes from Bayes factors
+    computed on the device while the samples are still in HBM."""
+    for d in (output_dir1, output_dir2):
+        os.makedirs(d, exist_ok=True)
+    if device is not None:
+        os.environ["MISO_DEVICE"] = str(int(device))
+    p = Settings.get_sampler_params()
+    bam1, bam2 = sam_utils.load_bam_reads(bam1_filename), sam_utils.load_bam_reads(bam2_filename)
+    ev1, info1 = collect_gene_events(gene_entries, bam1, output_dir1, read_len, overhang_len,
+                                     paired_end=paired_end, event_type=event_type, verbose=verbose)
+    ev2, info2 = collect_gene_events(gene_entries, bam2, output_dir2, read_len, overhang_len,
+                                     paired_end=paired_end, event_type=event_type, verbose=verbose)
+    # pair by gene: only genes that passed the filters in BOTH samples are compared
+    # (compare_miso leaves out events missing from one directory, hypothesis_test.py:262-264)
+    by_no2 = {e[4]: e for e in ev2}
+    pairs = [(a, by_no2[a[4]]) for a in ev1 if a[4] in by_no2]
+    parts = []
+    if paired_end:
+        mean_frag_len = int(paired_end[0])
+        frag_variance = np.power(int(paired_end[1]), 2)
+    for lo in range(0, len(pairs), max_events_per_launch):
+        chunk = pairs[lo:lo + max_events_per_launch]
+        if paired_end:
+            params = miso.get_paired_end_sampler_params(2, mean_frag_len, frag_variance, read_len,
+                                                        overhang_len=overhang_len)
+        else:
+            params = miso.get_single_end_sampler_params(2, read_len, overhang_len)
+        sampler = miso.MISOSampler(params, paired_end=bool(paired_end), log_dir=output_dir1)
+        part = "%s.part%06d" % (comparison_file, lo)
+        parts.append(part)
+        sampler.run_comparison_batch(p["num_iters"], [a[:3] for a, _ in chunk],
+                                     [b[:3] for _, b in chunk], part, num_chains=p["num_chains"],
+                                     burn_in=p["burn_in"], lag=p["lag"], seed=seed,
+                                     first_event_id=first_event_id + lo, verbose=verbose)
+    merge_tables(parts, comparison_file)
+    return len(pairs)
 
 
 def read_genes_file(genes_filename):
@@ -189,6 +260,11 @@ def main(argv=None):
     ap = argparse.ArgumentParser(description="MISO (Mixture of Isoforms model) on MI355X")
     ap.add_argument("--compute-gene-psi", nargs=4, metavar=("GENE_IDS", "INDEX", "BAM", "OUT"))
     ap.add_argument("--compute-genes-from-file", nargs=3, metavar=("GENES_FILE", "BAM", "OUT"))
+    ap.add_argument("--compare-genes-from-file", nargs=6,
+                    metavar=("GENES_FILE", "BAM1", "BAM2", "OUT1", "OUT2", "BF_FILE"),
+                    help="sample both RNA-seq samples and write the Bayes-factor table")
+    ap.add_argument("--summary-file", default=None,
+                    help="also write the summarize_miso table of this run (device-side summaries)")
     ap.add_argument("--paired-end", nargs=2, type=float, metavar=("MEAN", "SD"))
     ap.add_argument("--read-len", type=int)
     ap.add_argument("--overhang-len", type=int)
@@ -205,7 +281,15 @@ def main(argv=None):
         return 1
     overhang_len = a.overhang_len if a.overhang_len is not None else 1
     paired_end = tuple(a.paired_end) if a.paired_end else None
-    if a.compute_genes_from_file:
+    if a.compare_genes_from_file:
+        genes_filename, bam1, bam2, out1, out2, bf = (os.path.abspath(os.path.expanduser(x))
+                                                     for x in a.compare_genes_from_file)
+        entries = read_genes_file(genes_filename)
+        n = compare_gene_psi(entries, bam1, bam2, out1, out2, bf, a.read_len, overhang_len,
+                             paired_end=paired_end, event_type=a.event_type, seed=a.seed,
+                             first_event_id=a.first_event_id, device=a.device)
+        print("Compared %d genes" % n)
+    elif a.compute_genes_from_file:
         genes_filename, bam_filename, output_dir = (os.path.abspath(os.path.expanduser(p))
                                                     for p in a.compute_genes_from_file)
         for p in (genes_filename, bam_filename):
@@ -215,7 +299,8 @@ def main(argv=None):
         entries = read_genes_file(genes_filename)
         compute_gene_psi(None, None, bam_filename, output_dir, a.read_len, overhang_len,
                          paired_end=paired_end, event_type=a.event_type, gene_entries=entries,
-                         seed=a.seed, first_event_id=a.first_event_id, device=a.device)
+                         seed=a.seed, first_event_id=a.first_event_id, device=a.device,
+                         summary_file=a.summary_file)
         print("Processed %d genes" % len(entries))
     elif a.compute_gene_psi:
         gene_ids = a.compute_gene_psi[0].split(",")

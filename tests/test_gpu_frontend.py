@@ -165,3 +165,49 @@ def test_event_ids_pin_the_random_stream(tmp_path):
     assert together[0] is None
     for a, b in zip(alone, together[1:]):
         assert open(a, "rb").read() == open(b, "rb").read()
+
+
+def test_cli_summarize_and_compare(tmp_path):
+    """`miso --run ... --summarize` and `miso --run ... --compare BAM2`: the summarize_miso and
+    compare_miso tables (samples_utils.py:263-329, hypothesis_test.py:186-345) straight from the
+    run, numbers computed on the GPU."""
+    import miso_sampler
+    with gzip.open(os.path.join(DATA, "c2c12.Atp2b1.sam.gz"), "rt") as f:
+        lines = f.read().splitlines()
+    head = [l for l in lines if l.startswith("@")]
+    body = [l for l in lines if not l.startswith("@")]
+    bam1, bam2 = str(tmp_path / "s1.bam"), str(tmp_path / "s2.bam")
+    sam_to_bam("\n".join(head + body) + "\n", bam1)
+    # sample 2: drop most reads that only fit the long isoform -> psi shifts
+    keep = [l for i, l in enumerate(body) if "N" in l.split("\t")[5] or i % 3 == 0]
+    sam_to_bam("\n".join(head + keep) + "\n", bam2)
+    idx = str(tmp_path / "indexed")
+    settings = tmp_path / "settings.txt"
+    settings.write_text("[data]\nmin_event_reads = 20\n[sampler]\nburn_in = 200\nlag = 4\nnum_iters = 1000\nnum_chains = 2\n")
+    assert run(["-m", "miso_amd.index_gff", "--index", os.path.join(DATA, "Atp2b1.mm9.gff"), idx]).returncode == 0
+    out = str(tmp_path / "control")
+    r = run(["-m", "miso_amd.miso", "--run", idx, bam1, "--output-dir", out, "--read-len", "36",
+             "--settings-filename", str(settings), "-p", "1", "--seed", "31", "--summarize"])
+    assert r.returncode == 0, r.stdout
+    table = os.path.join(out, "summary", "control.miso_summary")
+    rows = [l.rstrip("\n").split("\t") for l in open(table)]
+    assert rows[0][:4] == ["event_name", "miso_posterior_mean", "ci_low", "ci_high"] and len(rows) == 2
+    assert rows[1][0] == "ENSMUSG00000019943"
+    samples, hdr, _ = miso_sampler.load_samples(os.path.join(out, "10", "ENSMUSG00000019943.miso"))
+    assert abs(float(rows[1][1]) - samples[:, 0].mean()) < 0.006
+    assert float(rows[1][2]) <= float(rows[1][1]) <= float(rows[1][3]) and rows[1][5] == hdr["counts"]
+    out2 = str(tmp_path / "cmp")
+    r = run(["-m", "miso_amd.miso", "--run", idx, bam1, "--compare", bam2, "--labels", "ctl", "kd",
+             "--output-dir", out2, "--read-len", "36", "--settings-filename", str(settings), "-p", "1",
+             "--seed", "31"])
+    logs = "".join(open(os.path.join(out2, "batch-logs", f)).read() for f in os.listdir(os.path.join(out2, "batch-logs")))
+    assert r.returncode == 0, r.stdout + logs
+    bf = os.path.join(out2, "ctl_vs_kd", "bayes-factors", "ctl_vs_kd.miso_bf")
+    rows = [l.rstrip("\n").split("\t") for l in open(bf)]
+    assert rows[0][0] == "event_name" and rows[0][8] == "bayes_factor" and len(rows) == 2, logs
+    for lab in ("ctl", "kd"):
+        assert os.path.isfile(os.path.join(out2, lab, "10", "ENSMUSG00000019943.miso"))
+    m1, m2, diff, bfv = float(rows[1][1]), float(rows[1][4]), float(rows[1][7]), float(rows[1][8])
+    assert abs((m1 - m2) - diff) < 0.011 and bfv >= 0
+    s1 = miso_sampler.load_samples(os.path.join(out2, "ctl", "10", "ENSMUSG00000019943.miso"))[0]
+    assert abs(m1 - s1[:, 0].mean()) < 0.006
