@@ -1,166 +1,149 @@
-"""`misopy/Gene.py` for Python 3, imported as `gene_utils` like the reference does (run_miso.py:19) --
-the gene model the sampler's caller reads (misopy/Gene.py:11-340, 696-715, 866-1010): intervals, exons,
-isoforms, genes, and the GFF -> Gene construction.  The read
-alignment helpers of the reference class (align_read_*, Gene.py:342-690) are the pure-Python
-predecessors of `splicing_matchIso` and are not on the path (miso_amd does them on the GPU).
+"""The gene model the sampler's caller reads, built from GFF3.
+
+Plays the role of misopy/Gene.py -- imported as `gene_utils`, the name run_miso.py:19 gives it.
+What the rest of the package relies on, and where the reference defines it:
+  * `Gene.parts`: every exon of every transcript in transcript order, one object per GFF record, so
+    an exon shared by two transcripts appears twice (make_gene_from_gff_records, Gene.py:915-1009);
+  * `Exon == Exon` compares coordinates and owning gene, not labels (Gene.py:78-88) -- `py2c_gene`
+    (py2c_gene.py:10-21) finds an isoform's exons with `parts.index(exon)` and therefore lands on the
+    first copy of a shared exon;
+  * an isoform is the list of its transcript's exons sorted by start; `genomic_start` / `genomic_end`
+    are the first exon's start and the last exon's end (Gene.py:696-715);
+  * isoforms keep the file order of their `mRNA` / `transcript` records and carry the transcript ID
+    as label; `iso_lens` are summed exon lengths.
+The pure-Python read alignment of the reference class (Gene.py:342-690) is the predecessor of
+`splicing_matchIso`; that job runs on the GPU here.
 """
-from . import gff_utils
-from .gff_utils import GFFDatabase
+from .gff_utils import GFFDatabase, TRANSCRIPT_TYPES
 
 
 class Interval(object):
     def __init__(self, start, end):
+        assert start <= end, "interval end before start"
         self.start, self.end = start, end
-        assert self.start <= self.end
-        self.len = self.end - self.start + 1
+
+    @property
+    def len(self):
+        return self.end - self.start + 1
 
     def contains(self, start, end):
         return self.start <= start and end <= self.end
 
 
 class Exon(Interval):
-    """Gene.py:45-88."""
-
     def __init__(self, start, end, label=None, gene=None, seq="", from_gff_record=None):
-        Interval.__init__(self, start, end)
         self.gene, self.label, self.seq = gene, label, seq
+        self.rec = self.parent_rec = None
         if from_gff_record is not None:
-            self.rec = from_gff_record['record']
-            self.parent_rec = from_gff_record['parent']
-            self.start, self.end = self.rec.start, self.rec.end
-            self.label = self.rec.attributes['ID'][0]              # use first ID in list
+            self.rec, self.parent_rec = from_gff_record["record"], from_gff_record["parent"]
+            start, end, self.label = self.rec.start, self.rec.end, self.rec.attributes["ID"][0]
+        Interval.__init__(self, start, end)
 
     def __eq__(self, other):
-        """Gene.py:78-88: same coordinates and same gene (NOT the label)."""
-        if other is None:
-            return False
-        return self.start == other.start and self.end == other.end and self.gene is other.gene
+        return (other is not None and (self.start, self.end) == (other.start, other.end)
+                and self.gene is other.gene)
 
     def __ne__(self, other):
-        return not self.__eq__(other)
+        return not self == other
 
     __hash__ = None
 
     def __repr__(self):
-        return "Exon([%d, %d], id = %s)(ParentGene = %s)" % (
-            self.start, self.end, self.label, self.gene.label if self.gene else None)
+        return "Exon(%s:%d-%d)" % (self.label, self.start, self.end)
 
 
 class Isoform(object):
-    """Gene.py:696-715."""
-
-    def __init__(self, gene, parts, seq=None, label=None):
-        self.gene, self.parts = gene, parts
+    def __init__(self, gene, parts, seq=None, label=None, desc=None):
+        self.gene, self.parts, self.seq, self.label, self.desc = gene, parts, seq, label, desc
         self.num_parts = len(parts)
-        self.len = sum(part.len for part in parts)
-        self.seq, self.label = seq, label
-        self.genomic_start = self.parts[0].start
-        self.genomic_end = self.parts[-1].end
-        self.desc = None
+        self.len = sum(p.len for p in parts)
+        self.genomic_start, self.genomic_end = parts[0].start, parts[-1].end
 
 
 class Gene(object):
-    """Gene.py:114-340: parts + isoform descriptions (lists of part labels)."""
+    """isoform_desc: one list of part labels per isoform; parts: the exon objects those labels name
+    (the first part carrying a label wins, Gene.py:246-250)."""
 
     def __init__(self, isoform_desc, parts, chrom=None, exons_seq=None, label="", strand="NA",
                  transcript_ids=None):
-        self.isoform_desc = isoform_desc
-        self.label = label if label != "" else "gene"
-        self.parts = []
-        for part in parts:                                         # create_parts, Gene.py:294-303
+        self.label = label or "gene"
+        self.chrom, self.strand = chrom, strand
+        self.isoform_desc, self.transcript_ids = isoform_desc, transcript_ids
+        self.parts = list(parts)
+        for part in self.parts:
             part.gene = self
-            self.parts.append(part)
         self.num_parts = len(self.parts)
-        self.chrom, self.strand, self.transcript_ids = chrom, strand, transcript_ids
-        self.isoforms, self.iso_lens = [], []
-        for iso in self.isoform_desc:                              # create_isoforms, :305-323
-            isoform_parts = []
-            for part_label in iso:
-                part = self.get_part_by_label(part_label)
-                if not part:
-                    raise Exception("Invalid description of isoforms: refers to undefined part "
-                                    "%s, gene: %s" % (part_label, self.label))
-                isoform_parts.append(part)
-            isoform = Isoform(self, isoform_parts)
-            isoform.desc = iso
-            self.isoforms.append(isoform)
-            self.iso_lens.append(isoform.len)
-        if self.transcript_ids is not None:                        # assign_transcript_ids, :325-334
-            if len(self.transcript_ids) != len(self.isoforms):
-                raise Exception("Transcript IDs do not match number of isoforms.")
-            for iso, tid in zip(self.isoforms, self.transcript_ids):
-                iso.label = tid
+        if transcript_ids is not None and len(transcript_ids) != len(isoform_desc):
+            raise Exception("Transcript IDs do not match number of isoforms.")
+        first_with_label = {}
+        for part in self.parts:
+            first_with_label.setdefault(part.label, part)
+        self.isoforms = []
+        for n, labels in enumerate(isoform_desc):
+            missing = [l for l in labels if l not in first_with_label]
+            if missing:
+                raise Exception("Invalid description of isoforms: refers to undefined part %s, gene: %s"
+                                % (missing[0], self.label))
+            self.isoforms.append(Isoform(self, [first_with_label[l] for l in labels], desc=labels,
+                                         label=None if transcript_ids is None else transcript_ids[n]))
+        self.iso_lens = [iso.len for iso in self.isoforms]
 
     def get_part_by_label(self, part_label):
-        """Gene.py:246-250: the first part carrying the label."""
-        for part in self.parts:
-            if part_label == part.label:
-                return part
-        return None
+        return next((p for p in self.parts if p.label == part_label), None)
 
     def __repr__(self):
-        return "gene_id: %s\nisoforms: %d" % (self.label, len(self.isoforms))
+        return "Gene(%s, %d isoforms)" % (self.label, len(self.isoforms))
 
 
 def make_gene_from_gff_records(gene_label, gene_hierarchy, gene_records):
-    """Gene.py:915-1009.  One isoform per mRNA/transcript in file order, exons sorted by start;
-    the gene's parts are ALL exons of all transcripts (shared exons appear once per transcript --
-    py2c_gene resolves them to the first equal part)."""
-    mRNAs = gene_hierarchy['mRNAs']
-    transcripts, isoform_desc, used_transcript_ids = [], [], []
-    chrom, strand = None, "NA"
-    transcript_ids = [rec.get_id() for rec in gene_records
-                      if rec.type == "mRNA" or rec.type == "transcript"]
-    if len(transcript_ids) == 0:
+    """A Gene from one gene's tree (gff_utils.GFFDatabase.gene_tree) and records."""
+    order = [r.get_id() for r in gene_records if r.type in TRANSCRIPT_TYPES]
+    if not order:
         raise Exception("Error: %s has no transcripts..." % gene_label)
-    for transcript_id in transcript_ids:
-        transcript_info = mRNAs[transcript_id]
-        transcript_rec = transcript_info['record']
-        chrom, strand = transcript_rec.seqid, transcript_rec.strand
-        transcript_exons = transcript_info['exons']
-        if len(transcript_exons) == 0:
-            print("%s has no exons" % transcript_id)
+    chrom, strand = None, "NA"
+    parts, descriptions, kept = [], [], []
+    for tid in order:
+        node = gene_hierarchy["mRNAs"][tid]
+        chrom, strand = node["record"].seqid, node["record"].strand
+        if not node["exons"]:
+            print("%s has no exons" % tid)
             continue
-        exons = [Exon(info['record'].start, info['record'].end,
-                      from_gff_record={'record': info['record'], 'parent': transcript_rec})
-                 for exon_id, info in transcript_exons.items()]
-        exons = sorted(exons, key=lambda e: e.start)
-        transcripts.append(exons)
-        isoform_desc.append([exon.label for exon in exons])
-        used_transcript_ids.append(transcript_id)
-    all_exons = []
-    for transcript in transcripts:
-        all_exons.extend(transcript)
-    return Gene(isoform_desc, all_exons, label=gene_label, chrom=chrom, strand=strand,
-                transcript_ids=used_transcript_ids)
+        exons = sorted((Exon(0, 0, from_gff_record={"record": e["record"], "parent": node["record"]})
+                        for e in node["exons"].values()), key=lambda ex: ex.start)
+        parts += exons
+        descriptions.append([ex.label for ex in exons])
+        kept.append(tid)
+    return Gene(descriptions, parts, label=gene_label, chrom=chrom, strand=strand, transcript_ids=kept)
 
 
 def load_genes_from_gff(gff_filename, include_introns=False, reverse_recs=False,
                         suppress_warnings=False):
-    """Gene.py:866-912: {gene_id: {'gene_object': Gene, 'hierarchy': hierarchy}} in file order."""
-    gff_db = GFFDatabase(gff_filename, include_introns=include_introns, reverse_recs=reverse_recs,
-                         suppress_warnings=suppress_warnings)
-    gff_genes = {}
-    for gene in gff_db.genes:
-        gene_label = gene.get_id()
-        gene_records, gene_hierarchy = gff_db.get_genes_records([gene_label])
-        if gene_label not in gene_hierarchy:
+    """{gene id: {'gene_object': Gene, 'hierarchy': {gene id: tree}}} for every gene record that has
+    transcripts, in file order (what index_gff.py serialises, Gene.py:866-912)."""
+    db = GFFDatabase(gff_filename, include_introns=include_introns, reverse_recs=reverse_recs,
+                     suppress_warnings=suppress_warnings)
+    genes = {}
+    for record in db.genes:
+        gene_id = record.get_id()
+        records, hierarchy = db.get_genes_records([gene_id])
+        if gene_id not in hierarchy:
             if not suppress_warnings:
-                print("Skipping gene %s..." % gene_label)
+                print("Skipping gene %s..." % gene_id)
             continue
-        gene_hierarchy[gene_label]['gene'] = gene
-        gene_obj = make_gene_from_gff_records(gene_label, gene_hierarchy[gene_label], gene_records)
-        if gene_obj is None:
-            continue
-        gff_genes[gene_label] = {'gene_object': gene_obj, 'hierarchy': gene_hierarchy}
+        hierarchy[gene_id]["gene"] = record
+        genes[gene_id] = {"gene_object": make_gene_from_gff_records(gene_id, hierarchy[gene_id], records),
+                          "hierarchy": hierarchy}
     if not suppress_warnings:
-        print("Loaded %d genes" % len(gff_genes))
-    return gff_genes
+        print("Loaded %d genes" % len(genes))
+    return genes
 
 
 def se_event_to_gene(up_len, se_len, dn_len, chrom, label=None):
-    """Gene.py:1033-1051."""
-    e1 = Exon(0, up_len - 1, label='A')
-    e2 = Exon(e1.end + 1, e1.end + se_len, label='B')
-    e3 = Exon(e2.end + 1, e2.end + dn_len, label='C')
-    return Gene([['A', 'B', 'C'], ['A', 'C']], [e1, e2, e3], label=label or "", chrom=chrom)
+    """A skipped-exon event as a two-isoform gene: exons A, B, C laid end to end from coordinate 0,
+    isoforms A-B-C and A-C (Gene.py:1033-1051)."""
+    bounds, start = [], 0
+    for length in (up_len, se_len, dn_len):
+        bounds.append((start, start + length - 1))
+        start += length
+    exons = [Exon(s, e, label=name) for (s, e), name in zip(bounds, "ABC")]
+    return Gene([["A", "B", "C"], ["A", "C"]], exons, label=label or "", chrom=chrom)

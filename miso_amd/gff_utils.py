@@ -1,58 +1,85 @@
-"""Python-3 mirror of the part of misopy/gff_utils.py that stands between a GFF3 annotation and
-the sampler: the record type, the v3 reader, the gene -> mRNA -> exon database
-and the helpers `run_miso.py` calls.  GFF v1/v2 parsing, the writer and CDS bookkeeping beyond
-what the hierarchy stores are out of scope.
+"""GFF3 annotations for the front end: records, the gene -> mRNA -> exon tables
+and the index helpers `run_miso.py` needs.
+
+Interface names follow misopy/gff_utils.py so callers read the same (`GFF`, `Reader`,
+`GFFDatabase`, `get_inclusive_txn_bounds`, `load_indexed_gff_file`, `get_gene_ids_to_gff_index`;
+reference lines 55-153, 164-292, 316-489, 509-747, 955-981), the implementation is this package's
+own: one pass over the file, GFF version 3 only.  Behaviour kept from the reference because it
+changes results: attribute values are URL-unquoted and comma-split, start/end are swapped when
+reversed, exons without an ID are named `parent@start@end@strand`, transcripts are `mRNA` or
+`transcript` records, a gene's transcripts and a transcript's exons keep file order.
 """
 import json
 import os
 import pickle
 import sys
-from collections import OrderedDict, defaultdict
-from urllib.parse import unquote as url_unquote
+from collections import OrderedDict
+from urllib.parse import unquote
 
 INDEX_MAP_BASENAME = "genes_to_filenames.json"
 BUNDLE_BASENAME = "genes_bundle.pickle"
 
+TRANSCRIPT_TYPES = ("mRNA", "transcript")
+
 
 class FormatError(Exception):
-    pass
+    """A line that is not a 9-column GFF3 record."""
 
 
-def parse_maybe_empty(s, parse_type=str):
-    """gff_utils.py:819-823."""
-    return None if s == '.' else parse_type(s)
+def parse_maybe_empty(text, parse_type=str):
+    """'.' is GFF's empty field."""
+    return None if text == "." else parse_type(text)
+
+
+def _attributes(column9):
+    """`tag=v1,v2;tag2=...` -> {tag: [values]}; malformed pairs are reported and dropped."""
+    out = {}
+    for pair in filter(None, column9.split(";")):
+        tag, sep, value = pair.partition("=")
+        if not sep or "=" in value:
+            sys.stderr.write("WARNING: Invalid attributes string: %s\n" % column9)
+            continue
+        out[unquote(tag)] = [unquote(v) for v in value.split(",")]
+    return out
 
 
 class GFF(object):
-    """A record from a GFF file (gff_utils.py:316-489)."""
+    """One annotation record: seqid, source, type, start, end, score, strand, phase, attributes."""
+    __slots__ = ("seqid", "source", "type", "start", "end", "score", "strand", "phase", "attributes")
 
     def __init__(self, seqid, source, type, start, end, score=None, strand=None, phase=None,
                  attributes=None):
+        if start > end:
+            start, end = end, start
+            if strand != "-":
+                sys.stderr.write("WARNING: start > end swapped for %s %s:%d-%d\n"
+                                 % (type, seqid, start, end))
         self.seqid, self.source, self.type = seqid, source, type
         self.start, self.end = start, end
         self.score, self.strand, self.phase = score, strand, phase
-        self.attributes = attributes if attributes else {}
-        if self.start > self.end:                                   # gff_utils.py:350-355
-            self.start, self.end = self.end, self.start
-            if strand != '-':
-                sys.stderr.write("WARNING: Swapping start and end fields, which must satisfy "
-                                 "start <= end:\n%r\n" % self)
-        self._set_default_exon_id()
+        self.attributes = attributes or {}
+        if type == "exon" and "ID" not in self.attributes:
+            self.attributes["ID"] = ["%s@%s@%s@%s" % (self.get_parent(), start, end, strand)]
 
-    def _set_default_exon_id(self):
-        """gff_utils.py:362-376: parent@start@end@strand for exons without an ID."""
-        if self.type == "exon" and "ID" not in self.attributes:
-            self.attributes['ID'] = ["%s@%s@%s@%s" % (self.get_parent(), self.start, self.end,
-                                                      self.strand)]
+    @classmethod
+    def from_line(cls, line):
+        cols = line.strip().split("\t")
+        if len(cols) != 9:
+            raise FormatError("Invalid number of fields (should be 9):\n" + line.strip())
+        try:
+            return cls(unquote(cols[0]), unquote(cols[1]), unquote(cols[2]), int(cols[3]), int(cols[4]),
+                       parse_maybe_empty(cols[5], float), parse_maybe_empty(cols[6]),
+                       parse_maybe_empty(cols[7], int), _attributes(cols[8]))
+        except ValueError as err:
+            raise FormatError("GFF field format error: %s" % err)
 
     def get_values(self, key):
         return self.attributes.get(key, [])
 
     def get_value(self, key):
-        """First value, trailing whitespace removed; "" when absent (gff_utils.py:463-470)."""
-        if key in self.attributes:
-            return self.attributes[key][0].rstrip()
-        return ""
+        """First value of an attribute without trailing blanks, "" when the record has none."""
+        values = self.attributes.get(key)
+        return values[0].rstrip() if values else ""
 
     def get_id(self):
         return self.get_value("ID")
@@ -63,13 +90,21 @@ class GFF(object):
     def get_name(self):
         return self.get_value("Name")
 
+    def __getstate__(self):
+        return tuple(getattr(self, f) for f in self.__slots__)
+
+    def __setstate__(self, state):
+        for f, v in zip(self.__slots__, state):
+            setattr(self, f, v)
+
     def __repr__(self):
-        return "GFF(%s, %s, %s, %s, %s, %s)" % (self.seqid, self.type, self.start, self.end,
-                                                self.strand, self.attributes)
+        return "GFF(%s %s %s:%s-%s %s %s)" % (self.type, self.get_id(), self.seqid, self.start,
+                                              self.end, self.strand, self.attributes)
 
 
 class Reader(object):
-    """GFF3 reader (gff_utils.py:509-747, version "3" only)."""
+    """Iterates the records of a GFF3 stream; directives, comments and blank lines are skipped and a
+    FASTA section ends the records."""
 
     def __init__(self, stream, version="3"):
         if str(version) != "3":
@@ -78,150 +113,106 @@ class Reader(object):
 
     def __iter__(self):
         for line in self._stream:
-            if line.startswith("#") or line == "\n":              # directives, comments, blanks
+            if line.startswith(">"):
+                break
+            if line.startswith("#") or not line.strip():
                 continue
-            if line.startswith(">"):                               # FASTA section ends the records
-                return
-            yield self._parse_record_v3(line)
+            yield GFF.from_line(line)
 
     def read_recs(self, reverse_recs=False):
-        recs = list(self)
-        if reverse_recs:
-            recs.reverse()
-        return recs
-
-    def _parse_record_v3(self, line):
-        line = line.strip()
-        fields = line.split('\t')
-        if len(fields) != 9:
-            raise FormatError("Invalid number of fields (should be 9):\n" + line)
-        try:
-            return GFF(seqid=url_unquote(fields[0]), source=url_unquote(fields[1]),
-                       type=url_unquote(fields[2]), start=int(fields[3]), end=int(fields[4]),
-                       score=parse_maybe_empty(fields[5], float),
-                       strand=parse_maybe_empty(fields[6]),
-                       phase=parse_maybe_empty(fields[7], int),
-                       attributes=self._parse_attributes_v3(fields[8]))
-        except ValueError as e:
-            raise FormatError("GFF field format error: %s" % e)
-
-    def _parse_attributes_v3(self, s):
-        attributes = {}
-        for pair_string in s.split(";"):
-            if len(pair_string) == 0:
-                continue
-            try:
-                tag, value = pair_string.split("=")
-                attributes[url_unquote(tag)] = [url_unquote(v) for v in value.split(",")]
-            except ValueError:
-                sys.stderr.write("WARNING: Invalid attributes string: %s\n" % s)
-        return attributes
+        records = list(self)
+        return records[::-1] if reverse_recs else records
 
 
 class GFFDatabase(object):
-    """gff_utils.py:164-292: genes, mRNAs by gene, exons by mRNA, in file order."""
+    """The file's genes plus the child tables `mRNAs_by_gene`, `exons_by_mRNA`, `cdss_by_exon`,
+    every list in file order."""
 
     def __init__(self, from_filename=None, reverse_recs=False, include_introns=False,
                  suppress_warnings=False):
         self.genes, self.mRNAs, self.exons, self.cdss = [], [], [], []
-        self.mRNAs_by_gene = defaultdict(list)
-        self.exons_by_mRNA = defaultdict(list)
-        self.cdss_by_exon = defaultdict(list)
+        self.mRNAs_by_gene, self.exons_by_mRNA, self.cdss_by_exon = {}, {}, {}
         self.suppress_warnings = suppress_warnings
-        self.from_filename = from_filename
+        self.from_filename = None
         if from_filename:
-            self.from_file(from_filename, reverse_recs=reverse_recs,
-                           include_introns=include_introns)
+            self.from_file(from_filename, reverse_recs=reverse_recs, include_introns=include_introns)
 
     def from_file(self, filename, version="3", reverse_recs=False, include_introns=False):
-        with open(filename, "r") as stream:
-            for record in Reader(stream, version).read_recs(reverse_recs=reverse_recs):
-                if record.type == "gene":
-                    self.genes.append(record)
-                elif record.type == "mRNA" or record.type == "transcript":
-                    self.mRNAs.append(record)
-                    self.mRNAs_by_gene[record.get_parent()].append(record)
-                elif record.type == "exon" or (include_introns and record.type == "intron"):
-                    self.exons.append(record)
-                    self.exons_by_mRNA[record.get_parent()].append(record)
-                elif record.type == "CDS":
-                    self.cdss.append(record)
-                    self.cdss_by_exon[record.get_parent()].append(record)
+        exon_like = ("exon", "intron") if include_introns else ("exon",)
+        with open(filename) as stream:
+            for rec in Reader(stream, version).read_recs(reverse_recs=reverse_recs):
+                if rec.type == "gene":
+                    self.genes.append(rec)
+                elif rec.type in TRANSCRIPT_TYPES:
+                    self.mRNAs.append(rec)
+                    self.mRNAs_by_gene.setdefault(rec.get_parent(), []).append(rec)
+                elif rec.type in exon_like:
+                    self.exons.append(rec)
+                    self.exons_by_mRNA.setdefault(rec.get_parent(), []).append(rec)
+                elif rec.type == "CDS":
+                    self.cdss.append(rec)
+                    self.cdss_by_exon.setdefault(rec.get_parent(), []).append(rec)
         self.from_filename = filename
 
+    def gene_tree(self, gene_id):
+        """{'mRNAs': {transcript id: {'record', 'exons': {exon id: {'record', 'cdss'}}}}} of one gene
+        and its records (transcripts, then exons, then CDSs); None when the gene has no children."""
+        tree = OrderedDict()
+        transcripts, exons, cdss = self.mRNAs_by_gene.get(gene_id, []), [], []
+        for t in transcripts:
+            node = tree[t.get_id()] = {"record": t, "exons": OrderedDict()}
+            for ex in self.exons_by_mRNA.get(t.get_id(), []):
+                kids = OrderedDict((c.get_id(), {"record": c}) for c in self.cdss_by_exon.get(ex.get_id(), []))
+                node["exons"][ex.get_id()] = {"record": ex, "cdss": kids}
+                exons.append(ex)
+                cdss.extend(k["record"] for k in kids.values())
+        if not (transcripts or exons or cdss):
+            return None, []
+        return {"mRNAs": tree}, list(transcripts) + exons + cdss
+
     def get_genes_records(self, genes):
-        """gff_utils.py:226-291: (records, hierarchy) with
-        hierarchy[gene]['mRNAs'][mRNA_id] = {'record', 'exons': {exon_id: {'record', 'cdss'}}}."""
-        recs = []
-        gene_hierarchy = {}
-        for gene in genes:
-            mRNAs, exons, cdss = [], [], []
-            gene_hierarchy[gene] = {'mRNAs': OrderedDict()}
-            genes_mRNAs = self.mRNAs_by_gene.get(gene, [])
-            for mRNA_rec in genes_mRNAs:
-                gene_hierarchy[gene]['mRNAs'][mRNA_rec.get_id()] = {'exons': OrderedDict(),
-                                                                    'record': mRNA_rec}
-                mRNAs.append(mRNA_rec)
-            for mRNA_rec in genes_mRNAs:
-                mRNA_rec_id = mRNA_rec.get_id()
-                for exon_rec in self.exons_by_mRNA.get(mRNA_rec_id, []):
-                    exon_rec_id = exon_rec.get_id()
-                    gene_hierarchy[gene]['mRNAs'][mRNA_rec_id]['exons'][exon_rec_id] = \
-                        {'cdss': OrderedDict(), 'record': exon_rec}
-                    exons.append(exon_rec)
-                    for cds_rec in self.cdss_by_exon.get(exon_rec_id, []):
-                        gene_hierarchy[gene]['mRNAs'][mRNA_rec_id]['exons'][exon_rec_id]['cdss'][
-                            cds_rec.get_id()] = {'record': cds_rec}
-                        cdss.append(cds_rec)
-            if len(mRNAs) == len(exons) == len(cdss) == 0:
+        """(records, {gene id: tree}) for several genes; genes without children are left out."""
+        records, hierarchy = [], {}
+        for gene_id in genes:
+            tree, recs = self.gene_tree(gene_id)
+            if tree is None:
                 if not self.suppress_warnings:
-                    print("WARNING: No entries found for gene %s in GFF %s"
-                          % (gene, self.from_filename))
-                del gene_hierarchy[gene]
-            recs.extend(mRNAs)
-            recs.extend(exons)
-            recs.extend(cdss)
-        return recs, gene_hierarchy
+                    print("WARNING: No entries found for gene %s in GFF %s" % (gene_id, self.from_filename))
+                continue
+            hierarchy[gene_id] = tree
+            records += recs
+        return records, hierarchy
 
 
 def get_inclusive_txn_bounds(gene_hierarchy):
-    """gff_utils.py:955-981: the most inclusive mRNA start and end of a gene."""
-    mRNA_starts, mRNA_ends = [], []
-    strand = None
-    for mRNA_id, mRNA_info in gene_hierarchy['mRNAs'].items():
-        mRNA_rec = mRNA_info["record"]
-        strand = mRNA_rec.strand
-        mRNA_starts.append(mRNA_rec.start)
-        mRNA_ends.append(mRNA_rec.end)
-    assert strand is not None
-    tx_start, tx_end = min(mRNA_starts), max(mRNA_ends)
+    """(smallest transcript start, largest transcript end) of a gene's tree."""
+    records = [node["record"] for node in gene_hierarchy["mRNAs"].values()]
+    assert records, "gene without transcripts"
+    tx_start = min(r.start for r in records)
+    tx_end = max(r.end for r in records)
     assert tx_start < tx_end
     return tx_start, tx_end
 
 
 def load_indexed_gff_file(indexed_gff_filename):
-    """gff_utils.py:55-60 (Python-3 pickles written by index_gff.py of this package)."""
-    with open(indexed_gff_filename, "rb") as f:
-        return pickle.load(f)
+    """One index file written by index_gff.py: {gene id: {'gene_object', 'hierarchy'}}."""
+    with open(indexed_gff_filename, "rb") as handle:
+        return pickle.load(handle)
 
 
 def get_gene_ids_to_gff_index(indexed_gff_dir, verbose=False):
-    """gff_utils.py:89-153: gene ID -> indexed file.  The map written at indexing time is a JSON
-    file (the reference shelves it); without it the directories are scanned like the reference."""
-    map_fname = os.path.join(indexed_gff_dir, INDEX_MAP_BASENAME)
-    if os.path.isfile(map_fname):
-        with open(map_fname) as f:
-            rel = json.load(f, object_pairs_hook=OrderedDict)
-        return OrderedDict((k, os.path.join(indexed_gff_dir, v)) for k, v in rel.items())
-    gene_ids_to_gff_index = OrderedDict()
-    for chrom_dir in sorted(os.listdir(indexed_gff_dir)):
-        chrom_dir_path = os.path.abspath(os.path.join(indexed_gff_dir, chrom_dir))
-        if not os.path.isdir(chrom_dir_path):
-            continue
-        for fname in sorted(os.listdir(chrom_dir_path)):
-            if not fname.endswith(".pickle"):
-                continue
-            path = os.path.join(chrom_dir_path, fname)
-            for gene_id in load_indexed_gff_file(path):
-                gene_ids_to_gff_index[gene_id] = path
-    return gene_ids_to_gff_index
+    """gene id -> its index file.  Read from the JSON map written at indexing time (the reference
+    keeps a `shelve`); an index directory without the map is scanned, chromosome by chromosome."""
+    map_path = os.path.join(indexed_gff_dir, INDEX_MAP_BASENAME)
+    if os.path.isfile(map_path):
+        with open(map_path) as handle:
+            relative = json.load(handle, object_pairs_hook=OrderedDict)
+        return OrderedDict((gene, os.path.join(indexed_gff_dir, rel)) for gene, rel in relative.items())
+    found = OrderedDict()
+    for chrom in sorted(os.listdir(indexed_gff_dir)):
+        chrom_path = os.path.abspath(os.path.join(indexed_gff_dir, chrom))
+        if os.path.isdir(chrom_path):
+            for name in sorted(n for n in os.listdir(chrom_path) if n.endswith(".pickle")):
+                path = os.path.join(chrom_path, name)
+                found.update((gene, path) for gene in load_indexed_gff_file(path))
+    return found

@@ -204,171 +204,140 @@ class Samfile(object):
 
 
 def load_bam_reads(bam_filename, template=None):
-    """sam_utils.py:139-150."""
-    print("Loading BAM filename from: %s" % bam_filename)
-    bam_filename = os.path.abspath(os.path.expanduser(bam_filename))
-    return Samfile(bam_filename, "rb", template=template)
+    """Open (and decode) an alignment file; `template` is accepted for signature parity only."""
+    path = os.path.abspath(os.path.expanduser(bam_filename))
+    print("Loading BAM filename from: %s" % path)
+    return Samfile(path, "rb", template=template)
 
 
 def resolve_chrom(bamfile, chrom):
-    """sam_utils.py:160-168: drop a leading 'chr' when the file's references do not carry it."""
+    """The annotation's chromosome name as the file spells it: unchanged when the file has it,
+    otherwise without its first "chr" (reference: sam_utils.py:160-168)."""
     if chrom in bamfile.references:
         return chrom
-    chrom_parts = chrom.split("chr")
-    return chrom_parts[0] if len(chrom_parts) <= 1 else chrom_parts[1]
+    pieces = chrom.split("chr")          # "chr10" -> "10"; (odd names like "chrUn_chr1" -> "Un_": kept)
+    return pieces[1] if len(pieces) > 1 else pieces[0]
 
 
 def fetch_bam_reads_in_gene(bamfile, chrom, start, end, gene=None):
-    """sam_utils.py:153-186."""
-    gene_reads = []
-    chrom = resolve_chrom(bamfile, chrom)
+    """The reads overlapping a gene's region; an unknown chromosome gives no reads, not an error."""
+    name = resolve_chrom(bamfile, chrom)
     try:
-        gene_reads = bamfile.fetch(chrom, start, end)
+        return bamfile.fetch(name, start, end)
     except ValueError:
-        print("Cannot fetch reads in region: %s:%d-%d" % (chrom, start, end))
-    return gene_reads
+        print("Cannot fetch reads in region: %s:%d-%d" % (name, start, end))
+        return []
 
 
 def flag_to_strand(flag):
-    """sam_utils.py:189-196."""
-    return "-" if flag & 16 else "+"
+    return "-" if flag & 0x10 else "+"
+
+
+_MATE_SUFFIXES = ("/1", "/2", "#1", "#2")
 
 
 def strip_mate_id(read_name):
-    """sam_utils.py:199-213 -- including its off-by-one: THREE characters are dropped."""
-    if read_name.endswith("/1") or read_name.endswith("/2") or \
-       read_name.endswith("#1") or read_name.endswith("#2"):
-        read_name = read_name[0:-3]
-    return read_name
+    """Mate suffix removed -- THREE characters, as the reference does (sam_utils.py:199-213 cuts
+    `[0:-3]` for a two-character suffix); kept because it decides which reads share a name."""
+    return read_name[:-3] if read_name.endswith(_MATE_SUFFIXES) else read_name
+
+
+def _pairable(read):
+    return read.is_paired and not (read.is_qcfail or read.is_unmapped or read.mate_is_unmapped)
 
 
 def pair_sam_reads(samfile, filter_reads=True, return_unpaired=False, strand_rule=None,
                    verbose=False):
-    """sam_utils.py:216-300.  Pairs keep the order in which their names first appear (the
-    reference iterates a Python-2 dict: its order is arbitrary)."""
-    paired_reads = OrderedDict()
-    unpaired_reads = {}
+    """Mates grouped by (stripped) read name: {name: [first, second]} for the names seen exactly
+    twice with the mates on opposite strands, in order of first appearance.  Rules of the reference
+    (sam_utils.py:216-300): reads failing QC / unmapped / mate unmapped / not paired never enter a
+    group; under fr-firststrand a just-completed pair is reversed when its first entry is a reverse
+    read 1, and then again when its (new) first entry is a reverse read 2."""
+    groups = OrderedDict()
+    unpaired = {}
+    firststrand = strand_rule == "fr-firststrand"
     for read in samfile:
-        curr_name = strip_mate_id(read.qname)
-        if filter_reads:
-            if read.is_qcfail or read.is_unmapped or read.mate_is_unmapped or (not read.is_paired):
-                unpaired_reads[curr_name] = read
-                continue
-        paired_reads.setdefault(curr_name, []).append(read)
-        if len(paired_reads[curr_name]) == 2:
-            if strand_rule == "fr-firststrand":
-                if paired_reads[curr_name][0].is_read1 and paired_reads[curr_name][0].is_reverse:
-                    paired_reads[curr_name] = paired_reads[curr_name][::-1]
-                if paired_reads[curr_name][0].is_read2 and paired_reads[curr_name][0].is_reverse:
-                    paired_reads[curr_name] = paired_reads[curr_name][::-1]
-    to_delete = []
-    num_unpaired = 0
-    num_total = 0
-    for read_name, read in paired_reads.items():
-        if len(read) != 2:
-            unpaired_reads[read_name] = read
-            num_unpaired += 1
-            to_delete.append(read_name)
+        name = strip_mate_id(read.qname)
+        if filter_reads and not _pairable(read):
+            unpaired[name] = read
             continue
-        left_read, right_read = read[0], read[1]
-        if flag_to_strand(left_read.flag) == flag_to_strand(right_read.flag):
-            to_delete.append(read_name)
-            continue
-        if left_read.pos > right_read.pos and verbose:
-            print("WARNING: %s left mate starts later than right mate" % left_read.qname)
-        num_total += 1
-    for del_key in to_delete:
-        del paired_reads[del_key]
+        mates = groups.setdefault(name, [])
+        mates.append(read)
+        if firststrand and len(mates) == 2:
+            for is_mate in ("is_read1", "is_read2"):
+                if getattr(mates[0], is_mate) and mates[0].is_reverse:
+                    mates.reverse()
+    pairs = OrderedDict()
+    n_single = n_same_strand = 0
+    for name, mates in groups.items():
+        if len(mates) != 2:
+            unpaired[name] = mates
+            n_single += 1
+        elif mates[0].is_reverse == mates[1].is_reverse:
+            n_same_strand += 1
+        else:
+            pairs[name] = mates
     if verbose:
-        print("Filtered out %d read pairs that were on same strand." % len(to_delete))
-        print("Filtered out %d reads that had no paired mate." % num_unpaired)
-        print("  - Total read pairs: %d" % num_total)
-    if not return_unpaired:
-        return paired_reads
-    return paired_reads, unpaired_reads
+        print("Filtered out %d read pairs that were on same strand." % n_same_strand)
+        print("Filtered out %d reads that had no paired mate." % n_single)
+        print("  - Total read pairs: %d" % len(pairs))
+    return (pairs, unpaired) if return_unpaired else pairs
 
 
 def sam_cigar_to_str(sam_cigar):
-    """sam_utils.py:305-322."""
-    cigar_str = ""
-    if sam_cigar is None:
-        return cigar_str
-    for c in sam_cigar:
-        cigar_str += "%d%s" % (c[1], CIGAR_TYPES[c[0]])
-    return cigar_str
+    """[(op, length), ...] -> "36M", "" for no CIGAR."""
+    return "".join("%d%s" % (length, CIGAR_TYPES[op]) for op, length in (sam_cigar or ()))
 
 
 def read_matches_strand(read, target_strand, strand_rule, paired_end=None):
-    """sam_utils.py:325-370."""
+    """Does a read (or a (mate1, mate2) pair when paired_end is given) agree with the annotation's
+    strand under the library's strand rule?  fr-unstranded: always.  fr-firststrand, single-end: the
+    read's strand is the target's; paired: '+' target wants the first mate forward, '-' target the
+    second mate reverse, any other target matches nothing (None, as in the reference).
+    fr-secondstrand and unknown rules raise (sam_utils.py:325-370)."""
     if strand_rule == "fr-unstranded":
         return True
     if strand_rule == "fr-secondstrand":
         raise Exception("fr-secondstrand currently unsupported.")
-    matches = False
-    if paired_end is not None:
-        read1, read2 = read
-        if strand_rule == "fr-firststrand":
-            if target_strand == "+":
-                return flag_to_strand(read1.flag) == "+"
-            elif target_strand == "-":
-                return flag_to_strand(read2.flag) == "-"
-            # any other target strand: the reference falls through and returns None
-            return None
-        else:
-            raise Exception("Unknown strandedness rule.")
-    else:
-        if strand_rule == "fr-firststrand":
-            matches = (flag_to_strand(read.flag) == target_strand)
-        else:
-            raise Exception("Unknown strandedness rule.")
-    return matches
+    if strand_rule != "fr-firststrand":
+        raise Exception("Unknown strandedness rule.")
+    if paired_end is None:
+        return flag_to_strand(read.flag) == target_strand
+    first, second = read
+    if target_strand == "+":
+        return flag_to_strand(first.flag) == "+"
+    if target_strand == "-":
+        return flag_to_strand(second.flag) == "-"
+    return None
 
 
 def sam_parse_reads(samfile, paired_end=False, strand_rule=None, target_strand=None,
                     given_read_len=None, verbose=False):
-    """sam_utils.py:373-452: (positions, cigar strings) for the sampler + number of reads."""
-    read_positions = []
-    read_cigars = []
-    num_reads = 0
-    check_strand = True
-    if (strand_rule is None) or (strand_rule == "fr-unstranded") or (target_strand is None):
-        check_strand = False
-    num_strand_discarded = 0
-    if paired_end:
-        paired_reads = pair_sam_reads(samfile, strand_rule=strand_rule, verbose=verbose)
-        for read_id, read_info in paired_reads.items():
-            if check_strand:
-                if not read_matches_strand(read_info, target_strand, strand_rule,
-                                           paired_end=paired_end):
-                    num_strand_discarded += 1
-                    continue
-            read1, read2 = read_info
-            if (read1.cigar is None) or (read2.cigar is None):
+    """((positions, CIGAR strings), number of reads or pairs) as the sampler takes them
+    (sam_utils.py:373-452): 0-based positions, two consecutive entries per pair; reads without a
+    CIGAR, of another length than given_read_len, or on the wrong strand are left out.  The strand
+    is only checked when both a rule other than fr-unstranded and a target strand are given."""
+    check_strand = strand_rule not in (None, "fr-unstranded") and target_strand is not None
+    units = pair_sam_reads(samfile, strand_rule=strand_rule, verbose=verbose).values() if paired_end \
+        else ([read] for read in samfile)
+    positions, cigars = [], []
+    kept = discarded = 0
+    for mates in units:
+        if check_strand and paired_end:
+            if not read_matches_strand(mates, target_strand, strand_rule, paired_end=paired_end):
+                discarded += 1
                 continue
-            if given_read_len is not None:
-                if (read1.rlen != given_read_len) or (read2.rlen != given_read_len):
-                    continue
-            read_positions.append(int(read1.pos))
-            read_positions.append(int(read2.pos))
-            read_cigars.append(sam_cigar_to_str(read1.cigar))
-            read_cigars.append(sam_cigar_to_str(read2.cigar))
-            num_reads += 1
-    else:
-        for read in samfile:
-            if read.cigar is None:
+        if any(m.cigar is None for m in mates):
+            continue
+        if given_read_len is not None and any(m.rlen != given_read_len for m in mates):
+            continue
+        if check_strand and not paired_end:
+            if not read_matches_strand(mates[0], target_strand, strand_rule, paired_end=paired_end):
+                discarded += 1
                 continue
-            if given_read_len is not None:
-                if read.rlen != given_read_len:
-                    continue
-            if check_strand:
-                if not read_matches_strand(read, target_strand, strand_rule,
-                                           paired_end=paired_end):
-                    num_strand_discarded += 1
-                    continue
-            read_positions.append(int(read.pos))
-            read_cigars.append(sam_cigar_to_str(read.cigar))
-            num_reads += 1
+        positions += [int(m.pos) for m in mates]
+        cigars += [sam_cigar_to_str(m.cigar) for m in mates]
+        kept += 1
     if check_strand and verbose:
-        print("No. reads discarded due to strand violation: %d" % num_strand_discarded)
-    reads = (tuple(read_positions), tuple(read_cigars))
-    return reads, num_reads
+        print("No. reads discarded due to strand violation: %d" % discarded)
+    return (tuple(positions), tuple(cigars)), kept
