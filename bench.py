@@ -118,6 +118,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--events", type=int, default=40000, help="events per GPU")
     ap.add_argument("--K", type=int, default=2)
+    ap.add_argument("--K-range", type=int, nargs=2, default=None, metavar=("LO", "HI"),
+                    help="isoforms per event drawn from [LO, HI] by event id (configs[3] proxy: whole-gene "
+                         "mode, mixed isoform counts in one batch); overrides --K, no CPU baseline")
     ap.add_argument("--reads", type=int, default=1000)
     ap.add_argument("--read-len", type=int, default=36)
     ap.add_argument("--iters", type=int, default=7500)
@@ -142,6 +145,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
 
+    if a.K_range:
+        a.no_cpu_baseline = True
+    k_spec = tuple(a.K_range) if a.K_range else a.K
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline and not a.paired:
         cpu = cpu_baseline(a)  # before anything touches the GPU (fork-safe)
@@ -157,7 +163,7 @@ def main():
 
     first = rank * a.events
     t_build = time.perf_counter()
-    batch = workload.build_batch(first, a.events, K=a.K, n_reads=a.reads, read_len=a.read_len,
+    batch = workload.build_batch(first, a.events, K=k_spec, n_reads=a.reads, read_len=a.read_len,
                                  iters=a.iters, burn=a.burn, lag=a.lag, chains=a.chains,
                                  paired=a.paired, device_match=not a.host_match)
     t_up = time.perf_counter()
@@ -243,9 +249,9 @@ def main():
             "config": {"workload": "configs[1] proxy: %d %s events/GPU, K=%d isoforms, %d reads of "
                                    "%d bp, %d iters (%d burn-in + %d kept), lag %d, %d chain(s)"
                                    % (a.events, "paired-end" if a.paired else "skipped-exon single-end",
-                                      a.K, a.reads, a.read_len, a.iters, a.burn, a.iters - a.burn,
+                                      a.K if not a.K_range else -1, a.reads, a.read_len, a.iters, a.burn, a.iters - a.burn,
                                       a.lag, a.chains),
-                       "events_per_gpu": a.events, "K": a.K, "reads": a.reads, "iters": a.iters,
+                       "events_per_gpu": a.events, "K": a.K if not a.K_range else list(a.K_range), "reads": a.reads, "iters": a.iters,
                        "burn_in": a.burn, "lag": a.lag, "chains": a.chains,
                        "parallelism": "static event shard x%d, no collective" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,

@@ -29,6 +29,8 @@ struct miso_batch {
   bool uploaded = false, launched = false, downloaded = false;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::vector<hipStream_t> aux_streams;   // kernels 2.. of a mixed batch run beside the first
+  std::vector<hipEvent_t> aux_done;
   miso::DevEvent *d_events = nullptr;
   unsigned char *d_in = nullptr, *d_out = nullptr;
   double *d_fp = nullptr;

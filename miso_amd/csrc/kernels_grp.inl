@@ -507,7 +507,8 @@ __global__ __launch_bounds__(256, KC <= 8 ? MISO_GRP_MINBLOCKS : 2) void sampler
   int64_t rfix = 0; int rbad = 0;
   const GibbsRng rng = gibbs_rng_init(a.seed, event_id, chain);
   // paired-end fast path: one isoform count for the whole wavefront
-  const bool pe_fast = PE && KC <= 16 && Kw >= KLO && __all(K == Kw);
+  // (the K <= 32 class has the quad path up to 20 isoforms: BASELINE configs[3] is 3-20 per gene)
+  const bool pe_fast = PE && (KC <= 16 || Kw <= 20) && Kw >= KLO && __all(K == Kw);
 
 #ifdef MISO_K2_PROFILE
   uint64_t gp_thr = 0, gp_loop = 0, gp_mh = 0;
@@ -639,6 +640,7 @@ __global__ __launch_bounds__(256, KC <= 8 ? MISO_GRP_MINBLOCKS : 2) void sampler
       else if constexpr (KC == 8) { if (Kw == 5) MISO_PEQ(5) else if (Kw == 6) MISO_PEQ(6) else if (Kw == 7) MISO_PEQ(7) else MISO_PEQ(8) }
       else if constexpr (KC == 12) { if (Kw == 9) MISO_PEQ(9) else if (Kw == 10) MISO_PEQ(10) else if (Kw == 11) MISO_PEQ(11) else MISO_PEQ(12) }
       else if constexpr (KC == 16) { if (Kw == 13) MISO_PEQ(13) else if (Kw == 14) MISO_PEQ(14) else if (Kw == 15) MISO_PEQ(15) else MISO_PEQ(16) }
+      else { if (Kw == 17) MISO_PEQ(17) else if (Kw == 18) MISO_PEQ(18) else if (Kw == 19) MISO_PEQ(19) else MISO_PEQ(20) }
 #undef MISO_PEQ
       wave_sync();
 #pragma unroll

@@ -84,6 +84,9 @@ void miso_batch::release() {
   d_slots = nullptr;
   if (ev0) (void) hipEventDestroy(ev0);
   if (ev1) (void) hipEventDestroy(ev1);
+  for (hipStream_t st : aux_streams) (void) hipStreamDestroy(st);
+  for (hipEvent_t e : aux_done) (void) hipEventDestroy(e);
+  aux_streams.clear(); aux_done.clear();
   if (stream) (void) hipStreamDestroy(stream);
   d_events = nullptr; d_in = d_out = nullptr; d_fp = nullptr; ev0 = ev1 = nullptr; stream = nullptr;
   uploaded = launched = downloaded = false;
@@ -354,7 +357,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   // ---- two-isoform events: sampler_k2<G> ----
   const size_t k2_fp = p.paired ? align_up(fd.prob.size() * 8, 16) : 0;
   const size_t k2_tab = p.paired ? 2 * fd.prob.size() * 4 : 0;   // per chain: int32[2 x il]
-  auto launch_k2 = [&](KernelArgs ka, int G) {
+  auto launch_k2 = [&](KernelArgs ka, int G, hipStream_t st) {
     const long chains = static_cast<long>(n_k2) * p.noChains;
     ka.slot_event = d_slots; ka.n_slots = n_k2;
     const int cpw = 64 / std::max(G, 1);
@@ -362,8 +365,8 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     const size_t k2_lds = k2_fp + 4 * static_cast<size_t>(cpw) * k2_tab;
 #define MISO_K2_LAUNCH(GG)                                                                           \
   case GG:                                                                                          \
-    if (p.paired) hipLaunchKernelGGL((sampler_k2<GG, true>), dim3(grid), dim3(256), k2_lds, stream, ka); \
-    else hipLaunchKernelGGL((sampler_k2<GG, false>), dim3(grid), dim3(256), 0, stream, ka);           \
+    if (p.paired) hipLaunchKernelGGL((sampler_k2<GG, true>), dim3(grid), dim3(256), k2_lds, st, ka); \
+    else hipLaunchKernelGGL((sampler_k2<GG, false>), dim3(grid), dim3(256), 0, st, ka);               \
     break;
     switch (G) {
       MISO_K2_LAUNCH(1) MISO_K2_LAUNCH(2) MISO_K2_LAUNCH(3) MISO_K2_LAUNCH(4) MISO_K2_LAUNCH(5)
@@ -395,15 +398,15 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     return G >= 2 && G <= 32 && !(G & (G - 1)) &&
            fp_bytes + 4 * static_cast<size_t>(64 / G) * grp_slice_bytes(run.kmax, sh.qs, sh.ts) <= LDS_MAX;
   };
-  auto launch_grp = [&](KernelArgs ka, const GenRun &run, const GrpShape &sh, int G) {
+  auto launch_grp = [&](KernelArgs ka, const GenRun &run, const GrpShape &sh, int G, hipStream_t st) {
     const long chains = static_cast<long>(run.count) * p.noChains;
     ka.slot_event = d_slots + n_k2 + run.first; ka.n_slots = run.count;
     ka.kstride = run.kmax; ka.cstride = sh.qs; ka.tstride = sh.ts;
     if (G == 64) {
       const unsigned grid = static_cast<unsigned>((chains + 3) / 4);
       const size_t lds = fp_bytes + 4 * 32 * sizeof(int);
-      if (p.paired) hipLaunchKernelGGL(sampler_wave<true>, dim3(grid), dim3(256), lds, stream, ka);
-      else hipLaunchKernelGGL(sampler_wave<false>, dim3(grid), dim3(256), lds, stream, ka);
+      if (p.paired) hipLaunchKernelGGL(sampler_wave<true>, dim3(grid), dim3(256), lds, st, ka);
+      else hipLaunchKernelGGL(sampler_wave<false>, dim3(grid), dim3(256), lds, st, ka);
     } else {
       const int cpw = 64 / G;
       const unsigned grid = static_cast<unsigned>(((chains + cpw - 1) / cpw + 3) / 4);
@@ -413,11 +416,11 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     if (p.paired) {                                                                                        \
       HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sampler_grp<GG, true, KC>),               \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));      \
-      hipLaunchKernelGGL((sampler_grp<GG, true, KC>), dim3(grid), dim3(256), lds, stream, ka);             \
+      hipLaunchKernelGGL((sampler_grp<GG, true, KC>), dim3(grid), dim3(256), lds, st, ka);                 \
     } else {                                                                                               \
       HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sampler_grp<GG, false, KC>),              \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));      \
-      hipLaunchKernelGGL((sampler_grp<GG, false, KC>), dim3(grid), dim3(256), lds, stream, ka);            \
+      hipLaunchKernelGGL((sampler_grp<GG, false, KC>), dim3(grid), dim3(256), lds, st, ka);                \
     }                                                                                                      \
   }
 #define MISO_GRP_LAUNCH(GG)                                    \
@@ -470,6 +473,18 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     return best;
   };
 
+  // A batch with several kernels (two-isoform events + one general kernel per isoform-count class)
+  // runs them CONCURRENTLY, one stream each: every kernel then only has its share of the device to
+  // fill, so the lanes-per-chain rule sees `wave_slots x share` (one after the other, each class of
+  // a whole-gene batch -- a few thousand chains -- would be spread thin over 32 lanes per chain and
+  // still leave the GPU half empty).
+  const long total_chains = static_cast<long>(n) * p.noChains;
+  const size_t n_kernels = (n_k2 > 0 ? 1 : 0) + gen_runs.size();
+  auto slots_for = [&](long chains) {
+    if (n_kernels <= 1 || total_chains <= 0) return wave_slots;
+    return std::max(1, static_cast<int>(static_cast<double>(wave_slots) * chains / total_chains));
+  };
+  const bool tune_runs = tune && n_kernels <= 1;   // trial launches would time a kernel alone
   int k2_G = 0;
   if (n_k2 > 0) {
     const long chains = static_cast<long>(n_k2) * p.noChains;
@@ -478,8 +493,8 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     if (const char *env = std::getenv("MISO_LANES_PER_CHAIN")) k2_G = std::atoi(env);
     else if (tuned_k2_G) k2_G = tuned_k2_G;
     else {
-      k2_G = choose_lanes_per_chain(chains, maxq, wave_slots, max_cpw);
-      if (tune && chains >= 4096 && std::getenv("MISO_AUTOTUNE_K2") != nullptr) {   // the rule is the measured optimum
+      k2_G = choose_lanes_per_chain(chains, maxq, slots_for(chains), max_cpw);
+      if (tune_runs && chains >= 4096 && std::getenv("MISO_AUTOTUNE_K2") != nullptr) {   // the rule is the measured optimum
         static const int kG[] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 16, 21, 32, 64};
         std::vector<int> cand{k2_G};
         for (int i = 0; i < 15; i++)
@@ -489,7 +504,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
                   kG[j] <= std::max(1, maxq))
                 cand.push_back(kG[j]);
           }
-        if (cand.size() > 1) k2_G = fastest(cand, [&](const KernelArgs &t, int g) { launch_k2(t, g); });
+        if (cand.size() > 1) k2_G = fastest(cand, [&](const KernelArgs &t, int g) { launch_k2(t, g, stream); });
         tuned_k2_G = k2_G;
       }
     }
@@ -517,15 +532,15 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
         const int cpw = 64 / g;
         if (!found || g <= std::max(2, run.maxq)) G = g;
         found = true;
-        if (!p.paired && (chains + cpw - 1) / cpw >= wave_slots) break;
+        if (!p.paired && (chains + cpw - 1) / cpw >= slots_for(chains)) break;
       }
-      if (tune && chains >= 2048 && G != 64) {
+      if (tune_runs && chains >= 2048 && G != 64) {
         std::vector<int> cand{G};
         // the rule errs on the small side (tail effect when the wavefronts do not fit one round)
         for (int g : {G * 2, G * 4})
           if (!p.paired && grp_fits(run, sh, g) && g <= std::max(2, 2 * run.maxq)) cand.push_back(g);
         if (cand.size() > 1)
-          G = fastest(cand, [&](const KernelArgs &t, int g) { launch_grp(t, run, sh, g); });
+          G = fastest(cand, [&](const KernelArgs &t, int g) { launch_grp(t, run, sh, g, stream); });
         run.tuned_G = G;
       }
     }
@@ -535,10 +550,24 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   }
 
   HIP_OK(hipEventRecord(ev0, stream));                  // events bracket the sampler kernels only
+  // kernel i > 0 goes to its own stream, forked from and joined back into the batch's stream
+  size_t kernel_no = 0;
+  auto stream_for_next = [&]() {
+    const size_t i = kernel_no++;
+    if (i == 0) return stream;
+    while (aux_streams.size() < i) {
+      hipStream_t st; hipEvent_t e;
+      HIP_OK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+      HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      aux_streams.push_back(st); aux_done.push_back(e);
+    }
+    HIP_OK(hipStreamWaitEvent(aux_streams[i - 1], ev0, 0));
+    return aux_streams[i - 1];
+  };
   if (n_k2 > 0) {
     lanes_per_chain = k2_G;
     last_kernels = "sampler_k2<" + std::to_string(k2_G) + (p.paired ? ", true>" : ", false>");
-    launch_k2(a, k2_G);
+    launch_k2(a, k2_G, stream_for_next());
   }
   for (size_t ri = 0; ri < gen_runs.size(); ri++) {
     const GenRun &run = gen_runs[ri];
@@ -548,7 +577,11 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
                              : "sampler_grp<" + std::to_string(G) + ", ") +
                     (p.paired ? "true" : "false") +
                     (G == 64 ? std::string(">") : ", " + std::to_string(run.kc) + ">");
-    launch_grp(a, run, grp_sh[ri], G);
+    launch_grp(a, run, grp_sh[ri], G, stream_for_next());
+  }
+  for (size_t i = 1; i < kernel_no; i++) {
+    HIP_OK(hipEventRecord(aux_done[i - 1], aux_streams[i - 1]));
+    HIP_OK(hipStreamWaitEvent(stream, aux_done[i - 1], 0));
   }
   HIP_OK(hipEventRecord(ev1, stream));
   launched = true; downloaded = false; summarized = false; compared = false;

@@ -30,6 +30,15 @@ def event_gene(event_id, K=2, min_len=50, max_len=300, gap=200):
     return exons, isoforms, expr
 
 
+def mixed_k(event_id, K):
+    """K itself, or for K = (lo, hi) a pure function of the event id in [lo, hi] -- BASELINE
+    configs[3]: whole-gene mode, 3-20 isoforms per gene."""
+    if isinstance(K, (tuple, list)):
+        lo, hi = K
+        return lo + int((int(event_id) * 2654435761) >> 7) % (hi - lo + 1)
+    return K
+
+
 def build_batch(first_event_id, n_events, K=2, n_reads=1000, read_len=36, iters=7500, burn=2500,
                 lag=1, chains=1, paired=False, mean=250.0, var=900.0, counts_trace=False,
                 device_match=False):
@@ -40,7 +49,7 @@ def build_batch(first_event_id, n_events, K=2, n_reads=1000, read_len=36, iters=
                    counts_trace=counts_trace, device_match=device_match)
     for i in range(n_events):
         gid = first_event_id + i
-        exons, isoforms, expr = event_gene(gid, K, **kw)
+        exons, isoforms, expr = event_gene(gid, mixed_k(gid, K), **kw)
         b.add_simulated(capi.Gene(exons, isoforms), expr, n_reads, GEN_SEED + gid)
     return b
 
@@ -48,7 +57,7 @@ def build_batch(first_event_id, n_events, K=2, n_reads=1000, read_len=36, iters=
 def event_reads(event_id, K=2, n_reads=1000, read_len=36, paired=False, mean=250.0, var=900.0):
     """The same reads build_batch gives event `event_id`, as (exons, isoforms, pos, cigars)."""
     kw = dict(min_len=400, max_len=800, gap=300) if paired else {}
-    exons, isoforms, expr = event_gene(event_id, K, **kw)
+    exons, isoforms, expr = event_gene(event_id, mixed_k(event_id, K), **kw)
     g = capi.Gene(exons, isoforms)
     _, pos, cig = capi.simulate_reads(g, expr, n_reads, read_len, GEN_SEED + int(event_id),
                                       mean if paired else 0.0, var if paired else 0.0)
