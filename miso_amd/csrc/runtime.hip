@@ -554,7 +554,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   size_t kernel_no = 0;
   auto stream_for_next = [&]() {
     const size_t i = kernel_no++;
-    if (i == 0) return stream;
+    if (i == 0 || std::getenv("MISO_SERIAL_KERNELS") != nullptr) return stream;
     while (aux_streams.size() < i) {
       hipStream_t st; hipEvent_t e;
       HIP_OK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -579,7 +579,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
                     (G == 64 ? std::string(">") : ", " + std::to_string(run.kc) + ">");
     launch_grp(a, run, grp_sh[ri], G, stream_for_next());
   }
-  for (size_t i = 1; i < kernel_no; i++) {
+  for (size_t i = 1; i < kernel_no && i <= aux_streams.size() && std::getenv("MISO_SERIAL_KERNELS") == nullptr; i++) {
     HIP_OK(hipEventRecord(aux_done[i - 1], aux_streams[i - 1]));
     HIP_OK(hipStreamWaitEvent(stream, aux_done[i - 1], 0));
   }
