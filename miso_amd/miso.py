@@ -55,7 +55,8 @@ class GenesDispatcher(object):
         self.summarize, self.compare_bam, self.labels = summarize, compare_bam, labels
         if compare_bam is not None and not os.path.isfile(compare_bam):
             raise IOError("BAM file %s not found." % compare_bam)
-        self.num_processors = int(num_proc) if num_proc is not None else max(1, visible_gpus())
+        self.n_gpus = max(1, visible_gpus())
+        self.num_processors = int(num_proc) if num_proc is not None else self.n_gpus
         self.batch_logs_dir = os.path.join(output_dir, "batch-logs")
         self.batch_genes_dir = os.path.join(output_dir, "batch-genes")
         os.makedirs(self.batch_logs_dir, exist_ok=True)
@@ -113,7 +114,8 @@ class GenesDispatcher(object):
                        self.bam_filename, self.output_dir]
                 if part:
                     cmd += ["--summary-file", part]
-            cmd += ["--read-len", str(self.read_len), "--device", str(batch_num),
+            # more chunks than GPUs (-p above the GPU count) share the GPUs round robin
+            cmd += ["--read-len", str(self.read_len), "--device", str(batch_num % self.n_gpus),
                     "--first-event-id", str(first)]
             if self.paired_end is not None:
                 cmd += ["--paired-end", "%.1f" % float(self.paired_end[0]),
@@ -128,7 +130,7 @@ class GenesDispatcher(object):
                 cmd += ["--seed", str(self.seed)]
             log = os.path.join(self.batch_logs_dir, "batch-%d-%s.log"
                                % (batch_num, time.strftime("%m-%d-%y_%H:%M:%S")))
-            print("Running batch of %d genes on GPU %d.." % (size, batch_num))
+            print("Running batch of %d genes on GPU %d.." % (size, batch_num % self.n_gpus))
             env = dict(os.environ)
             root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
             env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")

@@ -211,3 +211,39 @@ def test_cli_summarize_and_compare(tmp_path):
     assert abs((m1 - m2) - diff) < 0.011 and bfv >= 0
     s1 = miso_sampler.load_samples(os.path.join(out2, "ctl", "10", "ENSMUSG00000019943.miso"))[0]
     assert abs(m1 - s1[:, 0].mean()) < 0.006
+
+
+def test_results_do_not_depend_on_the_number_of_worker_processes(tmp_path):
+    """`miso --run -p 1` and `-p 3` (three chunks, here sharing the one GPU) over 7 genes, two of which
+    the skip rules drop: every .miso file identical -- each gene keeps its global number in the
+    random-number counter whatever the split."""
+    from miso_amd import workload
+    gff, sam = tmp_path / "g.gff", tmp_path / "r.sam"
+    lines, recs = ["##gff-version 3"], []
+    for e in range(7):
+        off = 10000 + e * 6000
+        exons, isoforms, pos, cig = workload.event_reads(e, 2 + (e % 3), 15 if e in (2, 5) else 300)
+        ex = [(s + off, t + off) for s, t in exons]
+        gid = "gene%d" % e
+        lines.append("chr1\tx\tgene\t%d\t%d\t.\t+\t.\tID=%s" % (ex[0][0], ex[-1][1], gid))
+        for m, iso in enumerate(isoforms):
+            tid = "%s.t%d" % (gid, m)
+            lines.append("chr1\tx\tmRNA\t%d\t%d\t.\t+\t.\tID=%s;Parent=%s" % (ex[iso[0]][0], ex[iso[-1]][1], tid, gid))
+            lines += ["chr1\tx\texon\t%d\t%d\t.\t+\t.\tID=%s.e%d;Parent=%s" % (ex[x][0], ex[x][1], tid, x, tid) for x in iso]
+        recs += ["r%d_%d\t0\tchr1\t%d\t255\t%s\t*\t0\t0\t%s\t%s" % (e, i, pos[i] + off, cig[i].decode(), "A" * 36, "I" * 36)
+                 for i in range(len(pos))]
+    gff.write_text("\n".join(lines) + "\n")
+    sam.write_text("@SQ\tSN:chr1\tLN:100000\n" + "\n".join(recs) + "\n")
+    settings = tmp_path / "s.txt"
+    settings.write_text("[data]\nmin_event_reads = 20\n[sampler]\nburn_in = 100\nlag = 5\nnum_iters = 600\nnum_chains = 2\n")
+    idx = str(tmp_path / "idx")
+    assert run(["-m", "miso_amd.index_gff", "--index", str(gff), idx]).returncode == 0
+    outs = {}
+    for nproc in (1, 3):
+        out = str(tmp_path / ("out%d" % nproc))
+        r = run(["-m", "miso_amd.miso", "--run", idx, str(sam), "--output-dir", out, "--read-len", "36",
+                 "--settings-filename", str(settings), "-p", str(nproc), "--seed", "77"])
+        assert r.returncode == 0, r.stdout
+        outs[nproc] = {f: open(os.path.join(out, "chr1", f), "rb").read() for f in sorted(os.listdir(os.path.join(out, "chr1")))}
+    assert sorted(outs[1]) == ["gene%d.miso" % e for e in (0, 1, 3, 4, 6)]      # 15-read genes skipped
+    assert outs[1] == outs[3]
