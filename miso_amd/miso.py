@@ -177,7 +177,8 @@ def main(argv=None):
     ap.add_argument("--paired-end", nargs=2, default=None, metavar=("MEAN", "SD"))
     ap.add_argument("--overhang-len", type=int, default=None)
     ap.add_argument("--output-dir", default=None)
-    ap.add_argument("-p", dest="num_proc", type=int, default=None, help="number of GPUs")
+    ap.add_argument("-p", dest="num_proc", type=int, default=None,
+                    help="worker processes (default: one per visible GPU; more share the GPUs round robin)")
     ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--summarize", action="store_true",
                     help="also write OUT/summary/<OUT>.miso_summary (summarize_miso's table) from "
