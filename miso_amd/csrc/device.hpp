@@ -77,7 +77,7 @@ struct KernelArgs {
 };
 
 constexpr uint64_t NO_TRACE = ~0ull;
-constexpr int MAX_DRAW_CLASSES = 32;  // single-end: per-class integer thresholds up to this many classes
+constexpr int MAX_DRAW_CLASSES = 64;  // single-end: per-class integer thresholds up to this many classes (if the LDS slice fits)
 
 // LDS bytes of one chain's slice in sampler_grp (layout: kernels_grp.hip `carve`): isoform stride ks
 // (even), cs single-end drawing-read classes (0 = no class path), ts paired-end score entries.
