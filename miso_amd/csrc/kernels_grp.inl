@@ -525,11 +525,17 @@ __global__ __launch_bounds__(256, KC <= 8 ? MISO_GRP_MINBLOCKS : 2) void sampler
       const int tw = ks - 1;
       // register-resident threshold set-up pays from ~9 isoforms on (measured: K=8 +6%, K=10 +6%,
       // K=16 +18%; K=3 -2%, K=5 -5% because the unroll is as wide as the class's largest K)
-      constexpr bool REG_THR = KC >= 12 && KC <= 16;
-      double psr[REG_THR ? KC : 1];
-      if constexpr (REG_THR) {
+      // (the K <= 32 kernel has it for wavefronts of up to 20 isoforms: thresholds were more than
+      // 40 % of the K = 18..20 iteration)
+      constexpr bool REG_CAP = KC >= 12;
+      constexpr int KR = KC == 32 ? 20 : KC;
+      const bool reg_thr = REG_CAP && Kw <= KR;          // wave-uniform
+      double psr[REG_CAP ? KR : 1];
+      if constexpr (REG_CAP) {
+        if (reg_thr) {
 #pragma unroll
-        for (int k = 0; k < KC; k++) psr[k] = (k < K) ? S.psi[k] : 0.0;
+          for (int k = 0; k < KR; k++) psr[k] = (k < K) ? S.psi[k] : 0.0;
+        }
       }
       for (int p0 = 0; p0 < npw; p0 += G) {
         const int p = p0 + sub;
@@ -538,12 +544,12 @@ __global__ __launch_bounds__(256, KC <= 8 ? MISO_GRP_MINBLOCKS : 2) void sampler
           const int cc = static_cast<int>(pr >> 8), kp = static_cast<int>(pr & 0xFFu);
           const uint32_t m = S.ctab[CLS_WORDS * cc];
           double T = 0.0, cumw = 0.0;
-          if constexpr (REG_THR) {
+          if (REG_CAP && reg_thr) {
             // psi from registers, branch-free: a serial chain of LDS reads (one per compatible
             // isoform, ~100 cycles each) was a third of the K=10 iteration.  Adding +0.0 for the
             // isoforms outside the class leaves the sum's bits unchanged (all terms are >= +0).
 #pragma unroll
-            for (int k = 0; k < KC; k++) {
+            for (int k = 0; k < (REG_CAP ? KR : 1); k++) {
               T = T + (((m >> k) & 1u) ? psr[k] : 0.0);   // ascending isoforms, as miso.c:11-22
               cumw = (k == kp) ? T : cumw;
             }
@@ -570,12 +576,13 @@ __global__ __launch_bounds__(256, KC <= 8 ? MISO_GRP_MINBLOCKS : 2) void sampler
           const uint32_t m = S.ctab[CLS_WORDS * cc];
           const int kmax = 31 - __clz(static_cast<int>(m));
           uint32_t run = 0, val = 0;
-          if constexpr (REG_THR) {
-            uint32_t tv[KC - 1];   // all loads first: they are independent, the stores below alias them
+          if (REG_CAP && reg_thr) {
+            constexpr int KT = REG_CAP ? KR - 1 : 1;
+            uint32_t tv[KT];   // all loads first: they are independent, the stores below alias them
 #pragma unroll
-            for (int k = 0; k < KC - 1; k++) tv[k] = (k < K - 1 && ((m >> k) & 1u)) ? S.thr[cc * tw + k] : 0u;
+            for (int k = 0; k < KT; k++) tv[k] = (k < K - 1 && ((m >> k) & 1u)) ? S.thr[cc * tw + k] : 0u;
 #pragma unroll
-            for (int k = 0; k < KC - 1; k++) {
+            for (int k = 0; k < KT; k++) {
               if (k < K - 1) {
                 if (k >= kmax) val = 0u;
                 else if ((m >> k) & 1u) { run = tv[k] > run ? tv[k] : run; val = run; }
