@@ -508,7 +508,11 @@ __global__ __launch_bounds__(256, KC <= 8 ? MISO_GRP_MINBLOCKS : 2) void sampler
   const GibbsRng rng = gibbs_rng_init(a.seed, event_id, chain);
   // paired-end fast path: one isoform count for the whole wavefront
   // (the K <= 32 class has the quad path up to 20 isoforms: BASELINE configs[3] is 3-20 per gene)
-  const bool pe_fast = PE && (KC <= 16 || Kw <= 20) && Kw >= KLO && __all(K == Kw);
+  // Chains of different K may share a wavefront (the last wavefront of every K inside a class): each
+  // then runs its own instantiation of the quad loop under divergence -- the loop has no wavefront-wide
+  // operation -- instead of dragging the whole wavefront to the generic path (those few wavefronts
+  // used to take 3x as long as everything else in a mixed batch and set the kernel's duration).
+  const bool pe_fast = PE && __all(K >= KLO && K <= (KC == 32 ? 20 : KC));
 
 #ifdef MISO_K2_PROFILE
   uint64_t gp_thr = 0, gp_loop = 0, gp_mh = 0;
@@ -643,11 +647,12 @@ __global__ __launch_bounds__(256, KC <= 8 ? MISO_GRP_MINBLOCKS : 2) void sampler
     else if (__any(write_ass)) pe_quads<KK, G, true>(frags, S.psi, lds_fp, sfix, a.il, S.cnt, drawass, write_ass, nqw, n_quads, n_draw, sub, rng, n0r0, acc, bad); \
     else pe_quads<KK, G, false>(frags, S.psi, lds_fp, sfix, a.il, S.cnt, drawass, write_ass, nqw, n_quads, n_draw, sub, rng, n0r0, acc, bad); \
   }
-      if constexpr (KC == 4) { if (Kw == 3) MISO_PEQ(3) else MISO_PEQ(4) }
-      else if constexpr (KC == 8) { if (Kw == 5) MISO_PEQ(5) else if (Kw == 6) MISO_PEQ(6) else if (Kw == 7) MISO_PEQ(7) else MISO_PEQ(8) }
-      else if constexpr (KC == 12) { if (Kw == 9) MISO_PEQ(9) else if (Kw == 10) MISO_PEQ(10) else if (Kw == 11) MISO_PEQ(11) else MISO_PEQ(12) }
-      else if constexpr (KC == 16) { if (Kw == 13) MISO_PEQ(13) else if (Kw == 14) MISO_PEQ(14) else if (Kw == 15) MISO_PEQ(15) else MISO_PEQ(16) }
-      else { if (Kw == 17) MISO_PEQ(17) else if (Kw == 18) MISO_PEQ(18) else if (Kw == 19) MISO_PEQ(19) else MISO_PEQ(20) }
+      // per-lane K: divergent only in wavefronts that mix isoform counts
+      if constexpr (KC == 4) { if (K == 3) MISO_PEQ(3) else MISO_PEQ(4) }
+      else if constexpr (KC == 8) { if (K == 5) MISO_PEQ(5) else if (K == 6) MISO_PEQ(6) else if (K == 7) MISO_PEQ(7) else MISO_PEQ(8) }
+      else if constexpr (KC == 12) { if (K == 9) MISO_PEQ(9) else if (K == 10) MISO_PEQ(10) else if (K == 11) MISO_PEQ(11) else MISO_PEQ(12) }
+      else if constexpr (KC == 16) { if (K == 13) MISO_PEQ(13) else if (K == 14) MISO_PEQ(14) else if (K == 15) MISO_PEQ(15) else MISO_PEQ(16) }
+      else { if (K == 17) MISO_PEQ(17) else if (K == 18) MISO_PEQ(18) else if (K == 19) MISO_PEQ(19) else MISO_PEQ(20) }
 #undef MISO_PEQ
       wave_sync();
 #pragma unroll
