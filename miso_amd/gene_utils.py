@@ -138,6 +138,24 @@ def load_genes_from_gff(gff_filename, include_introns=False, reverse_recs=False,
     return genes
 
 
+def gene_to_compact(gene, tx_start, tx_end):
+    """What a run needs of an indexed gene, as plain tuples (index_gff.py's one-file bundle): the
+    arguments `Gene` was built from plus the transcript bounds -- a whole genome loads in a fraction of
+    a second instead of unpickling every GFF record."""
+    return (gene.label, gene.chrom, gene.strand, tuple(gene.transcript_ids or ()),
+            tuple((p.start, p.end, p.label) for p in gene.parts),
+            tuple(tuple(iso.desc) for iso in gene.isoforms), int(tx_start), int(tx_end))
+
+
+def gene_from_compact(entry):
+    """(Gene, (tx_start, tx_end)) back from gene_to_compact's tuple."""
+    label, chrom, strand, tids, parts, descs, tx_start, tx_end = entry
+    exons = [Exon(s, e, label=l) for s, e, l in parts]
+    gene = Gene([list(d) for d in descs], exons, label=label, chrom=chrom, strand=strand,
+                transcript_ids=list(tids) if tids else None)
+    return gene, (tx_start, tx_end)
+
+
 def se_event_to_gene(up_len, se_len, dn_len, chrom, label=None):
     """A skipped-exon event as a two-isoform gene: exons A, B, C laid end to end from coordinate 0,
     isoforms A-B-C and A-C (Gene.py:1033-1051)."""

@@ -18,7 +18,7 @@ import time
 from collections import OrderedDict, defaultdict
 
 from . import gene_utils
-from .gff_utils import BUNDLE_BASENAME, INDEX_MAP_BASENAME
+from .gff_utils import BUNDLE_BASENAME, INDEX_MAP_BASENAME, get_inclusive_txn_bounds
 
 COMPRESS_PREFIX = "misocomp"                                       # misc_utils.COMPRESS_PREFIX
 
@@ -58,9 +58,13 @@ def serialize_genes(gff_genes, gff_filename, output_dir, compress_id=False):
         json.dump(gene_id_to_filename, f)
     # all genes once more in ONE file: a whole-genome run then opens one pickle instead of 40 000
     # (run_miso.collect_gene_events uses it when present; the per-gene files stay the reference layout)
+    bundle = {}
+    for chrom_genes in genes_by_chrom.values():
+        for gene_id, info in chrom_genes.items():
+            bounds = get_inclusive_txn_bounds(info["hierarchy"][gene_id])
+            bundle[gene_id] = gene_utils.gene_to_compact(info["gene_object"], *bounds)
     with open(os.path.join(output_dir, BUNDLE_BASENAME), "wb") as f:
-        pickle.dump({gene_id: info for chrom_genes in genes_by_chrom.values()
-                     for gene_id, info in chrom_genes.items()}, f, protocol=4)
+        pickle.dump(bundle, f, protocol=4)
     with open(os.path.join(output_dir, "compressed_ids_to_genes.json"), "w") as f:
         json.dump(compressed_id_to_gene_id, f)
     genes_filename = os.path.join(output_dir, "genes.gff")

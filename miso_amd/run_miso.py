@@ -19,7 +19,7 @@ import time
 
 import numpy as np
 
-from . import gff_utils, sam_utils
+from . import gene_utils, gff_utils, sam_utils
 from .settings import Settings
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -46,8 +46,10 @@ def collect_gene_events(gene_entries, bamfile, output_dir, read_len, overhang_le
         if root not in bundles:
             bpath = os.path.join(root, gff_utils.BUNDLE_BASENAME)
             bundles[root] = gff_utils.load_indexed_gff_file(bpath) if os.path.isfile(bpath) else None
+        tx_bounds = None
         if bundles[root] is not None and gene_id in bundles[root]:
-            gff_genes = {gene_id: bundles[root][gene_id]}
+            gene_obj, tx_bounds = gene_utils.gene_from_compact(bundles[root][gene_id])
+            gff_genes = {gene_id: {"gene_object": gene_obj}}
         else:
             if not os.path.exists(gff_index_filename):
                 print("Error: No GFF %s" % gff_index_filename)
@@ -67,7 +69,8 @@ def collect_gene_events(gene_entries, bamfile, output_dir, read_len, overhang_le
                 print("All isoforms of %s shorter than %d, so skipping" % (gene_id, read_len))
             info[gene_id] = "isoforms shorter than reads"
             continue
-        tx_start, tx_end = gff_utils.get_inclusive_txn_bounds(gene_info['hierarchy'][gene_id])
+        tx_start, tx_end = tx_bounds or \
+            gff_utils.get_inclusive_txn_bounds(gene_info['hierarchy'][gene_id])
         chrom = sam_utils.resolve_chrom(bamfile, gene_obj.chrom)
         if event_type is not None:
             chrom_dir = os.path.join(output_dir, event_type, gene_obj.chrom)
