@@ -104,6 +104,16 @@ int miso_batch_add_event_aln(struct miso_batch *batch, const struct miso_gene *g
                              int strand_rule, int target_strand, int given_read_len, int64_t min_reads,
                              const double *hyperp, int n_hyperp, int64_t *n_reads, int *event_index);
 
+/* The same for n events at once, reads collected and CIGARs parsed on n_threads host threads (<= 0:
+ * all usable cores), events appended in the order given; default hyperparameters.  n_reads[i] and
+ * event_index[i] as above.  On an error (bad CIGAR, ...) nothing is added and the first failing event's
+ * error is reported. */
+int miso_batch_add_events_aln(struct miso_batch *batch, int n, const struct miso_gene *const *genes,
+                              const miso_alnfile_t *f, const int *ref, const int64_t *start,
+                              const int64_t *end, int strand_rule, const int *target_strand,
+                              int given_read_len, int64_t min_reads, int n_threads, int64_t *n_reads,
+                              int *event_index);
+
 /* host threads the library uses by default: affinity mask capped by the cgroup CPU quota, <= 64 */
 int miso_usable_threads(void);
 

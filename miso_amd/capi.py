@@ -287,6 +287,29 @@ class Batch:
                                          0 if hy is None else len(hy), C.byref(n), C.byref(idx)))
         return idx.value, n.value
 
+    def add_events_aln(self, genes, alnfile, chroms, starts, ends, strand_rule=0, target_strands=None,
+                       read_len=None, min_reads=0, threads=0):
+        """Many events from one alignment file at once (miso_batch_add_events_aln: reads collected
+        and CIGARs parsed on host threads).  Returns (event indices (-1 = not added), reads found)."""
+        n = len(genes)
+        if n == 0:
+            return np.zeros(0, np.int32), np.zeros(0, np.int64)
+        tids = np.asarray([alnfile.gettid(c) for c in chroms], dtype=np.int32)
+        st = np.asarray(starts, dtype=np.int64)
+        en = np.asarray(ends, dtype=np.int64)
+        ts = np.asarray([ord(t[0]) if t else 0 for t in (target_strands or [None] * n)], dtype=np.int32)
+        gh = (C.c_void_p * n)(*[g.handle for g in genes])
+        idx = np.full(n, -1, np.int32)
+        cnt = np.zeros(n, np.int64)
+        L = lib()
+        L.miso_batch_add_events_aln.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                                C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
+        check(L.miso_batch_add_events_aln(self.handle, n, gh, alnfile._h, _p(tids), _p(st), _p(en),
+                                          int(strand_rule), _p(ts), int(read_len) if read_len else 0,
+                                          int(min_reads), int(threads), _p(cnt), _p(idx)))
+        return idx, cnt
+
     def result_lite(self, i):
         """(class_templates, class_counts, assignment, rundata) of event i -- no sample copy."""
         K, N, ncls = C.c_int(), C.c_int(), C.c_int()

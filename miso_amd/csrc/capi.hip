@@ -375,6 +375,91 @@ int miso_batch_add_event_aln(miso_batch_t *b, const miso_gene_t *gene, const mis
                               n_hyperp, event_index);
 }
 
+// Many events at once: the reads of every region are collected and their CIGARs parsed on n_threads
+// host threads, then appended in order (40 000 events x 1000 reads: the serial loop of
+// miso_batch_add_event_aln calls was the longest stage of a whole-genome run).
+int miso_batch_add_events_aln(miso_batch_t *b, int n, const miso_gene_t *const *genes,
+                              const miso_alnfile_t *f, const int *ref, const int64_t *start,
+                              const int64_t *end, int strand_rule, const int *target_strand,
+                              int given_read_len, int64_t min_reads, int n_threads, int64_t *n_reads,
+                              int *event_index) {
+  return guarded([&] {
+    need(b, "batch"); need(f, "alignment file");
+    if (n < 0) MISO_FAIL(MISO_EINVAL, "negative event count");
+    if (n == 0) return;
+    need(genes, "genes"); need(ref, "ref"); need(start, "start"); need(end, "end");
+    need(target_strand, "target_strand"); need(n_reads, "n_reads"); need(event_index, "event_index");
+    if (b->uploaded) MISO_FAIL(MISO_EINVAL, "batch already uploaded");
+    if (!b->p.device_match) {   // host matching packs at add time: keep the serial path
+      for (int i = 0; i < n; i++) {
+        const int rc = miso_batch_add_event_aln(b, genes[i], f, ref[i], start[i], end[i], strand_rule,
+                                                target_strand[i], given_read_len, min_reads, nullptr, 0,
+                                                &n_reads[i], &event_index[i]);
+        if (rc) throw Rethrow{rc};
+      }
+      return;
+    }
+    if (b->p.overHang < 0) MISO_FAIL(MISO_EINVAL, "Overhang length invalid. Must be positive");
+    if (b->p.readLength < 0) MISO_FAIL(MISO_EINVAL, "Read length cannot be negative");
+    const int paired = b->p.paired ? 1 : 0;
+    std::vector<miso_batch::Pending> made(n);
+    std::vector<int> err_code(n, 0);
+    std::vector<std::string> err_text(n);
+    std::atomic<int> next{0};
+    auto work = [&] {
+      std::vector<int32_t> pos; std::string cig; std::vector<const char *> cptr;
+      for (;;) {
+        const int i = next.fetch_add(1);
+        if (i >= n) return;
+        n_reads[i] = 0; event_index[i] = -1;
+        try {
+          if (!genes[i]) MISO_FAIL(MISO_EINVAL, "gene must not be NULL");
+          const Gene &g = genes[i]->g;
+          if (g.K < 2) MISO_FAIL(MISO_EINVAL, "At least two isoforms are needed");
+          if (g.K > MISO_MAX_ISOFORMS) MISO_FAIL(MISO_UNIMPLEMENTED, "More than 32 isoforms");
+          int64_t k = 0;
+          if (miso_aln_collect_reads(f, ref[i], start[i], end[i], paired, strand_rule, target_strand[i],
+                                     given_read_len, pos, cig, &k, nullptr))
+            MISO_FAIL(MISO_EINVAL, std::string("alignment reader: ") + miso_aln_last_error());
+          n_reads[i] = k;
+          if (k == 0 || k < min_reads) continue;
+          cptr.clear();
+          const char *c = cig.data();
+          for (size_t r = 0; r < pos.size(); r++) { cptr.push_back(c); c += std::strlen(c) + 1; }
+          miso_batch::Pending &pe = made[i];
+          pe.gene = g;
+          pe.pos.resize(pos.size());
+          for (size_t r = 0; r < pos.size(); r++) pe.pos[r] = pos[r] + 1;   // 1-based (miso_sampler.py:284)
+          pe.ct = parse_cigars(cptr.data(), static_cast<int>(pos.size()), b->p.readLength);
+        } catch (const Error &e) {
+          err_code[i] = e.code; err_text[i] = e.text;
+        } catch (const std::bad_alloc &) {
+          err_code[i] = MISO_ENOMEM; err_text[i] = "Error at capi.hip:0: allocation failed, Out of memory";
+        }
+      }
+    };
+    int T = n_threads > 0 ? n_threads : miso_usable_threads();
+    T = std::max(1, std::min(T, n));
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; t++) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+    for (int i = 0; i < n; i++)
+      if (err_code[i]) { g_last_error = err_text[i]; throw Rethrow{err_code[i]}; }   // first in order; nothing added
+    for (int i = 0; i < n; i++) {
+      if (n_reads[i] == 0 || n_reads[i] < min_reads) continue;
+      miso_batch::Pending &pe = made[i];
+      const int N = static_cast<int>(pe.pos.size()) / (paired ? 2 : 1);
+      pe.event = static_cast<int>(b->events.size());
+      PackedEvent ph;
+      ph.K = pe.gene.K; ph.N = N; ph.paired = paired != 0;
+      b->pending.push_back(std::move(pe));
+      b->events.push_back(std::move(ph));
+      event_index[i] = static_cast<int>(b->events.size()) - 1;
+    }
+  });
+}
+
 int miso_selftest_format(const double *x, int n, int decimals, char *out, int stride) {
   return guarded([&] {
     need(x, "x"); need(out, "out");

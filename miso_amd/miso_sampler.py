@@ -192,9 +192,32 @@ class MISOSampler:
                            device_match=True)
         written = [None] * len(events)
         slots = []
+        from sam_utils import STRAND_RULES
+        run = []          # consecutive AlnRegion events of one file and one set of rules: added together
+
+        def flush():
+            if not run:
+                return
+            r0 = run[0][1]
+            idxs, counts = batch.add_events_aln(
+                [c for _, _, _, c, _, _ in run], r0.bamfile, [r.chrom for _, r, _, _, _, _ in run],
+                [r.start for _, r, _, _, _, _ in run], [r.end for _, r, _, _, _, _ in run],
+                STRAND_RULES[r0.strand_rule], [r.target_strand for _, r, _, _, _, _ in run],
+                r0.read_len, r0.min_reads, 0)
+            for (i, r, gene, c_gene, out, ev_id), idx, n in zip(run, idxs, counts):
+                if idx < 0:
+                    if verbose:
+                        print("Only %d reads in gene %s, skipping" % (n, gene.label))
+                    continue
+                if ev_id is not None:
+                    batch.set_event_id(int(idx), ev_id)
+                slots.append((i, int(idx), gene, out))
+            del run[:]
+
         for i, ev in enumerate(events):
             reads, gene, output_file = ev[:3]
             prior = ev[3] if len(ev) > 3 and ev[3] is not None else None
+            ev_id = ev[4] if len(ev) > 4 else None
             num_isoforms = len(gene.isoforms)
             out = output_file + ".miso"
             if not isinstance(reads, AlnRegion) and len(reads[0]) == 0:  # miso_sampler.py:229-231
@@ -212,8 +235,18 @@ class MISOSampler:
             exons, isoforms = gene_tuples(gene)
             c_gene = capi.Gene(exons, isoforms)
             hyper = None if prior is None else [float(x) for x in prior]
+            if isinstance(reads, AlnRegion) and hyper is None and reads.bamfile.gettid(reads.chrom) >= 0 \
+                    and not os.environ.get("MISO_NO_BATCHED_ADD"):
+                same = run and (run[0][1].bamfile is reads.bamfile
+                                and run[0][1].strand_rule == reads.strand_rule
+                                and run[0][1].read_len == reads.read_len
+                                and run[0][1].min_reads == reads.min_reads)
+                if run and not same:
+                    flush()
+                run.append((i, reads, gene, c_gene, out, ev_id))
+                continue
+            flush()
             if isinstance(reads, AlnRegion):
-                from sam_utils import STRAND_RULES
                 idx, n = batch.add_event_aln(c_gene, reads.bamfile, reads.chrom, reads.start,
                                              reads.end, STRAND_RULES[reads.strand_rule],
                                              reads.target_strand, reads.read_len, reads.min_reads,
@@ -225,9 +258,11 @@ class MISOSampler:
             else:
                 pos = np.asarray(reads[0], dtype=np.int64) + 1            # 0-based -> 1-based (:284)
                 idx = batch.add_event(c_gene, pos.astype(np.int32), list(reads[1]), hyper)
-            if len(ev) > 4 and ev[4] is not None:
-                batch.set_event_id(idx, ev[4])          # the event's global number (see run_miso.py)
+            if ev_id is not None:
+                batch.set_event_id(idx, ev_id)          # the event's global number (see run_miso.py)
             slots.append((i, idx, gene, out))
+        flush()
+        slots.sort()
         return (batch, slots, written, int(num_iters), int(burn_in), int(lag))
 
     def finish_batch(self, state, seed=None, first_event_id=0, verbose=False, summary_file=None,

@@ -332,3 +332,29 @@ def test_parallel_sam_parse_equals_serial(tmp_path, sam_text):
     c = sam_utils.Samfile(str(big), threads=5)
     assert len(c) == len(a) + 1 and c.references[-1] == "chrUn"
     assert c.fetch("chrUn", 0, 100)[0].qname == "late"
+
+
+def test_batched_add_from_alignment_file_equals_single_adds(bam_path):
+    """miso_batch_add_events_aln (threads) against a loop of miso_batch_add_event_aln: same events in
+    the same order, same read counts, skipped regions reported the same way; a bad gene fails the call
+    and adds nothing."""
+    from miso_amd import capi
+    bam = sam_utils.Samfile(bam_path)
+    gene = gene_utils.load_genes_from_gff(GFF, suppress_warnings=True)["ENSMUSG00000019943"]["gene_object"]
+    exons = [(p.start, p.end) for p in gene.parts]
+    isoforms = [[gene.parts.index(p) for p in iso.parts] for iso in gene.isoforms]
+    g = capi.Gene(exons, isoforms)
+    regions = [("10", 98377804, 98486420), ("10", 5, 10), ("10", 98431328, 98457192),
+               ("10", 98377804, 98378005)] * 5
+    one = capi.Batch(36, iters=100, burn=10, lag=1, chains=1, device_match=True)
+    single = [one.add_event_aln(g, bam, c, s, e, 0, "+", 36, 20) for c, s, e in regions]
+    many = capi.Batch(36, iters=100, burn=10, lag=1, chains=1, device_match=True)
+    idx, cnt = many.add_events_aln([g] * len(regions), bam, [r[0] for r in regions], [r[1] for r in regions],
+                                   [r[2] for r in regions], 0, ["+"] * len(regions), 36, 20, threads=4)
+    assert [(int(i), int(n)) for i, n in zip(idx, cnt)] == single
+    assert len(one) == len(many) == sum(1 for i, _ in single if i >= 0) and len(many) >= 10
+    assert single[1] == (-1, 0)
+    lone = capi.Gene([(1, 100)], [[0]])                       # one isoform: refused like add_event
+    with pytest.raises(capi.InternalError, match="two isoforms"):
+        many.add_events_aln([g, lone], bam, ["10", "10"], [98377804] * 2, [98486420] * 2, 0, ["+", "+"], 36, 20)
+    assert len(many) == len(one)
