@@ -380,7 +380,8 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
 
   // ---- more than two isoforms: sampler_grp<G, PE, KC> per isoform-count class ----
   // a workgroup may use half of the CU's 160 KB of LDS (two workgroups per CU)
-  constexpr size_t LDS_MAX = 80 * 1024;
+  // MISO_LDS_MAX_KB (experiments): a larger cap lets one workgroup per CU hold more chains per wavefront
+  const size_t LDS_MAX = (std::getenv("MISO_LDS_MAX_KB") ? std::atoi(std::getenv("MISO_LDS_MAX_KB")) : 80) * 1024;
   const size_t fp_bytes = p.paired ? align_up(fd.prob.size() * 8, 16) : 0;
   struct GrpShape { int qs, ts; };
   auto grp_shape = [&](const GenRun &run) {
