@@ -34,6 +34,7 @@ __device__ __forceinline__ void summarize_column(const double *x, int K, int S, 
                                                  double *o) {
   __shared__ double part[256];
   __shared__ unsigned hist[256];
+  __shared__ unsigned wave_tot[4];
   __shared__ uint64_t s_prefix;
   __shared__ int s_rank;
   const int t = threadIdx.x;
@@ -85,11 +86,31 @@ __device__ __forceinline__ void summarize_column(const double *x, int K, int S, 
         }
       }
       __syncthreads();
-      if (t == 0) {
-        int r = s_rank, b = 0;
-        while (b < 255 && r >= static_cast<int>(hist[b])) { r -= hist[b]; b++; }
-        s_rank = r;
-        s_prefix = prefix | (static_cast<uint64_t>(b) << (8 * byte));
+      {
+        // which bin holds the wanted rank: inclusive prefix sums of the 256 bins, one bin per thread
+        // (wave scan + the three earlier waves' totals through LDS) -- thread 0 walking the bins one
+        // LDS read at a time was ~25 k cycles per pass, 16 passes per column
+        const unsigned h = hist[t];
+        unsigned inc = h;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const unsigned v = __shfl_up(inc, off);
+          if ((t & 63) >= off) inc += v;
+        }
+        if ((t & 63) == 63) wave_tot[t >> 6] = inc;
+        const int r0 = s_rank;
+        __syncthreads();
+        unsigned before = 0;
+        for (int w = 0; w < (t >> 6); w++) before += wave_tot[w];
+        inc += before;
+        const unsigned exc = inc - h;
+        const unsigned r = static_cast<unsigned>(r0);
+        // the first bin whose running total exceeds the rank; the last bin takes what is left, as the
+        // serial walk did (b stops at 255)
+        if ((r >= exc && r < inc) || (t == 255 && r >= inc)) {
+          s_rank = static_cast<int>(r - exc);
+          s_prefix = prefix | (static_cast<uint64_t>(t) << (8 * byte));
+        }
       }
       __syncthreads();
     }
