@@ -33,10 +33,10 @@ template <bool CACHED>
 __device__ __forceinline__ void summarize_column(const double *x, int K, int S, int rank_lo, int rank_hi,
                                                  double *o) {
   __shared__ double part[256];
-  __shared__ unsigned hist[256];
-  __shared__ unsigned wave_tot[4];
-  __shared__ uint64_t s_prefix;
-  __shared__ int s_rank;
+  __shared__ unsigned hist2[2][256];
+  __shared__ unsigned wave_tot2[2][4];
+  __shared__ uint64_t s_prefix2[2];
+  __shared__ int s_rank2[2];
   const int t = threadIdx.x;
 
   uint64_t keys[CACHED ? SUMMARY_CACHE : 1];
@@ -64,59 +64,95 @@ __device__ __forceinline__ void summarize_column(const double *x, int K, int S, 
   }
   const double mean = part[0] / static_cast<double>(S);
 
+  // both order statistics in the same eight passes: two prefixes, two histograms (the keys are
+  // tested against both; while the two ranks still share a prefix the two histograms are equal)
   double stat[2];
-  for (int which = 0; which < 2; which++) {
-    if (t == 0) { s_prefix = 0; s_rank = which == 0 ? rank_lo : rank_hi; }
+  if (t < 2) { s_prefix2[t] = 0; s_rank2[t] = t == 0 ? rank_lo : rank_hi; }
+  __syncthreads();
+  for (int byte = 7; byte >= 0; byte--) {
+    hist2[0][t] = 0; hist2[1][t] = 0;
     __syncthreads();
-    for (int byte = 7; byte >= 0; byte--) {
-      hist[t] = 0;
-      __syncthreads();
-      const uint64_t prefix = s_prefix;
-      const uint64_t mask = (byte == 7) ? 0ull : (~0ull << (8 * (byte + 1)));
-      if (CACHED) {
+    const uint64_t p0 = s_prefix2[0], p1 = s_prefix2[1];
+    const uint64_t mask = (byte == 7) ? 0ull : (~0ull << (8 * (byte + 1)));
+    if (CACHED) {
+      // psi lies in [0, 1]: the leading bytes of all keys coincide, so in the first passes every key
+      // of the column lands in ONE bin and 5000 same-address LDS atomics serialise.  Each thread
+      // therefore adds runs of equal bins at once, and a wavefront whose pending runs all name the
+      // same bin adds their total with a single atomic.
+      unsigned cb[2] = {0u, 0u}, cn[2] = {0u, 0u};
 #pragma unroll
-        for (int j = 0; j < SUMMARY_CACHE; j++) {
-          if (t + 256 * j < S && (keys[j] & mask) == prefix)
-            atomicAdd(&hist[(keys[j] >> (8 * byte)) & 0xFF], 1u);
-        }
-      } else {
-        for (int s = t; s < S; s += 256) {
-          const uint64_t key = order_key(x[static_cast<size_t>(s) * K]);
-          if ((key & mask) == prefix) atomicAdd(&hist[(key >> (8 * byte)) & 0xFF], 1u);
+      for (int j = 0; j < SUMMARY_CACHE; j++) {
+        if (t + 256 * j < S) {
+          const uint64_t km = keys[j] & mask;
+          const unsigned bin = static_cast<unsigned>(keys[j] >> (8 * byte)) & 0xFFu;
+#pragma unroll
+          for (int w = 0; w < 2; w++) {
+            if (km == (w == 0 ? p0 : p1)) {
+              if (cn[w] && cb[w] != bin) { atomicAdd(&hist2[w][cb[w]], cn[w]); cn[w] = 0; }
+              cb[w] = bin; cn[w]++;
+            }
+          }
         }
       }
-      __syncthreads();
-      {
-        // which bin holds the wanted rank: inclusive prefix sums of the 256 bins, one bin per thread
-        // (wave scan + the three earlier waves' totals through LDS) -- thread 0 walking the bins one
-        // LDS read at a time was ~25 k cycles per pass, 16 passes per column
-        const unsigned h = hist[t];
-        unsigned inc = h;
+#pragma unroll
+      for (int w = 0; w < 2; w++) {
+        const unsigned long long have = __ballot(cn[w] != 0);
+        if (have) {
+          const unsigned b0 = static_cast<unsigned>(__shfl(static_cast<int>(cb[w]), __ffsll(static_cast<long long>(have)) - 1));
+          if (__all(cn[w] == 0 || cb[w] == b0)) {
+            unsigned tot = cn[w];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) tot += __shfl_xor(static_cast<int>(tot), off);
+            if ((t & 63) == 0) atomicAdd(&hist2[w][b0], tot);
+          } else if (cn[w]) {
+            atomicAdd(&hist2[w][cb[w]], cn[w]);
+          }
+        }
+      }
+    } else {
+      for (int s = t; s < S; s += 256) {
+        const uint64_t key = order_key(x[static_cast<size_t>(s) * K]);
+        const uint64_t km = key & mask;
+        const unsigned bin = static_cast<unsigned>(key >> (8 * byte)) & 0xFFu;
+        if (km == p0) atomicAdd(&hist2[0][bin], 1u);
+        if (km == p1) atomicAdd(&hist2[1][bin], 1u);
+      }
+    }
+    __syncthreads();
+    {
+      // which bin holds the wanted rank: inclusive prefix sums of the 256 bins, one bin per thread
+      // (wave scan + the earlier waves' totals through LDS) -- thread 0 walking the bins one LDS
+      // read at a time was ~25 k cycles per pass
+      unsigned h[2], inc[2];
+#pragma unroll
+      for (int w = 0; w < 2; w++) {
+        h[w] = hist2[w][t]; inc[w] = h[w];
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
-          const unsigned v = __shfl_up(inc, off);
-          if ((t & 63) >= off) inc += v;
+          const unsigned v = __shfl_up(inc[w], off);
+          if ((t & 63) >= off) inc[w] += v;
         }
-        if ((t & 63) == 63) wave_tot[t >> 6] = inc;
-        const int r0 = s_rank;
-        __syncthreads();
+        if ((t & 63) == 63) wave_tot2[w][t >> 6] = inc[w];
+      }
+      const int r0[2] = {s_rank2[0], s_rank2[1]};
+      __syncthreads();
+#pragma unroll
+      for (int w = 0; w < 2; w++) {
         unsigned before = 0;
-        for (int w = 0; w < (t >> 6); w++) before += wave_tot[w];
-        inc += before;
-        const unsigned exc = inc - h;
-        const unsigned r = static_cast<unsigned>(r0);
-        // the first bin whose running total exceeds the rank; the last bin takes what is left, as the
-        // serial walk did (b stops at 255)
-        if ((r >= exc && r < inc) || (t == 255 && r >= inc)) {
-          s_rank = static_cast<int>(r - exc);
-          s_prefix = prefix | (static_cast<uint64_t>(t) << (8 * byte));
+        for (int q = 0; q < (t >> 6); q++) before += wave_tot2[w][q];
+        const unsigned incl = inc[w] + before, exc = incl - h[w];
+        const unsigned r = static_cast<unsigned>(r0[w]);
+        // the first bin whose running total exceeds the rank; the last bin takes what is left
+        if ((r >= exc && r < incl) || (t == 255 && r >= incl)) {
+          s_rank2[w] = static_cast<int>(r - exc);
+          s_prefix2[w] = (w == 0 ? p0 : p1) | (static_cast<uint64_t>(t) << (8 * byte));
         }
       }
-      __syncthreads();
     }
-    stat[which] = key_value(s_prefix);
     __syncthreads();
   }
+  stat[0] = key_value(s_prefix2[0]);
+  stat[1] = key_value(s_prefix2[1]);
   if (t == 0) { o[0] = mean; o[1] = stat[0]; o[2] = stat[1]; }
 }
 
