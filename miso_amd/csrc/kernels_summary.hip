@@ -190,67 +190,120 @@ __device__ __forceinline__ double block_tree_sum(double v, double *part) {
   return part[0];
 }
 
-__global__ __launch_bounds__(256) void compare_kernel(const DevEvent *ev1, const unsigned char *pool1,
-                                                      const DevEvent *ev2, const unsigned char *pool2,
-                                                      int n_events, int S, double smoothing,
-                                                      const uint64_t *cmp_off, double *out) {
-  __shared__ double part[256];
+// four sums at once, each in block_tree_sum's order (same bits), one set of barriers
+__device__ __forceinline__ void block_tree_sum4(double (&v)[4], double (*part4)[256]) {
+  const int t = threadIdx.x;
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; q++) part4[q][t] = v[q];
+  __syncthreads();
+  for (int stride = 128; stride >= 1; stride >>= 1) {
+    if (t < stride) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) part4[q][t] = part4[q][t] + part4[q][t + stride];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int q = 0; q < 4; q++) v[q] = part4[q][0];
+}
+
+// CACHED (S <= 256 * SUMMARY_CACHE): the paired differences stay in registers, so the two sample
+// columns are read once instead of three times.
+template <bool CACHED>
+__device__ __forceinline__ void compare_column(const double *x1, const double *x2, int K, int S,
+                                               double smoothing, double *o) {
+  __shared__ double part4[4][256];
   __shared__ int s_diff;
-  const int ev = blockIdx.x, k = blockIdx.y, t = threadIdx.x;
-  if (ev >= n_events) return;
-  const DevEvent E1 = ev1[ev], E2 = ev2[ev];
-  const int K = E1.K;
-  if (k >= K) return;
-  const double *x1 = reinterpret_cast<const double *>(pool1 + E1.off_samples) + k;
-  const double *x2 = reinterpret_cast<const double *>(pool2 + E2.off_samples) + k;
+  const int t = threadIdx.x;
+  double *part = part4[0];
   const double n = static_cast<double>(S);
 
   if (t == 0) s_diff = 0;
   const double d0 = x1[0] - x2[0];
-  double a1 = 0, a2 = 0, ad = 0, aabs = 0;
+  double acc[4] = {0, 0, 0, 0};   // sum psi1, sum psi2, sum d, sum |d|
+  double dv[CACHED ? SUMMARY_CACHE : 1];
   int differs = 0;
-  for (int s = t; s < S; s += 256) {
-    const double u = x1[static_cast<size_t>(s) * K], v = x2[static_cast<size_t>(s) * K];
-    const double d = u - v;
-    a1 = a1 + u; a2 = a2 + v; ad = ad + d; aabs = aabs + fabs(d);
-    differs |= (d - d0 != 0.0);
+  if (CACHED) {
+#pragma unroll
+    for (int j = 0; j < SUMMARY_CACHE; j++) {
+      const int s = t + 256 * j;
+      dv[j] = 0.0;
+      if (s < S) {
+        const double u = x1[static_cast<size_t>(s) * K], v = x2[static_cast<size_t>(s) * K];
+        const double d = u - v;
+        acc[0] = acc[0] + u; acc[1] = acc[1] + v; acc[2] = acc[2] + d; acc[3] = acc[3] + fabs(d);
+        differs |= (d - d0 != 0.0);
+        dv[j] = d;
+      }
+    }
+  } else {
+    for (int s = t; s < S; s += 256) {
+      const double u = x1[static_cast<size_t>(s) * K], v = x2[static_cast<size_t>(s) * K];
+      const double d = u - v;
+      acc[0] = acc[0] + u; acc[1] = acc[1] + v; acc[2] = acc[2] + d; acc[3] = acc[3] + fabs(d);
+      differs |= (d - d0 != 0.0);
+    }
   }
-  const double sum1 = block_tree_sum(a1, part);
-  const double sum2 = block_tree_sum(a2, part);
-  const double sumd = block_tree_sum(ad, part);
-  const double sumabs = block_tree_sum(aabs, part);
+  block_tree_sum4(acc, part4);
+  const double sum1 = acc[0], sum2 = acc[1], sumd = acc[2], sumabs = acc[3];
   if (differs) atomicOr(&s_diff, 1);
   __syncthreads();
   const bool all_same = s_diff == 0;
   const double mean_d = sumd / n, mad = sumabs / n;
 
   double bf, post = 0.0;
-  if (mad <= 0.009 || all_same) {       // wave-uniform: every thread sees the same sums
+  if (mad <= 0.009 || all_same) {       // block-uniform: every thread sees the same sums
     bf = 0.0;
     post = __longlong_as_double(0x7FF0000000000000ull);
   } else {
     double av = 0;
-    for (int s = t; s < S; s += 256) {
-      const double d = (x1[static_cast<size_t>(s) * K] - x2[static_cast<size_t>(s) * K]) - mean_d;
-      av = av + d * d;
+    if (CACHED) {
+#pragma unroll
+      for (int j = 0; j < SUMMARY_CACHE; j++)
+        if (t + 256 * j < S) { const double d = dv[j] - mean_d; av = av + d * d; }
+    } else {
+      for (int s = t; s < S; s += 256) {
+        const double d = (x1[static_cast<size_t>(s) * K] - x2[static_cast<size_t>(s) * K]) - mean_d;
+        av = av + d * d;
+      }
     }
     const double var = block_tree_sum(av, part) / (n - 1.0);
     const double cov = var * (smoothing * smoothing);
     const double inv2 = 1.0 / (2.0 * cov);
     double ae = 0;
-    for (int s = t; s < S; s += 256) {
-      const double d = x1[static_cast<size_t>(s) * K] - x2[static_cast<size_t>(s) * K];
-      ae = ae + miso_det_exp(-(d * d) * inv2);
+    if (CACHED) {
+#pragma unroll
+      for (int j = 0; j < SUMMARY_CACHE; j++)
+        if (t + 256 * j < S) ae = ae + miso_det_exp(-(dv[j] * dv[j]) * inv2);
+    } else {
+      for (int s = t; s < S; s += 256) {
+        const double d = x1[static_cast<size_t>(s) * K] - x2[static_cast<size_t>(s) * K];
+        ae = ae + miso_det_exp(-(d * d) * inv2);
+      }
     }
     const double se = block_tree_sum(ae, part);
     post = se / (n * miso_det_sqrt(6.283185307179586 * cov));
     if (post == 0.0) bf = 1e12;
     else { bf = 1.0 / post; if (bf > 1e12) bf = 1e12; }
   }
-  if (t == 0) {
-    double *o = out + cmp_off[ev] + 4 * k;
-    o[0] = sum1 / n; o[1] = sum2 / n; o[2] = bf; o[3] = post;
-  }
+  if (t == 0) { o[0] = sum1 / n; o[1] = sum2 / n; o[2] = bf; o[3] = post; }
+}
+
+__global__ __launch_bounds__(256) void compare_kernel(const DevEvent *ev1, const unsigned char *pool1,
+                                                      const DevEvent *ev2, const unsigned char *pool2,
+                                                      int n_events, int S, double smoothing,
+                                                      const uint64_t *cmp_off, double *out) {
+  const int ev = blockIdx.x, k = blockIdx.y;
+  if (ev >= n_events) return;
+  const DevEvent E1 = ev1[ev], E2 = ev2[ev];
+  const int K = E1.K;
+  if (k >= K) return;
+  const double *x1 = reinterpret_cast<const double *>(pool1 + E1.off_samples) + k;
+  const double *x2 = reinterpret_cast<const double *>(pool2 + E2.off_samples) + k;
+  double *o = out + cmp_off[ev] + 4 * k;
+  if (S <= 256 * SUMMARY_CACHE) compare_column<true>(x1, x2, K, S, smoothing, o);
+  else compare_column<false>(x1, x2, K, S, smoothing, o);
 }
 
 }  // namespace miso
