@@ -238,6 +238,20 @@ int miso_batch_get_match(const miso_batch_t *batch, int event_index, double *mat
 /* names of the kernels the last launch used (for profiles): e.g. "sampler_k2<3, false>" */
 int miso_batch_last_kernels(const miso_batch_t *batch, char *buf, int buflen);
 
+/* Measurement: what the last launch put on the device, kernel by kernel (bench.py's VALU roofline
+   prices it with the kernels' instruction counts, tools/isa_count.py): wavefronts launched, the sum
+   over wavefronts of the read loop's trips per Gibbs step, Gibbs steps run (noIterations + 1),
+   chains, and the Philox words (uniforms) the read loops generate per Gibbs step. */
+typedef struct {
+  char name[64];
+  double waves, trips, iterations, chains, words;
+} miso_kernel_stat_t;
+int miso_batch_launch_stats(const miso_batch_t *batch, miso_kernel_stat_t *stats, int max_kernels,
+                            int *n_kernels);
+/* placement diagnostics: HW_REG_HW_ID of the wavefront that ran each chain of event i (noChains
+   words; 0 for kernels that do not record it).  Needs downloaded results. */
+int miso_batch_get_placement(const miso_batch_t *batch, int event_index, uint32_t *hw_id);
+
 /* bytes the kernels of the last launch moved by the reference algorithm's accounting
    (SE (8K+20)N, PE (8K+28)N per chain-iteration + load/store) */
 int miso_batch_algorithmic_bytes(const miso_batch_t *batch, double *bytes);

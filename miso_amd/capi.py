@@ -39,6 +39,11 @@ class Params(C.Structure):
                 ("want_counts_trace", C.c_int), ("device_match", C.c_int)]
 
 
+class KernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("waves", C.c_double), ("trips", C.c_double),
+                ("iterations", C.c_double), ("chains", C.c_double), ("words", C.c_double)]
+
+
 _lib = None
 
 
@@ -351,6 +356,23 @@ class Batch:
         buf = C.create_string_buffer(256)
         check(lib().miso_batch_last_kernels(self.handle, buf, 256))
         return buf.value.decode()
+
+    def launch_stats(self):
+        """{"kernels": [{name, waves, trips, iterations, chains, words}], "uniforms": Philox words the
+        read loops consume per launch} of the last launch (miso_batch_launch_stats)."""
+        n = C.c_int(0)
+        arr = (KernelStat * 16)()
+        check(lib().miso_batch_launch_stats(self.handle, arr, 16, C.byref(n)))
+        ks = [{"name": arr[i].name.decode(), "waves": arr[i].waves, "trips": arr[i].trips,
+               "iterations": arr[i].iterations, "chains": arr[i].chains, "words": arr[i].words}
+              for i in range(min(n.value, 16))]
+        return {"kernels": ks, "uniforms": sum(k["words"] * k["iterations"] for k in ks)}
+
+    def placement(self, i):
+        """HW_REG_HW_ID of the wavefront that ran each chain of event i (after download)."""
+        out = np.zeros(self.params.noChains, np.uint32)
+        check(lib().miso_batch_get_placement(self.handle, i, _p(out)))
+        return out
 
     def algorithmic_bytes(self):
         b = C.c_double(0)

@@ -63,6 +63,7 @@ struct miso_batch {
   void resolve_pending();        // runs match_kernel for all pending events, packs them
   int lanes_per_chain = 0;        // G of the last sampler_k2 launch (0 = none)
   std::string last_kernels;       // names of the kernels of the last launch, comma separated
+  std::vector<miso_kernel_stat_t> kernel_stats;   // miso_batch_launch_stats
   int wave_slots = 2048;          // resident sampler_k2 wavefronts on the device
   std::vector<miso::DevEvent> h_events;
   std::vector<unsigned char> h_out;

@@ -596,6 +596,25 @@ int miso_batch_last_kernels(const miso_batch_t *b, char *buf, int buflen) {
   });
 }
 
+int miso_batch_launch_stats(const miso_batch_t *b, miso_kernel_stat_t *stats, int max_kernels, int *n_kernels) {
+  return guarded([&] {
+    need(b, "batch"); need(n_kernels, "n_kernels");
+    if (!b->launched) MISO_FAIL(MISO_EINVAL, "batch not launched");
+    *n_kernels = static_cast<int>(b->kernel_stats.size());
+    for (int i = 0; stats && i < max_kernels && i < *n_kernels; i++) stats[i] = b->kernel_stats[i];
+  });
+}
+
+int miso_batch_get_placement(const miso_batch_t *b, int i, uint32_t *hw_id) {
+  return guarded([&] {
+    need(b, "batch"); need(hw_id, "hw_id");
+    (void) event_at(b, i);
+    if (!b->downloaded) MISO_FAIL(MISO_EINVAL, "results not downloaded yet");
+    const ChainStats *st = reinterpret_cast<const ChainStats *>(b->h_out.data() + b->h_events[i].off_stats);
+    for (int c = 0; c < b->p.noChains; c++) hw_id[c] = st[c].hw_id;
+  });
+}
+
 int miso_batch_algorithmic_bytes(const miso_batch_t *b, double *bytes) {
   return guarded([&] {
     need(b, "batch"); need(bytes, "bytes");

@@ -55,7 +55,7 @@ struct MatchEvent {
 struct ChainStats {
   uint64_t counts_hash;
   int32_t accepted;
-  int32_t pad;
+  uint32_t hw_id;      // HW_REG_HW_ID of the wavefront that ran the chain (placement diagnostics)
 };
 
 struct KernelArgs {
@@ -73,6 +73,8 @@ struct KernelArgs {
   int32_t C, M, B, lag;     // chains, iterations (incl. burn-in), burn-in, lag
   int32_t start;            // MISO_START_AUTO / MISO_START_UNIFORM
   uint32_t first_event_id;
+  int32_t pair_waves;       // sampler_k2 with 8 wavefronts per workgroup: wavefronts w and w + 4 (one SIMD)
+                            // take the heaviest and the lightest remaining chain group (runtime.hip)
   uint64_t seed;
 };
 

@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void sampler_wave(const KernelArgs a) {
     ChainStats *st = reinterpret_cast<ChainStats *>(a.out_pool + E.off_stats) + chain;
     st->counts_hash = hash;
     st->accepted = accepted;
-    st->pad = 0;
+    st->hw_id = 0;
   }
 }
 

@@ -923,7 +923,7 @@ __global__ __launch_bounds__(256, KC <= 8 ? MISO_GRP_MINBLOCKS : 2) void sampler
       }
     if (sub == 0) {
       ChainStats *st = reinterpret_cast<ChainStats *>(a.out_pool + E.off_stats) + chain;
-      st->counts_hash = hash; st->accepted = accepted; st->pad = 0;
+      st->counts_hash = hash; st->accepted = accepted; st->hw_id = 0;
     }
   }
 }

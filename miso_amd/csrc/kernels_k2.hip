@@ -192,8 +192,12 @@ __device__ __forceinline__ void vec_eval4(F f, double a0, double a1, double a2, 
 
 }  // namespace
 
-template <int G, bool PE>
-__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void sampler_k2(const KernelArgs a) {
+// WPB = wavefronts per workgroup.  WPB = 8 (single-end): one workgroup fills a CU's eight resident
+// slots, wavefronts w and w + 4 share a SIMD, and with a.pair_waves the pair takes the p-th heaviest
+// and the p-th lightest group of chains (the slot list is sorted by drawing reads), so every SIMD
+// carries the same total work whatever the spread of the events' sizes.
+template <int G, bool PE, int WPB>
+__global__ __launch_bounds__(64 * WPB, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void sampler_k2(const KernelArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_k2[];
   double *lds_fp = reinterpret_cast<double *>(smem_k2);  // PE: fragment-length probabilities
   if (PE) {
@@ -212,7 +216,12 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   const int sub = lane_used ? lane - base_lane : 0;
   const int role = sub % NR;
   const long n_chains = static_cast<long>(a.n_slots) * a.C;
-  const long wave_id = static_cast<long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  long wave_id = static_cast<long>(blockIdx.x) * WPB + (threadIdx.x >> 6);
+  if (WPB == 8 && a.pair_waves) {
+    const int w = threadIdx.x >> 6;
+    const long p = 4 * static_cast<long>(blockIdx.x) + (w & 3);          // pair index: heaviest first
+    wave_id = (w < 4) ? p : static_cast<long>(gridDim.x) * 8 - 1 - p;    // ... with the p-th lightest
+  }
   if (wave_id * CPW >= n_chains) return;  // whole wavefront idle
   long slot = wave_id * CPW + grp;
   const bool live = lane_used && slot < n_chains;  // dead lanes shadow a chain and store nothing
@@ -502,13 +511,14 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     ChainStats *st = reinterpret_cast<ChainStats *>(a.out_pool + E.off_stats) + chain;
     st->counts_hash = hash;
     st->accepted = accepted;
-    st->pad = 0;
+    st->hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_REG_HW_ID, all 32 bits
   }
 }
 
-#define MISO_INSTANTIATE_K2(G)                                      \
-  template __global__ void sampler_k2<G, false>(const KernelArgs); \
-  template __global__ void sampler_k2<G, true>(const KernelArgs);
+#define MISO_INSTANTIATE_K2(G)                                         \
+  template __global__ void sampler_k2<G, false, 4>(const KernelArgs); \
+  template __global__ void sampler_k2<G, false, 8>(const KernelArgs); \
+  template __global__ void sampler_k2<G, true, 4>(const KernelArgs);
 MISO_INSTANTIATE_K2(1)
 MISO_INSTANTIATE_K2(2)
 MISO_INSTANTIATE_K2(3)

@@ -20,7 +20,7 @@
 namespace miso {
 
 template <bool PE> __global__ void sampler_wave(const KernelArgs a);
-template <int G, bool PE> __global__ void sampler_k2(const KernelArgs a);
+template <int G, bool PE, int WPB> __global__ void sampler_k2(const KernelArgs a);
 __global__ void compare_kernel(const DevEvent *, const unsigned char *, const DevEvent *, const unsigned char *, int, int,
                                double, const uint64_t *, double *);
 __global__ void match_kernel(const MatchEvent *, const int2 *, const int *, const int *, const int *, const int *,
@@ -357,16 +357,24 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   // ---- two-isoform events: sampler_k2<G> ----
   const size_t k2_fp = p.paired ? align_up(fd.prob.size() * 8, 16) : 0;
   const size_t k2_tab = p.paired ? 2 * fd.prob.size() * 4 : 0;   // per chain: int32[2 x il]
+  const bool k2_pair = !p.paired && !(std::getenv("MISO_K2_PAIR") && std::atoi(std::getenv("MISO_K2_PAIR")) == 0);
   auto launch_k2 = [&](KernelArgs ka, int G, hipStream_t st) {
     const long chains = static_cast<long>(n_k2) * p.noChains;
     ka.slot_event = d_slots; ka.n_slots = n_k2;
     const int cpw = 64 / std::max(G, 1);
-    const unsigned grid = static_cast<unsigned>(((chains + cpw - 1) / cpw + 3) / 4);
+    const long waves = (chains + cpw - 1) / cpw;
+    // single-end: workgroups of 8 wavefronts = one CU's resident slots; the two wavefronts of a SIMD
+    // take a heavy and a light group of chains (sampler_k2's WPB = 8).  MISO_K2_PAIR=0: the 4-wavefront
+    // workgroups in slot order (round-1 behaviour).
+    const bool pair = k2_pair;
+    ka.pair_waves = pair ? 1 : 0;
+    const unsigned grid = static_cast<unsigned>(pair ? (waves + 7) / 8 : (waves + 3) / 4);
     const size_t k2_lds = k2_fp + 4 * static_cast<size_t>(cpw) * k2_tab;
-#define MISO_K2_LAUNCH(GG)                                                                           \
-  case GG:                                                                                          \
-    if (p.paired) hipLaunchKernelGGL((sampler_k2<GG, true>), dim3(grid), dim3(256), k2_lds, st, ka); \
-    else hipLaunchKernelGGL((sampler_k2<GG, false>), dim3(grid), dim3(256), 0, st, ka);               \
+#define MISO_K2_LAUNCH(GG)                                                                              \
+  case GG:                                                                                             \
+    if (p.paired) hipLaunchKernelGGL((sampler_k2<GG, true, 4>), dim3(grid), dim3(256), k2_lds, st, ka); \
+    else if (pair) hipLaunchKernelGGL((sampler_k2<GG, false, 8>), dim3(grid), dim3(512), 0, st, ka);    \
+    else hipLaunchKernelGGL((sampler_k2<GG, false, 4>), dim3(grid), dim3(256), 0, st, ka);              \
     break;
     switch (G) {
       MISO_K2_LAUNCH(1) MISO_K2_LAUNCH(2) MISO_K2_LAUNCH(3) MISO_K2_LAUNCH(4) MISO_K2_LAUNCH(5)
@@ -550,6 +558,70 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     grp_G[ri] = G;
   }
 
+  // ---- what goes on the device, kernel by kernel (miso_batch_launch_stats) ----
+  kernel_stats.clear();
+  auto add_stat = [&](const std::string &name, double waves, double trips, double chains, double words) {
+    miso_kernel_stat_t ks{};
+    std::snprintf(ks.name, sizeof ks.name, "%s", name.c_str());
+    ks.waves = waves; ks.trips = trips; ks.iterations = static_cast<double>(p.noIterations) + 1.0;
+    ks.chains = chains; ks.words = words;
+    kernel_stats.push_back(ks);
+  };
+  auto k2_name = [&](int G) {
+    return "sampler_k2<" + std::to_string(G) + (p.paired ? ", true, 4>" : (k2_pair ? ", false, 8>" : ", false, 4>"));
+  };
+  if (n_k2 > 0) {
+    // slot order = events by drawing reads, descending, each with its noChains chains
+    std::vector<int> nd;
+    for (const PackedEvent &e : events) if (e.K == 2) nd.push_back(e.n_draw);
+    std::sort(nd.begin(), nd.end(), [](int x, int y) { return x > y; });
+    const int C = p.noChains, cpw = 64 / k2_G;
+    const long chains = static_cast<long>(n_k2) * C;
+    double trips = 0, words = 0;
+    long waves = 0;
+    for (long s0 = 0; s0 < chains; s0 += cpw, waves++) {
+      int mx = 0, any_rem = 0;
+      for (long sl = s0; sl < std::min(chains, s0 + cpw); sl++) {
+        const int n = nd[sl / C];
+        mx = std::max(mx, n >> 2); any_rem |= n & 3;
+        words += n;
+      }
+      const int t = (mx + 2 * k2_G - 1) / (2 * k2_G);       // trips of two Philox blocks per lane
+      trips += p.paired ? 2 * t + 1 : 2 * t + (any_rem ? 1 : 0);   // counted in blocks per lane
+    }
+    add_stat(k2_name(k2_G), static_cast<double>(waves), trips, static_cast<double>(chains), words);
+  }
+  for (size_t ri = 0; ri < gen_runs.size(); ri++) {
+    const GenRun &run = gen_runs[ri];
+    const int G = grp_G[ri], C = p.noChains, cpw = std::max(1, 64 / G);
+    const long chains = static_cast<long>(run.count) * C;
+    std::vector<const PackedEvent *> evs;   // the run's events in slot order
+    {
+      std::vector<int> gen;
+      for (size_t i = 0; i < events.size(); i++) if (events[i].K != 2) gen.push_back(static_cast<int>(i));
+      std::stable_sort(gen.begin(), gen.end(), [&](int x, int y) {
+        return events[x].K != events[y].K ? events[x].K > events[y].K : events[x].n_draw > events[y].n_draw; });
+      for (int j = 0; j < run.count; j++) evs.push_back(&events[gen[run.first + j]]);
+    }
+    const bool cls = !p.paired && grp_sh[ri].qs > 0;
+    double trips = 0, words = 0;
+    long waves = 0;
+    for (long s0 = 0; s0 < chains; s0 += cpw, waves++) {
+      int mx = 0, kmx = 0;
+      for (long sl = s0; sl < std::min(chains, s0 + cpw); sl++) {
+        const PackedEvent &e = *evs[sl / C];
+        mx = std::max(mx, cls ? e.n_units : (e.n_draw + 3) / 4);
+        kmx = std::max(kmx, e.K);
+        words += e.n_draw;
+      }
+      const int nw = (cls && kmx - 1 <= 3) ? 2 : 1;         // Philox blocks in flight (class path, K <= 4)
+      trips += (G == 64) ? mx : nw * ((mx + nw * G - 1) / (nw * G));
+    }
+    const std::string name = (G == 64 ? std::string("sampler_wave<") : "sampler_grp<" + std::to_string(G) + ", ") +
+                             (p.paired ? "true" : "false") + (G == 64 ? std::string(">") : ", " + std::to_string(run.kc) + ">");
+    add_stat(name, static_cast<double>(waves), trips, static_cast<double>(chains), words);
+  }
+
   HIP_OK(hipEventRecord(ev0, stream));                  // events bracket the sampler kernels only
   // kernel i > 0 goes to its own stream, forked from and joined back into the batch's stream
   size_t kernel_no = 0;
@@ -567,7 +639,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   };
   if (n_k2 > 0) {
     lanes_per_chain = k2_G;
-    last_kernels = "sampler_k2<" + std::to_string(k2_G) + (p.paired ? ", true>" : ", false>");
+    last_kernels = k2_name(k2_G);
     launch_k2(a, k2_G, stream_for_next());
   }
   for (size_t ri = 0; ri < gen_runs.size(); ri++) {

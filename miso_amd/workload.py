@@ -65,7 +65,40 @@ def event_reads(event_id, K=2, n_reads=1000, read_len=36, paired=False, mean=250
 
 
 def shard_bounds(n_events, world_size, rank):
-    """Static contiguous split of the event list (misopy/cluster_utils.py:23-32 chunk_list)."""
+    """Static contiguous split of the event list by COUNT (misopy/cluster_utils.py:23-32
+    chunk_list); kept for callers that know nothing about their events' cost."""
     base, extra = divmod(n_events, world_size)
     lo = rank * base + min(rank, extra)
     return lo, lo + base + (1 if rank < extra else 0)
+
+
+def event_costs(first_event_id, n_events, K, n_reads, iters, chains):
+    """Relative sampling cost of events [first, first + n): chains x iterations x reads (SURVEY
+    8e), times the isoform count for mixed batches (the per-read work grows with it)."""
+    ks = np.array([mixed_k(first_event_id + i, K) for i in range(n_events)], dtype=np.float64) \
+        if isinstance(K, (tuple, list)) else np.full(n_events, float(K))
+    return float(chains) * float(iters) * float(n_reads) * ks
+
+
+def shard_bounds_by_cost(costs, world_size, rank):
+    """Contiguous split of the event list into world_size shards of (nearly) equal total cost:
+    shard r ends at the event where the running cost first reaches (r + 1) / world_size of the
+    total (the boundary event goes to whichever side leaves the smaller error).  The reference
+    splits by count (cluster_utils.py:23-32); real events range from tens to 10^5 reads, so the
+    slowest worker would set the wall time.  Every rank computes the same bounds from the same
+    costs; events keep their global ids, so results do not depend on the split."""
+    costs = np.asarray(costs, dtype=np.float64)
+    n = len(costs)
+    if n == 0:
+        return 0, 0
+    prefix = np.concatenate([[0.0], np.cumsum(costs)])
+    total = prefix[-1]
+    cuts = [0]
+    for r in range(1, world_size):
+        target = total * r / world_size
+        i = int(np.searchsorted(prefix, target, side="left"))      # prefix[i] >= target
+        if i > 0 and target - prefix[i - 1] <= prefix[min(i, n)] - target:
+            i -= 1
+        cuts.append(min(max(i, cuts[-1]), n))
+    cuts.append(n)
+    return cuts[rank], cuts[rank + 1]
