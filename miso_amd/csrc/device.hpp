@@ -69,6 +69,7 @@ struct KernelArgs {
   int32_t kstride;          // sampler_grp: isoform stride of the per-chain LDS slices
   int32_t cstride;          // sampler_grp: SE drawing-read classes per chain in the LDS slice (0 = no class path)
   int32_t tstride;          // sampler_grp PE: score-table entries per chain staged in LDS (0 = none)
+  int32_t nc;               // sampler_flat: chains per wavefront
   int32_t n_events;
   int32_t C, M, B, lag;     // chains, iterations (incl. burn-in), burn-in, lag
   int32_t start;            // MISO_START_AUTO / MISO_START_UNIFORM
@@ -98,6 +99,36 @@ MISO_DEVHOST inline int grp_cls_bytes(int ks, int cs) {
 }
 MISO_DEVHOST inline int grp_slice_bytes(int ks, int cs, int ts) {
   return 15 * ks * 8 + 32 + (3 * ks + (ks & 1)) * 4 + grp_cls_bytes(ks, cs) + ((ts + 1) & ~1) * 4;
+}
+// ---- sampler_flat (kernels_flat.inl): one chain's LDS slice, byte offsets.  ks = isoform stride
+// (the launch's largest K), cs = most drawing-read classes of any event of the launch. ----
+constexpr int FLAT_SX = 16;     // per-chain double scalars
+constexpr int FLAT_MISC = 24;   // per-chain int scalars
+struct FlatLayout {
+  int psi, alpha, lp, tb, lr;   // double[2][ks]: buffer `parity` = current state and its cached logs, the other = proposal
+  int tc, u2;                   // double[ks] scratch
+  int cst, isc, hm1;            // double[ks] per-isoform constants (device.hpp, top)
+  int sx;                       // double[FLAT_SX]
+  int cnt, bas, dl;             // int[ks]: picks of the drawing reads, fixed reads, D_k
+  int misc;                     // int[FLAT_MISC]
+  int thr;                      // u32[cs x (ks - 1)]: thr[c][k] = words below it pick an isoform <= k
+  int ctab;                     // u32[CLS_WORDS x (cs + 1) + ks]: class rows, sentinel row, A_k
+  int bytes;
+};
+MISO_DEVHOST inline FlatLayout flat_layout(int ks, int cs) {
+  FlatLayout L{};
+  int o = 0;
+  L.psi = o; o += 16 * ks; L.alpha = o; o += 16 * ks; L.lp = o; o += 16 * ks; L.tb = o; o += 16 * ks;
+  L.lr = o; o += 16 * ks;
+  L.tc = o; o += 8 * ks; L.u2 = o; o += 8 * ks;
+  L.cst = o; o += 8 * ks; L.isc = o; o += 8 * ks; L.hm1 = o; o += 8 * ks;
+  L.sx = o; o += 8 * FLAT_SX;
+  L.cnt = o; o += 4 * ks; L.bas = o; o += 4 * ks; L.dl = o; o += 4 * ks;
+  L.misc = o; o += 4 * FLAT_MISC;
+  L.thr = o; o += 4 * cs * (ks - 1);
+  L.ctab = o; o += 4 * (CLS_WORDS * (cs + 1) + ks);
+  L.bytes = (o + 15) & ~15;
+  return L;
 }
 constexpr uint16_t FRAG_NONE = 0xFFFF;
 constexpr int32_t SFIX_BAD = INT32_MIN;  // == MISO_SFIX_BAD

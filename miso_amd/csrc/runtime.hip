@@ -27,6 +27,7 @@ __global__ void match_kernel(const MatchEvent *, const int2 *, const int *, cons
                              const int *, const int *, const int *, int, int, int, int, int, uint32_t *, uint16_t *);
 __global__ void summarize_kernel(const DevEvent *, const unsigned char *, int, int, int, int, const uint64_t *, double *);
 template <int G, bool PE, int KC> __global__ void sampler_grp(const KernelArgs a);
+template <int KC> __global__ void sampler_flat(const KernelArgs a);
 __global__ void selftest_detmath_kernel(const double *, int, double *, double *, double *, double *);
 __global__ void selftest_philox_kernel(const uint32_t *, int, uint32_t *);
 
@@ -518,10 +519,51 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       }
     }
   }
+  // single-end runs whose events all have a class table go to sampler_flat (kernels_flat.inl): NC chains
+  // per wavefront, as many as fit the wavefront's share of the LDS (two workgroups of four wavefronts
+  // per CU: 20 KB each), fewer when the batch would not fill the device otherwise.
+  // MISO_NO_FLAT=1: sampler_grp as in round 1 (A/B, tests); MISO_FLAT_NC=n forces the chains per wavefront.
+  std::vector<int> flat_nc(gen_runs.size(), 0);
+  for (size_t ri = 0; ri < gen_runs.size(); ri++) {
+    const GenRun &run = gen_runs[ri];
+    if (p.paired || run.nocls || std::getenv("MISO_NO_FLAT") != nullptr) continue;
+    const int slice = flat_layout(run.kmax, std::max(run.maxcls, 1)).bytes;
+    const int nc_max = std::min<int>(64, static_cast<int>(LDS_MAX / 4) / slice);
+    if (nc_max < 1) continue;
+    const long chains = static_cast<long>(run.count) * p.noChains;
+    int nc = static_cast<int>(std::min<long>(nc_max, std::max<long>(1, (chains + slots_for(chains) - 1) / slots_for(chains))));
+    if (const char *env = std::getenv("MISO_FLAT_NC")) nc = std::max(1, std::min(nc_max, std::atoi(env)));
+    flat_nc[ri] = nc;
+  }
+  auto flat_name = [&](const GenRun &run) { return "sampler_flat<" + std::to_string(run.kc) + ">"; };
+  auto launch_flat = [&](KernelArgs ka, const GenRun &run, int nc, hipStream_t st) {
+    const long chains = static_cast<long>(run.count) * p.noChains;
+    ka.slot_event = d_slots + n_k2 + run.first; ka.n_slots = run.count;
+    ka.kstride = run.kmax; ka.cstride = std::max(run.maxcls, 1); ka.tstride = 0; ka.nc = nc;
+    const long waves = (chains + nc - 1) / nc;
+    const unsigned grid = static_cast<unsigned>((waves + 3) / 4);
+    const size_t lds = 4 * static_cast<size_t>(nc) * flat_layout(ka.kstride, ka.cstride).bytes;
+#define MISO_FLAT_LAUNCH(KC)                                                                            \
+  {                                                                                                     \
+    HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sampler_flat<KC>),                       \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));     \
+    hipLaunchKernelGGL((sampler_flat<KC>), dim3(grid), dim3(256), lds, st, ka);                         \
+  }
+    switch (run.kc) {
+    case 4: MISO_FLAT_LAUNCH(4) break;
+    case 8: MISO_FLAT_LAUNCH(8) break;
+    case 12: MISO_FLAT_LAUNCH(12) break;
+    case 16: MISO_FLAT_LAUNCH(16) break;
+    default: MISO_FLAT_LAUNCH(32) break;
+    }
+#undef MISO_FLAT_LAUNCH
+    HIP_OK(hipGetLastError());
+  };
   std::vector<int> grp_G(gen_runs.size(), 64);
   std::vector<GrpShape> grp_sh(gen_runs.size());
   for (size_t ri = 0; ri < gen_runs.size(); ri++) {
     GenRun &run = gen_runs[ri];
+    if (flat_nc[ri] > 0) continue;
     const GrpShape sh = grp_sh[ri] = grp_shape(run);
     const long chains = static_cast<long>(run.count) * p.noChains;
     int G = 64;
@@ -593,7 +635,8 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   }
   for (size_t ri = 0; ri < gen_runs.size(); ri++) {
     const GenRun &run = gen_runs[ri];
-    const int G = grp_G[ri], C = p.noChains, cpw = std::max(1, 64 / G);
+    const bool flat = flat_nc[ri] > 0;
+    const int G = grp_G[ri], C = p.noChains, cpw = flat ? flat_nc[ri] : std::max(1, 64 / G);
     const long chains = static_cast<long>(run.count) * C;
     std::vector<const PackedEvent *> evs;   // the run's events in slot order
     {
@@ -607,17 +650,18 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     double trips = 0, words = 0;
     long waves = 0;
     for (long s0 = 0; s0 < chains; s0 += cpw, waves++) {
-      int mx = 0, kmx = 0;
+      int mx = 0, kmx = 0; long units = 0;
       for (long sl = s0; sl < std::min(chains, s0 + cpw); sl++) {
         const PackedEvent &e = *evs[sl / C];
         mx = std::max(mx, cls ? e.n_units : (e.n_draw + 3) / 4);
+        units += e.n_units;
         kmx = std::max(kmx, e.K);
         words += e.n_draw;
       }
       const int nw = (cls && kmx - 1 <= 3) ? 2 : 1;         // Philox blocks in flight (class path, K <= 4)
-      trips += (G == 64) ? mx : nw * ((mx + nw * G - 1) / (nw * G));
+      trips += flat ? (units + 63) / 64 : ((G == 64) ? mx : nw * ((mx + nw * G - 1) / (nw * G)));
     }
-    const std::string name = (G == 64 ? std::string("sampler_wave<") : "sampler_grp<" + std::to_string(G) + ", ") +
+    const std::string name = flat ? flat_name(run) : (G == 64 ? std::string("sampler_wave<") : "sampler_grp<" + std::to_string(G) + ", ") +
                              (p.paired ? "true" : "false") + (G == 64 ? std::string(">") : ", " + std::to_string(run.kc) + ">");
     add_stat(name, static_cast<double>(waves), trips, static_cast<double>(chains), words);
   }
@@ -645,6 +689,11 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   for (size_t ri = 0; ri < gen_runs.size(); ri++) {
     const GenRun &run = gen_runs[ri];
     const int G = grp_G[ri];
+    if (flat_nc[ri] > 0) {
+      last_kernels += std::string(last_kernels.empty() ? "" : ",") + flat_name(run);
+      launch_flat(a, run, flat_nc[ri], stream_for_next());
+      continue;
+    }
     last_kernels += std::string(last_kernels.empty() ? "" : ",") +
                     (G == 64 ? std::string("sampler_wave<")
                              : "sampler_grp<" + std::to_string(G) + ", ") +
