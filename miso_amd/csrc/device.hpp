@@ -111,21 +111,28 @@ struct FlatLayout {
   int sx;                       // double[FLAT_SX]
   int cnt, bas, dl;             // int[ks]: picks of the drawing reads, fixed reads, D_k
   int misc;                     // int[FLAT_MISC]
-  int thr;                      // u32[cs x (ks - 1)]: thr[c][k] = words below it pick an isoform <= k
+  int thr;                      // u32[cs x flat_trow(ks)]: thr[c][k] = words below it pick an isoform <= k (0 beyond K - 1)
   int ctab;                     // u32[CLS_WORDS x (cs + 1) + ks]: class rows, sentinel row, A_k
   int bytes;
 };
+// width of the read loop's register rows for a largest isoform count ks: the instantiated widths of
+// kernels_flat.inl's flat_units (2, 3 | 4..7 | 9, 11 | 15 | 19, 23, 31); thr rows have this stride
+MISO_DEVHOST inline int flat_trow(int ks) {
+  const int tw = ks - 1;
+  return tw <= 3 ? (tw <= 2 ? 2 : 3) : (tw <= 7 ? (tw <= 4 ? 4 : tw) : (tw <= 9 ? 9 : (tw <= 11 ? 11 : (tw <= 15 ? 15 : (tw <= 19 ? 19 : (tw <= 23 ? 23 : 31))))));
+}
 MISO_DEVHOST inline FlatLayout flat_layout(int ks, int cs) {
   FlatLayout L{};
+  const int tr = flat_trow(ks), kd = ks > tr + 1 ? ks : tr + 1;
   int o = 0;
   L.psi = o; o += 16 * ks; L.alpha = o; o += 16 * ks; L.lp = o; o += 16 * ks; L.tb = o; o += 16 * ks;
   L.lr = o; o += 16 * ks;
   L.tc = o; o += 8 * ks; L.u2 = o; o += 8 * ks;
   L.cst = o; o += 8 * ks; L.isc = o; o += 8 * ks; L.hm1 = o; o += 8 * ks;
   L.sx = o; o += 8 * FLAT_SX;
-  L.cnt = o; o += 4 * ks; L.bas = o; o += 4 * ks; L.dl = o; o += 4 * ks;
+  L.cnt = o; o += 4 * ks; L.bas = o; o += 4 * ks; L.dl = o; o += 4 * kd;
   L.misc = o; o += 4 * FLAT_MISC;
-  L.thr = o; o += 4 * cs * (ks - 1);
+  L.thr = o; o += 4 * cs * tr;
   L.ctab = o; o += 4 * (CLS_WORDS * (cs + 1) + ks);
   L.bytes = (o + 15) & ~15;
   return L;

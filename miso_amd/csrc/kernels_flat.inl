@@ -44,6 +44,9 @@
 
 namespace miso {
 
+// the kernel's dynamic LDS (declared here so that flat_units, which is not inlined, addresses it as LDS too)
+extern __shared__ __attribute__((aligned(16))) unsigned char smem_flat[];
+
 namespace {
 
 // LDS traffic between lanes of ONE wavefront: program order is enough once the compiler may not move
@@ -54,8 +57,8 @@ __device__ __forceinline__ void fsync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_RE
 enum { SX_SUMEXP = 0, SX_LTHETA, SX_MAXV, SX_E1, SX_E2, SX_X1, SX_X2, SX_LA0, SX_LA1, SX_LA2, SX_LR0, SX_LR1,
        SX_LR2, SX_SD, SX_SIGMA, SX_COVAR };
 // ... and int scalars (FlatLayout::misc)
-enum { MI_K = 0, MI_NDRAW, MI_NCLS, MI_NUNITS, MI_EVID, MI_CHAIN, MI_PAR, MI_ACCW, MI_C3K1, MI_P1LO, MI_P1HIK0,
-       MI_EV, MI_SAMP_LO, MI_SAMP_HI, MI_TRACE_LO, MI_TRACE_HI, MI_USTART };
+enum { MI_K = 0, MI_NDRAW, MI_NCLS, MI_NUNITS, MI_EVID, MI_CHAIN, MI_ACC, MI_ACCW, MI_C3K1, MI_P1LO, MI_P1HIK0,
+       MI_EV, MI_SAMP_LO, MI_SAMP_HI, MI_TRACE_LO, MI_TRACE_HI, MI_USTART, MI_NEXT };
 
 // The reference's draw compares rnd = fl(fl(u 2^-32) T) with a cumulative weight c: `rnd < c` when two
 // isoforms are compatible, `!(rnd > c)` otherwise (miso.c:69-79).  Both are monotone in the 32-bit word
@@ -79,78 +82,159 @@ __device__ __forceinline__ double flat_threshold(bool le, double c, double T, do
   }
   return t < 0.0 ? 0.0 : t;
 }
+// The same count when T is a normal finite number and 2 <= est <= 2^32 - 3 (the caller checks; otherwise it
+// takes flat_threshold): est is then within 2^-20 of the boundary (one rounding in c / T 2^32, one in the
+// test's product), so none of flat_threshold's clamps, range tests or outer tests can fire, and the count
+// is floor(est) - 1 + (tests that hold among floor - 1, floor, floor + 1) -- two tests decide it, because
+// the test is monotone in u: if it holds at floor the count is floor + 1 or floor + 2, else floor - 1 or floor.
+__device__ __forceinline__ double flat_threshold_fast(bool le, double c, double T, double est) {
+  const double t0 = __builtin_floor(est);
+  auto pred = [&](double u) { const double rnd = u * (1.0 / 4294967296.0) * T; return le ? !(rnd > c) : (rnd < c); };
+  const bool p0 = pred(t0);
+  const double u1 = p0 ? t0 + 1.0 : t0 - 1.0;
+  const bool p1 = pred(u1);
+  return p0 ? (p1 ? t0 + 2.0 : t0 + 1.0) : (p1 ? t0 : t0 - 1.0);
+}
 
-// The read loop of one wavefront-iteration for at most TW + 1 isoforms per chain.
-// Lane state: chain s, class c, unit i (within the chain), the class's unit range and thresholds.
+// D += (w0 < T) + (w1 < T) + (w2 < T) + (w3 < T).  Written out: hipcc funnels every compare through VCC
+// (v_cmp, two wait states, v_addc), three issue slots per compare; with four SGPR pairs in flight the
+// wait states are covered by the neighbouring compares: two slots per compare.
+__device__ __forceinline__ void count_below(int &D, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t T) {
+  uint64_t m0, m1, m2, m3, junk;
+  asm volatile(
+      "v_cmp_lt_u32_e64 %1, %6, %10\n\t"
+      "v_cmp_lt_u32_e64 %2, %7, %10\n\t"
+      "v_cmp_lt_u32_e64 %3, %8, %10\n\t"
+      "v_cmp_lt_u32_e64 %4, %9, %10\n\t"
+      "v_addc_co_u32_e64 %0, %5, %0, 0, %1\n\t"
+      "v_addc_co_u32_e64 %0, %5, %0, 0, %2\n\t"
+      "v_addc_co_u32_e64 %0, %5, %0, 0, %3\n\t"
+      "v_addc_co_u32_e64 %0, %5, %0, 0, %4\n\t"
+      : "+v"(D), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3), "=&s"(junk)
+      : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(T));
+}
+
+// The read loop of one wavefront-iteration for at most TW + 1 isoforms per chain (TW = the launch's
+// flat_trow or narrower; thr rows are zero beyond a chain's K - 1).
+// Lane state: chain s, class c, unit i (within the chain), the class's unit range and thresholds -- and
+// the SAME for the class that follows (N...), loaded when the current one was entered: by the time the
+// lane gets there the LDS reads are long done, so a class change costs register moves, not a chain of
+// dependent LDS round trips in front of the whole wavefront (some lane changes class in almost every
+// trip; profiles/r02_flat_phase_cycles_v1.txt).  Not inlined: its registers are allocated on their own,
+// away from the scalar pressure of the kernel's other phases.
+struct FlatUnitsArgs {
+  int woff;   // the wavefront's slices start here in smem_flat
+  int slice, off_ctab, off_thr, off_misc, off_dl, trow, trips;
+  uint32_t iter, k0, k1;
+};
 template <int TW>
-__device__ __forceinline__ void flat_units(unsigned char *wbase, const FlatLayout &L, int tws, int ncw, int trips,
-                                           int s0, int c0, int i0, int n_mine, uint32_t iter, uint32_t k0, uint32_t k1) {
-  if (trips == 0) return;
-  int s = s0, c = c0 - 1, i = i0;
-  int uend = i0, ust = 0, qd = 0, ncls = 0;   // uend == i forces the first class load
+__device__ __attribute__((noinline)) void flat_units(const FlatUnitsArgs A, int s0, int c0, int i0, int n_mine) {
+  if (A.trips == 0) return;
+  unsigned char *wbase = smem_flat + A.woff;
+  const int slice = __builtin_amdgcn_readfirstlane(A.slice), off_ctab = __builtin_amdgcn_readfirstlane(A.off_ctab),
+            off_thr = __builtin_amdgcn_readfirstlane(A.off_thr), off_misc = __builtin_amdgcn_readfirstlane(A.off_misc),
+            off_dl = __builtin_amdgcn_readfirstlane(A.off_dl), trow4 = 4 * __builtin_amdgcn_readfirstlane(A.trow);
+  const uint32_t iter = __builtin_amdgcn_readfirstlane(A.iter);
+  // current class: unit range, thresholds; current chain: slice, classes left, next chain with units
+  int i = i0, uend = i0, ust = 0, qd = 0, left = 0, next = -1;   // uend == i: the first trip enters a class
+  int sl = 0;   // byte offset of the chain's slice
   uint32_t hm = 0xFFu;
-  uint32_t T[TW];
+  uint32_t T[TW], NT[TW];
   int D[TW];
 #pragma unroll
-  for (int j = 0; j < TW; j++) { T[j] = 0u; D[j] = 0; }
+  for (int j = 0; j < TW; j++) { T[j] = 0u; NT[j] = 0u; D[j] = 0; }
   GibbsRng rng;
-  rng.k0 = k0; rng.k1 = k1; rng.p1lo = 0; rng.p1hi = 0; rng.c3k1 = 0;
+  rng.k0 = A.k0; rng.k1 = A.k1; rng.p1lo = 0; rng.p1hi = 0; rng.c3k1 = 0;
   uint32_t n0r0 = 0;
-  bool fresh = true;   // chain constants not loaded yet
-  for (int t = 0; t < trips; t++) {
-    const bool active = t < n_mine;
-    if (active && i == uend) {   // next class (of this chain or of the next one)
-      const int *mi = reinterpret_cast<const int *>(wbase + s * L.bytes + L.misc);
-      if (fresh) { ncls = mi[MI_NCLS]; }
-      c++;
-      if (!fresh && c == ncls) {   // next chain: hand the counters over first
-        int *dl = reinterpret_cast<int *>(wbase + s * L.bytes + L.dl);
+  // the class after the current one (loaded when the current one was entered)
+  int N_new = 1;        // ... is the first of another chain (or the lane's very first)
+  int N_sl = 0, N_rowp = 0, N_thp = 0, N_i = i0, N_ust = 0, N_uend = 0, N_qd = 0, N_left = 0, N_next = -1;
+  uint32_t N_hm = 0xFFu, N_c3k1 = 0, N_p1lo = 0, N_p1hik0 = 0;
+  int rowp = 0, thp = 0;   // byte offsets of the current class's table row / threshold row
+  bool have = false;       // D holds counts of the chain at sl
+  auto prefetch = [&](int psl, int prow, int pth, int newchain) __attribute__((always_inline)) {
+    const uint32_t *row = reinterpret_cast<const uint32_t *>(wbase + prow);
+    const uint32_t *th = reinterpret_cast<const uint32_t *>(wbase + pth);
+    N_ust = static_cast<int>(row[1]); N_qd = static_cast<int>(row[2]); N_hm = row[3];
+    N_uend = static_cast<int>(row[CLS_WORDS + 1]);
 #pragma unroll
-        for (int j = 0; j < TW; j++) { if (D[j]) atomicAdd(&dl[j], D[j]); D[j] = 0; }
-        do { s++; mi = reinterpret_cast<const int *>(wbase + s * L.bytes + L.misc); } while (mi[MI_NUNITS] == 0);
-        ncls = mi[MI_NCLS];
-        c = 0; i = 0;
-        fresh = true;
-      }
-      if (fresh) {
-        rng.c3k1 = static_cast<uint32_t>(mi[MI_C3K1]); rng.p1lo = static_cast<uint32_t>(mi[MI_P1LO]);
-        n0r0 = static_cast<uint32_t>(mi[MI_P1HIK0]) ^ iter;
-        fresh = false;
-      }
-      const uint32_t *row = reinterpret_cast<const uint32_t *>(wbase + s * L.bytes + L.ctab) + CLS_WORDS * c;
-      ust = static_cast<int>(row[1]); qd = static_cast<int>(row[2]); hm = row[3];
-      uend = static_cast<int>(row[CLS_WORDS + 1]);
-      const uint32_t *th = reinterpret_cast<const uint32_t *>(wbase + s * L.bytes + L.thr) + c * tws;
-      const int tw = mi[MI_K] - 1;
-#pragma unroll
-      for (int j = 0; j < TW; j++) T[j] = (j < tw) ? th[j] : 0u;
+    for (int j = 0; j < TW; j++) NT[j] = th[j];
+    if (newchain) {
+      const int *mi = reinterpret_cast<const int *>(wbase + psl + off_misc);
+      N_left = mi[MI_NCLS]; N_next = mi[MI_NEXT];
+      N_c3k1 = static_cast<uint32_t>(mi[MI_C3K1]); N_p1lo = static_cast<uint32_t>(mi[MI_P1LO]);
+      N_p1hik0 = static_cast<uint32_t>(mi[MI_P1HIK0]);
     }
-    uint32_t wm = active ? 0xFu : 0u;
-    if (i == ust) wm &= hm;
-    if (i == uend - 1) wm &= hm >> 4;
-    const miso_u32x4 u = philox_gibbs<true>(rng, static_cast<uint32_t>(active ? i - qd : 0), n0r0);
-#pragma unroll
-    for (int w = 0; w < 4; w++) {
-      const uint32_t uw = ((wm >> w) & 1u) ? u.v[w] : 0xFFFFFFFFu;   // never below a 32-bit threshold
-#pragma unroll
-      for (int j = 0; j < TW; j++) D[j] += (uw < T[j]) ? 1 : 0;
-    }
-    i += active ? 1 : 0;
-  }
+    N_sl = psl; N_rowp = prow; N_thp = pth; N_new = newchain;
+  };
   if (n_mine > 0) {
-    int *dl = reinterpret_cast<int *>(wbase + s * L.bytes + L.dl);
+    const int psl = s0 * slice;
+    prefetch(psl, psl + off_ctab + 4 * CLS_WORDS * c0, psl + off_thr + c0 * trow4, 1);
+    N_left -= c0;   // classes of the first chain from c0 on
+  }
+  // Two units per trip when the class has two left (one otherwise: the second block is then masked out):
+  // the class bookkeeping and the loop control are paid once per trip, and two Philox blocks interleave.
+  int rem = n_mine;   // units this lane still owes
+  for (;;) {
+    if (!__any(rem > 0)) break;
+    const bool active = rem > 0;
+    if (active && i == uend) {   // enter the prefetched class
+      if (N_new) {
+        if (have) {
+          int *dl = reinterpret_cast<int *>(wbase + sl + off_dl);
 #pragma unroll
-    for (int j = 0; j < TW; j++) if (D[j]) atomicAdd(&dl[j], D[j]);
+          for (int j = 0; j < TW; j++) { atomicAdd(&dl[j], D[j]); D[j] = 0; }
+        }
+        sl = N_sl; left = N_left; next = N_next; i = N_i; N_i = 0;
+        rng.c3k1 = N_c3k1; rng.p1lo = N_p1lo; n0r0 = N_p1hik0 ^ iter;
+        have = true;
+      }
+      rowp = N_rowp; thp = N_thp; ust = N_ust; uend = N_uend; qd = N_qd; hm = N_hm;
+#pragma unroll
+      for (int j = 0; j < TW; j++) T[j] = NT[j];
+      left--;
+      if (left > 0) prefetch(sl, rowp + 4 * CLS_WORDS, thp + trow4, 0);
+      else if (next >= 0) { const int psl = next * slice; prefetch(psl, psl + off_ctab, psl + off_thr, 1); }
+    }
+    const bool two = active && rem >= 2 && i + 1 < uend;
+    // words of a unit that belong to the class: all four except in the class's first / last unit
+    uint32_t wa = active ? 0xFu : 0u, wb = two ? 0xFu : 0u;
+    wa &= (i == ust) ? hm : 0xFu;
+    wa &= (i == uend - 1) ? (hm >> 4) : 0xFu;
+    wb &= (i + 1 == uend - 1) ? (hm >> 4) : 0xFu;
+    const int na = static_cast<int>(~wa), nb = static_cast<int>(~wb);
+    const miso_u32x4 ua = philox_gibbs<true>(rng, static_cast<uint32_t>(i - qd), n0r0);
+    const miso_u32x4 ub = philox_gibbs<true>(rng, static_cast<uint32_t>(i + 1 - qd), n0r0);
+    // a word outside the class becomes 0xFFFFFFFF: never below a 32-bit threshold
+    const uint32_t a0 = ua.v[0] | static_cast<uint32_t>(__builtin_amdgcn_sbfe(na, 0, 1));
+    const uint32_t a1 = ua.v[1] | static_cast<uint32_t>(__builtin_amdgcn_sbfe(na, 1, 1));
+    const uint32_t a2 = ua.v[2] | static_cast<uint32_t>(__builtin_amdgcn_sbfe(na, 2, 1));
+    const uint32_t a3 = ua.v[3] | static_cast<uint32_t>(__builtin_amdgcn_sbfe(na, 3, 1));
+    const uint32_t b0 = ub.v[0] | static_cast<uint32_t>(__builtin_amdgcn_sbfe(nb, 0, 1));
+    const uint32_t b1 = ub.v[1] | static_cast<uint32_t>(__builtin_amdgcn_sbfe(nb, 1, 1));
+    const uint32_t b2 = ub.v[2] | static_cast<uint32_t>(__builtin_amdgcn_sbfe(nb, 2, 1));
+    const uint32_t b3 = ub.v[3] | static_cast<uint32_t>(__builtin_amdgcn_sbfe(nb, 3, 1));
+#pragma unroll
+    for (int j = 0; j < TW; j++) { count_below(D[j], a0, a1, a2, a3, T[j]); count_below(D[j], b0, b1, b2, b3, T[j]); }
+    const int adv = active ? (two ? 2 : 1) : 0;
+    i += adv; rem -= adv;
+  }
+  if (have) {
+    int *dl = reinterpret_cast<int *>(wbase + sl + off_dl);
+#pragma unroll
+    for (int j = 0; j < TW; j++) atomicAdd(&dl[j], D[j]);
   }
 }
 
 }  // namespace
 
+#ifndef MISO_FLAT_MINBLOCKS
+#define MISO_FLAT_MINBLOCKS 2   // workgroups per CU the register budget allows
+#endif
 template <int KC>
-__global__ __launch_bounds__(256, 2) void sampler_flat(const KernelArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_flat[];
+__global__ __launch_bounds__(256, MISO_FLAT_MINBLOCKS) void sampler_flat(const KernelArgs a) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int NC = a.nc, ks = a.kstride, cs = a.cstride, tws = ks - 1;
+  const int NC = a.nc, ks = a.kstride, cs = a.cstride, tws = ks - 1, trow = flat_trow(ks);
   const FlatLayout L = flat_layout(ks, cs);
   unsigned char *wbase = smem_flat + static_cast<size_t>(wid) * NC * L.bytes;
   const long n_chains = static_cast<long>(a.n_slots) * a.C;
@@ -163,6 +247,8 @@ __global__ __launch_bounds__(256, 2) void sampler_flat(const KernelArgs a) {
 #define FD(s, off) reinterpret_cast<double *>(wbase + (s) * L.bytes + (off))
 #define FI(s, off) reinterpret_cast<int *>(wbase + (s) * L.bytes + (off))
 #define FU(s, off) reinterpret_cast<uint32_t *>(wbase + (s) * L.bytes + (off))
+  // buffer 0 of psi / alpha / lp / tb / lr = the current state and its cached logs, buffer 1 (+ ks) = the proposal
+  const int PR = ks;
 
   // ---- set-up: every chain's constants and class table into its slice ----
   int Kw = 0;
@@ -177,21 +263,26 @@ __global__ __launch_bounds__(256, 2) void sampler_flat(const KernelArgs a) {
     const int *base = reinterpret_cast<const int *>(a.in_pool + E.off_base);
     const uint32_t *gt = reinterpret_cast<const uint32_t *>(a.in_pool + E.off_cls);
     const uint32_t event_id = E.has_id ? E.explicit_id : a.first_event_id + static_cast<uint32_t>(ev);
-    for (int k = lane; k < K; k += 64) {
-      FD(s, L.cst)[k] = consts[k]; FD(s, L.isc)[k] = consts[K + k]; FD(s, L.hm1)[k] = consts[2 * K + k];
+    for (int k = lane; k < ks; k += 64) {
+      const bool in = k < K;
+      FD(s, L.cst)[k] = in ? consts[k] : 0.0; FD(s, L.isc)[k] = in ? consts[K + k] : 0.0;
+      FD(s, L.hm1)[k] = in ? consts[2 * K + k] : 0.0;
       // miso.c:330-447 START_AUTO: K != 2 -> alpha = 1/(K-1); START_UNIFORM -> 0
       FD(s, L.alpha)[k] = (a.start == MISO_START_AUTO && K != 2 && k < K - 1) ? 1.0 / (K - 1) : 0.0;
-      FD(s, L.alpha)[ks + k] = 0.0;
-      FD(s, L.psi)[k] = 0.0; FD(s, L.psi)[ks + k] = 0.0;
-      FI(s, L.cnt)[k] = 0; FI(s, L.bas)[k] = base[k]; FI(s, L.dl)[k] = 0;
-      FU(s, L.ctab)[CLS_WORDS * (cs + 1) + k] = gt[CLS_WORDS * (E.n_dcls + 1) + k];   // A_k
+      FD(s, L.alpha)[PR + k] = 0.0;
+      FD(s, L.psi)[k] = 0.0; FD(s, L.psi)[PR + k] = 0.0;
+      FD(s, L.lp)[k] = 0.0; FD(s, L.lp)[PR + k] = 0.0; FD(s, L.tb)[k] = 0.0; FD(s, L.tb)[PR + k] = 0.0;
+      FD(s, L.lr)[k] = 0.0; FD(s, L.lr)[PR + k] = 0.0; FD(s, L.tc)[k] = 0.0; FD(s, L.u2)[k] = 0.0;
+      FI(s, L.cnt)[k] = 0; FI(s, L.bas)[k] = in ? base[k] : 0; FI(s, L.dl)[k] = 0;
+      FU(s, L.ctab)[CLS_WORDS * (cs + 1) + k] = in ? gt[CLS_WORDS * (E.n_dcls + 1) + k] : 0u;   // A_k
     }
     for (int i = lane; i < CLS_WORDS * (E.n_dcls + 1); i += 64) FU(s, L.ctab)[i] = gt[i];
+    for (int i = lane; i < cs * trow; i += 64) FU(s, L.thr)[i] = 0u;
     if (lane == 0) {
       int *mi = FI(s, L.misc);
       mi[MI_K] = K; mi[MI_NDRAW] = E.n_draw; mi[MI_NCLS] = E.n_dcls; mi[MI_NUNITS] = E.n_units;
       mi[MI_EVID] = static_cast<int>(event_id); mi[MI_CHAIN] = static_cast<int>(chain);
-      mi[MI_PAR] = 0; mi[MI_ACCW] = 0; mi[MI_EV] = ev;
+      mi[MI_ACC] = 0; mi[MI_ACCW] = 0; mi[MI_EV] = ev; mi[MI_NEXT] = -1;
       const GibbsRng g = gibbs_rng_init(a.seed, event_id, chain);
       mi[MI_C3K1] = static_cast<int>(g.c3k1); mi[MI_P1LO] = static_cast<int>(g.p1lo);
       mi[MI_P1HIK0] = static_cast<int>(g.p1hi ^ g.k0);
@@ -204,11 +295,19 @@ __global__ __launch_bounds__(256, 2) void sampler_flat(const KernelArgs a) {
   }
   Kw = __builtin_amdgcn_readfirstlane(Kw);
   fsync();
-  // the wavefront's unit list: chain s owns units [ustart_s, ustart_s + n_units_s)
+  // the wavefront's unit list: chain s owns units [ustart_s, ustart_s + n_units_s); MI_NEXT = the next
+  // chain that has units at all
   int total_units = 0;
-  for (int s = 0; s < ncw; s++) {
-    if (lane == 0) FI(s, L.misc)[MI_USTART] = total_units;
-    total_units += FI(s, L.misc)[MI_NUNITS];
+  {
+    int nxt = -1;
+    for (int s = ncw - 1; s >= 0; s--) {
+      if (lane == 0) FI(s, L.misc)[MI_NEXT] = nxt;
+      if (FI(s, L.misc)[MI_NUNITS] > 0) nxt = s;
+    }
+    for (int s = 0; s < ncw; s++) {
+      if (lane == 0) FI(s, L.misc)[MI_USTART] = total_units;
+      total_units += FI(s, L.misc)[MI_NUNITS];
+    }
   }
   total_units = __builtin_amdgcn_readfirstlane(total_units);
   const int trips = (total_units + 63) / 64;   // units per lane
@@ -246,14 +345,26 @@ __global__ __launch_bounds__(256, 2) void sampler_flat(const KernelArgs a) {
   const float inv_k1 = 1.0f / static_cast<float>(tws), inv_k = 1.0f / static_cast<float>(ks),
               inv_2k = 1.0f / static_cast<float>(2 * ks - 1), inv_k2 = 1.0f / static_cast<float>(ks + 2),
               inv_cs = 1.0f / static_cast<float>(max(cs, 1));
-  // flat loop over (chain s, item j < nper): idx = s * nper + j
+  // flat loop over (chain s, item j < nper): idx = s * nper + j; lanes past the end shadow item 0 of
+  // chain 0 (loads stay inside the slice) and are switched off by `on`
 #define FLAT_BEGIN(nper, inv)                                                   \
   for (int base_ = 0; base_ < ncw * (nper); base_ += 64) {                      \
     const int idx_ = base_ + lane;                                              \
-    const bool on_ = idx_ < ncw * (nper);                                       \
-    const int s = on_ ? static_cast<int>((static_cast<float>(idx_) + 0.5f) * (inv)) : 0; \
-    const int j = on_ ? idx_ - s * (nper) : (nper);
+    const bool on = idx_ < ncw * (nper);                                        \
+    const int s = on ? static_cast<int>((static_cast<float>(idx_) + 0.5f) * (inv)) : 0; \
+    const int j = on ? idx_ - s * (nper) : 0;
 #define FLAT_END }
+  // a leader's vector: all loads first (one LDS latency), then the reference's left-to-right arithmetic
+  // (in chunks of CH isoforms, so that the K <= 32 kernel does not hold whole vectors in registers)
+  constexpr int CH = KC <= 8 ? KC : (KC <= 16 ? 8 : 4);
+#define CHUNKS_BEGIN                                                            \
+  _Pragma("unroll") for (int k0 = 0; k0 < KC; k0 += CH) {                       \
+    if (k0 < Kw) {
+#define CHUNKS_END }}
+#define LOADC(v, p)                                                             \
+  double v[CH];                                                                 \
+  _Pragma("unroll") for (int i_ = 0; i_ < CH; i_++) v[i_] = (k0 + i_ < Kw) ? (p)[k0 + i_] : 0.0;
+#define EACH(k) _Pragma("unroll") for (int i_ = 0, k = k0; i_ < CH; i_++, k++) if (k < Kw)
 
 #ifdef MISO_K2_PROFILE
   uint64_t fp_mh = 0, fp_thr = 0, fp_loop = 0;
@@ -261,91 +372,82 @@ __global__ __launch_bounds__(256, 2) void sampler_flat(const KernelArgs a) {
 
   // ---- alpha' = alpha + sd z ; psi' = logit_inv(alpha') (miso.c:449-471), then the psi-only parts of
   // both scores of the new point: lp = log x, tb = lp + cst, lr = log(x_k / x_K'), jacobian.
-  // sp / dp: source / destination buffer of every chain relative to its parity (0 = current). ----
-  auto propose_and_logs = [&](uint32_t iter, int srel, int drel, double &jac_out) {
+  // SRC / DST: buffer offsets (0 = current, PR = proposal) of alpha read / everything written. ----
+  auto propose_and_logs = [&](uint32_t iter, int SRC, int DST, double &jac_out) {
     FLAT_BEGIN(tws, inv_k1)   // pass 1 (qnorm) + pass 2 (exp), one normal per lane
       const int *mi = FI(s, L.misc);
       const int K = mi[MI_K];
-      if (j < K - 1) {
-        const int par = mi[MI_PAR];
-        const int w = 2 + 2 * j;
-        const miso_u32x4 b = miso_draw_block(a.seed, static_cast<uint32_t>(mi[MI_EVID]), static_cast<uint32_t>(mi[MI_CHAIN]),
-                                             iter, MISO_SITE_MH, static_cast<uint32_t>(w >> 2));
-        const bool odd = (j & 1) != 0;   // w & 3 = 0 for odd j, 2 for even j
-        const double z = miso_det_norm_from_unif(miso_u01(odd ? b.v[0] : b.v[2]), miso_u01(odd ? b.v[1] : b.v[3]));
-        const double an = FD(s, L.alpha)[(par ^ srel) * ks + j] + FD(s, L.sx)[SX_SD] * z;
-        FD(s, L.alpha)[(par ^ drel) * ks + j] = an;
-        FD(s, L.tc)[j] = miso_det_exp(an);
+      const uint32_t evid = static_cast<uint32_t>(mi[MI_EVID]), chain = static_cast<uint32_t>(mi[MI_CHAIN]);
+      const double al = FD(s, L.alpha)[SRC + j], sd = FD(s, L.sx)[SX_SD];
+      const int w = 2 + 2 * j;
+      const miso_u32x4 b = miso_draw_block(a.seed, evid, chain, iter, MISO_SITE_MH, static_cast<uint32_t>(w >> 2));
+      const bool odd = (j & 1) != 0;   // w & 3 = 0 for odd j, 2 for even j
+      const double z = miso_det_norm_from_unif(miso_u01(odd ? b.v[0] : b.v[2]), miso_u01(odd ? b.v[1] : b.v[3]));
+      const double an = al + sd * z;
+      const double ex = miso_det_exp(an);
+      if (on && j < K - 1) {
+        FD(s, L.alpha)[DST + j] = an;
+        FD(s, L.tc)[j] = ex;
         if (j == 0) FI(s, L.misc)[MI_ACCW] = static_cast<int>(b.v[0]);   // block 0, word 0 (miso.c:870)
       }
     FLAT_END
     fsync();
     if (leader) {
-      const double *tc = FD(ls, L.tc);
       double acc = 0.0;
-      for (int k = 0; k < Kw - 1; k++) if (k < lK - 1) acc = acc + tc[k];
+      CHUNKS_BEGIN
+        LOADC(tc, FD(ls, L.tc))
+        EACH(k) acc = (k < lK - 1) ? acc + tc[i_] : acc;
+      CHUNKS_END
       FD(ls, L.sx)[SX_SUMEXP] = acc + 1.0;
     }
     fsync();
     FLAT_BEGIN(tws, inv_k1)
-      const int *mi = FI(s, L.misc);
-      if (j < mi[MI_K] - 1) FD(s, L.psi)[(mi[MI_PAR] ^ drel) * ks + j] = FD(s, L.tc)[j] / FD(s, L.sx)[SX_SUMEXP];
+      const int K = FI(s, L.misc)[MI_K];
+      const double q = FD(s, L.tc)[j] / FD(s, L.sx)[SX_SUMEXP];
+      if (on && j < K - 1) FD(s, L.psi)[DST + j] = q;
     FLAT_END
     fsync();
     if (leader) {
-      double *x = FD(ls, L.psi) + (FI(ls, L.misc)[MI_PAR] ^ drel) * ks;
+      double *x = FD(ls, L.psi) + DST;
       double sumpsi = 0.0, ltheta = 1.0, prod = 1.0;
-      for (int k = 0; k < Kw - 1; k++) if (k < lK - 1) { const double t = x[k]; sumpsi = sumpsi + t; ltheta = ltheta - t; prod = prod * t; }
+      CHUNKS_BEGIN
+        LOADC(xv, x)
+        EACH(k) {
+          const bool in = k < lK - 1;
+          sumpsi = in ? sumpsi + xv[i_] : sumpsi; ltheta = in ? ltheta - xv[i_] : ltheta; prod = in ? prod * xv[i_] : prod;
+        }
+      CHUNKS_END
       x[lK - 1] = 1 - sumpsi;
       FD(ls, L.sx)[SX_LTHETA] = ltheta;
       jac_out = 1.0 / prod / ltheta;
     }
     fsync();
     FLAT_BEGIN(2 * ks - 1, inv_2k)   // pass 3 (log): 2K - 1 arguments per chain
-      const int *mi = FI(s, L.misc);
-      const int K = mi[MI_K];
+      const int K = FI(s, L.misc)[MI_K];
       const bool firsthalf = j < ks;
       const int k = firsthalf ? j : j - ks;
-      if (firsthalf ? (k < K) : (k < K - 1)) {
-        const int d = (mi[MI_PAR] ^ drel) * ks;
-        const double xv = FD(s, L.psi)[d + k];
-        const double r = miso_det_log(firsthalf ? xv : xv / FD(s, L.sx)[SX_LTHETA]);
-        if (firsthalf) { FD(s, L.lp)[d + k] = r; FD(s, L.tb)[d + k] = r + FD(s, L.cst)[k]; }
-        else FD(s, L.lr)[d + k] = r;
+      const double xv = FD(s, L.psi)[DST + k], lt = FD(s, L.sx)[SX_LTHETA], cst = FD(s, L.cst)[k];
+      const double r = miso_det_log(firsthalf ? xv : xv / lt);
+      if (on && (firsthalf ? (k < K) : (k < K - 1))) {
+        if (firsthalf) { FD(s, L.lp)[DST + k] = r; FD(s, L.tb)[DST + k] = r + cst; }
+        else FD(s, L.lr)[DST + k] = r;
       }
     FLAT_END
     fsync();
   };
-  auto leader_max = [&](int rel) {   // miso.c:137-140: maxv starts at entry 0
+  auto leader_max = [&](int BUF) {   // miso.c:137-140: maxv starts at entry 0
     double maxv = 0.0;
     if (leader) {
-      const double *tb = FD(ls, L.tb) + (FI(ls, L.misc)[MI_PAR] ^ rel) * ks;
-      maxv = tb[0];
-      for (int k = 1; k < Kw; k++) if (k < lK) { const double v = tb[k]; if (v > maxv) maxv = v; }
+      maxv = (FD(ls, L.tb) + BUF)[0];
+      CHUNKS_BEGIN
+        LOADC(tb, FD(ls, L.tb) + BUF)
+        EACH(k) maxv = (k >= 1 && k < lK && tb[i_] > maxv) ? tb[i_] : maxv;
+      CHUNKS_END
       FD(ls, L.sx)[SX_MAXV] = maxv;
     }
     return maxv;
   };
   auto count_of = [&](int s, int k) { return FI(s, L.bas)[k] + FI(s, L.cnt)[k]; };
-  // joint log score from cached logs and the current counts (miso.c:243-307), leader lanes
-  auto joint_sums = [&](int rel, double lse) {
-    const int d = (FI(ls, L.misc)[MI_PAR] ^ rel) * ks;
-    const double *lp = FD(ls, L.lp) + d, *tb = FD(ls, L.tb) + d, *isc = FD(ls, L.isc), *hm1 = FD(ls, L.hm1);
-    double readProb = 0.0, assProb = 0.0, psiProb = 0.0;
-    for (int k = 0; k < Kw; k++) {
-      if (k < lK) {
-        const int ck = count_of(ls, k);
-        if (ck != 0) {
-          readProb = readProb + static_cast<double>(ck) * isc[k];
-          assProb = assProb + static_cast<double>(ck) * (tb[k] - lse);
-        }
-      }
-    }
-    for (int k = 0; k < Kw; k++) if (k < lK) psiProb = psiProb + hm1[k] * lp[k];
-    psiProb = psiProb + l_lg_sum;
-    psiProb = psiProb - l_lg_each;
-    return readProb + assProb + psiProb;
-  };
 
   // ---- per-read picks by direct evaluation of the reference's scan (miso.c:11-22, 69-80): the final
   // assignment of chain 0 (miso.c:943-946) and the fallback when a threshold does not fit 32 bits ----
@@ -355,7 +457,7 @@ __global__ __launch_bounds__(256, 2) void sampler_flat(const KernelArgs a) {
     const DevEvent E = a.events[mi[MI_EV]];
     const uint32_t *masks = reinterpret_cast<const uint32_t *>(a.in_pool + E.off_draw);
     uint8_t *drawass = a.out_pool + E.off_drawass;
-    const double *psi = FD(s, L.psi) + mi[MI_PAR] * ks;
+    const double *psi = FD(s, L.psi);
     for (int q = lane; q < (n_draw + 3) / 4; q += 64) {
       const miso_u32x4 u = miso_draw_block(a.seed, static_cast<uint32_t>(mi[MI_EVID]), static_cast<uint32_t>(mi[MI_CHAIN]),
                                            iter, MISO_SITE_GIBBS, static_cast<uint32_t>(q));
@@ -390,45 +492,44 @@ __global__ __launch_bounds__(256, 2) void sampler_flat(const KernelArgs a) {
     bool slow = false;
     FLAT_BEGIN(cs, inv_cs)
       const int *mi = FI(s, L.misc);
-      const int K = mi[MI_K];
-      if (j < mi[MI_NCLS]) {
-        const uint32_t m = FU(s, L.ctab)[CLS_WORDS * j];
-        const double *psi = FD(s, L.psi) + mi[MI_PAR] * ks;
-        double ps[KC];
+      const int K = mi[MI_K], ncls = mi[MI_NCLS];
+      const uint32_t m = FU(s, L.ctab)[CLS_WORDS * j];
+      const double *psi = FD(s, L.psi);
+      double ps[KC];
 #pragma unroll
-        for (int k = 0; k < KC; k++) ps[k] = (k < K) ? psi[k] : 0.0;
-        // total weight, ascending isoforms (miso.c:11-22); +0.0 for the others leaves the bits alone
-        double T = 0.0;
+      for (int k = 0; k < KC; k++) ps[k] = (k < Kw) ? psi[k] : 0.0;
+      const bool mine = on && j < ncls;
+      // total weight, ascending isoforms (miso.c:11-22); +0.0 for the others leaves the bits alone
+      double T = 0.0;
 #pragma unroll
-        for (int k = 0; k < KC; k++) if (k < Kw) T = T + (((m >> k) & 1u) ? ps[k] : 0.0);
-        const double inv = 4294967296.0 / T;
-        const bool two = __popc(m) == 2;
-        const int kmax = 31 - __clz(static_cast<int>(m));
-        uint32_t *th = FU(s, L.thr) + j * tws;
-        double cum = 0.0;
-        uint32_t run = 0u;
+      for (int k = 0; k < KC; k++) if (k < Kw) T = T + ((k < K && ((m >> k) & 1u)) ? ps[k] : 0.0);
+      const double inv = 4294967296.0 / T;
+      const bool tnormal = T >= 1e-280 && T <= 1e280;   // products with u 2^-32 stay normal
+      const bool le = __popc(m) != 2;
+      const int kmax = 31 - __clz(static_cast<int>(m));
+      uint32_t *th = FU(s, L.thr) + j * trow;
+      double cum = 0.0;
+      uint32_t run = 0u;
 #pragma unroll
-        for (int k = 0; k < KC - 1; k++) {
-          if (k < Kw - 1) {
-            const bool member = (m >> k) & 1u;
-            cum = cum + (member ? ps[k] : 0.0);
-            uint32_t val = 0u;
-            if (k < kmax) {   // a member before the last one: first j with u < t_j == u < max(t_0..t_j)
-              if (member) {
-                const double t = flat_threshold(!two, cum, T, cum * inv);
-                slow |= t >= 4294967296.0;
-                const uint32_t tu = static_cast<uint32_t>(t);
-                run = tu > run ? tu : run;
-              }
-              val = run;
-            }
-            if (k < K - 1) th[k] = val;
-          }
+      for (int k = 0; k < KC - 1; k++) {
+        if (k < Kw - 1) {
+          const bool member = k < K && ((m >> k) & 1u);
+          cum = cum + (member ? ps[k] : 0.0);
+          // a member before the last one: first j with u < t_j == u < max(t_0..t_j)
+          const bool use = mine && member && k < kmax;
+          const double est = cum * inv;
+          double t;
+          if (__any(use && !(tnormal && est >= 2.0 && est <= 4294967293.0))) t = flat_threshold(le, cum, T, est);
+          else t = flat_threshold_fast(le, cum, T, est);
+          slow |= use && t >= 4294967296.0;
+          const uint32_t tu = static_cast<uint32_t>(t);
+          run = (use && tu > run) ? tu : run;
+          if (mine && k < K - 1) th[k] = (k < kmax) ? run : 0u;
         }
       }
     FLAT_END
     FLAT_BEGIN(ks, inv_k)
-      if (j < FI(s, L.misc)[MI_K]) { FI(s, L.dl)[j] = 0; FI(s, L.cnt)[j] = 0; }
+      if (on) { FI(s, L.dl)[j] = 0; FI(s, L.cnt)[j] = 0; if (j == 0) for (int x = ks; x <= trow; x++) FI(s, L.dl)[x] = 0; }
     FLAT_END
     fsync();
     FPROF_T(t1);
@@ -439,7 +540,10 @@ __global__ __launch_bounds__(256, 2) void sampler_flat(const KernelArgs a) {
       return;
     }
     const int tww = Kw - 1;
-#define MISO_FUNITS(TW) flat_units<TW>(wbase, L, tws, ncw, trips, s0, c0, i0, n_mine, iter, k0, k1);
+    FlatUnitsArgs ua;
+    ua.woff = wid * NC * L.bytes; ua.slice = L.bytes; ua.off_ctab = L.ctab; ua.off_thr = L.thr; ua.off_misc = L.misc; ua.off_dl = L.dl;
+    ua.trow = trow; ua.trips = trips; ua.iter = iter; ua.k0 = k0; ua.k1 = k1;
+#define MISO_FUNITS(TW) flat_units<TW>(ua, s0, c0, i0, n_mine);
     if constexpr (KC == 4) { if (tww <= 2) MISO_FUNITS(2) else MISO_FUNITS(3) }
     else if constexpr (KC == 8) { if (tww <= 4) MISO_FUNITS(4) else if (tww == 5) MISO_FUNITS(5) else if (tww == 6) MISO_FUNITS(6) else MISO_FUNITS(7) }
     else if constexpr (KC == 12) { if (tww <= 9) MISO_FUNITS(9) else MISO_FUNITS(11) }
@@ -450,14 +554,14 @@ __global__ __launch_bounds__(256, 2) void sampler_flat(const KernelArgs a) {
     // D_k (+ the reads of classes that end at or before k) -> picks per isoform
     FLAT_BEGIN(ks, inv_k)
       const int *mi = FI(s, L.misc);
-      const int K = mi[MI_K];
-      if (j < K) {
-        const uint32_t *A = FU(s, L.ctab) + CLS_WORDS * (cs + 1);
-        const int *dl = FI(s, L.dl);
-        const int hi = (j < K - 1) ? dl[j] + static_cast<int>(A[j]) : mi[MI_NDRAW];
-        const int lo = (j > 0) ? dl[j - 1] + static_cast<int>(A[j - 1]) : 0;
-        FI(s, L.cnt)[j] = hi - lo;
-      }
+      const int K = mi[MI_K], nd = mi[MI_NDRAW];
+      const uint32_t *A = FU(s, L.ctab) + CLS_WORDS * (cs + 1);
+      const int *dl = FI(s, L.dl);
+      const int jm = max(j - 1, 0);
+      const int dj = dl[j], dm = dl[jm], aj = static_cast<int>(A[j]), am = static_cast<int>(A[jm]);
+      const int hi = (j < K - 1) ? dj + aj : nd;
+      const int lo = (j > 0) ? dm + am : 0;
+      if (on && j < K) FI(s, L.cnt)[j] = hi - lo;
     FLAT_END
     fsync();
     FPROF_T(t2);
@@ -470,29 +574,40 @@ __global__ __launch_bounds__(256, 2) void sampler_flat(const KernelArgs a) {
     const double maxv = leader_max(0);
     fsync();
     FLAT_BEGIN(ks, inv_k)
-      const int *mi = FI(s, L.misc);
-      if (j < mi[MI_K]) FD(s, L.tc)[j] = miso_det_exp(FD(s, L.tb)[mi[MI_PAR] * ks + j] - FD(s, L.sx)[SX_MAXV]);
+      const int K = FI(s, L.misc)[MI_K];
+      const double r = miso_det_exp(FD(s, L.tb)[j] - FD(s, L.sx)[SX_MAXV]);
+      if (on && j < K) FD(s, L.tc)[j] = r;
     FLAT_END
     fsync();
     if (leader) {
-      const double *tc = FD(ls, L.tc);
       double acc = 0.0;
-      for (int k = 0; k < Kw; k++) if (k < lK) acc = acc + tc[k];
+      CHUNKS_BEGIN
+        LOADC(tc, FD(ls, L.tc))
+        EACH(k) acc = (k < lK) ? acc + tc[i_] : acc;
+      CHUNKS_END
       l_lse = miso_det_log(acc) + maxv;
     }
     fsync();
   }
   gibbs(MISO_ITER_INIT);
 
+  const bool tracing = __any(LE_.off_trace != NO_TRACE);   // all events of a batch trace or none
   for (int m = 0; m < a.M; m++) {
-    if (leader)
-      for (int k = 0; k < Kw; k++)
-        if (k < lK) hash = (hash ^ static_cast<uint32_t>(count_of(ls, k))) * 0x100000001B3ull;
-    if (LE_.off_trace != NO_TRACE) {   // all events of a batch trace or none
+    // this iteration's view of the counts: the leader's registers (hash, both joint scores)
+    int cn[KC];
+    if (leader) {
+      const int *bas = FI(ls, L.bas), *cnt = FI(ls, L.cnt);
+#pragma unroll
+      for (int k = 0; k < KC; k++) cn[k] = (k < Kw) ? bas[k] + cnt[k] : 0;
+#pragma unroll
+      for (int k = 0; k < KC; k++)
+        if (k < Kw) hash = (k < lK) ? (hash ^ static_cast<uint32_t>(cn[k])) * 0x100000001B3ull : hash;
+    }
+    if (tracing) {
       FLAT_BEGIN(ks, inv_k)
         const int *mi = FI(s, L.misc);
         const int K = mi[MI_K];
-        if (j < K) {
+        if (on && j < K) {
           const uint64_t to = (static_cast<uint64_t>(static_cast<uint32_t>(mi[MI_TRACE_HI])) << 32) | static_cast<uint32_t>(mi[MI_TRACE_LO]);
           reinterpret_cast<int32_t *>(a.out_pool + to)[(static_cast<size_t>(m) * a.C + mi[MI_CHAIN]) * K + j] = count_of(s, j);
         }
@@ -500,72 +615,111 @@ __global__ __launch_bounds__(256, 2) void sampler_flat(const KernelArgs a) {
     }
     FPROF_T(m0);
     double jacN = 0.0;
-    propose_and_logs(static_cast<uint32_t>(m), 0, 1, jacN);                          // passes 1, 2, 3
-    const double maxN = leader_max(1);
+    propose_and_logs(static_cast<uint32_t>(m), 0, PR, jacN);                          // passes 1, 2, 3
+    const double maxN = leader_max(PR);
     // Gaussian parts of the two proposal densities (miso.c:110-117): proposal -> current uses the
     // current psi's log ratios against alpha', current -> proposal the proposal's against alpha
     FLAT_BEGIN(tws, inv_k1)
-      const int *mi = FI(s, L.misc);
-      if (j < mi[MI_K] - 1) {
-        const int cu = mi[MI_PAR] * ks, pr = (mi[MI_PAR] ^ 1) * ks;
-        const double sigma = FD(s, L.sx)[SX_SIGMA];
-        const double t1 = FD(s, L.lr)[cu + j] - FD(s, L.alpha)[pr + j];
-        FD(s, L.tc)[j] = (-0.5) * t1 * t1 / sigma;
-        const double t2 = FD(s, L.lr)[pr + j] - FD(s, L.alpha)[cu + j];
-        FD(s, L.u2)[j] = (-0.5) * t2 * t2 / sigma;
-      }
+      const int K = FI(s, L.misc)[MI_K];
+      const double sigma = FD(s, L.sx)[SX_SIGMA];
+      const double t1 = FD(s, L.lr)[j] - FD(s, L.alpha)[PR + j];
+      const double t2 = FD(s, L.lr)[PR + j] - FD(s, L.alpha)[j];
+      const double g1 = (-0.5) * t1 * t1 / sigma, g2 = (-0.5) * t2 * t2 / sigma;
+      if (on && j < K - 1) { FD(s, L.tc)[j] = g1; FD(s, L.u2)[j] = g2; }
     FLAT_END
     fsync();
     if (leader) {
-      const double *tc = FD(ls, L.tc), *u2 = FD(ls, L.u2);
       double e1 = 0.0, e2 = 0.0;
-      for (int k = 0; k < Kw - 1; k++) if (k < lK - 1) { e1 = e1 + tc[k]; e2 = e2 + u2[k]; }
+      CHUNKS_BEGIN
+        LOADC(tc, FD(ls, L.tc))
+        LOADC(u2, FD(ls, L.u2))
+        EACH(k) { e1 = (k < lK - 1) ? e1 + tc[i_] : e1; e2 = (k < lK - 1) ? e2 + u2[i_] : e2; }
+      CHUNKS_END
       FD(ls, L.sx)[SX_E1] = e1; FD(ls, L.sx)[SX_E2] = e2;
     }
     fsync();
     FLAT_BEGIN(ks + 2, inv_k2)                                                         // pass 4: exp
-      const int *mi = FI(s, L.misc);
-      const int K = mi[MI_K];
+      const int K = FI(s, L.misc)[MI_K];
       const bool iso = j < ks;
-      if (iso ? (j < K) : true) {
-        const double *sx = FD(s, L.sx);
-        const double arg = iso ? FD(s, L.tb)[(mi[MI_PAR] ^ 1) * ks + j] - sx[SX_MAXV] : (j == ks ? sx[SX_E1] : sx[SX_E2]);
-        const double r = miso_det_exp(arg);
+      const double *sx = FD(s, L.sx);
+      const double tbv = FD(s, L.tb)[PR + (iso ? j : 0)], mx = sx[SX_MAXV], e1 = sx[SX_E1], e2 = sx[SX_E2];
+      const double r = miso_det_exp(iso ? tbv - mx : (j == ks ? e1 : e2));
+      if (on && (iso ? (j < K) : true)) {
         if (iso) FD(s, L.tc)[j] = r; else FD(s, L.sx)[SX_X1 + (j - ks)] = r;
       }
     FLAT_END
     fsync();
     if (leader) {
-      const double *tc = FD(ls, L.tc);
       double *sx = FD(ls, L.sx);
+      const double x1 = sx[SX_X1], x2 = sx[SX_X2];
       double sumtc = 0.0;
-      for (int k = 0; k < Kw; k++) if (k < lK) sumtc = sumtc + tc[k];
-      sx[SX_LA0] = sumtc; sx[SX_LA1] = l_covar * l_jac * sx[SX_X1]; sx[SX_LA2] = l_covar * jacN * sx[SX_X2];
+      CHUNKS_BEGIN
+        LOADC(tc, FD(ls, L.tc))
+        EACH(k) sumtc = (k < lK) ? sumtc + tc[i_] : sumtc;
+      CHUNKS_END
+      sx[SX_LA0] = sumtc; sx[SX_LA1] = l_covar * l_jac * x1; sx[SX_LA2] = l_covar * jacN * x2;
     }
     fsync();
     for (int base_ = 0; base_ < ncw * 3; base_ += 64) {                                // pass 5: log
       const int idx_ = base_ + lane;
-      if (idx_ < ncw * 3) {
-        const int s = idx_ / 3, j = idx_ - 3 * s;
-        FD(s, L.sx)[SX_LR0 + j] = miso_det_log(FD(s, L.sx)[SX_LA0 + j]);
-      }
+      const bool on = idx_ < ncw * 3;
+      const int s = on ? idx_ / 3 : 0, j = on ? idx_ - 3 * s : 0;
+      const double r = miso_det_log(FD(s, L.sx)[SX_LA0 + j]);
+      if (on) FD(s, L.sx)[SX_LR0 + j] = r;
     }
     fsync();
     double cJS = 0.0;
     if (leader) {
+      // joint log score of the proposal and of the current point for the current counts (miso.c:243-307)
       const double *sx = FD(ls, L.sx);
       const double lseN = sx[SX_LR0] + maxN, ptoCS = sx[SX_LR1], ctoPS = sx[SX_LR2];
-      const double pp = joint_sums(1, lseN);
-      const double pc = joint_sums(0, l_lse);
-      const double acceptP = (m > 0) ? miso_det_exp(pp + ptoCS - (pc + ctoPS)) : miso_det_exp(pp - pc);  // pass 6
-      const bool acc = (acceptP >= 1) || (miso_u01(static_cast<uint32_t>(FI(ls, L.misc)[MI_ACCW])) < acceptP);
-      cJS = pc;
-      if (acc) {   // the proposal and its cached logs become the current state
-        FI(ls, L.misc)[MI_PAR] ^= 1;
-        l_jac = jacN; l_lse = lseN;
-        cJS = pp; accepted++;
+      const uint32_t accw = static_cast<uint32_t>(FI(ls, L.misc)[MI_ACCW]);
+      // both scores in one walk: rp / ap = the two count-weighted sums, pq = the Dirichlet part; [0] proposal, [1] current
+      double rp[2] = {0.0, 0.0}, ap[2] = {0.0, 0.0}, pq[2] = {0.0, 0.0};
+      const double lse2[2] = {lseN, l_lse};
+      CHUNKS_BEGIN
+        LOADC(isc, FD(ls, L.isc))
+        LOADC(hm1, FD(ls, L.hm1))
+        LOADC(lpN, FD(ls, L.lp) + PR)
+        LOADC(tbN, FD(ls, L.tb) + PR)
+        LOADC(lpC, FD(ls, L.lp))
+        LOADC(tbC, FD(ls, L.tb))
+        EACH(k) {
+          const bool in = k < lK, nz = in && cn[k] != 0;
+          const double ck = static_cast<double>(cn[k]);
+          rp[0] = nz ? rp[0] + ck * isc[i_] : rp[0];
+          ap[0] = nz ? ap[0] + ck * (tbN[i_] - lse2[0]) : ap[0];
+          pq[0] = in ? pq[0] + hm1[i_] * lpN[i_] : pq[0];
+          rp[1] = nz ? rp[1] + ck * isc[i_] : rp[1];
+          ap[1] = nz ? ap[1] + ck * (tbC[i_] - lse2[1]) : ap[1];
+          pq[1] = in ? pq[1] + hm1[i_] * lpC[i_] : pq[1];
+        }
+      CHUNKS_END
+      double pj[2];
+#pragma unroll
+      for (int which = 0; which < 2; which++) {
+        double psiProb = pq[which];
+        psiProb = psiProb + l_lg_sum;
+        psiProb = psiProb - l_lg_each;
+        pj[which] = rp[which] + ap[which] + psiProb;
       }
+      const double pp = pj[0], pc = pj[1];
+      const double acceptP = (m > 0) ? miso_det_exp(pp + ptoCS - (pc + ctoPS)) : miso_det_exp(pp - pc);  // pass 6
+      const bool acc = (acceptP >= 1) || (miso_u01(accw) < acceptP);
+      cJS = pc;
+      FI(ls, L.misc)[MI_ACC] = acc ? 1 : 0;
+      if (acc) { l_jac = jacN; l_lse = lseN; cJS = pp; accepted++; }
     }
+    fsync();
+    // accepted: the proposal and its cached logs become the current state
+    FLAT_BEGIN(ks, inv_k)
+      const int acc = FI(s, L.misc)[MI_ACC];
+      const double v0 = FD(s, L.psi)[PR + j], v1 = FD(s, L.alpha)[PR + j], v2 = FD(s, L.lp)[PR + j],
+                   v3 = FD(s, L.tb)[PR + j], v4 = FD(s, L.lr)[PR + j];
+      if (on && acc) {
+        FD(s, L.psi)[j] = v0; FD(s, L.alpha)[j] = v1; FD(s, L.lp)[j] = v2; FD(s, L.tb)[j] = v3; FD(s, L.lr)[j] = v4;
+      }
+    FLAT_END
     fsync();
     FPROF_T(m1);
     FPROF_ADD(fp_mh, m0, m1);
@@ -574,10 +728,11 @@ __global__ __launch_bounds__(256, 2) void sampler_flat(const KernelArgs a) {
         FLAT_BEGIN(ks, inv_k)
           const int *mi = FI(s, L.misc);
           const int K = mi[MI_K];
-          if (j < K) {
+          const double v = FD(s, L.psi)[j];
+          if (on && j < K) {
             const uint64_t so = (static_cast<uint64_t>(static_cast<uint32_t>(mi[MI_SAMP_HI])) << 32) | static_cast<uint32_t>(mi[MI_SAMP_LO]);
             const size_t col = static_cast<size_t>(noS) + mi[MI_CHAIN];
-            reinterpret_cast<double *>(a.out_pool + so)[col * K + j] = FD(s, L.psi)[mi[MI_PAR] * ks + j];
+            reinterpret_cast<double *>(a.out_pool + so)[col * K + j] = v;
           }
         FLAT_END
         if (leader) reinterpret_cast<double *>(a.out_pool + LE_.off_loglik)[static_cast<size_t>(noS) + lchain] = cJS;
@@ -592,11 +747,11 @@ __global__ __launch_bounds__(256, 2) void sampler_flat(const KernelArgs a) {
   if (leader)
     for (int k = 0; k < Kw; k++)
       if (k < lK) hash = (hash ^ static_cast<uint32_t>(count_of(ls, k))) * 0x100000001B3ull;
-  if (LE_.off_trace != NO_TRACE) {
+  if (tracing) {
     FLAT_BEGIN(ks, inv_k)
       const int *mi = FI(s, L.misc);
       const int K = mi[MI_K];
-      if (j < K) {
+      if (on && j < K) {
         const uint64_t to = (static_cast<uint64_t>(static_cast<uint32_t>(mi[MI_TRACE_HI])) << 32) | static_cast<uint32_t>(mi[MI_TRACE_LO]);
         reinterpret_cast<int32_t *>(a.out_pool + to)[(static_cast<size_t>(a.M) * a.C + mi[MI_CHAIN]) * K + j] = count_of(s, j);
       }
@@ -622,6 +777,10 @@ __global__ __launch_bounds__(256, 2) void sampler_flat(const KernelArgs a) {
 #undef FU
 #undef FLAT_BEGIN
 #undef FLAT_END
+#undef LOADC
+#undef EACH
+#undef CHUNKS_BEGIN
+#undef CHUNKS_END
 }
 
 }  // namespace miso

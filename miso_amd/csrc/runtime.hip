@@ -531,7 +531,11 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     const int nc_max = std::min<int>(64, static_cast<int>(LDS_MAX / 4) / slice);
     if (nc_max < 1) continue;
     const long chains = static_cast<long>(run.count) * p.noChains;
-    int nc = static_cast<int>(std::min<long>(nc_max, std::max<long>(1, (chains + slots_for(chains) - 1) / slots_for(chains))));
+    // the fewest rounds of resident wavefronts that nc_max allows, then the fewest chains per wavefront
+    // that still makes that many rounds (a 40 000-chain batch at nc_max = 17 would run 1.15 rounds = 2)
+    const long slots = std::max(1, slots_for(chains));
+    const long rounds = std::max<long>(1, (chains + slots * nc_max - 1) / (slots * nc_max));
+    int nc = static_cast<int>(std::min<long>(nc_max, std::max<long>(1, (chains + slots * rounds - 1) / (slots * rounds))));
     if (const char *env = std::getenv("MISO_FLAT_NC")) nc = std::max(1, std::min(nc_max, std::atoi(env)));
     flat_nc[ri] = nc;
   }

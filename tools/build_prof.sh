@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p tools/_build
-F="-DMISO_K2_PROFILE -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -Iinclude -Imiso_amd/csrc -Wno-unused-result"
+F="$EXTRA -DMISO_K2_PROFILE -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -Iinclude -Imiso_amd/csrc -Wno-unused-result"
 for f in runtime kernels kernels_k2 kernels_grp_c4 kernels_grp_c8 kernels_grp_c12 kernels_grp_c16 kernels_grp_c32 kernels_flat_c4 kernels_flat_c8 kernels_flat_c12 kernels_flat_c16 kernels_flat_c32 kernels_summary kernels_match capi; do
   /opt/rocm/bin/hipcc $F -c miso_amd/csrc/$f.hip -o tools/_build/$f.o &
 done
