@@ -36,6 +36,7 @@ struct miso_batch {
   double *d_fp = nullptr;
   int32_t *d_slots = nullptr;     // [k2 events sorted by n_draw desc | all other events]
   int n_k2 = 0, n_gen = 0;
+  int n_k2w = 0;                  // paired-end: the first n_k2w two-isoform slots take sampler_k2's MODE 2
   // the other events, grouped by isoform-count class (sampler_grp<G, PE, KC> holds K in (KC_prev, KC])
   struct GenRun {
     int first = 0, count = 0;     // slice of d_slots (after the n_k2 two-isoform events)

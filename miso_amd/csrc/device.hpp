@@ -34,6 +34,8 @@ struct DevEvent {
   uint32_t explicit_id;// the event's id in the Philox counter when has_id (else first_event_id + index)
   int32_t has_id;
   uint64_t off_sfix;   // PE: int32[K x il] fixed-point scores, MISO_SFIX_BAD = non-finite
+  int32_t pe_delta;    // PE, K = 2: no drawing read touches a non-finite score (sampler_k2 MODE 2)
+  int32_t pad_;
   // byte offsets into the output pool
   uint64_t off_samples; // double[S x K]  (reference layout: K x S column-major)
   uint64_t off_loglik;  // double[S]

@@ -463,6 +463,13 @@ PackedEvent pack_event_masks(const miso_params_t &p, const FragmentDist *fd, int
     else e.draw_frag.insert(e.draw_frag.end(), frags + static_cast<size_t>(i) * K, frags + static_cast<size_t>(i + 1) * K);
     e.n_draw++;
   }
+  if (p.paired && K == 2) {   // sampler_k2 MODE 2: may the read loop skip the "bad score" bookkeeping?
+    e.pe_delta = true;
+    for (int r = 0; r < e.n_draw && e.pe_delta; r++)
+      if (e.sfix_table[e.draw_frag[static_cast<size_t>(r) * 2]] == SFIX_BAD ||
+          e.sfix_table[static_cast<size_t>(il) + e.draw_frag[static_cast<size_t>(r) * 2 + 1]] == SFIX_BAD)
+        e.pe_delta = false;
+  }
   if (p.paired)   // whole quads of reads on the device: pad with incompatible reads
     while ((e.draw_frag.size() / K) % 4) e.draw_frag.insert(e.draw_frag.end(), K, FRAG_NONE);
   if (!p.paired) {

@@ -107,6 +107,7 @@ struct PackedEvent {
   int max_cls_size = 0;                 // ... most isoforms any drawing class is compatible with
   std::vector<uint16_t> draw_frag;      // paired-end: n_draw x K
   std::vector<int32_t> sfix_table;      // paired-end: K x il fixed-point isoscores
+  bool pe_delta = false;                // paired-end, two isoforms: every drawing read's two scores are finite
   std::vector<int32_t> fixed_ass;       // N: -1 / isoform for fixed reads, -2 for drawing reads
   // header material for the caller (miso.c:762, miso_paired.c:386-391)
   std::vector<double> class_templates;  // K x ncls

@@ -196,8 +196,15 @@ __device__ __forceinline__ void vec_eval4(F f, double a0, double a1, double a2, 
 // slots, wavefronts w and w + 4 share a SIMD, and with a.pair_waves the pair takes the p-th heaviest
 // and the p-th lightest group of chains (the slot list is sorted by drawing reads), so every SIMD
 // carries the same total work whatever the spread of the events' sizes.
-template <int G, bool PE, int WPB>
+// MODE: 0 single-end; 1 paired-end, any event; 2 paired-end events none of whose drawing reads touches a
+// non-finite score (most): the read loop without the "bad score" bookkeeping, fragment indices prefetched.
+// (Tried and dropped: per-iteration weight tables w_k[f] = psi_k fp[f] per chain plus a per-read score
+// difference -- 17 % fewer VALU per read, but 3.9 KB of LDS per chain instead of 1.9 KB and 8 B instead of
+// 4 B per read and iteration from L2 / MALL made it 7 % SLOWER: profiles/r02_pe_k2_modes.txt.)
+template <int G, int MODE, int WPB>
 __global__ __launch_bounds__(64 * WPB, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void sampler_k2(const KernelArgs a) {
+  constexpr bool PE = MODE != 0;
+  constexpr bool PEW = MODE == 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_k2[];
   double *lds_fp = reinterpret_cast<double *>(smem_k2);  // PE: fragment-length probabilities
   if (PE) {
@@ -293,6 +300,50 @@ __global__ __launch_bounds__(64 * WPB, 2) __attribute__((amdgpu_waves_per_eu(2, 
   uint64_t pf_mh = 0, pf_thr = 0, pf_loop = 0, pf_red = 0, pf_rec = 0;
 #endif
   auto gibbs = [&](uint32_t iter) {
+    if (PEW) {
+      // MODE 2: no drawing read of the event touches a non-finite score (host.cpp pe_delta), so the loop
+      // carries no "bad" bookkeeping, and the next quad's fragment indices are fetched one trip ahead
+      const uint32_t n0r0 = rng.p1hi ^ iter ^ k0;
+      const int nq = (n_draw + 3) >> 2;
+      const double x0 = cur.x0, x1 = cur.x1;
+      int d0 = 0; int64_t acc = 0;
+      const int q_last = max(nq - 1, 0);
+      uint4 fn = fragq[min(sub, q_last)];
+      for (int j = 0; j < 2 * trips + 1; j++) {
+        const int q = sub + j * G;
+        const uint4 f = fn;
+        fn = fragq[min(q + G, q_last)];
+        const miso_u32x4 u = philox_gibbs<true>(rng, static_cast<uint32_t>(q), n0r0);
+        const int left = (q < nq && lane_used) ? n_draw - 4 * q : 0;   // reads of this quad that exist
+        const uint32_t ff[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const bool valid = left > r;
+          const uint32_t fv = valid ? ff[r] : 0u;                  // reads past the end: a valid address
+          const uint32_t f0 = fv & 0xFFFFu, f1 = fv >> 16;
+          const double c0 = 0.0 + x0 * lds_fp[f0];                 // miso_paired.c:11-22, 64-68
+          const double T = c0 + x1 * lds_fp[f1];
+          const bool p0 = miso_u01(u.v[r]) * T < c0;
+          const int32_t v = lds_tab[p0 ? f0 : a.il + f1];
+          acc += valid ? v : 0;
+          d0 += (valid & p0) ? 1 : 0;
+        }
+      }
+      if (POW2) {
+#pragma unroll
+        for (int off = G >> 1; off >= 1; off >>= 1) { d0 += __shfl_xor(d0, off); acc += __shfl_xor(acc, off); }
+      } else {
+        int tot = 0; int64_t ta = 0;
+#pragma unroll
+        for (int j = 0; j < G; j++) { tot += __shfl(d0, base_lane + j); ta += __shfl(acc, base_lane + j); }
+        d0 = tot; acc = ta;
+      }
+      cnt0 = base0 + d0;
+      cnt1 = base1 + (n_draw - d0);
+      rfix = E.base_sfix + acc;
+      rbad = E.base_bad;
+      return;
+    }
     if (PE) {
       const uint32_t n0r0 = rng.p1hi ^ iter ^ k0;
       const int nq = (n_draw + 3) >> 2;
@@ -515,10 +566,11 @@ __global__ __launch_bounds__(64 * WPB, 2) __attribute__((amdgpu_waves_per_eu(2, 
   }
 }
 
-#define MISO_INSTANTIATE_K2(G)                                         \
-  template __global__ void sampler_k2<G, false, 4>(const KernelArgs); \
-  template __global__ void sampler_k2<G, false, 8>(const KernelArgs); \
-  template __global__ void sampler_k2<G, true, 4>(const KernelArgs);
+#define MISO_INSTANTIATE_K2(G)                                     \
+  template __global__ void sampler_k2<G, 0, 4>(const KernelArgs); \
+  template __global__ void sampler_k2<G, 0, 8>(const KernelArgs); \
+  template __global__ void sampler_k2<G, 1, 4>(const KernelArgs); \
+  template __global__ void sampler_k2<G, 2, 4>(const KernelArgs);
 MISO_INSTANTIATE_K2(1)
 MISO_INSTANTIATE_K2(2)
 MISO_INSTANTIATE_K2(3)

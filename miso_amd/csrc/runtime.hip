@@ -20,7 +20,7 @@
 namespace miso {
 
 template <bool PE> __global__ void sampler_wave(const KernelArgs a);
-template <int G, bool PE, int WPB> __global__ void sampler_k2(const KernelArgs a);
+template <int G, int MODE, int WPB> __global__ void sampler_k2(const KernelArgs a);
 __global__ void compare_kernel(const DevEvent *, const unsigned char *, const DevEvent *, const unsigned char *, int, int,
                                double, const uint64_t *, double *);
 __global__ void match_kernel(const MatchEvent *, const int2 *, const int *, const int *, const int *, const int *,
@@ -265,6 +265,7 @@ void miso_batch::upload(int dev) {
     d.off_cls = in_off; in_off = align_up(in_off + e.dcls_tab.size() * 4, 16);
     d.off_clsmask = in_off; in_off = align_up(in_off + e.dcls_pairs.size() * 2, 16);
     d.off_sfix = in_off; in_off = align_up(in_off + e.sfix_table.size() * 4, 16);
+    d.pe_delta = e.pe_delta ? 1 : 0;
     d.off_samples = out_off; out_off = align_up(out_off + static_cast<uint64_t>(Sn) * e.K * 8, 16);
     d.off_loglik = out_off; out_off = align_up(out_off + static_cast<uint64_t>(Sn) * 8, 16);
     d.off_drawass = out_off; out_off = align_up(out_off + static_cast<uint64_t>(e.n_draw), 16);
@@ -311,8 +312,13 @@ void miso_batch::upload(int dev) {
   // number of drawing reads so the chains sharing a wavefront loop equally long
   std::vector<int32_t> k2, gen;
   for (int i = 0; i < n; i++) ((events[i].K == 2) ? k2 : gen).push_back(i);
-  std::stable_sort(k2.begin(), k2.end(),
-                   [&](int x, int y) { return events[x].n_draw > events[y].n_draw; });
+  // (paired-end: the events sampler_k2's MODE 2 can take come first, MISO_NO_PE_DELTA=1 sends all to MODE 1)
+  const bool use_delta = std::getenv("MISO_NO_PE_DELTA") == nullptr;
+  std::stable_sort(k2.begin(), k2.end(), [&](int x, int y) {
+    const bool dx = use_delta && events[x].pe_delta, dy = use_delta && events[y].pe_delta;
+    return dx != dy ? dx : events[x].n_draw > events[y].n_draw; });
+  n_k2w = 0;
+  for (int i : k2) n_k2w += (use_delta && events[i].pe_delta) ? 1 : 0;
   // the general kernel's wavefronts loop to their largest K and longest draw list: group alike
   std::stable_sort(gen.begin(), gen.end(), [&](int x, int y) {
     return events[x].K != events[y].K ? events[x].K > events[y].K : events[x].n_draw > events[y].n_draw; });
@@ -359,9 +365,14 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   const size_t k2_fp = p.paired ? align_up(fd.prob.size() * 8, 16) : 0;
   const size_t k2_tab = p.paired ? 2 * fd.prob.size() * 4 : 0;   // per chain: int32[2 x il]
   const bool k2_pair = !p.paired && !(std::getenv("MISO_K2_PAIR") && std::atoi(std::getenv("MISO_K2_PAIR")) == 0);
-  auto launch_k2 = [&](KernelArgs ka, int G, hipStream_t st) {
-    const long chains = static_cast<long>(n_k2) * p.noChains;
-    ka.slot_event = d_slots; ka.n_slots = n_k2;
+  // paired-end: the first n_k2w slots go to MODE 2 (no drawing read with a non-finite score), the rest to
+  // MODE 1; single-end: everything is "the rest".  Both keep the event's score table (2 il int32) per chain in LDS.
+  const size_t k2w_tab = k2_tab;
+  auto launch_k2 = [&](KernelArgs ka, int G, hipStream_t st, bool wpart = false) {
+    const int first = wpart ? 0 : n_k2w, count = wpart ? n_k2w : n_k2 - n_k2w;
+    const long chains = static_cast<long>(count) * p.noChains;
+    if (chains <= 0) return;
+    ka.slot_event = d_slots + first; ka.n_slots = count;
     const int cpw = 64 / std::max(G, 1);
     const long waves = (chains + cpw - 1) / cpw;
     // single-end: workgroups of 8 wavefronts = one CU's resident slots; the two wavefronts of a SIMD
@@ -370,12 +381,20 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     const bool pair = k2_pair;
     ka.pair_waves = pair ? 1 : 0;
     const unsigned grid = static_cast<unsigned>(pair ? (waves + 7) / 8 : (waves + 3) / 4);
-    const size_t k2_lds = k2_fp + 4 * static_cast<size_t>(cpw) * k2_tab;
+    const size_t k2_lds = k2_fp + 4 * static_cast<size_t>(cpw) * (wpart ? k2w_tab : k2_tab);
+    if (k2_lds > 160 * 1024) MISO_FAIL(MISO_UNIMPLEMENTED, "Fragment-length distribution too wide for the two-isoform paired-end kernel");
 #define MISO_K2_LAUNCH(GG)                                                                              \
   case GG:                                                                                             \
-    if (p.paired) hipLaunchKernelGGL((sampler_k2<GG, true, 4>), dim3(grid), dim3(256), k2_lds, st, ka); \
-    else if (pair) hipLaunchKernelGGL((sampler_k2<GG, false, 8>), dim3(grid), dim3(512), 0, st, ka);    \
-    else hipLaunchKernelGGL((sampler_k2<GG, false, 4>), dim3(grid), dim3(256), 0, st, ka);              \
+    if (p.paired && wpart) {                                                                           \
+      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sampler_k2<GG, 2, 4>),                \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(k2_lds))); \
+      hipLaunchKernelGGL((sampler_k2<GG, 2, 4>), dim3(grid), dim3(256), k2_lds, st, ka);               \
+    } else if (p.paired) {                                                                             \
+      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sampler_k2<GG, 1, 4>),                \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(k2_lds))); \
+      hipLaunchKernelGGL((sampler_k2<GG, 1, 4>), dim3(grid), dim3(256), k2_lds, st, ka);               \
+    } else if (pair) hipLaunchKernelGGL((sampler_k2<GG, 0, 8>), dim3(grid), dim3(512), 0, st, ka);     \
+    else hipLaunchKernelGGL((sampler_k2<GG, 0, 4>), dim3(grid), dim3(256), 0, st, ka);                 \
     break;
     switch (G) {
       MISO_K2_LAUNCH(1) MISO_K2_LAUNCH(2) MISO_K2_LAUNCH(3) MISO_K2_LAUNCH(4) MISO_K2_LAUNCH(5)
@@ -489,15 +508,15 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   // a whole-gene batch -- a few thousand chains -- would be spread thin over 32 lanes per chain and
   // still leave the GPU half empty).
   const long total_chains = static_cast<long>(n) * p.noChains;
-  const size_t n_kernels = (n_k2 > 0 ? 1 : 0) + gen_runs.size();
+  const size_t n_kernels = (n_k2 - n_k2w > 0 ? 1 : 0) + (n_k2w > 0 ? 1 : 0) + gen_runs.size();
   auto slots_for = [&](long chains) {
     if (n_kernels <= 1 || total_chains <= 0) return wave_slots;
     return std::max(1, static_cast<int>(static_cast<double>(wave_slots) * chains / total_chains));
   };
   const bool tune_runs = tune && n_kernels <= 1;   // trial launches would time a kernel alone
-  int k2_G = 0;
-  if (n_k2 > 0) {
-    const long chains = static_cast<long>(n_k2) * p.noChains;
+  int k2_G = 0, k2w_G = 0;
+  if (n_k2 - n_k2w > 0) {
+    const long chains = static_cast<long>(n_k2 - n_k2w) * p.noChains;
     const int maxq = (events[k2_first_event()].n_draw + 3) / 4;
     const int max_cpw = p.paired ? std::max<int>(1, static_cast<int>((60 * 1024 - k2_fp) / (4 * k2_tab))) : 64;
     if (const char *env = std::getenv("MISO_LANES_PER_CHAIN")) k2_G = std::atoi(env);
@@ -518,6 +537,14 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
         tuned_k2_G = k2_G;
       }
     }
+  }
+  if (n_k2w > 0) {   // MODE 2: two workgroups per CU may share the LDS (80 KB each)
+    const long chains = static_cast<long>(n_k2w) * p.noChains;
+    const int maxq = (events[k2_first_event()].n_draw + 3) / 4;
+    const int max_cpw = std::max<int>(1, static_cast<int>((LDS_MAX - k2_fp) / (4 * k2w_tab)));
+    if (const char *env = std::getenv("MISO_LANES_PER_CHAIN")) k2w_G = std::atoi(env);
+    else k2w_G = choose_lanes_per_chain(chains, maxq, slots_for(chains), max_cpw);
+    while (k2w_G < 64 && static_cast<size_t>(64 / k2w_G) > static_cast<size_t>(max_cpw)) k2w_G *= 2;   // a forced choice never exceeds the LDS
   }
   // single-end runs whose events all have a class table go to sampler_flat (kernels_flat.inl): NC chains
   // per wavefront, as many as fit the wavefront's share of the LDS (two workgroups of four wavefronts
@@ -613,16 +640,20 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     ks.chains = chains; ks.words = words;
     kernel_stats.push_back(ks);
   };
-  auto k2_name = [&](int G) {
-    return "sampler_k2<" + std::to_string(G) + (p.paired ? ", true, 4>" : (k2_pair ? ", false, 8>" : ", false, 4>"));
+  auto k2_name = [&](int G, bool wpart) {
+    return "sampler_k2<" + std::to_string(G) + (p.paired ? (wpart ? ", 2, 4>" : ", 1, 4>") : (k2_pair ? ", 0, 8>" : ", 0, 4>"));
   };
-  if (n_k2 > 0) {
+  const bool use_delta = std::getenv("MISO_NO_PE_DELTA") == nullptr;
+  for (int part = 0; part < 2; part++) {
+    const bool wpart = part == 0;
+    const int count = wpart ? n_k2w : n_k2 - n_k2w, k2G = wpart ? k2w_G : k2_G;
+    if (count <= 0) continue;
     // slot order = events by drawing reads, descending, each with its noChains chains
     std::vector<int> nd;
-    for (const PackedEvent &e : events) if (e.K == 2) nd.push_back(e.n_draw);
+    for (const PackedEvent &e : events) if (e.K == 2 && (use_delta && e.pe_delta) == wpart) nd.push_back(e.n_draw);
     std::sort(nd.begin(), nd.end(), [](int x, int y) { return x > y; });
-    const int C = p.noChains, cpw = 64 / k2_G;
-    const long chains = static_cast<long>(n_k2) * C;
+    const int C = p.noChains, cpw = 64 / k2G;
+    const long chains = static_cast<long>(count) * C;
     double trips = 0, words = 0;
     long waves = 0;
     for (long s0 = 0; s0 < chains; s0 += cpw, waves++) {
@@ -632,10 +663,10 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
         mx = std::max(mx, n >> 2); any_rem |= n & 3;
         words += n;
       }
-      const int t = (mx + 2 * k2_G - 1) / (2 * k2_G);       // trips of two Philox blocks per lane
+      const int t = (mx + 2 * k2G - 1) / (2 * k2G);         // trips of two Philox blocks per lane
       trips += p.paired ? 2 * t + 1 : 2 * t + (any_rem ? 1 : 0);   // counted in blocks per lane
     }
-    add_stat(k2_name(k2_G), static_cast<double>(waves), trips, static_cast<double>(chains), words);
+    add_stat(k2_name(k2G, wpart), static_cast<double>(waves), trips, static_cast<double>(chains), words);
   }
   for (size_t ri = 0; ri < gen_runs.size(); ri++) {
     const GenRun &run = gen_runs[ri];
@@ -685,9 +716,14 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     HIP_OK(hipStreamWaitEvent(aux_streams[i - 1], ev0, 0));
     return aux_streams[i - 1];
   };
-  if (n_k2 > 0) {
+  if (n_k2w > 0) {
+    lanes_per_chain = k2w_G;
+    last_kernels = k2_name(k2w_G, true);
+    launch_k2(a, k2w_G, stream_for_next(), true);
+  }
+  if (n_k2 - n_k2w > 0) {
     lanes_per_chain = k2_G;
-    last_kernels = k2_name(k2_G);
+    last_kernels += std::string(last_kernels.empty() ? "" : ",") + k2_name(k2_G, false);
     launch_k2(a, k2_G, stream_for_next());
   }
   for (size_t ri = 0; ri < gen_runs.size(); ri++) {
