@@ -16,9 +16,9 @@ chains x iterations x reads), every event keeps its global id, there is no colle
 path; ranks only meet in a gloo barrier and a max-over-ranks of the elapsed time.
 
 The line carries, besides the contract's keys:
-  roofline            the dominant kernel against the bound that applies to it: VALU issue
-                      (instructions per loop trip priced from the disassembly, tools/isa_count.py and
-                      tools/issue_bench.hip -> profiles/valu_model.json), with the RNG fraction, the
+  roofline            the dominant kernel against the bound that applies to it: VALU issue (VALU
+                      instructions per chain-iteration and their issue cycles from the committed
+                      rocprofv3 passes, profiles/valu_model.json), with the RNG fraction, the
                       measured HBM fraction and SURVEY 8(d)'s algorithmic-bytes figure beside it
   cpu_baseline        the real reference C core (oracle/_ref) on the host cores, bounded sample
   delta_psi_vs_reference   |delta psi| with a pass/fail: 4 x MCSE from 16 reference seeds per event
@@ -29,7 +29,6 @@ import argparse
 import json
 import math
 import os
-import re
 import socket
 import subprocess
 import sys
@@ -218,44 +217,39 @@ def load_json(name):
         return {}
 
 
-def kernel_family(name):
-    """'sampler_k2f<3, false>' -> 'sampler_k2f<*, false>' (lanes per chain do not change the loop bodies'
-    instruction mix beyond what the model's per-G entries hold)."""
-    return re.sub(r"<\s*\d+\s*,", "<*,", name)
-
-
 def roofline_for(batch, kernel_ms, workload_key):
-    """VALU-issue roofline of the launch's dominant kernel + the other fractions (see module doc)."""
+    """The launch against the bound that applies to it.  The sampler kernels are VALU-issue bound (no HBM
+    stream, no MFMA): `achieved` = VALU issue cycles the launch needs per second of kernel time, priced
+    from the committed rocprofv3 passes of this very workload (profiles/valu_model.json: VALU
+    wave-instructions per chain-iteration x the issue cycles one takes, tools/prof_summary.py) and scaled
+    to this run's chains, iterations and measured kernel time; `peak` = 1024 SIMDs x 2.4 GHz.  Beside it:
+    the share of the Philox ceiling, the measured HBM fraction and SURVEY 8(d)'s algorithmic-bytes figure."""
     stats = batch.launch_stats()
     name = batch.last_kernels()
-    model = load_json("valu_model.json")
     t = kernel_ms * 1e-3
     alg_bytes = batch.algorithmic_bytes()
     out = {"bound": "valu", "unit": "Gcycle/s", "peak": round(VALU_PEAK_GCYC, 1),
            "kernel": name, "kernel_ms": round(kernel_ms, 3)}
-    cyc, parts = 0.0, []
-    for k in stats["kernels"]:
-        m = model.get(k["name"]) or model.get(kernel_family(k["name"]))
-        if m is None:
-            cyc = None
-            break
-        c = k["iterations"] * (k["waves"] * m["iter_cycles"] + k["trips"] * m["trip_cycles"])
-        parts.append({"kernel": k["name"], "waves": k["waves"], "trips_per_iteration": k["trips"],
-                      "iter_cycles": m["iter_cycles"], "trip_cycles": m["trip_cycles"],
-                      "issue_cycles": c})
-        cyc += c
-    if cyc is not None:
+    m = load_json("valu_model.json").get(workload_key)
+    chain_iters = sum(k["chains"] * k["iterations"] for k in stats["kernels"])
+    if m is not None:
+        cyc = m["valu_per_chain_iteration"] * chain_iters * m["issue_cycles_per_valu"]
         out["achieved"] = round(cyc / t / 1e9, 1)
         out["frac"] = round(cyc / t / 1e9 / VALU_PEAK_GCYC, 4)
-        out["model"] = parts
-        out["model_source"] = "profiles/valu_model.json (tools/isa_count.py x tools/issue_bench.hip)"
+        out["model"] = {"valu_per_chain_iteration": round(m["valu_per_chain_iteration"], 1),
+                        "issue_cycles_per_valu": round(m["issue_cycles_per_valu"], 3),
+                        "chain_iterations": chain_iters, "source": "profiles/valu_model.json <- " + m["source"],
+                        "profiled_valu_busy": {k: (None if v["valu_busy"] is None else round(v["valu_busy"], 4))
+                                               for k, v in m["kernels"].items()},
+                        "profiled_wave_slot_occupancy": {k: (None if v["wave_slot_occupancy"] is None else round(v["wave_slot_occupancy"], 4))
+                                                         for k, v in m["kernels"].items()}}
     else:
         out["achieved"] = None
         out["frac"] = None
-        out["model"] = "no instruction model committed for %s" % name
+        out["model"] = "no rocprofv3 PMC pass committed for this workload (%s)" % workload_key
     rng_ceiling = load_json("rng_ceiling.json").get("philox4x32_10_outputs_per_s", 2885e9)
     out["rng_frac"] = round(stats["uniforms"] / t / rng_ceiling, 4)
-    out["rng_note"] = "Philox4x32-10 words generated / s over the chip's measured ceiling (tools/rng_bench.hip)"
+    out["rng_note"] = "Philox4x32-10 words consumed / s over the chip's measured ceiling (tools/rng_bench.hip)"
     traffic = load_json("traffic.json").get(workload_key)
     out["traffic"] = None if traffic is None else traffic["hbm_bytes_per_launch"]
     out["hbm_measured_frac"] = None if traffic is None else round(

@@ -364,7 +364,11 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   // ---- two-isoform events: sampler_k2<G> ----
   const size_t k2_fp = p.paired ? align_up(fd.prob.size() * 8, 16) : 0;
   const size_t k2_tab = p.paired ? 2 * fd.prob.size() * 4 : 0;   // per chain: int32[2 x il]
-  const bool k2_pair = !p.paired && !(std::getenv("MISO_K2_PAIR") && std::atoi(std::getenv("MISO_K2_PAIR")) == 0);
+  // (only when the batch's wavefronts fit the resident slots once: with several rounds the hardware hands
+  // out workgroups as slots free up, heaviest first, and the 4-wavefront workgroups balance better --
+  // MISO defaults, 6 chains x 40 000 events at one lane per chain: 374 ms paired, 351 ms unpaired)
+  const bool k2_pair_env = !p.paired && !(std::getenv("MISO_K2_PAIR") && std::atoi(std::getenv("MISO_K2_PAIR")) == 0);
+  bool k2_pair = k2_pair_env;
   // paired-end: the first n_k2w slots go to MODE 2 (no drawing read with a non-finite score), the rest to
   // MODE 1; single-end: everything is "the rest".  Both keep the event's score table (2 il int32) per chain in LDS.
   const size_t k2w_tab = k2_tab;
@@ -631,6 +635,10 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     grp_G[ri] = G;
   }
 
+  if (k2_pair && k2_G > 0) {
+    const long waves = (static_cast<long>(n_k2 - n_k2w) * p.noChains + 64 / k2_G - 1) / (64 / k2_G);
+    k2_pair = waves <= wave_slots || std::getenv("MISO_K2_PAIR") != nullptr;
+  }
   // ---- what goes on the device, kernel by kernel (miso_batch_launch_stats) ----
   kernel_stats.clear();
   auto add_stat = [&](const std::string &name, double waves, double trips, double chains, double words) {

@@ -300,12 +300,15 @@ class MISOSampler:
     # -- two RNA-seq samples over the same events + Bayes factors (compare_miso) ----------------
     def run_comparison_batch(self, num_iters, events1, events2, comparison_file, num_chains=6,
                              burn_in=1000, lag=2, seed=None, seed2=None, first_event_id=0,
-                             confidence_level=0.95, smoothing=0.3, verbose=False):
+                             confidence_level=0.95, smoothing=0.3, verbose=False, event_ids=None):
         """events1[i] and events2[i] = (reads, gene, output_file[, prior_params]) describe the SAME
         event in sample 1 and sample 2.  Samples both on the GPU, writes every .miso file and the
         `.miso_bf` table of hypothesis_test.py:186-345 with Bayes factors computed on the device.
         Events skipped in either sample (no reads, one isoform, output exists) are left out, as
-        compare_miso leaves out events missing from one directory (hypothesis_test.py:262-264)."""
+        compare_miso leaves out events missing from one directory (hypothesis_test.py:262-264).
+        event_ids[i] (optional): event i's id in the random-number counter -- its number in the caller's
+        full event list -- so that skipped events and chunking change nobody's random stream; default
+        first_event_id + position among the events that are run."""
         if len(events1) != len(events2):
             raise ValueError("the two samples must list the same events")
         keep = []
@@ -322,6 +325,8 @@ class MISOSampler:
                       first_event_id=first_event_id, summary=confidence_level, smoothing=smoothing)
             if self.paired_end:
                 kw["paired"] = (float(self.mean_frag_len), float(self.frag_variance), 4.0)
+            if event_ids is not None:
+                kw["event_ids"] = tuple(int(event_ids[p[0]]) for p in keep)
             r1, r2, cmp = pysplicing.MISOCompareBatch(
                 tuple(p[2][:4] for p in keep), tuple(p[3][:4] for p in keep),
                 int(self.params["read_len"]), int(num_iters), int(burn_in), int(lag),

@@ -434,17 +434,17 @@ static PyObject *batch_common(PyObject *events, miso_params_t *p, PyObject *seed
 static PyObject *py_miso_compare_batch(PyObject *self, PyObject *args, PyObject *kw) {
   static char *kwlist[] = {"events1", "events2", "readLength", "noIterations", "noBurnIn", "noLag",
                            "overhang", "no_chains", "start", "stop", "seed", "seed2", "first_event_id",
-                           "summary", "smoothing", "paired", NULL};
-  PyObject *ev1, *ev2, *seedobj = NULL, *seed2obj = NULL, *summaryobj = NULL, *pairedobj = NULL;
+                           "summary", "smoothing", "paired", "event_ids", NULL};
+  PyObject *ev1, *ev2, *seedobj = NULL, *seed2obj = NULL, *summaryobj = NULL, *pairedobj = NULL, *idsobj = NULL;
   PyObject *r1 = NULL, *r2 = NULL, *cmp = NULL, *out = NULL;
   int readLength, iters = 5000, burn = 500, lag = 10, overhang = 1, chains = 6;
   int start = MISO_START_AUTO, stop = MISO_STOP_FIXEDNO, rc;
   unsigned int first = 0; double smoothing = 0.3, conf = 0.95, mean = 0, var = 0, devs = 0;
   unsigned long long seed, seed2; Py_ssize_t i, n;
   miso_params_t p; miso_batch_t *b1 = NULL, *b2 = NULL;
-  if (!PyArg_ParseTupleAndKeywords(args, kw, "OOi|iiiiiii$OOIOdO", kwlist, &ev1, &ev2, &readLength, &iters,
+  if (!PyArg_ParseTupleAndKeywords(args, kw, "OOi|iiiiiii$OOIOdOO", kwlist, &ev1, &ev2, &readLength, &iters,
                                    &burn, &lag, &overhang, &chains, &start, &stop, &seedobj, &seed2obj,
-                                   &first, &summaryobj, &smoothing, &pairedobj)) return NULL;
+                                   &first, &summaryobj, &smoothing, &pairedobj, &idsobj)) return NULL;
   if (seedobj && seedobj != Py_None) { seed = PyLong_AsUnsignedLongLongMask(seedobj); if (PyErr_Occurred()) return NULL; }
   else if (default_seed(&seed)) return NULL;
   /* the two samples must not share random numbers: identical draws would correlate the chains */
@@ -461,6 +461,20 @@ static PyObject *py_miso_compare_batch(PyObject *self, PyObject *args, PyObject 
   if (PyTuple_Size(ev2) != n) { PyErr_SetString(PyExc_ValueError, "the two samples must list the same events"); return NULL; }
   if (!(b1 = fill_batch(ev1, &p))) goto done;
   if (!(b2 = fill_batch(ev2, &p))) goto done;
+  /* event_ids: every event's id in the Philox counter (its number in the caller's full event list), so
+     that events dropped by the caller's skip rules, the chunking and the number of GPUs change nobody's
+     random stream -- as miso_batch_set_event_id does for MISOBatch's callers */
+  if (idsobj && idsobj != Py_None) {
+    if (!PyTuple_Check(idsobj) || PyTuple_Size(idsobj) != n) {
+      PyErr_SetString(PyExc_ValueError, "event_ids must be a tuple with one id per event"); goto done;
+    }
+    for (i = 0; i < n; i++) {
+      unsigned long id = PyLong_AsUnsignedLongMask(PyTuple_GET_ITEM(idsobj, i));
+      if (PyErr_Occurred()) goto done;
+      if ((rc = miso_batch_set_event_id(b1, (int) i, (uint32_t) id)) ||
+          (rc = miso_batch_set_event_id(b2, (int) i, (uint32_t) id))) { raise_miso(rc); goto done; }
+    }
+  }
   if (n > 0 && (run_batch(b1, seed, first) || run_batch(b2, seed2, first))) goto done;
   if (!(r1 = results_list(b1, n, conf)) || !(r2 = results_list(b2, n, conf))) goto done;
   if (n > 0 && (rc = miso_batch_compare(b1, b2, smoothing))) { raise_miso(rc); goto done; }

@@ -241,7 +241,8 @@ def compare_gene_psi(gene_entries, bam1_filename, bam2_filename, output_dir1, ou
         sampler.run_comparison_batch(p["num_iters"], [a[:3] for a, _ in chunk],
                                      [b[:3] for _, b in chunk], part, num_chains=p["num_chains"],
                                      burn_in=p["burn_in"], lag=p["lag"], seed=seed,
-                                     first_event_id=first_event_id + lo, verbose=verbose)
+                                     first_event_id=first_event_id + lo, verbose=verbose,
+                                     event_ids=[first_event_id + a[4] for a, _ in chunk])
     merge_tables(parts, comparison_file)
     return len(pairs)
 

@@ -1,0 +1,56 @@
+"""CPU: `python bench.py --gpus 2` starts two ranks itself (one fresh process per GPU through
+torch.distributed.run, gloo control plane), splits the global event list into contiguous cost-balanced
+shards and prints ONE line with n_gpus == 2.  `--stub` keeps every GPU call out (host packing only):
+what is checked is the launcher, the sharding, the barrier / max-over-ranks and the line's shape --
+the reference's dispatcher likewise starts its own workers (misopy/miso.py:165-187, 205-214) over
+count-based chunks (cluster_utils.py:23-32)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_starts_its_own_ranks_and_shards_by_cost():
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub", "--events", "37",
+           "--reads", "60", "--iters", "20", "--burn", "5", "--steps", "2", "--warmup", "0"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout                      # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["stub"] is True and d["scaling"] == "weak"
+    assert d["metric"].startswith("AS events/sec") and d["unit"] == "events/s"
+    shards = d["config"]["shards"]
+    assert [s[0] for s in shards] == [0, 1]
+    assert shards[0][1] == 0 and shards[0][2] == shards[1][1] and shards[1][2] == 2 * 37   # contiguous cover
+    assert abs((shards[0][2] - shards[0][1]) - 37) <= 1                                    # equal costs: equal split
+    assert d["roofline"]["bound"] == "valu" and d["cpu_baseline"] is None
+
+
+def test_cost_balanced_shards():
+    sys.path.insert(0, ROOT)
+    from miso_amd import workload
+    rng = np.random.default_rng(5)
+    costs = rng.integers(20, 100000, size=5000).astype(float)      # real events: tens to 10^5 reads
+    for world in (2, 3, 8):
+        bounds = [workload.shard_bounds_by_cost(costs, world, r) for r in range(world)]
+        assert bounds[0][0] == 0 and bounds[-1][1] == len(costs)
+        assert all(bounds[r][1] == bounds[r + 1][0] for r in range(world - 1))
+        loads = np.array([costs[lo:hi].sum() for lo, hi in bounds])
+        assert loads.max() <= costs.sum() / world + costs.max()     # within one event of the ideal
+        by_count = np.array([costs[lo:hi].sum() for lo, hi in
+                             (workload.shard_bounds(len(costs), world, r) for r in range(world))])
+        assert loads.max() <= by_count.max() + 1e-9                 # never worse than the count split
+    assert workload.shard_bounds_by_cost([], 4, 2) == (0, 0)
+    assert [workload.shard_bounds_by_cost([5.0], 3, r) for r in range(3)] in (
+        [(0, 0), (0, 0), (0, 1)], [(0, 0), (0, 1), (1, 1)], [(0, 1), (1, 1), (1, 1)])
+    # mixed isoform counts weigh in: K = 20 genes cost more than K = 3 genes
+    c = workload.event_costs(0, 1000, (3, 20), 1000, 7500, 1)
+    assert c.min() == 3 * 7500 * 1000 and c.max() == 20 * 7500 * 1000

@@ -247,3 +247,62 @@ def test_results_do_not_depend_on_the_number_of_worker_processes(tmp_path):
         outs[nproc] = {f: open(os.path.join(out, "chr1", f), "rb").read() for f in sorted(os.listdir(os.path.join(out, "chr1")))}
     assert sorted(outs[1]) == ["gene%d.miso" % e for e in (0, 1, 3, 4, 6)]      # 15-read genes skipped
     assert outs[1] == outs[3]
+
+
+def _seven_genes(tmp_path, tag, small=(2, 5), n_reads=300, shift=0):
+    """GFF3 + SAM of 7 synthetic genes (2-4 isoforms); the genes in `small` get 15 reads (below
+    min_event_reads = 20: the skip rules drop them)."""
+    from miso_amd import workload
+    gff, sam = tmp_path / ("g%s.gff" % tag), tmp_path / ("r%s.sam" % tag)
+    lines, recs = ["##gff-version 3"], []
+    for e in range(7):
+        off = 10000 + e * 6000
+        exons, isoforms, pos, cig = workload.event_reads(e + shift, 2 + (e % 3), 15 if e in small else n_reads)
+        ex = [(s + off, t + off) for s, t in workload.event_gene(e, 2 + (e % 3))[0]]
+        gid = "gene%d" % e
+        lines.append("chr1\tx\tgene\t%d\t%d\t.\t+\t.\tID=%s" % (ex[0][0], ex[-1][1], gid))
+        for m, iso in enumerate(isoforms):
+            tid = "%s.t%d" % (gid, m)
+            lines.append("chr1\tx\tmRNA\t%d\t%d\t.\t+\t.\tID=%s;Parent=%s" % (ex[iso[0]][0], ex[iso[-1]][1], tid, gid))
+            lines += ["chr1\tx\texon\t%d\t%d\t.\t+\t.\tID=%s.e%d;Parent=%s" % (ex[x][0], ex[x][1], tid, x, tid) for x in iso]
+        recs += ["r%d_%d\t0\tchr1\t%d\t255\t%s\t*\t0\t0\t%s\t%s" % (e, i, pos[i] + off, cig[i].decode(), "A" * 36, "I" * 36)
+                 for i in range(len(pos))]
+    gff.write_text("\n".join(lines) + "\n")
+    sam.write_text("@SQ\tSN:chr1\tLN:100000\n" + "\n".join(recs) + "\n")
+    return gff, sam
+
+
+def test_compare_results_do_not_depend_on_the_number_of_worker_processes(tmp_path):
+    """`miso --run ... --compare BAM2` with -p 1 and -p 3 over 7 genes, one skipped in sample 1 and another
+    in sample 2: both samples' .miso files and the .miso_bf table are byte-identical whatever the split,
+    and sample 1's files equal those of a plain `miso --run` of the same alignments -- every gene keeps
+    its number in the full gene list as its id in the random-number counter (the compare
+    path numbered the genes by their position among the kept pairs)."""
+    gff, sam1 = _seven_genes(tmp_path, "1", small=(2,))
+    _, sam2 = _seven_genes(tmp_path, "2", small=(5,), n_reads=280)
+    settings = tmp_path / "s.txt"
+    settings.write_text("[data]\nmin_event_reads = 20\n[sampler]\nburn_in = 100\nlag = 5\nnum_iters = 600\nnum_chains = 2\n")
+    idx = str(tmp_path / "idx")
+    assert run(["-m", "miso_amd.index_gff", "--index", str(gff), idx]).returncode == 0
+    outs = {}
+    for nproc in (1, 3):
+        out = str(tmp_path / ("cmp%d" % nproc))
+        r = run(["-m", "miso_amd.miso", "--run", idx, str(sam1), "--compare", str(sam2), "--labels", "a", "b",
+                 "--output-dir", out, "--read-len", "36", "--settings-filename", str(settings), "-p", str(nproc),
+                 "--seed", "77"])
+        assert r.returncode == 0, r.stdout
+        files = {}
+        for lab in ("a", "b"):
+            d = os.path.join(out, lab, "chr1")
+            files.update({lab + "/" + f: open(os.path.join(d, f), "rb").read() for f in sorted(os.listdir(d))})
+        files["bf"] = open(os.path.join(out, "a_vs_b", "bayes-factors", "a_vs_b.miso_bf"), "rb").read()
+        outs[nproc] = files
+    kept = [e for e in range(7) if e not in (2, 5)]
+    assert sorted(k for k in outs[1] if k.startswith("a/")) == ["a/gene%d.miso" % e for e in kept]
+    assert outs[1] == outs[3]
+    plain = str(tmp_path / "plain")
+    r = run(["-m", "miso_amd.miso", "--run", idx, str(sam1), "--output-dir", plain, "--read-len", "36",
+             "--settings-filename", str(settings), "-p", "2", "--seed", "77"])
+    assert r.returncode == 0, r.stdout
+    for e in kept:
+        assert open(os.path.join(plain, "chr1", "gene%d.miso" % e), "rb").read() == outs[1]["a/gene%d.miso" % e], e

@@ -73,6 +73,56 @@ def test_full_size_layout_and_shard_independence(orc):
     assert abs(err.mean()) < 0.01 and np.sqrt((err ** 2).mean()) < 0.06, (err.mean(), err.std())
 
 
+@pytest.mark.parametrize("K,paired,E", [(2, True, 4096), (10, True, 2048), (10, False, 6144), (5, False, 8192)])
+def test_full_size_spot_checks_of_the_other_kernels(orc, K, paired, E):
+    """1000 reads (pairs) x 7500 iterations, the production kernels at production shapes (paired-end
+    K = 2: sampler_k2 MODE 2; paired-end K = 10: sampler_grp; single-end K = 5 / 10: sampler_flat with
+    several chains per wavefront): three events of each batch against the oracle's counter mode -- the
+    hash of every iteration's assignment counts, all psi samples, all log scores, the final assignment.
+    A wrap-around or drift that needs thousands of iterations to show would show here."""
+    kw = dict(K=K, n_reads=1000, iters=7500, burn=2500, lag=1, chains=1, paired=paired)
+    b = workload.build_batch(0, E, device_match=True, **kw)
+    b.run(seed=42, first_event_id=0)
+    for e in (0, E // 2 + 1, E - 1):
+        exons, isoforms, pos, cig = workload.event_reads(e, K, 1000, paired=paired)
+        g = orc.gene(flat(exons), isoforms)
+        if paired:
+            cpu = orc.miso_paired(g, pos, cig, 36, 250.0, 900.0, iters=7500, burn=2500, lag=1, chains=1,
+                                  mode=OrcLib.COUNTER, seed=42, event_id=e, trace=True)
+        else:
+            cpu = orc.miso(g, pos, cig, 36, iters=7500, burn=2500, lag=1, chains=1, mode=OrcLib.COUNTER,
+                           seed=42, event_id=e, trace=True)
+        assert cpu.rc == 0
+        r = b.result(e)
+        assert np.array_equal(r.counts_hash, cpu.trace["counts_hash"]), (K, paired, e, b.last_kernels())
+        assert np.array_equal(r.samples, cpu.samples) and np.array_equal(r.loglik, cpu.loglik, equal_nan=True)
+        assert np.array_equal(r.assignment, cpu.assignment)
+        assert r.rundata.noAccepted == cpu.accepted
+
+
+def test_mixed_paired_end_batch_concurrent_equals_serial():
+    """BASELINE configs[3] proxy: 2048 genes of 3-20 isoforms, paired-end, full iterations: the five
+    isoform-count classes' kernels running concurrently (one stream each) give exactly the results of
+    the same kernels run one after the other."""
+    kw = dict(K=(3, 20), n_reads=1000, iters=7500, burn=2500, lag=1, chains=1, paired=True)
+    b = workload.build_batch(0, 2048, device_match=True, **kw)
+    old = os.environ.pop("MISO_SERIAL_KERNELS", None)
+    try:
+        b.run(seed=42, first_event_id=0)
+        with np.errstate(over="ignore"):
+            d0, m0 = _digest(b, 2048)
+        assert len(b.last_kernels().split("sampler_")) > 3        # several kernels in one launch
+        os.environ["MISO_SERIAL_KERNELS"] = "1"
+        b.run(seed=42, first_event_id=0)
+        with np.errstate(over="ignore"):
+            d1, m1 = _digest(b, 2048)
+    finally:
+        os.environ.pop("MISO_SERIAL_KERNELS", None)
+        if old is not None:
+            os.environ["MISO_SERIAL_KERNELS"] = old
+    assert d0 == d1 and np.array_equal(m0, m1)
+
+
 def test_empty_and_degenerate_events():
     """No reads, no compatible reads, one read, reads all of one class, 20 isoforms."""
     G = miso_amd.Gene([(1, 100), (201, 300), (401, 500)], [[0, 1, 2], [0, 2]])

@@ -44,6 +44,73 @@ def main(prof_dir, out):
     open(out, "w").write(txt)
     print(txt)
     update_traffic(prof_dir)
+    update_valu_model(prof_dir)
+
+
+def bench_key(bench):
+    c = bench["config"]
+    return "%s|events=%d|K=%s|reads=%d|iters=%d|chains=%d|paired=%d" % (
+        bench["roofline"]["kernel"], c["events_per_gpu"], c["K"], c["reads"], c["iters"], c["chains"],
+        int("paired-end" in c["workload"]))
+
+
+def update_valu_model(prof_dir):
+    """profiles/valu_model.json: what bench.py's VALU roofline is priced with.  Per profiled workload, from
+    the rocprofv3 passes of this directory: VALU wave-instructions per chain-iteration (SQ_INSTS_VALU), the
+    issue cycles they took while issuing (4 x SQ_ACTIVE_INST_VALU quad-cycles / SQ_INSTS_VALU), the share
+    of the SIMDs' cycles that was (4 x SQ_ACTIVE_INST_VALU / (SIMDs x kernel cycles), kernel cycles =
+    GRBM_GUI_ACTIVE / 8 XCDs) and the share of the wave slots that was occupied (SQ_WAVE_CYCLES)."""
+    import json
+    try:
+        bench = json.loads(open(os.path.join(prof_dir, "bench_trace.json")).read().strip().split("\n")[-1])
+        sdb = glob.glob(os.path.join(prof_dir, "pmc_sq", "*.db"))[0]
+        fdb = glob.glob(os.path.join(prof_dir, "pmc_fetch", "*.db"))[0]
+        tdb = glob.glob(os.path.join(prof_dir, "trace", "*.db"))[0]
+    except (OSError, ValueError, IndexError):
+        return
+    def counters(db):
+        _, rows = q(db, "select kernel_name, counter_name, avg(value) from counters_collection where kernel_name like "
+                        "'%sampler_%' group by kernel_name, counter_name")
+        out = {}
+        for k, c, v in rows:
+            out.setdefault(k, {})[c] = v
+        return out
+    sq, fe = counters(sdb), counters(fdb)
+    _, rows = q(tdb, "select name, avg(end-start) from kernels where name like '%sampler_%' group by name")
+    dur = {r[0]: r[1] for r in rows}
+    c = bench["config"]
+    chain_iters = float(c["events_per_gpu"]) * c["chains"] * (c["iters"] + 1)
+    kernels = {}
+    for k, v in sq.items():
+        if "SQ_INSTS_VALU" not in v:
+            continue
+        cycles = fe.get(k, {}).get("GRBM_GUI_ACTIVE", 0.0) / 8.0          # per XCD
+        kernels[k] = {
+            "valu_instructions": v["SQ_INSTS_VALU"], "active_valu_quadcycles": v["SQ_ACTIVE_INST_VALU"],
+            "wave_quadcycles": v.get("SQ_WAVE_CYCLES"), "waves": v.get("SQ_WAVES"),
+            "kernel_ns": dur.get(k), "kernel_cycles": cycles,
+            "issue_cycles_per_valu": 4.0 * v["SQ_ACTIVE_INST_VALU"] / v["SQ_INSTS_VALU"],
+            "valu_busy": (4.0 * v["SQ_ACTIVE_INST_VALU"] / (1024.0 * cycles)) if cycles else None,
+            "wave_slot_occupancy": (4.0 * v["SQ_WAVE_CYCLES"] / (2048.0 * cycles)) if cycles and v.get("SQ_WAVE_CYCLES") else None,
+        }
+    if not kernels:
+        return
+    tot_valu = sum(k["valu_instructions"] for k in kernels.values())
+    tot_act = sum(k["active_valu_quadcycles"] for k in kernels.values())
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "valu_model.json")
+    try:
+        table = json.load(open(path))
+    except (OSError, ValueError):
+        table = {}
+    table[bench_key(bench)] = {
+        "source": os.path.basename(prof_dir.rstrip("/")), "chain_iterations": chain_iters,
+        "valu_per_chain_iteration": tot_valu / chain_iters,
+        "issue_cycles_per_valu": 4.0 * tot_act / tot_valu,
+        "kernels": kernels,
+    }
+    json.dump(table, open(path, "w"), indent=1, sort_keys=True)
+    print("valu model:", bench_key(bench), {k: round(v, 3) if isinstance(v, float) else v
+                                            for k, v in table[bench_key(bench)].items() if k != "kernels"})
 
 
 def update_traffic(prof_dir):
