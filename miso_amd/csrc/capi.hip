@@ -229,6 +229,7 @@ int miso_batch_add_problem(miso_batch_t *b, int noiso, int n_reads, const double
                            const double *hyperp, int *event_index) {
   return guarded([&] {
     need(b, "batch"); need(isolength, "isolength"); need(noexons, "noexons");
+    if (noiso < 0 || n_reads < 0) MISO_FAIL(MISO_EINVAL, "Negative isoform or read count");
     if (n_reads > 0) need(match, "match");
     if (b->p.paired && n_reads > 0) need(fragmentLength, "fragmentLength");
     if (b->uploaded) MISO_FAIL(MISO_EINVAL, "batch already uploaded");
@@ -435,6 +436,10 @@ int miso_batch_add_events_aln(miso_batch_t *b, int n, const miso_gene_t *const *
           err_code[i] = e.code; err_text[i] = e.text;
         } catch (const std::bad_alloc &) {
           err_code[i] = MISO_ENOMEM; err_text[i] = "Error at capi.hip:0: allocation failed, Out of memory";
+        } catch (const std::exception &e) {   // nothing may leave a worker thread (std::terminate)
+          err_code[i] = MISO_EINTERNAL; err_text[i] = std::string("Error at capi.hip:0: ") + e.what() + ", Internal error";
+        } catch (...) {
+          err_code[i] = MISO_EINTERNAL; err_text[i] = "Error at capi.hip:0: unknown exception, Internal error";
         }
       }
     };
@@ -492,6 +497,15 @@ int miso_batch_write_miso_files(const miso_batch_t *b, int n, const int *event_i
         } catch (const Error &err) {
           std::lock_guard<std::mutex> g(mu);
           if (!first_code) { first_code = err.code; first_error = err.text; }
+        } catch (const std::bad_alloc &) {
+          std::lock_guard<std::mutex> g(mu);
+          if (!first_code) { first_code = MISO_ENOMEM; first_error = "Error at capi.hip:0: allocation failed, Out of memory"; }
+        } catch (const std::exception &e) {   // nothing may leave a worker thread (std::terminate)
+          std::lock_guard<std::mutex> g(mu);
+          if (!first_code) { first_code = MISO_EINTERNAL; first_error = std::string("Error at capi.hip:0: ") + e.what() + ", Internal error"; }
+        } catch (...) {
+          std::lock_guard<std::mutex> g(mu);
+          if (!first_code) { first_code = MISO_EINTERNAL; first_error = "Error at capi.hip:0: unknown exception, Internal error"; }
         }
       }
     };

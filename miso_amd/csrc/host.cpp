@@ -354,7 +354,14 @@ PackedEvent pack_event(const miso_params_t &p, const FragmentDist *fd, int K, in
       const size_t j = static_cast<size_t>(i) * K + k;
       if (match[j] != 0) {
         m |= 1u << k;
-        if (p.paired) frags[j] = static_cast<uint16_t>(fraglen[j] - fd->start);
+        if (p.paired) {
+          // the fragment length indexes the fragment-probability and score tables: a caller-made problem
+          // outside [start, start + il) would read out of bounds on the host and on the device
+          const long fl = static_cast<long>(fraglen[j]) - fd->start;
+          if (fl < 0 || fl >= static_cast<long>(fd->prob.size()))
+            MISO_FAIL(MISO_EINVAL, "Fragment length outside the fragment-length distribution");
+          frags[j] = static_cast<uint16_t>(fl);
+        }
       }
       if (!p.paired && match[j] != 0.0 && match[j] != 1.0) binary = false;
     }

@@ -225,7 +225,11 @@ void miso_batch::resolve_pending() {
         events[q.event] = pack_event_masks(p, pe ? &fd : nullptr, K, N, mk, f, nullptr, q.gene.isolen.data(),
                                            q.gene.noexons.data(), q.hyper.empty() ? nullptr : q.hyper.data());
       }
-    } catch (const Error &e) { codes[t] = e.code; errors[t] = e.text; }
+    } catch (const Error &e) { codes[t] = e.code; errors[t] = e.text;
+    } catch (const std::bad_alloc &) { codes[t] = MISO_ENOMEM; errors[t] = "Error at runtime.hip:0: allocation failed, Out of memory";
+    } catch (const std::exception &e) {   // nothing may leave a worker thread (std::terminate)
+      codes[t] = MISO_EINTERNAL; errors[t] = std::string("Error at runtime.hip:0: ") + e.what() + ", Internal error";
+    } catch (...) { codes[t] = MISO_EINTERNAL; errors[t] = "Error at runtime.hip:0: unknown exception, Internal error"; }
   });
   for (int t = 0; t < nthreads; t++) if (codes[t]) throw Error(codes[t], errors[t], Error::Formatted{});
   pending.clear();

@@ -33,9 +33,33 @@ def chunk_list(seq, num):
 
 
 def visible_gpus():
-    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-    import pysplicing
-    return int(pysplicing.deviceCount())
+    """GPUs this run may use, WITHOUT initialising HIP in the dispatcher (it only starts worker
+    processes; a parent that holds a GPU context and forks is the fragile pattern bench.py avoids):
+    HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES if set, else the KFD topology's GPU nodes, else a
+    short-lived child process asks the runtime."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    nodes = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for d in os.listdir(nodes):
+            props = dict(line.split()[:2] for line in open(os.path.join(nodes, d, "properties")) if line.strip())
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+        if n > 0:
+            return n
+    except (OSError, ValueError):
+        pass
+    code = "import sys; sys.path.insert(0, %r); import pysplicing; print(int(pysplicing.deviceCount()))" \
+        % os.path.dirname(os.path.abspath(__file__))
+    try:
+        out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                             text=True, timeout=120)
+        return int(out.stdout.strip().splitlines()[-1])
+    except (OSError, ValueError, IndexError, subprocess.SubprocessError):
+        return 0
 
 
 class GenesDispatcher(object):

@@ -139,3 +139,20 @@ def test_miso_file_number_formatting_equals_python():
                          np.nextafter(ties2, 1e9), np.nextafter(ties2, -1e9),
                          [-0.004, -0.005, 0.005, 1e15, -1e300, np.nan, -np.inf, 199999.995, 200000.0]])
     assert mismatches(ll, 2) == []
+
+
+def test_add_problem_rejects_fragment_lengths_outside_the_distribution():
+    """A caller-made paired-end problem whose fragment length does not index the fragment-length
+    distribution (mean 250, sd 30, 4 sd: 130..370) is an error, not an out-of-bounds table read."""
+    match = np.ones((3, 2))
+    for bad in (5, 100000, -1):
+        b = miso_amd.Batch(36, iters=10, burn=2, lag=1, chains=1, paired=True, mean=250.0, var=900.0)
+        fl = np.full((3, 2), 250, np.int32)
+        fl[1, 0] = bad
+        with pytest.raises(miso_amd.InternalError, match="Fragment length"):
+            b.add_problem(match, [1000, 900], [3, 2], fraglen=fl)
+    b = miso_amd.Batch(36, iters=10, burn=2, lag=1, chains=1, paired=True, mean=250.0, var=900.0)
+    fl = np.full((3, 2), 250, np.int32)
+    fl[1, 0] = -1
+    m2 = match.copy(); m2[1, 0] = 0            # incompatible: its fragment length is not looked at
+    assert b.add_problem(m2, [1000, 900], [3, 2], fraglen=fl) == 0
