@@ -109,7 +109,7 @@ __device__ __forceinline__ bool k2_pred(int64_t u, double p0, double T) {
   return static_cast<double>(static_cast<uint32_t>(u)) * (1.0 / 4294967296.0) * T < p0;
 }
 
-__device__ __forceinline__ uint64_t k2_threshold(double p0, double T) {
+__device__ __forceinline__ uint64_t k2_threshold_exact(double p0, double T) {
   double est = p0 / T * 4294967296.0;
   est = (est > 0.0) ? est : 0.0;  // also catches NaN
   est = (est > 4294967296.0) ? 4294967296.0 : est;
@@ -124,6 +124,22 @@ __device__ __forceinline__ uint64_t k2_threshold(double p0, double T) {
     for (int g = 0; g < 4096 && t < 4294967296ll && k2_pred(t, p0, T); g++) t++;
   }
   t = t < 0 ? 0 : t;
+  return static_cast<uint64_t>(t);
+}
+
+// The same count when T is a normal finite number and the estimate lies in [2, 2^32 - 3] (wave-uniform
+// test; otherwise k2_threshold_exact): the estimate is then within 2^-20 of the boundary (two roundings
+// in p0 / T 2^32, one in the test's product), so none of the exact routine's clamps, range tests or
+// outer tests can fire, and because the test is monotone in u two evaluations decide the count.
+__device__ __forceinline__ uint64_t k2_threshold(double p0, double T) {
+  const double est = p0 / T * 4294967296.0;
+  const bool safe = T >= 1e-280 && T <= 1e280 && est >= 2.0 && est <= 4294967293.0;
+  if (!__all(safe)) return k2_threshold_exact(p0, T);
+  const double t0 = __builtin_floor(est);
+  auto pred = [&](double u) { return u * (1.0 / 4294967296.0) * T < p0; };
+  const bool q0 = pred(t0);
+  const bool q1 = pred(q0 ? t0 + 1.0 : t0 - 1.0);
+  const double t = q0 ? (q1 ? t0 + 2.0 : t0 + 1.0) : (q1 ? t0 : t0 - 1.0);
   return static_cast<uint64_t>(t);
 }
 
@@ -454,11 +470,17 @@ __global__ __launch_bounds__(64 * WPB, 2) __attribute__((amdgpu_waves_per_eu(2, 
     }
   };
 
-  // alpha' = alpha + sd z, psi' = logit_inv(alpha') (miso.c:449-471); also the accept word
-  auto propose = [&](uint32_t iter, double &alphaN, double &x0, double &x1, uint32_t &accept_word) {
+  // the iteration's MH-site draws: the accept word and the proposal's standard normal (random.c:1543-1551).
+  // They depend on (seed, event, chain, iteration) only, not on the chain's state, so the NR lanes of a
+  // chain compute them for NR consecutive iterations at once (lane role r: iteration m0 + r) -- one
+  // Philox block + qnorm per NR iterations per lane instead of one per iteration on every lane.
+  auto mh_draws = [&](uint32_t iter, double &z, uint32_t &accept_word) {
     const miso_u32x4 b = miso_philox4x32_10(0u, iter, c2_mh, event_id, k0, k1);
     accept_word = b.v[0];
-    const double z = miso_det_norm_from_unif(miso_u01(b.v[2]), miso_u01(b.v[3]));
+    z = miso_det_norm_from_unif(miso_u01(b.v[2]), miso_u01(b.v[3]));
+  };
+  // alpha' = alpha + sd z, psi' = logit_inv(alpha') (miso.c:449-471)
+  auto propose = [&](double z, double &alphaN, double &x0, double &x1) {
     alphaN = alpha + c.sd * z;
     const double e = miso_det_exp(alphaN);
     const double sumexp = (0.0 + e) + 1.0;
@@ -468,8 +490,9 @@ __global__ __launch_bounds__(64 * WPB, 2) __attribute__((amdgpu_waves_per_eu(2, 
 
   // ---- initial state (miso.c:362-369 K == 2: alpha = 0; miso.c:834, 841) ----
   {
-    double aN, x0, x1; uint32_t w;
-    propose(MISO_ITER_INIT, aN, x0, x1, w);
+    double aN, x0, x1, z; uint32_t w;
+    mh_draws(MISO_ITER_INIT, z, w);
+    propose(z, aN, x0, x1);
     alpha = aN;
     cur = psi_terms(x0, x1, c.cst0, c.cst1);
   }
@@ -480,6 +503,7 @@ __global__ __launch_bounds__(64 * WPB, 2) __attribute__((amdgpu_waves_per_eu(2, 
   int accepted = 0, lagCounter = 0, noS = 0;
   const bool writer = live && sub == 0;
 
+  double zbuf = 0.0; uint32_t awbuf = 0u;   // this lane's share of the next NR iterations' MH draws
   for (int m = 0; m < a.M; m++) {
     hash = (hash ^ static_cast<uint32_t>(cnt0)) * 0x100000001B3ull;
     hash = (hash ^ static_cast<uint32_t>(cnt1)) * 0x100000001B3ull;
@@ -489,7 +513,18 @@ __global__ __launch_bounds__(64 * WPB, 2) __attribute__((amdgpu_waves_per_eu(2, 
     }
     PROF_T(m0);
     double alphaN, x0, x1; uint32_t accept_word;
-    propose(static_cast<uint32_t>(m), alphaN, x0, x1, accept_word);
+    {
+      double z;
+      if (NR == 1) {
+        mh_draws(static_cast<uint32_t>(m), z, accept_word);
+      } else {
+        const int ph = m % NR;
+        if (ph == 0) mh_draws(static_cast<uint32_t>(m + role), zbuf, awbuf);   // iterations m .. m + NR - 1
+        z = lane_bcast(zbuf, base_lane + ph);
+        accept_word = static_cast<uint32_t>(__shfl(static_cast<int>(awbuf), base_lane + ph));
+      }
+      propose(z, alphaN, x0, x1);
+    }
     PsiTerms nw;
     double ptoCS, ctoPS;
     {
