@@ -45,6 +45,7 @@ struct miso_batch {
     int maxcls = 0;               // most drawing-read classes (single-end)
     bool nocls = false;           // some single-end event has no class table (> MAX_DRAW_CLASSES classes)
     int tuned_G = 0;              // lanes per chain picked by the first launch's trial runs
+    int tuned_flat = -1;          // sampler_flat (1) or sampler_grp (0) by the first launch's trial runs, -1 = not tried
   };
   std::vector<GenRun> gen_runs;
   int tuned_k2_G = 0;             // ditto for the two-isoform kernel

@@ -228,11 +228,13 @@ __device__ __attribute__((noinline)) void flat_units(const FlatUnitsArgs A, int 
 
 }  // namespace
 
-#ifndef MISO_FLAT_MINBLOCKS
-#define MISO_FLAT_MINBLOCKS 2   // workgroups per CU the register budget allows
+// workgroups per CU the register budget allows: three for the narrow classes (168 VGPRs; the scalar
+// step waits on LDS round trips and a third wavefront per SIMD fills the gaps), two otherwise
+#ifndef MISO_FLAT_WGS_SMALL
+#define MISO_FLAT_WGS_SMALL 3
 #endif
 template <int KC>
-__global__ __launch_bounds__(256, MISO_FLAT_MINBLOCKS) void sampler_flat(const KernelArgs a) {
+__global__ __launch_bounds__(256, KC <= 8 ? MISO_FLAT_WGS_SMALL : 2) void sampler_flat(const KernelArgs a) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int NC = a.nc, ks = a.kstride, cs = a.cstride, tws = ks - 1, trow = flat_trow(ks);
   const FlatLayout L = flat_layout(ks, cs);
@@ -428,9 +430,19 @@ __global__ __launch_bounds__(256, MISO_FLAT_MINBLOCKS) void sampler_flat(const K
       const int k = firsthalf ? j : j - ks;
       const double xv = FD(s, L.psi)[DST + k], lt = FD(s, L.sx)[SX_LTHETA], cst = FD(s, L.cst)[k];
       const double r = miso_det_log(firsthalf ? xv : xv / lt);
+      // (iterations) the lane that has the proposal's log ratio also forms the Gaussian parts of the two
+      // proposal densities (miso.c:110-117): proposal -> current uses the current psi's log ratios against
+      // alpha', current -> proposal the proposal's against alpha
+      const double sigma = FD(s, L.sx)[SX_SIGMA];
+      const double t1 = FD(s, L.lr)[k] - FD(s, L.alpha)[PR + k];
+      const double t2 = r - FD(s, L.alpha)[k];
+      const double g1 = (-0.5) * t1 * t1 / sigma, g2 = (-0.5) * t2 * t2 / sigma;
       if (on && (firsthalf ? (k < K) : (k < K - 1))) {
         if (firsthalf) { FD(s, L.lp)[DST + k] = r; FD(s, L.tb)[DST + k] = r + cst; }
-        else FD(s, L.lr)[DST + k] = r;
+        else {
+          FD(s, L.lr)[DST + k] = r;
+          if (DST != 0) { FD(s, L.tc)[k] = g1; FD(s, L.u2)[k] = g2; }
+        }
       }
     FLAT_END
     fsync();
@@ -528,13 +540,14 @@ __global__ __launch_bounds__(256, MISO_FLAT_MINBLOCKS) void sampler_flat(const K
         }
       }
     FLAT_END
-    FLAT_BEGIN(ks, inv_k)
-      if (on) { FI(s, L.dl)[j] = 0; FI(s, L.cnt)[j] = 0; if (j == 0) for (int x = ks; x <= trow; x++) FI(s, L.dl)[x] = 0; }
-    FLAT_END
-    fsync();
+    fsync();   // (dl is zero here: set-up, and the end of every Gibbs step)
     FPROF_T(t1);
     FPROF_ADD(fp_thr, t0, t1);
     if (__any(slow)) {   // a non-final threshold of 2^32 cannot be held in 32 bits: direct path this time
+      FLAT_BEGIN(ks, inv_k)
+        if (on) FI(s, L.cnt)[j] = 0;
+      FLAT_END
+      fsync();
       for (int s = 0; s < ncw; s++) direct_chain(s, iter, true, false);
       fsync();
       return;
@@ -564,6 +577,9 @@ __global__ __launch_bounds__(256, MISO_FLAT_MINBLOCKS) void sampler_flat(const K
       if (on && j < K) FI(s, L.cnt)[j] = hi - lo;
     FLAT_END
     fsync();
+    FLAT_BEGIN(ks, inv_k)   // D_k back to zero for the next step
+      if (on) { FI(s, L.dl)[j] = 0; if (j == 0) for (int x = ks; x <= trow; x++) FI(s, L.dl)[x] = 0; }
+    FLAT_END
     FPROF_T(t2);
     FPROF_ADD(fp_loop, t1, t2);
   };
@@ -617,17 +633,6 @@ __global__ __launch_bounds__(256, MISO_FLAT_MINBLOCKS) void sampler_flat(const K
     double jacN = 0.0;
     propose_and_logs(static_cast<uint32_t>(m), 0, PR, jacN);                          // passes 1, 2, 3
     const double maxN = leader_max(PR);
-    // Gaussian parts of the two proposal densities (miso.c:110-117): proposal -> current uses the
-    // current psi's log ratios against alpha', current -> proposal the proposal's against alpha
-    FLAT_BEGIN(tws, inv_k1)
-      const int K = FI(s, L.misc)[MI_K];
-      const double sigma = FD(s, L.sx)[SX_SIGMA];
-      const double t1 = FD(s, L.lr)[j] - FD(s, L.alpha)[PR + j];
-      const double t2 = FD(s, L.lr)[PR + j] - FD(s, L.alpha)[j];
-      const double g1 = (-0.5) * t1 * t1 / sigma, g2 = (-0.5) * t2 * t2 / sigma;
-      if (on && j < K - 1) { FD(s, L.tc)[j] = g1; FD(s, L.u2)[j] = g2; }
-    FLAT_END
-    fsync();
     if (leader) {
       double e1 = 0.0, e2 = 0.0;
       CHUNKS_BEGIN
@@ -711,30 +716,29 @@ __global__ __launch_bounds__(256, MISO_FLAT_MINBLOCKS) void sampler_flat(const K
       if (acc) { l_jac = jacN; l_lse = lseN; cJS = pp; accepted++; }
     }
     fsync();
-    // accepted: the proposal and its cached logs become the current state
+    // accepted: the proposal and its cached logs become the current state; the same lanes record the
+    // sample when one is due (miso.c:882-893)
+    const bool rec = m >= a.B && lagCounter == a.lag - 1;
     FLAT_BEGIN(ks, inv_k)
-      const int acc = FI(s, L.misc)[MI_ACC];
+      const int *mi = FI(s, L.misc);
+      const int acc = mi[MI_ACC], K = mi[MI_K];
       const double v0 = FD(s, L.psi)[PR + j], v1 = FD(s, L.alpha)[PR + j], v2 = FD(s, L.lp)[PR + j],
                    v3 = FD(s, L.tb)[PR + j], v4 = FD(s, L.lr)[PR + j];
+      const double c0 = FD(s, L.psi)[j];
       if (on && acc) {
         FD(s, L.psi)[j] = v0; FD(s, L.alpha)[j] = v1; FD(s, L.lp)[j] = v2; FD(s, L.tb)[j] = v3; FD(s, L.lr)[j] = v4;
+      }
+      if (rec && on && j < K) {
+        const uint64_t so = (static_cast<uint64_t>(static_cast<uint32_t>(mi[MI_SAMP_HI])) << 32) | static_cast<uint32_t>(mi[MI_SAMP_LO]);
+        const size_t col = static_cast<size_t>(noS) + mi[MI_CHAIN];
+        reinterpret_cast<double *>(a.out_pool + so)[col * K + j] = acc ? v0 : c0;
       }
     FLAT_END
     fsync();
     FPROF_T(m1);
     FPROF_ADD(fp_mh, m0, m1);
-    if (m >= a.B) {  // miso.c:882-893
-      if (lagCounter == a.lag - 1) {
-        FLAT_BEGIN(ks, inv_k)
-          const int *mi = FI(s, L.misc);
-          const int K = mi[MI_K];
-          const double v = FD(s, L.psi)[j];
-          if (on && j < K) {
-            const uint64_t so = (static_cast<uint64_t>(static_cast<uint32_t>(mi[MI_SAMP_HI])) << 32) | static_cast<uint32_t>(mi[MI_SAMP_LO]);
-            const size_t col = static_cast<size_t>(noS) + mi[MI_CHAIN];
-            reinterpret_cast<double *>(a.out_pool + so)[col * K + j] = v;
-          }
-        FLAT_END
+    if (m >= a.B) {
+      if (rec) {
         if (leader) reinterpret_cast<double *>(a.out_pool + LE_.off_loglik)[static_cast<size_t>(noS) + lchain] = cJS;
         noS += a.C;
         lagCounter = 0;

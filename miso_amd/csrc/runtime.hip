@@ -563,12 +563,15 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     const GenRun &run = gen_runs[ri];
     if (p.paired || run.nocls || std::getenv("MISO_NO_FLAT") != nullptr) continue;
     const int slice = flat_layout(run.kmax, std::max(run.maxcls, 1)).bytes;
-    const int nc_max = std::min<int>(64, static_cast<int>(LDS_MAX / 4) / slice);
+    // workgroups per CU: 3 for K <= 4 (kernels_flat.inl's register budget allows it up to K = 8), else 2; MISO_FLAT_WGS overrides
+    const int wgs = std::getenv("MISO_FLAT_WGS") ? std::max(1, std::atoi(std::getenv("MISO_FLAT_WGS"))) : (run.kc <= 4 ? 3 : 2);   // measured: K=3 +2 %, K=4 +4 %; K=5..8 no gain
+    const size_t lds_wave = std::getenv("MISO_LDS_MAX_KB") ? LDS_MAX / 4 : static_cast<size_t>(160 * 1024 / (4 * wgs)) - 64;
+    const int nc_max = std::min<int>(64, static_cast<int>(lds_wave) / slice);
     if (nc_max < 1) continue;
     const long chains = static_cast<long>(run.count) * p.noChains;
     // the fewest rounds of resident wavefronts that nc_max allows, then the fewest chains per wavefront
     // that still makes that many rounds (a 40 000-chain batch at nc_max = 17 would run 1.15 rounds = 2)
-    const long slots = std::max(1, slots_for(chains));
+    const long slots = std::max<long>(1, static_cast<long>(slots_for(chains)) * wgs / 2);
     const long rounds = std::max<long>(1, (chains + slots * nc_max - 1) / (slots * nc_max));
     int nc = static_cast<int>(std::min<long>(nc_max, std::max<long>(1, (chains + slots * rounds - 1) / (slots * rounds))));
     if (const char *env = std::getenv("MISO_FLAT_NC")) nc = std::max(1, std::min(nc_max, std::atoi(env)));
@@ -602,7 +605,13 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   std::vector<GrpShape> grp_sh(gen_runs.size());
   for (size_t ri = 0; ri < gen_runs.size(); ri++) {
     GenRun &run = gen_runs[ri];
-    if (flat_nc[ri] > 0) continue;
+    // sampler_flat or sampler_grp?  Measured on the batch's first launch like the lanes per chain below
+    // (flat wins at every isoform count of profiles/r02_flat_vs_grp_sweep.txt but 5); a small or untuned
+    // batch takes sampler_flat.
+    const bool contest = flat_nc[ri] > 0 && tune_runs && static_cast<long>(run.count) * p.noChains >= 2048 &&
+                         run.tuned_flat < 0 && std::getenv("MISO_FLAT_NC") == nullptr;
+    if (flat_nc[ri] > 0 && run.tuned_flat == 0) flat_nc[ri] = 0;
+    if (flat_nc[ri] > 0 && !contest) continue;
     const GrpShape sh = grp_sh[ri] = grp_shape(run);
     const long chains = static_cast<long>(run.count) * p.noChains;
     int G = 64;
@@ -637,6 +646,13 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     // a forced (or odd) choice never exceeds the LDS budget: fewer chains per wavefront instead
     while (G < 64 && !grp_fits(run, sh, G)) G = (G < 2) ? 2 : ((G & (G - 1)) ? 64 : G * 2);
     grp_G[ri] = G;
+    if (contest) {
+      const int nc = flat_nc[ri];
+      const int win = (G == 64) ? 0 : fastest({0, G}, [&](const KernelArgs &t, int g) {
+        if (g == 0) launch_flat(t, run, nc, stream); else launch_grp(t, run, sh, g, stream); });
+      run.tuned_flat = win == 0 ? 1 : 0;
+      if (win != 0) flat_nc[ri] = 0;
+    }
   }
 
   if (k2_pair && k2_G > 0) {
