@@ -366,7 +366,7 @@ def main():
         a.no_cpu_baseline = True
     k_spec = tuple(a.K_range) if a.K_range else a.K
     cpu = sample_rows = study_rows = None
-    if rank == 0 and not a.no_cpu_baseline and default_shape and not a.stub:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and default_shape and not a.stub:
         cpu, sample_rows, study_rows = cpu_reference(a)  # before anything touches the GPU (fork-safe)
 
     from miso_amd import capi, workload
