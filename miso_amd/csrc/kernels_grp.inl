@@ -46,6 +46,9 @@
 #define GPROF_ADD(acc, t0, t1)
 #endif
 
+#ifndef MISO_PE_MASKED_FROM
+#define MISO_PE_MASKED_FROM 6   // paired-end quad loop: exec-masked form above this many isoforms, branch-free form up to it
+#endif
 #ifndef MISO_GRP_ILP_MAX_TW
 #define MISO_GRP_ILP_MAX_TW 3   // single-end class path: two Philox blocks in flight per lane up to K = 4 (measured: +3% at K=3, a loss from K=5)
 #endif
@@ -368,8 +371,14 @@ __device__ __forceinline__ void pe_quads(const uint16_t *frags, const double *ps
     const miso_u32x4 u = philox_gibbs<true>(rng, static_cast<uint32_t>(q), n0r0);
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      uint32_t fr[KK]; double w[KK]; bool val[KK];
-      double T = 0.0; int nv = 0;
+      // The reference's scan (miso_paired.c:11-22, 64-75) as compares against the running cumulative
+      // weights: c_k = c_(k-1) + w_k with w_k = +0.0 for an incompatible isoform (bit-neutral: every weight
+      // is >= +0), T = c_(KK-1), rnd = u T.  The scan stops at the first compatible k with `rnd < c_k` (two
+      // compatible isoforms) / `!(rnd > c_k)` (more); the tests are monotone in k and an incompatible k
+      // repeats its predecessor's c, so the pick is the NUMBER of isoforms whose test fails, held to
+      // [first compatible, last compatible] (rnd = 0 or NaN before the first one; "ran off the end").
+      uint32_t fr[KK]; double c[KK]; bool val[KK];
+      double T = 0.0; int nv = 0, firstv = KK, lastv = -1;
 #pragma unroll
       for (int k = 0; k < KK; k++) {
         const int idx = j * KK + k;
@@ -377,23 +386,23 @@ __device__ __forceinline__ void pe_quads(const uint16_t *frags, const double *ps
         val[k] = fr[k] != FRAG_NONE;
         const double fpv = lds_fp[val[k] ? fr[k] : 0u];   // unconditional gather, masked below
         const double wk = ps[k] * fpv;
-        w[k] = val[k] ? wk : 0.0;
-        T = T + w[k];
+        T = T + (val[k] ? wk : 0.0);
+        c[k] = T;
         nv += val[k] ? 1 : 0;
+        firstv = (val[k] && firstv == KK) ? k : firstv;
+        lastv = val[k] ? k : lastv;
       }
       const double rnd = miso_u01(u.v[j]) * T;
-      double cum = 0.0; int idx = 0, sel = -1, lastv = -1;
+      const bool two = nv == 2;
+      int sel = 0;
 #pragma unroll
-      for (int k = 0; k < KK; k++) {   // the reference's scan (miso_paired.c:64-75) over the valid isoforms
-        cum = cum + w[k];
+      for (int k = 0; k < KK; k++) {
         // bitwise, not short-circuit: `&&` on f64 compares comes back as branches
-        const bool two = nv == 2, first = idx == 0, lt = rnd < cum, ngt = !(rnd > cum);
-        const bool stop = val[k] & ((two & (lt | !first)) | (!two & ngt));
-        sel = ((sel < 0) & stop) ? k : sel;
-        lastv = val[k] ? k : lastv;
-        idx += val[k] ? 1 : 0;
+        const bool lt = rnd < c[k], gt = rnd > c[k];
+        sel += ((two & !lt) | (!two & gt)) ? 1 : 0;
       }
-      sel = (sel < 0) ? lastv : sel;   // ran off the end: the last valid isoform
+      sel = max(sel, firstv);
+      sel = min(sel, lastv);          // lastv = -1 (no compatible isoform: a padding read): not picked
       uint32_t fsel = 0;
 #pragma unroll
       for (int k = 0; k < KK; k++) { fsel = (sel == k) ? fr[k] : fsel; cl[k] += (sel == k) ? 1 : 0; }
@@ -643,7 +652,7 @@ __global__ __launch_bounds__(256, KC <= 8 ? MISO_GRP_MINBLOCKS : 2) void sampler
       const uint32_t n0r0 = rng.p1hi ^ iter ^ rng.k0;
 #define MISO_PEQ(KK)                                                                                  \
   {                                                                                                   \
-    if constexpr ((KK) > 6) pe_quads_masked<KK, G>(frags, S.psi, lds_fp, sfix, a.il, S.cnt, drawass, write_ass, nqw, n_quads, n_draw, sub, rng, n0r0, acc, bad); \
+    if constexpr ((KK) > MISO_PE_MASKED_FROM) pe_quads_masked<KK, G>(frags, S.psi, lds_fp, sfix, a.il, S.cnt, drawass, write_ass, nqw, n_quads, n_draw, sub, rng, n0r0, acc, bad); \
     else if (__any(write_ass)) pe_quads<KK, G, true>(frags, S.psi, lds_fp, sfix, a.il, S.cnt, drawass, write_ass, nqw, n_quads, n_draw, sub, rng, n0r0, acc, bad); \
     else pe_quads<KK, G, false>(frags, S.psi, lds_fp, sfix, a.il, S.cnt, drawass, write_ass, nqw, n_quads, n_draw, sub, rng, n0r0, acc, bad); \
   }
