@@ -376,6 +376,7 @@ def main():
         # has no exchange step, so no RCCL communicator is created.
         import torch
         import torch.distributed as dist
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # single node: never depend on the hostname resolving
         dist.init_process_group("gloo")
     if not a.stub:
         capi.set_device(local_rank)
