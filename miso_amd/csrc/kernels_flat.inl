@@ -502,6 +502,9 @@ __global__ __launch_bounds__(256, KC <= 8 ? MISO_FLAT_WGS_SMALL : 2) void sample
     FPROF_T(t0);
     // thresholds: one lane per (chain, class)
     bool slow = false;
+#ifdef MISO_FLAT_SKIP_THR
+    if (a.M < 0)
+#endif
     FLAT_BEGIN(cs, inv_cs)
       const int *mi = FI(s, L.misc);
       const int K = mi[MI_K], ncls = mi[MI_NCLS];
@@ -553,6 +556,9 @@ __global__ __launch_bounds__(256, KC <= 8 ? MISO_FLAT_WGS_SMALL : 2) void sample
       return;
     }
     const int tww = Kw - 1;
+#ifdef MISO_FLAT_SKIP_LOOP   // instruction accounting (tools/flat_phase_valu.sh): results are wrong
+    if (a.M >= 0) return;
+#endif
     FlatUnitsArgs ua;
     ua.woff = wid * NC * L.bytes; ua.slice = L.bytes; ua.off_ctab = L.ctab; ua.off_thr = L.thr; ua.off_misc = L.misc; ua.off_dl = L.dl;
     ua.trow = trow; ua.trips = trips; ua.iter = iter; ua.k0 = k0; ua.k1 = k1;
