@@ -34,6 +34,10 @@
 
 #pragma clang fp contract(off)
 
+#ifndef MISO_FLAT_UQ
+#define MISO_FLAT_UQ 2   // Philox blocks (work units) per lane and trip of the read loop (4 measured slower: K=10 39.1k vs 41.1k)
+#endif
+
 #ifdef MISO_K2_PROFILE
 #define FPROF_T(var) const uint64_t var = __builtin_readcyclecounter()
 #define FPROF_ADD(acc, t0, t1) acc += (t1) - (t0)
@@ -172,8 +176,12 @@ __device__ __attribute__((noinline)) void flat_units(const FlatUnitsArgs A, int 
     prefetch(psl, psl + off_ctab + 4 * CLS_WORDS * c0, psl + off_thr + c0 * trow4, 1);
     N_left -= c0;   // classes of the first chain from c0 on
   }
-  // Two units per trip when the class has two left (one otherwise: the second block is then masked out):
-  // the class bookkeeping and the loop control are paid once per trip, and two Philox blocks interleave.
+  // Up to UQ units per trip -- as many as the class and the lane's range still hold (blocks beyond that are
+  // masked out): the class bookkeeping, the edge masks and the loop control are paid once per trip, and the
+  // Philox blocks of a trip interleave.  Measured per block and wavefront at UQ = 2: generator 36 +
+  // compares 8 (K - 1) + ~58 of bookkeeping (profiles/r02_flat_phase_valu.txt); UQ = 4 halves the latter per
+  // block but masks out more blocks at class ends and range ends: measured 3-5 % slower at every K.
+  constexpr int UQ = TW <= 15 ? MISO_FLAT_UQ : 2;   // (the widest rows keep two: registers)
   int rem = n_mine;   // units this lane still owes
   for (;;) {
     if (!__any(rem > 0)) break;
@@ -196,28 +204,27 @@ __device__ __attribute__((noinline)) void flat_units(const FlatUnitsArgs A, int 
       if (left > 0) prefetch(sl, rowp + 4 * CLS_WORDS, thp + trow4, 0);
       else if (next >= 0) { const int psl = next * slice; prefetch(psl, psl + off_ctab, psl + off_thr, 1); }
     }
-    const bool two = active && rem >= 2 && i + 1 < uend;
-    // words of a unit that belong to the class: all four except in the class's first / last unit
-    uint32_t wa = active ? 0xFu : 0u, wb = two ? 0xFu : 0u;
-    wa &= (i == ust) ? hm : 0xFu;
-    wa &= (i == uend - 1) ? (hm >> 4) : 0xFu;
-    wb &= (i + 1 == uend - 1) ? (hm >> 4) : 0xFu;
-    const int na = static_cast<int>(~wa), nb = static_cast<int>(~wb);
-    const miso_u32x4 ua = philox_gibbs<true>(rng, static_cast<uint32_t>(i - qd), n0r0);
-    const miso_u32x4 ub = philox_gibbs<true>(rng, static_cast<uint32_t>(i + 1 - qd), n0r0);
-    // a word outside the class becomes 0xFFFFFFFF: never below a 32-bit threshold
-    const uint32_t a0 = ua.v[0] | static_cast<uint32_t>(__builtin_amdgcn_sbfe(na, 0, 1));
-    const uint32_t a1 = ua.v[1] | static_cast<uint32_t>(__builtin_amdgcn_sbfe(na, 1, 1));
-    const uint32_t a2 = ua.v[2] | static_cast<uint32_t>(__builtin_amdgcn_sbfe(na, 2, 1));
-    const uint32_t a3 = ua.v[3] | static_cast<uint32_t>(__builtin_amdgcn_sbfe(na, 3, 1));
-    const uint32_t b0 = ub.v[0] | static_cast<uint32_t>(__builtin_amdgcn_sbfe(nb, 0, 1));
-    const uint32_t b1 = ub.v[1] | static_cast<uint32_t>(__builtin_amdgcn_sbfe(nb, 1, 1));
-    const uint32_t b2 = ub.v[2] | static_cast<uint32_t>(__builtin_amdgcn_sbfe(nb, 2, 1));
-    const uint32_t b3 = ub.v[3] | static_cast<uint32_t>(__builtin_amdgcn_sbfe(nb, 3, 1));
+    // blocks of this trip: units i .. i + nb - 1 of the current class
+    const int nb = active ? min(min(UQ, rem), uend - i) : 0;
+    uint32_t w[UQ][4];
 #pragma unroll
-    for (int j = 0; j < TW; j++) { count_below(D[j], a0, a1, a2, a3, T[j]); count_below(D[j], b0, b1, b2, b3, T[j]); }
-    const int adv = active ? (two ? 2 : 1) : 0;
-    i += adv; rem -= adv;
+    for (int b = 0; b < UQ; b++) {
+      const miso_u32x4 u = philox_gibbs<true>(rng, static_cast<uint32_t>(i + b - qd), n0r0);
+      // words of a unit that belong to the class: all four except in the class's first / last unit; a word
+      // outside becomes 0xFFFFFFFF (never below a 32-bit threshold)
+      uint32_t wm = (b < nb) ? 0xFu : 0u;
+      if (b == 0) wm &= (i == ust) ? hm : 0xFu;
+      wm &= (i + b == uend - 1) ? (hm >> 4) : 0xFu;
+      const int nm = static_cast<int>(~wm);
+#pragma unroll
+      for (int x = 0; x < 4; x++) w[b][x] = u.v[x] | static_cast<uint32_t>(__builtin_amdgcn_sbfe(nm, x, 1));
+    }
+#pragma unroll
+    for (int j = 0; j < TW; j++) {
+#pragma unroll
+      for (int b = 0; b < UQ; b++) count_below(D[j], w[b][0], w[b][1], w[b][2], w[b][3], T[j]);
+    }
+    i += nb; rem -= nb;
   }
   if (have) {
     int *dl = reinterpret_cast<int *>(wbase + sl + off_dl);
