@@ -62,6 +62,36 @@ def visible_gpus():
         return 0
 
 
+def _forked_worker(argv, log, worker_no=0, n_workers=1):
+    """One worker of `miso --run`, forked from the dispatcher: output to its log file, its share of the
+    host cores (the native stages -- read collection, CIGAR parsing, `.miso` formatting -- size their
+    thread pools by the affinity mask: N workers with all cores each would oversubscribe N-fold), then
+    run_miso.main on this process's own GPU (the dispatcher never touched the GPU runtime)."""
+    fd = os.open(log, os.O_WRONLY | os.O_CREAT | os.O_APPEND, 0o644)
+    if n_workers > 1:
+        try:
+            cores = sorted(os.sched_getaffinity(0))
+            mine = cores[worker_no::n_workers] or cores
+            os.sched_setaffinity(0, mine)
+        except (AttributeError, OSError):
+            pass
+    sys.stdout.flush(); sys.stderr.flush()
+    os.dup2(fd, 1); os.dup2(fd, 2)
+    rc = 1
+    try:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        if root not in sys.path:
+            sys.path.insert(0, root)
+        from . import run_miso
+        rc = run_miso.main(argv)
+    except BaseException:
+        import traceback
+        traceback.print_exc()
+    finally:
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(rc if isinstance(rc, int) else 1)
+
+
 class GenesDispatcher(object):
     """miso.py:69-337, with GPUs for processors."""
 
@@ -112,6 +142,7 @@ class GenesDispatcher(object):
         batches = self.output_batch_files()
         print("Preparing to run %d batches of jobs..." % len(batches))
         procs = []
+        jobs = []
         parts = []
         if self.compare_bam is not None:
             out1, out2 = (os.path.join(self.output_dir, l) for l in self.labels)
@@ -155,18 +186,41 @@ class GenesDispatcher(object):
             log = os.path.join(self.batch_logs_dir, "batch-%d-%s.log"
                                % (batch_num, time.strftime("%m-%d-%y_%H:%M:%S")))
             print("Running batch of %d genes on GPU %d.." % (size, batch_num % self.n_gpus))
+            jobs.append((batch_num, cmd, log))
+        # One decode per node: this process reads the alignment file(s) ONCE through the HIP-free reader
+        # library and forks the workers, which inherit the decoded columns (copy-on-write, nothing copied);
+        # each worker then initialises its own GPU.  The reference re-opens the BAM per event through an
+        # index (run_miso.py:86,100); round 1 decoded the whole file in every worker (`-p 4` on one GPU was
+        # slower than `-p 1`).  MISO_DISPATCH=subprocess: fresh interpreters that decode for themselves.
+        if os.environ.get("MISO_DISPATCH", "fork") == "subprocess" or not jobs:
             env = dict(os.environ)
             root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
             env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
-            procs.append((batch_num, subprocess.Popen(cmd, stdout=open(log, "a"),
-                                                      stderr=subprocess.STDOUT, env=env), log))
+            for batch_num, cmd, log in jobs:
+                procs.append((batch_num, subprocess.Popen(cmd, stdout=open(log, "a"),
+                                                          stderr=subprocess.STDOUT, env=env), log))
+            waits = [(b, p.wait, lambda p=p: p.returncode, log) for b, p, log in procs]
+        else:
+            import multiprocessing
+            from . import sam_utils
+            sam_utils.use_reader_library()
+            for path in (self.bam_filename, self.compare_bam):
+                if path is not None:
+                    full = os.path.abspath(os.path.expanduser(path))
+                    sam_utils._PRELOADED[full] = sam_utils.Samfile(full, "rb")
+            ctx = multiprocessing.get_context("fork")
+            sys.stdout.flush()
+            waits = []
+            for k, (batch_num, cmd, log) in enumerate(jobs):
+                p = ctx.Process(target=_forked_worker, args=(cmd[3:], log, k, len(jobs)))
+                p.start()
+                waits.append((batch_num, p.join, lambda p=p: p.exitcode, log))
         failed = 0
-        for batch_num, p, log in procs:
-            p.wait()
-            if p.returncode != 0:
+        for batch_num, wait, code, log in waits:
+            wait()
+            if code() != 0:
                 failed += 1
-                print("WARNING: batch %d might have failed (exit %d), see %s"
-                      % (batch_num, p.returncode, log))
+                print("WARNING: batch %d might have failed (exit %s), see %s" % (batch_num, code(), log))
         if table is not None:
             from .run_miso import merge_tables
             merge_tables(parts, table)

@@ -39,15 +39,28 @@ class _Columns(C.Structure):
 
 
 _lib = None
+_READER_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmiso_aln.so")
+_reader_only = False
+_PRELOADED = {}   # absolute path -> Samfile decoded by the dispatcher before it forked this worker
+
+
+def use_reader_library():
+    """Load the alignment reader from libmiso_aln.so (the same code without the HIP kernels): for a
+    process that must not initialise the GPU runtime -- `miso --run`'s dispatcher decodes the
+    alignments ONCE and then forks one worker per GPU; the workers inherit the decoded file."""
+    global _reader_only, _lib
+    if _lib is None:
+        _reader_only = True
 
 
 def _native():
     global _lib
     if _lib is None:
-        if not os.path.exists(_LIB_PATH):
+        path = _READER_LIB_PATH if _reader_only else _LIB_PATH
+        if not os.path.exists(path):
             raise ImportError("miso_amd: %s is missing -- build it with "
-                              "`python __graft_entry__.py`" % _LIB_PATH)
-        L = C.CDLL(_LIB_PATH)
+                              "`python __graft_entry__.py`" % path)
+        L = C.CDLL(path)
         L.miso_aln_last_error.restype = C.c_char_p
         L.miso_aln_ref_name.restype = C.c_char_p
         L.miso_aln_ref_name.argtypes = [C.c_void_p, C.c_int]
@@ -206,6 +219,9 @@ class Samfile(object):
 def load_bam_reads(bam_filename, template=None):
     """Open (and decode) an alignment file; `template` is accepted for signature parity only."""
     path = os.path.abspath(os.path.expanduser(bam_filename))
+    if path in _PRELOADED:      # decoded by the dispatcher before this worker was forked
+        print("Using the alignments of %s decoded by the dispatcher" % path)
+        return _PRELOADED[path]
     print("Loading BAM filename from: %s" % path)
     return Samfile(path, "rb", template=template)
 

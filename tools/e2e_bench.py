@@ -23,6 +23,10 @@ def main():
     ap.add_argument("--reads", type=int, default=1000)
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--keep", default=None)
+    ap.add_argument("--runs", default=None,
+                    help="comma list of P:DISPATCH (e.g. 1:fork,4:fork,4:subprocess): run `miso --run -p P` once per "
+                         "entry on the same generated data (DISPATCH = fork: one decode per node; subprocess: "
+                         "every worker decodes for itself)")
     a = ap.parse_args()
     work = a.keep or tempfile.mkdtemp(prefix="miso_e2e_")
     os.makedirs(work, exist_ok=True)
@@ -70,23 +74,25 @@ def main():
     settings = os.path.join(work, "settings.txt")
     open(settings, "w").write("[data]\nfilter_results = True\nmin_event_reads = 20\n[sampler]\n"
                               "burn_in = 500\nlag = 10\nnum_iters = 5000\nnum_chains = 6\n")
-    t0 = time.time()
-    rc = subprocess.call([sys.executable, "-m", "miso_amd.miso", "--run", idx, sam, "--output-dir", out,
-                          "--read-len", "36", "--settings-filename", settings, "-p", str(a.gpus),
-                          "--seed", "1"], env=env, stdout=subprocess.DEVNULL)
-    t_run = time.time() - t0
-    n_files = sum(len([f for f in fs if f.endswith(".miso")]) for _, _, fs in os.walk(out))
-    logs = os.path.join(out, "batch-logs")
-    tail = ""
-    for f in sorted(os.listdir(logs)):
-        lines = open(os.path.join(logs, f)).read().strip().split("\n")
-        tail += "  " + f + ": " + " | ".join(lines[-2:]) + "\n"
-    size = sum(os.path.getsize(os.path.join(d, f)) for d, _, fs in os.walk(out) for f in fs) / 1e6
-    print("events %d x %d reads, MISO defaults (6 chains, 5000 iterations, lag 10), %d GPU(s)"
-          % (a.events, a.reads, a.gpus))
-    print("generate %.1f s | index_gff %.1f s | miso --run %.1f s (rc %d) -> %d .miso files, %.0f MB | "
-          "%.0f events/s end to end" % (t_gen, t_index, t_run, rc, n_files, size, n_files / t_run))
-    print(tail, end="")
+    runs = [(a.gpus, os.environ.get("MISO_DISPATCH", "fork"))] if not a.runs else \
+        [(int(r.split(":")[0]), r.split(":")[1]) for r in a.runs.split(",")]
+    print("events %d x %d reads, MISO defaults (6 chains, 5000 iterations, lag 10); generate %.1f s | index_gff %.1f s"
+          % (a.events, a.reads, t_gen, t_index))
+    for procs, dispatch in runs:
+        shutil.rmtree(out, ignore_errors=True)
+        t0 = time.time()
+        rc = subprocess.call([sys.executable, "-m", "miso_amd.miso", "--run", idx, sam, "--output-dir", out,
+                              "--read-len", "36", "--settings-filename", settings, "-p", str(procs),
+                              "--seed", "1"], env=dict(env, MISO_DISPATCH=dispatch), stdout=subprocess.DEVNULL)
+        t_run = time.time() - t0
+        n_files = sum(len([f for f in fs if f.endswith(".miso")]) for _, _, fs in os.walk(out))
+        size = sum(os.path.getsize(os.path.join(d, f)) for d, _, fs in os.walk(out) for f in fs) / 1e6
+        print("miso --run -p %d (%s): %.1f s (rc %d) -> %d .miso files, %.0f MB | %.0f events/s end to end"
+              % (procs, dispatch, t_run, rc, n_files, size, n_files / t_run), flush=True)
+        logs = os.path.join(out, "batch-logs")
+        for f in sorted(os.listdir(logs))[:2]:
+            lines = open(os.path.join(logs, f)).read().strip().split("\n")
+            print("  " + f + ": " + " | ".join(lines[-2:]))
     if not a.keep:
         shutil.rmtree(work, ignore_errors=True)
 
