@@ -37,6 +37,7 @@ __device__ __forceinline__ void summarize_column(const double *x, int K, int S, 
   __shared__ unsigned wave_tot2[2][4];
   __shared__ uint64_t s_prefix2[2];
   __shared__ int s_rank2[2];
+  __shared__ int s_single2[2];
   const int t = threadIdx.x;
 
   uint64_t keys[CACHED ? SUMMARY_CACHE : 1];
@@ -67,7 +68,7 @@ __device__ __forceinline__ void summarize_column(const double *x, int K, int S, 
   // both order statistics in the same eight passes: two prefixes, two histograms (the keys are
   // tested against both; while the two ranks still share a prefix the two histograms are equal)
   double stat[2];
-  if (t < 2) { s_prefix2[t] = 0; s_rank2[t] = t == 0 ? rank_lo : rank_hi; }
+  if (t < 2) { s_prefix2[t] = 0; s_rank2[t] = t == 0 ? rank_lo : rank_hi; s_single2[t] = 0; }
   __syncthreads();
   for (int byte = 7; byte >= 0; byte--) {
     hist2[0][t] = 0; hist2[1][t] = 0;
@@ -146,10 +147,28 @@ __device__ __forceinline__ void summarize_column(const double *x, int K, int S, 
         if ((r >= exc && r < incl) || (t == 255 && r >= incl)) {
           s_rank2[w] = static_cast<int>(r - exc);
           s_prefix2[w] = (w == 0 ? p0 : p1) | (static_cast<uint64_t>(t) << (8 * byte));
+          s_single2[w] = h[w] == 1u;   // one key left under this prefix: it IS the order statistic
         }
       }
     }
     __syncthreads();
+    // Early exit: 5000 keys rarely share more than their leading four or five bytes, so after that many
+    // passes each wanted rank is alone in its bin; the remaining passes would only spell out its low bytes.
+    // The lone key is fetched from the registers instead (the value returned is still one of the samples).
+    if (CACHED && byte > 0 && s_single2[0] && s_single2[1]) {
+      const uint64_t q0 = s_prefix2[0], q1 = s_prefix2[1];
+      const uint64_t m2 = ~0ull << (8 * byte);
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < SUMMARY_CACHE; j++) {
+        if (t + 256 * j < S) {
+          if ((keys[j] & m2) == q0) s_prefix2[0] = keys[j];
+          if ((keys[j] & m2) == q1) s_prefix2[1] = keys[j];
+        }
+      }
+      __syncthreads();
+      break;
+    }
   }
   stat[0] = key_value(s_prefix2[0]);
   stat[1] = key_value(s_prefix2[1]);
