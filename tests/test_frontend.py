@@ -358,3 +358,43 @@ def test_batched_add_from_alignment_file_equals_single_adds(bam_path):
     with pytest.raises(capi.InternalError, match="two isoforms"):
         many.add_events_aln([g, lone], bam, ["10", "10"], [98377804] * 2, [98486420] * 2, 0, ["+", "+"], 36, 20)
     assert len(many) == len(one)
+
+
+def test_reader_only_library_and_fork_inheritance(bam_path):
+    """`miso --run`'s dispatcher (miso_amd/miso.py): the alignment file decoded ONCE through
+    libmiso_aln.so -- the reader without the HIP kernels, so the parent never initialises the GPU
+    runtime -- and inherited by a forked worker, whose load_bam_reads() returns the parent's object;
+    the worker's fetch / parse_reads give what a fresh decode through the full library gives."""
+    import multiprocessing
+    import subprocess
+    import sys
+    code = r"""
+import os, sys, multiprocessing
+import numpy as np
+sys.path.insert(0, %r)
+from miso_amd import sam_utils
+sam_utils.use_reader_library()
+path = %r
+sam_utils._PRELOADED[path] = sam_utils.Samfile(path, "rb")
+assert sam_utils._native()._name.endswith("libmiso_aln.so")
+assert not any("libamdhip64" in l or "libmiso_amd.so" in l for l in open("/proc/self/maps"))   # no HIP in the parent
+def child(q):
+    f = sam_utils.load_bam_reads(path)
+    assert f is sam_utils._PRELOADED[path]
+    tid = f.references[0]
+    (pos, cig), n = f.parse_reads(tid, 0, 10 ** 9)
+    q.put((f.mapped_plus_unmapped, len(pos), tuple(cig[:3]), n))
+ctx = multiprocessing.get_context("fork")
+q = ctx.Queue()
+p = ctx.Process(target=child, args=(q,)); p.start()
+got = q.get(timeout=60); p.join()
+print(repr(got))
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code % (root, os.path.abspath(bam_path))], capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    fresh = sam_utils.Samfile(os.path.abspath(bam_path), "rb")
+    (pos, cig), n = fresh.parse_reads(fresh.references[0], 0, 10 ** 9)
+    want = (fresh.mapped_plus_unmapped, len(pos), tuple(cig[:3]), n)
+    assert eval(out.stdout.strip().splitlines()[-1]) == want
