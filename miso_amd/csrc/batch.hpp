@@ -44,6 +44,7 @@ struct miso_batch {
     int kmax = 2, maxq = 1;       // most isoforms, most draw quads
     int maxcls = 0;               // most drawing-read classes (single-end)
     bool nocls = false;           // some single-end event has no class table (> MAX_DRAW_CLASSES classes)
+    bool dense = true;            // paired-end: every event has dense quad records (pe_dense)
     int tuned_G = 0;              // lanes per chain picked by the first launch's trial runs
     int tuned_flat = -1;          // sampler_flat (1) or sampler_grp (0) by the first launch's trial runs, -1 = not tried
   };

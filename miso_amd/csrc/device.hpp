@@ -35,7 +35,9 @@ struct DevEvent {
   int32_t has_id;
   uint64_t off_sfix;   // PE: int32[K x il] fixed-point scores, MISO_SFIX_BAD = non-finite
   int32_t pe_delta;    // PE, K = 2: no drawing read touches a non-finite score (sampler_k2 MODE 2)
-  int32_t pad_;
+  int32_t dense_nobad; // PE dense records: no drawing read touches a non-finite score
+  uint64_t off_dense;  // PE, 3 <= K <= PE_DENSE_KMAX: quad records of pe_dense (kernels_grp.inl), NO_DENSE = none
+  uint64_t off_sfixd;  // PE dense: int32[K x (il + 2)] scores in the records' index space
   // byte offsets into the output pool
   uint64_t off_samples; // double[S x K]  (reference layout: K x S column-major)
   uint64_t off_loglik;  // double[S]
@@ -53,6 +55,12 @@ struct MatchEvent {
   int32_t read_off;    // first read (mate) of the event in the batch-wide read arrays
   int32_t out_off;     // first output slot: masks[out_off + r] / frags[(out_off + r) * K + k]
 };
+
+#ifdef __HIPCC__
+#define MISO_DEVHOST_EARLY __host__ __device__
+#else
+#define MISO_DEVHOST_EARLY
+#endif
 
 struct ChainStats {
   uint64_t counts_hash;
@@ -78,10 +86,22 @@ struct KernelArgs {
   uint32_t first_event_id;
   int32_t pair_waves;       // sampler_k2 with 8 wavefronts per workgroup: wavefronts w and w + 4 (one SIMD)
                             // take the heaviest and the lightest remaining chain group (runtime.hip)
+  int32_t pe_dense;         // sampler_grp PE: rows of the replicated fragment-probability table in LDS (0 = plain
+                            // table, the quad loops of pe_quads); every event of the launch has dense records
+  int32_t pe_force_exact;   // tests: every read through pe_dense's exact (cold) scan
   uint64_t seed;
 };
 
 constexpr uint64_t NO_TRACE = ~0ull;
+constexpr uint64_t NO_DENSE = ~0ull;
+// Paired-end dense records (host.cpp pack_event_masks -> kernels_grp.inl pe_dense).  Index space: isoform k,
+// fragment-length index f -> k * il2 + f with il2 = il + 2; two more entries per isoform: PE_ZERO
+// (incompatible: probability -0.0, never picked) and PE_ONE (probability 1, score 0: the padding reads
+// that complete the last quad always pick isoform 0).  One quad = 4 reads x K u16 indices, then 4 u16 of
+// flags (word 0: bit j set when read j has MORE than two compatible isoforms), 2K + 2 dwords.
+constexpr int PE_DENSE_KMAX = 20;
+MISO_DEVHOST_EARLY inline int pe_dense_il2(int il) { return il + 2; }
+MISO_DEVHOST_EARLY inline int pe_dense_quad_u16(int K) { return 4 * K + 4; }
 constexpr int MAX_DRAW_CLASSES = 64;  // single-end: per-class integer thresholds up to this many classes (if the LDS slice fits)
 
 // LDS bytes of one chain's slice in sampler_grp (layout: kernels_grp.hip `carve`): isoform stride ks

@@ -108,6 +108,11 @@ struct PackedEvent {
   std::vector<uint16_t> draw_frag;      // paired-end: n_draw x K
   std::vector<int32_t> sfix_table;      // paired-end: K x il fixed-point isoscores
   bool pe_delta = false;                // paired-end, two isoforms: every drawing read's two scores are finite
+  // paired-end, 3 <= K <= PE_DENSE_KMAX (device.hpp): the drawing reads as quad records for pe_dense
+  // (kernels_grp.inl) -- indices k * (il + 2) + f, flags -- and the scores in that index space
+  std::vector<uint16_t> draw_dense;     // n_quads x (4K + 4); empty = not available
+  std::vector<int32_t> sfix_dense;      // K x (il + 2)
+  bool dense_nobad = false;             // no compatible (read, isoform) of a drawing read has a non-finite score
   std::vector<int32_t> fixed_ass;       // N: -1 / isoform for fixed reads, -2 for drawing reads
   // header material for the caller (miso.c:762, miso_paired.c:386-391)
   std::vector<double> class_templates;  // K x ncls

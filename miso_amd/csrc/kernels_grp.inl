@@ -419,6 +419,128 @@ __device__ __forceinline__ void pe_quads(const uint16_t *frags, const double *ps
   acc_out = acc; bad_out = bad;
 }
 
+
+// ---- paired-end read loop over the DENSE records (device.hpp; host.cpp pack_event_masks) ----
+// One lane = one quad of reads per trip, as pe_quads, but nothing in the loop asks whether an isoform is
+// compatible: the record's index of an incompatible (read, isoform) points at a probability of -0.0.
+//   * cumulative weights c_k = c_(k-1) + psi_k fp[idx_k] start from -0.0: the incompatible isoforms in
+//     front of the first compatible one keep c_k = -0.0, every other c_k has exactly the bits of the
+//     reference's running sum (adding -0.0 changes nothing; -0.0 + w = w, also for w = +0.0);
+//   * the reference's scan (miso_paired.c:11-22, 64-75) stops at the first compatible k with `rnd < c_k`
+//     (two compatible isoforms; the second one unconditionally) or `!(rnd > c_k)` (more).  As SIGNED
+//     INTEGERS the bit patterns order like the doubles (all >= +0) with -0.0 below everything, so
+//     "isoform k is passed over" is  bits(rnd) - adj >= bits(c_k),  adj = 0 / 1 for the two rules (rnd = +0
+//     with adj = 1 gives -1: stops at the first compatible isoform, as `!(0 > c)` does);
+//   * the tests are monotone in k (an incompatible isoform repeats its predecessor's c), so the pick is
+//     the first k whose test holds: its table index by a chain of selects, the per-isoform counts from
+//     the running totals "reads that passed over k" (no per-read counter update, no atomics in the loop);
+//   * all of this is exact whenever rnd < T (then T > 0 and the scan cannot run past the last compatible
+//     isoform).  Anything else -- T = 0, subnormal or non-finite weights -- takes pe_pick_exact, the
+//     reference's scan as written (cold; MISO_PE_FORCE_EXACT=1 sends every read there, tests).
+__device__ __attribute__((noinline)) int pe_pick_exact(const uint16_t *rec, int K, int il2, const double *psi,
+                                                       const double *fp_rep, bool two, uint32_t word) {
+  const int zero = il2 - 2;
+  double T = 0.0; int nv = 0;
+  for (int k = 0; k < K; k++) {
+    const int idx = rec[k];
+    if (idx - k * il2 != zero) { T = T + psi[k] * fp_rep[idx]; nv++; }
+  }
+  const double rnd = miso_u01(word) * T;
+  double cum = 0.0; int seen = 0, sel = -1;
+  for (int k = 0; k < K; k++) {
+    const int idx = rec[k];
+    if (idx - k * il2 == zero) continue;
+    cum = cum + psi[k] * fp_rep[idx];
+    const bool stop = two ? (seen == 0 ? (rnd < cum) : true) : !(rnd > cum);
+    seen++;
+    if (sel < 0 && (stop || seen == nv)) sel = k;
+  }
+  return sel;
+}
+
+template <int KK, int G, bool WRITE, bool BADCHK>
+__device__ __forceinline__ void pe_dense(const uint32_t *fq, const double *psi, const double *fp_rep,
+                                         const int32_t *stab, int il2, int *dl, uint8_t *drawass,
+                                         bool write_ass, int nqw, int n_quads, int n_draw, int sub,
+                                         const GibbsRng &rng, uint32_t n0r0, bool force_exact,
+                                         int64_t &acc_out, int &bad_out) {
+  constexpr int ND = 2 * KK + 2;   // dwords per quad
+  double ps[KK];
+#pragma unroll
+  for (int k = 0; k < KK; k++) ps[k] = psi[k];
+  const int q_last = max(n_quads - 1, 0);
+  uint32_t nxt[ND];
+  {
+    const uint32_t *src = fq + static_cast<size_t>(min(sub, q_last)) * ND;
+#pragma unroll
+    for (int i = 0; i < ND; i++) nxt[i] = src[i];
+  }
+  int64_t acc = 0; int bad = 0;
+  int over[KK - 1];   // reads of this lane that passed over isoform k
+#pragma unroll
+  for (int k = 0; k < KK - 1; k++) over[k] = 0;
+  const unsigned char *fpb = reinterpret_cast<const unsigned char *>(fp_rep);
+  const unsigned char *stb = reinterpret_cast<const unsigned char *>(stab);
+  for (int q0 = 0; q0 < nqw; q0 += G) {
+    const int q = q0 + sub;
+    const bool inq = q < n_quads;
+    uint32_t cur[ND];
+#pragma unroll
+    for (int i = 0; i < ND; i++) cur[i] = nxt[i];
+    {
+      const uint32_t *src = fq + static_cast<size_t>(min(q + G, q_last)) * ND;
+#pragma unroll
+      for (int i = 0; i < ND; i++) nxt[i] = src[i];
+    }
+    const miso_u32x4 u = philox_gibbs<true>(rng, static_cast<uint32_t>(q), n0r0);
+    const uint32_t flags = cur[2 * KK];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      uint32_t off[KK]; int64_t cb[KK];
+      double T = -0.0;
+#pragma unroll
+      for (int k = 0; k < KK; k++) {
+        const int h = j * KK + k;
+        off[k] = (h & 1) ? ((cur[h >> 1] >> 13) & 0x7FFF8u) : ((cur[h >> 1] << 3) & 0x7FFF8u);   // index x 8
+        T = T + ps[k] * *reinterpret_cast<const double *>(fpb + off[k]);
+        cb[k] = __double_as_longlong(T);
+      }
+      const double rnd = miso_u01(u.v[j]) * T;
+      const bool ok = inq & (rnd < T) & !force_exact;
+      const int64_t rb = __double_as_longlong(rnd) - static_cast<int64_t>((flags >> j) & 1u);
+      uint32_t fsel = off[0]; int sel = 0;
+#pragma unroll
+      for (int k = 0; k < KK - 1; k++) {
+        const bool pass = ok & (rb >= cb[k]);
+        over[k] += pass ? 1 : 0;
+        fsel = pass ? off[k + 1] : fsel;
+        if (WRITE) sel += pass ? 1 : 0;
+      }
+      if (__builtin_expect(__any(inq & !ok), 0)) {
+        if (inq & !ok) {   // the reference's scan as written
+          const uint16_t *rec = reinterpret_cast<const uint16_t *>(fq + static_cast<size_t>(q) * ND) + j * KK;
+          sel = pe_pick_exact(rec, KK, il2, psi, fp_rep, ((flags >> j) & 1u) == 0, u.v[j]);
+          fsel = static_cast<uint32_t>(rec[sel]) << 3;
+#pragma unroll
+          for (int k = 0; k < KK - 1; k++) over[k] += (k < sel) ? 1 : 0;
+        }
+      }
+      const int32_t v = *reinterpret_cast<const int32_t *>(stb + (fsel >> 1));
+      if (BADCHK) {
+        const bool isbad = v == SFIX_BAD;
+        bad |= (inq & isbad) ? 1 : 0;
+        acc += (inq & !isbad) ? v : 0;
+      } else {
+        acc += inq ? v : 0;
+      }
+      if (WRITE) { if (write_ass && inq && 4 * q + j < n_draw) drawass[4 * q + j] = static_cast<uint8_t>(sel); }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < KK - 1; k++) if (over[k]) atomicAdd(&dl[k], over[k]);
+  acc_out = acc; bad_out = bad;
+}
+
 }  // namespace
 
 template <int G, bool PE, int KC>
@@ -429,10 +551,18 @@ __global__ __launch_bounds__(256, KC <= 8 ? MISO_GRP_MINBLOCKS : 2) void sampler
   constexpr int KLO = KC == 4 ? 3 : (KC == 8 ? 5 : (KC == 12 ? 9 : (KC == 16 ? 13 : 17)));   // the class holds K in [KLO, KC]
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int CPW = 64 / G;
-  const int fp_bytes = PE ? ((a.il * 8 + 15) & ~15) : 0;
+  const int il2 = pe_dense_il2(a.il);
+  const int fp_bytes = PE ? (((a.pe_dense ? a.pe_dense * il2 : a.il) * 8 + 15) & ~15) : 0;
   double *lds_fp = reinterpret_cast<double *>(smem);
   if (PE) {
-    for (int i = threadIdx.x; i < a.il; i += blockDim.x) lds_fp[i] = a.frag_prob[i];
+    if (a.pe_dense) {   // one row per isoform: [probabilities, -0.0 (PE_ZERO), 1.0 (PE_ONE)]; row 0 serves the plain paths too
+      for (int i = threadIdx.x; i < a.pe_dense * il2; i += blockDim.x) {
+        const int f = i % il2;
+        lds_fp[i] = f < a.il ? a.frag_prob[f] : (f == a.il ? -0.0 : 1.0);
+      }
+    } else {
+      for (int i = threadIdx.x; i < a.il; i += blockDim.x) lds_fp[i] = a.frag_prob[i];
+    }
     __syncthreads();
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -502,11 +632,16 @@ __global__ __launch_bounds__(256, KC <= 8 ? MISO_GRP_MINBLOCKS : 2) void sampler
   const uint32_t *masks = reinterpret_cast<const uint32_t *>(a.in_pool + E.off_draw);
   const uint16_t *frags = reinterpret_cast<const uint16_t *>(a.in_pool + E.off_draw);
   const int32_t *sfix = reinterpret_cast<const int32_t *>(a.in_pool + E.off_sfix);
+  // dense records (pe_dense): every event of the launch has them (runtime.hip)
+  const bool dense = PE && a.pe_dense > 0;
+  const uint32_t *dq = reinterpret_cast<const uint32_t *>(a.in_pool + (dense ? E.off_dense : E.off_draw));
+  const int32_t *sfixd = reinterpret_cast<const int32_t *>(a.in_pool + (dense ? E.off_sfixd : E.off_sfix));
   if (PE && a.tstride > 0) {  // score table into the chain's slice: no per-read gather from L2
-    for (int i = sub; i < K * a.il; i += G) S.stab[i] = sfix[i];
-    sfix = S.stab;
+    if (dense) { for (int i = sub; i < K * il2; i += G) S.stab[i] = sfixd[i]; sfixd = S.stab; }
+    else { for (int i = sub; i < K * a.il; i += G) S.stab[i] = sfix[i]; sfix = S.stab; }
     wave_sync();
   }
+  const bool dense_nobad = dense && __all(E.dense_nobad != 0);
   double *samples = reinterpret_cast<double *>(a.out_pool + E.off_samples);
   double *loglik = reinterpret_cast<double *>(a.out_pool + E.off_loglik);
   uint8_t *drawass = a.out_pool + E.off_drawass;
@@ -527,7 +662,9 @@ __global__ __launch_bounds__(256, KC <= 8 ? MISO_GRP_MINBLOCKS : 2) void sampler
   uint64_t gp_thr = 0, gp_loop = 0, gp_mh = 0;
 #endif
   // ---- Gibbs step for the chain's current psi (in S.psi) ----
-  auto gibbs = [&](uint32_t iter, bool write_ass) {
+  // always_inline: outlined (as it was for the larger classes), the lambda sees the slices through generic
+  // pointers and every LDS access becomes a flat_load / flat_store
+  auto gibbs = [&](uint32_t iter, bool write_ass) __attribute__((always_inline)) {
     GPROF_T(t0);
     for (int k0 = 0; k0 < Kw; k0 += G) { const int k = k0 + sub; if (k < K) S.cnt[k] = 0; }
     wave_sync();
@@ -648,6 +785,35 @@ __global__ __launch_bounds__(256, KC <= 8 ? MISO_GRP_MINBLOCKS : 2) void sampler
       }
     }
     int64_t acc = 0; int bad = 0;
+    if (PE && pe_fast && dense) {
+      const uint32_t n0r0 = rng.p1hi ^ iter ^ rng.k0;
+      for (int k0 = 0; k0 < Kw; k0 += G) { const int k = k0 + sub; if (k < K) S.dl[k] = 0; }
+      wave_sync();
+#define MISO_PED(KK)                                                                                  \
+  {                                                                                                   \
+    if (__any(write_ass)) pe_dense<KK, G, true, true>(dq, S.psi, lds_fp, sfixd, il2, S.dl, drawass, write_ass, nqw, n_quads, n_draw, sub, rng, n0r0, a.pe_force_exact != 0, acc, bad); \
+    else if (dense_nobad) pe_dense<KK, G, false, false>(dq, S.psi, lds_fp, sfixd, il2, S.dl, drawass, write_ass, nqw, n_quads, n_draw, sub, rng, n0r0, a.pe_force_exact != 0, acc, bad); \
+    else pe_dense<KK, G, false, true>(dq, S.psi, lds_fp, sfixd, il2, S.dl, drawass, write_ass, nqw, n_quads, n_draw, sub, rng, n0r0, a.pe_force_exact != 0, acc, bad); \
+  }
+      if constexpr (KC == 4) { if (K == 3) MISO_PED(3) else MISO_PED(4) }
+      else if constexpr (KC == 8) { if (K == 5) MISO_PED(5) else if (K == 6) MISO_PED(6) else if (K == 7) MISO_PED(7) else MISO_PED(8) }
+      else if constexpr (KC == 12) { if (K == 9) MISO_PED(9) else if (K == 10) MISO_PED(10) else if (K == 11) MISO_PED(11) else MISO_PED(12) }
+      else if constexpr (KC == 16) { if (K == 13) MISO_PED(13) else if (K == 14) MISO_PED(14) else if (K == 15) MISO_PED(15) else MISO_PED(16) }
+      else { if (K == 17) MISO_PED(17) else if (K == 18) MISO_PED(18) else if (K == 19) MISO_PED(19) else MISO_PED(20) }
+#undef MISO_PED
+      wave_sync();
+      // reads that passed over k - 1 but not k picked k
+      for (int k0 = 0; k0 < Kw; k0 += G) {
+        const int k = k0 + sub;
+        if (k < K) S.cnt[k] = (k > 0 ? S.dl[k - 1] : n_draw) - (k < K - 1 ? S.dl[k] : 0);
+      }
+      wave_sync();
+#pragma unroll
+      for (int off = G >> 1; off >= 1; off >>= 1) { acc += __shfl_xor(acc, off); bad |= __shfl_xor(bad, off); }
+      rfix = E.base_sfix + acc;
+      rbad = bad | E.base_bad;
+      return;
+    }
     if (PE && pe_fast) {
       const uint32_t n0r0 = rng.p1hi ^ iter ^ rng.k0;
 #define MISO_PEQ(KK)                                                                                  \

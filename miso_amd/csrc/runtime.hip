@@ -270,6 +270,12 @@ void miso_batch::upload(int dev) {
     d.off_clsmask = in_off; in_off = align_up(in_off + e.dcls_pairs.size() * 2, 16);
     d.off_sfix = in_off; in_off = align_up(in_off + e.sfix_table.size() * 4, 16);
     d.pe_delta = e.pe_delta ? 1 : 0;
+    d.dense_nobad = e.dense_nobad ? 1 : 0;
+    d.off_dense = d.off_sfixd = NO_DENSE;
+    if (!e.draw_dense.empty()) {
+      d.off_dense = in_off; in_off = align_up(in_off + e.draw_dense.size() * 2, 16);
+      d.off_sfixd = in_off; in_off = align_up(in_off + e.sfix_dense.size() * 4, 16);
+    }
     d.off_samples = out_off; out_off = align_up(out_off + static_cast<uint64_t>(Sn) * e.K * 8, 16);
     d.off_loglik = out_off; out_off = align_up(out_off + static_cast<uint64_t>(Sn) * 8, 16);
     d.off_drawass = out_off; out_off = align_up(out_off + static_cast<uint64_t>(e.n_draw), 16);
@@ -298,6 +304,10 @@ void miso_batch::upload(int dev) {
     }
     if (!e.sfix_table.empty())
       std::memcpy(h_in.data() + d.off_sfix, e.sfix_table.data(), e.sfix_table.size() * 4);
+    if (!e.draw_dense.empty()) {
+      std::memcpy(h_in.data() + d.off_dense, e.draw_dense.data(), e.draw_dense.size() * 2);
+      std::memcpy(h_in.data() + d.off_sfixd, e.sfix_dense.data(), e.sfix_dense.size() * 4);
+    }
   }
   {
     hipDeviceProp_t prop;
@@ -340,6 +350,7 @@ void miso_batch::upload(int dev) {
     r.maxq = std::max(r.maxq, (e.n_draw + 3) / 4);
     r.maxcls = std::max(r.maxcls, static_cast<int>(e.dcls_mask.size()));
     if (!e.paired && e.n_draw > 0 && e.dcls_mask.empty()) r.nocls = true;
+    if (!e.paired || e.draw_dense.empty()) r.dense = false;
   }
   n_k2 = static_cast<int>(k2.size()); n_gen = static_cast<int>(gen.size());
   k2.insert(k2.end(), gen.begin(), gen.end());
@@ -418,20 +429,34 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   // a workgroup may use half of the CU's 160 KB of LDS (two workgroups per CU)
   // MISO_LDS_MAX_KB (experiments): a larger cap lets one workgroup per CU hold more chains per wavefront
   const size_t LDS_MAX = (std::getenv("MISO_LDS_MAX_KB") ? std::atoi(std::getenv("MISO_LDS_MAX_KB")) : 80) * 1024;
-  const size_t fp_bytes = p.paired ? align_up(fd.prob.size() * 8, 16) : 0;
+  const size_t fp_plain = p.paired ? align_up(fd.prob.size() * 8, 16) : 0;
+  // paired-end dense path (pe_dense): the probability table once per isoform of the launch, so that the
+  // records' indices address probabilities and scores alike; MISO_NO_PE_DENSE=1 (tests, A/B): the quad
+  // loops over the plain records
+  const bool dense_env = std::getenv("MISO_NO_PE_DENSE") == nullptr;
+  const int il2 = pe_dense_il2(static_cast<int>(fd.prob.size()));
+  auto fp_rows = [&](const GenRun &run) {
+    return (p.paired && dense_env && run.dense && static_cast<size_t>(run.kmax) * il2 * 8 <= 48 * 1024) ? run.kmax : 0;
+  };
+  auto fp_bytes_of = [&](const GenRun &run) {
+    const int rows = fp_rows(run);
+    return rows ? align_up(static_cast<size_t>(rows) * il2 * 8, 16) : fp_plain;
+  };
   struct GrpShape { int qs, ts; };
   auto grp_shape = [&](const GenRun &run) {
+    const size_t fp_bytes = fp_bytes_of(run);
     // single-end: per-class thresholds join the slice (class path) when every event has a class
     // table; MISO_NO_CLASS_PATH=1 (tests): force the direct mask path of sampler_grp
     const bool no_cls = std::getenv("MISO_NO_CLASS_PATH") != nullptr;
     int qs = (!p.paired && !no_cls && !run.nocls && run.maxcls > 0) ? run.maxcls : 0;
     if (qs && 4 * 2 * static_cast<size_t>(grp_slice_bytes(run.kmax, qs, 0)) > LDS_MAX) qs = 0;
     // paired-end: the per-event score table (K x il int32) joins the slice when >= 4 chains still fit
-    int ts = p.paired ? run.kmax * static_cast<int>(fd.prob.size()) : 0;
+    int ts = p.paired ? run.kmax * (fp_rows(run) ? il2 : static_cast<int>(fd.prob.size())) : 0;
     if (ts && fp_bytes + 4 * 4 * static_cast<size_t>(grp_slice_bytes(run.kmax, 0, ts)) > LDS_MAX) ts = 0;
     return GrpShape{qs, ts};
   };
   auto grp_fits = [&](const GenRun &run, const GrpShape &sh, int G) {
+    const size_t fp_bytes = fp_bytes_of(run);
     return G >= 2 && G <= 32 && !(G & (G - 1)) &&
            fp_bytes + 4 * static_cast<size_t>(64 / G) * grp_slice_bytes(run.kmax, sh.qs, sh.ts) <= LDS_MAX;
   };
@@ -439,6 +464,9 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     const long chains = static_cast<long>(run.count) * p.noChains;
     ka.slot_event = d_slots + n_k2 + run.first; ka.n_slots = run.count;
     ka.kstride = run.kmax; ka.cstride = sh.qs; ka.tstride = sh.ts;
+    ka.pe_dense = G == 64 ? 0 : fp_rows(run);
+    ka.pe_force_exact = std::getenv("MISO_PE_FORCE_EXACT") != nullptr;
+    const size_t fp_bytes = G == 64 ? fp_plain : fp_bytes_of(run);
     if (G == 64) {
       const unsigned grid = static_cast<unsigned>((chains + 3) / 4);
       const size_t lds = fp_bytes + 4 * 32 * sizeof(int);
