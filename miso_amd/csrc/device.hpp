@@ -98,7 +98,8 @@ constexpr uint64_t NO_DENSE = ~0ull;
 // fragment-length index f -> k * il2 + f with il2 = il + 2; two more entries per isoform: PE_ZERO
 // (incompatible: probability -0.0, never picked) and PE_ONE (probability 1, score 0: the padding reads
 // that complete the last quad always pick isoform 0).  One quad = 4 reads x K u16 indices, then 4 u16 of
-// flags (word 0: bit j set when read j has MORE than two compatible isoforms), 2K + 2 dwords.
+// flags (word 0: bit j set when read j has MORE than two compatible isoforms), 2K + 2 dwords.  After the
+// event's last quad comes one more made of padding reads only.
 constexpr int PE_DENSE_KMAX = 20;
 MISO_DEVHOST_EARLY inline int pe_dense_il2(int il) { return il + 2; }
 MISO_DEVHOST_EARLY inline int pe_dense_quad_u16(int K) { return 4 * K + 4; }

@@ -484,7 +484,7 @@ PackedEvent pack_event_masks(const miso_params_t &p, const FragmentDist *fd, int
     // tables -- no validity tests left in the read loop -- and one flag per read: which of the
     // reference's two stopping rules applies (miso_paired.c:64-75: exactly two compatible isoforms or more).
     const int il2 = pe_dense_il2(il), qw = pe_dense_quad_u16(K);
-    const int nq = (e.n_draw + 3) / 4;
+    const int nq = (e.n_draw + 3) / 4 + 1;   // + one quad of padding reads: what the lanes beyond the last quad process
     e.draw_dense.assign(static_cast<size_t>(nq) * qw, 0);
     e.dense_nobad = true;
     for (int r = 0; r < 4 * nq; r++) {

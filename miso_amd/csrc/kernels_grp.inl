@@ -46,6 +46,18 @@
 #define GPROF_ADD(acc, t0, t1)
 #endif
 
+#ifndef MISO_PE_SDWA
+#define MISO_PE_SDWA 1
+#endif
+#ifndef MISO_PE_ASM_TESTS
+#define MISO_PE_ASM_TESTS 1
+#endif
+#ifndef MISO_PE_MAD
+#define MISO_PE_MAD 1
+#endif
+#ifndef MISO_PE_AB_UPTO
+#define MISO_PE_AB_UPTO 4   // pe_dense: two loop bodies with alternating record registers up to this many isoforms
+#endif
 #ifndef MISO_PE_MASKED_FROM
 #define MISO_PE_MASKED_FROM 6   // paired-end quad loop: exec-masked form above this many isoforms, branch-free form up to it
 #endif
@@ -458,9 +470,76 @@ __device__ __attribute__((noinline)) int pe_pick_exact(const uint16_t *rec, int 
   return sel;
 }
 
-template <int KK, int G, bool WRITE, bool BADCHK>
+// LDS reads by byte address (the workgroup's dynamic LDS starts at address 0: sampler_grp checks): no
+// pointer arithmetic on a symbol the compiler cannot fold, and never a flat_load.
+typedef const __attribute__((address_space(3))) double *lds_cdp;
+typedef const __attribute__((address_space(3))) int32_t *lds_cip;
+__device__ __forceinline__ double lds_f64(uint32_t addr) { return *reinterpret_cast<lds_cdp>(static_cast<uintptr_t>(addr)); }
+__device__ __forceinline__ int32_t lds_i32(uint32_t addr) { return *reinterpret_cast<lds_cip>(static_cast<uintptr_t>(addr)); }
+// 8 x (16-bit half HALF of w): one SDWA shift instead of shift + mask
+template <int HALF> __device__ __forceinline__ uint32_t half_x8(uint32_t w, uint32_t three) {
+  uint32_t r;
+  if constexpr (HALF == 0)
+    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(three), "v"(w));
+  else
+    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(three), "v"(w));
+  return r;
+}
+// N (1..4) stopping tests of one read: isoform k + i is passed over when rb >= cb[i]; then the pick's table
+// offset moves on to nx[i] and the isoform's running total grows by one.  The compares first, into N
+// SGPR pairs, so that no select or add-with-carry waits on the compare in front of it.
+template <int N>
+__device__ __forceinline__ void pe_tests(int64_t rb, const int64_t *cb, const uint32_t *nx, uint32_t &fsel, int *over) {
+  uint64_t m0, m1, m2, m3, junk;
+  if constexpr (N == 4) {
+    asm volatile(
+        "v_cmp_ge_i64_e64 %5, %10, %11\n\tv_cmp_ge_i64_e64 %6, %10, %12\n\tv_cmp_ge_i64_e64 %7, %10, %13\n\tv_cmp_ge_i64_e64 %8, %10, %14\n\t"
+        "v_cndmask_b32_e64 %0, %0, %15, %5\n\tv_addc_co_u32_e64 %1, %9, %1, 0, %5\n\t"
+        "v_cndmask_b32_e64 %0, %0, %16, %6\n\tv_addc_co_u32_e64 %2, %9, %2, 0, %6\n\t"
+        "v_cndmask_b32_e64 %0, %0, %17, %7\n\tv_addc_co_u32_e64 %3, %9, %3, 0, %7\n\t"
+        "v_cndmask_b32_e64 %0, %0, %18, %8\n\tv_addc_co_u32_e64 %4, %9, %4, 0, %8\n\t"
+        : "+v"(fsel), "+v"(over[0]), "+v"(over[1]), "+v"(over[2]), "+v"(over[3]), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3), "=&s"(junk)
+        : "v"(rb), "v"(cb[0]), "v"(cb[1]), "v"(cb[2]), "v"(cb[3]), "v"(nx[0]), "v"(nx[1]), "v"(nx[2]), "v"(nx[3]));
+  } else if constexpr (N == 3) {
+    asm volatile(
+        "v_cmp_ge_i64_e64 %4, %8, %9\n\tv_cmp_ge_i64_e64 %5, %8, %10\n\tv_cmp_ge_i64_e64 %6, %8, %11\n\t"
+        "v_cndmask_b32_e64 %0, %0, %12, %4\n\tv_addc_co_u32_e64 %1, %7, %1, 0, %4\n\t"
+        "v_cndmask_b32_e64 %0, %0, %13, %5\n\tv_addc_co_u32_e64 %2, %7, %2, 0, %5\n\t"
+        "v_cndmask_b32_e64 %0, %0, %14, %6\n\tv_addc_co_u32_e64 %3, %7, %3, 0, %6\n\t"
+        : "+v"(fsel), "+v"(over[0]), "+v"(over[1]), "+v"(over[2]), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(junk)
+        : "v"(rb), "v"(cb[0]), "v"(cb[1]), "v"(cb[2]), "v"(nx[0]), "v"(nx[1]), "v"(nx[2]));
+  } else if constexpr (N == 2) {
+    asm volatile(
+        "v_cmp_ge_i64_e64 %3, %6, %7\n\tv_cmp_ge_i64_e64 %4, %6, %8\n\t"
+        "v_cndmask_b32_e64 %0, %0, %9, %3\n\tv_addc_co_u32_e64 %1, %5, %1, 0, %3\n\t"
+        "v_cndmask_b32_e64 %0, %0, %10, %4\n\tv_addc_co_u32_e64 %2, %5, %2, 0, %4\n\t"
+        : "+v"(fsel), "+v"(over[0]), "+v"(over[1]), "=&s"(m0), "=&s"(m1), "=&s"(junk)
+        : "v"(rb), "v"(cb[0]), "v"(cb[1]), "v"(nx[0]), "v"(nx[1]));
+  } else {
+    asm volatile(
+        "v_cmp_ge_i64_e64 %2, %4, %5\n\t"
+        "v_cndmask_b32_e64 %0, %0, %6, %2\n\tv_addc_co_u32_e64 %1, %3, %1, 0, %2\n\t"
+        : "+v"(fsel), "+v"(over[0]), "=&s"(m0), "=&s"(junk)
+        : "v"(rb), "v"(cb[0]), "v"(nx[0]));
+  }
+}
+template <int KK>
+__device__ __forceinline__ void pe_all_tests(int64_t rb, const int64_t (&cb)[KK], const uint32_t (&off)[KK], uint32_t &fsel, int (&over)[KK - 1]) {
+  constexpr int NT = KK - 1;
+#pragma unroll
+  for (int k = 0; k + 4 <= NT; k += 4) pe_tests<4>(rb, &cb[k], &off[k + 1], fsel, &over[k]);
+  constexpr int R = NT & 3, K0 = NT - R;
+  if constexpr (R == 3) pe_tests<3>(rb, &cb[K0], &off[K0 + 1], fsel, &over[K0]);
+  else if constexpr (R == 2) pe_tests<2>(rb, &cb[K0], &off[K0 + 1], fsel, &over[K0]);
+  else if constexpr (R == 1) pe_tests<1>(rb, &cb[K0], &off[K0 + 1], fsel, &over[K0]);
+}
+
+// The loop.  fq: the event's records, n_quads of them followed by one quad of padding reads, which the lanes
+// beyond the event's last quad process instead (it changes nothing: no range test in the loop).
+// STAB_LDS: the score table is the chain's LDS copy at byte address stab_lds, else stab_glob in global memory.
+template <int KK, int G, bool WRITE, bool BADCHK, bool STAB_LDS>
 __device__ __forceinline__ void pe_dense(const uint32_t *fq, const double *psi, const double *fp_rep,
-                                         const int32_t *stab, int il2, int *dl, uint8_t *drawass,
+                                         uint32_t stab_lds, const int32_t *stab_glob, int il2, int *dl, uint8_t *drawass,
                                          bool write_ass, int nqw, int n_quads, int n_draw, int sub,
                                          const GibbsRng &rng, uint32_t n0r0, bool force_exact,
                                          int64_t &acc_out, int &bad_out) {
@@ -468,32 +547,49 @@ __device__ __forceinline__ void pe_dense(const uint32_t *fq, const double *psi, 
   double ps[KK];
 #pragma unroll
   for (int k = 0; k < KK; k++) ps[k] = psi[k];
-  const int q_last = max(n_quads - 1, 0);
-  uint32_t nxt[ND];
-  {
-    const uint32_t *src = fq + static_cast<size_t>(min(sub, q_last)) * ND;
-#pragma unroll
-    for (int i = 0; i < ND; i++) nxt[i] = src[i];
-  }
   int64_t acc = 0; int bad = 0;
   int over[KK - 1];   // reads of this lane that passed over isoform k
 #pragma unroll
   for (int k = 0; k < KK - 1; k++) over[k] = 0;
-  const unsigned char *fpb = reinterpret_cast<const unsigned char *>(fp_rep);
-  const unsigned char *stb = reinterpret_cast<const unsigned char *>(stab);
-  for (int q0 = 0; q0 < nqw; q0 += G) {
-    const int q = q0 + sub;
-    const bool inq = q < n_quads;
-    uint32_t cur[ND];
+  const uint32_t three = 3u;
+  const unsigned char *stg = reinterpret_cast<const unsigned char *>(stab_glob);
+  auto score = [&](uint32_t fsel) __attribute__((always_inline)) {   // fsel = 8 x index
+    if constexpr (STAB_LDS) return lds_i32(stab_lds + (fsel >> 1));
+    else return *reinterpret_cast<const int32_t *>(stg + (fsel >> 1));
+  };
+  auto load = [&](uint32_t (&r)[ND], int q) __attribute__((always_inline)) {
+    const uint32_t *src = fq + static_cast<uint32_t>(min(q, n_quads)) * static_cast<uint32_t>(ND);
 #pragma unroll
-    for (int i = 0; i < ND; i++) cur[i] = nxt[i];
-    {
-      const uint32_t *src = fq + static_cast<size_t>(min(q + G, q_last)) * ND;
+    for (int i = 0; i < ND; i++) r[i] = src[i];
+  };
+  // the scores of a quad's four picks are fetched when the picks are known and added one trip later: nothing
+  // in the loop waits for a gather it has just issued (the last read's score used to be waited for right away,
+  // and with it -- the counter is in order -- the next quad's records)
+  int32_t pend[4] = {0, 0, 0, 0};
+  auto settle = [&]() __attribute__((always_inline)) {
 #pragma unroll
-      for (int i = 0; i < ND; i++) nxt[i] = src[i];
+    for (int j = 0; j < 4; j++) {
+      const int32_t v = pend[j];
+      if (BADCHK) {
+        const bool isbad = v == SFIX_BAD;
+        bad |= isbad ? 1 : 0;
+        acc += isbad ? 0 : v;
+      } else {
+#if MISO_PE_MAD
+        uint64_t junk;
+        asm("v_mad_i64_i32 %0, %1, %2, 1, %0" : "+v"(acc), "=s"(junk) : "v"(v));   // acc += v, one instruction
+#else
+        acc += v;
+#endif
+      }
     }
+  };
+  const uint32_t neutral = static_cast<uint32_t>(il2 - 1) << 3;   // PE_ONE of isoform 0: score 0
+  auto process = [&](const uint32_t (&cur)[ND], int q) __attribute__((always_inline)) {
     const miso_u32x4 u = philox_gibbs<true>(rng, static_cast<uint32_t>(q), n0r0);
     const uint32_t flags = cur[2 * KK];
+    bool okj[4];
+    uint32_t fs[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       uint32_t off[KK]; int64_t cb[KK];
@@ -501,41 +597,88 @@ __device__ __forceinline__ void pe_dense(const uint32_t *fq, const double *psi, 
 #pragma unroll
       for (int k = 0; k < KK; k++) {
         const int h = j * KK + k;
-        off[k] = (h & 1) ? ((cur[h >> 1] >> 13) & 0x7FFF8u) : ((cur[h >> 1] << 3) & 0x7FFF8u);   // index x 8
-        T = T + ps[k] * *reinterpret_cast<const double *>(fpb + off[k]);
+#if MISO_PE_SDWA
+        off[k] = (h & 1) ? half_x8<1>(cur[h >> 1], three) : half_x8<0>(cur[h >> 1], three);
+#else
+        off[k] = (h & 1) ? ((cur[h >> 1] >> 13) & 0x7FFF8u) : ((cur[h >> 1] << 3) & 0x7FFF8u);
+#endif
+        T = T + ps[k] * lds_f64(off[k]);
         cb[k] = __double_as_longlong(T);
       }
       const double rnd = miso_u01(u.v[j]) * T;
-      const bool ok = inq & (rnd < T) & !force_exact;
-      const int64_t rb = __double_as_longlong(rnd) - static_cast<int64_t>((flags >> j) & 1u);
-      uint32_t fsel = off[0]; int sel = 0;
+      const bool ok = (rnd < T) & !force_exact;
+      okj[j] = ok;
+      int64_t rb = __double_as_longlong(rnd) - static_cast<int64_t>((flags >> j) & 1u);
+      rb = ok ? rb : INT64_MIN;     // not exact here: pe_pick_exact below (and what this makes the tests do is taken back there)
+      uint32_t fsel = off[0];
+#if MISO_PE_ASM_TESTS
+      pe_all_tests<KK>(rb, cb, off, fsel, over);
+#else
 #pragma unroll
       for (int k = 0; k < KK - 1; k++) {
-        const bool pass = ok & (rb >= cb[k]);
+        const bool pass = rb >= cb[k];
         over[k] += pass ? 1 : 0;
         fsel = pass ? off[k + 1] : fsel;
-        if (WRITE) sel += pass ? 1 : 0;
       }
-      if (__builtin_expect(__any(inq & !ok), 0)) {
-        if (inq & !ok) {   // the reference's scan as written
-          const uint16_t *rec = reinterpret_cast<const uint16_t *>(fq + static_cast<size_t>(q) * ND) + j * KK;
-          sel = pe_pick_exact(rec, KK, il2, psi, fp_rep, ((flags >> j) & 1u) == 0, u.v[j]);
-          fsel = static_cast<uint32_t>(rec[sel]) << 3;
+#endif
+      if (WRITE) {
+        if (write_ass && ok && 4 * q + j < n_draw) drawass[4 * q + j] = static_cast<uint8_t>((fsel >> 3) / static_cast<uint32_t>(il2));
+      }
+      fs[j] = BADCHK ? (ok ? fsel : neutral) : fsel;
+    }
+    if constexpr (!STAB_LDS) settle();   // the previous quad's
 #pragma unroll
-          for (int k = 0; k < KK - 1; k++) over[k] += (k < sel) ? 1 : 0;
+    for (int j = 0; j < 4; j++) pend[j] = score(fs[j]);
+    if constexpr (STAB_LDS) settle();    // an LDS read is not worth the four registers across the trip (K = 3, 4: -4 %)
+    const bool okq = okj[0] & okj[1] & okj[2] & okj[3];
+    if (__builtin_expect(__any(!okq), 0)) {
+#pragma unroll 1
+      for (int j = 0; j < 4; j++) {
+        if (okj[j]) continue;   // the reference's scan as written
+        const uint16_t *rec = reinterpret_cast<const uint16_t *>(fq + static_cast<size_t>(min(q, n_quads)) * ND) + j * KK;
+        const int sel = pe_pick_exact(rec, KK, il2, psi, fp_rep, ((flags >> j) & 1u) == 0, u.v[j]);
+        // what the loop above did with rb = INT64_MIN: passed over the incompatible isoforms in front of the
+        // first compatible one (their c is -0.0 = INT64_MIN) and took the score there
+        int lead = 0;
+        while (lead < KK - 1 && rec[lead] == lead * il2 + il2 - 2) lead++;
+#pragma unroll
+        for (int k = 0; k < KK - 1; k++) over[k] += ((k < sel) ? 1 : 0) - ((k < lead) ? 1 : 0);
+        const int32_t vx = score(static_cast<uint32_t>(rec[sel]) << 3);
+        if (BADCHK) {
+          if (vx == SFIX_BAD) bad = 1; else acc += vx;
+        } else {
+          acc += static_cast<int64_t>(vx) - score(static_cast<uint32_t>(rec[lead]) << 3);
         }
+        if (WRITE) { if (write_ass && 4 * q + j < n_draw) drawass[4 * q + j] = static_cast<uint8_t>(sel); }
       }
-      const int32_t v = *reinterpret_cast<const int32_t *>(stb + (fsel >> 1));
-      if (BADCHK) {
-        const bool isbad = v == SFIX_BAD;
-        bad |= (inq & isbad) ? 1 : 0;
-        acc += (inq & !isbad) ? v : 0;
-      } else {
-        acc += inq ? v : 0;
-      }
-      if (WRITE) { if (write_ass && inq && 4 * q + j < n_draw) drawass[4 * q + j] = static_cast<uint8_t>(sel); }
+    }
+  };
+  if constexpr (KK <= MISO_PE_AB_UPTO) {
+    // two quads per trip, each fetched while the other is worked on (no register copies)
+    uint32_t A[ND], B[ND];
+    int q = sub;
+    load(A, q);
+    for (int q0 = 0; q0 < nqw; q0 += 2 * G) {
+      load(B, q + G);
+      process(A, q);
+      load(A, q + 2 * G);
+      if (q0 + G < nqw) process(B, q + G);
+      q += 2 * G;
+    }
+  } else {
+    // wider records: one loop body, the next quad fetched into a second set of registers and copied over
+    // (two bodies cost more registers than the copies cost time: K = 5..16 were 10-15 % slower that way)
+    uint32_t nxt[ND];
+    load(nxt, sub);
+    for (int q0 = 0; q0 < nqw; q0 += G) {
+      uint32_t cur[ND];
+#pragma unroll
+      for (int i = 0; i < ND; i++) cur[i] = nxt[i];
+      load(nxt, q0 + sub + G);
+      process(cur, q0 + sub);
     }
   }
+  settle();
 #pragma unroll
   for (int k = 0; k < KK - 1; k++) if (over[k]) atomicAdd(&dl[k], over[k]);
   acc_out = acc; bad_out = bad;
@@ -642,6 +785,10 @@ __global__ __launch_bounds__(256, KC <= 8 ? MISO_GRP_MINBLOCKS : 2) void sampler
     wave_sync();
   }
   const bool dense_nobad = dense && __all(E.dense_nobad != 0);
+  // pe_dense reads the LDS by byte address: the dynamic LDS (the only LDS of this kernel) starts at 0
+  if (dense && static_cast<uint32_t>(reinterpret_cast<uintptr_t>(smem)) != 0u) __builtin_trap();
+  const uint32_t stab_lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(S.stab));
+  const int32_t *sfixd_glob = reinterpret_cast<const int32_t *>(a.in_pool + (dense ? E.off_sfixd : E.off_sfix));   // provably global memory
   double *samples = reinterpret_cast<double *>(a.out_pool + E.off_samples);
   double *loglik = reinterpret_cast<double *>(a.out_pool + E.off_loglik);
   uint8_t *drawass = a.out_pool + E.off_drawass;
@@ -789,17 +936,19 @@ __global__ __launch_bounds__(256, KC <= 8 ? MISO_GRP_MINBLOCKS : 2) void sampler
       const uint32_t n0r0 = rng.p1hi ^ iter ^ rng.k0;
       for (int k0 = 0; k0 < Kw; k0 += G) { const int k = k0 + sub; if (k < K) S.dl[k] = 0; }
       wave_sync();
-#define MISO_PED(KK)                                                                                  \
+#define MISO_PED2(KK, LDS)                                                                            \
   {                                                                                                   \
-    if (__any(write_ass)) pe_dense<KK, G, true, true>(dq, S.psi, lds_fp, sfixd, il2, S.dl, drawass, write_ass, nqw, n_quads, n_draw, sub, rng, n0r0, a.pe_force_exact != 0, acc, bad); \
-    else if (dense_nobad) pe_dense<KK, G, false, false>(dq, S.psi, lds_fp, sfixd, il2, S.dl, drawass, write_ass, nqw, n_quads, n_draw, sub, rng, n0r0, a.pe_force_exact != 0, acc, bad); \
-    else pe_dense<KK, G, false, true>(dq, S.psi, lds_fp, sfixd, il2, S.dl, drawass, write_ass, nqw, n_quads, n_draw, sub, rng, n0r0, a.pe_force_exact != 0, acc, bad); \
+    if (__any(write_ass)) pe_dense<KK, G, true, true, LDS>(dq, S.psi, lds_fp, stab_lds, sfixd_glob, il2, S.dl, drawass, write_ass, nqw, n_quads, n_draw, sub, rng, n0r0, a.pe_force_exact != 0, acc, bad); \
+    else if (dense_nobad) pe_dense<KK, G, false, false, LDS>(dq, S.psi, lds_fp, stab_lds, sfixd_glob, il2, S.dl, drawass, write_ass, nqw, n_quads, n_draw, sub, rng, n0r0, a.pe_force_exact != 0, acc, bad); \
+    else pe_dense<KK, G, false, true, LDS>(dq, S.psi, lds_fp, stab_lds, sfixd_glob, il2, S.dl, drawass, write_ass, nqw, n_quads, n_draw, sub, rng, n0r0, a.pe_force_exact != 0, acc, bad); \
   }
+#define MISO_PED(KK) { if (a.tstride > 0) MISO_PED2(KK, true) else MISO_PED2(KK, false) }
       if constexpr (KC == 4) { if (K == 3) MISO_PED(3) else MISO_PED(4) }
       else if constexpr (KC == 8) { if (K == 5) MISO_PED(5) else if (K == 6) MISO_PED(6) else if (K == 7) MISO_PED(7) else MISO_PED(8) }
       else if constexpr (KC == 12) { if (K == 9) MISO_PED(9) else if (K == 10) MISO_PED(10) else if (K == 11) MISO_PED(11) else MISO_PED(12) }
       else if constexpr (KC == 16) { if (K == 13) MISO_PED(13) else if (K == 14) MISO_PED(14) else if (K == 15) MISO_PED(15) else MISO_PED(16) }
       else { if (K == 17) MISO_PED(17) else if (K == 18) MISO_PED(18) else if (K == 19) MISO_PED(19) else MISO_PED(20) }
+#undef MISO_PED2
 #undef MISO_PED
       wave_sync();
       // reads that passed over k - 1 but not k picked k

@@ -1,0 +1,14 @@
+#!/bin/bash
+# Variant library for A/B runs: recompile only the listed translation units with extra defines, link with
+# the in-tree objects of everything else.   tools/build_variant.sh NAME "-DMISO_X=1" kernels_grp_c8 kernels_grp_c12
+# -> tools/_build/libmiso_NAME.so   (run with MISO_AMD_LIB=tools/_build/libmiso_NAME.so)
+set -e
+cd "$(dirname "$0")/.."
+name=$1; defs=$2; shift 2
+mkdir -p tools/_build/$name
+cp miso_amd/csrc/*.o tools/_build/$name/
+F="$defs -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -Iinclude -Imiso_amd/csrc -Wno-unused-result"
+for f in "$@"; do /opt/rocm/bin/hipcc $F -c miso_amd/csrc/$f.hip -o tools/_build/$name/$f.o & done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC tools/_build/$name/*.o -o tools/_build/libmiso_$name.so -lz -lpthread
+rm -rf tools/_build/$name
