@@ -690,7 +690,13 @@ template <int G, bool PE, int KC>
 #ifndef MISO_GRP_MINBLOCKS
 #define MISO_GRP_MINBLOCKS 3   // measured: K=3 89.7k -> 114.4k events/s going from 2 to 3 (register budget 168)
 #endif
-__global__ __launch_bounds__(256, KC <= 8 ? MISO_GRP_MINBLOCKS : 2) void sampler_grp(const KernelArgs a) {
+// paired-end: workgroups per CU the register budget is set for.  Registers beat occupancy in pe_dense (K=5
+// 30.3k -> 39.3k, K=8 20.1k -> 27.5k events/s going from 3 to 2; 4: 19.1k / 13.0k; K=3 53.1k -> 58.1k, K=4 47.1k ->
+// 51.2k; one workgroup per CU: no gain up to 8 isoforms, 19.9k -> 12.5k at 10)
+#ifndef MISO_GRP_PE_BLOCKS
+#define MISO_GRP_PE_BLOCKS 2
+#endif
+__global__ __launch_bounds__(256, PE ? MISO_GRP_PE_BLOCKS : (KC <= 8 ? MISO_GRP_MINBLOCKS : 2)) void sampler_grp(const KernelArgs a) {
   constexpr int KLO = KC == 4 ? 3 : (KC == 8 ? 5 : (KC == 12 ? 9 : (KC == 16 ? 13 : 17)));   // the class holds K in [KLO, KC]
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int CPW = 64 / G;
@@ -961,6 +967,8 @@ __global__ __launch_bounds__(256, KC <= 8 ? MISO_GRP_MINBLOCKS : 2) void sampler
       for (int off = G >> 1; off >= 1; off >>= 1) { acc += __shfl_xor(acc, off); bad |= __shfl_xor(bad, off); }
       rfix = E.base_sfix + acc;
       rbad = bad | E.base_bad;
+      GPROF_T(t2);
+      GPROF_ADD(gp_loop, t0, t2);
       return;
     }
     if (PE && pe_fast) {

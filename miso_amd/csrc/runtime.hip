@@ -651,10 +651,13 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       // rule of thumb.  single-end: the per-iteration scalar step costs the same per wavefront
       // whatever G is, so pack as many chains per wavefront as still fills the device: the smallest
       // G whose wavefronts occupy every resident slot; a batch too small for that takes the largest.
-      // paired-end: the read loop waits on memory and more wavefronts hide it: largest G up to 16.
+      // paired-end: the read loop waits on memory and more wavefronts hide it: largest G up to 16; 32 from
+      // nine isoforms on (measured, pe_dense: K=10 19.5k -> 19.9k, K=20 7.35k -> 7.57k events/s; K=5 29.9k ->
+      // 28.9k, K=3 53k -> 46k) and whenever 16 would leave the kernel's share of the device unfilled.
       bool found = false;
+      const bool pe32 = p.paired && (run.kc >= 12 || (chains + 3) / 4 < slots_for(chains));
       for (int g : {2, 4, 8, 16, 32}) {
-        if (p.paired && g > 16 && found) break;
+        if (p.paired && g > 16 && found && !pe32) break;
         if (!grp_fits(run, sh, g)) continue;
         const int cpw = 64 / g;
         if (!found || g <= std::max(2, run.maxq)) G = g;
