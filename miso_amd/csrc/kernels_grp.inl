@@ -73,6 +73,43 @@ namespace {
 // is told not to move them: a wavefront-scope fence is enough (no s_barrier: chains never span waves)
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 
+// The sequential sums, products and maxima of the Metropolis-Hastings step over a slice array, in CHUNKS of
+// four: the chunk's values are read first (independent LDS reads, one round trip), then the chain runs in
+// registers with the entries beyond n switched to the operation's neutral element (x + 0.0 on a sum that
+// started from +0.0, x - 0.0, x * 1.0: all bit-neutral).  A loop over n reads the LDS once per step, each
+// read a full round trip in front of a dependent add: a dozen such loops were most of the step's time from
+// ten isoforms on (profiles/r02_pe_phase_experiments.txt).  nw = the wavefront's largest n (uniform bound).
+// Chunk width MH_CH: the whole class at once up to eight isoforms paired-end (K=3 57.3k -> 63.2k events/s against
+// chunks of four), four beyond (the registers of a wider chunk spill: K=10 19.9k -> 13.9k), one = the plain loop
+// single-end (168-register budget: K=5 81k -> 30k with the class-wide form, 77.6k with chunks of four).
+template <int MH_CH> __device__ __forceinline__ void load_chunk(const double *v, int k0, int n, double (&t)[MH_CH]) {
+  const int last = max(n - 1, 0);
+#pragma unroll
+  for (int i = 0; i < MH_CH; i++) t[i] = v[min(k0 + i, last)];
+}
+template <int MH_CH, bool ONE = false> __device__ __forceinline__ double seq_sum_u(const double *v, int n, int nw) {
+  double acc = 0.0;
+#pragma unroll 1
+  for (int k0 = 0; k0 < (ONE ? 1 : nw); k0 += MH_CH) {   // ONE: the chunk covers the class, a single pass
+    double t[MH_CH];
+    load_chunk<MH_CH>(v, k0, n, t);
+#pragma unroll
+    for (int i = 0; i < MH_CH; i++) acc = acc + (k0 + i < n ? t[i] : 0.0);
+  }
+  return acc;
+}
+template <int MH_CH, bool ONE = false> __device__ __forceinline__ double seq_max_u(const double *v, int n, int nw) {
+  double m = v[0];
+#pragma unroll 1
+  for (int k0 = 0; k0 < (ONE ? 1 : nw); k0 += MH_CH) {
+    double t[MH_CH];
+    load_chunk<MH_CH>(v, k0, n, t);
+#pragma unroll
+    for (int i = 0; i < MH_CH; i++) m = (k0 + i > 0 && k0 + i < n && t[i] > m) ? t[i] : m;
+  }
+  return m;
+}
+
 __device__ __forceinline__ double seq_sum(const double *v, int n) {
   double acc = 0.0;
   for (int k = 0; k < n; k++) acc = acc + v[k];
@@ -678,7 +715,7 @@ __device__ __forceinline__ void pe_dense(const uint32_t *fq, const double *psi, 
       process(cur, q0 + sub);
     }
   }
-  settle();
+  if constexpr (!STAB_LDS) settle();   // the last quad's
 #pragma unroll
   for (int k = 0; k < KK - 1; k++) if (over[k]) atomicAdd(&dl[k], over[k]);
   acc_out = acc; bad_out = bad;
@@ -698,6 +735,8 @@ template <int G, bool PE, int KC>
 #endif
 __global__ __launch_bounds__(256, PE ? MISO_GRP_PE_BLOCKS : (KC <= 8 ? MISO_GRP_MINBLOCKS : 2)) void sampler_grp(const KernelArgs a) {
   constexpr int KLO = KC == 4 ? 3 : (KC == 8 ? 5 : (KC == 12 ? 9 : (KC == 16 ? 13 : 17)));   // the class holds K in [KLO, KC]
+  constexpr int MH_CH = PE ? (KC <= 8 ? KC : 4) : 1;   // chunk width of the Metropolis-Hastings step's serial chains (seq_sum_u)
+  constexpr bool MH_ONE = MH_CH >= KC;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int CPW = 64 / G;
   const int il2 = pe_dense_il2(a.il);
@@ -1090,10 +1129,10 @@ __global__ __launch_bounds__(256, PE ? MISO_GRP_PE_BLOCKS : (KC <= 8 ? MISO_GRP_
       }
     }
     wave_sync();
-    const double sumexp = seq_sum(S.tc, K - 1) + 1.0;
+    const double sumexp = seq_sum_u<MH_CH, MH_ONE>(S.tc, K - 1, Kw - 1) + 1.0;
     for (int k0 = 0; k0 < Kw; k0 += G) { const int k = k0 + sub; if (k < K - 1) psi_out[k] = S.tc[k] / sumexp; }
     wave_sync();
-    const double sumpsi = seq_sum(psi_out, K - 1);
+    const double sumpsi = seq_sum_u<MH_CH, MH_ONE>(psi_out, K - 1, Kw - 1);
     if (sub == 0) psi_out[K - 1] = 1 - sumpsi;
     wave_sync();
   };
@@ -1103,7 +1142,13 @@ __global__ __launch_bounds__(256, PE ? MISO_GRP_PE_BLOCKS : (KC <= 8 ? MISO_GRP_
   // ONE log pass over 2K-1 arguments. ----
   auto log_pass = [&](const double *x, double *lp, double *tb, double *lr, double &jac) {
     double ltheta = 1.0, prod = 1.0;
-    for (int i = 0; i < K - 1; i++) { const double t = x[i]; ltheta = ltheta - t; prod = prod * t; }
+#pragma unroll 1
+    for (int k0 = 0; k0 < (MH_ONE ? 1 : Kw - 1); k0 += MH_CH) {
+      double t[MH_CH];
+      load_chunk<MH_CH>(x, k0, K - 1, t);
+#pragma unroll
+      for (int i = 0; i < MH_CH; i++) { ltheta = ltheta - (k0 + i < K - 1 ? t[i] : 0.0); prod = prod * (k0 + i < K - 1 ? t[i] : 1.0); }
+    }
     jac = 1.0 / prod / ltheta;
     for (int s0 = 0; s0 < 2 * Kw - 1; s0 += G) {
       const int s = s0 + sub;
@@ -1117,23 +1162,30 @@ __global__ __launch_bounds__(256, PE ? MISO_GRP_PE_BLOCKS : (KC <= 8 ? MISO_GRP_
     }
     wave_sync();
   };
-  auto max_of = [&](const double *tb) {
-    double maxv = tb[0];
-    for (int k = 1; k < K; k++) { const double v = tb[k]; if (v > maxv) maxv = v; }
-    return maxv;
-  };
+  auto max_of = [&](const double *tb) { return seq_max_u<MH_CH, MH_ONE>(tb, K, Kw); };
   // ---- joint log score from cached logs and the current counts (miso.c:243-307; PE miso_paired.c:133-174) ----
   auto joint_sums = [&](const double *lp, const double *tb, double lse, double readProbPE) {
     double readProb = 0.0, assProb = 0.0, psiProb = 0.0;
-    for (int k = 0; k < K; k++) {
-      const int ck = count_of(k);
-      if (ck != 0) {
-        if (!PE) readProb = readProb + static_cast<double>(ck) * S.isc[k];
-        assProb = assProb + static_cast<double>(ck) * (tb[k] - lse);
+#pragma unroll 1
+    for (int k0 = 0; k0 < (MH_ONE ? 1 : Kw); k0 += MH_CH) {
+      int ck[MH_CH]; double tbv[MH_CH], iscv[MH_CH], lpv[MH_CH], hv[MH_CH];
+#pragma unroll
+      for (int i = 0; i < MH_CH; i++) {
+        const int kk = min(k0 + i, K - 1);
+        ck[i] = count_of(kk); tbv[i] = tb[kk]; lpv[i] = lp[kk]; hv[i] = S.hm1[kk];
+        iscv[i] = PE ? 0.0 : S.isc[kk];
       }
+#pragma unroll
+      for (int i = 0; i < MH_CH; i++) {
+        const bool on = k0 + i < K && ck[i] != 0;
+        if (!PE) readProb = on ? readProb + static_cast<double>(ck[i]) * iscv[i] : readProb;
+        assProb = on ? assProb + static_cast<double>(ck[i]) * (tbv[i] - lse) : assProb;
+      }
+      // (the two sums are independent chains: interleaving them is the reference's order within each)
+#pragma unroll
+      for (int i = 0; i < MH_CH; i++) psiProb = k0 + i < K ? psiProb + hv[i] * lpv[i] : psiProb;
     }
     if (PE) readProb = readProbPE;
-    for (int k = 0; k < K; k++) psiProb = psiProb + S.hm1[k] * lp[k];
     psiProb = psiProb + c.lg_sum;
     psiProb = psiProb - c.lg_each;
     return readProb + assProb + psiProb;
@@ -1151,7 +1203,7 @@ __global__ __launch_bounds__(256, PE ? MISO_GRP_PE_BLOCKS : (KC <= 8 ? MISO_GRP_
     const double maxv = max_of(S.tb);
     for (int k0 = 0; k0 < Kw; k0 += G) { const int k = k0 + sub; if (k < K) S.tc[k] = miso_det_exp(S.tb[k] - maxv); }
     wave_sync();
-    lse = miso_det_log(seq_sum(S.tc, K)) + maxv;
+    lse = miso_det_log(seq_sum_u<MH_CH, MH_ONE>(S.tc, K, Kw)) + maxv;
     wave_sync();
   }
   gibbs(MISO_ITER_INIT, live && chain == 0 && a.M == 0);
@@ -1160,7 +1212,14 @@ __global__ __launch_bounds__(256, PE ? MISO_GRP_PE_BLOCKS : (KC <= 8 ? MISO_GRP_
   int accepted = 0, lagCounter = 0, noS = 0;
 
   for (int m = 0; m < a.M; m++) {
-    for (int k = 0; k < K; k++) hash = (hash ^ static_cast<uint32_t>(count_of(k))) * 0x100000001B3ull;
+#pragma unroll 1
+    for (int k0 = 0; k0 < (MH_ONE ? 1 : Kw); k0 += MH_CH) {
+      int ck[MH_CH];
+#pragma unroll
+      for (int i = 0; i < MH_CH; i++) ck[i] = count_of(min(k0 + i, K - 1));
+#pragma unroll
+      for (int i = 0; i < MH_CH; i++) hash = k0 + i < K ? (hash ^ static_cast<uint32_t>(ck[i])) * 0x100000001B3ull : hash;
+    }
     if (trace && live)
       for (int k0 = 0; k0 < Kw; k0 += G) {
         const int k = k0 + sub;
@@ -1183,7 +1242,7 @@ __global__ __launch_bounds__(256, PE ? MISO_GRP_PE_BLOCKS : (KC <= 8 ? MISO_GRP_
       }
     }
     wave_sync();
-    const double e1 = seq_sum(S.tc, K - 1), e2 = seq_sum(S.u2, K - 1);
+    const double e1 = seq_sum_u<MH_CH, MH_ONE>(S.tc, K - 1, Kw - 1), e2 = seq_sum_u<MH_CH, MH_ONE>(S.u2, K - 1, Kw - 1);
     wave_sync();
     for (int s0 = 0; s0 < Kw + 2; s0 += G) {                                        // pass 4: exp
       const int s = s0 + sub;
@@ -1195,7 +1254,7 @@ __global__ __launch_bounds__(256, PE ? MISO_GRP_PE_BLOCKS : (KC <= 8 ? MISO_GRP_
     }
     wave_sync();
     {                                                                               // pass 5: log
-      const double sumtc = seq_sum(S.tc, K);
+      const double sumtc = seq_sum_u<MH_CH, MH_ONE>(S.tc, K, Kw);
       const double x1 = S.sx[0], x2 = S.sx[1];
       wave_sync();
       for (int s0 = 0; s0 < 3; s0 += G) {
