@@ -290,6 +290,8 @@ MATRIX = [  # (label, overrides): the other shapes BASELINE's metric names, 40 0
     ("SE K=10, 1 chain, 7500 iters", dict(K=10)),
     ("SE K=2, MISO defaults (6 chains, 5000 iters, 500 burn-in, lag 10)", dict(K=2, chains=6, iters=5000, burn=500, lag=10)),
     ("PE K=2 (mean 250, sd 30), 1 chain, 7500 iters", dict(K=2, paired=True)),
+    # BASELINE configs[3]: whole-gene mode, 3-20 isoforms per gene, paired-end; "events" are genes here
+    ("PE K=3..20 per gene (whole-gene mix), 1 chain, 7500 iters", dict(K=(3, 20), paired=True, events=16384)),
 ]
 
 
@@ -300,7 +302,7 @@ def run_matrix(a, local_rank):
         cfg = dict(K=a.K, reads=a.reads, read_len=a.read_len, iters=a.iters, burn=a.burn, lag=a.lag,
                    chains=a.chains, paired=False)
         cfg.update(ov)
-        n = a.matrix_events
+        n = min(a.matrix_events, cfg.get("events", a.matrix_events))
         b = workload.build_batch(0, n, K=cfg["K"], n_reads=cfg["reads"], read_len=cfg["read_len"],
                                  iters=cfg["iters"], burn=cfg["burn"], lag=cfg["lag"], chains=cfg["chains"],
                                  paired=cfg["paired"], device_match=True)

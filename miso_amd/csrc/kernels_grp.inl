@@ -736,7 +736,7 @@ template <int G, bool PE, int KC>
 __global__ __launch_bounds__(256, PE ? MISO_GRP_PE_BLOCKS : (KC <= 8 ? MISO_GRP_MINBLOCKS : 2)) void sampler_grp(const KernelArgs a) {
   constexpr int KLO = KC == 4 ? 3 : (KC == 8 ? 5 : (KC == 12 ? 9 : (KC == 16 ? 13 : 17)));   // the class holds K in [KLO, KC]
   constexpr int MH_CH = PE ? (KC <= 8 ? KC : 4) : 1;   // chunk width of the Metropolis-Hastings step's serial chains (seq_sum_u)
-  constexpr bool MH_ONE = MH_CH >= KC;
+  constexpr bool MH_ONE = PE && KC <= 4;   // a single pass without the loop around it (K=3 57.2k -> 60.6k; at five to eight isoforms the loop form is faster: 39.5k against 35.9k at K=5)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int CPW = 64 / G;
   const int il2 = pe_dense_il2(a.il);
