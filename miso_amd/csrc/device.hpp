@@ -101,6 +101,11 @@ constexpr uint64_t NO_DENSE = ~0ull;
 // flags (word 0: bit j set when read j has MORE than two compatible isoforms), 2K + 2 dwords.  After the
 // event's last quad comes one more made of padding reads only.
 constexpr int PE_DENSE_KMAX = 20;
+// Two isoforms (sampler_k2 MODE 2), same idea: one u32 per read, f0 | (il + f1) << 16, into tables of
+// 2 il + 2 entries -- probabilities [fp, fp, 0.0, 1.0], scores [isoform 0, isoform 1, 0, 0] -- so that one index
+// serves the probability and the score; a padding read is (2 il) | (2 il + 1) << 16: weight 0 against a
+// positive one, never isoform 0, score 0.  Quads of four reads, one quad of padding reads after the last.
+MISO_DEVHOST_EARLY inline int pe_k2_entries(int il) { return 2 * il + 2; }
 MISO_DEVHOST_EARLY inline int pe_dense_il2(int il) { return il + 2; }
 MISO_DEVHOST_EARLY inline int pe_dense_quad_u16(int K) { return 4 * K + 4; }
 constexpr int MAX_DRAW_CLASSES = 64;  // single-end: per-class integer thresholds up to this many classes (if the LDS slice fits)

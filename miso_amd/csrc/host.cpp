@@ -479,6 +479,15 @@ PackedEvent pack_event_masks(const miso_params_t &p, const FragmentDist *fd, int
   }
   if (p.paired)   // whole quads of reads on the device: pad with incompatible reads
     while ((e.draw_frag.size() / K) % 4) e.draw_frag.insert(e.draw_frag.end(), K, FRAG_NONE);
+  if (p.paired && K == 2 && e.pe_delta && pe_k2_entries(il) <= 0xFFFF) {   // sampler_k2 MODE 2 (device.hpp)
+    const int nq = (e.n_draw + 3) / 4 + 1;
+    e.draw_dense.resize(static_cast<size_t>(nq) * 8);   // u16 pairs: one u32 per read, little-endian
+    for (int r = 0; r < 4 * nq; r++) {
+      const bool real = r < e.n_draw;
+      e.draw_dense[2 * r] = static_cast<uint16_t>(real ? e.draw_frag[static_cast<size_t>(r) * 2] : 2 * il);
+      e.draw_dense[2 * r + 1] = static_cast<uint16_t>(real ? il + e.draw_frag[static_cast<size_t>(r) * 2 + 1] : 2 * il + 1);
+    }
+  }
   if (p.paired && K >= 3 && K <= PE_DENSE_KMAX && static_cast<size_t>(K) * pe_dense_il2(il) <= 0xFFFFu) {
     // Quad records of pe_dense (device.hpp): every (read, isoform) as an index into K replicated
     // tables -- no validity tests left in the read loop -- and one flag per read: which of the

@@ -547,14 +547,14 @@ __device__ __forceinline__ void pe_tests(int64_t rb, const int64_t *cb, const ui
         : "v"(rb), "v"(cb[0]), "v"(cb[1]), "v"(cb[2]), "v"(nx[0]), "v"(nx[1]), "v"(nx[2]));
   } else if constexpr (N == 2) {
     asm volatile(
-        "v_cmp_ge_i64_e64 %3, %6, %7\n\tv_cmp_ge_i64_e64 %4, %6, %8\n\t"
+        "v_cmp_ge_i64_e64 %3, %6, %7\n\tv_cmp_ge_i64_e64 %4, %6, %8\n\ts_nop 0\n\t"
         "v_cndmask_b32_e64 %0, %0, %9, %3\n\tv_addc_co_u32_e64 %1, %5, %1, 0, %3\n\t"
         "v_cndmask_b32_e64 %0, %0, %10, %4\n\tv_addc_co_u32_e64 %2, %5, %2, 0, %4\n\t"
         : "+v"(fsel), "+v"(over[0]), "+v"(over[1]), "=&s"(m0), "=&s"(m1), "=&s"(junk)
         : "v"(rb), "v"(cb[0]), "v"(cb[1]), "v"(nx[0]), "v"(nx[1]));
   } else {
     asm volatile(
-        "v_cmp_ge_i64_e64 %2, %4, %5\n\t"
+        "v_cmp_ge_i64_e64 %2, %4, %5\n\ts_nop 1\n\t"
         "v_cndmask_b32_e64 %0, %0, %6, %2\n\tv_addc_co_u32_e64 %1, %3, %1, 0, %2\n\t"
         : "+v"(fsel), "+v"(over[0]), "=&s"(m0), "=&s"(junk)
         : "v"(rb), "v"(cb[0]), "v"(nx[0]));

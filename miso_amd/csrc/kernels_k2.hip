@@ -217,14 +217,25 @@ __device__ __forceinline__ void vec_eval4(F f, double a0, double a1, double a2, 
 // (Tried and dropped: per-iteration weight tables w_k[f] = psi_k fp[f] per chain plus a per-read score
 // difference -- 17 % fewer VALU per read, but 3.9 KB of LDS per chain instead of 1.9 KB and 8 B instead of
 // 4 B per read and iteration from L2 / MALL made it 7 % SLOWER: profiles/r02_pe_k2_modes.txt.)
+typedef const __attribute__((address_space(3))) double *k2_lds_cdp;
+typedef const __attribute__((address_space(3))) int32_t *k2_lds_cip;
+__device__ __forceinline__ double k2_lds_f64(uint32_t addr) { return *reinterpret_cast<k2_lds_cdp>(static_cast<uintptr_t>(addr)); }
+__device__ __forceinline__ int32_t k2_lds_i32(uint32_t addr) { return *reinterpret_cast<k2_lds_cip>(static_cast<uintptr_t>(addr)); }
+
 template <int G, int MODE, int WPB>
 __global__ __launch_bounds__(64 * WPB, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void sampler_k2(const KernelArgs a) {
   constexpr bool PE = MODE != 0;
   constexpr bool PEW = MODE == 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_k2[];
   double *lds_fp = reinterpret_cast<double *>(smem_k2);  // PE: fragment-length probabilities
+  const int tab_n = PEW ? pe_k2_entries(a.il) : 2 * a.il;   // entries of the score table (and, MODE 2, of the probabilities)
   if (PE) {
-    for (int i = threadIdx.x; i < a.il; i += blockDim.x) lds_fp[i] = a.frag_prob[i];
+    for (int i = threadIdx.x; i < a.il; i += blockDim.x) {
+      const double v = a.frag_prob[i];
+      lds_fp[i] = v;
+      if (PEW) lds_fp[a.il + i] = v;               // MODE 2 (device.hpp pe_k2_entries): [fp, fp, 0.0, 1.0]
+    }
+    if (PEW && threadIdx.x == 0) { lds_fp[2 * a.il] = 0.0; lds_fp[2 * a.il + 1] = 1.0; }
     __syncthreads();                               // the only block-level barrier
   }
   constexpr int CPW = 64 / G;                      // chains per wavefront
@@ -288,13 +299,18 @@ __global__ __launch_bounds__(64 * WPB, 2) __attribute__((amdgpu_waves_per_eu(2, 
   const uint4 *fragq = reinterpret_cast<const uint4 *>(a.in_pool + E.off_draw);  // PE: 4 reads x (f0 | f1 << 16)
   // PE: the event's fixed-point score table (2 x il int32) sits in the chain's LDS slice: a per-read
   // gather from L2 would cost more than the whole rest of the Gibbs step
-  int32_t *lds_tab = reinterpret_cast<int32_t *>(smem_k2 + ((a.il * 8 + 15) & ~15)) +
-                     (static_cast<size_t>(threadIdx.x >> 6) * CPW + grp) * (2 * a.il);
+  int32_t *lds_tab = reinterpret_cast<int32_t *>(smem_k2 + (((PEW ? tab_n : a.il) * 8 + 15) & ~15)) +
+                     (static_cast<size_t>(threadIdx.x >> 6) * CPW + grp) * tab_n;
   if (PE) {
     const int32_t *sfix = reinterpret_cast<const int32_t *>(a.in_pool + E.off_sfix);
-    for (int i = sub; i < 2 * a.il; i += G) lds_tab[i] = sfix[i];
+    for (int i = sub; i < tab_n; i += G) lds_tab[i] = i < 2 * a.il ? sfix[i] : 0;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   }
+  // MODE 2 reads the LDS by byte address (no symbol arithmetic, never a flat access): the dynamic LDS -- the
+  // only LDS of this kernel -- starts at 0
+  if (PEW && static_cast<uint32_t>(reinterpret_cast<uintptr_t>(smem_k2)) != 0u) __builtin_trap();
+  const uint32_t tab_addr = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds_tab));
+  const uint4 *denseq = reinterpret_cast<const uint4 *>(a.in_pool + (PEW ? E.off_dense : E.off_draw));
   PsiTerms cur;
   double alpha = 0.0;
 
@@ -317,34 +333,57 @@ __global__ __launch_bounds__(64 * WPB, 2) __attribute__((amdgpu_waves_per_eu(2, 
 #endif
   auto gibbs = [&](uint32_t iter) {
     if (PEW) {
-      // MODE 2: no drawing read of the event touches a non-finite score (host.cpp pe_delta), so the loop
-      // carries no "bad" bookkeeping, and the next quad's fragment indices are fetched one trip ahead
+      // MODE 2: no drawing read of the event touches a non-finite score (host.cpp pe_delta): no "bad"
+      // bookkeeping; dense records (device.hpp pe_k2_entries): one index per (read, isoform) serves the
+      // probability and the score, lanes beyond the last quad work on the quad of padding reads behind it
+      // (weight 0 against a positive one: never isoform 0, score 0) -- no range tests; the next quad's
+      // record is fetched one trip ahead.  Per read: two SDWA shifts, two LDS reads by byte address, the
+      // reference's arithmetic (miso_paired.c:11-22, 64-68), one select, one add-with-carry for the count,
+      // one 64-bit multiply-add for the score sum.
       const uint32_t n0r0 = rng.p1hi ^ iter ^ k0;
       const int nq = (n_draw + 3) >> 2;
       const double x0 = cur.x0, x1 = cur.x1;
       int d0 = 0; int64_t acc = 0;
-      const int q_last = max(nq - 1, 0);
-      uint4 fn = fragq[min(sub, q_last)];
+      const uint32_t three = 3u;
+      auto rec_at = [&](int q) __attribute__((always_inline)) { return denseq[(lane_used && q < nq) ? q : nq]; };
+      uint4 fn = rec_at(sub);
       for (int j = 0; j < 2 * trips + 1; j++) {
         const int q = sub + j * G;
         const uint4 f = fn;
-        fn = fragq[min(q + G, q_last)];
+        fn = rec_at(q + G);
         const miso_u32x4 u = philox_gibbs<true>(rng, static_cast<uint32_t>(q), n0r0);
-        const int left = (q < nq && lane_used) ? n_draw - 4 * q : 0;   // reads of this quad that exist
         const uint32_t ff[4] = {f.x, f.y, f.z, f.w};
+        uint32_t o0[4], sel[4]; double c0[4], rnd[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-          const bool valid = left > r;
-          const uint32_t fv = valid ? ff[r] : 0u;                  // reads past the end: a valid address
-          const uint32_t f0 = fv & 0xFFFFu, f1 = fv >> 16;
-          // miso_paired.c:11-22, 64-68.  (Dropping the "0.0 +" -- an identity here -- was measured 6 % SLOWER:
-          // 256 ms vs 241 ms per launch; the add seems to give the scheduler a better order.)
-          const double c0 = 0.0 + x0 * lds_fp[f0];
-          const double T = c0 + x1 * lds_fp[f1];
-          const bool p0 = miso_u01(u.v[r]) * T < c0;
-          const int32_t v = lds_tab[p0 ? f0 : a.il + f1];
-          acc += valid ? v : 0;
-          d0 += (valid & p0) ? 1 : 0;
+          uint32_t o1;   // 8 x index
+          asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(o0[r]) : "v"(three), "v"(ff[r]));
+          asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(o1) : "v"(three), "v"(ff[r]));
+          // (Dropping the "0.0 +" -- an identity here -- was measured 6 % SLOWER in the loop's first form;
+          // the add seems to give the scheduler a better order.)
+          c0[r] = 0.0 + x0 * k2_lds_f64(o0[r]);
+          const double T = c0[r] + x1 * k2_lds_f64(o1);
+          rnd[r] = miso_u01(u.v[r]) * T;
+          sel[r] = o1;
+        }
+        {   // the four compares first: a VALU read of an SGPR must stay two instructions behind the compare that wrote it
+          uint64_t m0, m1, m2, m3, junk;
+          asm("v_cmp_lt_f64_e64 %5, %10, %14\n\tv_cmp_lt_f64_e64 %6, %11, %15\n\tv_cmp_lt_f64_e64 %7, %12, %16\n\tv_cmp_lt_f64_e64 %8, %13, %17\n\t"
+              "v_cndmask_b32_e64 %0, %0, %18, %5\n\tv_addc_co_u32_e64 %4, %9, %4, 0, %5\n\t"
+              "v_cndmask_b32_e64 %1, %1, %19, %6\n\tv_addc_co_u32_e64 %4, %9, %4, 0, %6\n\t"
+              "v_cndmask_b32_e64 %2, %2, %20, %7\n\tv_addc_co_u32_e64 %4, %9, %4, 0, %7\n\t"
+              "v_cndmask_b32_e64 %3, %3, %21, %8\n\tv_addc_co_u32_e64 %4, %9, %4, 0, %8"
+              : "+v"(sel[0]), "+v"(sel[1]), "+v"(sel[2]), "+v"(sel[3]), "+v"(d0), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3), "=&s"(junk)
+              : "v"(rnd[0]), "v"(rnd[1]), "v"(rnd[2]), "v"(rnd[3]), "v"(c0[0]), "v"(c0[1]), "v"(c0[2]), "v"(c0[3]),
+                "v"(o0[0]), "v"(o0[1]), "v"(o0[2]), "v"(o0[3]));
+        }
+        int32_t v[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) v[r] = k2_lds_i32(tab_addr + (sel[r] >> 1));
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          uint64_t junk;
+          asm("v_mad_i64_i32 %0, %1, %2, 1, %0" : "+v"(acc), "=s"(junk) : "v"(v[r]));
         }
       }
       if (POW2) {

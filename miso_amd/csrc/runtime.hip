@@ -329,10 +329,10 @@ void miso_batch::upload(int dev) {
   // (paired-end: the events sampler_k2's MODE 2 can take come first, MISO_NO_PE_DELTA=1 sends all to MODE 1)
   const bool use_delta = std::getenv("MISO_NO_PE_DELTA") == nullptr;
   std::stable_sort(k2.begin(), k2.end(), [&](int x, int y) {
-    const bool dx = use_delta && events[x].pe_delta, dy = use_delta && events[y].pe_delta;
+    const bool dx = use_delta && events[x].pe_delta && !events[x].draw_dense.empty(), dy = use_delta && events[y].pe_delta && !events[y].draw_dense.empty();
     return dx != dy ? dx : events[x].n_draw > events[y].n_draw; });
   n_k2w = 0;
-  for (int i : k2) n_k2w += (use_delta && events[i].pe_delta) ? 1 : 0;
+  for (int i : k2) n_k2w += (use_delta && events[i].pe_delta && !events[i].draw_dense.empty()) ? 1 : 0;
   // the general kernel's wavefronts loop to their largest K and longest draw list: group alike
   std::stable_sort(gen.begin(), gen.end(), [&](int x, int y) {
     return events[x].K != events[y].K ? events[x].K > events[y].K : events[x].n_draw > events[y].n_draw; });
@@ -386,7 +386,9 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   bool k2_pair = k2_pair_env;
   // paired-end: the first n_k2w slots go to MODE 2 (no drawing read with a non-finite score), the rest to
   // MODE 1; single-end: everything is "the rest".  Both keep the event's score table (2 il int32) per chain in LDS.
-  const size_t k2w_tab = k2_tab;
+  // MODE 2 reads the dense records (device.hpp pe_k2_entries): both tables with 2 il + 2 entries
+  const size_t k2w_fp = p.paired ? align_up(static_cast<size_t>(pe_k2_entries(static_cast<int>(fd.prob.size()))) * 8, 16) : 0;
+  const size_t k2w_tab = p.paired ? static_cast<size_t>(pe_k2_entries(static_cast<int>(fd.prob.size()))) * 4 : 0;
   auto launch_k2 = [&](KernelArgs ka, int G, hipStream_t st, bool wpart = false) {
     const int first = wpart ? 0 : n_k2w, count = wpart ? n_k2w : n_k2 - n_k2w;
     const long chains = static_cast<long>(count) * p.noChains;
@@ -400,7 +402,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     const bool pair = k2_pair;
     ka.pair_waves = pair ? 1 : 0;
     const unsigned grid = static_cast<unsigned>(pair ? (waves + 7) / 8 : (waves + 3) / 4);
-    const size_t k2_lds = k2_fp + 4 * static_cast<size_t>(cpw) * (wpart ? k2w_tab : k2_tab);
+    const size_t k2_lds = (wpart ? k2w_fp : k2_fp) + 4 * static_cast<size_t>(cpw) * (wpart ? k2w_tab : k2_tab);
     if (k2_lds > 160 * 1024) MISO_FAIL(MISO_UNIMPLEMENTED, "Fragment-length distribution too wide for the two-isoform paired-end kernel");
 #define MISO_K2_LAUNCH(GG)                                                                              \
   case GG:                                                                                             \
@@ -577,7 +579,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   if (n_k2w > 0) {   // MODE 2: two workgroups per CU may share the LDS (80 KB each)
     const long chains = static_cast<long>(n_k2w) * p.noChains;
     const int maxq = (events[k2_first_event()].n_draw + 3) / 4;
-    const int max_cpw = std::max<int>(1, static_cast<int>((LDS_MAX - k2_fp) / (4 * k2w_tab)));
+    const int max_cpw = std::max<int>(1, static_cast<int>((LDS_MAX - k2w_fp) / (4 * k2w_tab)));
     if (const char *env = std::getenv("MISO_LANES_PER_CHAIN")) k2w_G = std::atoi(env);
     else k2w_G = choose_lanes_per_chain(chains, maxq, slots_for(chains), max_cpw);
     while (k2w_G < 64 && static_cast<size_t>(64 / k2w_G) > static_cast<size_t>(max_cpw)) k2w_G *= 2;   // a forced choice never exceeds the LDS
@@ -709,7 +711,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     if (count <= 0) continue;
     // slot order = events by drawing reads, descending, each with its noChains chains
     std::vector<int> nd;
-    for (const PackedEvent &e : events) if (e.K == 2 && (use_delta && e.pe_delta) == wpart) nd.push_back(e.n_draw);
+    for (const PackedEvent &e : events) if (e.K == 2 && (use_delta && e.pe_delta && !e.draw_dense.empty()) == wpart) nd.push_back(e.n_draw);
     std::sort(nd.begin(), nd.end(), [](int x, int y) { return x > y; });
     const int C = p.noChains, cpw = 64 / k2G;
     const long chains = static_cast<long>(count) * C;
