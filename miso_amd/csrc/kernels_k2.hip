@@ -217,6 +217,12 @@ __device__ __forceinline__ void vec_eval4(F f, double a0, double a1, double a2, 
 // (Tried and dropped: per-iteration weight tables w_k[f] = psi_k fp[f] per chain plus a per-read score
 // difference -- 17 % fewer VALU per read, but 3.9 KB of LDS per chain instead of 1.9 KB and 8 B instead of
 // 4 B per read and iteration from L2 / MALL made it 7 % SLOWER: profiles/r02_pe_k2_modes.txt.)
+#ifndef MISO_K2_PE_UNROLL
+#define MISO_K2_PE_UNROLL 1
+#endif
+#ifndef MISO_K2_PE_IDENT
+#define MISO_K2_PE_IDENT 1
+#endif
 typedef const __attribute__((address_space(3))) double *k2_lds_cdp;
 typedef const __attribute__((address_space(3))) int32_t *k2_lds_cip;
 __device__ __forceinline__ double k2_lds_f64(uint32_t addr) { return *reinterpret_cast<k2_lds_cdp>(static_cast<uintptr_t>(addr)); }
@@ -347,6 +353,7 @@ __global__ __launch_bounds__(64 * WPB, 2) __attribute__((amdgpu_waves_per_eu(2, 
       const uint32_t three = 3u;
       auto rec_at = [&](int q) __attribute__((always_inline)) { return denseq[(lane_used && q < nq) ? q : nq]; };
       uint4 fn = rec_at(sub);
+#pragma unroll MISO_K2_PE_UNROLL
       for (int j = 0; j < 2 * trips + 1; j++) {
         const int q = sub + j * G;
         const uint4 f = fn;
@@ -361,7 +368,11 @@ __global__ __launch_bounds__(64 * WPB, 2) __attribute__((amdgpu_waves_per_eu(2, 
           asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(o1) : "v"(three), "v"(ff[r]));
           // (Dropping the "0.0 +" -- an identity here -- was measured 6 % SLOWER in the loop's first form;
           // the add seems to give the scheduler a better order.)
+#if MISO_K2_PE_IDENT
           c0[r] = 0.0 + x0 * k2_lds_f64(o0[r]);
+#else
+          c0[r] = x0 * k2_lds_f64(o0[r]);
+#endif
           const double T = c0[r] + x1 * k2_lds_f64(o1);
           rnd[r] = miso_u01(u.v[r]) * T;
           sel[r] = o1;

@@ -6,7 +6,7 @@ set -u
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 OUT=$PWD/gpurun_out
 mkdir -p $OUT
-for tag_args in "se_k2:" "se_k2_defaults:--chains 6 --iters 5000 --burn 500 --lag 10" "se_k5:--K 5" "se_k10:--K 10" "pe_k2:--paired" ${EXTRA_TAGS:-}; do
+for tag_args in "se_k2:" "se_k2_defaults:--chains 6 --iters 5000 --burn 500 --lag 10" "se_k5:--K 5" "se_k10:--K 10" "pe_k2:--paired" "pe_k5:--paired --K 5" "pe_k10:--paired --K 10 --events 20000"; do
   tag=${tag_args%%:*}; args=${tag_args#*:}
   bash tools/profile.sh $tag $args > /dev/null 2>&1
   python3 tools/prof_summary.py $OUT/prof_$tag $OUT/r02_${tag}_summary.txt > $OUT/r02_${tag}_summary.log 2>&1
