@@ -86,20 +86,24 @@ struct KernelArgs {
   uint32_t first_event_id;
   int32_t pair_waves;       // sampler_k2 with 8 wavefronts per workgroup: wavefronts w and w + 4 (one SIMD)
                             // take the heaviest and the lightest remaining chain group (runtime.hip)
-  int32_t pe_dense;         // sampler_grp PE: rows of the replicated fragment-probability table in LDS (0 = plain
-                            // table, the quad loops of pe_quads); every event of the launch has dense records
+  int32_t pe_dense;         // sampler_grp PE: every event of the launch has dense records (pe_dense) and the LDS
+                            // probability table carries the two extra entries PE_ZERO, PE_ONE (0 = the quad loops of pe_quads)
   int32_t pe_force_exact;   // tests: every read through pe_dense's exact (cold) scan
   uint64_t seed;
 };
 
 constexpr uint64_t NO_TRACE = ~0ull;
 constexpr uint64_t NO_DENSE = ~0ull;
-// Paired-end dense records (host.cpp pack_event_masks -> kernels_grp.inl pe_dense).  Index space: isoform k,
-// fragment-length index f -> k * il2 + f with il2 = il + 2; two more entries per isoform: PE_ZERO
-// (incompatible: probability -0.0, never picked) and PE_ONE (probability 1, score 0: the padding reads
-// that complete the last quad always pick isoform 0).  One quad = 4 reads x K u16 indices, then 4 u16 of
-// flags (word 0: bit j set when read j has MORE than two compatible isoforms), 2K + 2 dwords.  After the
-// event's last quad comes one more made of padding reads only.
+// Paired-end dense records (host.cpp pack_event_masks -> kernels_grp.inl pe_dense), available when the
+// fragment-length range has at most 254 values (il + 2 <= 256: mean +- 4 sd up to sd = 31; wider ranges take
+// the plain records' loops).  One BYTE per (read, isoform): the fragment-length index f, or PE_ZERO = il for an
+// incompatible isoform (probability -0.0: never picked), or PE_ONE = il + 1 for isoform 0 of a padding read
+// (probability 1: always picked, score 0) -- the LDS probability table has il2 = il + 2 entries, the event's
+// score table (sfix_dense) K rows of il2.  One quad = 4 reads x K bytes (byte h = j K + k), then one dword of
+// flags (bit j: read j has MORE than two compatible isoforms): K + 1 dwords.  What a chain streams per
+// iteration is half of the u16 records' bytes -- the loop is bound by what crosses from the infinity cache into
+// the L2s (~5 TB/s, profiles/r02_pe_k5_summary.txt).  After the event's last quad comes one more made of
+// padding reads only (the lanes beyond the end work on it).
 constexpr int PE_DENSE_KMAX = 20;
 // Two isoforms (sampler_k2 MODE 2), same idea: one u32 per read, f0 | (il + f1) << 16, into tables of
 // 2 il + 2 entries -- probabilities [fp, fp, 0.0, 1.0], scores [isoform 0, isoform 1, 0, 0] -- so that one index
@@ -107,7 +111,7 @@ constexpr int PE_DENSE_KMAX = 20;
 // positive one, never isoform 0, score 0.  Quads of four reads, one quad of padding reads after the last.
 MISO_DEVHOST_EARLY inline int pe_k2_entries(int il) { return 2 * il + 2; }
 MISO_DEVHOST_EARLY inline int pe_dense_il2(int il) { return il + 2; }
-MISO_DEVHOST_EARLY inline int pe_dense_quad_u16(int K) { return 4 * K + 4; }
+MISO_DEVHOST_EARLY inline int pe_dense_quad_dwords(int K) { return K + 1; }
 constexpr int MAX_DRAW_CLASSES = 64;  // single-end: per-class integer thresholds up to this many classes (if the LDS slice fits)
 
 // LDS bytes of one chain's slice in sampler_grp (layout: kernels_grp.hip `carve`): isoform stride ks

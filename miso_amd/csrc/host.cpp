@@ -488,27 +488,28 @@ PackedEvent pack_event_masks(const miso_params_t &p, const FragmentDist *fd, int
       e.draw_dense[2 * r + 1] = static_cast<uint16_t>(real ? il + e.draw_frag[static_cast<size_t>(r) * 2 + 1] : 2 * il + 1);
     }
   }
-  if (p.paired && K >= 3 && K <= PE_DENSE_KMAX && static_cast<size_t>(K) * pe_dense_il2(il) <= 0xFFFFu) {
-    // Quad records of pe_dense (device.hpp): every (read, isoform) as an index into K replicated
-    // tables -- no validity tests left in the read loop -- and one flag per read: which of the
-    // reference's two stopping rules applies (miso_paired.c:64-75: exactly two compatible isoforms or more).
-    const int il2 = pe_dense_il2(il), qw = pe_dense_quad_u16(K);
+  if (p.paired && K >= 3 && K <= PE_DENSE_KMAX && pe_dense_il2(il) <= 256) {
+    // Quad records of pe_dense (device.hpp): every (read, isoform) as one byte -- no validity tests left in
+    // the read loop -- and one flag per read: which of the reference's two stopping rules applies
+    // (miso_paired.c:64-75: exactly two compatible isoforms or more).
+    const int il2 = pe_dense_il2(il), qd = pe_dense_quad_dwords(K);
     const int nq = (e.n_draw + 3) / 4 + 1;   // + one quad of padding reads: what the lanes beyond the last quad process
-    e.draw_dense.assign(static_cast<size_t>(nq) * qw, 0);
+    e.draw_dense.assign(static_cast<size_t>(nq) * qd * 2, 0);
+    uint8_t *bytes = reinterpret_cast<uint8_t *>(e.draw_dense.data());
     e.dense_nobad = true;
     for (int r = 0; r < 4 * nq; r++) {
-      uint16_t *rec = e.draw_dense.data() + static_cast<size_t>(r / 4) * qw;
+      uint8_t *quad = bytes + static_cast<size_t>(r / 4) * qd * 4;
       int nv = 0;
       for (int k = 0; k < K; k++) {
         const uint16_t f = r < e.n_draw ? e.draw_frag[static_cast<size_t>(r) * K + k] : FRAG_NONE;
-        int idx = k * il2 + il;                              // PE_ZERO
+        int idx = il;                                        // PE_ZERO
         if (f != FRAG_NONE) {
-          idx = k * il2 + f; nv++;
+          idx = f; nv++;
           if (e.sfix_table[static_cast<size_t>(k) * il + f] == SFIX_BAD) e.dense_nobad = false;
         } else if (r >= e.n_draw && k == 0) idx = il + 1;    // PE_ONE: a padding read picks isoform 0
-        rec[(r % 4) * K + k] = static_cast<uint16_t>(idx);
+        quad[(r % 4) * K + k] = static_cast<uint8_t>(idx);
       }
-      if (nv > 2) rec[4 * K] |= static_cast<uint16_t>(1u << (r % 4));
+      if (nv > 2) quad[4 * K] |= static_cast<uint8_t>(1u << (r % 4));
     }
     e.sfix_dense.assign(static_cast<size_t>(K) * il2, 0);
     for (int k = 0; k < K; k++)

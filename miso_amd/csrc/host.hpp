@@ -109,8 +109,9 @@ struct PackedEvent {
   std::vector<int32_t> sfix_table;      // paired-end: K x il fixed-point isoscores
   bool pe_delta = false;                // paired-end, two isoforms: every drawing read's two scores are finite
   // paired-end, 3 <= K <= PE_DENSE_KMAX (device.hpp): the drawing reads as quad records for pe_dense
-  // (kernels_grp.inl) -- indices k * (il + 2) + f, flags -- and the scores in that index space
-  std::vector<uint16_t> draw_dense;     // n_quads x (4K + 4); empty = not available
+  // (kernels_grp.inl) -- one byte per (read, isoform), flags; two isoforms: sampler_k2 MODE 2's u16 pairs --
+  // and the scores in that index space (layouts: device.hpp)
+  std::vector<uint16_t> draw_dense;     // raw little-endian storage; empty = not available
   std::vector<int32_t> sfix_dense;      // K x (il + 2)
   bool dense_nobad = false;             // no compatible (read, isoform) of a drawing read has a non-finite score
   std::vector<int32_t> fixed_ass;       // N: -1 / isoform for fixed reads, -2 for drawing reads

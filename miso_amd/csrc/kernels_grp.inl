@@ -471,8 +471,10 @@ __device__ __forceinline__ void pe_quads(const uint16_t *frags, const double *ps
 
 // ---- paired-end read loop over the DENSE records (device.hpp; host.cpp pack_event_masks) ----
 // One lane = one quad of reads per trip, as pe_quads, but nothing in the loop asks whether an isoform is
-// compatible: the record's index of an incompatible (read, isoform) points at a probability of -0.0.
-//   * cumulative weights c_k = c_(k-1) + psi_k fp[idx_k] start from -0.0: the incompatible isoforms in
+// compatible: the record's byte for an incompatible (read, isoform) points at a probability of -0.0.
+//   * per (read, isoform) two SDWA instructions on the record's byte: 8 x f (the LDS address of the
+//     probability) and k il2 + f (the index of the score);
+//   * cumulative weights c_k = c_(k-1) + psi_k fp[f_k] start from -0.0: the incompatible isoforms in
 //     front of the first compatible one keep c_k = -0.0, every other c_k has exactly the bits of the
 //     reference's running sum (adding -0.0 changes nothing; -0.0 + w = w, also for w = +0.0);
 //   * the reference's scan (miso_paired.c:11-22, 64-75) stops at the first compatible k with `rnd < c_k`
@@ -481,7 +483,7 @@ __device__ __forceinline__ void pe_quads(const uint16_t *frags, const double *ps
 //     "isoform k is passed over" is  bits(rnd) - adj >= bits(c_k),  adj = 0 / 1 for the two rules (rnd = +0
 //     with adj = 1 gives -1: stops at the first compatible isoform, as `!(0 > c)` does);
 //   * the tests are monotone in k (an incompatible isoform repeats its predecessor's c), so the pick is
-//     the first k whose test holds: its table index by a chain of selects, the per-isoform counts from
+//     the first k whose test holds: its score index by a chain of selects, the per-isoform counts from
 //     the running totals "reads that passed over k" (no per-read counter update, no atomics in the loop);
 //   * all of this is exact whenever rnd < T (then T > 0 and the scan cannot run past the last compatible
 //     isoform).  Anything else -- T = 0, subnormal or non-finite weights -- takes pe_pick_exact, the
@@ -492,14 +494,14 @@ __device__ __attribute__((noinline)) int pe_pick_exact(const uint16_t *rec, int 
   double T = 0.0; int nv = 0;
   for (int k = 0; k < K; k++) {
     const int idx = rec[k];
-    if (idx - k * il2 != zero) { T = T + psi[k] * fp_rep[idx]; nv++; }
+    if (idx - k * il2 != zero) { T = T + psi[k] * fp_rep[idx - k * il2]; nv++; }
   }
   const double rnd = miso_u01(word) * T;
   double cum = 0.0; int seen = 0, sel = -1;
   for (int k = 0; k < K; k++) {
     const int idx = rec[k];
     if (idx - k * il2 == zero) continue;
-    cum = cum + psi[k] * fp_rep[idx];
+    cum = cum + psi[k] * fp_rep[idx - k * il2];
     const bool stop = two ? (seen == 0 ? (rnd < cum) : true) : !(rnd > cum);
     seen++;
     if (sel < 0 && (stop || seen == nv)) sel = k;
@@ -513,13 +515,21 @@ typedef const __attribute__((address_space(3))) double *lds_cdp;
 typedef const __attribute__((address_space(3))) int32_t *lds_cip;
 __device__ __forceinline__ double lds_f64(uint32_t addr) { return *reinterpret_cast<lds_cdp>(static_cast<uintptr_t>(addr)); }
 __device__ __forceinline__ int32_t lds_i32(uint32_t addr) { return *reinterpret_cast<lds_cip>(static_cast<uintptr_t>(addr)); }
-// 8 x (16-bit half HALF of w): one SDWA shift instead of shift + mask
-template <int HALF> __device__ __forceinline__ uint32_t half_x8(uint32_t w, uint32_t three) {
+// 8 x (byte B of w): one SDWA shift instead of shift + mask; (byte B of w) + add: one SDWA add
+template <int B> __device__ __forceinline__ uint32_t byte_x8(uint32_t w, uint32_t three) {
   uint32_t r;
-  if constexpr (HALF == 0)
-    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(three), "v"(w));
-  else
-    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(three), "v"(w));
+  if constexpr (B == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(three), "v"(w));
+  else if constexpr (B == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(three), "v"(w));
+  else if constexpr (B == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(three), "v"(w));
+  else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(three), "v"(w));
+  return r;
+}
+template <int B> __device__ __forceinline__ uint32_t byte_plus(uint32_t w, uint32_t add) {
+  uint32_t r;
+  if constexpr (B == 0) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(r) : "v"(w), "s"(add));
+  else if constexpr (B == 1) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(r) : "v"(w), "s"(add));
+  else if constexpr (B == 2) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(r) : "v"(w), "s"(add));
+  else asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(r) : "v"(w), "s"(add));
   return r;
 }
 // N (1..4) stopping tests of one read: isoform k + i is passed over when rb >= cb[i]; then the pick's table
@@ -580,7 +590,7 @@ __device__ __forceinline__ void pe_dense(const uint32_t *fq, const double *psi, 
                                          bool write_ass, int nqw, int n_quads, int n_draw, int sub,
                                          const GibbsRng &rng, uint32_t n0r0, bool force_exact,
                                          int64_t &acc_out, int &bad_out) {
-  constexpr int ND = 2 * KK + 2;   // dwords per quad
+  constexpr int ND = KK + 1;   // dwords per quad: 4 KK index bytes, one dword of flags
   double ps[KK];
 #pragma unroll
   for (int k = 0; k < KK; k++) ps[k] = psi[k];
@@ -590,10 +600,13 @@ __device__ __forceinline__ void pe_dense(const uint32_t *fq, const double *psi, 
   for (int k = 0; k < KK - 1; k++) over[k] = 0;
   const uint32_t three = 3u;
   const unsigned char *stg = reinterpret_cast<const unsigned char *>(stab_glob);
-  auto score = [&](uint32_t fsel) __attribute__((always_inline)) {   // fsel = 8 x index
-    if constexpr (STAB_LDS) return lds_i32(stab_lds + (fsel >> 1));
-    else return *reinterpret_cast<const int32_t *>(stg + (fsel >> 1));
+  auto score = [&](uint32_t pk) __attribute__((always_inline)) {   // pk = k il2 + f: index into the score table
+    if constexpr (STAB_LDS) return lds_i32(stab_lds + (pk << 2));
+    else return *reinterpret_cast<const int32_t *>(stg + (pk << 2));
   };
+  uint32_t krow[KK];   // k il2 (uniform)
+#pragma unroll
+  for (int k = 0; k < KK; k++) krow[k] = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(k * il2));
   auto load = [&](uint32_t (&r)[ND], int q) __attribute__((always_inline)) {
     const uint32_t *src = fq + static_cast<uint32_t>(min(q, n_quads)) * static_cast<uint32_t>(ND);
 #pragma unroll
@@ -621,25 +634,28 @@ __device__ __forceinline__ void pe_dense(const uint32_t *fq, const double *psi, 
       }
     }
   };
-  const uint32_t neutral = static_cast<uint32_t>(il2 - 1) << 3;   // PE_ONE of isoform 0: score 0
+  const uint32_t neutral = static_cast<uint32_t>(il2 - 1);        // PE_ONE of isoform 0: score 0
   auto process = [&](const uint32_t (&cur)[ND], int q) __attribute__((always_inline)) {
     const miso_u32x4 u = philox_gibbs<true>(rng, static_cast<uint32_t>(q), n0r0);
-    const uint32_t flags = cur[2 * KK];
+    const uint32_t flags = cur[KK];
     bool okj[4];
     uint32_t fs[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      uint32_t off[KK]; int64_t cb[KK];
+      uint32_t pk[KK]; int64_t cb[KK];
       double T = -0.0;
 #pragma unroll
       for (int k = 0; k < KK; k++) {
         const int h = j * KK + k;
-#if MISO_PE_SDWA
-        off[k] = (h & 1) ? half_x8<1>(cur[h >> 1], three) : half_x8<0>(cur[h >> 1], three);
-#else
-        off[k] = (h & 1) ? ((cur[h >> 1] >> 13) & 0x7FFF8u) : ((cur[h >> 1] << 3) & 0x7FFF8u);
-#endif
-        T = T + ps[k] * lds_f64(off[k]);
+        const uint32_t w = cur[h >> 2];
+        uint32_t off;
+        switch (h & 3) {   // h is a compile-time constant after unrolling
+        case 0: off = byte_x8<0>(w, three); pk[k] = byte_plus<0>(w, krow[k]); break;
+        case 1: off = byte_x8<1>(w, three); pk[k] = byte_plus<1>(w, krow[k]); break;
+        case 2: off = byte_x8<2>(w, three); pk[k] = byte_plus<2>(w, krow[k]); break;
+        default: off = byte_x8<3>(w, three); pk[k] = byte_plus<3>(w, krow[k]); break;
+        }
+        T = T + ps[k] * lds_f64(off);
         cb[k] = __double_as_longlong(T);
       }
       const double rnd = miso_u01(u.v[j]) * T;
@@ -647,19 +663,19 @@ __device__ __forceinline__ void pe_dense(const uint32_t *fq, const double *psi, 
       okj[j] = ok;
       int64_t rb = __double_as_longlong(rnd) - static_cast<int64_t>((flags >> j) & 1u);
       rb = ok ? rb : INT64_MIN;     // not exact here: pe_pick_exact below (and what this makes the tests do is taken back there)
-      uint32_t fsel = off[0];
+      uint32_t fsel = pk[0];
 #if MISO_PE_ASM_TESTS
-      pe_all_tests<KK>(rb, cb, off, fsel, over);
+      pe_all_tests<KK>(rb, cb, pk, fsel, over);
 #else
 #pragma unroll
       for (int k = 0; k < KK - 1; k++) {
         const bool pass = rb >= cb[k];
         over[k] += pass ? 1 : 0;
-        fsel = pass ? off[k + 1] : fsel;
+        fsel = pass ? pk[k + 1] : fsel;
       }
 #endif
       if (WRITE) {
-        if (write_ass && ok && 4 * q + j < n_draw) drawass[4 * q + j] = static_cast<uint8_t>((fsel >> 3) / static_cast<uint32_t>(il2));
+        if (write_ass && ok && 4 * q + j < n_draw) drawass[4 * q + j] = static_cast<uint8_t>(fsel / static_cast<uint32_t>(il2));
       }
       fs[j] = BADCHK ? (ok ? fsel : neutral) : fsel;
     }
@@ -672,7 +688,10 @@ __device__ __forceinline__ void pe_dense(const uint32_t *fq, const double *psi, 
 #pragma unroll 1
       for (int j = 0; j < 4; j++) {
         if (okj[j]) continue;   // the reference's scan as written
-        const uint16_t *rec = reinterpret_cast<const uint16_t *>(fq + static_cast<size_t>(min(q, n_quads)) * ND) + j * KK;
+        const uint8_t *rec8 = reinterpret_cast<const uint8_t *>(fq + static_cast<size_t>(min(q, n_quads)) * ND) + j * KK;
+        uint16_t rec[KK];   // k il2 + f, the index space of pe_pick_exact and the score table
+#pragma unroll 1
+        for (int k = 0; k < KK; k++) rec[k] = static_cast<uint16_t>(k * il2 + rec8[k]);
         const int sel = pe_pick_exact(rec, KK, il2, psi, fp_rep, ((flags >> j) & 1u) == 0, u.v[j]);
         // what the loop above did with rb = INT64_MIN: passed over the incompatible isoforms in front of the
         // first compatible one (their c is -0.0 = INT64_MIN) and took the score there
@@ -680,11 +699,11 @@ __device__ __forceinline__ void pe_dense(const uint32_t *fq, const double *psi, 
         while (lead < KK - 1 && rec[lead] == lead * il2 + il2 - 2) lead++;
 #pragma unroll
         for (int k = 0; k < KK - 1; k++) over[k] += ((k < sel) ? 1 : 0) - ((k < lead) ? 1 : 0);
-        const int32_t vx = score(static_cast<uint32_t>(rec[sel]) << 3);
+        const int32_t vx = score(rec[sel]);
         if (BADCHK) {
           if (vx == SFIX_BAD) bad = 1; else acc += vx;
         } else {
-          acc += static_cast<int64_t>(vx) - score(static_cast<uint32_t>(rec[lead]) << 3);
+          acc += static_cast<int64_t>(vx) - score(rec[lead]);
         }
         if (WRITE) { if (write_ass && 4 * q + j < n_draw) drawass[4 * q + j] = static_cast<uint8_t>(sel); }
       }

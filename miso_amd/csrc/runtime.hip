@@ -432,17 +432,13 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   // MISO_LDS_MAX_KB (experiments): a larger cap lets one workgroup per CU hold more chains per wavefront
   const size_t LDS_MAX = (std::getenv("MISO_LDS_MAX_KB") ? std::atoi(std::getenv("MISO_LDS_MAX_KB")) : 80) * 1024;
   const size_t fp_plain = p.paired ? align_up(fd.prob.size() * 8, 16) : 0;
-  // paired-end dense path (pe_dense): the probability table once per isoform of the launch, so that the
-  // records' indices address probabilities and scores alike; MISO_NO_PE_DENSE=1 (tests, A/B): the quad
-  // loops over the plain records
+  // paired-end dense path (pe_dense): byte records, the probability table with its two extra entries, the
+  // score table with rows of il + 2; MISO_NO_PE_DENSE=1 (tests, A/B): the quad loops over the plain records
   const bool dense_env = std::getenv("MISO_NO_PE_DENSE") == nullptr;
   const int il2 = pe_dense_il2(static_cast<int>(fd.prob.size()));
-  auto fp_rows = [&](const GenRun &run) {
-    return (p.paired && dense_env && run.dense && static_cast<size_t>(run.kmax) * il2 * 8 <= 48 * 1024) ? run.kmax : 0;
-  };
+  auto fp_rows = [&](const GenRun &run) { return (p.paired && dense_env && run.dense) ? 1 : 0; };
   auto fp_bytes_of = [&](const GenRun &run) {
-    const int rows = fp_rows(run);
-    return rows ? align_up(static_cast<size_t>(rows) * il2 * 8, 16) : fp_plain;
+    return fp_rows(run) ? align_up(static_cast<size_t>(il2) * 8, 16) : fp_plain;
   };
   struct GrpShape { int qs, ts; };
   auto grp_shape = [&](const GenRun &run) {
@@ -657,7 +653,8 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       // nine isoforms on (measured, pe_dense: K=10 19.5k -> 19.9k, K=20 7.35k -> 7.57k events/s; K=5 29.9k ->
       // 28.9k, K=3 53k -> 46k) and whenever 16 would leave the kernel's share of the device unfilled.
       bool found = false;
-      const bool pe32 = p.paired && (run.kc >= 12 || (chains + 3) / 4 < slots_for(chains));
+      // (a whole-gene mix -- several classes side by side -- runs 9 % faster with 32 everywhere: 14.4k -> 15.7k genes/s)
+      const bool pe32 = p.paired && (run.kc >= 12 || n_kernels > 1 || (chains + 3) / 4 < slots_for(chains));
       for (int g : {2, 4, 8, 16, 32}) {
         if (p.paired && g > 16 && found && !pe32) break;
         if (!grp_fits(run, sh, g)) continue;
