@@ -94,6 +94,19 @@ MISO_TAB miso_tab_qf[8] = { 2.04426310338993978564e-15, 1.4215117583164458887e-7
 MISO_DM uint64_t miso_d2u(double x) { uint64_t u; memcpy(&u, &x, 8); return u; }
 MISO_DM double miso_u2d(uint64_t u) { double x; memcpy(&x, &u, 8); return x; }
 MISO_DM double miso_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+/* fma(a, b, c) with c a table coefficient.  Device: c is wave-uniform and sits in an SGPR pair (scalar load);
+   written as the one instruction it is -- hipcc otherwise copies the coefficient into a VGPR pair first (two
+   v_mov_b32) to use the two-operand v_fmac_f64: three issue slots per Horner step instead of one, 22 of them
+   per exp / log call (a fifth of the Metropolis-Hastings step's VALU instructions).  Same fused operation. */
+#if defined(__HIP_DEVICE_COMPILE__)
+static __device__ __forceinline__ double miso_fma_tab(double a, double b, double c) {
+  double r;
+  __asm__("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+  return r;
+}
+#else
+#define miso_fma_tab miso_fma
+#endif
 
 /* 2^n for n in [-1022, 1023] */
 MISO_DM double miso_pow2i(int n) { return miso_u2d((uint64_t) (n + 1023) << 52); }
@@ -117,7 +130,7 @@ MISO_DM double miso_det_exp(double x) {
   {
     MISO_TAB_PTR te = MISO_TAB_REF(miso_tab_exp);
     p = te[0];
-    for (i = 1; i < 12; i++) p = miso_fma(p, r, te[i]);
+    for (i = 1; i < 12; i++) p = miso_fma_tab(p, r, te[i]);
   }
   p = miso_fma(p, r, 1.0);
   p = miso_fma(p, r, 1.0);
@@ -151,7 +164,7 @@ MISO_DM double miso_det_log(double x) {
   {
     MISO_TAB_PTR tl = MISO_TAB_REF(miso_tab_log);
     q = tl[0];
-    for (i = 1; i < 12; i++) q = miso_fma(q, z, tl[i]);
+    for (i = 1; i < 12; i++) q = miso_fma_tab(q, z, tl[i]);
   }
   R = z * q;                      /* log(1+f) = 2s + s*R = f - s*(f - R) */
   ed = (double) e;
