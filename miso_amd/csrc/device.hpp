@@ -89,6 +89,8 @@ struct KernelArgs {
   int32_t pe_dense;         // sampler_grp PE: every event of the launch has dense records (pe_dense) and the LDS
                             // probability table carries the two extra entries PE_ZERO, PE_ONE (0 = the quad loops of pe_quads)
   int32_t pe_force_exact;   // tests: every read through pe_dense's exact (cold) scan
+  int32_t mix_blocks;       // sampler_k2_mix<GA, GB>: the first mix_blocks workgroups run the first mix_slots events
+  int32_t mix_slots;        // with GA lanes per chain, the rest the remaining events with GB (runtime.hip)
   uint64_t seed;
 };
 

@@ -228,8 +228,10 @@ typedef const __attribute__((address_space(3))) int32_t *k2_lds_cip;
 __device__ __forceinline__ double k2_lds_f64(uint32_t addr) { return *reinterpret_cast<k2_lds_cdp>(static_cast<uintptr_t>(addr)); }
 __device__ __forceinline__ int32_t k2_lds_i32(uint32_t addr) { return *reinterpret_cast<k2_lds_cip>(static_cast<uintptr_t>(addr)); }
 
+// The kernel's body: workgroup block_x of grid_x (what blockIdx.x / gridDim.x are for sampler_k2 itself;
+// sampler_k2_mix runs two bodies of different lanes per chain side by side in one launch).
 template <int G, int MODE, int WPB>
-__global__ __launch_bounds__(64 * WPB, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void sampler_k2(const KernelArgs a) {
+__device__ __forceinline__ void k2_body(const KernelArgs &a, unsigned block_x, unsigned grid_x) {
   constexpr bool PE = MODE != 0;
   constexpr bool PEW = MODE == 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_k2[];
@@ -256,11 +258,11 @@ __global__ __launch_bounds__(64 * WPB, 2) __attribute__((amdgpu_waves_per_eu(2, 
   const int sub = lane_used ? lane - base_lane : 0;
   const int role = sub % NR;
   const long n_chains = static_cast<long>(a.n_slots) * a.C;
-  long wave_id = static_cast<long>(blockIdx.x) * WPB + (threadIdx.x >> 6);
+  long wave_id = static_cast<long>(block_x) * WPB + (threadIdx.x >> 6);
   if (WPB == 8 && a.pair_waves) {
     const int w = threadIdx.x >> 6;
-    const long p = 4 * static_cast<long>(blockIdx.x) + (w & 3);          // pair index: heaviest first
-    wave_id = (w < 4) ? p : static_cast<long>(gridDim.x) * 8 - 1 - p;    // ... with the p-th lightest
+    const long p = 4 * static_cast<long>(block_x) + (w & 3);             // pair index: heaviest first
+    wave_id = (w < 4) ? p : static_cast<long>(grid_x) * 8 - 1 - p;       // ... with the p-th lightest
   }
   if (wave_id * CPW >= n_chains) return;  // whole wavefront idle
   long slot = wave_id * CPW + grp;
@@ -652,6 +654,38 @@ __global__ __launch_bounds__(64 * WPB, 2) __attribute__((amdgpu_waves_per_eu(2, 
     st->hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_REG_HW_ID, all 32 bits
   }
 }
+
+template <int G, int MODE, int WPB>
+__global__ __launch_bounds__(64 * WPB, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void sampler_k2(const KernelArgs a) {
+  k2_body<G, MODE, WPB>(a, blockIdx.x, gridDim.x);
+}
+
+// Single-end, one launch, two lane widths: the events with the most drawing reads (the first mix_slots of the
+// launch's list, which is ordered by them) get GA = GB + 1 lanes per chain, the rest GB.  The single-width
+// launch leaves wave slots empty whenever chains / (64 / G) is not the device's slot count (40 000 chains at
+// 21 per wavefront: 1905 of 2048) and its heaviest wavefront pair sets the kernel's duration; the split fills
+// every CU with one 8-wavefront workgroup and gives the heavy events shorter loops.  Two separate launches do
+// not work: the dispatcher then sometimes gives a CU to both kernels in turn (101 ms or 182 ms per launch,
+// at random).
+template <int GA, int GB>
+__global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void sampler_k2_mix(const KernelArgs a) {
+  KernelArgs part = a;
+  if (blockIdx.x < static_cast<unsigned>(a.mix_blocks)) {
+    part.n_slots = a.mix_slots;
+    k2_body<GA, 0, 8>(part, blockIdx.x, static_cast<unsigned>(a.mix_blocks));
+  } else {
+    part.slot_event = a.slot_event + a.mix_slots;
+    part.n_slots = a.n_slots - a.mix_slots;
+    k2_body<GB, 0, 8>(part, blockIdx.x - static_cast<unsigned>(a.mix_blocks), gridDim.x - static_cast<unsigned>(a.mix_blocks));
+  }
+}
+template __global__ void sampler_k2_mix<2, 1>(const KernelArgs);
+template __global__ void sampler_k2_mix<3, 2>(const KernelArgs);
+template __global__ void sampler_k2_mix<4, 3>(const KernelArgs);
+template __global__ void sampler_k2_mix<5, 4>(const KernelArgs);
+template __global__ void sampler_k2_mix<6, 5>(const KernelArgs);
+template __global__ void sampler_k2_mix<7, 6>(const KernelArgs);
+template __global__ void sampler_k2_mix<8, 7>(const KernelArgs);
 
 #define MISO_INSTANTIATE_K2(G)                                     \
   template __global__ void sampler_k2<G, 0, 4>(const KernelArgs); \

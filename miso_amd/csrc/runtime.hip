@@ -21,6 +21,7 @@ namespace miso {
 
 template <bool PE> __global__ void sampler_wave(const KernelArgs a);
 template <int G, int MODE, int WPB> __global__ void sampler_k2(const KernelArgs a);
+template <int GA, int GB> __global__ void sampler_k2_mix(const KernelArgs a);
 __global__ void compare_kernel(const DevEvent *, const unsigned char *, const DevEvent *, const unsigned char *, int, int,
                                double, const uint64_t *, double *);
 __global__ void match_kernel(const MatchEvent *, const int2 *, const int *, const int *, const int *, const int *,
@@ -389,8 +390,9 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   // MODE 2 reads the dense records (device.hpp pe_k2_entries): both tables with 2 il + 2 entries
   const size_t k2w_fp = p.paired ? align_up(static_cast<size_t>(pe_k2_entries(static_cast<int>(fd.prob.size()))) * 8, 16) : 0;
   const size_t k2w_tab = p.paired ? static_cast<size_t>(pe_k2_entries(static_cast<int>(fd.prob.size()))) * 4 : 0;
-  auto launch_k2 = [&](KernelArgs ka, int G, hipStream_t st, bool wpart = false) {
-    const int first = wpart ? 0 : n_k2w, count = wpart ? n_k2w : n_k2 - n_k2w;
+  auto launch_k2 = [&](KernelArgs ka, int G, hipStream_t st, bool wpart = false, int sub_first = 0, int sub_count = -1) {
+    int first = wpart ? 0 : n_k2w, count = wpart ? n_k2w : n_k2 - n_k2w;
+    if (sub_count >= 0) { first += sub_first; count = sub_count; }   // a part of the list (single-end split, below)
     const long chains = static_cast<long>(count) * p.noChains;
     if (chains <= 0) return;
     ka.slot_event = d_slots + first; ka.n_slots = count;
@@ -689,6 +691,49 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     const long waves = (static_cast<long>(n_k2 - n_k2w) * p.noChains + 64 / k2_G - 1) / (64 / k2_G);
     k2_pair = waves <= wave_slots || std::getenv("MISO_K2_PAIR") != nullptr;
   }
+  // ---- single-end two-isoform events in one launch with two lane widths (sampler_k2_mix, kernels_k2.hip) ----
+  // Only when the batch runs as ONE round of paired 8-wavefront workgroups (k2_pair) that does not fill the CUs:
+  // the heaviest events get G + 1 lanes per chain, as many of them as still leave one CU per workgroup.
+  // MISO_K2_MIX=0 switches it off (A/B), MISO_K2_SPLIT=n forces the number of events of the wide part.
+  int k2_mix = 0, k2_mix_blocks = 0;
+  {
+    const int count = n_k2 - n_k2w, C = p.noChains, G = k2_G;
+    const char *off = std::getenv("MISO_K2_MIX");
+    if (!p.paired && k2_pair && count > 0 && G >= 1 && G <= 7 && n_kernels <= 1 && !(off && std::atoi(off) == 0)) {
+      const int cus = wave_slots / 8, cpwA = 64 / (G + 1), cpwB = 64 / G;
+      auto blocks = [&](long chains, int cpw) { return static_cast<int>(((chains + cpw - 1) / cpw + 7) / 8); };
+      auto total = [&](int y) { return blocks(static_cast<long>(y) * C, cpwA) + blocks(static_cast<long>(count - y) * C, cpwB); };
+      if (total(0) < cus && blocks(static_cast<long>(count) * C, cpwB) * 8 >= wave_slots / 2) {
+        int y = 0;
+        if (const char *env = std::getenv("MISO_K2_SPLIT")) y = std::max(0, std::min(count - 1, std::atoi(env)));
+        else {
+          int lo = 0, hi = count - 1;          // total(y) grows with y: the largest y that still fits
+          while (lo < hi) { const int mid = (lo + hi + 1) / 2; if (total(mid) <= cus) lo = mid; else hi = mid - 1; }
+          y = lo;
+        }
+        if (y > 0 && total(y) <= cus) { k2_mix = y; k2_mix_blocks = blocks(static_cast<long>(y) * C, cpwA); }
+      }
+    }
+  }
+  auto k2_mix_name = [&](int G) { return "sampler_k2_mix<" + std::to_string(G + 1) + ", " + std::to_string(G) + ">"; };
+  auto launch_k2_mix = [&](KernelArgs ka, int G, hipStream_t st) {
+    const int first = n_k2w, count = n_k2 - n_k2w, C = p.noChains, cpwB = 64 / G;
+    ka.slot_event = d_slots + first; ka.n_slots = count;
+    ka.pair_waves = 1; ka.mix_slots = k2_mix; ka.mix_blocks = k2_mix_blocks;
+    const long wavesB = (static_cast<long>(count - k2_mix) * C + cpwB - 1) / cpwB;
+    const unsigned grid = static_cast<unsigned>(k2_mix_blocks + (wavesB + 7) / 8);
+    switch (G) {
+    case 1: hipLaunchKernelGGL((sampler_k2_mix<2, 1>), dim3(grid), dim3(512), 0, st, ka); break;
+    case 2: hipLaunchKernelGGL((sampler_k2_mix<3, 2>), dim3(grid), dim3(512), 0, st, ka); break;
+    case 3: hipLaunchKernelGGL((sampler_k2_mix<4, 3>), dim3(grid), dim3(512), 0, st, ka); break;
+    case 4: hipLaunchKernelGGL((sampler_k2_mix<5, 4>), dim3(grid), dim3(512), 0, st, ka); break;
+    case 5: hipLaunchKernelGGL((sampler_k2_mix<6, 5>), dim3(grid), dim3(512), 0, st, ka); break;
+    case 6: hipLaunchKernelGGL((sampler_k2_mix<7, 6>), dim3(grid), dim3(512), 0, st, ka); break;
+    default: hipLaunchKernelGGL((sampler_k2_mix<8, 7>), dim3(grid), dim3(512), 0, st, ka); break;
+    }
+    HIP_OK(hipGetLastError());
+  };
+
   // ---- what goes on the device, kernel by kernel (miso_batch_launch_stats) ----
   kernel_stats.clear();
   auto add_stat = [&](const std::string &name, double waves, double trips, double chains, double words) {
@@ -710,21 +755,31 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     std::vector<int> nd;
     for (const PackedEvent &e : events) if (e.K == 2 && (use_delta && e.pe_delta && !e.draw_dense.empty()) == wpart) nd.push_back(e.n_draw);
     std::sort(nd.begin(), nd.end(), [](int x, int y) { return x > y; });
-    const int C = p.noChains, cpw = 64 / k2G;
+    const int C = p.noChains;
     const long chains = static_cast<long>(count) * C;
     double trips = 0, words = 0;
     long waves = 0;
-    for (long s0 = 0; s0 < chains; s0 += cpw, waves++) {
-      int mx = 0, any_rem = 0;
-      for (long sl = s0; sl < std::min(chains, s0 + cpw); sl++) {
-        const int n = nd[sl / C];
-        mx = std::max(mx, n >> 2); any_rem |= n & 3;
-        words += n;
+    auto slice = [&](long c0, long c1, int G) {   // chains [c0, c1) of the list with G lanes per chain
+      const int cpw = 64 / G;
+      for (long s0 = c0; s0 < c1; s0 += cpw, waves++) {
+        int mx = 0, any_rem = 0;
+        for (long sl = s0; sl < std::min(c1, s0 + cpw); sl++) {
+          const int n = nd[sl / C];
+          mx = std::max(mx, n >> 2); any_rem |= n & 3;
+          words += n;
+        }
+        const int t = (mx + 2 * G - 1) / (2 * G);             // trips of two Philox blocks per lane
+        trips += p.paired ? 2 * t + 1 : 2 * t + (any_rem ? 1 : 0);   // counted in blocks per lane
       }
-      const int t = (mx + 2 * k2G - 1) / (2 * k2G);         // trips of two Philox blocks per lane
-      trips += p.paired ? 2 * t + 1 : 2 * t + (any_rem ? 1 : 0);   // counted in blocks per lane
+    };
+    if (!wpart && k2_mix > 0) {
+      slice(0, static_cast<long>(k2_mix) * C, k2G + 1);
+      slice(static_cast<long>(k2_mix) * C, chains, k2G);
+      add_stat(k2_mix_name(k2G), static_cast<double>(waves), trips, static_cast<double>(chains), words);
+    } else {
+      slice(0, chains, k2G);
+      add_stat(k2_name(k2G, wpart), static_cast<double>(waves), trips, static_cast<double>(chains), words);
     }
-    add_stat(k2_name(k2G, wpart), static_cast<double>(waves), trips, static_cast<double>(chains), words);
   }
   for (size_t ri = 0; ri < gen_runs.size(); ri++) {
     const GenRun &run = gen_runs[ri];
@@ -781,8 +836,13 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   }
   if (n_k2 - n_k2w > 0) {
     lanes_per_chain = k2_G;
-    last_kernels += std::string(last_kernels.empty() ? "" : ",") + k2_name(k2_G, false);
-    launch_k2(a, k2_G, stream_for_next());
+    if (k2_mix > 0) {
+      last_kernels += std::string(last_kernels.empty() ? "" : ",") + k2_mix_name(k2_G);
+      launch_k2_mix(a, k2_G, stream_for_next());
+    } else {
+      last_kernels += std::string(last_kernels.empty() ? "" : ",") + k2_name(k2_G, false);
+      launch_k2(a, k2_G, stream_for_next());
+    }
   }
   for (size_t ri = 0; ri < gen_runs.size(); ri++) {
     const GenRun &run = gen_runs[ri];
