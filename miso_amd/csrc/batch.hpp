@@ -47,6 +47,7 @@ struct miso_batch {
     bool dense = true;            // paired-end: every event has dense quad records (pe_dense)
     int tuned_G = 0;              // lanes per chain picked by the first launch's trial runs
     int tuned_flat = -1;          // sampler_flat (1) or sampler_grp (0) by the first launch's trial runs, -1 = not tried
+    int tuned_nc = 0;             // sampler_flat's chains per wavefront by the first launch's trial runs, 0 = not tried
   };
   std::vector<GenRun> gen_runs;
   int tuned_k2_G = 0;             // ditto for the two-isoform kernel

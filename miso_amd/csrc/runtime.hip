@@ -586,7 +586,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   // per wavefront, as many as fit the wavefront's share of the LDS (two workgroups of four wavefronts
   // per CU: 20 KB each), fewer when the batch would not fill the device otherwise.
   // MISO_NO_FLAT=1: sampler_grp as in round 1 (A/B, tests); MISO_FLAT_NC=n forces the chains per wavefront.
-  std::vector<int> flat_nc(gen_runs.size(), 0);
+  std::vector<int> flat_nc(gen_runs.size(), 0), flat_nc_max(gen_runs.size(), 0);
   for (size_t ri = 0; ri < gen_runs.size(); ri++) {
     const GenRun &run = gen_runs[ri];
     if (p.paired || run.nocls || std::getenv("MISO_NO_FLAT") != nullptr) continue;
@@ -603,7 +603,8 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     const long rounds = std::max<long>(1, (chains + slots * nc_max - 1) / (slots * nc_max));
     int nc = static_cast<int>(std::min<long>(nc_max, std::max<long>(1, (chains + slots * rounds - 1) / (slots * rounds))));
     if (const char *env = std::getenv("MISO_FLAT_NC")) nc = std::max(1, std::min(nc_max, std::atoi(env)));
-    flat_nc[ri] = nc;
+    else if (run.tuned_nc > 0) nc = std::min(nc_max, run.tuned_nc);
+    flat_nc[ri] = nc; flat_nc_max[ri] = nc_max;
   }
   auto flat_name = [&](const GenRun &run) { return "sampler_flat<" + std::to_string(run.kc) + ">"; };
   auto launch_flat = [&](KernelArgs ka, const GenRun &run, int nc, hipStream_t st) {
@@ -636,6 +637,18 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     // sampler_flat or sampler_grp?  Measured on the batch's first launch like the lanes per chain below
     // (flat wins at every isoform count of profiles/r02_flat_vs_grp_sweep.txt but 5); a small or untuned
     // batch takes sampler_flat.
+    // sampler_flat's chains per wavefront: the rule above counts rounds of resident wavefronts, but the lanes
+    // also split unevenly over a wavefront's chains and items (K=5: 8 per wavefront 85.9k events/s, 9: 77.4k,
+    // 10 -- the rule -- 82.2k; K=6: 8: 76.5k, 10: 70.6k; K=8: 6: 57.1k, 10: 55.0k): the first launch of a large
+    // batch times the rule's choice against 8 and 6 (trial launches as for the lanes per chain below).
+    if (flat_nc[ri] > 0 && tune_runs && run.tuned_nc == 0 && static_cast<long>(run.count) * p.noChains >= 2048 &&
+        std::getenv("MISO_FLAT_NC") == nullptr) {
+      std::vector<int> cand{flat_nc[ri]};
+      for (int c : {8, 6}) if (c <= flat_nc_max[ri] && std::find(cand.begin(), cand.end(), c) == cand.end()) cand.push_back(c);
+      if (cand.size() > 1)
+        flat_nc[ri] = fastest(cand, [&](const KernelArgs &t, int c) { launch_flat(t, run, c, stream); });
+      run.tuned_nc = flat_nc[ri];
+    }
     const bool contest = flat_nc[ri] > 0 && tune_runs && static_cast<long>(run.count) * p.noChains >= 2048 &&
                          run.tuned_flat < 0 && std::getenv("MISO_FLAT_NC") == nullptr;
     if (flat_nc[ri] > 0 && run.tuned_flat == 0) flat_nc[ri] = 0;
