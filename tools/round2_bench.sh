@@ -10,8 +10,10 @@ run --chains 6 --iters 5000 --burn 500 --lag 10      # MISO defaults
 for K in 3 4 5 6 8 10 12; do run --K $K; done
 run --K 16 --events 8192; run --K 20 --events 8192
 run --paired                           # configs[2]: PE K=2
-for K in 3 5 8 10; do run --paired --K $K --events 8192; done
+for K in 3 4 5 8; do run --paired --K $K; done
+for K in 10 16 20; do run --paired --K $K --events 20000; done
 run --K-range 3 20                                     # configs[3] proxy: mixed batch, concurrent kernels
+run --paired --K-range 3 20 --events 16384
 run --paired --K-range 3 20 --events 8192
 python3 - <<'PY'
 import json
