@@ -140,3 +140,32 @@ def test_empty_and_degenerate_events():
     for r in (r0, r1, r2, r3):
         assert np.isfinite(r.samples).all() and np.allclose(r.samples.sum(1), 1.0)
     assert r3.samples[:, 0].mean() > 0.5                      # nine inclusion reads pull psi up
+
+
+@pytest.mark.parametrize("n_events,chains", [(24000, 1), (9000, 3), (3000, 6)])
+def test_two_lane_widths_in_one_launch_equal_the_single_width(n_events, chains):
+    """sampler_k2_mix (the events with the most drawing reads on G + 1 lanes per chain, the rest on G, one launch)
+    against the single-width launch (MISO_K2_MIX=0): identical samples, log scores, counts."""
+    kw = dict(n_reads=600, iters=120, burn=40, lag=2, chains=chains)
+    b = workload.build_batch(0, n_events, **kw)
+    old = os.environ.pop("MISO_K2_MIX", None)
+    try:
+        b.run(seed=9, first_event_id=0)
+        mixed_kernel = b.last_kernels()
+        with np.errstate(over="ignore"):
+            d_mix, m_mix = _digest(b, n_events)
+        ll_mix = [b.result(i).loglik.copy() for i in (0, n_events // 2, n_events - 1)]
+        os.environ["MISO_K2_MIX"] = "0"
+        b.run(seed=9, first_event_id=0)
+        with np.errstate(over="ignore"):
+            d_one, m_one = _digest(b, n_events)
+        ll_one = [b.result(i).loglik.copy() for i in (0, n_events // 2, n_events - 1)]
+        single_kernel = b.last_kernels()
+    finally:
+        os.environ.pop("MISO_K2_MIX", None)
+        if old is not None:
+            os.environ["MISO_K2_MIX"] = old
+    assert "sampler_k2_mix" in mixed_kernel and "sampler_k2_mix" not in single_kernel, (mixed_kernel, single_kernel)
+    assert d_mix == d_one and np.array_equal(m_mix, m_one)
+    for x, y in zip(ll_mix, ll_one):
+        assert np.array_equal(x, y, equal_nan=True)
