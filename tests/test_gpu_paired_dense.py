@@ -85,3 +85,28 @@ def test_plain_records_equal_dense_records():
     for d, p in zip(out["dense"], out["plain"]):
         assert np.array_equal(d.counts_trace, p.counts_trace) and np.array_equal(d.samples, p.samples)
         assert np.array_equal(d.loglik, p.loglik, equal_nan=True) and np.array_equal(d.assignment, p.assignment)
+
+
+@pytest.mark.parametrize("K,sd", [(2, 60.0), (3, 60.0), (10, 45.0), (4, 31.0), (4, 32.0)])
+def test_wide_fragment_distributions(orc, K, sd):
+    """More than 254 fragment lengths (mean +- 4 sd with sd > 31): the byte records of pe_dense do not apply and
+    the plain records' loops run; sampler_k2's u16 records still do.  sd = 31 / 32 straddle the limit."""
+    mean, var = 300.0, sd * sd
+    exons, isoforms, expr = workload.event_gene(11, K, min_len=500, max_len=900, gap=300)
+    g = orc.gene(flat(exons), isoforms)
+    orc.rng_seed(77)
+    rc, iso, pos, cig = orc.simulate_paired_reads(g, [1.0 / K] * K, 500, 36, mean, var)
+    assert rc == 0
+    kw = dict(iters=200, burn=50, lag=2, chains=2)
+    b = miso_amd.Batch(36, paired=True, mean=mean, var=var, counts_trace=True, **kw)
+    for _ in range(3):
+        b.add_event(miso_amd.Gene(exons, isoforms), pos, cig)
+    b.run(seed=4, first_event_id=0)
+    for e in range(3):
+        cpu = orc.miso_paired(g, pos, cig, 36, mean, var, mode=OrcLib.COUNTER, seed=4, event_id=e, trace=True, **kw)
+        assert cpu.rc == 0
+        r = b.result(e, trace=True)
+        where = (K, sd, e, b.last_kernels())
+        assert np.array_equal(r.counts_trace, cpu.trace["counts_trace"]), where
+        assert np.array_equal(r.samples, cpu.samples) and np.array_equal(r.loglik, cpu.loglik, equal_nan=True), where
+        assert np.array_equal(r.assignment, cpu.assignment), where
