@@ -37,6 +37,8 @@ struct DevEvent {
   int32_t pe_delta;    // PE, K = 2: no drawing read touches a non-finite score (sampler_k2 MODE 2)
   int32_t dense_nobad; // PE dense records: no drawing read touches a non-finite score
   uint64_t off_dense;  // PE, 3 <= K <= PE_DENSE_KMAX: quad records of pe_dense (kernels_grp.inl), NO_DENSE = none
+  uint64_t off_units;  // SE with a class table: u32 per work unit (Philox block x class), in unit order:
+                       // bits 0-3 the block's words that belong to the class, 4-11 the class, 12-31 the block
   uint64_t off_sfixd;  // PE dense: int32[K x (il + 2)] scores in the records' index space
   // byte offsets into the output pool
   uint64_t off_samples; // double[S x K]  (reference layout: K x S column-major)
@@ -89,6 +91,7 @@ struct KernelArgs {
   int32_t pe_dense;         // sampler_grp PE: every event of the launch has dense records (pe_dense) and the LDS
                             // probability table carries the two extra entries PE_ZERO, PE_ONE (0 = the quad loops of pe_quads)
   int32_t pe_force_exact;   // tests: every read through pe_dense's exact (cold) scan
+  int32_t flat_desc;        // sampler_flat: read loop over the unit descriptors (flat_units_desc), 0 = the walking loop
   int32_t mix_blocks;       // sampler_k2_mix<GA, GB>: the first mix_blocks workgroups run the first mix_slots events
   int32_t mix_slots;        // with GA lanes per chain, the rest the remaining events with GB (runtime.hip)
   uint64_t seed;

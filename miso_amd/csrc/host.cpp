@@ -566,6 +566,9 @@ PackedEvent pack_event_masks(const miso_params_t &p, const FragmentDist *fd, int
                                          static_cast<uint32_t>(e.n_units - q0), head | tail << 4};
         e.dcls_tab.insert(e.dcls_tab.end(), row, row + CLS_WORDS);
         e.n_units += q1 - q0 + 1;
+        for (int q = q0; q <= q1; q++)   // the unit's descriptor (sampler_flat's read loop, device.hpp)
+          e.unit_desc.push_back(((q == q0 ? head : 0xFu) & (q == q1 ? tail : 0xFu)) | static_cast<uint32_t>(c) << 4 |
+                                static_cast<uint32_t>(q) << 12);
         for (int k = 0, j = 0; j < nv - 1; k++)   // every member but the last
           if ((e.dcls_mask[c] >> k) & 1u) { e.dcls_pairs.push_back(static_cast<uint16_t>(c << 8 | k)); j++; }
       }

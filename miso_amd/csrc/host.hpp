@@ -104,6 +104,7 @@ struct PackedEvent {
   std::vector<uint16_t> dcls_pairs;     // ... (class << 8 | isoform) for every class member but its last
                                         // (all four empty with more than MAX_DRAW_CLASSES classes)
   int n_units = 0;                      // ... work units: (Philox block, class) incidences
+  std::vector<uint32_t> unit_desc;      // ... one word per unit, in unit order: word mask | class << 4 | Philox block << 12 (device.hpp)
   int max_cls_size = 0;                 // ... most isoforms any drawing class is compatible with
   std::vector<uint16_t> draw_frag;      // paired-end: n_draw x K
   std::vector<int32_t> sfix_table;      // paired-end: K x il fixed-point isoscores

@@ -62,7 +62,7 @@ enum { SX_SUMEXP = 0, SX_LTHETA, SX_MAXV, SX_E1, SX_E2, SX_X1, SX_X2, SX_LA0, SX
        SX_LR2, SX_SD, SX_SIGMA, SX_COVAR };
 // ... and int scalars (FlatLayout::misc)
 enum { MI_K = 0, MI_NDRAW, MI_NCLS, MI_NUNITS, MI_EVID, MI_CHAIN, MI_ACC, MI_ACCW, MI_C3K1, MI_P1LO, MI_P1HIK0,
-       MI_EV, MI_SAMP_LO, MI_SAMP_HI, MI_TRACE_LO, MI_TRACE_HI, MI_USTART, MI_NEXT };
+       MI_EV, MI_SAMP_LO, MI_SAMP_HI, MI_TRACE_LO, MI_TRACE_HI, MI_USTART, MI_NEXT, MI_LANE0, MI_LANES, MI_DESC };
 
 // The reference's draw compares rnd = fl(fl(u 2^-32) T) with a cumulative weight c: `rnd < c` when two
 // isoforms are compatible, `!(rnd > c)` otherwise (miso.c:69-79).  Both are monotone in the 32-bit word
@@ -233,6 +233,68 @@ __device__ __attribute__((noinline)) void flat_units(const FlatUnitsArgs A, int 
   }
 }
 
+
+// The read loop over UNIT DESCRIPTORS (device.hpp DevEvent::off_units, host.cpp): every chain of the wavefront
+// has a fixed group of lanes, in proportion to its units (sampler_flat's set-up); lane r of g takes the chain's
+// units r, r + g, r + 2g ...: the descriptor (class, Philox block, which of its four words belong to the class)
+// comes from global memory, coalesced within the group and fetched one trip ahead, the class's thresholds from
+// the chain's LDS row.  No walk over classes and chains, no state to carry from unit to unit: against flat_units
+// (contiguous unit ranges per lane, perfectly balanced) the lane groups are rounded to whole lanes (a few per
+// cent more trips) and a trip costs ~30 % fewer instructions.
+template <int TW>
+__device__ __attribute__((noinline)) void flat_units_desc(const FlatUnitsArgs A, const uint32_t *pool_words, int ms, int r, int g) {
+  if (A.trips == 0 || g <= 0) return;
+  unsigned char *wbase = smem_flat + A.woff;
+  const int slice = __builtin_amdgcn_readfirstlane(A.slice), off_thr = __builtin_amdgcn_readfirstlane(A.off_thr),
+            off_misc = __builtin_amdgcn_readfirstlane(A.off_misc), off_dl = __builtin_amdgcn_readfirstlane(A.off_dl),
+            trow4 = 4 * __builtin_amdgcn_readfirstlane(A.trow);
+  const uint32_t iter = __builtin_amdgcn_readfirstlane(A.iter);
+  const int sl = ms * slice;
+  const int *mi = reinterpret_cast<const int *>(wbase + sl + off_misc);
+  const int nu = mi[MI_NUNITS];
+  const uint32_t *desc = pool_words + static_cast<uint32_t>(mi[MI_DESC]);
+  GibbsRng rng;
+  rng.k0 = A.k0; rng.k1 = A.k1; rng.p1hi = 0;
+  rng.c3k1 = static_cast<uint32_t>(mi[MI_C3K1]); rng.p1lo = static_cast<uint32_t>(mi[MI_P1LO]);
+  const uint32_t n0r0 = static_cast<uint32_t>(mi[MI_P1HIK0]) ^ iter;
+  const unsigned char *thr = wbase + sl + off_thr;
+  constexpr int UQ = 2;
+  int D[TW];
+#pragma unroll
+  for (int j = 0; j < TW; j++) D[j] = 0;
+  uint32_t dn[UQ];   // the next trip's descriptors (0 = no unit: no word counts)
+#pragma unroll
+  for (int b = 0; b < UQ; b++) { const int u = r + b * g; dn[b] = (u < nu) ? desc[u] : 0u; }
+  for (int u0 = r; __any(u0 < nu); u0 += UQ * g) {
+    uint32_t d[UQ];
+#pragma unroll
+    for (int b = 0; b < UQ; b++) {
+      d[b] = dn[b];
+      const int un = u0 + (UQ + b) * g;
+      dn[b] = (un < nu) ? desc[un] : 0u;
+    }
+    uint32_t T[UQ][TW], w[UQ][4];
+#pragma unroll
+    for (int b = 0; b < UQ; b++) {
+      const uint32_t *row = reinterpret_cast<const uint32_t *>(thr + ((d[b] >> 4) & 0xFFu) * trow4);
+#pragma unroll
+      for (int j = 0; j < TW; j++) T[b][j] = row[j];
+      const miso_u32x4 u = philox_gibbs<true>(rng, d[b] >> 12, n0r0);
+      const int nm = static_cast<int>(~d[b]);   // a word outside the class becomes 0xFFFFFFFF (never below a 32-bit threshold)
+#pragma unroll
+      for (int x = 0; x < 4; x++) w[b][x] = u.v[x] | static_cast<uint32_t>(__builtin_amdgcn_sbfe(nm, x, 1));
+    }
+#pragma unroll
+    for (int j = 0; j < TW; j++) {
+#pragma unroll
+      for (int b = 0; b < UQ; b++) count_below(D[j], w[b][0], w[b][1], w[b][2], w[b][3], T[b][j]);
+    }
+  }
+  int *dl = reinterpret_cast<int *>(wbase + sl + off_dl);
+#pragma unroll
+  for (int j = 0; j < TW; j++) if (D[j]) atomicAdd(&dl[j], D[j]);
+}
+
 }  // namespace
 
 // workgroups per CU the register budget allows: three for the narrow classes (168 VGPRs; the scalar
@@ -292,6 +354,8 @@ __global__ __launch_bounds__(256, KC <= 8 ? MISO_FLAT_WGS_SMALL : 2) void sample
       mi[MI_K] = K; mi[MI_NDRAW] = E.n_draw; mi[MI_NCLS] = E.n_dcls; mi[MI_NUNITS] = E.n_units;
       mi[MI_EVID] = static_cast<int>(event_id); mi[MI_CHAIN] = static_cast<int>(chain);
       mi[MI_ACC] = 0; mi[MI_ACCW] = 0; mi[MI_EV] = ev; mi[MI_NEXT] = -1;
+      mi[MI_DESC] = static_cast<int>(static_cast<uint32_t>(E.off_units >> 2));   // dword offset of the event's unit descriptors in the input pool
+      mi[MI_LANE0] = 0; mi[MI_LANES] = 0;
       const GibbsRng g = gibbs_rng_init(a.seed, event_id, chain);
       mi[MI_C3K1] = static_cast<int>(g.c3k1); mi[MI_P1LO] = static_cast<int>(g.p1lo);
       mi[MI_P1HIK0] = static_cast<int>(g.p1hi ^ g.k0);
@@ -320,7 +384,39 @@ __global__ __launch_bounds__(256, KC <= 8 ? MISO_FLAT_WGS_SMALL : 2) void sample
   }
   total_units = __builtin_amdgcn_readfirstlane(total_units);
   const int trips = (total_units + 63) / 64;   // units per lane
+  // lanes per chain for flat_units_desc: in proportion to the chain's units, every chain with units at least one,
+  // 64 in all (largest remainders first; static for the whole run)
+  const bool use_desc = a.flat_desc != 0;
+  if (use_desc && total_units > 0 && lane == 0) {
+    int sum = 0;
+    for (int s = 0; s < ncw; s++) {
+      const int nu = FI(s, L.misc)[MI_NUNITS];
+      const int gs = nu > 0 ? max(1, static_cast<int>((64L * nu) / total_units)) : 0;
+      FI(s, L.misc)[MI_LANES] = gs; sum += gs;
+    }
+    while (sum != 64) {   // give a lane to the chain with the most units per lane / take one from the one with the fewest
+      int best = -1; double bv = 0.0;
+      for (int s = 0; s < ncw; s++) {
+        const int nu = FI(s, L.misc)[MI_NUNITS], gs = FI(s, L.misc)[MI_LANES];
+        if (nu <= 0 || (sum > 64 && gs <= 1)) continue;
+        const double v = sum < 64 ? static_cast<double>(nu) / gs : -static_cast<double>(nu) / (gs - 1);
+        if (best < 0 || v > bv) { best = s; bv = v; }
+      }
+      if (best < 0) break;
+      FI(best, L.misc)[MI_LANES] += sum < 64 ? 1 : -1;
+      sum += sum < 64 ? 1 : -1;
+    }
+    int l0 = 0;
+    for (int s = 0; s < ncw; s++) { FI(s, L.misc)[MI_LANE0] = l0; l0 += FI(s, L.misc)[MI_LANES]; }
+  }
   fsync();
+  int d_ms = 0, d_r = 0, d_g = 0;   // this lane's chain, rank and group size (flat_units_desc)
+  if (use_desc && total_units > 0) {
+    for (int s = 0; s < ncw; s++) {
+      const int l0 = FI(s, L.misc)[MI_LANE0], gs = FI(s, L.misc)[MI_LANES];
+      if (lane >= l0 && lane < l0 + gs) { d_ms = s; d_r = lane - l0; d_g = gs; }
+    }
+  }
   // this lane's first unit: chain, class, unit within the chain (static for the whole run)
   int s0 = 0, c0 = 0, i0 = 0, n_mine = 0;
   {
@@ -569,7 +665,7 @@ __global__ __launch_bounds__(256, KC <= 8 ? MISO_FLAT_WGS_SMALL : 2) void sample
     FlatUnitsArgs ua;
     ua.woff = wid * NC * L.bytes; ua.slice = L.bytes; ua.off_ctab = L.ctab; ua.off_thr = L.thr; ua.off_misc = L.misc; ua.off_dl = L.dl;
     ua.trow = trow; ua.trips = trips; ua.iter = iter; ua.k0 = k0; ua.k1 = k1;
-#define MISO_FUNITS(TW) flat_units<TW>(ua, s0, c0, i0, n_mine);
+#define MISO_FUNITS(TW) { if (use_desc) flat_units_desc<TW>(ua, reinterpret_cast<const uint32_t *>(a.in_pool), d_ms, d_r, d_g); else flat_units<TW>(ua, s0, c0, i0, n_mine); }
     if constexpr (KC == 4) { if (tww <= 2) MISO_FUNITS(2) else MISO_FUNITS(3) }
     else if constexpr (KC == 8) { if (tww <= 4) MISO_FUNITS(4) else if (tww == 5) MISO_FUNITS(5) else if (tww == 6) MISO_FUNITS(6) else MISO_FUNITS(7) }
     else if constexpr (KC == 12) { if (tww <= 9) MISO_FUNITS(9) else MISO_FUNITS(11) }

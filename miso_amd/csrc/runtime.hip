@@ -269,6 +269,7 @@ void miso_batch::upload(int dev) {
     d.n_pairs = static_cast<int32_t>(e.dcls_pairs.size());
     d.off_cls = in_off; in_off = align_up(in_off + e.dcls_tab.size() * 4, 16);
     d.off_clsmask = in_off; in_off = align_up(in_off + e.dcls_pairs.size() * 2, 16);
+    d.off_units = in_off; in_off = align_up(in_off + e.unit_desc.size() * 4, 16);
     d.off_sfix = in_off; in_off = align_up(in_off + e.sfix_table.size() * 4, 16);
     d.pe_delta = e.pe_delta ? 1 : 0;
     d.dense_nobad = e.dense_nobad ? 1 : 0;
@@ -298,6 +299,7 @@ void miso_batch::upload(int dev) {
     std::memcpy(h_in.data() + d.off_base, e.base_count.data(), e.base_count.size() * 4);
     if (e.paired) std::memcpy(h_in.data() + d.off_draw, e.draw_frag.data(), e.draw_frag.size() * 2);
     else std::memcpy(h_in.data() + d.off_draw, e.draw_mask.data(), e.draw_mask.size() * 4);
+    if (!e.unit_desc.empty()) std::memcpy(h_in.data() + d.off_units, e.unit_desc.data(), e.unit_desc.size() * 4);
     if (!e.dcls_tab.empty()) {
       std::memcpy(h_in.data() + d.off_cls, e.dcls_tab.data(), e.dcls_tab.size() * 4);
       if (!e.dcls_pairs.empty())
@@ -611,6 +613,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     const long chains = static_cast<long>(run.count) * p.noChains;
     ka.slot_event = d_slots + n_k2 + run.first; ka.n_slots = run.count;
     ka.kstride = run.kmax; ka.cstride = std::max(run.maxcls, 1); ka.tstride = 0; ka.nc = nc;
+    ka.flat_desc = std::getenv("MISO_FLAT_NO_DESC") == nullptr ? 1 : 0;   // MISO_FLAT_NO_DESC=1: the walking read loop (A/B, tests)
     const long waves = (chains + nc - 1) / nc;
     const unsigned grid = static_cast<unsigned>((waves + 3) / 4);
     const size_t lds = 4 * static_cast<size_t>(nc) * flat_layout(ka.kstride, ka.cstride).bytes;
