@@ -241,6 +241,9 @@ __device__ __attribute__((noinline)) void flat_units(const FlatUnitsArgs A, int 
 // the chain's LDS row.  No walk over classes and chains, no state to carry from unit to unit: against flat_units
 // (contiguous unit ranges per lane, perfectly balanced) the lane groups are rounded to whole lanes (a few per
 // cent more trips) and a trip costs ~30 % fewer instructions.
+#ifndef MISO_FLAT_DESC_UQ
+#define MISO_FLAT_DESC_UQ 2   // units per lane and trip
+#endif
 template <int TW>
 __device__ __attribute__((noinline)) void flat_units_desc(const FlatUnitsArgs A, const uint32_t *pool_words, int ms, int r, int g) {
   if (A.trips == 0 || g <= 0) return;
@@ -258,7 +261,7 @@ __device__ __attribute__((noinline)) void flat_units_desc(const FlatUnitsArgs A,
   rng.c3k1 = static_cast<uint32_t>(mi[MI_C3K1]); rng.p1lo = static_cast<uint32_t>(mi[MI_P1LO]);
   const uint32_t n0r0 = static_cast<uint32_t>(mi[MI_P1HIK0]) ^ iter;
   const unsigned char *thr = wbase + sl + off_thr;
-  constexpr int UQ = 2;
+  constexpr int UQ = MISO_FLAT_DESC_UQ;
   int D[TW];
 #pragma unroll
   for (int j = 0; j < TW; j++) D[j] = 0;
@@ -386,7 +389,7 @@ __global__ __launch_bounds__(256, KC <= 8 ? MISO_FLAT_WGS_SMALL : 2) void sample
   const int trips = (total_units + 63) / 64;   // units per lane
   // lanes per chain for flat_units_desc: in proportion to the chain's units, every chain with units at least one,
   // 64 in all (largest remainders first; static for the whole run)
-  const bool use_desc = a.flat_desc != 0;
+  const bool use_desc = a.flat_desc != 0 && Kw >= 4;   // three isoforms: the walking loop is 2 % faster (two thresholds per unit: little to save)
   if (use_desc && total_units > 0 && lane == 0) {
     int sum = 0;
     for (int s = 0; s < ncw; s++) {
