@@ -41,13 +41,12 @@ struct miso_batch {
   struct GenRun {
     int first = 0, count = 0;     // slice of d_slots (after the n_k2 two-isoform events)
     int kc = 4;                   // 4, 8, 12, 16 or 32
-    int kmax = 2, maxq = 1;       // most isoforms, most draw quads
+    int kmax = 2, kmin = 64, maxq = 1;   // most / fewest isoforms, most draw quads
     int maxcls = 0;               // most drawing-read classes (single-end)
     bool nocls = false;           // some single-end event has no class table (> MAX_DRAW_CLASSES classes)
     bool dense = true;            // paired-end: every event has dense quad records (pe_dense)
     int tuned_G = 0;              // lanes per chain picked by the first launch's trial runs
     int tuned_flat = -1;          // sampler_flat (1) or sampler_grp (0) by the first launch's trial runs, -1 = not tried
-    int tuned_nc = 0;             // sampler_flat's chains per wavefront by the first launch's trial runs, 0 = not tried
   };
   std::vector<GenRun> gen_runs;
   int tuned_k2_G = 0;             // ditto for the two-isoform kernel

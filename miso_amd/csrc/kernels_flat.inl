@@ -390,7 +390,8 @@ __global__ __launch_bounds__(256, KC <= 8 ? MISO_FLAT_WGS_SMALL : 2) void sample
   const int trips = (total_units + 63) / 64;   // units per lane
   // lanes per chain for flat_units_desc: in proportion to the chain's units, every chain with units at least one,
   // 64 in all (largest remainders first; static for the whole run)
-  const bool use_desc = a.flat_desc != 0 && Kw >= 4;   // three isoforms: the walking loop is 2 % faster (two thresholds per unit: little to save)
+  const bool use_desc = a.flat_desc != 0;   // (decided by the host per launch; a second condition here -- the wavefront's largest K --
+                                            //  cost 7 % at K=5: 93.5k -> 87.2k events/s, for no visible reason in the read loop itself)
   if (use_desc && total_units > 0 && lane == 0) {
     int sum = 0;
     for (int s = 0; s < ncw; s++) {

@@ -350,6 +350,7 @@ void miso_batch::upload(int dev) {
     GenRun &r = gen_runs.back();
     r.count++;
     r.kmax = std::max(r.kmax, e.K);
+    r.kmin = std::min(r.kmin, e.K);
     r.maxq = std::max(r.maxq, (e.n_draw + 3) / 4);
     r.maxcls = std::max(r.maxcls, static_cast<int>(e.dcls_mask.size()));
     if (!e.paired && e.n_draw > 0 && e.dcls_mask.empty()) r.nocls = true;
@@ -604,8 +605,13 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     const long slots = std::max<long>(1, static_cast<long>(slots_for(chains)) * wgs / 2);
     const long rounds = std::max<long>(1, (chains + slots * nc_max - 1) / (slots * nc_max));
     int nc = static_cast<int>(std::min<long>(nc_max, std::max<long>(1, (chains + slots * rounds - 1) / (slots * rounds))));
+    // five to eight isoforms: how the 64 lanes divide over a wavefront's chains and items matters more than the
+    // rounds -- measured on one device, 40 000 events (events/s at 5 / 6 / 7 / 8 / 10 chains per wavefront):
+    // K=6 69.4k / 67.5k / 72.2k / 77.2k / 68.6k, K=7 64.1k / 61.4k / 68.8k / 73.5k / 64.3k, K=8 55.8k / 57.1k /
+    // 52.6k / 55.1k / 54.4k; K=5: 8 -> 93.4k, 7 -> 90.3k, 10 -> 86.8k.  (Timing the candidates on the first launch
+    // was tried: a 7 % difference is inside the noise of a 200-iteration trial, the choice flipped between runs.)
+    if (run.kc == 8) nc = std::min(nc, run.kmin >= 8 ? 6 : 8);
     if (const char *env = std::getenv("MISO_FLAT_NC")) nc = std::max(1, std::min(nc_max, std::atoi(env)));
-    else if (run.tuned_nc > 0) nc = std::min(nc_max, run.tuned_nc);
     flat_nc[ri] = nc; flat_nc_max[ri] = nc_max;
   }
   auto flat_name = [&](const GenRun &run) { return "sampler_flat<" + std::to_string(run.kc) + ">"; };
@@ -613,7 +619,9 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     const long chains = static_cast<long>(run.count) * p.noChains;
     ka.slot_event = d_slots + n_k2 + run.first; ka.n_slots = run.count;
     ka.kstride = run.kmax; ka.cstride = std::max(run.maxcls, 1); ka.tstride = 0; ka.nc = nc;
-    ka.flat_desc = std::getenv("MISO_FLAT_NO_DESC") == nullptr ? 1 : 0;   // MISO_FLAT_NO_DESC=1: the walking read loop (A/B, tests)
+    // the descriptor read loop from four isoforms on (three: the walking loop is 2 % faster -- two thresholds per unit,
+    // little to save); MISO_FLAT_NO_DESC=1: the walking loop everywhere (A/B, tests)
+    ka.flat_desc = (std::getenv("MISO_FLAT_NO_DESC") == nullptr && run.kmax >= 4) ? 1 : 0;
     const long waves = (chains + nc - 1) / nc;
     const unsigned grid = static_cast<unsigned>((waves + 3) / 4);
     const size_t lds = 4 * static_cast<size_t>(nc) * flat_layout(ka.kstride, ka.cstride).bytes;
@@ -640,18 +648,6 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     // sampler_flat or sampler_grp?  Measured on the batch's first launch like the lanes per chain below
     // (flat wins at every isoform count of profiles/r02_flat_vs_grp_sweep.txt but 5); a small or untuned
     // batch takes sampler_flat.
-    // sampler_flat's chains per wavefront: the rule above counts rounds of resident wavefronts, but the lanes
-    // also split unevenly over a wavefront's chains and items (K=5: 8 per wavefront 85.9k events/s, 9: 77.4k,
-    // 10 -- the rule -- 82.2k; K=6: 8: 76.5k, 10: 70.6k; K=8: 6: 57.1k, 10: 55.0k): the first launch of a large
-    // batch times the rule's choice against 8 and 6 (trial launches as for the lanes per chain below).
-    if (flat_nc[ri] > 0 && tune_runs && run.tuned_nc == 0 && static_cast<long>(run.count) * p.noChains >= 2048 &&
-        std::getenv("MISO_FLAT_NC") == nullptr) {
-      std::vector<int> cand{flat_nc[ri]};
-      for (int c : {8, 6}) if (c <= flat_nc_max[ri] && std::find(cand.begin(), cand.end(), c) == cand.end()) cand.push_back(c);
-      if (cand.size() > 1)
-        flat_nc[ri] = fastest(cand, [&](const KernelArgs &t, int c) { launch_flat(t, run, c, stream); });
-      run.tuned_nc = flat_nc[ri];
-    }
     const bool contest = flat_nc[ri] > 0 && tune_runs && static_cast<long>(run.count) * p.noChains >= 2048 &&
                          run.tuned_flat < 0 && std::getenv("MISO_FLAT_NC") == nullptr;
     if (flat_nc[ri] > 0 && run.tuned_flat == 0) flat_nc[ri] = 0;
