@@ -611,6 +611,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     // 52.6k / 55.1k / 54.4k; K=5: 8 -> 93.4k, 7 -> 90.3k, 10 -> 86.8k.  (Timing the candidates on the first launch
     // was tried: a 7 % difference is inside the noise of a 200-iteration trial, the choice flipped between runs.)
     if (run.kc == 8) nc = std::min(nc, run.kmin >= 8 ? 6 : 8);
+    if (run.kc == 4 && run.kmin >= 4) nc = std::min(nc, 8);   // four isoforms, descriptor loop: 8 -> 119.8k, 16 -> 116.1k, 13 -> 85.5k
     if (const char *env = std::getenv("MISO_FLAT_NC")) nc = std::max(1, std::min(nc_max, std::atoi(env)));
     flat_nc[ri] = nc; flat_nc_max[ri] = nc_max;
   }
