@@ -263,8 +263,10 @@ def roofline_for(batch, kernel_ms, workload_key):
 
 
 def traffic_key(kernel, events, K, reads, iters, chains, paired):
-    return "%s|events=%d|K=%s|reads=%d|iters=%d|chains=%d|paired=%d" % (
-        kernel, events, K, reads, iters, chains, int(paired))
+    """One canonical key per workload: K as "lo-hi" for isoform ranges, reads as a number or "hg19"."""
+    k = "%d-%d" % tuple(K) if isinstance(K, (tuple, list)) else str(K)
+    return "%s|events=%d|K=%s|reads=%s|iters=%d|chains=%d|paired=%d" % (
+        kernel, events, k, reads, iters, chains, int(paired))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -286,6 +288,13 @@ def time_batch(batch, seed, first, steps, warmup, barrier=None):
 
 
 MATRIX = [  # (label, overrides): the other shapes BASELINE's metric names, 40 000 events each
+    # read counts as a real annotation sees them (workload.HG19_LIKE: log-normal, median 300, 20 ... 10^5 reads per
+    # event, a handful of 10^4 ... 10^5-read events per 40 000): "reads_iter_per_s" is what to compare with the uniform rows
+    ("SE K=2, hg19-like read counts (20..1e5 per event), 1 chain, 7500 iters", dict(K=2, reads="hg19")),
+    ("SE K=2, hg19-like read counts, MISO defaults (6 chains, 5000 iters, 500 burn-in, lag 10)",
+     dict(K=2, reads="hg19", chains=6, iters=5000, burn=500, lag=10)),
+    ("PE K=2, hg19-like read counts, 1 chain, 7500 iters", dict(K=2, paired=True, reads="hg19")),
+    ("SE K=5, hg19-like read counts, 1 chain, 7500 iters", dict(K=5, reads="hg19")),
     ("SE K=5, 1 chain, 7500 iters", dict(K=5)),
     ("SE K=10, 1 chain, 7500 iters", dict(K=10)),
     ("SE K=2, MISO defaults (6 chains, 5000 iters, 500 burn-in, lag 10)", dict(K=2, chains=6, iters=5000, burn=500, lag=10)),
@@ -303,7 +312,9 @@ def run_matrix(a, local_rank):
                    chains=a.chains, paired=False)
         cfg.update(ov)
         n = min(a.matrix_events, cfg.get("events", a.matrix_events))
-        b = workload.build_batch(0, n, K=cfg["K"], n_reads=cfg["reads"], read_len=cfg["read_len"],
+        reads_spec = workload.HG19_LIKE if cfg["reads"] == "hg19" else cfg["reads"]
+        total_reads = sum(workload.event_n_reads(e, reads_spec) for e in range(n))
+        b = workload.build_batch(0, n, K=cfg["K"], n_reads=reads_spec, read_len=cfg["read_len"],
                                  iters=cfg["iters"], burn=cfg["burn"], lag=cfg["lag"], chains=cfg["chains"],
                                  paired=cfg["paired"], device_match=True)
         b.upload(local_rank)
@@ -312,6 +323,7 @@ def run_matrix(a, local_rank):
         r = roofline_for(b, avg, traffic_key(b.last_kernels(), n, cfg["K"], cfg["reads"], cfg["iters"],
                                              cfg["chains"], cfg["paired"]))
         rows.append({"workload": label, "events": n, "events_per_s": round(2 * n / elapsed, 1),
+                     "reads_iter_per_s": round(2.0 * total_reads * cfg["chains"] * cfg["iters"] / elapsed, 1),
                      "kernel": r["kernel"], "kernel_ms": r["kernel_ms"], "valu_frac": r["frac"],
                      "rng_frac": r["rng_frac"], "hbm_measured_frac": r["hbm_measured_frac"],
                      "algorithmic_GBs": r["algorithmic_GBs"]})
@@ -330,6 +342,8 @@ def main():
                     help="isoforms per event drawn from [LO, HI] by event id (configs[3] proxy: whole-gene "
                          "mode, mixed isoform counts in one batch); overrides --K, no CPU baseline")
     ap.add_argument("--reads", type=int, default=1000)
+    ap.add_argument("--reads-dist", choices=["fixed", "hg19"], default="fixed",
+                    help="hg19: heavy-tailed read counts per event (workload.HG19_LIKE) instead of --reads for every event")
     ap.add_argument("--read-len", type=int, default=36)
     ap.add_argument("--iters", type=int, default=7500)
     ap.add_argument("--burn", type=int, default=2500)
@@ -363,7 +377,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
 
-    default_shape = not a.K_range and not a.paired
+    default_shape = not a.K_range and not a.paired and a.reads_dist == "fixed"
     if a.K_range:
         a.no_cpu_baseline = True
     k_spec = tuple(a.K_range) if a.K_range else a.K
@@ -385,11 +399,12 @@ def main():
 
     # the rank's shard of the global event list: contiguous, balanced by cost
     n_global = a.events * world
-    costs = workload.event_costs(0, n_global, k_spec, a.reads, a.iters, a.chains)
+    reads_spec = workload.HG19_LIKE if a.reads_dist == "hg19" else a.reads
+    costs = workload.event_costs(0, n_global, k_spec, reads_spec, a.iters, a.chains)
     first, last = workload.shard_bounds_by_cost(costs, world, rank)
     n_local = last - first
     t_build = time.perf_counter()
-    batch = workload.build_batch(first, n_local, K=k_spec, n_reads=a.reads, read_len=a.read_len,
+    batch = workload.build_batch(first, n_local, K=k_spec, n_reads=reads_spec, read_len=a.read_len,
                                  iters=a.iters, burn=a.burn, lag=a.lag, chains=a.chains,
                                  paired=a.paired, device_match=not a.host_match and not a.stub)
     t_up = time.perf_counter()
@@ -427,7 +442,7 @@ def main():
         batch.summarize(0.95)
         summary_ms = 1e3 * (time.perf_counter() - t1)
     if a.compare and not a.stub:
-        other = workload.build_batch(first + (1 << 24), n_local, K=a.K, n_reads=a.reads,
+        other = workload.build_batch(first + (1 << 24), n_local, K=a.K, n_reads=reads_spec,
                                      read_len=a.read_len, iters=a.iters, burn=a.burn, lag=a.lag,
                                      chains=a.chains, paired=a.paired)
         other.upload(local_rank)
@@ -450,8 +465,8 @@ def main():
             roof = {"bound": "valu", "achieved": None, "peak": VALU_PEAK_GCYC, "unit": "Gcycle/s", "frac": None,
                     "traffic": None}
         else:
-            roof = roofline_for(batch, avg_ms, traffic_key(batch.last_kernels(), n_local, a.K if not a.K_range else -1,
-                                                           a.reads, a.iters, a.chains, a.paired))
+            roof = roofline_for(batch, avg_ms, traffic_key(batch.last_kernels(), n_local, k_spec,
+                                                           "hg19" if a.reads_dist == "hg19" else a.reads, a.iters, a.chains, a.paired))
         kind = "paired-end" if a.paired else "skipped-exon single-end"
         if a.K_range:
             wl = ("configs[3] proxy (whole-gene mode): %d %s genes/GPU, %d-%d isoforms" % (a.events, kind, a.K_range[0], a.K_range[1]))

@@ -248,6 +248,21 @@ typedef struct {
 } miso_kernel_stat_t;
 int miso_batch_launch_stats(const miso_batch_t *batch, miso_kernel_stat_t *stats, int max_kernels,
                             int *n_kernels);
+/* Host arithmetic, no device needed: the lanes-per-chain plan of the two-isoform sampler's one-launch-many-widths
+   kernel (sampler_k2_multi) for a list of events ordered by drawing reads, most first -- the answer to "events are
+   independent and cost O(reads)" (miso.c:845-900) on a machine whose unit of work is a 64-lane wavefront.
+   n_draw[n_events]: reads with two compatible isoforms per event; chains per event; paired: 0 / 1;
+   resident_workgroups: what the device holds at once (256 single-end, 512 paired-end on MI355X);
+   max_chains_per_wave: LDS limit (64 = none); cost5: {per block, step with 1, 2, 3, >= 4 cooperating lanes} in VALU
+   instructions or NULL for the measured defaults; forced_target > 0 fixes the bound on a wavefront's step.
+   Out: *n_runs runs (<= 16); run r holds events [run_first_event[r], run_first_event[r + 1]) on workgroups
+   [run_first_workgroup[r], run_first_workgroup[r + 1]) with run_lanes[r] lanes per chain (512 = one chain per
+   workgroup); both first_* arrays have *n_runs + 1 entries (caller provides 17); estimate3 (may be NULL):
+   {sum of wavefront steps, longest wavefront step, 1 = one round of resident workgroups / 2 = several}. */
+int miso_plan_lanes(const int *n_draw, int n_events, int chains, int paired, int resident_workgroups,
+                    int max_chains_per_wave, const double *cost5, double forced_target, int *n_runs,
+                    int *run_first_event, int *run_first_workgroup, int *run_lanes, double *estimate3);
+
 /* placement diagnostics: HW_REG_HW_ID of the wavefront that ran each chain of event i (noChains
    words; 0 for kernels that do not record it).  Needs downloaded results. */
 int miso_batch_get_placement(const miso_batch_t *batch, int event_index, uint32_t *hw_id);

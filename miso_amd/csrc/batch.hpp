@@ -7,8 +7,11 @@
 #include <string>
 #include <vector>
 
+#include <functional>
+
 #include "device.hpp"
 #include "host.hpp"
+#include "plan.hpp"
 
 namespace miso {
 int device_count();
@@ -35,6 +38,12 @@ struct miso_batch {
   unsigned char *d_in = nullptr, *d_out = nullptr;
   double *d_fp = nullptr;
   int32_t *d_slots = nullptr;     // [k2 events sorted by n_draw desc | all other events]
+  std::vector<int32_t> h_slots;   // the same list on the host
+  bool use_delta = true;          // paired-end: MODE 2 events first in the list (fixed at upload)
+  miso::LanePlan k2_plan;         // sampler_k2_multi: the runs of equal lanes per chain (runtime.hip), valid for k2_plan_key
+  long k2_plan_key = -1;
+  miso::LanePlan k2w_plan;        // the same for the paired-end MODE 2 events (sampler_k2_multi<2, 4>)
+  long k2w_plan_key = -1;
   int n_k2 = 0, n_gen = 0;
   int n_k2w = 0;                  // paired-end: the first n_k2w two-isoform slots take sampler_k2's MODE 2
   // the other events, grouped by isoform-count class (sampler_grp<G, PE, KC> holds K in (KC_prev, KC])
@@ -66,7 +75,8 @@ struct miso_batch {
   void resolve_pending();        // runs match_kernel for all pending events, packs them
   int lanes_per_chain = 0;        // G of the last sampler_k2 launch (0 = none)
   std::string last_kernels;       // names of the kernels of the last launch, comma separated
-  std::vector<miso_kernel_stat_t> kernel_stats;   // miso_batch_launch_stats
+  std::vector<miso_kernel_stat_t> kernel_stats;   // miso_batch_launch_stats, filled on demand by stats_builder
+  std::function<void()> stats_builder;            // set by launch(): the walk over events and wavefronts is not part of a launch
   int wave_slots = 2048;          // resident sampler_k2 wavefronts on the device
   std::vector<miso::DevEvent> h_events;
   std::vector<unsigned char> h_out;

@@ -614,8 +614,33 @@ int miso_batch_launch_stats(const miso_batch_t *b, miso_kernel_stat_t *stats, in
   return guarded([&] {
     need(b, "batch"); need(n_kernels, "n_kernels");
     if (!b->launched) MISO_FAIL(MISO_EINVAL, "batch not launched");
+    if (b->stats_builder) {   // the walk over events and wavefronts happens here, once, not inside every launch
+      miso_batch_t *mb = const_cast<miso_batch_t *>(b);
+      mb->stats_builder();
+      mb->stats_builder = nullptr;
+    }
     *n_kernels = static_cast<int>(b->kernel_stats.size());
     for (int i = 0; stats && i < max_kernels && i < *n_kernels; i++) stats[i] = b->kernel_stats[i];
+  });
+}
+
+int miso_plan_lanes(const int *n_draw, int n_events, int chains, int paired, int resident_workgroups, int max_chains_per_wave,
+                    const double *cost5, double forced_target, int *n_runs, int *run_first_event, int *run_first_workgroup,
+                    int *run_lanes, double *estimate3) {
+  return guarded([&] {
+    need(n_draw, "n_draw"); need(n_runs, "n_runs"); need(run_first_event, "run_first_event");
+    need(run_first_workgroup, "run_first_workgroup"); need(run_lanes, "run_lanes");
+    for (int i = 1; i < n_events; i++) if (n_draw[i] > n_draw[i - 1]) MISO_FAIL(MISO_EINVAL, "n_draw must not increase along the list");
+    static const int se_widths[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 32, 64};
+    static const int pe_widths[] = {4, 8, 16, 32, 64};
+    LaneCost cost = paired ? k2_cost_paired() : k2_cost_single();
+    if (cost5) { cost.block = cost5[0]; for (int i = 1; i <= 4; i++) cost.step[i] = cost5[i]; }
+    const LanePlan pl = paired ? plan_lanes(n_draw, n_events, chains, pe_widths, 5, 4, 4, resident_workgroups, max_chains_per_wave, cost, forced_target)
+                               : plan_lanes(n_draw, n_events, chains, se_widths, 12, 8, 8, resident_workgroups, max_chains_per_wave, cost, forced_target);
+    *n_runs = pl.n_segs;
+    for (int i = 0; i <= pl.n_segs; i++) { run_first_event[i] = pl.seg_slot[i]; run_first_workgroup[i] = pl.seg_block[i]; }
+    for (int i = 0; i < pl.n_segs; i++) run_lanes[i] = pl.seg_lanes[i];
+    if (estimate3) { estimate3[0] = pl.est_total; estimate3[1] = pl.est_max; estimate3[2] = pl.rounds; }
   });
 }
 

@@ -70,6 +70,10 @@ struct ChainStats {
   uint32_t hw_id;      // HW_REG_HW_ID of the wavefront that ran the chain (placement diagnostics)
 };
 
+constexpr int K2_MAX_SEGS = 16;
+constexpr int K2_WIDE = 512;   // seg_lanes value: one chain per workgroup
+constexpr int K2_RED_BYTES = 2 * 8 * 16;   // two buffers x (up to) 8 wavefronts x {int64 score sum, int count, int bad}
+
 struct KernelArgs {
   const DevEvent *events;
   const unsigned char *in_pool;
@@ -94,7 +98,15 @@ struct KernelArgs {
   int32_t flat_desc;        // sampler_flat: read loop over the unit descriptors (flat_units_desc), 0 = the walking loop
   int32_t mix_blocks;       // sampler_k2_mix<GA, GB>: the first mix_blocks workgroups run the first mix_slots events
   int32_t mix_slots;        // with GA lanes per chain, the rest the remaining events with GB (runtime.hip)
+  int32_t red_off;          // sampler_k2_multi: byte offset of the workgroup-wide chains' reduction scratch in the dynamic LDS
   uint64_t seed;
+  // sampler_k2_multi (kernels_k2m.hip): the launch's events (ordered by drawing reads, most first) cut into runs
+  // of equal lanes per chain.  Run s: workgroups [seg_block[s], seg_block[s + 1]), events (slots)
+  // [seg_slot[s], seg_slot[s + 1]) of the launch's list, seg_lanes[s] lanes per chain (K2_WIDE = the whole workgroup).
+  int32_t n_segs;
+  int32_t seg_block[K2_MAX_SEGS + 1];
+  int32_t seg_slot[K2_MAX_SEGS + 1];
+  int32_t seg_lanes[K2_MAX_SEGS];
 };
 
 constexpr uint64_t NO_TRACE = ~0ull;

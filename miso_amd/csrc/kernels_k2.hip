@@ -1,659 +1,8 @@
-// kernels_k2.hip -- the two-isoform single-end sampler (SE / RI / A3SS / A5SS / MXE events:
-// BASELINE.json configs[1]), lane-packed for CDNA4.
-//
-// Why a second kernel: with K = 2 the per-iteration scalar math (propose + Metropolis-Hastings,
-// miso.c:449-552: ~11 f64 transcendentals and ~13 f64 divisions) costs as much as the whole Gibbs
-// sweep over ~500 ambiguous reads, and both are VALU-issue bound on gfx950 (f64 = 4 cycles per
-// wave instruction, measured).  One wavefront per chain (sampler_wave) wastes 63/64 of the scalar
-// issue slots.  Here a chain owns G lanes (G = 1..64, a power of two picked by the host):
-//
-//   * MH step, G >= 4: the FOUR lanes of every quad evaluate ONE transcendental routine on FOUR
-//     different arguments (log psi'_0 | log psi'_1 | logit psi'_0, then three exps, then three
-//     logs) and exchange results with DPP quad broadcasts: 5 routine calls per iteration instead
-//     of 11.  Every value is still produced by the same miso_detmath routine on the same input,
-//     so the bits are unchanged.  Terms that depend only on the CURRENT psi are cached and
-//     swapped on acceptance.
-//   * Gibbs step: the G lanes stride over the chain's draw quads (one Philox4x32-10 block = the
-//     uniforms of four consecutive ambiguous reads, two blocks in flight per trip).  With two
-//     compatible isoforms the reference's test  U * (psi0 + psi1) < psi0  (miso.c:69-73) is
-//     monotone in the 32-bit uniform, so it becomes ONE u32 compare against the threshold
-//     t = #{u : fl(fl(u 2^-32)(psi0+psi1)) < psi0}, found exactly once per iteration.  Round 0 of
-//     Philox is partly hoisted: the counter words (iteration, site|chain, event) are chain
-//     constants.
-//   * a log2(G)-step cross-lane add gives the chain its count.
-// No LDS, no barriers; chain state lives in VGPRs.  Reads with fewer than two compatible isoforms
-// never reach the device (host.hpp PackedEvent).
-#include <hip/hip_runtime.h>
-
-#include "device.hpp"
-#include "miso_amd.h"
-#include "miso_detmath.h"
-#include "miso_philox.h"
-#include "gibbs_rng.hpp"
-
-#pragma clang fp contract(off)
-
-#ifndef MISO_K2_UQ
-#define MISO_K2_UQ 2   // Philox blocks in flight per lane in the single-end read loop
-#endif
-
-#ifdef MISO_K2_PROFILE
-#define PROF_T(var) const uint64_t var = __builtin_readcyclecounter()
-#define PROF_ADD(acc, t0, t1) acc += (t1) - (t0)
-#else
-#define PROF_T(var)
-#define PROF_ADD(acc, t0, t1)
-#endif
+// kernels_k2.hip -- the single-width launches of the two-isoform sampler (kernels_k2.inl) and the launch with
+// two lane widths; the launch with a lane width per event lives in kernels_k2m.hip.
+#include "kernels_k2.inl"
 
 namespace miso {
-
-namespace {
-
-// everything the MH step needs about one psi = (x0, x1) that does not depend on the counts
-struct PsiTerms {
-  double x0, x1;      // psi
-  double lx0, lx1;    // log psi_k                               (miso.c:136-138, 174)
-  double lpn0, lpn1;  // log psi_k + cst_k - logsumexp           (miso.c:136-149)
-  double lgt;         // log(psi_0 / (1 - psi_0))                (miso.c:113)
-  double pr;          // 1 / psi_0 / (1 - psi_0)                 (miso.c:105-110)
-};
-
-struct K2Consts {
-  double cst0, cst1, is0, is1, hm0, hm1, lg_sum, lg_each, sigma, sd, covar;
-};
-
-// scalar form (set-up, and the whole MH step when G < 4)
-__device__ __forceinline__ PsiTerms psi_terms(double x0, double x1, double cst0, double cst1) {
-  PsiTerms t;
-  t.x0 = x0; t.x1 = x1;
-  t.lx0 = miso_det_log(x0);
-  t.lx1 = miso_det_log(x1);
-  const double lp0 = t.lx0 + cst0, lp1 = t.lx1 + cst1;
-  const bool m1 = lp1 > lp0;  // miso.c:137-140: maxv starts at entry 0
-  const double maxv = m1 ? lp1 : lp0;
-  const double ex0 = miso_det_exp(lp0 - maxv), ex1 = miso_det_exp(lp1 - maxv);
-  const double lse = miso_det_log((0.0 + ex0) + ex1) + maxv;
-  t.lpn0 = lp0 - lse;
-  t.lpn1 = lp1 - lse;
-  const double ltheta = 1.0 - x0;
-  t.lgt = miso_det_log(x0 / ltheta);
-  t.pr = 1.0 / (1.0 * x0) / ltheta;
-  return t;
-}
-
-// miso.c:243-307 with the per-read sums taken from the counts
-template <bool PE>
-__device__ __forceinline__ double joint(const PsiTerms &t, int c0, int c1, const K2Consts &c, double readProbPE) {
-  double readProb = 0.0, assProb = 0.0, psiProb = 0.0;
-  if (c0 != 0) { if (!PE) readProb = readProb + static_cast<double>(c0) * c.is0; assProb = assProb + static_cast<double>(c0) * t.lpn0; }
-  if (c1 != 0) { if (!PE) readProb = readProb + static_cast<double>(c1) * c.is1; assProb = assProb + static_cast<double>(c1) * t.lpn1; }
-  if (PE) readProb = readProbPE;  // miso_paired.c:157-163, summed in 2^-26 fixed point
-  psiProb = psiProb + c.hm0 * t.lx0;
-  psiProb = psiProb + c.hm1 * t.lx1;
-  psiProb = psiProb + c.lg_sum;
-  psiProb = psiProb - c.lg_each;
-  return readProb + assProb + psiProb;
-}
-
-// miso.c:97-122 for len = 1: exponent of the logistic-normal density of theta around mu
-__device__ __forceinline__ double prop_exponent(double lgt, double mu, double sigma) {
-  const double tmp = lgt - mu;
-  return 0.0 + (-0.5) * tmp * tmp / sigma;
-}
-
-// #{u in [0, 2^32) : fl(fl(u * 2^-32) * T) < p0}  -- the reference's two-way draw as a threshold
-__device__ __forceinline__ bool k2_pred(int64_t u, double p0, double T) {
-  // the reference's test for uniform word u; u outside [0, 2^32) extends it monotonically
-  if (u < 0) return true;
-  if (u >= 4294967296ll) return false;
-  return static_cast<double>(static_cast<uint32_t>(u)) * (1.0 / 4294967296.0) * T < p0;
-}
-
-__device__ __forceinline__ uint64_t k2_threshold_exact(double p0, double T) {
-  double est = p0 / T * 4294967296.0;
-  est = (est > 0.0) ? est : 0.0;  // also catches NaN
-  est = (est > 4294967296.0) ? 4294967296.0 : est;
-  const int64_t t0 = static_cast<int64_t>(est);
-  // The predicate is monotone in u and est is within one step of the boundary, so the threshold is
-  // t0 - 1 + (number of true tests among t0-1, t0, t0+1); the two outer tests guard that claim.
-  const int n = k2_pred(t0 - 1, p0, T) + k2_pred(t0, p0, T) + k2_pred(t0 + 1, p0, T);
-  int64_t t = t0 - 1 + n;
-  if (!k2_pred(t0 - 2, p0, T) || k2_pred(t0 + 2, p0, T)) {  // never taken for finite psi; exact fallback
-    t = t0 < 0 ? 0 : (t0 > 4294967296ll ? 4294967296ll : t0);
-    for (int g = 0; g < 4096 && t > 0 && !k2_pred(t - 1, p0, T); g++) t--;
-    for (int g = 0; g < 4096 && t < 4294967296ll && k2_pred(t, p0, T); g++) t++;
-  }
-  t = t < 0 ? 0 : t;
-  return static_cast<uint64_t>(t);
-}
-
-// The same count when T is a normal finite number and the estimate lies in [2, 2^32 - 3] (wave-uniform
-// test; otherwise k2_threshold_exact): the estimate is then within 2^-20 of the boundary (two roundings
-// in p0 / T 2^32, one in the test's product), so none of the exact routine's clamps, range tests or
-// outer tests can fire, and because the test is monotone in u two evaluations decide the count.
-__device__ __forceinline__ uint64_t k2_threshold(double p0, double T) {
-  const double est = p0 / T * 4294967296.0;
-  const bool safe = T >= 1e-280 && T <= 1e280 && est >= 2.0 && est <= 4294967293.0;
-  if (!__all(safe)) return k2_threshold_exact(p0, T);
-  const double t0 = __builtin_floor(est);
-  auto pred = [&](double u) { return u * (1.0 / 4294967296.0) * T < p0; };
-  const bool q0 = pred(t0);
-  const bool q1 = pred(q0 ? t0 + 1.0 : t0 - 1.0);
-  const double t = q0 ? (q1 ? t0 + 2.0 : t0 + 1.0) : (q1 ? t0 : t0 - 1.0);
-  return static_cast<uint64_t>(t);
-}
-
-// value held by lane J of the caller's quad (v_mov_b32 with DPP quad_perm, full rate)
-template <int J> __device__ __forceinline__ double quad_bcast(double v) {
-  constexpr int ctrl = J | (J << 2) | (J << 4) | (J << 6);
-  const uint64_t u = miso_d2u(v);
-  const uint32_t lo = __builtin_amdgcn_mov_dpp(static_cast<int>(u), ctrl, 0xF, 0xF, true);
-  const uint32_t hi = __builtin_amdgcn_mov_dpp(static_cast<int>(u >> 32), ctrl, 0xF, 0xF, true);
-  return miso_u2d((static_cast<uint64_t>(hi) << 32) | lo);
-}
-
-// value held by an arbitrary lane (ds_bpermute): used when a chain's lanes are not quad aligned
-__device__ __forceinline__ double lane_bcast(double v, int src_lane) {
-  const uint64_t u = miso_d2u(v);
-  const uint32_t lo = __shfl(static_cast<int>(u), src_lane);
-  const uint32_t hi = __shfl(static_cast<int>(u >> 32), src_lane);
-  return miso_u2d((static_cast<uint64_t>(hi) << 32) | lo);
-}
-
-// Evaluate routine f on 3 or 4 arguments with NR lanes of the chain working in parallel: the lane
-// with role r evaluates argument r, results are broadcast back to every lane of the chain
-// (NR == 1: plain scalar calls).  QUAD: the chain's lanes start on a quad boundary (DPP broadcast).
-// Written with scalars only -- argument arrays end up on the stack (scratch) in some instantiations.
-template <int NR, bool QUAD, int R> __device__ __forceinline__ double role_bcast(double y, int base) {
-  if (QUAD && NR == 4) return quad_bcast<R>(y);
-  return lane_bcast(y, base + R);
-}
-
-template <int NR, bool QUAD, class F>
-__device__ __forceinline__ void vec_eval3(F f, double a0, double a1, double a2, double &o0, double &o1,
-                                          double &o2, int role, int base) {
-  if (NR == 1) { o0 = f(a0); o1 = f(a1); o2 = f(a2); return; }
-  if (NR == 2) {
-    const double y = f(role == 1 ? a1 : a0);
-    o0 = role_bcast<NR, QUAD, 0>(y, base); o1 = role_bcast<NR, QUAD, 1>(y, base);
-    o2 = f(a2);
-    return;
-  }
-  const double y = f(role == 1 ? a1 : (role == 2 ? a2 : a0));
-  o0 = role_bcast<NR, QUAD, 0>(y, base); o1 = role_bcast<NR, QUAD, 1>(y, base);
-  o2 = role_bcast<NR, QUAD, 2>(y, base);
-}
-
-template <int NR, bool QUAD, class F>
-__device__ __forceinline__ void vec_eval4(F f, double a0, double a1, double a2, double a3, double &o0,
-                                          double &o1, double &o2, double &o3, int role, int base) {
-  if (NR == 1) { o0 = f(a0); o1 = f(a1); o2 = f(a2); o3 = f(a3); return; }
-  if (NR == 2) {
-    const double y = f(role == 1 ? a1 : a0), z = f(role == 1 ? a3 : a2);
-    o0 = role_bcast<NR, QUAD, 0>(y, base); o1 = role_bcast<NR, QUAD, 1>(y, base);
-    o2 = role_bcast<NR, QUAD, 0>(z, base); o3 = role_bcast<NR, QUAD, 1>(z, base);
-    return;
-  }
-  if (NR == 3) {
-    const double y = f(role == 1 ? a1 : (role == 2 ? a2 : a0));
-    o0 = role_bcast<NR, QUAD, 0>(y, base); o1 = role_bcast<NR, QUAD, 1>(y, base);
-    o2 = role_bcast<NR, QUAD, 2>(y, base);
-    o3 = f(a3);
-    return;
-  }
-  const double y = f(role == 1 ? a1 : (role == 2 ? a2 : (role == 3 ? a3 : a0)));
-  o0 = role_bcast<NR, QUAD, 0>(y, base); o1 = role_bcast<NR, QUAD, 1>(y, base);
-  o2 = role_bcast<NR, QUAD, 2>(y, base); o3 = role_bcast<NR, QUAD, 3>(y, base);
-}
-
-}  // namespace
-
-// WPB = wavefronts per workgroup.  WPB = 8 (single-end): one workgroup fills a CU's eight resident
-// slots, wavefronts w and w + 4 share a SIMD, and with a.pair_waves the pair takes the p-th heaviest
-// and the p-th lightest group of chains (the slot list is sorted by drawing reads), so every SIMD
-// carries the same total work whatever the spread of the events' sizes.
-// MODE: 0 single-end; 1 paired-end, any event; 2 paired-end events none of whose drawing reads touches a
-// non-finite score (most): the read loop without the "bad score" bookkeeping, fragment indices prefetched.
-// (Tried and dropped: per-iteration weight tables w_k[f] = psi_k fp[f] per chain plus a per-read score
-// difference -- 17 % fewer VALU per read, but 3.9 KB of LDS per chain instead of 1.9 KB and 8 B instead of
-// 4 B per read and iteration from L2 / MALL made it 7 % SLOWER: profiles/r02_pe_k2_modes.txt.)
-#ifndef MISO_K2_PE_UNROLL
-#define MISO_K2_PE_UNROLL 1
-#endif
-#ifndef MISO_K2_PE_IDENT
-#define MISO_K2_PE_IDENT 1
-#endif
-typedef const __attribute__((address_space(3))) double *k2_lds_cdp;
-typedef const __attribute__((address_space(3))) int32_t *k2_lds_cip;
-__device__ __forceinline__ double k2_lds_f64(uint32_t addr) { return *reinterpret_cast<k2_lds_cdp>(static_cast<uintptr_t>(addr)); }
-__device__ __forceinline__ int32_t k2_lds_i32(uint32_t addr) { return *reinterpret_cast<k2_lds_cip>(static_cast<uintptr_t>(addr)); }
-
-// The kernel's body: workgroup block_x of grid_x (what blockIdx.x / gridDim.x are for sampler_k2 itself;
-// sampler_k2_mix runs two bodies of different lanes per chain side by side in one launch).
-template <int G, int MODE, int WPB>
-__device__ __forceinline__ void k2_body(const KernelArgs &a, unsigned block_x, unsigned grid_x) {
-  constexpr bool PE = MODE != 0;
-  constexpr bool PEW = MODE == 2;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_k2[];
-  double *lds_fp = reinterpret_cast<double *>(smem_k2);  // PE: fragment-length probabilities
-  const int tab_n = PEW ? pe_k2_entries(a.il) : 2 * a.il;   // entries of the score table (and, MODE 2, of the probabilities)
-  if (PE) {
-    for (int i = threadIdx.x; i < a.il; i += blockDim.x) {
-      const double v = a.frag_prob[i];
-      lds_fp[i] = v;
-      if (PEW) lds_fp[a.il + i] = v;               // MODE 2 (device.hpp pe_k2_entries): [fp, fp, 0.0, 1.0]
-    }
-    if (PEW && threadIdx.x == 0) { lds_fp[2 * a.il] = 0.0; lds_fp[2 * a.il + 1] = 1.0; }
-    __syncthreads();                               // the only block-level barrier
-  }
-  constexpr int CPW = 64 / G;                      // chains per wavefront
-  constexpr int NR = G >= 4 ? 4 : G;               // lanes cooperating on the scalar math
-  constexpr bool QUAD = (G % 4) == 0;
-  constexpr bool POW2 = (G & (G - 1)) == 0;
-  const int lane = threadIdx.x & 63;
-  const int grp_raw = lane / G;
-  const bool lane_used = grp_raw < CPW;            // 64 % G lanes at the top of the wave idle
-  const int grp = lane_used ? grp_raw : CPW - 1;
-  const int base_lane = grp * G;
-  const int sub = lane_used ? lane - base_lane : 0;
-  const int role = sub % NR;
-  const long n_chains = static_cast<long>(a.n_slots) * a.C;
-  long wave_id = static_cast<long>(block_x) * WPB + (threadIdx.x >> 6);
-  if (WPB == 8 && a.pair_waves) {
-    const int w = threadIdx.x >> 6;
-    const long p = 4 * static_cast<long>(block_x) + (w & 3);             // pair index: heaviest first
-    wave_id = (w < 4) ? p : static_cast<long>(grid_x) * 8 - 1 - p;       // ... with the p-th lightest
-  }
-  if (wave_id * CPW >= n_chains) return;  // whole wavefront idle
-  long slot = wave_id * CPW + grp;
-  const bool live = lane_used && slot < n_chains;  // dead lanes shadow a chain and store nothing
-  if (slot >= n_chains) slot = n_chains - 1;
-
-  const int ev = a.slot_event[slot / a.C];
-  const uint32_t chain = static_cast<uint32_t>(slot % a.C);
-  const DevEvent E = a.events[ev];
-  const uint32_t event_id = E.has_id ? E.explicit_id : a.first_event_id + static_cast<uint32_t>(ev);
-  const double *consts = reinterpret_cast<const double *>(a.in_pool + E.off_consts);
-  const int *base = reinterpret_cast<const int *>(a.in_pool + E.off_base);
-  K2Consts c;
-  c.cst0 = consts[0]; c.cst1 = consts[1]; c.is0 = consts[2]; c.is1 = consts[3];
-  c.hm0 = consts[4]; c.hm1 = consts[5]; c.lg_sum = consts[6]; c.lg_each = consts[7];
-  c.sigma = consts[8]; c.sd = consts[9]; c.covar = consts[10];
-  const int base0 = base[0], base1 = base[1];
-  const int n_draw = E.n_draw;
-  const int nfq = n_draw >> 2, rem = n_draw & 3;  // full draw quads, draws in the partial one
-  // trips of the Gibbs loop (UQ quads per lane per trip); must be wave-uniform
-  constexpr int UQ = PE ? 2 : MISO_K2_UQ;
-  int trips = (nfq + UQ * G - 1) / (UQ * G);
-  int any_rem = rem;
-  for (int off = 32; off >= 1; off >>= 1) {
-    trips = max(trips, __shfl_xor(trips, off));
-    any_rem |= __shfl_xor(any_rem, off);
-  }
-  trips = __builtin_amdgcn_readfirstlane(trips);     // wave-uniform by construction: say so
-  any_rem = __builtin_amdgcn_readfirstlane(any_rem);
-
-  double *samples = reinterpret_cast<double *>(a.out_pool + E.off_samples);
-  double *loglik = reinterpret_cast<double *>(a.out_pool + E.off_loglik);
-  uint8_t *drawass = a.out_pool + E.off_drawass;
-  int32_t *trace = (E.off_trace == NO_TRACE) ? nullptr
-                                             : reinterpret_cast<int32_t *>(a.out_pool + E.off_trace);
-  const uint32_t k0 = static_cast<uint32_t>(a.seed), k1 = static_cast<uint32_t>(a.seed >> 32);
-  const uint32_t c2_gibbs = MISO_SITE_GIBBS | (chain << 8), c2_mh = MISO_SITE_MH | (chain << 8);
-  const GibbsRng rng = gibbs_rng_init(a.seed, event_id, chain);
-
-  int cnt0 = 0, cnt1 = 0;
-  int64_t rfix = 0; int rbad = 0;   // PE: fixed-point sum of the assigned reads' fragment scores
-  const uint4 *fragq = reinterpret_cast<const uint4 *>(a.in_pool + E.off_draw);  // PE: 4 reads x (f0 | f1 << 16)
-  // PE: the event's fixed-point score table (2 x il int32) sits in the chain's LDS slice: a per-read
-  // gather from L2 would cost more than the whole rest of the Gibbs step
-  int32_t *lds_tab = reinterpret_cast<int32_t *>(smem_k2 + (((PEW ? tab_n : a.il) * 8 + 15) & ~15)) +
-                     (static_cast<size_t>(threadIdx.x >> 6) * CPW + grp) * tab_n;
-  if (PE) {
-    const int32_t *sfix = reinterpret_cast<const int32_t *>(a.in_pool + E.off_sfix);
-    for (int i = sub; i < tab_n; i += G) lds_tab[i] = i < 2 * a.il ? sfix[i] : 0;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  }
-  // MODE 2 reads the LDS by byte address (no symbol arithmetic, never a flat access): the dynamic LDS -- the
-  // only LDS of this kernel -- starts at 0
-  if (PEW && static_cast<uint32_t>(reinterpret_cast<uintptr_t>(smem_k2)) != 0u) __builtin_trap();
-  const uint32_t tab_addr = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds_tab));
-  const uint4 *denseq = reinterpret_cast<const uint4 *>(a.in_pool + (PEW ? E.off_dense : E.off_draw));
-  PsiTerms cur;
-  double alpha = 0.0;
-
-  // paired-end pick of one read (miso_paired.c:11-22, 64-68): weights psi_k * fragProb(frag_k)
-  auto pe_pick = [&](uint32_t ff, uint32_t uword, int64_t &acc, int &bad) __attribute__((always_inline)) {
-    const uint32_t f0 = ff & 0xFFFFu, f1 = ff >> 16;
-    const double c0 = 0.0 + cur.x0 * lds_fp[f0];
-    const double T = c0 + cur.x1 * lds_fp[f1];
-    const bool p0 = miso_u01(uword) * T < c0;
-    const int32_t v = lds_tab[p0 ? f0 : a.il + f1];
-    const bool isbad = v == SFIX_BAD;
-    bad |= isbad ? 1 : 0;
-    acc += isbad ? 0 : v;
-    return p0;
-  };
-
-  // Gibbs step for the current psi (miso.c:30-91 restricted to two compatible isoforms)
-#ifdef MISO_K2_PROFILE
-  uint64_t pf_mh = 0, pf_thr = 0, pf_loop = 0, pf_red = 0, pf_rec = 0;
-#endif
-  auto gibbs = [&](uint32_t iter) {
-    if (PEW) {
-      // MODE 2: no drawing read of the event touches a non-finite score (host.cpp pe_delta): no "bad"
-      // bookkeeping; dense records (device.hpp pe_k2_entries): one index per (read, isoform) serves the
-      // probability and the score, lanes beyond the last quad work on the quad of padding reads behind it
-      // (weight 0 against a positive one: never isoform 0, score 0) -- no range tests; the next quad's
-      // record is fetched one trip ahead.  Per read: two SDWA shifts, two LDS reads by byte address, the
-      // reference's arithmetic (miso_paired.c:11-22, 64-68), one select, one add-with-carry for the count,
-      // one 64-bit multiply-add for the score sum.
-      const uint32_t n0r0 = rng.p1hi ^ iter ^ k0;
-      const int nq = (n_draw + 3) >> 2;
-      const double x0 = cur.x0, x1 = cur.x1;
-      int d0 = 0; int64_t acc = 0;
-      const uint32_t three = 3u;
-      auto rec_at = [&](int q) __attribute__((always_inline)) { return denseq[(lane_used && q < nq) ? q : nq]; };
-      uint4 fn = rec_at(sub);
-#pragma unroll MISO_K2_PE_UNROLL
-      for (int j = 0; j < 2 * trips + 1; j++) {
-        const int q = sub + j * G;
-        const uint4 f = fn;
-        fn = rec_at(q + G);
-        const miso_u32x4 u = philox_gibbs<true>(rng, static_cast<uint32_t>(q), n0r0);
-        const uint32_t ff[4] = {f.x, f.y, f.z, f.w};
-        uint32_t o0[4], sel[4]; double c0[4], rnd[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          uint32_t o1;   // 8 x index
-          asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(o0[r]) : "v"(three), "v"(ff[r]));
-          asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(o1) : "v"(three), "v"(ff[r]));
-          // (Dropping the "0.0 +" -- an identity here -- was measured 6 % SLOWER in the loop's first form;
-          // the add seems to give the scheduler a better order.)
-#if MISO_K2_PE_IDENT
-          c0[r] = 0.0 + x0 * k2_lds_f64(o0[r]);
-#else
-          c0[r] = x0 * k2_lds_f64(o0[r]);
-#endif
-          const double T = c0[r] + x1 * k2_lds_f64(o1);
-          rnd[r] = miso_u01(u.v[r]) * T;
-          sel[r] = o1;
-        }
-        {   // the four compares first: a VALU read of an SGPR must stay two instructions behind the compare that wrote it
-          uint64_t m0, m1, m2, m3, junk;
-          asm("v_cmp_lt_f64_e64 %5, %10, %14\n\tv_cmp_lt_f64_e64 %6, %11, %15\n\tv_cmp_lt_f64_e64 %7, %12, %16\n\tv_cmp_lt_f64_e64 %8, %13, %17\n\t"
-              "v_cndmask_b32_e64 %0, %0, %18, %5\n\tv_addc_co_u32_e64 %4, %9, %4, 0, %5\n\t"
-              "v_cndmask_b32_e64 %1, %1, %19, %6\n\tv_addc_co_u32_e64 %4, %9, %4, 0, %6\n\t"
-              "v_cndmask_b32_e64 %2, %2, %20, %7\n\tv_addc_co_u32_e64 %4, %9, %4, 0, %7\n\t"
-              "v_cndmask_b32_e64 %3, %3, %21, %8\n\tv_addc_co_u32_e64 %4, %9, %4, 0, %8"
-              : "+v"(sel[0]), "+v"(sel[1]), "+v"(sel[2]), "+v"(sel[3]), "+v"(d0), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3), "=&s"(junk)
-              : "v"(rnd[0]), "v"(rnd[1]), "v"(rnd[2]), "v"(rnd[3]), "v"(c0[0]), "v"(c0[1]), "v"(c0[2]), "v"(c0[3]),
-                "v"(o0[0]), "v"(o0[1]), "v"(o0[2]), "v"(o0[3]));
-        }
-        int32_t v[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) v[r] = k2_lds_i32(tab_addr + (sel[r] >> 1));
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          uint64_t junk;
-          asm("v_mad_i64_i32 %0, %1, %2, 1, %0" : "+v"(acc), "=s"(junk) : "v"(v[r]));
-        }
-      }
-      if (POW2) {
-#pragma unroll
-        for (int off = G >> 1; off >= 1; off >>= 1) { d0 += __shfl_xor(d0, off); acc += __shfl_xor(acc, off); }
-      } else {
-        int tot = 0; int64_t ta = 0;
-#pragma unroll
-        for (int j = 0; j < G; j++) { tot += __shfl(d0, base_lane + j); ta += __shfl(acc, base_lane + j); }
-        d0 = tot; acc = ta;
-      }
-      cnt0 = base0 + d0;
-      cnt1 = base1 + (n_draw - d0);
-      rfix = E.base_sfix + acc;
-      rbad = E.base_bad;
-      return;
-    }
-    if (PE) {
-      const uint32_t n0r0 = rng.p1hi ^ iter ^ k0;
-      const int nq = (n_draw + 3) >> 2;
-      int d0 = 0, bad = 0; int64_t acc = 0;
-      // No data-dependent branches: a quad beyond the chain's reads is loaded from a clamped address
-      // and its reads are masked, so the four reads' LDS gathers are all in flight at once (the
-      // guarded form waited on each read's tables separately: 16 s_waitcnt per quad) and the round
-      // keys are rebuilt per block instead of spilled (gibbs_rng.hpp).
-      const int q_last = max(nq - 1, 0);
-      const double x0 = cur.x0, x1 = cur.x1;
-      for (int j = 0; j < 2 * trips + 1; j++) {
-        const int q = sub + j * G;
-        const miso_u32x4 u = philox_gibbs<true>(rng, static_cast<uint32_t>(q), n0r0);
-        const uint4 f = fragq[min(q, q_last)];
-        const int left = (q < nq && lane_used) ? n_draw - 4 * q : 0;   // reads of this quad that exist
-        const uint32_t ff[4] = {f.x, f.y, f.z, f.w};
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const bool valid = left > r;
-          const uint32_t fv = valid ? ff[r] : 0u;
-          const uint32_t f0 = fv & 0xFFFFu, f1 = fv >> 16;
-          const double c0 = 0.0 + x0 * lds_fp[f0];               // miso_paired.c:11-22, 64-68
-          const double T = c0 + x1 * lds_fp[f1];
-          const bool p0 = miso_u01(u.v[r]) * T < c0;
-          const int32_t v = lds_tab[p0 ? f0 : a.il + f1];
-          const bool isbad = v == SFIX_BAD;
-          bad |= (valid & isbad) ? 1 : 0;
-          acc += (valid & !isbad) ? v : 0;
-          d0 += (valid & p0) ? 1 : 0;
-        }
-      }
-      if (POW2) {
-#pragma unroll
-        for (int off = G >> 1; off >= 1; off >>= 1) {
-          d0 += __shfl_xor(d0, off); acc += __shfl_xor(acc, off); bad |= __shfl_xor(bad, off);
-        }
-      } else {
-        int tot = 0, tb = 0; int64_t ta = 0;
-#pragma unroll
-        for (int j = 0; j < G; j++) {
-          tot += __shfl(d0, base_lane + j); ta += __shfl(acc, base_lane + j); tb |= __shfl(bad, base_lane + j);
-        }
-        d0 = tot; acc = ta; bad = tb;
-      }
-      cnt0 = base0 + d0;
-      cnt1 = base1 + (n_draw - d0);
-      rfix = E.base_sfix + acc;
-      rbad = bad | E.base_bad;
-      return;
-    }
-    PROF_T(g0);
-    const uint64_t t = k2_threshold(cur.x0, (0.0 + cur.x0) + cur.x1);
-    const uint32_t tm = static_cast<uint32_t>(t - 1);  // u < t  <=>  t != 0 && u <= t - 1
-    const uint32_t n0r0 = rng.p1hi ^ iter ^ k0;
-    int d0 = 0;
-    PROF_T(g1);
-    PROF_ADD(pf_thr, g0, g1);
-    for (int j = 0; j < trips; j++) {
-      // UQ independent Philox blocks in flight per lane: the 9 dependent rounds of one block leave
-      // the multiplier pipe idle between rounds; interleaved blocks fill it
-      miso_u32x4 u[UQ];
-#pragma unroll
-      for (int i = 0; i < UQ; i++)
-        u[i] = philox_gibbs(rng, static_cast<uint32_t>(sub + (UQ * j + i) * G), n0r0);
-#pragma unroll
-      for (int i = 0; i < UQ; i++) {
-        const int ci = (u[i].v[0] <= tm) + (u[i].v[1] <= tm) + (u[i].v[2] <= tm) + (u[i].v[3] <= tm);
-        d0 += (sub + (UQ * j + i) * G < nfq) ? ci : 0;
-      }
-    }
-    if (any_rem) {  // the partial quad, owned by one lane of the group
-      const miso_u32x4 u = philox_gibbs(rng, static_cast<uint32_t>(nfq), n0r0);
-      const int cp = (rem > 0 && u.v[0] <= tm) + (rem > 1 && u.v[1] <= tm) + (rem > 2 && u.v[2] <= tm);
-      d0 += (sub == (nfq % G)) ? cp : 0;
-    }
-    if (t == 0 || !lane_used) d0 = 0;
-    PROF_T(g2);
-    PROF_ADD(pf_loop, g1, g2);
-    if (POW2) {
-#pragma unroll
-      for (int off = G >> 1; off >= 1; off >>= 1) d0 += __shfl_xor(d0, off);
-    } else {
-      int tot = 0;
-#pragma unroll
-      for (int j = 0; j < G; j++) tot += __shfl(d0, base_lane + j);
-      d0 = tot;
-    }
-    cnt0 = base0 + d0;
-    cnt1 = base1 + (n_draw - d0);
-    PROF_T(g3);
-    PROF_ADD(pf_red, g2, g3);
-  };
-
-  // the per-read picks of one Gibbs step, written once for the caller (miso.c:943-946)
-  auto gibbs_write = [&](uint32_t iter) {
-    const uint64_t t = PE ? 0 : k2_threshold(cur.x0, (0.0 + cur.x0) + cur.x1);
-    const int nq = (n_draw + 3) >> 2;
-    for (int q = sub; q < nq; q += G) {
-      const miso_u32x4 u = miso_philox4x32_10(static_cast<uint32_t>(q), iter, c2_gibbs, event_id, k0, k1);
-      const uint4 f = PE ? fragq[q] : make_uint4(0, 0, 0, 0);
-      const uint32_t ff[4] = {f.x, f.y, f.z, f.w};
-      for (int j = 0; j < 4; j++) {
-        if (4 * q + j >= n_draw) continue;
-        int64_t dummy = 0; int db = 0;
-        const bool p0 = PE ? pe_pick(ff[j], u.v[j], dummy, db) : (static_cast<uint64_t>(u.v[j]) < t);
-        drawass[4 * q + j] = p0 ? 0 : 1;
-      }
-    }
-  };
-
-  // the iteration's MH-site draws: the accept word and the proposal's standard normal (random.c:1543-1551).
-  // They depend on (seed, event, chain, iteration) only, not on the chain's state, so the NR lanes of a
-  // chain compute them for NR consecutive iterations at once (lane role r: iteration m0 + r) -- one
-  // Philox block + qnorm per NR iterations per lane instead of one per iteration on every lane.
-  auto mh_draws = [&](uint32_t iter, double &z, uint32_t &accept_word) {
-    const miso_u32x4 b = miso_philox4x32_10(0u, iter, c2_mh, event_id, k0, k1);
-    accept_word = b.v[0];
-    z = miso_det_norm_from_unif(miso_u01(b.v[2]), miso_u01(b.v[3]));
-  };
-  // alpha' = alpha + sd z, psi' = logit_inv(alpha') (miso.c:449-471)
-  auto propose = [&](double z, double &alphaN, double &x0, double &x1) {
-    alphaN = alpha + c.sd * z;
-    const double e = miso_det_exp(alphaN);
-    const double sumexp = (0.0 + e) + 1.0;
-    x0 = e / sumexp;
-    x1 = 1 - (0.0 + x0);
-  };
-
-  // ---- initial state (miso.c:362-369 K == 2: alpha = 0; miso.c:834, 841) ----
-  {
-    double aN, x0, x1, z; uint32_t w;
-    mh_draws(MISO_ITER_INIT, z, w);
-    propose(z, aN, x0, x1);
-    alpha = aN;
-    cur = psi_terms(x0, x1, c.cst0, c.cst1);
-  }
-  gibbs(MISO_ITER_INIT);
-  if (a.M == 0 && live && chain == 0) gibbs_write(MISO_ITER_INIT);
-
-  uint64_t hash = 0xCBF29CE484222325ull;
-  int accepted = 0, lagCounter = 0, noS = 0;
-  const bool writer = live && sub == 0;
-
-  double zbuf = 0.0; uint32_t awbuf = 0u;   // this lane's share of the next NR iterations' MH draws
-  for (int m = 0; m < a.M; m++) {
-    hash = (hash ^ static_cast<uint32_t>(cnt0)) * 0x100000001B3ull;
-    hash = (hash ^ static_cast<uint32_t>(cnt1)) * 0x100000001B3ull;
-    if (trace && writer) {
-      int32_t *row = trace + (static_cast<size_t>(m) * a.C + chain) * 2;
-      row[0] = cnt0; row[1] = cnt1;
-    }
-    PROF_T(m0);
-    double alphaN, x0, x1; uint32_t accept_word;
-    {
-      double z;
-      if (NR == 1) {
-        mh_draws(static_cast<uint32_t>(m), z, accept_word);
-      } else {
-        const int ph = m % NR;
-        if (ph == 0) mh_draws(static_cast<uint32_t>(m + role), zbuf, awbuf);   // iterations m .. m + NR - 1
-        z = lane_bcast(zbuf, base_lane + ph);
-        accept_word = static_cast<uint32_t>(__shfl(static_cast<int>(awbuf), base_lane + ph));
-      }
-      propose(z, alphaN, x0, x1);
-    }
-    PsiTerms nw;
-    double ptoCS, ctoPS;
-    {
-      // NR lanes, one routine, NR arguments per call (see vec_eval)
-      auto f_log = [](double v) { return miso_det_log(v); };
-      auto f_exp = [](double v) { return miso_det_exp(v); };
-      const double ltheta = 1.0 - x0;
-      double lgtN;
-      vec_eval3<NR, QUAD>(f_log, x0, x1, x0 / ltheta, nw.lx0, nw.lx1, lgtN, role, base_lane);
-      nw.x0 = x0; nw.x1 = x1; nw.lgt = lgtN;
-      nw.pr = 1.0 / (1.0 * x0) / ltheta;
-      const double lp0 = nw.lx0 + c.cst0, lp1 = nw.lx1 + c.cst1;
-      const double maxv = (lp1 > lp0) ? lp1 : lp0;  // miso.c:137-140: maxv starts at entry 0
-      double ex0, ex1, xp, xc;
-      vec_eval4<NR, QUAD>(f_exp, lp0 - maxv, lp1 - maxv,
-                          prop_exponent(cur.lgt, alphaN, c.sigma),   // theta = psi,  mu = alpha'
-                          prop_exponent(nw.lgt, alpha, c.sigma),     // theta = psi', mu = alpha
-                          ex0, ex1, xp, xc, role, base_lane);
-      double ls;
-      vec_eval3<NR, QUAD>(f_log, (0.0 + ex0) + ex1, c.covar * cur.pr * xp, c.covar * nw.pr * xc, ls, ptoCS,
-                          ctoPS, role, base_lane);
-      const double lse = ls + maxv;
-      nw.lpn0 = lp0 - lse;
-      nw.lpn1 = lp1 - lse;
-    }
-    const double rp = PE ? (rbad ? miso_u2d(0x7FF8000000000000ull)
-                                 : static_cast<double>(rfix) * (1.0 / MISO_SFIX_SCALE))
-                         : 0.0;
-    const double pp = joint<PE>(nw, cnt0, cnt1, c, rp);
-    const double pc = joint<PE>(cur, cnt0, cnt1, c, rp);
-    const double acceptP = (m > 0) ? miso_det_exp(pp + ptoCS - (pc + ctoPS)) : miso_det_exp(pp - pc);
-    const bool acc = (acceptP >= 1) || (miso_u01(accept_word) < acceptP);
-    double cJS = pc;
-    if (acc) { cur = nw; alpha = alphaN; cJS = pp; accepted++; }
-    PROF_T(m1);
-    PROF_ADD(pf_mh, m0, m1);
-
-    if (m >= a.B) {  // miso.c:882-893
-      if (lagCounter == a.lag - 1) {
-        if (writer) {
-          const size_t col = static_cast<size_t>(noS) + chain;
-          *reinterpret_cast<double2 *>(samples + col * 2) = make_double2(cur.x0, cur.x1);
-          loglik[col] = cJS;
-        }
-        noS += a.C;
-        lagCounter = 0;
-      } else {
-        lagCounter++;
-      }
-    }
-    PROF_T(m2);
-    PROF_ADD(pf_rec, m1, m2);
-    gibbs(static_cast<uint32_t>(m));
-  }
-#ifdef MISO_K2_PROFILE
-  if (writer && chain == 0 && a.M > 8) {  // smuggle the phase cycle counts out through the log scores
-    loglik[0] = static_cast<double>(pf_mh); loglik[1] = static_cast<double>(pf_thr);
-    loglik[2] = static_cast<double>(pf_loop); loglik[3] = static_cast<double>(pf_red);
-    loglik[4] = static_cast<double>(pf_rec);
-  }
-#endif
-  if (a.M > 0 && live && chain == 0) gibbs_write(static_cast<uint32_t>(a.M - 1));
-  hash = (hash ^ static_cast<uint32_t>(cnt0)) * 0x100000001B3ull;
-  hash = (hash ^ static_cast<uint32_t>(cnt1)) * 0x100000001B3ull;
-  if (writer) {
-    if (trace) {
-      int32_t *row = trace + (static_cast<size_t>(a.M) * a.C + chain) * 2;
-      row[0] = cnt0; row[1] = cnt1;
-    }
-    ChainStats *st = reinterpret_cast<ChainStats *>(a.out_pool + E.off_stats) + chain;
-    st->counts_hash = hash;
-    st->accepted = accepted;
-    st->hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_REG_HW_ID, all 32 bits
-  }
-}
 
 template <int G, int MODE, int WPB>
 __global__ __launch_bounds__(64 * WPB, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void sampler_k2(const KernelArgs a) {

@@ -22,6 +22,7 @@ namespace miso {
 template <bool PE> __global__ void sampler_wave(const KernelArgs a);
 template <int G, int MODE, int WPB> __global__ void sampler_k2(const KernelArgs a);
 template <int GA, int GB> __global__ void sampler_k2_mix(const KernelArgs a);
+template <int MODE, int WPB> __global__ void sampler_k2_multi(const KernelArgs a);
 __global__ void compare_kernel(const DevEvent *, const unsigned char *, const DevEvent *, const unsigned char *, int, int,
                                double, const uint64_t *, double *);
 __global__ void match_kernel(const MatchEvent *, const int2 *, const int *, const int *, const int *, const int *,
@@ -330,7 +331,7 @@ void miso_batch::upload(int dev) {
   std::vector<int32_t> k2, gen;
   for (int i = 0; i < n; i++) ((events[i].K == 2) ? k2 : gen).push_back(i);
   // (paired-end: the events sampler_k2's MODE 2 can take come first, MISO_NO_PE_DELTA=1 sends all to MODE 1)
-  const bool use_delta = std::getenv("MISO_NO_PE_DELTA") == nullptr;
+  use_delta = std::getenv("MISO_NO_PE_DELTA") == nullptr;   // fixed here: the slot order depends on it
   std::stable_sort(k2.begin(), k2.end(), [&](int x, int y) {
     const bool dx = use_delta && events[x].pe_delta && !events[x].draw_dense.empty(), dy = use_delta && events[y].pe_delta && !events[y].draw_dense.empty();
     return dx != dy ? dx : events[x].n_draw > events[y].n_draw; });
@@ -339,7 +340,7 @@ void miso_batch::upload(int dev) {
   // the general kernel's wavefronts loop to their largest K and longest draw list: group alike
   std::stable_sort(gen.begin(), gen.end(), [&](int x, int y) {
     return events[x].K != events[y].K ? events[x].K > events[y].K : events[x].n_draw > events[y].n_draw; });
-  gen_runs.clear(); tuned_k2_G = 0;
+  gen_runs.clear(); tuned_k2_G = 0; k2_plan_key = k2w_plan_key = -1;
   for (size_t j = 0; j < gen.size(); j++) {
     const PackedEvent &e = events[gen[j]];
     const int kc = e.K <= 4 ? 4 : (e.K <= 8 ? 8 : (e.K <= 12 ? 12 : (e.K <= 16 ? 16 : 32)));
@@ -358,6 +359,7 @@ void miso_batch::upload(int dev) {
   }
   n_k2 = static_cast<int>(k2.size()); n_gen = static_cast<int>(gen.size());
   k2.insert(k2.end(), gen.begin(), gen.end());
+  h_slots = k2;
   HIP_OK(hipMalloc(reinterpret_cast<void **>(&d_slots), std::max<size_t>(n, 1) * sizeof(int32_t)));
   if (n) HIP_OK(hipMemcpy(d_slots, k2.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
   if (p.paired) {
@@ -580,9 +582,12 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   if (n_k2w > 0) {   // MODE 2: two workgroups per CU may share the LDS (80 KB each)
     const long chains = static_cast<long>(n_k2w) * p.noChains;
     const int maxq = (events[k2_first_event()].n_draw + 3) / 4;
-    const int max_cpw = std::max<int>(1, static_cast<int>((LDS_MAX - k2w_fp) / (4 * k2w_tab)));
-    if (const char *env = std::getenv("MISO_LANES_PER_CHAIN")) k2w_G = std::atoi(env);
-    else k2w_G = choose_lanes_per_chain(chains, maxq, slots_for(chains), max_cpw);
+    const long lds_left = static_cast<long>(LDS_MAX) - static_cast<long>(k2w_fp);
+    const int max_cpw = static_cast<int>(std::max<long>(1, lds_left / static_cast<long>(4 * k2w_tab)));
+    if (const char *env = std::getenv("MISO_LANES_PER_CHAIN")) {
+      k2w_G = std::atoi(env);
+      if (k2w_G < 1 || k2w_G > 64) MISO_FAIL(MISO_EINVAL, "MISO_LANES_PER_CHAIN must be one of 1-10,12,16,21,32,64");
+    } else k2w_G = choose_lanes_per_chain(chains, maxq, slots_for(chains), max_cpw);
     while (k2w_G < 64 && static_cast<size_t>(64 / k2w_G) > static_cast<size_t>(max_cpw)) k2w_G *= 2;   // a forced choice never exceeds the LDS
   }
   // single-end runs whose events all have a class table go to sampler_flat (kernels_flat.inl): NC chains
@@ -747,7 +752,106 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     HIP_OK(hipGetLastError());
   };
 
-  // ---- what goes on the device, kernel by kernel (miso_batch_launch_stats) ----
+  // ---- single-end two-isoform events: a lane width per event (sampler_k2_multi, kernels_k2m.hip) ----
+  // Default for single-end batches; MISO_K2_MULTI=0 (A/B, tests) or a forced MISO_LANES_PER_CHAIN: the
+  // single-width / two-width launches above.  The plan depends on the list, the chains and this kernel's share of
+  // the device only: made once per upload.  MISO_K2_COST="block,step1,step2,step3,step4" overrides the cost model,
+  // MISO_K2_TARGET=x forces the bound on a wavefront's step (tests: small batches with many widths).
+  bool k2_multi = false;
+  {
+    const int count = n_k2 - n_k2w;
+    const char *off = std::getenv("MISO_K2_MULTI");
+    if (!p.paired && count > 0 && std::getenv("MISO_LANES_PER_CHAIN") == nullptr && !(off && std::atoi(off) == 0)) {
+      const int resident = std::max(1, slots_for(static_cast<long>(count) * p.noChains) / 8);
+      const long key = static_cast<long>(resident) * 64 + p.noChains;
+      if (k2_plan_key != key || std::getenv("MISO_K2_TARGET") || std::getenv("MISO_K2_COST") || std::getenv("MISO_K2_WPB")) {
+        static const int widths[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 32, 64};
+        LaneCost cost = k2_cost_single();
+        if (const char *env = std::getenv("MISO_K2_COST"))
+          std::sscanf(env, "%lf,%lf,%lf,%lf,%lf", &cost.block, &cost.step[1], &cost.step[2], &cost.step[3], &cost.step[4]);
+        std::vector<int> nd(count);
+        for (int i = 0; i < count; i++) nd[i] = events[h_slots[n_k2w + i]].n_draw;
+        const double forced = std::getenv("MISO_K2_TARGET") ? std::atof(std::getenv("MISO_K2_TARGET")) : 0.0;
+        k2_plan = plan_lanes(nd.data(), count, p.noChains, widths, 12, 8, 8, resident, 64, cost, forced);
+        // several rounds: smaller workgroups (a workgroup starts when ALL its wavefronts' slots are free; with 8 the
+        // slots of early finishers idle: MISO defaults on 40 000 events 425 ms, with 4: see profiles/r03_k2_multi_ab.txt)
+        int wpb = k2_plan.rounds == 1 ? 8 : 4;
+        if (const char *env = std::getenv("MISO_K2_WPB")) wpb = std::atoi(env);
+        if (wpb != 8 && wpb != 4 && wpb != 1) MISO_FAIL(MISO_EINVAL, "MISO_K2_WPB must be 8, 4 or 1");
+        if (wpb != 8) k2_plan = plan_lanes(nd.data(), count, p.noChains, widths, 12, wpb >= 4 ? wpb : 0, wpb, resident * 8 / wpb, 64, cost, forced);
+        k2_plan_key = key;
+      }
+      k2_multi = k2_plan.n_segs > 0;
+    }
+  }
+  // ---- paired-end two-isoform events of MODE 2, likewise (sampler_k2_multi<2, 4>): 4, 8, ... 64 lanes per chain as far
+  // as the chains' score tables fit the workgroup's LDS, 256 lanes (the workgroup) for the largest events ----
+  bool k2w_multi = false;
+  size_t k2w_multi_lds = 0;
+  {
+    const char *off = std::getenv("MISO_K2_MULTI");
+    if (p.paired && n_k2w > 0 && std::getenv("MISO_LANES_PER_CHAIN") == nullptr && !(off && std::atoi(off) == 0)) {
+      const long lds_left = static_cast<long>(LDS_MAX) - static_cast<long>(k2w_fp) - K2_RED_BYTES;
+      const int max_cpw = static_cast<int>(std::max<long>(0, lds_left / static_cast<long>(4 * k2w_tab)));
+      const int resident = std::max(1, slots_for(static_cast<long>(n_k2w) * p.noChains) / 4);
+      const long key = static_cast<long>(resident) * 64 + p.noChains;
+      if (max_cpw >= 1 && (k2w_plan_key != key || std::getenv("MISO_K2_TARGET") || std::getenv("MISO_K2_COST"))) {
+        static const int widths[] = {4, 8, 16, 32, 64};
+        LaneCost cost = k2_cost_paired();
+        if (const char *env = std::getenv("MISO_K2_COST"))
+          std::sscanf(env, "%lf,%lf,%lf,%lf,%lf", &cost.block, &cost.step[1], &cost.step[2], &cost.step[3], &cost.step[4]);
+        std::vector<int> nd(n_k2w);
+        for (int i = 0; i < n_k2w; i++) nd[i] = events[h_slots[i]].n_draw;
+        const double forced = std::getenv("MISO_K2_TARGET") ? std::atof(std::getenv("MISO_K2_TARGET")) : 0.0;
+        k2w_plan = plan_lanes(nd.data(), n_k2w, p.noChains, widths, 5, 4, 4, resident, max_cpw, cost, forced);
+        k2w_plan_key = key;
+      }
+      k2w_multi = max_cpw >= 1 && k2w_plan.n_segs > 0;
+      if (k2w_multi) {
+        int cpw = 1;
+        for (int i = 0; i < k2w_plan.n_segs; i++)
+          if (k2w_plan.seg_lanes[i] != K2_WIDE) cpw = std::max(cpw, 64 / k2w_plan.seg_lanes[i]);
+        k2w_multi_lds = align_up(k2w_fp + 4 * static_cast<size_t>(cpw) * k2w_tab, 16);
+      }
+    }
+  }
+  auto launch_k2_multi = [&](KernelArgs ka, hipStream_t st, bool wpart = false) {
+    if (wpart) {
+      ka.slot_event = d_slots; ka.n_slots = n_k2w;
+      ka.pair_waves = 0;
+      ka.red_off = static_cast<int32_t>(k2w_multi_lds);
+      ka.n_segs = k2w_plan.n_segs;
+      for (int i = 0; i <= k2w_plan.n_segs; i++) { ka.seg_block[i] = k2w_plan.seg_block[i]; ka.seg_slot[i] = k2w_plan.seg_slot[i]; }
+      for (int i = 0; i < k2w_plan.n_segs; i++) ka.seg_lanes[i] = k2w_plan.seg_lanes[i];
+      const int lds = static_cast<int>(k2w_multi_lds + K2_RED_BYTES);
+      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sampler_k2_multi<2, 4>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      hipLaunchKernelGGL((sampler_k2_multi<2, 4>), dim3(static_cast<unsigned>(k2w_plan.seg_block[k2w_plan.n_segs])), dim3(256),
+                         lds, st, ka);
+      HIP_OK(hipGetLastError());
+      return;
+    }
+    ka.slot_event = d_slots + n_k2w; ka.n_slots = n_k2 - n_k2w;
+    ka.pair_waves = (k2_plan.rounds == 1 && k2_plan.wpb == 8) ? 1 : 0;
+    ka.red_off = 0;
+    ka.n_segs = k2_plan.n_segs;
+    for (int i = 0; i <= k2_plan.n_segs; i++) { ka.seg_block[i] = k2_plan.seg_block[i]; ka.seg_slot[i] = k2_plan.seg_slot[i]; }
+    for (int i = 0; i < k2_plan.n_segs; i++) ka.seg_lanes[i] = k2_plan.seg_lanes[i];
+    const dim3 grid(static_cast<unsigned>(k2_plan.seg_block[k2_plan.n_segs]));
+    switch (k2_plan.wpb) {
+    case 8: hipLaunchKernelGGL((sampler_k2_multi<0, 8>), grid, dim3(512), K2_RED_BYTES, st, ka); break;
+    case 4: hipLaunchKernelGGL((sampler_k2_multi<0, 4>), grid, dim3(256), K2_RED_BYTES, st, ka); break;
+    default: hipLaunchKernelGGL((sampler_k2_multi<0, 1>), grid, dim3(64), 0, st, ka); break;
+    }
+    HIP_OK(hipGetLastError());
+  };
+
+  auto k2_name = [&](int G, bool wpart) {
+    return "sampler_k2<" + std::to_string(G) + (p.paired ? (wpart ? ", 2, 4>" : ", 1, 4>") : (k2_pair ? ", 0, 8>" : ", 0, 4>"));
+  };
+  // ---- what goes on the device, kernel by kernel (miso_batch_launch_stats): built on demand ----
+  const LanePlan plan_copy = k2_plan, planw_copy = k2w_plan;
+  stats_builder = [=]() {
   kernel_stats.clear();
   auto add_stat = [&](const std::string &name, double waves, double trips, double chains, double words) {
     miso_kernel_stat_t ks{};
@@ -759,7 +863,8 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   auto k2_name = [&](int G, bool wpart) {
     return "sampler_k2<" + std::to_string(G) + (p.paired ? (wpart ? ", 2, 4>" : ", 1, 4>") : (k2_pair ? ", 0, 8>" : ", 0, 4>"));
   };
-  const bool use_delta = std::getenv("MISO_NO_PE_DELTA") == nullptr;
+  auto k2_mix_name = [&](int G) { return "sampler_k2_mix<" + std::to_string(G + 1) + ", " + std::to_string(G) + ">"; };
+  auto flat_name = [&](const GenRun &run) { return "sampler_flat<" + std::to_string(run.kc) + ">"; };
   for (int part = 0; part < 2; part++) {
     const bool wpart = part == 0;
     const int count = wpart ? n_k2w : n_k2 - n_k2w, k2G = wpart ? k2w_G : k2_G;
@@ -785,7 +890,23 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
         trips += p.paired ? 2 * t + 1 : 2 * t + (any_rem ? 1 : 0);   // counted in blocks per lane
       }
     };
-    if (!wpart && k2_mix > 0) {
+    if (wpart ? k2w_multi : k2_multi) {
+      const LanePlan &pl = wpart ? planw_copy : plan_copy;
+      for (int sg = 0; sg < pl.n_segs; sg++) {
+        const long c0 = static_cast<long>(pl.seg_slot[sg]) * C, c1 = static_cast<long>(pl.seg_slot[sg + 1]) * C;
+        if (pl.seg_lanes[sg] == K2_WIDE) {
+          for (long c = c0; c < c1; c++) {
+            const int n = nd[c / C];
+            const int wl = 64 * pl.wpb;
+            const int t = ((n >> 2) + 2 * wl - 1) / (2 * wl);
+            trips += pl.wpb * (p.paired ? 2 * t + 1 : 2 * t + ((n & 3) ? 1 : 0));
+            words += n; waves += pl.wpb;
+          }
+        } else slice(c0, c1, pl.seg_lanes[sg]);
+      }
+      add_stat("sampler_k2_multi<" + std::string(wpart ? "2, " : "0, ") + std::to_string(pl.wpb) + ">", static_cast<double>(waves), trips,
+               static_cast<double>(chains), words);
+    } else if (!wpart && k2_mix > 0) {
       slice(0, static_cast<long>(k2_mix) * C, k2G + 1);
       slice(static_cast<long>(k2_mix) * C, chains, k2G);
       add_stat(k2_mix_name(k2G), static_cast<double>(waves), trips, static_cast<double>(chains), words);
@@ -826,6 +947,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
                              (p.paired ? "true" : "false") + (G == 64 ? std::string(">") : ", " + std::to_string(run.kc) + ">");
     add_stat(name, static_cast<double>(waves), trips, static_cast<double>(chains), words);
   }
+  };   // stats_builder
 
   HIP_OK(hipEventRecord(ev0, stream));                  // events bracket the sampler kernels only
   // kernel i > 0 goes to its own stream, forked from and joined back into the batch's stream
@@ -842,14 +964,22 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     HIP_OK(hipStreamWaitEvent(aux_streams[i - 1], ev0, 0));
     return aux_streams[i - 1];
   };
-  if (n_k2w > 0) {
+  if (n_k2w > 0 && k2w_multi) {
+    lanes_per_chain = k2w_plan.seg_lanes[k2w_plan.n_segs - 1];
+    last_kernels = "sampler_k2_multi<2, 4>";
+    launch_k2_multi(a, stream_for_next(), true);
+  } else if (n_k2w > 0) {
     lanes_per_chain = k2w_G;
     last_kernels = k2_name(k2w_G, true);
     launch_k2(a, k2w_G, stream_for_next(), true);
   }
   if (n_k2 - n_k2w > 0) {
     lanes_per_chain = k2_G;
-    if (k2_mix > 0) {
+    if (k2_multi) {
+      lanes_per_chain = k2_plan.seg_lanes[k2_plan.n_segs - 1];
+      last_kernels += std::string(last_kernels.empty() ? "" : ",") + "sampler_k2_multi<0, " + std::to_string(k2_plan.wpb) + ">";
+      launch_k2_multi(a, stream_for_next());
+    } else if (k2_mix > 0) {
       last_kernels += std::string(last_kernels.empty() ? "" : ",") + k2_mix_name(k2_G);
       launch_k2_mix(a, k2_G, stream_for_next());
     } else {

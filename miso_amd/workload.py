@@ -39,6 +39,25 @@ def mixed_k(event_id, K):
     return K
 
 
+# Read counts of a real run are nothing like "1000 per event": an hg19 event set sees tens of reads at most events
+# and 10^4 ... 10^5 at a few highly expressed genes.  HG19_LIKE = log-normal, median 300, sigma 1 (mean ~ 495),
+# clipped to [20, 10^5], and one event in ~10 000 planted at 3 x 10^4 ... 10^5 reads.
+HG19_LIKE = ("lognormal", 300.0, 1.0, 20, 100000, 9973)
+
+
+def event_n_reads(event_id, n_reads):
+    """n_reads itself, or for a distribution spec (HG19_LIKE) a pure function of the event id."""
+    if not isinstance(n_reads, (tuple, list)):
+        return int(n_reads)
+    kind, median, sigma, lo, hi, plant = n_reads
+    assert kind == "lognormal"
+    rng = np.random.default_rng(7919 * GEN_SEED + int(event_id))
+    n = median * np.exp(sigma * rng.standard_normal())
+    if plant and int(event_id) % plant == plant // 2:
+        n = hi * rng.uniform(0.3, 1.0)
+    return int(min(max(round(n), lo), hi))
+
+
 def build_batch(first_event_id, n_events, K=2, n_reads=1000, read_len=36, iters=7500, burn=2500,
                 lag=1, chains=1, paired=False, mean=250.0, var=900.0, counts_trace=False,
                 device_match=False):
@@ -50,7 +69,7 @@ def build_batch(first_event_id, n_events, K=2, n_reads=1000, read_len=36, iters=
     for i in range(n_events):
         gid = first_event_id + i
         exons, isoforms, expr = event_gene(gid, mixed_k(gid, K), **kw)
-        b.add_simulated(capi.Gene(exons, isoforms), expr, n_reads, GEN_SEED + gid)
+        b.add_simulated(capi.Gene(exons, isoforms), expr, event_n_reads(gid, n_reads), GEN_SEED + gid)
     return b
 
 
@@ -59,7 +78,7 @@ def event_reads(event_id, K=2, n_reads=1000, read_len=36, paired=False, mean=250
     kw = dict(min_len=400, max_len=800, gap=300) if paired else {}
     exons, isoforms, expr = event_gene(event_id, mixed_k(event_id, K), **kw)
     g = capi.Gene(exons, isoforms)
-    _, pos, cig = capi.simulate_reads(g, expr, n_reads, read_len, GEN_SEED + int(event_id),
+    _, pos, cig = capi.simulate_reads(g, expr, event_n_reads(event_id, n_reads), read_len, GEN_SEED + int(event_id),
                                       mean if paired else 0.0, var if paired else 0.0)
     return exons, isoforms, pos, cig
 
@@ -77,7 +96,9 @@ def event_costs(first_event_id, n_events, K, n_reads, iters, chains):
     8e), times the isoform count for mixed batches (the per-read work grows with it)."""
     ks = np.array([mixed_k(first_event_id + i, K) for i in range(n_events)], dtype=np.float64) \
         if isinstance(K, (tuple, list)) else np.full(n_events, float(K))
-    return float(chains) * float(iters) * float(n_reads) * ks
+    nr = np.array([event_n_reads(first_event_id + i, n_reads) for i in range(n_events)], dtype=np.float64) \
+        if isinstance(n_reads, (tuple, list)) else np.full(n_events, float(n_reads))
+    return float(chains) * float(iters) * nr * ks
 
 
 def shard_bounds_by_cost(costs, world_size, rank):

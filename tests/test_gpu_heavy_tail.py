@@ -1,0 +1,93 @@
+"""GPU: events of 20 ... 60 000 reads in ONE launch, bit for bit against the oracle's counter mode.
+
+The reference spends O(reads) per event and events share nothing (miso.c:845-900); the two-isoform kernels
+therefore give every event its own number of lanes per chain -- up to a whole workgroup for the largest
+(kernels_k2m.hip, plan.cpp) -- inside one launch.  Results must not depend on that choice: the same batch is
+sampled with the planner's widths, with every chain squeezed onto the narrowest layout, with every chain spread
+as wide as its draws allow (small bound on a wavefront's step), and with the single-width launch.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import miso_amd
+from _libs import OrcLib
+from _problems import flat, se_gene, expr_for
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [20, 60000, 300, 5, 0, 2500, 20000, 40, 1000, 150, 7000, 64, 33000, 3, 511]
+
+
+def _env(**kw):
+    class _Ctx:
+        def __enter__(self):
+            self.old = {k: os.environ.get(k) for k in kw}
+            for k, v in kw.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = str(v)
+
+        def __exit__(self, *a):
+            for k, v in self.old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+    return _Ctx()
+
+
+def _events(orc, paired, sizes):
+    out = []
+    for j, n in enumerate(sizes):
+        exons, isoforms = se_gene(2, exlen=500 if paired else 90 + 7 * j, gap=300 if paired else 100)
+        g = orc.gene(flat(exons), isoforms)
+        orc.rng_seed(4000 + j)
+        w = np.array([0.2 + 0.05 * (j % 12), 1.0])
+        if paired:
+            rc, _, pos, cig = orc.simulate_paired_reads(g, w / w.sum(), max(n, 1), 36, 250.0, 900.0)
+            pos, cig = pos[:2 * n], cig[:2 * n]
+        else:
+            rc, _, pos, cig = orc.simulate_reads(g, w / w.sum(), max(n, 1), 36)
+            pos, cig = pos[:n], cig[:n]
+        assert rc == 0
+        out.append((exons, isoforms, g, pos, cig))
+    return out
+
+
+@pytest.mark.parametrize("paired,chains", [(False, 1), (False, 3), (True, 1), (True, 2)])
+def test_mixed_read_counts_one_launch_bit_exact(orc, paired, chains):
+    sizes = SIZES if not paired else [s // 2 for s in SIZES]
+    evs = _events(orc, paired, sizes)
+    kw = dict(iters=90, burn=20, lag=3, chains=chains)
+    cpu = []
+    for i, (exons, isoforms, g, pos, cig) in enumerate(evs):
+        if paired:
+            r = orc.miso_paired(g, pos, cig, 36, 250.0, 900.0, mode=OrcLib.COUNTER, seed=11, event_id=700 + i,
+                                trace=True, **kw)
+        else:
+            r = orc.miso(g, pos, cig, 36, mode=OrcLib.COUNTER, seed=11, event_id=700 + i, trace=True, **kw)
+        assert r.rc == 0
+        cpu.append(r)
+    variants = [dict(), dict(MISO_K2_TARGET="1e12"), dict(MISO_K2_TARGET="1400"), dict(MISO_K2_TARGET="2600"),
+                dict(MISO_K2_MULTI="0")]
+    kernels = set()
+    for v in variants:
+        with _env(**v):
+            b = miso_amd.Batch(36, paired=paired, mean=250.0 if paired else 0.0, var=900.0 if paired else 0.0,
+                               device_match=True, **kw)
+            for exons, isoforms, g, pos, cig in evs:
+                b.add_event(miso_amd.Gene(exons, isoforms), pos, cig)
+            b.run(seed=11, first_event_id=700)
+            kernels.add(b.last_kernels())
+            for i, r in enumerate(cpu):
+                gpu = b.result(i)
+                where = (v, sizes[i], b.last_kernels())
+                assert (gpu.counts_hash == r.trace["counts_hash"]).all(), where
+                assert np.array_equal(gpu.samples, r.samples, equal_nan=True), where
+                assert np.array_equal(gpu.loglik, r.loglik, equal_nan=True), where
+                assert (gpu.assignment == r.assignment).all(), where
+                assert gpu.rundata.noAccepted == r.accepted, where
+    assert any("multi" in k for k in kernels), kernels

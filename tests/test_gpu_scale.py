@@ -143,29 +143,33 @@ def test_empty_and_degenerate_events():
 
 
 @pytest.mark.parametrize("n_events,chains", [(24000, 1), (9000, 3), (3000, 6)])
-def test_two_lane_widths_in_one_launch_equal_the_single_width(n_events, chains):
-    """sampler_k2_mix (the events with the most drawing reads on G + 1 lanes per chain, the rest on G, one launch)
-    against the single-width launch (MISO_K2_MIX=0): identical samples, log scores, counts."""
+def test_lane_widths_per_event_two_widths_and_one_width_agree(n_events, chains):
+    """Three ways to put the same two-isoform batch on the device -- sampler_k2_multi (a lane width per event, the
+    default), sampler_k2_mix (MISO_K2_MULTI=0: the events with the most drawing reads on G + 1 lanes per chain, the
+    rest on G) and the single-width launch (MISO_K2_MIX=0 on top): identical samples, log scores, counts."""
     kw = dict(n_reads=600, iters=120, burn=40, lag=2, chains=chains)
     b = workload.build_batch(0, n_events, **kw)
-    old = os.environ.pop("MISO_K2_MIX", None)
+    keys = ("MISO_K2_MIX", "MISO_K2_MULTI")
+    old = {k: os.environ.pop(k, None) for k in keys}
+    got = []
     try:
-        b.run(seed=9, first_event_id=0)
-        mixed_kernel = b.last_kernels()
-        with np.errstate(over="ignore"):
-            d_mix, m_mix = _digest(b, n_events)
-        ll_mix = [b.result(i).loglik.copy() for i in (0, n_events // 2, n_events - 1)]
-        os.environ["MISO_K2_MIX"] = "0"
-        b.run(seed=9, first_event_id=0)
-        with np.errstate(over="ignore"):
-            d_one, m_one = _digest(b, n_events)
-        ll_one = [b.result(i).loglik.copy() for i in (0, n_events // 2, n_events - 1)]
-        single_kernel = b.last_kernels()
+        for env in ({}, {"MISO_K2_MULTI": "0"}, {"MISO_K2_MULTI": "0", "MISO_K2_MIX": "0"}):
+            for k in keys:
+                os.environ.pop(k, None)
+            os.environ.update(env)
+            b.run(seed=9, first_event_id=0)
+            with np.errstate(over="ignore"):
+                d, m = _digest(b, n_events)
+            got.append((b.last_kernels(), d, m, [b.result(i).loglik.copy() for i in (0, n_events // 2, n_events - 1)]))
     finally:
-        os.environ.pop("MISO_K2_MIX", None)
-        if old is not None:
-            os.environ["MISO_K2_MIX"] = old
-    assert "sampler_k2_mix" in mixed_kernel and "sampler_k2_mix" not in single_kernel, (mixed_kernel, single_kernel)
-    assert d_mix == d_one and np.array_equal(m_mix, m_one)
-    for x, y in zip(ll_mix, ll_one):
-        assert np.array_equal(x, y, equal_nan=True)
+        for k in keys:
+            os.environ.pop(k, None)
+            if old[k] is not None:
+                os.environ[k] = old[k]
+    names = [g[0] for g in got]
+    assert "sampler_k2_multi" in names[0] and "sampler_k2<" in names[2], names
+    assert "sampler_k2_multi" not in names[1] and "sampler_k2_mix" not in names[2], names
+    for g in got[1:]:
+        assert g[1] == got[0][1] and np.array_equal(g[2], got[0][2]), (g[0], got[0][0])
+        for x, y in zip(g[3], got[0][3]):
+            assert np.array_equal(x, y, equal_nan=True)
