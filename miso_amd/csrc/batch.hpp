@@ -56,6 +56,13 @@ struct miso_batch {
     bool dense = true;            // paired-end: every event has dense quad records (pe_dense)
     int tuned_G = 0;              // lanes per chain picked by the first launch's trial runs
     int tuned_flat = -1;          // sampler_flat (1) or sampler_grp (0) by the first launch's trial runs, -1 = not tried
+    // sampler_flat: which chains every wavefront owns (runtime.hip flat_waves; two words per wavefront)
+    std::vector<int32_t> wave_tab;
+    int32_t *d_wave_tab = nullptr;
+    long wave_key = -1;
+    int wave_nc = 0;              // most chains of any wavefront = slices per wavefront in LDS
+    int wave_wide = 0;            // chains that own a whole workgroup
+    bool wave_packed = false;     // wavefronts packed by work units (events of very different sizes)
   };
   std::vector<GenRun> gen_runs;
   int tuned_k2_G = 0;             // ditto for the two-isoform kernel

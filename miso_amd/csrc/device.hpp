@@ -70,6 +70,7 @@ struct ChainStats {
   uint32_t hw_id;      // HW_REG_HW_ID of the wavefront that ran the chain (placement diagnostics)
 };
 
+constexpr int FLAT_WIDE = 0x100;  // sampler_flat wave_tab: the workgroup's four wavefronts share ONE chain
 constexpr int K2_MAX_SEGS = 16;
 constexpr int K2_WIDE = 512;   // seg_lanes value: one chain per workgroup
 constexpr int K2_RED_BYTES = 2 * 8 * 16;   // two buffers x (up to) 8 wavefronts x {int64 score sum, int count, int bad}
@@ -98,6 +99,7 @@ struct KernelArgs {
   int32_t flat_desc;        // sampler_flat: read loop over the unit descriptors (flat_units_desc), 0 = the walking loop
   int32_t mix_blocks;       // sampler_k2_mix<GA, GB>: the first mix_blocks workgroups run the first mix_slots events
   int32_t mix_slots;        // with GA lanes per chain, the rest the remaining events with GB (runtime.hip)
+  const int32_t *wave_tab;  // sampler_flat: two words per wavefront: first chain of the launch's list, chains | FLAT_WIDE (runtime.hip)
   int32_t red_off;          // sampler_k2_multi: byte offset of the workgroup-wide chains' reduction scratch in the dynamic LDS
   uint64_t seed;
   // sampler_k2_multi (kernels_k2m.hip): the launch's events (ordered by drawing reads, most first) cut into runs

@@ -312,11 +312,20 @@ __global__ __launch_bounds__(256, KC <= 8 ? MISO_FLAT_WGS_SMALL : 2) void sample
   const int NC = a.nc, ks = a.kstride, cs = a.cstride, tws = ks - 1, trow = flat_trow(ks);
   const FlatLayout L = flat_layout(ks, cs);
   unsigned char *wbase = smem_flat + static_cast<size_t>(wid) * NC * L.bytes;
-  const long n_chains = static_cast<long>(a.n_slots) * a.C;
+  // Which chains this wavefront owns comes from the host (runtime.hip: flat_waves): a.wave_tab[wavefront] = {first
+  // chain of the launch's list, chains | FLAT_WIDE}.  Uniform batches: NC chains each; batches whose events differ
+  // widely in size (real read counts: 20 ... 10^5 per event, miso.c:845-900 is O(reads) per event): as many
+  // consecutive chains as make about the same number of work units per wavefront, and the largest chains one per
+  // WORKGROUP (FLAT_WIDE: the four wavefronts each keep the chain's state in their own slice and run the scalar step
+  // redundantly -- same inputs, same bits --, the read loop's units are dealt over all 256 lanes, the per-wavefront
+  // counts meet through LDS, two barriers per Gibbs step; wavefront 0 writes the outputs).
   const long wave_id = static_cast<long>(blockIdx.x) * 4 + wid;
-  const long first_slot = wave_id * NC;
-  if (first_slot >= n_chains) return;   // no block-level barrier below
-  const int ncw = __builtin_amdgcn_readfirstlane(static_cast<int>(min(static_cast<long>(NC), n_chains - first_slot)));
+  const int wt_first = __builtin_amdgcn_readfirstlane(a.wave_tab[2 * wave_id]), wt_n = __builtin_amdgcn_readfirstlane(a.wave_tab[2 * wave_id + 1]);
+  const bool wide = (wt_n & FLAT_WIDE) != 0;
+  const long first_slot = wt_first;
+  const int ncw = wt_n & 0xFF;
+  if (ncw == 0) return;   // padding wavefront of the last workgroup (never in a FLAT_WIDE workgroup: no barrier missed)
+  const bool writes = !wide || wid == 0;
   const uint32_t k0 = static_cast<uint32_t>(a.seed), k1 = static_cast<uint32_t>(a.seed >> 32);
 
 #define FD(s, off) reinterpret_cast<double *>(wbase + (s) * L.bytes + (off))
@@ -422,6 +431,7 @@ __global__ __launch_bounds__(256, KC <= 8 ? MISO_FLAT_WGS_SMALL : 2) void sample
       if (lane >= l0 && lane < l0 + gs) { d_ms = s; d_r = lane - l0; d_g = gs; }
     }
   }
+  if (wide) { d_ms = 0; d_r = wid * 64 + lane; d_g = 256; }   // one chain, all four wavefronts' lanes
   // this lane's first unit: chain, class, unit within the chain (static for the whole run)
   int s0 = 0, c0 = 0, i0 = 0, n_mine = 0;
   {
@@ -678,6 +688,18 @@ __global__ __launch_bounds__(256, KC <= 8 ? MISO_FLAT_WGS_SMALL : 2) void sample
     else { if (tww <= 19) MISO_FUNITS(19) else if (tww <= 23) MISO_FUNITS(23) else MISO_FUNITS(31) }
 #undef MISO_FUNITS
     fsync();
+    if (wide) {
+      // every wavefront's D_k -> the sum of all four, in every wavefront's own slice (the slices start NC slices apart)
+      __syncthreads();
+      int tot = 0;
+      if (lane <= trow) {
+#pragma unroll
+        for (int w = 0; w < 4; w++) tot += reinterpret_cast<const int *>(smem_flat + static_cast<size_t>(w) * NC * L.bytes + L.dl)[lane];
+      }
+      __syncthreads();
+      if (lane <= trow) FI(0, L.dl)[lane] = tot;
+      fsync();
+    }
     // D_k (+ the reads of classes that end at or before k) -> picks per isoform
     FLAT_BEGIN(ks, inv_k)
       const int *mi = FI(s, L.misc);
@@ -739,7 +761,7 @@ __global__ __launch_bounds__(256, KC <= 8 ? MISO_FLAT_WGS_SMALL : 2) void sample
         const int K = mi[MI_K];
         if (on && j < K) {
           const uint64_t to = (static_cast<uint64_t>(static_cast<uint32_t>(mi[MI_TRACE_HI])) << 32) | static_cast<uint32_t>(mi[MI_TRACE_LO]);
-          reinterpret_cast<int32_t *>(a.out_pool + to)[(static_cast<size_t>(m) * a.C + mi[MI_CHAIN]) * K + j] = count_of(s, j);
+          if (writes) reinterpret_cast<int32_t *>(a.out_pool + to)[(static_cast<size_t>(m) * a.C + mi[MI_CHAIN]) * K + j] = count_of(s, j);
         }
       FLAT_END
     }
@@ -842,7 +864,7 @@ __global__ __launch_bounds__(256, KC <= 8 ? MISO_FLAT_WGS_SMALL : 2) void sample
       if (on && acc) {
         FD(s, L.psi)[j] = v0; FD(s, L.alpha)[j] = v1; FD(s, L.lp)[j] = v2; FD(s, L.tb)[j] = v3; FD(s, L.lr)[j] = v4;
       }
-      if (rec && on && j < K) {
+      if (rec && on && j < K && writes) {
         const uint64_t so = (static_cast<uint64_t>(static_cast<uint32_t>(mi[MI_SAMP_HI])) << 32) | static_cast<uint32_t>(mi[MI_SAMP_LO]);
         const size_t col = static_cast<size_t>(noS) + mi[MI_CHAIN];
         reinterpret_cast<double *>(a.out_pool + so)[col * K + j] = acc ? v0 : c0;
@@ -853,7 +875,7 @@ __global__ __launch_bounds__(256, KC <= 8 ? MISO_FLAT_WGS_SMALL : 2) void sample
     FPROF_ADD(fp_mh, m0, m1);
     if (m >= a.B) {
       if (rec) {
-        if (leader) reinterpret_cast<double *>(a.out_pool + LE_.off_loglik)[static_cast<size_t>(noS) + lchain] = cJS;
+        if (leader && writes) reinterpret_cast<double *>(a.out_pool + LE_.off_loglik)[static_cast<size_t>(noS) + lchain] = cJS;
         noS += a.C;
         lagCounter = 0;
       } else {
@@ -871,13 +893,13 @@ __global__ __launch_bounds__(256, KC <= 8 ? MISO_FLAT_WGS_SMALL : 2) void sample
       const int K = mi[MI_K];
       if (on && j < K) {
         const uint64_t to = (static_cast<uint64_t>(static_cast<uint32_t>(mi[MI_TRACE_HI])) << 32) | static_cast<uint32_t>(mi[MI_TRACE_LO]);
-        reinterpret_cast<int32_t *>(a.out_pool + to)[(static_cast<size_t>(a.M) * a.C + mi[MI_CHAIN]) * K + j] = count_of(s, j);
+        if (writes) reinterpret_cast<int32_t *>(a.out_pool + to)[(static_cast<size_t>(a.M) * a.C + mi[MI_CHAIN]) * K + j] = count_of(s, j);
       }
     FLAT_END
   }
   // chain 0's final picks, read by read (miso.c:943-946): the last Gibbs step's draws once more
   for (int s = 0; s < ncw; s++)
-    if (FI(s, L.misc)[MI_CHAIN] == 0)
+    if (FI(s, L.misc)[MI_CHAIN] == 0 && writes)
       direct_chain(s, a.M > 0 ? static_cast<uint32_t>(a.M - 1) : MISO_ITER_INIT, false, true);
 #ifdef MISO_K2_PROFILE
   if (leader && lchain == 0 && a.M > 8) {
@@ -885,7 +907,7 @@ __global__ __launch_bounds__(256, KC <= 8 ? MISO_FLAT_WGS_SMALL : 2) void sample
     loglik[0] = static_cast<double>(fp_mh); loglik[1] = static_cast<double>(fp_thr); loglik[2] = static_cast<double>(fp_loop);
   }
 #endif
-  if (leader) {
+  if (leader && writes) {
     ChainStats *st = reinterpret_cast<ChainStats *>(a.out_pool + LE_.off_stats) + lchain;
     st->counts_hash = hash; st->accepted = accepted;
     st->hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4);

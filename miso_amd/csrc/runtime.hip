@@ -87,6 +87,7 @@ void miso_batch::release() {
   d_slots = nullptr;
   if (ev0) (void) hipEventDestroy(ev0);
   if (ev1) (void) hipEventDestroy(ev1);
+  for (GenRun &run : gen_runs) { if (run.d_wave_tab) (void) hipFree(run.d_wave_tab); run.d_wave_tab = nullptr; run.wave_key = -1; }
   for (hipStream_t st : aux_streams) (void) hipStreamDestroy(st);
   for (hipEvent_t e : aux_done) (void) hipEventDestroy(e);
   aux_streams.clear(); aux_done.clear();
@@ -621,16 +622,97 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     flat_nc[ri] = nc; flat_nc_max[ri] = nc_max;
   }
   auto flat_name = [&](const GenRun &run) { return "sampler_flat<" + std::to_string(run.kc) + ">"; };
-  auto launch_flat = [&](KernelArgs ka, const GenRun &run, int nc, hipStream_t st) {
+  // Which chains a wavefront of sampler_flat owns (kernels_flat.inl: a.wave_tab).  Uniform batches: `nc` consecutive
+  // chains each.  When the batch's events differ widely in size -- the heaviest wavefront of the uniform rule would
+  // carry more than twice the average wavefront's work units -- the wavefronts are packed by UNITS instead: as many
+  // consecutive chains (at most nc_max: the LDS) as make about the average wavefront's units, a chain of several
+  // times that alone in a WORKGROUP (FLAT_WIDE: 256 lanes), workgroups ordered heaviest first (the hardware starts
+  // them in index order).  MISO_FLAT_PACK=0 / 1: never / always (tests, A/B).
+  // How many units per wavefront: as many as nc_max average chains have -- the scalar step costs a wavefront the same
+  // for 2 chains and for 13, so fewer, fuller wavefronts win (hg19-like read counts, 40 000 events, K = 5: 497 ms at 8
+  // average chains per wavefront, 425 ms at 13+) -- unless that leaves the device part empty: fewer wavefronts than
+  // resident slots, or a second round that is less than half full (K = 3: 3349 wavefronts on 3072 slots 286 ms,
+  // 5704 wavefronts 270 ms); then the wavefront count goes to 0.95 x one or two rounds
+  // (profiles/r03_flat_pack_sweep.txt).  A forced MISO_FLAT_NC sets the average chains per wavefront instead.
+  auto flat_waves = [&](GenRun &run, int nc, int nc_max, long resident) {
     const long chains = static_cast<long>(run.count) * p.noChains;
+    const int C = p.noChains;
+    const char *env = std::getenv("MISO_FLAT_PACK");
+    const long key = static_cast<long>(nc) * 4 + (env ? 1 + (std::atoi(env) != 0) : 0);
+    if (run.wave_key == key && run.d_wave_tab) return;
+    auto units_of = [&](long c) { return static_cast<long>(events[h_slots[n_k2 + run.first + c / C]].n_units); };
+    long total = 0, head = 0;
+    for (long c = 0; c < chains; c++) { const long u = units_of(c); total += u; if (c < nc) head += u; }
+    long heaviest = head;   // the list is ordered by isoforms first: look at every wavefront of the uniform rule
+    for (long c = 0, sum = 0; c < chains; c++) {
+      sum += units_of(c);
+      if ((c + 1) % nc == 0 || c + 1 == chains) { heaviest = std::max(heaviest, sum); sum = 0; }
+    }
+    const double mean_wave = static_cast<double>(total) * nc / std::max<long>(1, chains);
+    const bool pack = env ? std::atoi(env) != 0 : (chains > nc && static_cast<double>(heaviest) > 2.0 * mean_wave);
+    struct W { int32_t first, n; long units; };
+    std::vector<W> waves, wides;
+    if (!pack) {
+      for (long c = 0; c < chains; c += nc) waves.push_back(W{static_cast<int32_t>(c), static_cast<int32_t>(std::min<long>(nc, chains - c)), 0});
+      run.wave_nc = nc;
+    } else {
+      const int cap = std::min(nc_max, 255);
+      int most = 1;
+      auto pack_with = [&](double U) {
+        waves.clear(); wides.clear(); most = 1;
+        const double wide_min = std::max(3.0 * U, 2048.0);
+        for (long c = 0; c < chains;) {
+          const long u = units_of(c);
+          if (static_cast<double>(u) >= wide_min) { wides.push_back(W{static_cast<int32_t>(c), 1, u}); c++; continue; }
+          W w{static_cast<int32_t>(c), 0, 0};
+          while (c < chains && w.n < cap) {
+            const long v = units_of(c);
+            if (static_cast<double>(v) >= wide_min || (w.n > 0 && static_cast<double>(w.units + v) > 1.05 * U)) break;
+            w.units += v; w.n++; c++;
+          }
+          most = std::max(most, static_cast<int>(w.n));
+          waves.push_back(w);
+        }
+        return static_cast<long>(waves.size() + 4 * wides.size());
+      };
+      const double per_chain = static_cast<double>(total) / std::max<long>(1, chains);
+      const bool forced = std::getenv("MISO_FLAT_NC") != nullptr;
+      const long n_waves = pack_with(std::max(64.0, per_chain * (forced ? nc : cap)));
+      if (!forced && n_waves < 3 * resident / 2) {
+        const double want = 0.95 * static_cast<double>(n_waves <= resident ? resident : 2 * resident);
+        if (static_cast<double>(n_waves) < want) pack_with(std::max(64.0, static_cast<double>(total) / want));
+      }
+      std::stable_sort(wides.begin(), wides.end(), [](const W &x, const W &y) { return x.units > y.units; });
+      std::stable_sort(waves.begin(), waves.end(), [](const W &x, const W &y) { return x.units > y.units; });
+      run.wave_nc = most;
+    }
+    run.wave_tab.clear();
+    for (const W &w : wides) for (int i = 0; i < 4; i++) { run.wave_tab.push_back(w.first); run.wave_tab.push_back(1 | FLAT_WIDE); }
+    for (const W &w : waves) { run.wave_tab.push_back(w.first); run.wave_tab.push_back(w.n); }
+    while ((run.wave_tab.size() / 2) % 4) { run.wave_tab.push_back(0); run.wave_tab.push_back(0); }   // padding wavefronts
+    run.wave_wide = static_cast<int>(wides.size());
+    run.wave_packed = pack;
+    if (run.d_wave_tab) (void) hipFree(run.d_wave_tab);
+    run.d_wave_tab = nullptr;
+    HIP_OK(hipMalloc(reinterpret_cast<void **>(&run.d_wave_tab), std::max<size_t>(run.wave_tab.size(), 2) * sizeof(int32_t)));
+    HIP_OK(hipMemcpy(run.d_wave_tab, run.wave_tab.data(), run.wave_tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    run.wave_key = key;
+  };
+  auto launch_flat = [&](KernelArgs ka, GenRun &run, int nc, int nc_max, hipStream_t st) {
+    {
+      const long chains = static_cast<long>(run.count) * p.noChains;
+      const int wgs = std::getenv("MISO_FLAT_WGS") ? std::max(1, std::atoi(std::getenv("MISO_FLAT_WGS"))) : (run.kc <= 4 ? 3 : 2);
+      flat_waves(run, nc, nc_max, std::max<long>(1, static_cast<long>(slots_for(chains)) * wgs / 2));
+    }
     ka.slot_event = d_slots + n_k2 + run.first; ka.n_slots = run.count;
-    ka.kstride = run.kmax; ka.cstride = std::max(run.maxcls, 1); ka.tstride = 0; ka.nc = nc;
+    ka.kstride = run.kmax; ka.cstride = std::max(run.maxcls, 1); ka.tstride = 0; ka.nc = run.wave_nc;
+    ka.wave_tab = run.d_wave_tab;
     // the descriptor read loop from four isoforms on (three: the walking loop is 2 % faster -- two thresholds per unit,
-    // little to save); MISO_FLAT_NO_DESC=1: the walking loop everywhere (A/B, tests)
-    ka.flat_desc = (std::getenv("MISO_FLAT_NO_DESC") == nullptr && run.kmax >= 4) ? 1 : 0;
-    const long waves = (chains + nc - 1) / nc;
-    const unsigned grid = static_cast<unsigned>((waves + 3) / 4);
-    const size_t lds = 4 * static_cast<size_t>(nc) * flat_layout(ka.kstride, ka.cstride).bytes;
+    // little to save) and whenever a chain owns a whole workgroup; MISO_FLAT_NO_DESC=1: the walking loop everywhere
+    // (A/B, tests; not with workgroup-wide chains)
+    ka.flat_desc = ((std::getenv("MISO_FLAT_NO_DESC") == nullptr && run.kmax >= 4) || run.wave_wide > 0) ? 1 : 0;
+    const unsigned grid = static_cast<unsigned>(run.wave_tab.size() / 8);
+    const size_t lds = 4 * static_cast<size_t>(run.wave_nc) * flat_layout(ka.kstride, ka.cstride).bytes;
 #define MISO_FLAT_LAUNCH(KC)                                                                            \
   {                                                                                                     \
     HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sampler_flat<KC>),                       \
@@ -699,7 +781,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     if (contest) {
       const int nc = flat_nc[ri];
       const int win = (G == 64) ? 0 : fastest({0, G}, [&](const KernelArgs &t, int g) {
-        if (g == 0) launch_flat(t, run, nc, stream); else launch_grp(t, run, sh, g, stream); });
+        if (g == 0) launch_flat(t, run, nc, flat_nc_max[ri], stream); else launch_grp(t, run, sh, g, stream); });
       run.tuned_flat = win == 0 ? 1 : 0;
       if (win != 0) flat_nc[ri] = 0;
     }
@@ -931,6 +1013,17 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     const bool cls = !p.paired && grp_sh[ri].qs > 0;
     double trips = 0, words = 0;
     long waves = 0;
+    if (flat) {   // the wavefronts as flat_waves laid them out
+      for (size_t w = 0; w + 1 < run.wave_tab.size(); w += 2) {
+        const int first = run.wave_tab[w], n = run.wave_tab[w + 1] & 0xFF;
+        const bool wide = (run.wave_tab[w + 1] & FLAT_WIDE) != 0;
+        if (n == 0) continue;
+        long units = 0;
+        for (long sl = first; sl < first + n; sl++) { units += evs[sl / C]->n_units; if (!wide || (w / 2) % 4 == 0) words += evs[sl / C]->n_draw; }
+        trips += wide ? (units + 255) / 256 : (units + 63) / 64;
+        waves++;
+      }
+    } else
     for (long s0 = 0; s0 < chains; s0 += cpw, waves++) {
       int mx = 0, kmx = 0; long units = 0;
       for (long sl = s0; sl < std::min(chains, s0 + cpw); sl++) {
@@ -992,7 +1085,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     const int G = grp_G[ri];
     if (flat_nc[ri] > 0) {
       last_kernels += std::string(last_kernels.empty() ? "" : ",") + flat_name(run);
-      launch_flat(a, run, flat_nc[ri], stream_for_next());
+      launch_flat(a, gen_runs[ri], flat_nc[ri], flat_nc_max[ri], stream_for_next());
       continue;
     }
     last_kernels += std::string(last_kernels.empty() ? "" : ",") +

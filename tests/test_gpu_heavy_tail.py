@@ -91,3 +91,41 @@ def test_mixed_read_counts_one_launch_bit_exact(orc, paired, chains):
                 assert (gpu.assignment == r.assignment).all(), where
                 assert gpu.rundata.noAccepted == r.accepted, where
     assert any("multi" in k for k in kernels), kernels
+
+
+@pytest.mark.parametrize("K,chains", [(3, 1), (5, 2), (10, 1), (18, 1)])
+def test_mixed_read_counts_three_or_more_isoforms_bit_exact(orc, K, chains):
+    """sampler_flat: wavefronts packed by work units, the largest chains one per workgroup (runtime.hip flat_waves,
+    kernels_flat.inl FLAT_WIDE) against the uniform layout and the oracle."""
+    sizes = [20, 40000, 300, 5, 0, 2500, 12000, 40, 1000, 150, 7000, 64, 3, 511, 90, 200, 35, 800]
+    evs = []
+    for j, n in enumerate(sizes):
+        exons, isoforms = se_gene(K, exlen=90 + 7 * j, gap=100)
+        g = orc.gene(flat(exons), isoforms)
+        orc.rng_seed(5000 + j)
+        rc, _, pos, cig = orc.simulate_reads(g, expr_for(K), max(n, 1), 36)
+        assert rc == 0
+        evs.append((exons, isoforms, g, pos[:n], cig[:n]))
+    kw = dict(iters=60, burn=10, lag=2, chains=chains)
+    cpu = []
+    for i, (exons, isoforms, g, pos, cig) in enumerate(evs):
+        r = orc.miso(g, pos, cig, 36, mode=OrcLib.COUNTER, seed=13, event_id=900 + i, trace=True, **kw)
+        assert r.rc == 0
+        cpu.append(r)
+    variants = [dict(), dict(MISO_FLAT_PACK="1"), dict(MISO_FLAT_PACK="1", MISO_FLAT_NC="4"),
+                dict(MISO_FLAT_PACK="0", MISO_FLAT_NC="3"), dict(MISO_FLAT_PACK="1", MISO_FLAT_NC="2", MISO_FLAT_NO_DESC="1")]
+    for v in variants:
+        with _env(**v):
+            b = miso_amd.Batch(36, device_match=True, **kw)
+            for exons, isoforms, g, pos, cig in evs:
+                b.add_event(miso_amd.Gene(exons, isoforms), pos, cig)
+            b.run(seed=13, first_event_id=900)
+            assert "sampler_flat" in b.last_kernels()
+            for i, r in enumerate(cpu):
+                gpu = b.result(i)
+                where = (v, K, sizes[i])
+                assert (gpu.counts_hash == r.trace["counts_hash"]).all(), where
+                assert np.array_equal(gpu.samples, r.samples, equal_nan=True), where
+                assert np.array_equal(gpu.loglik, r.loglik, equal_nan=True), where
+                assert (gpu.assignment == r.assignment).all(), where
+                assert gpu.rundata.noAccepted == r.accepted, where
