@@ -18,17 +18,22 @@ path; ranks only meet in a gloo barrier and a max-over-ranks of the elapsed time
 The line carries, besides the contract's keys:
   roofline            the dominant kernel against the bound that applies to it: VALU issue (VALU
                       instructions per chain-iteration and their issue cycles from the committed
-                      rocprofv3 passes, profiles/valu_model.json), with the RNG fraction, the
-                      measured HBM fraction and SURVEY 8(d)'s algorithmic-bytes figure beside it
+                      rocprofv3 passes of this workload, profiles/valu_model.json -- a MODEL priced with
+                      this run's kernel time, and said so), with the share of the instruction floor,
+                      the RNG fraction, the measured HBM fraction and SURVEY 8(d)'s algorithmic bytes
   cpu_baseline        the real reference C core (oracle/_ref) on the host cores, bounded sample
-  delta_psi_vs_reference   |delta psi| with a pass/fail: 4 x MCSE from 16 reference seeds per event
-  matrix              the other shapes of the metric (K = 5, 10; MISO default settings; paired-end),
-                      timed inside the same run
+  delta_psi_vs_reference   |delta psi| with a pass/fail: 4 x MCSE from reference seeds, per event
+  summary_ms / compare_ms  rows f2 / f3 (configs[4]) on the resident samples, outside the timed region
+  matrix              the other shapes of the metric (hg19-like read counts; K = 5, 10; MISO default
+                      settings; paired-end K = 2, 5, 10; the whole-gene paired-end mix), each timed in
+                      this run with its own roofline, cpu_baseline and delta_psi (all isoforms, mean and
+                      both credible-interval bounds)
 """
 import argparse
 import json
 import math
 import os
+import re
 import socket
 import subprocess
 import sys
@@ -60,45 +65,6 @@ def self_launch(n_gpus):
     return subprocess.call(cmd, env=env)
 
 
-# ------------------------------------------------------------------------------------------------
-# CPU side: the real reference (oracle/_ref) or the oracle port, timed and used for |delta psi|
-# ------------------------------------------------------------------------------------------------
-def _psi_stats(smp):
-    """Posterior mean, Chen-Shao 95 % bounds (credible_intervals.py:31-55) and sd of isoform 0."""
-    import numpy as np
-    x = np.sort(np.asarray(smp)[:, 0])
-    n = len(x)
-    return (float(x.mean()), float(x[int(round(0.025 * n)) - 1]), float(x[int(round(0.975 * n)) - 1]),
-            float(x.std(ddof=1)))
-
-
-def _cpu_worker(args):
-    """One host process: `ev_seeds` = [(event id, reference seed)], run one after the other."""
-    kind, ev_seeds, K, n_reads, read_len, iters, burn, lag, chains = args
-    devnull = os.open(os.devnull, os.O_WRONLY)
-    os.dup2(devnull, 1)  # the reference prints "no chains: %d" per call (miso.c:837)
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from _libs import OrcLib, RefLib
-    from miso_amd import workload
-    L = RefLib() if kind == "reference" else OrcLib()
-    probs = {}
-    for e, _ in ev_seeds:
-        if e not in probs:
-            exons, isoforms, pos, cig = workload.event_reads(e, K, n_reads, read_len)
-            probs[e] = (L.gene([c for ex in exons for c in ex], isoforms), pos, cig)
-    out = []
-    busy = 0.0
-    for e, seed in ev_seeds:
-        g, pos, cig = probs[e]
-        L.rng_seed(seed)   # the reference's generator is one global stream (random.c:491)
-        t0 = time.perf_counter()
-        r = L.miso(g, pos, cig, read_len, iters=iters, burn=burn, lag=lag, chains=chains)
-        busy += time.perf_counter() - t0
-        assert r.rc == 0
-        out.append((e, seed) + _psi_stats(r.samples))
-    return busy, out
-
-
 def usable_cores():
     """Host cores this process may really use: affinity mask capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0))
@@ -111,99 +77,212 @@ def usable_cores():
     return n
 
 
-def cpu_reference(a):
-    """(cpu_baseline dict, timing-sample rows, seed-study rows).  P processes (the reference's own
-    parallelism is processes, misopy/miso.py:165-187).  Phase 1, timed: --cpu-events events per
-    process under one seed.  Phase 2, not timed: the first --dpsi-events events under --dpsi-seeds
-    further seeds each, from which the Monte-Carlo standard error of one run's posterior mean is
-    estimated event by event (tolerance 4 x MCSE from >= 8 reference seeds)."""
+# ------------------------------------------------------------------------------------------------
+# workloads: the headline and the matrix rows share one description
+# ------------------------------------------------------------------------------------------------
+BASE_SHAPE = dict(K=2, reads=1000, read_len=36, iters=7500, burn=2500, lag=1, chains=1, paired=False, mean=250.0, var=900.0)
+
+
+def shape_of(a, **ov):
+    """{K, reads ("hg19" or a number), read_len, iters, burn, lag, chains, paired, mean, var} of a workload."""
+    sh = dict(K=a.K, reads=("hg19" if a.reads_dist == "hg19" else a.reads), read_len=a.read_len, iters=a.iters,
+              burn=a.burn, lag=a.lag, chains=a.chains, paired=bool(a.paired), mean=250.0, var=900.0)
+    sh.update(ov)
+    if isinstance(sh["K"], list):
+        sh["K"] = tuple(sh["K"])
+    return sh
+
+
+def reads_spec(sh):
+    from miso_amd import workload
+    return workload.HG19_LIKE if sh["reads"] == "hg19" else sh["reads"]
+
+
+def workload_key(events, sh):
+    """One canonical key per workload (profiles/valu_model.json, traffic.json): K as "lo-hi" for isoform
+    ranges, reads as a number or "hg19".  The kernel is NOT part of the key: the entry names the kernels it
+    was profiled with and bench.py refuses a profile of other kernels."""
+    K = sh["K"]
+    k = "%d-%d" % tuple(K) if isinstance(K, (tuple, list)) else str(K)
+    return "events=%d|K=%s|reads=%s|iters=%d|chains=%d|paired=%d" % (
+        events, k, sh["reads"], sh["iters"], sh["chains"], int(sh["paired"]))
+
+
+def build(first, n, sh, device_match=True):
+    from miso_amd import workload
+    return workload.build_batch(first, n, K=sh["K"], n_reads=reads_spec(sh), read_len=sh["read_len"],
+                                iters=sh["iters"], burn=sh["burn"], lag=sh["lag"], chains=sh["chains"],
+                                paired=sh["paired"], mean=sh["mean"], var=sh["var"], device_match=device_match)
+
+
+MATRIX = [  # (id, label, shape overrides, events, reference runs of the row: (events, seeds) or None)
+    # read counts as a real annotation sees them (workload.HG19_LIKE: log-normal, median 300, 20 ... 10^5 reads per
+    # event, a handful of 10^4 ... 10^5-read events per 40 000): "reads_iter_per_s" is what to compare with the uniform rows
+    ("se_k2_hg19", "SE K=2, hg19-like read counts (20..1e5 per event), 1 chain, 7500 iters", dict(reads="hg19"), 40000, (64, 8)),
+    ("se_k2_hg19_defaults", "SE K=2, hg19-like read counts, MISO defaults (6 chains, 5000 iters, 500 burn-in, lag 10)",
+     dict(reads="hg19", chains=6, iters=5000, burn=500, lag=10), 40000, None),
+    ("pe_k2_hg19", "PE K=2, hg19-like read counts, 1 chain, 7500 iters", dict(paired=True, reads="hg19"), 40000, (64, 8)),
+    ("se_k5_hg19", "SE K=5, hg19-like read counts, 1 chain, 7500 iters", dict(K=5, reads="hg19"), 40000, (64, 8)),
+    ("se_k5", "SE K=5, 1 chain, 7500 iters", dict(K=5), 40000, (64, 8)),
+    ("se_k10", "SE K=10, 1 chain, 7500 iters", dict(K=10), 40000, (64, 8)),
+    ("se_k2_defaults", "SE K=2, MISO defaults (6 chains, 5000 iters, 500 burn-in, lag 10)",
+     dict(chains=6, iters=5000, burn=500, lag=10), 40000, (64, 8)),
+    ("pe_k2", "PE K=2 (mean 250, sd 30), 1 chain, 7500 iters", dict(paired=True), 40000, (64, 8)),
+    ("pe_k5", "PE K=5, 1 chain, 7500 iters", dict(K=5, paired=True), 40000, (64, 8)),
+    ("pe_k10", "PE K=10, 1 chain, 7500 iters", dict(K=10, paired=True), 20000, (64, 8)),
+    # BASELINE configs[3]: whole-gene mode, 3-20 isoforms per gene, paired-end; "events" are genes here
+    ("pe_mix", "PE K=3..20 per gene (whole-gene mix), 1 chain, 7500 iters", dict(K=(3, 20), paired=True), 16384, (32, 1)),
+]
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU side: the real reference (oracle/_ref) or the oracle port, timed and used for |delta psi|
+# ------------------------------------------------------------------------------------------------
+def _psi_stats(smp):
+    """Per isoform: posterior mean, Chen-Shao 95 % bounds (credible_intervals.py:31-55), sd."""
+    import numpy as np
+    x = np.sort(np.asarray(smp), axis=0)
+    n = x.shape[0]
+    lo, hi = int(round(0.025 * n)) - 1, int(round(0.975 * n)) - 1
+    return x.mean(0).tolist(), x[lo].tolist(), x[hi].tolist(), x.std(0, ddof=1).tolist()
+
+
+def _cpu_worker(job):
+    """One host process, one workload: `ev_seeds` = [(event id, reference seed)], run one after the other."""
+    kind, sh, ev_seeds = job
+    devnull = os.open(os.devnull, os.O_WRONLY)
+    os.dup2(devnull, 1)  # the reference prints "no chains: %d" per call (miso.c:837)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _libs import OrcLib, RefLib
+    from miso_amd import workload
+    L = RefLib() if kind == "reference" else OrcLib()
+    probs = {}
+    for e, _ in ev_seeds:
+        if e not in probs:
+            exons, isoforms, pos, cig = workload.event_reads(e, sh["K"], reads_spec(sh), sh["read_len"], sh["paired"],
+                                                             sh["mean"], sh["var"])
+            probs[e] = (L.gene([c for ex in exons for c in ex], isoforms), pos, cig)
+    out = []
+    busy = 0.0
+    kw = dict(iters=sh["iters"], burn=sh["burn"], lag=sh["lag"], chains=sh["chains"])
+    for e, seed in ev_seeds:
+        g, pos, cig = probs[e]
+        L.rng_seed(seed)   # the reference's generator is one global stream (random.c:491)
+        t0 = time.perf_counter()
+        if sh["paired"]:
+            r = L.miso_paired(g, pos, cig, sh["read_len"], sh["mean"], sh["var"], **kw)
+        else:
+            r = L.miso(g, pos, cig, sh["read_len"], **kw)
+        busy += time.perf_counter() - t0
+        assert r.rc == 0
+        out.append((e, seed) + _psi_stats(r.samples))
+    return busy, out
+
+
+def cpu_studies(wanted):
+    """Everything the host cores do, before anything touches the GPU (fork-safe), in ONE process pool (the
+    reference's own parallelism is processes, misopy/miso.py:165-187).  `wanted`: {id: (shape, timed
+    [(event, seed)], study [(event, seed)])}.  Timed runs give the cpu_baseline (runs / the slowest process's
+    busy time); study runs (several reference seeds per event) give the Monte-Carlo standard error of one run's
+    posterior summaries, event by event (tolerance 4 x MCSE from >= 8 reference seeds).
+    A workload whose timed list is empty is timed on its study runs."""
     import multiprocessing as mp
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from _libs import RefLib
     kind = "reference" if RefLib.available() else "port"
     cores = usable_cores()
-    shape = (a.K, a.reads, a.read_len, a.iters, a.burn, a.lag, a.chains)
-    per_proc = a.cpu_events
-    jobs = [(kind, [(e, 42 + e) for e in range(p * per_proc, (p + 1) * per_proc)]) + shape for p in range(cores)]
-    ctx = mp.get_context("fork")
+    jobs, tags = [], []
+    for wid, (sh, timed, study) in wanted.items():
+        for which, lst in (("timed", timed), ("study", study)):
+            for p in range(cores):
+                part = lst[p::cores]
+                if part:
+                    jobs.append((kind, sh, part)); tags.append((wid, which))
+    out = {wid: {"timed": [], "study": [], "timed_busy": [], "study_busy": []} for wid in wanted}
     t0 = time.perf_counter()
-    with ctx.Pool(cores) as pool:
-        res = pool.map(_cpu_worker, jobs)
-        wall = time.perf_counter() - t0
-        times = [r[0] for r in res]
-        study = []
-        if a.dpsi_events > 0 and a.dpsi_seeds > 1:
-            pairs = [(e, 1000003 * (s + 1) + e) for e in range(a.dpsi_events) for s in range(a.dpsi_seeds)]
-            jobs2 = [(kind, pairs[p::cores]) + shape for p in range(cores)]
-            t1 = time.perf_counter()
-            study = [row for r in pool.map(_cpu_worker, jobs2) for row in r[1]]
-            study_s = time.perf_counter() - t1
-        else:
-            study_s = 0.0
-    busy = max(times)
-    base = {"value": round(cores * per_proc / busy, 3), "unit": "events/s", "cores": cores, "kind": kind,
-            "sample": "%d events/process x %d processes (same synthetic events, K=%d N=%d iters=%d burn=%d "
-                      "lag=%d chains=%d), slowest process %.2fs, pool wall %.2fs; + %d events x %d seeds for "
-                      "the |dpsi| tolerance (%.1fs, not timed)"
-                      % (per_proc, cores, a.K, a.reads, a.iters, a.burn, a.lag, a.chains, busy, wall,
-                         a.dpsi_events, a.dpsi_seeds, study_s),
-            "value_1core": round(per_proc / (sum(times) / len(times)), 3)}
-    return base, [row for r in res for row in r[1]], study
+    with mp.get_context("fork").Pool(cores) as pool:
+        for (wid, which), (busy, rows) in zip(tags, pool.map(_cpu_worker, jobs, chunksize=1)):
+            out[wid][which] += rows
+            out[wid][which + "_busy"].append(busy)
+    wall = time.perf_counter() - t0
+    for wid, (sh, timed, study) in wanted.items():
+        o = out[wid]
+        which = "timed" if timed else "study"
+        runs, busy = len(o[which]), o[which + "_busy"]
+        n_ev = len(set(r[0] for r in o[which]))
+        o["baseline"] = {
+            "value": round(runs / max(busy), 3), "unit": "events/s", "cores": len(busy), "kind": kind,
+            "sample": "%d reference runs (%d events x %d seed(s), the workload's own synthetic events: K=%s reads=%s iters=%d "
+                      "burn=%d lag=%d chains=%d%s) on %d processes, slowest process busy %.2fs%s"
+                      % (runs, n_ev, max(1, runs // max(1, n_ev)), sh["K"], sh["reads"], sh["iters"], sh["burn"], sh["lag"],
+                         sh["chains"], " paired-end" if sh["paired"] else "", len(busy), max(busy),
+                         "" if timed else "; the runs of the |dpsi| study are the timing sample"),
+            "value_1core": round(runs / sum(busy), 3)}
+    return out, wall
 
 
-def delta_psi(batch, a, sample_rows, study_rows):
-    """BASELINE's "|delta psi| vs ref" with a pass/fail.  GPU = device-side posterior mean and
-    Chen-Shao bounds of isoform 0 (summarize_kernel); reference = the real C core on the same events
-    under independent random streams."""
+def delta_psi(batch, study_rows, sample_rows=None):
+    """BASELINE's "|delta psi| vs ref" with a pass/fail, ALL isoforms, posterior mean and both Chen-Shao bounds.
+    GPU = device-side summaries (summarize_kernel); reference = the real C core on the same events under
+    independent random streams, S seeds per event.  For every (event, isoform, statistic) the GPU's value must lie
+    within 4 x MCSE x sqrt(1 + 1/S) of the mean over the reference's seeds, MCSE = the seed-to-seed standard
+    deviation of that statistic in the reference.  MCSE is itself estimated from S seeds, so the ratio is Student-t
+    with S - 1 degrees of freedom: the check fails when more ratios exceed 4 than that explains (binomial tail
+    < 1e-3) or when any ratio exceeds a hard limit set where the whole table would exceed it with probability 1e-3."""
     import numpy as np
+    from scipy import stats
     batch.summarize(0.95)
     n_local = len(batch)
-    rows = [r for r in sample_rows if r[0] < n_local]
-    d_mean, d_lo, d_hi = [], [], []
-    for e, _, m, lo, hi, sd in rows:
-        gm, glo, ghi = batch.summary(e)
-        d_mean.append(abs(gm[0] - m)); d_lo.append(abs(glo[0] - lo)); d_hi.append(abs(ghi[0] - hi))
-    out = {"events": len(rows), "mean_abs_dpsi": round(float(np.mean(d_mean)), 6),
-           "max_abs_dpsi": round(float(np.max(d_mean)), 6),
-           "mean_abs_dci_low": round(float(np.mean(d_lo)), 6),
-           "mean_abs_dci_high": round(float(np.mean(d_hi)), 6)}
+    out = {}
+    if sample_rows:   # single runs of the reference (the timing sample): plain differences, isoform 0
+        rows = [r for r in sample_rows if r[0] < n_local]
+        d = np.array([[abs(batch.summary(r[0])[j][0] - r[2 + j][0]) for j in range(3)] for r in rows])
+        out.update({"events": len(rows), "mean_abs_dpsi": round(float(d[:, 0].mean()), 6),
+                    "max_abs_dpsi": round(float(d[:, 0].max()), 6),
+                    "mean_abs_dci_low": round(float(d[:, 1].mean()), 6), "mean_abs_dci_high": round(float(d[:, 2].mean()), 6)})
     by_event = {}
     for e, _, m, lo, hi, sd in study_rows:
         if e < n_local:
-            by_event.setdefault(e, []).append((m, sd))
-    if by_event:
-        S = a.dpsi_seeds
-        z, worst = [], None
-        for e, runs in sorted(by_event.items()):
-            means = np.array([r[0] for r in runs])
-            mcse = float(means.std(ddof=1))            # sd of one run's posterior mean over seeds
-            post_sd = float(np.mean([r[1] for r in runs]))
-            gm = batch.summary(e)[0][0]
-            # GPU run (one chain, same MCSE) minus the mean of S reference runs
-            tol = 4.0 * mcse * math.sqrt(1.0 + 1.0 / len(means))
-            d = abs(gm - float(means.mean()))
-            rec = {"event": e, "abs_dpsi": round(d, 6), "tolerance": round(tol, 6), "mcse": round(mcse, 6),
-                   "posterior_sd": round(post_sd, 6), "ref_seed_range": round(float(np.ptp(means)), 6)}
-            z.append(d / max(tol / 4.0, 1e-300))
-            if worst is None or d / max(tol, 1e-300) > worst["abs_dpsi"] / max(worst["tolerance"], 1e-300):
-                worst = rec
-        z = np.array(z)
-        n_fail = int((z > 4.0).sum())
-        # MCSE comes from S seeds, so the statistic is Student-t with S-1 degrees of freedom, not
-        # normal: P(|t_15| > 4) = 1.2e-3 per event.  The run fails when more events exceed 4 x MCSE
-        # than that explains (binomial tail < 1e-3) or when any event is beyond 8 x MCSE.
-        from scipy import stats
-        p1 = 2 * stats.t.sf(4.0, S - 1)
-        allowed = int(stats.binom.isf(1e-3, len(z), p1))
-        out.update({"tolerance": "4*MCSE", "mcse_from": "%d reference seeds per event, %d events" % (S, len(z)),
-                    "n_fail": n_fail, "n_fail_allowed": allowed,
-                    "expected_exceedances_t%d" % (S - 1): round(len(z) * p1, 3),
-                    "max_z_in_mcse": round(float(z.max()), 3), "worst_event": worst,
-                    "pass": bool(n_fail <= allowed and float(z.max()) <= 8.0)})
-    out["note"] = ("isoform 0; independent random streams, so differences are Monte-Carlo error: the K=2 "
-                   "proposal step is 0.05 in logit space (miso.c:188, 328), so events with few informative "
-                   "reads mix slowly and two runs of the REFERENCE differ by the same amounts "
-                   "(worst_event.ref_seed_range)")
+            by_event.setdefault(e, []).append((m, lo, hi, sd))
+    if not by_event:
+        return out
+    S = min(len(v) for v in by_event.values())
+    if S < 2:
+        return out
+    z, absd, worst = [], [], None
+    names = ("mean", "ci_low", "ci_high")
+    for e, runs in sorted(by_event.items()):
+        g = batch.summary(e)
+        for j in range(3):
+            ref = np.array([r[j] for r in runs])            # [S, K]
+            mcse = ref.std(0, ddof=1)
+            d = np.abs(np.asarray(g[j]) - ref.mean(0))
+            zz = d / np.maximum(mcse * math.sqrt(1.0 + 1.0 / len(runs)), 1e-12)
+            # a statistic that does not move between seeds and equals the GPU's (psi pinned at a bound) passes
+            zz = np.where((mcse < 1e-12) & (d < 1e-9), 0.0, zz)
+            z.extend(zz.tolist())
+            if j == 0:
+                absd.extend(d.tolist())
+            k = int(np.argmax(zz))
+            if worst is None or zz[k] > worst["z_in_mcse"]:
+                worst = {"event": e, "isoform": k, "statistic": names[j], "abs_delta": round(float(d[k]), 6),
+                         "mcse": round(float(mcse[k]), 6), "z_in_mcse": round(float(zz[k]), 3),
+                         "posterior_sd": round(float(np.mean([r[3][k] for r in runs])), 6),
+                         "ref_seed_range": round(float(np.ptp(ref[:, k])), 6)}
+    z = np.array(z)
+    p1 = 2 * stats.t.sf(4.0, S - 1)
+    allowed = int(stats.binom.isf(1e-3, len(z), p1))
+    hard = float(stats.t.isf(0.5e-3 / len(z), S - 1))     # n x P(|t| > hard) = 1e-3
+    n_fail = int((z > 4.0).sum())
+    out.update({"tolerance": "4*MCSE*sqrt(1+1/S): every isoform, posterior mean and both 95% bounds",
+                "mcse_from": "%d reference seeds per event, %d events, %d (event, isoform, statistic) checks" % (S, len(by_event), len(z)),
+                "mean_abs_dpsi_all_isoforms": round(float(np.mean(absd)), 6), "max_abs_dpsi_all_isoforms": round(float(np.max(absd)), 6),
+                "n_fail": n_fail, "n_fail_allowed": allowed, "expected_exceedances_t%d" % (S - 1): round(len(z) * p1, 2),
+                "max_z_in_mcse": round(float(z.max()), 3), "hard_limit_z": round(hard, 2), "worst": worst,
+                "pass": bool(n_fail <= allowed and float(z.max()) <= hard),
+                "note": "independent random streams, so differences are Monte-Carlo error; the proposal step is small (miso.c:188, "
+                        "328), events with few informative reads mix slowly and two runs of the REFERENCE differ by the same "
+                        "amounts (worst.ref_seed_range)"})
     return out
 
 
@@ -217,40 +296,66 @@ def load_json(name):
         return {}
 
 
-def roofline_for(batch, kernel_ms, workload_key):
+def valu_floor(K, paired, draws_per_chain):
+    """VALU wave-instructions one chain-iteration cannot avoid in this formulation: one
+    Philox4x32-10 block per four draws (36 once round 0 is hoisted), per draw K - 1 compare-and-count pairs
+    (single-end; paired-end ~15 per read and compatible isoform for weights, compare, select, score gather), and the
+    scalar step's 5K + 3 transcendentals at ~55 instructions each if every lane of a wavefront has one to do, plus
+    its ~3K divisions."""
+    K = float(K)
+    per_block = 36.0 + (8.0 * (K - 1.0) if not paired else 30.0 * K)
+    return draws_per_chain / 256.0 * per_block + ((5.0 * K + 3.0) * 55.0 + 3.0 * K * 10.0) / 64.0
+
+
+def roofline_for(batch, kernel_ms, key, sh):
     """The launch against the bound that applies to it.  The sampler kernels are VALU-issue bound (no HBM
-    stream, no MFMA): `achieved` = VALU issue cycles the launch needs per second of kernel time, priced
-    from the committed rocprofv3 passes of this very workload (profiles/valu_model.json: VALU
-    wave-instructions per chain-iteration x the issue cycles one takes, tools/prof_summary.py) and scaled
-    to this run's chains, iterations and measured kernel time; `peak` = 1024 SIMDs x 2.4 GHz.  Beside it:
-    the share of the Philox ceiling, the measured HBM fraction and SURVEY 8(d)'s algorithmic-bytes figure."""
+    stream, no MFMA): `achieved` = VALU issue cycles the launch needs per second of kernel time.  It is a MODEL
+    (`frac_source`): VALU wave-instructions per chain-iteration and the issue cycles one takes come from the
+    committed rocprofv3 PMC passes of this very workload and these very kernels (profiles/valu_model.json,
+    tools/prof_summary.py), scaled to this run's chains, iterations and MEASURED kernel time; `peak` = 1024 SIMDs
+    x 2.4 GHz.  A profile of other kernels than the ones this run launched is refused (frac null).
+    `floor_frac` = the instruction floor / the profiled instructions per chain-iteration: useful issue, not busy
+    issue.  Beside them: the share of the Philox ceiling, the measured HBM fraction and SURVEY 8(d)'s
+    algorithmic-bytes figure."""
     stats = batch.launch_stats()
     name = batch.last_kernels()
     t = kernel_ms * 1e-3
     alg_bytes = batch.algorithmic_bytes()
     out = {"bound": "valu", "unit": "Gcycle/s", "peak": round(VALU_PEAK_GCYC, 1),
            "kernel": name, "kernel_ms": round(kernel_ms, 3)}
-    m = load_json("valu_model.json").get(workload_key)
+    m = load_json("valu_model.json").get(key)
     chain_iters = sum(k["chains"] * k["iterations"] for k in stats["kernels"])
-    if m is not None:
+    chains = sum(k["chains"] for k in stats["kernels"])
+    draws = sum(k["words"] for k in stats["kernels"]) / max(chains, 1.0)
+    profiled = None if m is None else sorted(re.search(r"miso::(sampler_[^(]+)\(", k).group(1) for k in m["kernels"])
+    if m is not None and profiled == sorted(name.split(",")):
         cyc = m["valu_per_chain_iteration"] * chain_iters * m["issue_cycles_per_valu"]
         out["achieved"] = round(cyc / t / 1e9, 1)
         out["frac"] = round(cyc / t / 1e9 / VALU_PEAK_GCYC, 4)
+        out["frac_source"] = ("model: VALU instructions per chain-iteration x issue cycles per instruction from the committed "
+                              "rocprofv3 PMC pass of this workload and these kernels (profiles/valu_model.json <- %s), x this "
+                              "run's chain-iterations / this run's measured kernel time" % m["source"])
         out["model"] = {"valu_per_chain_iteration": round(m["valu_per_chain_iteration"], 1),
                         "issue_cycles_per_valu": round(m["issue_cycles_per_valu"], 3),
-                        "chain_iterations": chain_iters, "source": "profiles/valu_model.json <- " + m["source"],
+                        "chain_iterations": chain_iters,
                         "profiled_valu_busy": {k: (None if v["valu_busy"] is None else round(v["valu_busy"], 4))
                                                for k, v in m["kernels"].items()},
                         "profiled_wave_slot_occupancy": {k: (None if v["wave_slot_occupancy"] is None else round(v["wave_slot_occupancy"], 4))
                                                          for k, v in m["kernels"].items()}}
+        if not isinstance(sh["K"], (tuple, list)):
+            fl = valu_floor(sh["K"], sh["paired"], draws)
+            out["floor_valu_per_chain_iteration"] = round(fl, 1)
+            out["floor_frac"] = round(fl / m["valu_per_chain_iteration"], 4)
     else:
         out["achieved"] = None
         out["frac"] = None
-        out["model"] = "no rocprofv3 PMC pass committed for this workload (%s)" % workload_key
+        out["frac_source"] = ("no rocprofv3 PMC pass committed for this workload (%s)" % key) if m is None else \
+            ("the committed profile of this workload is of other kernels (%s): re-profile" % ",".join(profiled))
+    out["draws_per_chain"] = round(draws, 1)
     rng_ceiling = load_json("rng_ceiling.json").get("philox4x32_10_outputs_per_s", 2885e9)
     out["rng_frac"] = round(stats["uniforms"] / t / rng_ceiling, 4)
     out["rng_note"] = "Philox4x32-10 words consumed / s over the chip's measured ceiling (tools/rng_bench.hip)"
-    traffic = load_json("traffic.json").get(workload_key)
+    traffic = load_json("traffic.json").get(key)
     out["traffic"] = None if traffic is None else traffic["hbm_bytes_per_launch"]
     out["hbm_measured_frac"] = None if traffic is None else round(
         traffic["hbm_bytes_per_launch"] / t / 1e9 / HBM_PEAK_GBS, 5)
@@ -260,13 +365,6 @@ def roofline_for(batch, kernel_ms, workload_key):
                                "chain-iteration); the kernels keep the event on chip, so this exceeds the "
                                "HBM peak and is not a utilisation figure")
     return out
-
-
-def traffic_key(kernel, events, K, reads, iters, chains, paired):
-    """One canonical key per workload: K as "lo-hi" for isoform ranges, reads as a number or "hg19"."""
-    k = "%d-%d" % tuple(K) if isinstance(K, (tuple, list)) else str(K)
-    return "%s|events=%d|K=%s|reads=%s|iters=%d|chains=%d|paired=%d" % (
-        kernel, events, k, reads, iters, chains, int(paired))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -287,46 +385,61 @@ def time_batch(batch, seed, first, steps, warmup, barrier=None):
     return time.perf_counter() - t0, kernel_ms
 
 
-MATRIX = [  # (label, overrides): the other shapes BASELINE's metric names, 40 000 events each
-    # read counts as a real annotation sees them (workload.HG19_LIKE: log-normal, median 300, 20 ... 10^5 reads per
-    # event, a handful of 10^4 ... 10^5-read events per 40 000): "reads_iter_per_s" is what to compare with the uniform rows
-    ("SE K=2, hg19-like read counts (20..1e5 per event), 1 chain, 7500 iters", dict(K=2, reads="hg19")),
-    ("SE K=2, hg19-like read counts, MISO defaults (6 chains, 5000 iters, 500 burn-in, lag 10)",
-     dict(K=2, reads="hg19", chains=6, iters=5000, burn=500, lag=10)),
-    ("PE K=2, hg19-like read counts, 1 chain, 7500 iters", dict(K=2, paired=True, reads="hg19")),
-    ("SE K=5, hg19-like read counts, 1 chain, 7500 iters", dict(K=5, reads="hg19")),
-    ("SE K=5, 1 chain, 7500 iters", dict(K=5)),
-    ("SE K=10, 1 chain, 7500 iters", dict(K=10)),
-    ("SE K=2, MISO defaults (6 chains, 5000 iters, 500 burn-in, lag 10)", dict(K=2, chains=6, iters=5000, burn=500, lag=10)),
-    ("PE K=2 (mean 250, sd 30), 1 chain, 7500 iters", dict(K=2, paired=True)),
-    # BASELINE configs[3]: whole-gene mode, 3-20 isoforms per gene, paired-end; "events" are genes here
-    ("PE K=3..20 per gene (whole-gene mix), 1 chain, 7500 iters", dict(K=(3, 20), paired=True, events=16384)),
-]
+def stream_rows(batch, n_events, sh, first, seed, device):
+    """Rows f2 / f3 on the samples where they are (outside the timed region): device-side summaries and the
+    two-sample Bayes factors of BASELINE configs[4], with the HBM bytes they stream."""
+    S = sh["chains"] * (sh["iters"] - sh["burn"]) // sh["lag"]
+    K = sh["K"] if not isinstance(sh["K"], (tuple, list)) else None
+    batch.summarize(0.95)                      # first call: code object load
+    t1 = time.perf_counter()
+    batch.summarize(0.95)
+    summary_ms = 1e3 * (time.perf_counter() - t1)
+    other = build(first + (1 << 24), n_events, sh, device_match=False)
+    other.upload(device)
+    other.launch(seed=seed ^ 0x5851F42D4C957F2D, first_event_id=first)
+    other.sync()
+    batch.compare(other, 0.3)
+    t1 = time.perf_counter()
+    batch.compare(other, 0.3)
+    compare_ms = 1e3 * (time.perf_counter() - t1)
+    del other
+    out = {"summary_ms": round(summary_ms, 3), "compare_ms": round(compare_ms, 3)}
+    if K:
+        sb, cb = 8.0 * K * S * n_events, 2 * 8.0 * K * S * n_events
+        out["summary_hbm_frac"] = round(sb / (summary_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        out["compare_hbm_frac"] = round(cb / (compare_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        out["stream_note"] = ("wall time of the whole call (allocation, launch, result copy, host sync) over the algorithmic sample "
+                              "bytes (8 K S per event, twice for the comparison) and 8 TB/s; the kernels alone: DESIGN.md 4.6 / 4.7")
+    return out
 
 
-def run_matrix(a, local_rank):
+def run_matrix(a, local_rank, studies):
     from miso_amd import workload
     rows = []
-    for label, ov in MATRIX:
-        cfg = dict(K=a.K, reads=a.reads, read_len=a.read_len, iters=a.iters, burn=a.burn, lag=a.lag,
-                   chains=a.chains, paired=False)
-        cfg.update(ov)
-        n = min(a.matrix_events, cfg.get("events", a.matrix_events))
-        reads_spec = workload.HG19_LIKE if cfg["reads"] == "hg19" else cfg["reads"]
-        total_reads = sum(workload.event_n_reads(e, reads_spec) for e in range(n))
-        b = workload.build_batch(0, n, K=cfg["K"], n_reads=reads_spec, read_len=cfg["read_len"],
-                                 iters=cfg["iters"], burn=cfg["burn"], lag=cfg["lag"], chains=cfg["chains"],
-                                 paired=cfg["paired"], device_match=True)
+    only = set(a.matrix_only.split(",")) if a.matrix_only else None
+    for wid, label, ov, events, _ in MATRIX:
+        if only and wid not in only:
+            continue
+        sh = dict(BASE_SHAPE, **ov)
+        n = min(a.matrix_events, events)
+        spec = reads_spec(sh)
+        total_reads = sum(workload.event_n_reads(e, spec) for e in range(n))
+        b = build(0, n, sh)
         b.upload(local_rank)
         elapsed, kms = time_batch(b, a.seed, 0, 2, 1)
         avg = sum(kms) / len(kms)
-        r = roofline_for(b, avg, traffic_key(b.last_kernels(), n, cfg["K"], cfg["reads"], cfg["iters"],
-                                             cfg["chains"], cfg["paired"]))
-        rows.append({"workload": label, "events": n, "events_per_s": round(2 * n / elapsed, 1),
-                     "reads_iter_per_s": round(2.0 * total_reads * cfg["chains"] * cfg["iters"] / elapsed, 1),
-                     "kernel": r["kernel"], "kernel_ms": r["kernel_ms"], "valu_frac": r["frac"],
-                     "rng_frac": r["rng_frac"], "hbm_measured_frac": r["hbm_measured_frac"],
-                     "algorithmic_GBs": r["algorithmic_GBs"]})
+        r = roofline_for(b, avg, workload_key(n, sh), sh)
+        row = {"id": wid, "workload": label, "events": n, "events_per_s": round(2 * n / elapsed, 1),
+               "reads_iter_per_s": round(2.0 * total_reads * sh["chains"] * sh["iters"] / elapsed, 1),
+               "kernel": r["kernel"], "kernel_ms": r["kernel_ms"], "valu_frac": r["frac"], "floor_frac": r.get("floor_frac"),
+               "frac_source": r["frac_source"], "rng_frac": r["rng_frac"], "hbm_measured_frac": r["hbm_measured_frac"],
+               "algorithmic_GBs": r["algorithmic_GBs"]}
+        st = studies.get(wid) if studies else None
+        if st:
+            row["cpu_baseline"] = st["baseline"]
+            if len(st["study"]) >= 2 * len(set(r_[0] for r_ in st["study"])):   # at least two reference seeds per event
+                row["delta_psi"] = delta_psi(b, st["study"])
+        rows.append(row)
         del b
     return rows
 
@@ -340,7 +453,7 @@ def main():
     ap.add_argument("--K", type=int, default=2)
     ap.add_argument("--K-range", type=int, nargs=2, default=None, metavar=("LO", "HI"),
                     help="isoforms per event drawn from [LO, HI] by event id (configs[3] proxy: whole-gene "
-                         "mode, mixed isoform counts in one batch); overrides --K, no CPU baseline")
+                         "mode, mixed isoform counts in one batch); overrides --K")
     ap.add_argument("--reads", type=int, default=1000)
     ap.add_argument("--reads-dist", choices=["fixed", "hg19"], default="fixed",
                     help="hg19: heavy-tailed read counts per event (workload.HG19_LIKE) instead of --reads for every event")
@@ -355,16 +468,13 @@ def main():
                     help="reference events per host process (~12 s of CPU work per core at the default shape)")
     ap.add_argument("--dpsi-events", type=int, default=128, help="events of the |delta psi| tolerance study")
     ap.add_argument("--dpsi-seeds", type=int, default=16, help="reference seeds per event of that study")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-matrix", action="store_true", help="skip the other shapes (K=5, K=10, defaults, paired-end)")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="no reference runs at all (no cpu_baseline, no delta_psi)")
+    ap.add_argument("--no-matrix", action="store_true", help="skip the other shapes (hg19-like, K=5, K=10, defaults, paired-end)")
+    ap.add_argument("--matrix-only", default="", help="comma-separated row ids of the matrix to run (default: all)")
     ap.add_argument("--matrix-events", type=int, default=40000)
+    ap.add_argument("--no-streams", action="store_true", help="skip the device-side summaries / Bayes factors (rows f2, f3)")
     ap.add_argument("--host-match", action="store_true",
                     help="compute the read x isoform compatibility on the host instead of the GPU (row f1)")
-    ap.add_argument("--compare", action="store_true",
-                    help="also sample a second RNA-seq sample of the same events and time the device-side "
-                         "Bayes factors (BASELINE configs[4]; outside the timed region)")
-    ap.add_argument("--summarize", action="store_true",
-                    help="also time the device-side posterior summaries (outside the timed region)")
     ap.add_argument("--stub", action="store_true",
                     help="TEST ONLY (tests/test_bench_launch.py): build and shard the events on the host, skip "
                          "every GPU call; the line says \"stub\": true and its value means nothing")
@@ -377,13 +487,37 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
 
+    # every rank's native thread pools (event construction, packing) get this rank's share of the host cores, not
+    # all of them (N ranks x all cores on N-times-fewer cores each would dominate the run's wall time)
+    if world > 1:
+        cores = sorted(os.sched_getaffinity(0))
+        share = max(1, min(len(cores), usable_cores()) // world)
+        mine = cores[(local_rank * share) % len(cores):][:share] or cores[:1]
+        try:
+            os.sched_setaffinity(0, mine)
+        except OSError:
+            pass
+
+    sh = shape_of(a, K=tuple(a.K_range) if a.K_range else a.K)
     default_shape = not a.K_range and not a.paired and a.reads_dist == "fixed"
-    if a.K_range:
-        a.no_cpu_baseline = True
-    k_spec = tuple(a.K_range) if a.K_range else a.K
-    cpu = sample_rows = study_rows = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline and default_shape and not a.stub:
-        cpu, sample_rows, study_rows = cpu_reference(a)  # before anything touches the GPU (fork-safe)
+    want_matrix = world == 1 and default_shape and not a.no_matrix and not a.stub
+    studies = cpu_wall = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and not a.stub:
+        wanted = {}
+        if default_shape:
+            timed = [(e, 42 + e) for e in range(a.cpu_events * usable_cores())]
+            study = [(e, 1000003 * (s + 1) + e) for e in range(a.dpsi_events) for s in range(a.dpsi_seeds)] if a.dpsi_seeds > 1 else []
+            wanted["main"] = (sh, timed, study)
+        else:   # another shape on the command line (profiles): a bounded sample of it, timed on the study's runs
+            ne, ns = (32, 1) if a.K_range else (64, 8)
+            wanted["main"] = (sh, [], [(e, 1000003 * (s + 1) + e) for e in range(ne) for s in range(ns)])
+        if want_matrix:
+            only = set(a.matrix_only.split(",")) if a.matrix_only else None
+            for wid, _, ov, _, st in MATRIX:
+                if st is None or (only and wid not in only):
+                    continue
+                wanted[wid] = (dict(BASE_SHAPE, **ov), [], [(e, 1000003 * (s + 1) + e) for e in range(st[0]) for s in range(st[1])])
+        studies, cpu_wall = cpu_studies(wanted)   # before anything touches the GPU (fork-safe)
 
     from miso_amd import capi, workload
     dist = None
@@ -399,14 +533,11 @@ def main():
 
     # the rank's shard of the global event list: contiguous, balanced by cost
     n_global = a.events * world
-    reads_spec = workload.HG19_LIKE if a.reads_dist == "hg19" else a.reads
-    costs = workload.event_costs(0, n_global, k_spec, reads_spec, a.iters, a.chains)
+    costs = workload.event_costs(0, n_global, sh["K"], reads_spec(sh), a.iters, a.chains)
     first, last = workload.shard_bounds_by_cost(costs, world, rank)
     n_local = last - first
     t_build = time.perf_counter()
-    batch = workload.build_batch(first, n_local, K=k_spec, n_reads=reads_spec, read_len=a.read_len,
-                                 iters=a.iters, burn=a.burn, lag=a.lag, chains=a.chains,
-                                 paired=a.paired, device_match=not a.host_match and not a.stub)
+    batch = build(first, n_local, sh, device_match=not a.host_match and not a.stub)
     t_up = time.perf_counter()
     if not a.stub:
         batch.upload(local_rank)   # device_match: read x isoform compatibility on the GPU, then packing
@@ -425,7 +556,7 @@ def main():
         elapsed, kernel_ms = time.perf_counter() - t0, [10.0] * a.steps
     else:
         elapsed, kernel_ms = time_batch(batch, a.seed, first, a.steps, a.warmup, barrier)
-    shard = [rank, first, last]
+    shard = [rank, first, last, float(costs[first:last].sum())]
     if dist is not None:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64)
@@ -436,46 +567,34 @@ def main():
     else:
         shards = [shard]
 
-    summary_ms = compare_ms = None
-    if a.summarize and not a.stub:
-        t1 = time.perf_counter()
-        batch.summarize(0.95)
-        summary_ms = 1e3 * (time.perf_counter() - t1)
-    if a.compare and not a.stub:
-        other = workload.build_batch(first + (1 << 24), n_local, K=a.K, n_reads=reads_spec,
-                                     read_len=a.read_len, iters=a.iters, burn=a.burn, lag=a.lag,
-                                     chains=a.chains, paired=a.paired)
-        other.upload(local_rank)
-        other.launch(seed=a.seed ^ 0x5851F42D4C957F2D, first_event_id=first)
-        other.sync()
-        t1 = time.perf_counter()
-        batch.compare(other, 0.3)
-        compare_ms = 1e3 * (time.perf_counter() - t1)
-        del other
-
     rc = 0
     if rank == 0:
-        delta = None
-        if cpu is not None and sample_rows:
-            delta = delta_psi(batch, a, sample_rows, study_rows)
-            if delta.get("pass") is False:
-                rc = 3
         avg_ms = sum(kernel_ms) / len(kernel_ms)
         if a.stub:
             roof = {"bound": "valu", "achieved": None, "peak": VALU_PEAK_GCYC, "unit": "Gcycle/s", "frac": None,
                     "traffic": None}
         else:
-            roof = roofline_for(batch, avg_ms, traffic_key(batch.last_kernels(), n_local, k_spec,
-                                                           "hg19" if a.reads_dist == "hg19" else a.reads, a.iters, a.chains, a.paired))
+            roof = roofline_for(batch, avg_ms, workload_key(n_local, sh), sh)
+        cpu = delta = None
+        if studies and "main" in studies:
+            cpu = studies["main"]["baseline"]
+            delta = delta_psi(batch, studies["main"]["study"], studies["main"]["timed"])
+            if delta.get("pass") is False:
+                rc = 3
+        streams = {}
+        if not a.stub and not a.no_streams and world == 1:
+            streams = stream_rows(batch, n_local, sh, first, a.seed, local_rank)
         kind = "paired-end" if a.paired else "skipped-exon single-end"
+        rd = "hg19-like read counts (20..1e5)" if a.reads_dist == "hg19" else "%d reads" % a.reads
         if a.K_range:
             wl = ("configs[3] proxy (whole-gene mode): %d %s genes/GPU, %d-%d isoforms" % (a.events, kind, a.K_range[0], a.K_range[1]))
         elif a.paired:
             wl = "configs[2] proxy: %d paired-end events/GPU (insert 250 +- 30), K=%d isoforms" % (a.events, a.K)
         else:
             wl = "configs[1] proxy (hg19 SE set): %d %s events/GPU, K=%d isoforms" % (a.events, kind, a.K)
-        wl += ", %d reads of %d bp, %d iters (%d burn-in + %d kept), lag %d, %d chain(s)" % (
-            a.reads, a.read_len, a.iters, a.burn, a.iters - a.burn, a.lag, a.chains)
+        wl += ", %s of %d bp, %d iters (%d burn-in + %d kept), lag %d, %d chain(s)" % (
+            rd, a.read_len, a.iters, a.burn, a.iters - a.burn, a.lag, a.chains)
+        tot = sum(s[3] for s in shards)
         out = {
             "metric": "AS events/sec at 5000 iters (1k reads x 2-10 iso)",
             "value": round(n_global * a.steps / elapsed, 1), "unit": "events/s", "n_gpus": world, "steps": a.steps,
@@ -483,24 +602,29 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": wl, "events_per_gpu": a.events,
-                       "K": a.K if not a.K_range else list(a.K_range), "reads": a.reads, "iters": a.iters,
+                       "K": a.K if not a.K_range else list(a.K_range), "reads": sh["reads"], "iters": a.iters,
                        "burn_in": a.burn, "lag": a.lag, "chains": a.chains,
                        "parallelism": "%d contiguous cost-balanced event shards, one process per GPU, "
                                       "no collective on the data path" % world,
-                       "shards": [[r, lo, hi] for r, lo, hi in shards]},
+                       "shards": [[r, lo, hi] for r, lo, hi, _ in shards],
+                       "shard_cost_share": [round(c / tot, 5) if tot else None for _, _, _, c in shards]},
             "roofline": roof,
             "cpu_baseline": cpu,
             "delta_psi_vs_reference": delta,
             "host_build_s": round(t_build, 2), "upload_s": round(t_up, 3),
             "match_kernel_ms": None if a.stub else round(batch.match_ms(), 3),
-            "summary_ms": None if summary_ms is None else round(summary_ms, 3),
-            "compare_ms": None if compare_ms is None else round(compare_ms, 3),
+            "summary_ms": streams.get("summary_ms"), "compare_ms": streams.get("compare_ms"),
+            "summary_hbm_frac": streams.get("summary_hbm_frac"), "compare_hbm_frac": streams.get("compare_hbm_frac"),
+            "stream_note": streams.get("stream_note"),
+            "cpu_reference_wall_s": None if cpu_wall is None else round(cpu_wall, 1),
         }
         if a.stub:
             out["stub"] = True
-        elif world == 1 and default_shape and not a.no_matrix:
+        elif want_matrix:
             del batch
-            out["matrix"] = run_matrix(a, local_rank)
+            out["matrix"] = run_matrix(a, local_rank, studies)
+            if any(r.get("delta_psi", {}).get("pass") is False for r in out["matrix"]):
+                rc = 3
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

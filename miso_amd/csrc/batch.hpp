@@ -39,6 +39,7 @@ struct miso_batch {
   double *d_fp = nullptr;
   int32_t *d_slots = nullptr;     // [k2 events sorted by n_draw desc | all other events]
   std::vector<int32_t> h_slots;   // the same list on the host
+  bool k2_general = false;        // paired-end, tables too wide for the two-isoform kernel's LDS: K = 2 events take sampler_grp
   bool use_delta = true;          // paired-end: MODE 2 events first in the list (fixed at upload)
   miso::LanePlan k2_plan;         // sampler_k2_multi: the runs of equal lanes per chain (runtime.hip), valid for k2_plan_key
   long k2_plan_key = -1;
@@ -98,7 +99,7 @@ struct miso_batch {
   int k2_first_event() const {  // the k2 event with the most drawing reads (list is sorted)
     int best = -1;
     for (size_t i = 0; i < events.size(); i++)
-      if (events[i].K == 2 && (best < 0 || events[i].n_draw > events[best].n_draw))
+      if (events[i].K == 2 && !k2_general && (best < 0 || events[i].n_draw > events[best].n_draw))
         best = static_cast<int>(i);
     return best;
   }

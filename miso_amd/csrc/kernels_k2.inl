@@ -257,6 +257,10 @@ __device__ __forceinline__ void k2_body(const KernelArgs &a, unsigned block_x, u
   constexpr int NR = G >= 4 ? 4 : G;               // lanes cooperating on the scalar math
   constexpr bool QUAD = (G % 4) == 0;
   constexpr bool POW2 = (G & (G - 1)) == 0;
+#ifdef MISO_K2_WAVETIME   // tools/wave_time.py: how long every wavefront ran, through ChainStats::hw_id (diagnostic build)
+  uint64_t wt_t0;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wt_t0) : : "memory");   // 100 MHz; "memory": stays where it is
+#endif
   const int lane = threadIdx.x & 63;
   const int grp_raw = lane / G;
   const bool lane_used = grp_raw < CPW;            // 64 % G lanes at the top of the wave idle
@@ -677,6 +681,11 @@ __device__ __forceinline__ void k2_body(const KernelArgs &a, unsigned block_x, u
     st->counts_hash = hash;
     st->accepted = accepted;
     st->hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_REG_HW_ID, all 32 bits
+#ifdef MISO_K2_WAVETIME
+    uint64_t wt_t1;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wt_t1) : : "memory");
+    st->hw_id = static_cast<uint32_t>(wt_t1 - wt_t0);
+#endif
   }
 }
 

@@ -102,7 +102,11 @@ LanePlan plan_lanes(const int *n_draw, int n_events, int chains, const int *widt
       plan.est_last = cost.wave_step(plan.seg_lanes[plan.n_segs - 1], n_draw[n_events - 1]);
     return plan;
   };
-  if (forced_target > 0) return evaluate(forced_target);
+  auto simd_share = [&](const LanePlan &plan) {   // total work over the SIMDs that have any
+    const double simds = std::min(0.5 * static_cast<double>(P.resident) * wpb, std::ceil(0.5 * static_cast<double>(plan.waves)));
+    return plan.est_total / std::max(1.0, simds);
+  };
+  if (forced_target > 0) { LanePlan f = evaluate(forced_target); f.est = std::max(simd_share(f), 2.0 * f.est_max); return f; }
   int narrow = widths[0];
   for (int i = 0; i < n_widths; i++) if (64 / widths[i] <= max_cpw) { narrow = widths[i]; break; }
   double lo = cost.step[4] + 2.0 * cost.block;
@@ -117,7 +121,9 @@ LanePlan plan_lanes(const int *n_draw, int n_events, int chains, const int *widt
       const double mid = 0.5 * (lo + hi);
       if (P.cut(mid, nullptr) <= P.resident) hi = mid; else lo = mid;
     }
-    return evaluate(hi);
+    best = evaluate(hi);
+    best.est = std::max(simd_share(best), best.est_pair);
+    return best;
   }
   // Several rounds.  Time of the launch in VALU issue slots of one SIMD: the hardware starts workgroups in index
   // order as slots free up -- heaviest first, lightest last --, so the launch ends within one of the LAST wavefronts
@@ -133,7 +139,7 @@ LanePlan plan_lanes(const int *n_draw, int n_events, int chains, const int *widt
     const LanePlan plan = evaluate(D);
     const double e = estimate(plan);
     if (std::getenv("MISO_PLAN_DEBUG")) std::fprintf(stderr, "[plan] D %.0f waves %ld total %.0f max %.0f last %.0f est %.0f\n", D, plan.waves, plan.est_total, plan.est_max, plan.est_last, e);
-    if (!have || e < best_est) { best = plan; best_est = e; have = true; }
+    if (!have || e < best_est) { best = plan; best_est = e; best.est = e; have = true; }
     if (D <= lo) break;
   }
   return best;

@@ -62,6 +62,7 @@ struct LanePlan {
   double est_last = 0;       // wave_step of the last (lightest) wavefront
   double est_pair = 0;       // one round: the busiest SIMD = heaviest + lightest wavefront of a run (a.pair_waves)
   int wpb = 8;               // wavefronts per workgroup the plan was made for
+  double est = 0;            // the launch's estimated duration in VALU issue slots of one SIMD (what plan_lanes minimises)
 };
 
 // n_draw: the launch's events' drawing reads, most first; `chains` chains per event; widths: the instantiated lanes

@@ -329,8 +329,12 @@ void miso_batch::upload(int dev) {
   HIP_OK(hipMemcpy(d_in, h_in.data(), in_bytes, hipMemcpyHostToDevice));
   // launch lists: two-isoform events (single- or paired-end) go to sampler_k2, ordered by their
   // number of drawing reads so the chains sharing a wavefront loop equally long
+  // (paired-end with a fragment-length distribution so wide that one chain's tables do not fit a CU's LDS -- sd beyond
+  // ~400 -- : the two-isoform events take the general kernel, whose tables may stay in global memory, like the
+  // reference, which takes any sd, miso_paired.c:299-308; MISO_K2_GENERAL=1 forces it: tests)
+  k2_general = p.paired && (48 * fd.prob.size() + 64 > 150 * 1024 || std::getenv("MISO_K2_GENERAL") != nullptr);
   std::vector<int32_t> k2, gen;
-  for (int i = 0; i < n; i++) ((events[i].K == 2) ? k2 : gen).push_back(i);
+  for (int i = 0; i < n; i++) ((events[i].K == 2 && !k2_general) ? k2 : gen).push_back(i);
   // (paired-end: the events sampler_k2's MODE 2 can take come first, MISO_NO_PE_DELTA=1 sends all to MODE 1)
   use_delta = std::getenv("MISO_NO_PE_DELTA") == nullptr;   // fixed here: the slot order depends on it
   std::stable_sort(k2.begin(), k2.end(), [&](int x, int y) {
@@ -356,7 +360,7 @@ void miso_batch::upload(int dev) {
     r.maxq = std::max(r.maxq, (e.n_draw + 3) / 4);
     r.maxcls = std::max(r.maxcls, static_cast<int>(e.dcls_mask.size()));
     if (!e.paired && e.n_draw > 0 && e.dcls_mask.empty()) r.nocls = true;
-    if (!e.paired || e.draw_dense.empty()) r.dense = false;
+    if (!e.paired || e.draw_dense.empty() || e.K == 2) r.dense = false;   // (K = 2: draw_dense holds sampler_k2's records)
   }
   n_k2 = static_cast<int>(k2.size()); n_gen = static_cast<int>(gen.size());
   k2.insert(k2.end(), gen.begin(), gen.end());
@@ -877,7 +881,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       const int max_cpw = static_cast<int>(std::max<long>(0, lds_left / static_cast<long>(4 * k2w_tab)));
       const int resident = std::max(1, slots_for(static_cast<long>(n_k2w) * p.noChains) / 4);
       const long key = static_cast<long>(resident) * 64 + p.noChains;
-      if (max_cpw >= 1 && (k2w_plan_key != key || std::getenv("MISO_K2_TARGET") || std::getenv("MISO_K2_COST"))) {
+      if (max_cpw >= 1 && (k2w_plan_key != key || std::getenv("MISO_K2_TARGET") || std::getenv("MISO_K2_COST") || std::getenv("MISO_K2W_WPB"))) {
         static const int widths[] = {4, 8, 16, 32, 64};
         LaneCost cost = k2_cost_paired();
         if (const char *env = std::getenv("MISO_K2_COST"))
@@ -886,6 +890,15 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
         for (int i = 0; i < n_k2w; i++) nd[i] = events[h_slots[i]].n_draw;
         const double forced = std::getenv("MISO_K2_TARGET") ? std::atof(std::getenv("MISO_K2_TARGET")) : 0.0;
         k2w_plan = plan_lanes(nd.data(), n_k2w, p.noChains, widths, 5, 4, 4, resident, max_cpw, cost, forced);
+        // The widest a chain can be is its workgroup: 256 lanes with 4 wavefronts, 512 with 8 (one workgroup per CU,
+        // twice the LDS each: the same chains per CU).  8-wavefront workgroups lose ~19 % when the launch runs in
+        // several rounds (a workgroup starts when ALL its slots are free), so they are taken only when the largest
+        // events would otherwise outlast the launch (hg19-like read counts: 218 ms -> 175 ms; uniform: 217 ms -> 259 ms, not taken; profiles/r03_pe_k2_wpb.txt).
+        {
+          const LanePlan p8 = plan_lanes(nd.data(), n_k2w, p.noChains, widths, 5, 8, 8, std::max(1, resident / 2), max_cpw, cost, forced);
+          const char *env = std::getenv("MISO_K2W_WPB");
+          if (env ? std::atoi(env) == 8 : 1.2 * p8.est < k2w_plan.est) k2w_plan = p8;
+        }
         k2w_plan_key = key;
       }
       k2w_multi = max_cpw >= 1 && k2w_plan.n_segs > 0;
@@ -893,7 +906,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
         int cpw = 1;
         for (int i = 0; i < k2w_plan.n_segs; i++)
           if (k2w_plan.seg_lanes[i] != K2_WIDE) cpw = std::max(cpw, 64 / k2w_plan.seg_lanes[i]);
-        k2w_multi_lds = align_up(k2w_fp + 4 * static_cast<size_t>(cpw) * k2w_tab, 16);
+        k2w_multi_lds = align_up(k2w_fp + static_cast<size_t>(k2w_plan.wpb) * cpw * k2w_tab, 16);
       }
     }
   }
@@ -906,10 +919,16 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       for (int i = 0; i <= k2w_plan.n_segs; i++) { ka.seg_block[i] = k2w_plan.seg_block[i]; ka.seg_slot[i] = k2w_plan.seg_slot[i]; }
       for (int i = 0; i < k2w_plan.n_segs; i++) ka.seg_lanes[i] = k2w_plan.seg_lanes[i];
       const int lds = static_cast<int>(k2w_multi_lds + K2_RED_BYTES);
-      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sampler_k2_multi<2, 4>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-      hipLaunchKernelGGL((sampler_k2_multi<2, 4>), dim3(static_cast<unsigned>(k2w_plan.seg_block[k2w_plan.n_segs])), dim3(256),
-                         lds, st, ka);
+      const dim3 grid(static_cast<unsigned>(k2w_plan.seg_block[k2w_plan.n_segs]));
+      if (k2w_plan.wpb == 8) {
+        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sampler_k2_multi<2, 8>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL((sampler_k2_multi<2, 8>), grid, dim3(512), lds, st, ka);
+      } else {
+        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sampler_k2_multi<2, 4>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL((sampler_k2_multi<2, 4>), grid, dim3(256), lds, st, ka);
+      }
       HIP_OK(hipGetLastError());
       return;
     }
@@ -953,7 +972,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     if (count <= 0) continue;
     // slot order = events by drawing reads, descending, each with its noChains chains
     std::vector<int> nd;
-    for (const PackedEvent &e : events) if (e.K == 2 && (use_delta && e.pe_delta && !e.draw_dense.empty()) == wpart) nd.push_back(e.n_draw);
+    for (const PackedEvent &e : events) if (e.K == 2 && !k2_general && (use_delta && e.pe_delta && !e.draw_dense.empty()) == wpart) nd.push_back(e.n_draw);
     std::sort(nd.begin(), nd.end(), [](int x, int y) { return x > y; });
     const int C = p.noChains;
     const long chains = static_cast<long>(count) * C;
@@ -1005,7 +1024,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     std::vector<const PackedEvent *> evs;   // the run's events in slot order
     {
       std::vector<int> gen;
-      for (size_t i = 0; i < events.size(); i++) if (events[i].K != 2) gen.push_back(static_cast<int>(i));
+      for (size_t i = 0; i < events.size(); i++) if (events[i].K != 2 || k2_general) gen.push_back(static_cast<int>(i));
       std::stable_sort(gen.begin(), gen.end(), [&](int x, int y) {
         return events[x].K != events[y].K ? events[x].K > events[y].K : events[x].n_draw > events[y].n_draw; });
       for (int j = 0; j < run.count; j++) evs.push_back(&events[gen[run.first + j]]);
@@ -1059,7 +1078,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   };
   if (n_k2w > 0 && k2w_multi) {
     lanes_per_chain = k2w_plan.seg_lanes[k2w_plan.n_segs - 1];
-    last_kernels = "sampler_k2_multi<2, 4>";
+    last_kernels = "sampler_k2_multi<2, " + std::to_string(k2w_plan.wpb) + ">";
     launch_k2_multi(a, stream_for_next(), true);
   } else if (n_k2w > 0) {
     lanes_per_chain = k2w_G;

@@ -32,34 +32,41 @@ def chunk_list(seq, num):
     return out
 
 
-def visible_gpus():
-    """GPUs this run may use, WITHOUT initialising HIP in the dispatcher (it only starts worker
-    processes; a parent that holds a GPU context and forks is the fragile pattern bench.py avoids):
-    HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES if set, else the KFD topology's GPU nodes, else a
-    short-lived child process asks the runtime."""
-    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
-        v = os.environ.get(var)
-        if v is not None:
-            return len([x for x in v.split(",") if x.strip() != ""])
+def _kfd_gpu_nodes():
+    """GPU nodes of the KFD topology: every GPU of the HOST, including ones this process may not open (a container's
+    device cgroup, render-node permissions, a 1-GPU lease on an 8-GPU box) -- an upper bound, never the answer."""
     nodes = "/sys/class/kfd/kfd/topology/nodes"
+    n = 0
     try:
-        n = 0
         for d in os.listdir(nodes):
             props = dict(line.split()[:2] for line in open(os.path.join(nodes, d, "properties")) if line.strip())
             if int(props.get("simd_count", "0")) > 0:
                 n += 1
-        if n > 0:
-            return n
     except (OSError, ValueError):
-        pass
+        return None
+    return n
+
+
+def visible_gpus():
+    """GPUs this run may use, WITHOUT initialising HIP in the dispatcher (it only starts worker
+    processes; a parent that holds a GPU context and forks is the fragile pattern bench.py avoids):
+    HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES if set, else a short-lived child process asks the runtime -- it
+    reports the devices this process can really open.  The KFD topology (all GPUs of the host) only caps that
+    answer, or stands in when the child cannot be started."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
     code = "import sys; sys.path.insert(0, %r); import pysplicing; print(int(pysplicing.deviceCount()))" \
         % os.path.dirname(os.path.abspath(__file__))
+    kfd = _kfd_gpu_nodes()
     try:
         out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
                              text=True, timeout=120)
-        return int(out.stdout.strip().splitlines()[-1])
+        n = int(out.stdout.strip().splitlines()[-1])
+        return n if kfd is None else min(n, kfd) if kfd > 0 else n
     except (OSError, ValueError, IndexError, subprocess.SubprocessError):
-        return 0
+        return kfd or 0
 
 
 def _forked_worker(argv, log, worker_no=0, n_workers=1):
@@ -200,21 +207,31 @@ class GenesDispatcher(object):
                 procs.append((batch_num, subprocess.Popen(cmd, stdout=open(log, "a"),
                                                           stderr=subprocess.STDOUT, env=env), log))
             waits = [(b, p.wait, lambda p=p: p.returncode, log) for b, p, log in procs]
-        else:
-            import multiprocessing
-            from . import sam_utils
+            return self._finish(waits, parts, table)
+        import multiprocessing
+        from . import sam_utils
+        try:
             sam_utils.use_reader_library()
             for path in (self.bam_filename, self.compare_bam):
                 if path is not None:
                     full = os.path.abspath(os.path.expanduser(path))
                     sam_utils._PRELOADED[full] = sam_utils.Samfile(full, "rb")
-            ctx = multiprocessing.get_context("fork")
-            sys.stdout.flush()
-            waits = []
-            for k, (batch_num, cmd, log) in enumerate(jobs):
-                p = ctx.Process(target=_forked_worker, args=(cmd[3:], log, k, len(jobs)))
-                p.start()
-                waits.append((batch_num, p.join, lambda p=p: p.exitcode, log))
+        except (ImportError, OSError, RuntimeError, ValueError) as e:
+            # no reader library (a partial build) or the one decode failed: the workers decode for themselves
+            print("One decode per node not possible (%s): starting workers that read the alignment file themselves" % e)
+            sam_utils._PRELOADED.clear()
+            os.environ["MISO_DISPATCH"] = "subprocess"
+            return self.run()
+        ctx = multiprocessing.get_context("fork")
+        sys.stdout.flush()
+        waits = []
+        for k, (batch_num, cmd, log) in enumerate(jobs):
+            p = ctx.Process(target=_forked_worker, args=(cmd[3:], log, k, len(jobs)))
+            p.start()
+            waits.append((batch_num, p.join, lambda p=p: p.exitcode, log))
+        return self._finish(waits, parts, table)
+
+    def _finish(self, waits, parts, table):
         failed = 0
         for batch_num, wait, code, log in waits:
             wait()

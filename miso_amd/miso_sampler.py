@@ -123,6 +123,7 @@ class MISOSampler:
             self.mean_frag_len = params["mean_frag_len"]
             self.frag_variance = params["frag_variance"]
         self.log_dir = log_dir
+        self.skipped_genes = []       # (gene label, reason) of genes a batch had to leave out (prepare_batch)
 
     # -- one event per call: miso_sampler.py:199-373 ------------------------------------------
     def run_sampler(self, num_iters, reads, gene, hyperparameters, params, output_file,
@@ -195,16 +196,41 @@ class MISOSampler:
         from sam_utils import STRAND_RULES
         run = []          # consecutive AlnRegion events of one file and one set of rules: added together
 
+        # One gene that cannot be sampled (a malformed CIGAR in its reads, an isoform count beyond the kernels' limit,
+        # an inconsistent annotation entry) is reported and skipped, like the reference's worker, which runs every
+        # gene in its own try block (run_miso.py:205-256, one event per C call): it never costs the other 65 535
+        # events of the batch their results.
+        skippable = (NotImplementedError, capi.InternalError, ValueError)
+
+        def skip(gene, err):
+            print("Skipping gene %s: %s" % (getattr(gene, "label", "?"), str(err).strip().splitlines()[-1]))
+            self.skipped_genes.append((getattr(gene, "label", None), str(err)))
+
         def flush():
             if not run:
                 return
             r0 = run[0][1]
-            idxs, counts = batch.add_events_aln(
-                [c for _, _, _, c, _, _ in run], r0.bamfile, [r.chrom for _, r, _, _, _, _ in run],
-                [r.start for _, r, _, _, _, _ in run], [r.end for _, r, _, _, _, _ in run],
-                STRAND_RULES[r0.strand_rule], [r.target_strand for _, r, _, _, _, _ in run],
-                r0.read_len, r0.min_reads, 0)
+            try:
+                idxs, counts = batch.add_events_aln(
+                    [c for _, _, _, c, _, _ in run], r0.bamfile, [r.chrom for _, r, _, _, _, _ in run],
+                    [r.start for _, r, _, _, _, _ in run], [r.end for _, r, _, _, _, _ in run],
+                    STRAND_RULES[r0.strand_rule], [r.target_strand for _, r, _, _, _, _ in run],
+                    r0.read_len, r0.min_reads, 0)
+            except skippable:
+                # the batched call adds nothing when one of its genes fails: one by one, skipping the culprit(s)
+                idxs, counts = [], []
+                for _, r, gene, c_gene, _, _ in run:
+                    try:
+                        idx, n = batch.add_event_aln(c_gene, r.bamfile, r.chrom, r.start, r.end,
+                                                     STRAND_RULES[r.strand_rule], r.target_strand, r.read_len,
+                                                     r.min_reads, None)
+                    except skippable as e:
+                        skip(gene, e)
+                        idx, n = -2, 0
+                    idxs.append(idx); counts.append(n)
             for (i, r, gene, c_gene, out, ev_id), idx, n in zip(run, idxs, counts):
+                if idx == -2:
+                    continue
                 if idx < 0:
                     if verbose:
                         print("Only %d reads in gene %s, skipping" % (n, gene.label))
@@ -232,8 +258,15 @@ class MISOSampler:
                 if verbose:
                     print("Gene %s has only one isoform; skipping..." % gene.label)
                 continue
-            exons, isoforms = gene_tuples(gene)
-            c_gene = capi.Gene(exons, isoforms)
+            try:
+                exons, isoforms = gene_tuples(gene)
+                c_gene = capi.Gene(exons, isoforms)
+                if c_gene.noiso > capi.MISO_MAX_ISOFORMS:
+                    raise NotImplementedError("%d isoforms: more than the %d the sampler kernels hold"
+                                              % (c_gene.noiso, capi.MISO_MAX_ISOFORMS))
+            except skippable as e:
+                skip(gene, e)
+                continue
             hyper = None if prior is None else [float(x) for x in prior]
             if isinstance(reads, AlnRegion) and hyper is None and reads.bamfile.gettid(reads.chrom) >= 0 \
                     and not os.environ.get("MISO_NO_BATCHED_ADD"):
@@ -246,18 +279,22 @@ class MISOSampler:
                 run.append((i, reads, gene, c_gene, out, ev_id))
                 continue
             flush()
-            if isinstance(reads, AlnRegion):
-                idx, n = batch.add_event_aln(c_gene, reads.bamfile, reads.chrom, reads.start,
-                                             reads.end, STRAND_RULES[reads.strand_rule],
-                                             reads.target_strand, reads.read_len, reads.min_reads,
-                                             hyper)
-                if idx < 0:
-                    if verbose:
-                        print("Only %d reads in gene %s, skipping" % (n, gene.label))
-                    continue
-            else:
-                pos = np.asarray(reads[0], dtype=np.int64) + 1            # 0-based -> 1-based (:284)
-                idx = batch.add_event(c_gene, pos.astype(np.int32), list(reads[1]), hyper)
+            try:
+                if isinstance(reads, AlnRegion):
+                    idx, n = batch.add_event_aln(c_gene, reads.bamfile, reads.chrom, reads.start,
+                                                 reads.end, STRAND_RULES[reads.strand_rule],
+                                                 reads.target_strand, reads.read_len, reads.min_reads,
+                                                 hyper)
+                    if idx < 0:
+                        if verbose:
+                            print("Only %d reads in gene %s, skipping" % (n, gene.label))
+                        continue
+                else:
+                    pos = np.asarray(reads[0], dtype=np.int64) + 1            # 0-based -> 1-based (:284)
+                    idx = batch.add_event(c_gene, pos.astype(np.int32), list(reads[1]), hyper)
+            except skippable as e:
+                skip(gene, e)
+                continue
             if ev_id is not None:
                 batch.set_event_id(idx, ev_id)          # the event's global number (see run_miso.py)
             slots.append((i, idx, gene, out))

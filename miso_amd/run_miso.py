@@ -110,6 +110,15 @@ def collect_gene_events(gene_entries, bamfile, output_dir, read_len, overhang_le
     return events, info
 
 
+def _check_device(device):
+    """A worker that was handed a device it cannot open (the dispatcher counted GPUs the process may not use) stops
+    here with a clear message and a non-zero exit status instead of failing batch by batch."""
+    from . import capi
+    n = capi.device_count()
+    if not 0 <= int(device) < n:
+        raise SystemExit("miso: --device %d, but this process can open %d HIP device(s)" % (int(device), n))
+
+
 def compute_gene_psi(gene_ids, gff_index_filename, bam_filename, output_dir, read_len,
                      overhang_len, paired_end=None, event_type=None, verbose=True, bamfile=None,
                      seed=None, first_event_id=0, device=None, gene_entries=None,
@@ -128,6 +137,7 @@ def compute_gene_psi(gene_ids, gff_index_filename, bam_filename, output_dir, rea
     burn_in, lag = settings_params["burn_in"], settings_params["lag"]
     num_iters, num_chains = settings_params["num_iters"], settings_params["num_chains"]
     if device is not None:
+        _check_device(device)
         os.environ["MISO_DEVICE"] = str(int(device))               # read by pysplicing per launch
     t0 = time.time()
     own = bamfile is None
@@ -213,6 +223,7 @@ def compare_gene_psi(gene_entries, bam1_filename, bam2_filename, output_dir1, ou
     for d in (output_dir1, output_dir2):
         os.makedirs(d, exist_ok=True)
     if device is not None:
+        _check_device(device)
         os.environ["MISO_DEVICE"] = str(int(device))
     p = Settings.get_sampler_params()
     bam1, bam2 = sam_utils.load_bam_reads(bam1_filename), sam_utils.load_bam_reads(bam2_filename)

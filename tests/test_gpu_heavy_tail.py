@@ -129,3 +129,34 @@ def test_mixed_read_counts_three_or_more_isoforms_bit_exact(orc, K, chains):
                 assert np.array_equal(gpu.loglik, r.loglik, equal_nan=True), where
                 assert (gpu.assignment == r.assignment).all(), where
                 assert gpu.rundata.noAccepted == r.accepted, where
+
+
+@pytest.mark.parametrize("sd,forced", [(30.0, True), (450.0, False)])
+def test_two_isoform_paired_end_through_the_general_kernel(orc, sd, forced):
+    """Fragment-length distributions too wide for the two-isoform kernel's LDS tables (sd beyond ~400; the
+    reference takes any sd, miso_paired.c:299-308) send K = 2 paired-end events to the general kernel instead of
+    failing the batch; MISO_K2_GENERAL=1 forces that route at sd = 30.  Bit-exact against the oracle either way."""
+    mean, var = 250.0 if sd < 100 else 1500.0, sd * sd
+    evs = []
+    for j, n in enumerate([300, 40, 900, 0, 150]):
+        exons, isoforms = se_gene(2, exlen=600 if sd < 100 else 4000, gap=300)
+        g = orc.gene(flat(exons), isoforms)
+        orc.rng_seed(6000 + j)
+        rc, _, pos, cig = orc.simulate_paired_reads(g, np.array([0.4, 0.6]), max(n, 1), 36, mean, var)
+        assert rc == 0
+        evs.append((exons, isoforms, g, pos[:2 * n], cig[:2 * n]))
+    kw = dict(iters=80, burn=20, lag=2, chains=2)
+    with _env(MISO_K2_GENERAL="1" if forced else None):
+        b = miso_amd.Batch(36, paired=True, mean=mean, var=var, device_match=True, **kw)
+        for exons, isoforms, g, pos, cig in evs:
+            b.add_event(miso_amd.Gene(exons, isoforms), pos, cig)
+        b.run(seed=21, first_event_id=40)
+    assert "sampler_k2" not in b.last_kernels(), b.last_kernels()
+    for i, (exons, isoforms, g, pos, cig) in enumerate(evs):
+        r = orc.miso_paired(g, pos, cig, 36, mean, var, mode=OrcLib.COUNTER, seed=21, event_id=40 + i, trace=True, **kw)
+        assert r.rc == 0
+        gpu = b.result(i)
+        assert (gpu.counts_hash == r.trace["counts_hash"]).all(), (sd, i)
+        assert np.array_equal(gpu.samples, r.samples, equal_nan=True), (sd, i)
+        assert np.array_equal(gpu.loglik, r.loglik, equal_nan=True), (sd, i)
+        assert (gpu.assignment == r.assignment).all(), (sd, i)

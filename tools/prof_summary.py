@@ -48,10 +48,12 @@ def main(prof_dir, out):
 
 
 def bench_key(bench):
+    """bench.py's workload_key: the kernel is not part of the key (the entry names its kernels)."""
     c = bench["config"]
-    return "%s|events=%d|K=%s|reads=%d|iters=%d|chains=%d|paired=%d" % (
-        bench["roofline"]["kernel"], c["events_per_gpu"], c["K"], c["reads"], c["iters"], c["chains"],
-        int("paired-end" in c["workload"]))
+    K = c["K"]
+    k = "%d-%d" % tuple(K) if isinstance(K, (list, tuple)) else str(K)
+    return "events=%d|K=%s|reads=%s|iters=%d|chains=%d|paired=%d" % (
+        c["events_per_gpu"], k, c["reads"], c["iters"], c["chains"], int("paired-end" in c["workload"]))
 
 
 def update_valu_model(prof_dir):
@@ -131,10 +133,7 @@ def update_traffic(prof_dir):
     fetch_kb, write_kb = avg(fdb, "FETCH_SIZE"), avg(wdb, "WRITE_SIZE")
     if fetch_kb is None or write_kb is None:
         return
-    c = bench["config"]
-    key = "%s|events=%d|K=%d|reads=%d|iters=%d|chains=%d|paired=%d" % (
-        bench["roofline"]["kernel"], c["events_per_gpu"], c["K"], c["reads"], c["iters"], c["chains"],
-        int("paired-end" in c["workload"]))
+    key = bench_key(bench)
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")
     try:
         table = json.load(open(path))
