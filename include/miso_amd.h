@@ -216,8 +216,21 @@ int miso_batch_get_trace(const miso_batch_t *batch, int event_index, uint64_t *c
    interval = order statistics int(round(alpha/2 n)) - 1 and int(round((1-alpha/2) n)) - 1 of the
    sorted samples, alpha = 1 - confidence_level.  mean / ci_low / ci_high: noiso doubles each. */
 int miso_batch_summarize(miso_batch_t *batch, double confidence_level);
+/* The same summaries of the samples AS THE `.miso` FILE HANDS THEM ON: summarize_miso never sees the sampler's
+   doubles, it parses the file's "%.4f" text (misopy/samples_utils.py:130-262).  Every sample is first rounded to
+   four decimals exactly as a correctly rounded "%.4f" prints it and read back as the nearest double; the credible
+   interval bounds are order statistics of those values, the mean their exact sum / n: what the reference computes
+   from the file this run writes, bit for bit for the bounds, to the last bit or two of a float sum for the mean. */
+int miso_batch_summarize_as_text(miso_batch_t *batch, double confidence_level);
 int miso_batch_get_summary(const miso_batch_t *batch, int event_index, double *mean, double *ci_low,
                            double *ci_high);
+
+/* Samples that were produced elsewhere -- parsed `.miso` files: summarize_miso and compare_miso work on directories of
+   them (misopy/samples_utils.py:263-329, hypothesis_test.py:186-345).  Event i has noiso[i] isoforms and n_samples
+   samples in the file's layout (samples[i]: n_samples rows of noiso[i] values).  The batch lives on `device` and
+   supports miso_batch_summarize[_as_text], miso_batch_compare and their getters only. */
+int miso_batch_from_samples(int n_events, const int *noiso, int n_samples, const double *const *samples, int device,
+                            miso_batch_t **batch);
 
 /* Two-sample comparison on the device (compare_miso, misopy/hypothesis_test.py:89-179, 348-380):
    `sample1` and `sample2` hold the SAME events in the same order (one batch per RNA-seq sample),

@@ -248,9 +248,12 @@ class Batch:
     def run(self, device=0, seed=0, first_event_id=0):
         check(lib().miso_batch_run(self.handle, int(device), int(seed), int(first_event_id)))
 
-    def summarize(self, confidence_level=0.95):
-        """Device-side posterior means and credible intervals of every event (no sample download)."""
-        check(lib().miso_batch_summarize(self.handle, C.c_double(confidence_level)))
+    def summarize(self, confidence_level=0.95, as_text=False):
+        """Device-side posterior means and credible intervals of every event (no sample download).  as_text: of the
+        samples as the `.miso` file hands them to summarize_miso, i.e. after "%.4f" (miso_batch_summarize_as_text)."""
+        f = lib().miso_batch_summarize_as_text if as_text else lib().miso_batch_summarize
+        f.argtypes = [C.c_void_p, C.c_double]
+        check(f(self.handle, C.c_double(confidence_level)))
 
     def summary(self, i):
         """(mean[K], ci_low[K], ci_high[K]) of event i after summarize()."""
@@ -407,6 +410,25 @@ class Batch:
         tr = np.zeros((M + 1, Cn, K), np.int32) if trace else None
         check(lib().miso_batch_get_trace(self.handle, i, _p(h), _p(tr)))
         return EventResult(samples[:S], ll[:S], ct[:ncls], cc[:ncls], ass[:N], rd, h, tr)
+
+
+class SamplesBatch(Batch):
+    """Posterior samples produced elsewhere (parsed `.miso` files) on the device: summarize(), summary(i),
+    compare(other), comparison(i) as on a sampled batch (miso_batch_from_samples)."""
+
+    def __init__(self, samples, device=0):
+        arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in samples]     # each [S, K]
+        n = len(arrs)
+        S = arrs[0].shape[0] if n else 1
+        if any(a.ndim != 2 or a.shape[0] != S for a in arrs):
+            raise ValueError("every event needs the same number of samples")
+        K = np.asarray([a.shape[1] for a in arrs], dtype=np.int32)
+        ptrs = (C.c_void_p * max(n, 1))(*[a.ctypes.data for a in arrs])
+        self.params = Params(0, 36, 1, 1, S, S, 0, 1, MISO_ALGO_REASSIGN, MISO_START_AUTO, MISO_STOP_FIXEDNO, 0.0, 0.0, 4.0, 0, 0)
+        self.handle = C.c_void_p()
+        L = lib()
+        L.miso_batch_from_samples.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        check(L.miso_batch_from_samples(n, _p(K), int(S), ptrs, int(device), C.byref(self.handle)))
 
 
 def simulate_reads(gene, expression, n_reads, read_len, sim_seed, mean=0.0, var=0.0, num_devs=4.0):

@@ -110,6 +110,7 @@ struct miso_batch {
   void launch(uint64_t seed, uint32_t first_event_id);
   void sync(float *ms);
   void download();
-  void summarize(double confidence_level);
+  void summarize(double confidence_level, bool as_text = false);
+  void adopt_samples(int n, const int *K, int S, const double *const *samples, int dev);
   void compare(miso_batch &other, double smoothing);
 };

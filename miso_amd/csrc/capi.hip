@@ -536,8 +536,27 @@ int miso_batch_get_trace(const miso_batch_t *b, int i, uint64_t *counts_hash, in
   });
 }
 
+int miso_batch_from_samples(int n_events, const int *noiso, int n_samples, const double *const *samples, int device,
+                            miso_batch_t **batch) {
+  return guarded([&] {
+    need(batch, "batch");
+    if (n_events > 0) { need(noiso, "noiso"); need(samples, "samples"); }
+    for (int i = 0; i < n_events; i++) need(samples[i], "samples[i]");
+    miso_params_t p{};
+    p.readLength = 36; p.overHang = 1; p.noChains = 1; p.noIterations = n_samples; p.maxIterations = n_samples;
+    p.noBurnIn = 0; p.noLag = 1; p.algorithm = MISO_ALGO_REASSIGN; p.start = MISO_START_AUTO; p.stop = MISO_STOP_FIXEDNO;
+    std::unique_ptr<miso_batch> b(batch_new(p));
+    b->adopt_samples(n_events, noiso, n_samples, samples, device);
+    *batch = b.release();
+  });
+}
+
 int miso_batch_summarize(miso_batch_t *b, double confidence_level) {
   return guarded([&] { need(b, "batch"); b->summarize(confidence_level); });
+}
+
+int miso_batch_summarize_as_text(miso_batch_t *b, double confidence_level) {
+  return guarded([&] { need(b, "batch"); b->summarize(confidence_level, true); });
 }
 
 int miso_batch_get_summary(const miso_batch_t *b, int i, double *mean, double *ci_low, double *ci_high) {

@@ -29,10 +29,38 @@ __device__ __forceinline__ double key_value(uint64_t k) {
 
 constexpr int SUMMARY_CACHE = 32;   // samples per thread held in registers (S <= 8192)
 
-template <bool CACHED>
+// TEXT: summarise what summarize_miso READS, not what the sampler computed: the reference's summaries come from the
+// `.miso` file (samples_utils.py:130-262 -> credible_intervals.py), where every sample is the text "%.4f" of psi.
+// k = psi x 10^4 rounded to the nearest integer, ties to even, decided on the EXACT product (fma gives the rounding
+// error of the multiplication), which is what a correctly rounded "%.4f" prints; the value read back is the double
+// nearest to k / 10^4 = the correctly rounded quotient.  The mean is then the exact integer sum of the k over
+// S x 10^4 (correctly rounded; numpy's pairwise float sum of the same values agrees to the last bit or two).
+__device__ __forceinline__ long long text_digits(double v) {
+  const double p = v * 10000.0;
+  const double e = __builtin_fma(v, 10000.0, -p);        // v x 10^4 = p + e exactly
+  double r = __builtin_rint(p);                          // nearest, ties to even
+  const double d = (p - r) + e;                          // exact: both terms are tiny and on a common grid
+  if (d > 0.5) r = r + 1.0; else if (d < -0.5) r = r - 1.0;
+  else if (d == 0.5 && (static_cast<long long>(r) & 1)) r = r + 1.0;     // a tie decided against an odd r
+  else if (d == -0.5 && (static_cast<long long>(r) & 1)) r = r - 1.0;
+  return static_cast<long long>(r);
+}
+
+template <bool CACHED, bool TEXT>
 __device__ __forceinline__ void summarize_column(const double *x, int K, int S, int rank_lo, int rank_hi,
                                                  double *o) {
   __shared__ double part[256];
+  __shared__ long long ipart[256];
+  __shared__ int s_nonfinite;
+  if (TEXT) { if (threadIdx.x == 0) s_nonfinite = 0; __syncthreads(); }
+  long long iacc = 0;
+  auto as_read = [&](double v) {   // TEXT: the sample as the `.miso` file hands it on
+    if (!TEXT) return v;
+    if (!(v == v) || v - v != 0.0) { s_nonfinite = 1; return v; }     // "nan" / "inf" stay what they are
+    const long long k = text_digits(v);
+    iacc += k;
+    return static_cast<double>(k) / 10000.0;
+  };
   __shared__ unsigned hist2[2][256];
   __shared__ unsigned wave_tot2[2][4];
   __shared__ uint64_t s_prefix2[2];
@@ -47,7 +75,7 @@ __device__ __forceinline__ void summarize_column(const double *x, int K, int S, 
     for (int j = 0; j < SUMMARY_CACHE; j++) {
       const int s = t + 256 * j;
       if (s < S) {
-        const double v = x[static_cast<size_t>(s) * K];
+        const double v = as_read(x[static_cast<size_t>(s) * K]);
         acc = acc + v;
         keys[j] = order_key(v);
       } else {
@@ -55,15 +83,18 @@ __device__ __forceinline__ void summarize_column(const double *x, int K, int S, 
       }
     }
   } else {
-    for (int s = t; s < S; s += 256) acc = acc + x[static_cast<size_t>(s) * K];
+    for (int s = t; s < S; s += 256) acc = acc + as_read(x[static_cast<size_t>(s) * K]);
   }
   part[t] = acc;
+  if (TEXT) ipart[t] = iacc;
   __syncthreads();
   for (int stride = 128; stride >= 1; stride >>= 1) {
-    if (t < stride) part[t] = part[t] + part[t + stride];
+    if (t < stride) { part[t] = part[t] + part[t + stride]; if (TEXT) ipart[t] = ipart[t] + ipart[t + stride]; }
     __syncthreads();
   }
-  const double mean = part[0] / static_cast<double>(S);
+  const double mean = !TEXT ? part[0] / static_cast<double>(S)
+                            : (s_nonfinite ? part[0] / static_cast<double>(S)
+                                           : static_cast<double>(ipart[0]) / (static_cast<double>(S) * 10000.0));
 
   // both order statistics in the same eight passes: two prefixes, two histograms (the keys are
   // tested against both; while the two ranks still share a prefix the two histograms are equal)
@@ -112,7 +143,8 @@ __device__ __forceinline__ void summarize_column(const double *x, int K, int S, 
       }
     } else {
       for (int s = t; s < S; s += 256) {
-        const uint64_t key = order_key(x[static_cast<size_t>(s) * K]);
+        const double vq = x[static_cast<size_t>(s) * K];
+        const uint64_t key = order_key((TEXT && vq == vq && vq - vq == 0.0) ? static_cast<double>(text_digits(vq)) / 10000.0 : vq);
         const uint64_t km = key & mask;
         const unsigned bin = static_cast<unsigned>(key >> (8 * byte)) & 0xFFu;
         if (km == p0) atomicAdd(&hist2[0][bin], 1u);
@@ -177,15 +209,18 @@ __device__ __forceinline__ void summarize_column(const double *x, int K, int S, 
 
 __global__ __launch_bounds__(256) void summarize_kernel(const DevEvent *events, const unsigned char *out_pool,
                                                         int n_events, int S, int rank_lo, int rank_hi,
-                                                        const uint64_t *sum_off, double *summary) {
+                                                        const uint64_t *sum_off, double *summary, int as_text) {
   const int ev = blockIdx.x, k = blockIdx.y;
   if (ev >= n_events) return;
   const DevEvent E = events[ev];
   if (k >= E.K) return;
   const double *x = reinterpret_cast<const double *>(out_pool + E.off_samples) + k;
   double *o = summary + sum_off[ev] + 3 * k;
-  if (S <= 256 * SUMMARY_CACHE) summarize_column<true>(x, E.K, S, rank_lo, rank_hi, o);
-  else summarize_column<false>(x, E.K, S, rank_lo, rank_hi, o);
+  if (as_text) {
+    if (S <= 256 * SUMMARY_CACHE) summarize_column<true, true>(x, E.K, S, rank_lo, rank_hi, o);
+    else summarize_column<false, true>(x, E.K, S, rank_lo, rank_hi, o);
+  } else if (S <= 256 * SUMMARY_CACHE) summarize_column<true, false>(x, E.K, S, rank_lo, rank_hi, o);
+  else summarize_column<false, false>(x, E.K, S, rank_lo, rank_hi, o);
 }
 
 

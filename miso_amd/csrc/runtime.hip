@@ -27,7 +27,7 @@ __global__ void compare_kernel(const DevEvent *, const unsigned char *, const De
                                double, const uint64_t *, double *);
 __global__ void match_kernel(const MatchEvent *, const int2 *, const int *, const int *, const int *, const int *,
                              const int *, const int *, const int *, int, int, int, int, int, uint32_t *, uint16_t *);
-__global__ void summarize_kernel(const DevEvent *, const unsigned char *, int, int, int, int, const uint64_t *, double *);
+__global__ void summarize_kernel(const DevEvent *, const unsigned char *, int, int, int, int, const uint64_t *, double *, int);
 template <int G, bool PE, int KC> __global__ void sampler_grp(const KernelArgs a);
 template <int KC> __global__ void sampler_flat(const KernelArgs a);
 __global__ void selftest_detmath_kernel(const double *, int, double *, double *, double *, double *);
@@ -1133,7 +1133,7 @@ void miso_batch::sync(float *ms) {
 // Posterior mean and Chen-Shao credible interval of every isoform, computed where the samples are
 // (credible_intervals.py:31-55: order statistics int(round(alpha/2 n)) - 1 and
 // int(round((1 - alpha/2) n)) - 1, Python-2 rounding = half away from zero).
-void miso_batch::summarize(double confidence_level) {
+void miso_batch::summarize(double confidence_level, bool as_text) {
   if (!launched) MISO_FAIL(MISO_EINVAL, "batch not launched");
   HIP_OK(hipSetDevice(device));
   const int n = static_cast<int>(events.size()), Sn = S();
@@ -1152,7 +1152,7 @@ void miso_batch::summarize(double confidence_level) {
   HIP_OK(hipMalloc(reinterpret_cast<void **>(&d_sum), off * sizeof(double)));
   HIP_OK(hipMemcpyAsync(d_off, h_sum_off.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
   hipLaunchKernelGGL(summarize_kernel, dim3(n, kmax), dim3(256), 0, stream, d_events, d_out, n, Sn, lo, hi,
-                     d_off, d_sum);
+                     d_off, d_sum, as_text ? 1 : 0);
   HIP_OK(hipGetLastError());
   HIP_OK(hipMemcpyAsync(h_summary.data(), d_sum, off * sizeof(double), hipMemcpyDeviceToHost, stream));
   HIP_OK(hipStreamSynchronize(stream));
@@ -1191,6 +1191,41 @@ void miso_batch::compare(miso_batch &other, double smoothing) {
   HIP_OK(hipStreamSynchronize(stream));
   (void) hipFree(d_off); (void) hipFree(d_cmp);
   compared = true;
+}
+
+// A batch that holds posterior samples produced elsewhere -- parsed `.miso` files (summarize_miso / compare_miso
+// work on directories of them, misopy/samples_utils.py:263-329, hypothesis_test.py:186-345): event i has K[i] isoforms
+// and S samples in the file's layout (rows of K values).  Only the output pool exists; summarize / compare and their
+// getters work on it as on a sampled batch.
+void miso_batch::adopt_samples(int n, const int *K, int Sn, const double *const *samples, int dev) {
+  if (uploaded) release();
+  if (device_count() <= 0) MISO_FAIL(MISO_ENODEVICE, "no HIP device: the summaries have no CPU path");
+  if (n < 0 || Sn < 1) MISO_FAIL(MISO_EINVAL, "Invalid number of events or samples");
+  device = dev;
+  HIP_OK(hipSetDevice(dev));
+  events.assign(n, PackedEvent{});
+  h_events.assign(n, DevEvent{});
+  uint64_t off = 0;
+  for (int i = 0; i < n; i++) {
+    if (K[i] < 1 || K[i] > MISO_MAX_ISOFORMS) MISO_FAIL(MISO_EINVAL, "Invalid number of isoforms");
+    events[i].K = K[i];
+    DevEvent &d = h_events[i];
+    d.K = K[i];
+    d.off_samples = off; off = align_up(off + static_cast<uint64_t>(Sn) * K[i] * 8, 16);
+    d.off_trace = NO_TRACE; d.off_dense = d.off_sfixd = NO_DENSE;
+  }
+  out_bytes = std::max<uint64_t>(off, 16);
+  HIP_OK(hipStreamCreate(&stream));
+  HIP_OK(hipEventCreate(&ev0));
+  HIP_OK(hipEventCreate(&ev1));
+  HIP_OK(hipMalloc(reinterpret_cast<void **>(&d_events), std::max<size_t>(n, 1) * sizeof(DevEvent)));
+  HIP_OK(hipMalloc(reinterpret_cast<void **>(&d_out), out_bytes));
+  if (n) HIP_OK(hipMemcpy(d_events, h_events.data(), n * sizeof(DevEvent), hipMemcpyHostToDevice));
+  std::vector<unsigned char> h(out_bytes, 0);
+  for (int i = 0; i < n; i++) std::memcpy(h.data() + h_events[i].off_samples, samples[i], static_cast<size_t>(Sn) * K[i] * 8);
+  HIP_OK(hipMemcpy(d_out, h.data(), out_bytes, hipMemcpyHostToDevice));
+  n_k2 = n_k2w = n_gen = 0; gen_runs.clear();
+  uploaded = launched = true; downloaded = false; summarized = compared = false;
 }
 
 void miso_batch::download() {

@@ -311,7 +311,7 @@ class MISOSampler:
         batch.run(device=dev, seed=seed if seed is not None else random.getrandbits(64),
                   first_event_id=first_event_id)
         if summary_file is not None:
-            batch.summarize(confidence_level)
+            batch.summarize(confidence_level, as_text=True)     # summarize_miso summarises the file's text
         idxs, paths, headers, rows = [], [], [], []
         for i, idx, gene, out in slots:
             templates, counts, assignments, rd = batch.result_lite(idx)

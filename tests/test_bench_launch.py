@@ -54,3 +54,31 @@ def test_cost_balanced_shards():
     # mixed isoform counts weigh in: K = 20 genes cost more than K = 3 genes
     c = workload.event_costs(0, 1000, (3, 20), 1000, 7500, 1)
     assert c.min() == 3 * 7500 * 1000 and c.max() == 20 * 7500 * 1000
+
+
+def test_eight_ranks_heavy_tailed_events_balanced_by_cost():
+    """`--gpus 8` on real-looking read counts (workload.HG19_LIKE: 20 ... 10^5 reads per event): eight gloo ranks,
+    contiguous shards, every shard's cost within one event of an eighth of the total (the reference's count split
+    -- cluster_utils.py:23-32 -- would leave the worker that drew the 10^5-read events far behind), every rank's
+    native thread pools confined to its share of the host cores."""
+    sys.path.insert(0, ROOT)
+    from miso_amd import workload
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    per = 700
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--stub", "--events", str(per),
+           "--reads-dist", "hg19", "--iters", "20", "--burn", "5", "--steps", "1", "--warmup", "0"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout + out.stderr
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 8 and d["stub"] is True and d["config"]["reads"] == "hg19"
+    shards = d["config"]["shards"]
+    assert [s[0] for s in shards] == list(range(8)) and shards[0][1] == 0 and shards[-1][2] == 8 * per
+    assert all(shards[r][2] == shards[r + 1][1] for r in range(7))
+    costs = workload.event_costs(0, 8 * per, 2, workload.HG19_LIKE, 20, 1)
+    share = np.array(d["config"]["shard_cost_share"])
+    assert abs(share.sum() - 1.0) < 1e-3
+    assert share.max() <= 1.0 / 8 + costs.max() / costs.sum() + 1e-6
+    counts = np.array([s[2] - s[1] for s in shards])
+    assert counts.max() > 1.15 * counts.min()          # equal cost is NOT equal count on such events

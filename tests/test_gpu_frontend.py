@@ -2,6 +2,7 @@
 misopy/test_miso.py:131-171 test_z_gene_psi: Atp2b1 GFF + c2c12 SAM), through the CLI, one child
 process per GPU -- and the result against (a) the REAL reference's run stored in the golden fixture
 (posterior mean within Monte-Carlo error) and (b) the oracle's counter mode (every printed digit)."""
+import glob
 import gzip
 import os
 import subprocess
@@ -211,6 +212,62 @@ def test_cli_summarize_and_compare(tmp_path):
     assert abs((m1 - m2) - diff) < 0.011 and bfv >= 0
     s1 = miso_sampler.load_samples(os.path.join(out2, "ctl", "10", "ENSMUSG00000019943.miso"))[0]
     assert abs(m1 - s1[:, 0].mean()) < 0.006
+
+
+def test_summarize_and_compare_existing_miso_directories(tmp_path):
+    """summarize_miso --summarize-samples / compare_miso --compare-samples on directories of `.miso` files
+    (misopy/samples_utils.py:263-329, hypothesis_test.py:186-345): the table written from the files equals, line
+    for line, the table the live run wrote (which summarises the same text, miso_batch_summarize_as_text); the
+    comparison's means / bounds equal the numpy restatement on the parsed files, its Bayes factors the
+    scipy-pinned checker within the float tolerance of tests/test_gpu_compare.py."""
+    import miso_sampler
+    from _compare_ref import bayes_factor
+    from _summary_ref import credible_interval
+    from miso_amd import samples_utils
+    from miso_sampler import SimpleGene
+    rng = np.random.default_rng(5)
+    dirs = []
+    for label, shift in (("ctl", 0.0), ("kd", 0.25)):
+        out = tmp_path / label
+        params = miso_sampler.get_single_end_sampler_params(2, 36, 1)
+        sampler = miso_sampler.MISOSampler(params, paired_end=False)
+        events = []
+        for e in range(70):                       # > 64 files: the parallel parser
+            K = 2 + (e % 3)
+            exons = [(1 + 200 * i, 100 + 200 * i) for i in range(K + 1)]
+            isoforms = [list(range(K + 1))] + [[x for x in range(K + 1) if x != k] for k in range(1, K)]
+            gene = SimpleGene(exons, isoforms, label="ev%03d" % e, chrom="chr%d" % (e % 3))
+            n = 60 + 7 * e
+            pos = rng.integers(1, 200 * K + 60, size=n)
+            if shift:
+                pos = np.where(rng.random(n) < shift, rng.integers(1, 60, size=n), pos)
+            events.append(((list(int(x) for x in pos), ["36M"] * n), gene, str(out / gene.chrom / gene.label)))
+        sampler.run_sampler_batch(600, events, num_chains=2, burn_in=100, lag=2, seed=9, first_event_id=0,
+                                  summary_file=str(tmp_path / (label + ".live_summary")))
+        dirs.append(str(out))
+    for label, d in zip(("ctl", "kd"), dirs):
+        table = str(tmp_path / "sum" / "summary" / (label + ".miso_summary"))
+        assert samples_utils.main(["--summarize-samples", d, str(tmp_path / "sum")]) == 0
+        live = sorted(open(str(tmp_path / (label + ".live_summary"))).read().splitlines()[1:])
+        walked = sorted(open(table).read().splitlines()[1:])
+        assert walked == live and len(walked) > 30
+    assert samples_utils.main(["--compare-samples", dirs[0], dirs[1], str(tmp_path / "cmp")]) == 0
+    rows = [l.split("\t") for l in open(str(tmp_path / "cmp" / "ctl_vs_kd" / "bayes-factors" / "ctl_vs_kd.miso_bf")).read().splitlines()]
+    assert rows[0][0] == "event_name" and rows[0][8] == "bayes_factor" and len(rows) > 30
+    checked = 0
+    for r in rows[1:]:
+        s1 = samples_utils.parse_miso_file(glob.glob(os.path.join(dirs[0], "*", r[0] + ".miso"))[0])[1]
+        s2 = samples_utils.parse_miso_file(glob.glob(os.path.join(dirs[1], "*", r[0] + ".miso"))[0])[1]
+        K = s1.shape[1]
+        lo1 = [credible_interval(s1[:, k])[0] for k in range(K)]
+        assert r[2] == (",".join("%.2f" % v for v in lo1) if K > 2 else "%.2f" % lo1[0])
+        bfs = [bayes_factor(s1[:, k], s2[:, k], 0.3)[0] for k in range(K)]
+        want = ",".join("%.2f" % max(v, 0) for v in bfs) if K > 2 else "%.2f" % bfs[0]
+        got = [float(x) for x in r[8].split(",")]
+        for g, w in zip(got, [float(x) for x in want.split(",")]):
+            assert abs(g - w) <= 0.011 + 1e-6 * abs(w), (r[0], r[8], want)
+        checked += 1
+    assert checked > 30
 
 
 def test_results_do_not_depend_on_the_number_of_worker_processes(tmp_path):

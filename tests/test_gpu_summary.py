@@ -150,3 +150,30 @@ def test_summary_more_samples_than_the_register_cache():
         m, lo, hi = b.summary(i)
         em, elo, ehi = summarize(_cols(r), 0.95)
         assert np.array_equal(lo, elo) and np.array_equal(hi, ehi) and np.array_equal(m, em)
+
+
+@pytest.mark.parametrize("K,paired,S_big", [(2, False, False), (5, False, False), (3, True, False), (2, False, True)])
+def test_summary_of_the_file_text_equals_what_summarize_miso_reads(K, paired, S_big):
+    """miso_batch_summarize_as_text: the reference summarises the `.miso` FILE (samples_utils.py:130-262 ->
+    credible_intervals.py:4-72), i.e. every sample after "%.4f" and float().  The device rounds each sample to four
+    decimals exactly as Python's % does and reads it back as float() would: the interval bounds equal the numpy
+    restatement of credible_intervals.py on the parsed text bit for bit, the mean is the exact sum of the printed
+    digits over n (numpy's float mean of the parsed values agrees to 1e-15)."""
+    probs = [(pe_problem if paired else se_problem)(K=K, n_reads=120 + 61 * i, seed=300 + i) for i in range(4)]
+    kw = dict(iters=9000, burn=500, lag=1, chains=1) if S_big else dict(iters=1500, burn=300, lag=2, chains=3)
+    b = _batch(probs, paired=paired, **kw)
+    b.summarize(0.95, as_text=True)
+    for i in range(len(probs)):
+        r = b.result(i)
+        text = np.array([[float("%.4f" % v) for v in row] for row in r.samples])      # what the file hands on
+        digits = np.array([[int(round(float("%.4f" % v) * 10000)) for v in row] for row in r.samples])
+        m, lo, hi = b.summary(i)
+        for k in range(K):
+            elo, ehi = credible_interval(text[:, k], 0.95)
+            assert lo[k] == elo and hi[k] == ehi, (i, k)
+            assert m[k] == digits[:, k].sum() / (len(text) * 10000.0), (i, k)
+            assert abs(m[k] - text[:, k].mean()) < 1e-15
+    # the full-precision summary is a different thing (otherwise this test would show nothing)
+    text_lo = [b.summary(i)[1].copy() for i in range(len(probs))]
+    b.summarize(0.95)
+    assert any(not np.array_equal(b.summary(i)[1], text_lo[i]) for i in range(len(probs)))
