@@ -197,10 +197,17 @@ def test_legacy_test_pysplicing_script_shape():
     assert np.all(np.abs(psi - np.array([0.2, 0.3, 0.5])) < 0.06)
 
 
-def test_batch_path_raises_the_module_exception(tmp_path):
-    """A bad CIGAR in run_sampler_batch surfaces as pysplicing.InternalError, like run_sampler's."""
+def test_batch_path_skips_a_bad_gene_and_the_single_event_path_raises(tmp_path, capsys):
+    """A bad CIGAR: the one-event call raises pysplicing.InternalError as the reference's does (pyerror.c:27-44); inside
+    a batch the gene is reported and skipped -- the reference's worker runs each gene in its own try block
+    (run_miso.py:205-256) -- and nothing is written for it."""
     gene = miso_sampler.SimpleGene([(1, 100), (201, 300), (401, 500)], [[0, 1, 2], [0, 2]])
     s = miso_sampler.MISOSampler(miso_sampler.get_single_end_sampler_params(2, 36))
+    written = s.run_sampler_batch(100, [(((10, 20), ("36M", "3Q")), gene, str(tmp_path / "x"))],
+                                  num_chains=1, burn_in=10, lag=1, seed=1)
+    assert written == [None] and not os.path.exists(str(tmp_path / "x.miso"))
+    assert len(s.skipped_genes) == 1 and "CIGAR" in s.skipped_genes[0][1]
+    assert "Skipping gene" in capsys.readouterr().out
+    cg = pysplicing.createGene(((1, 100), (201, 300), (401, 500)), ((0, 1, 2), (0, 2)))
     with pytest.raises(pysplicing.InternalError, match="CIGAR"):
-        s.run_sampler_batch(100, [(((10, 20), ("36M", "3Q")), gene, str(tmp_path / "x"))],
-                            num_chains=1, burn_in=10, lag=1, seed=1)
+        pysplicing.MISO(cg, 0, (11, 21), ("36M", "3Q"), 36, 100, 10, 1, (1.0, 1.0), 1, 1)
