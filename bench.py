@@ -328,7 +328,8 @@ def roofline_for(batch, kernel_ms, key, sh):
     chains = sum(k["chains"] for k in stats["kernels"])
     draws = sum(k["words"] for k in stats["kernels"]) / max(chains, 1.0)
     profiled = None if m is None else sorted(re.search(r"miso::(sampler_[^(]+)\(", k).group(1) for k in m["kernels"])
-    if m is not None and profiled == sorted(name.split(",")):
+    launched = sorted(re.findall(r"sampler_\w+<[^>]*>", name))
+    if m is not None and profiled == launched:
         cyc = m["valu_per_chain_iteration"] * chain_iters * m["issue_cycles_per_valu"]
         out["achieved"] = round(cyc / t / 1e9, 1)
         out["frac"] = round(cyc / t / 1e9 / VALU_PEAK_GCYC, 4)

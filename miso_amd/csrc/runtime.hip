@@ -760,7 +760,12 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       // 28.9k, K=3 53k -> 46k) and whenever 16 would leave the kernel's share of the device unfilled.
       bool found = false;
       // (a whole-gene mix -- several classes side by side -- runs 9 % faster with 32 everywhere: 14.4k -> 15.7k genes/s)
-      const bool pe32 = p.paired && (run.kc >= 12 || n_kernels > 1 || (chains + 3) / 4 < slots_for(chains));
+      // (round 3, 20 000 events of one isoform count: 16 lanes beat 32 from nine isoforms on as well once the launch
+      // is more than a round and a half of wavefronts -- K = 9 21.3k -> 26.8k, K = 10 20.8k -> 26.9k, K = 12 19.1k ->
+      // 22.5k, K = 16 14.4k -> 16.6k, K = 20 10.7k -> 10.9k events/s; the mix keeps 32: 16.8k vs 14.2k genes/s;
+      // profiles/r03_pe_lanes_sweep.txt)
+      const bool pe32 = p.paired && (n_kernels > 1 || (run.kc >= 12 && 2 * ((chains + 3) / 4) < 3 * static_cast<long>(slots_for(chains))) ||
+                                     (chains + 3) / 4 < slots_for(chains));
       for (int g : {2, 4, 8, 16, 32}) {
         if (p.paired && g > 16 && found && !pe32) break;
         if (!grp_fits(run, sh, g)) continue;
