@@ -123,6 +123,7 @@ MATRIX = [  # (id, label, shape overrides, events, reference runs of the row: (e
      dict(reads="hg19", chains=6, iters=5000, burn=500, lag=10), 40000, None),
     ("pe_k2_hg19", "PE K=2, hg19-like read counts, 1 chain, 7500 iters", dict(paired=True, reads="hg19"), 40000, (64, 8)),
     ("se_k5_hg19", "SE K=5, hg19-like read counts, 1 chain, 7500 iters", dict(K=5, reads="hg19"), 40000, (64, 8)),
+    ("pe_k5_hg19", "PE K=5, hg19-like read counts, 1 chain, 7500 iters", dict(K=5, paired=True, reads="hg19"), 40000, (64, 8)),
     ("se_k5", "SE K=5, 1 chain, 7500 iters", dict(K=5), 40000, (64, 8)),
     ("se_k10", "SE K=10, 1 chain, 7500 iters", dict(K=10), 40000, (64, 8)),
     ("se_k2_defaults", "SE K=2, MISO defaults (6 chains, 5000 iters, 500 burn-in, lag 10)",

@@ -357,8 +357,8 @@ class Batch:
         return m, fl
 
     def last_kernels(self):
-        buf = C.create_string_buffer(256)
-        check(lib().miso_batch_last_kernels(self.handle, buf, 256))
+        buf = C.create_string_buffer(2048)
+        check(lib().miso_batch_last_kernels(self.handle, buf, 2048))
         return buf.value.decode()
 
     def launch_stats(self):

@@ -55,6 +55,8 @@ struct miso_batch {
     int maxcls = 0;               // most drawing-read classes (single-end)
     bool nocls = false;           // some single-end event has no class table (> MAX_DRAW_CLASSES classes)
     bool dense = true;            // paired-end: every event has dense quad records (pe_dense)
+    int force_G = 0;              // paired-end size bucket: at least this many lanes per chain (events several times the class's mean size)
+    bool wide = false;            // paired-end size bucket: one chain per workgroup (sampler_grp<64, true, KC, true>)
     int tuned_G = 0;              // lanes per chain picked by the first launch's trial runs
     int tuned_flat = -1;          // sampler_flat (1) or sampler_grp (0) by the first launch's trial runs, -1 = not tried
     // sampler_flat: which chains every wavefront owns (runtime.hip flat_waves; two words per wavefront)

@@ -742,7 +742,14 @@ __device__ __forceinline__ void pe_dense(const uint32_t *fq, const double *psi, 
 
 }  // namespace
 
-template <int G, bool PE, int KC>
+// WIDE (paired-end dense records, G = 64): ONE chain per workgroup -- genes with tens of thousands of read pairs, whose
+// read loop on 16 or 32 lanes would outlast the rest of the batch (the reference costs O(reads) per gene and genes
+// share nothing, miso_paired.c:393-552).  The four wavefronts keep the chain's state in their own slices and run the
+// scalar step redundantly (same inputs, same routines, same bits); pe_dense deals the chain's quads over all 256
+// lanes; the per-wavefront "passed over k" totals, score sums and bad flags meet through LDS (a.red_off: scratch
+// behind the slices), two barriers per Gibbs step; wavefront 0 writes the outputs, every wavefront its share of the
+// final picks.
+template <int G, bool PE, int KC, bool WIDE = false>
 #ifndef MISO_GRP_MINBLOCKS
 #define MISO_GRP_MINBLOCKS 3   // measured: K=3 89.7k -> 114.4k events/s going from 2 to 3 (register budget 168)
 #endif
@@ -755,6 +762,8 @@ template <int G, bool PE, int KC>
 __global__ __launch_bounds__(256, PE ? MISO_GRP_PE_BLOCKS : (KC <= 8 ? MISO_GRP_MINBLOCKS : 2)) void sampler_grp(const KernelArgs a) {
   constexpr int KLO = KC == 4 ? 3 : (KC == 8 ? 5 : (KC == 12 ? 9 : (KC == 16 ? 13 : 17)));   // the class holds K in [KLO, KC]
   constexpr int MH_CH = PE ? (KC <= 8 ? KC : 4) : 1;   // chunk width of the Metropolis-Hastings step's serial chains (seq_sum_u)
+  static_assert(!WIDE || (PE && G == 64), "workgroup-wide chains: paired-end, whole wavefronts");
+  constexpr int GS = WIDE ? 256 : G;       // lanes striding over one chain's quads
   constexpr bool MH_ONE = PE && KC <= 4;   // a single pass without the loop around it (K=3 57.2k -> 60.6k; at five to eight isoforms the loop form is faster: 39.5k against 35.9k at K=5)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int CPW = 64 / G;
@@ -775,11 +784,13 @@ __global__ __launch_bounds__(256, PE ? MISO_GRP_PE_BLOCKS : (KC <= 8 ? MISO_GRP_
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int grp = lane / G, sub = lane - grp * G;
   const long n_chains = static_cast<long>(a.n_slots) * a.C;
-  const long wave_id = static_cast<long>(blockIdx.x) * 4 + wave;
-  if (wave_id * CPW >= n_chains) return;  // no block-level barrier below
+  const long wave_id = WIDE ? static_cast<long>(blockIdx.x) : static_cast<long>(blockIdx.x) * 4 + wave;
+  if (wave_id * CPW >= n_chains) return;  // no block-level barrier below (WIDE: the whole workgroup leaves)
   long slot = wave_id * CPW + grp;
-  const bool live = slot < n_chains;
-  if (!live) slot = n_chains - 1;           // shadow a real chain, store nothing
+  const bool live_all = slot < n_chains;
+  const bool live = live_all && (!WIDE || wave == 0);   // who stores the chain's outputs
+  if (!live_all) slot = n_chains - 1;       // shadow a real chain, store nothing
+  const int sub_r = WIDE ? static_cast<int>(threadIdx.x) : sub;   // this lane's place among the chain's GS lanes
   const int ks = a.kstride, cs = a.cstride;
   Slice S = carve(smem + fp_bytes + (static_cast<size_t>(wave) * CPW + grp) * grp_slice_bytes(ks, cs, a.tstride),
                   ks, cs);
@@ -868,6 +879,7 @@ __global__ __launch_bounds__(256, PE ? MISO_GRP_PE_BLOCKS : (KC <= 8 ? MISO_GRP_
   // operation -- instead of dragging the whole wavefront to the generic path (those few wavefronts
   // used to take 3x as long as everything else in a mixed batch and set the kernel's duration).
   const bool pe_fast = PE && __all(K >= KLO && K <= (KC == 32 ? 20 : KC));
+  if (WIDE && !(pe_fast && dense)) __builtin_trap();   // the host sends only genes with dense records here (runtime.hip)
 
 #ifdef MISO_K2_PROFILE
   uint64_t gp_thr = 0, gp_loop = 0, gp_mh = 0;
@@ -1002,9 +1014,9 @@ __global__ __launch_bounds__(256, PE ? MISO_GRP_PE_BLOCKS : (KC <= 8 ? MISO_GRP_
       wave_sync();
 #define MISO_PED2(KK, LDS)                                                                            \
   {                                                                                                   \
-    if (__any(write_ass)) pe_dense<KK, G, true, true, LDS>(dq, S.psi, lds_fp, stab_lds, sfixd_glob, il2, S.dl, drawass, write_ass, nqw, n_quads, n_draw, sub, rng, n0r0, a.pe_force_exact != 0, acc, bad); \
-    else if (dense_nobad) pe_dense<KK, G, false, false, LDS>(dq, S.psi, lds_fp, stab_lds, sfixd_glob, il2, S.dl, drawass, write_ass, nqw, n_quads, n_draw, sub, rng, n0r0, a.pe_force_exact != 0, acc, bad); \
-    else pe_dense<KK, G, false, true, LDS>(dq, S.psi, lds_fp, stab_lds, sfixd_glob, il2, S.dl, drawass, write_ass, nqw, n_quads, n_draw, sub, rng, n0r0, a.pe_force_exact != 0, acc, bad); \
+    if (__any(write_ass)) pe_dense<KK, GS, true, true, LDS>(dq, S.psi, lds_fp, stab_lds, sfixd_glob, il2, S.dl, drawass, write_ass, nqw, n_quads, n_draw, sub_r, rng, n0r0, a.pe_force_exact != 0, acc, bad); \
+    else if (dense_nobad) pe_dense<KK, GS, false, false, LDS>(dq, S.psi, lds_fp, stab_lds, sfixd_glob, il2, S.dl, drawass, write_ass, nqw, n_quads, n_draw, sub_r, rng, n0r0, a.pe_force_exact != 0, acc, bad); \
+    else pe_dense<KK, GS, false, true, LDS>(dq, S.psi, lds_fp, stab_lds, sfixd_glob, il2, S.dl, drawass, write_ass, nqw, n_quads, n_draw, sub_r, rng, n0r0, a.pe_force_exact != 0, acc, bad); \
   }
 #define MISO_PED(KK) { if (a.tstride > 0) MISO_PED2(KK, true) else MISO_PED2(KK, false) }
       if constexpr (KC == 4) { if (K == 3) MISO_PED(3) else MISO_PED(4) }
@@ -1015,14 +1027,31 @@ __global__ __launch_bounds__(256, PE ? MISO_GRP_PE_BLOCKS : (KC <= 8 ? MISO_GRP_
 #undef MISO_PED2
 #undef MISO_PED
       wave_sync();
+#pragma unroll
+      for (int off = G >> 1; off >= 1; off >>= 1) { acc += __shfl_xor(acc, off); bad |= __shfl_xor(bad, off); }
+      if constexpr (WIDE) {   // the four wavefronts' totals -> every wavefront's own slice / registers
+        struct Red { int64_t acc; int bad, pad; };
+        Red *red = reinterpret_cast<Red *>(smem + a.red_off);
+        if (lane == 0) red[wave] = Red{acc, bad, 0};
+        __syncthreads();
+        int tot = 0; int64_t ta = 0; int tb = 0;
+        const size_t slice_bytes = grp_slice_bytes(ks, cs, a.tstride);
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+          if (lane < K - 1) tot += carve(smem + fp_bytes + w * slice_bytes, ks, cs).dl[lane];
+          ta += red[w].acc; tb |= red[w].bad;
+        }
+        __syncthreads();
+        if (lane < K - 1) S.dl[lane] = tot;
+        acc = ta; bad = tb;
+        wave_sync();
+      }
       // reads that passed over k - 1 but not k picked k
       for (int k0 = 0; k0 < Kw; k0 += G) {
         const int k = k0 + sub;
         if (k < K) S.cnt[k] = (k > 0 ? S.dl[k - 1] : n_draw) - (k < K - 1 ? S.dl[k] : 0);
       }
       wave_sync();
-#pragma unroll
-      for (int off = G >> 1; off >= 1; off >>= 1) { acc += __shfl_xor(acc, off); bad |= __shfl_xor(bad, off); }
       rfix = E.base_sfix + acc;
       rbad = bad | E.base_bad;
       GPROF_T(t2);
@@ -1225,7 +1254,7 @@ __global__ __launch_bounds__(256, PE ? MISO_GRP_PE_BLOCKS : (KC <= 8 ? MISO_GRP_
     lse = miso_det_log(seq_sum_u<MH_CH, MH_ONE>(S.tc, K, Kw)) + maxv;
     wave_sync();
   }
-  gibbs(MISO_ITER_INIT, live && chain == 0 && a.M == 0);
+  gibbs(MISO_ITER_INIT, live_all && chain == 0 && a.M == 0);
 
   uint64_t hash = 0xCBF29CE484222325ull;
   int accepted = 0, lagCounter = 0, noS = 0;
@@ -1317,7 +1346,7 @@ __global__ __launch_bounds__(256, PE ? MISO_GRP_PE_BLOCKS : (KC <= 8 ? MISO_GRP_
         lagCounter++;
       }
     }
-    gibbs(static_cast<uint32_t>(m), live && chain == 0 && m == a.M - 1);
+    gibbs(static_cast<uint32_t>(m), live_all && chain == 0 && m == a.M - 1);
   }
   for (int k = 0; k < K; k++) hash = (hash ^ static_cast<uint32_t>(count_of(k))) * 0x100000001B3ull;
 #ifdef MISO_K2_PROFILE

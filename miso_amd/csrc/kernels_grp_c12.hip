@@ -10,4 +10,5 @@ MISO_INSTANTIATE_GRP(4)
 MISO_INSTANTIATE_GRP(8)
 MISO_INSTANTIATE_GRP(16)
 MISO_INSTANTIATE_GRP(32)
+template __global__ void sampler_grp<64, true, 12, true>(const KernelArgs);   // one chain per workgroup
 }  // namespace miso

@@ -28,7 +28,7 @@ __global__ void compare_kernel(const DevEvent *, const unsigned char *, const De
 __global__ void match_kernel(const MatchEvent *, const int2 *, const int *, const int *, const int *, const int *,
                              const int *, const int *, const int *, int, int, int, int, int, uint32_t *, uint16_t *);
 __global__ void summarize_kernel(const DevEvent *, const unsigned char *, int, int, int, int, const uint64_t *, double *, int);
-template <int G, bool PE, int KC> __global__ void sampler_grp(const KernelArgs a);
+template <int G, bool PE, int KC, bool WIDE = false> __global__ void sampler_grp(const KernelArgs a);
 template <int KC> __global__ void sampler_flat(const KernelArgs a);
 __global__ void selftest_detmath_kernel(const double *, int, double *, double *, double *, double *);
 __global__ void selftest_philox_kernel(const uint32_t *, int, uint32_t *);
@@ -342,15 +342,43 @@ void miso_batch::upload(int dev) {
     return dx != dy ? dx : events[x].n_draw > events[y].n_draw; });
   n_k2w = 0;
   for (int i : k2) n_k2w += (use_delta && events[i].pe_delta && !events[i].draw_dense.empty()) ? 1 : 0;
-  // the general kernel's wavefronts loop to their largest K and longest draw list: group alike
+  // the general kernel's wavefronts loop to their largest K and longest draw list: group alike.
+  // Paired-end (sampler_grp gives every chain of a launch the same lanes): genes of very different sizes -- real
+  // read counts, 20 ... 10^5 pairs per gene; the reference costs O(reads) per gene, miso_paired.c:393-552 -- are
+  // split into size buckets per isoform-count class, each its own launch beside the others: genes of >= 8 x the
+  // class's median drawing pairs take at least 32 lanes per chain, genes of >= 32 x (and >= 4096 pairs) a whole
+  // workgroup (256 lanes, kernels_grp.inl WIDE).  MISO_NO_PE_BUCKETS=1: one launch per class as before (A/B, tests).
+  auto kc_of = [](int K) { return K <= 4 ? 4 : (K <= 8 ? 8 : (K <= 12 ? 12 : (K <= 16 ? 16 : 32))); };
+  std::vector<int> bucket(n, 0);   // 0 normal, 1 at least 32 lanes, 2 workgroup-wide
+  if (p.paired && std::getenv("MISO_NO_PE_BUCKETS") == nullptr) {
+    std::vector<int> sizes[33];
+    for (int i : gen) sizes[kc_of(events[i].K)].push_back(events[i].n_draw);
+    double median[33] = {0};
+    for (int kc : {4, 8, 12, 16, 32})
+      if (!sizes[kc].empty()) {
+        std::nth_element(sizes[kc].begin(), sizes[kc].begin() + sizes[kc].size() / 2, sizes[kc].end());
+        median[kc] = std::max(1, sizes[kc][sizes[kc].size() / 2]);
+      }
+    const bool dense_ok = std::getenv("MISO_NO_PE_DENSE") == nullptr;
+    for (int i : gen) {
+      const PackedEvent &e = events[i];
+      const double med = median[kc_of(e.K)];
+      const bool can_wide = dense_ok && !e.draw_dense.empty() && e.K >= 3 && e.K <= PE_DENSE_KMAX;
+      if (can_wide && e.n_draw >= 4096 && e.n_draw >= 32.0 * med) bucket[i] = 2;
+      else if (e.n_draw >= 256 && e.n_draw >= 8.0 * med) bucket[i] = 1;
+    }
+  }
   std::stable_sort(gen.begin(), gen.end(), [&](int x, int y) {
+    const int kx = kc_of(events[x].K), ky = kc_of(events[y].K);
+    if (kx != ky) return kx > ky;
+    if (bucket[x] != bucket[y]) return bucket[x] > bucket[y];
     return events[x].K != events[y].K ? events[x].K > events[y].K : events[x].n_draw > events[y].n_draw; });
   gen_runs.clear(); tuned_k2_G = 0; k2_plan_key = k2w_plan_key = -1;
   for (size_t j = 0; j < gen.size(); j++) {
     const PackedEvent &e = events[gen[j]];
-    const int kc = e.K <= 4 ? 4 : (e.K <= 8 ? 8 : (e.K <= 12 ? 12 : (e.K <= 16 ? 16 : 32)));
-    if (gen_runs.empty() || gen_runs.back().kc != kc) {
-      GenRun r; r.first = static_cast<int>(j); r.kc = kc;
+    const int kc = kc_of(e.K), bk = bucket[gen[j]];
+    if (gen_runs.empty() || gen_runs.back().kc != kc || (gen_runs.back().wide ? 2 : (gen_runs.back().force_G ? 1 : 0)) != bk) {
+      GenRun r; r.first = static_cast<int>(j); r.kc = kc; r.wide = bk == 2; r.force_G = bk == 1 ? 32 : 0;
       gen_runs.push_back(r);
     }
     GenRun &r = gen_runs.back();
@@ -476,8 +504,29 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     ka.kstride = run.kmax; ka.cstride = sh.qs; ka.tstride = sh.ts;
     ka.pe_dense = G == 64 ? 0 : fp_rows(run);
     ka.pe_force_exact = std::getenv("MISO_PE_FORCE_EXACT") != nullptr;
-    const size_t fp_bytes = G == 64 ? fp_plain : fp_bytes_of(run);
-    if (G == 64) {
+    const size_t fp_bytes = (G == 64 && !run.wide) ? fp_plain : fp_bytes_of(run);
+    if (run.wide) {   // one chain per workgroup: four slices (one per wavefront) + the reduction scratch behind them
+      ka.pe_dense = fp_rows(run);
+      if (!ka.pe_dense) MISO_FAIL(MISO_EINTERNAL, "workgroup-wide paired-end chains need the dense records");
+      const size_t lds0 = align_up(fp_bytes + 4 * static_cast<size_t>(grp_slice_bytes(run.kmax, 0, sh.ts)), 16);
+      ka.red_off = static_cast<int32_t>(lds0);
+      const size_t lds = lds0 + 64;
+      const unsigned grid = static_cast<unsigned>(chains);
+#define MISO_GRP_WIDE(KC)                                                                                  \
+  {                                                                                                        \
+    HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sampler_grp<64, true, KC, true>),           \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));        \
+    hipLaunchKernelGGL((sampler_grp<64, true, KC, true>), dim3(grid), dim3(256), lds, st, ka);             \
+  }
+      switch (run.kc) {
+      case 4: MISO_GRP_WIDE(4) break;
+      case 8: MISO_GRP_WIDE(8) break;
+      case 12: MISO_GRP_WIDE(12) break;
+      case 16: MISO_GRP_WIDE(16) break;
+      default: MISO_GRP_WIDE(32) break;
+      }
+#undef MISO_GRP_WIDE
+    } else if (G == 64) {
       const unsigned grid = static_cast<unsigned>((chains + 3) / 4);
       const size_t lds = fp_bytes + 4 * 32 * sizeof(int);
       if (p.paired) hipLaunchKernelGGL(sampler_wave<true>, dim3(grid), dim3(256), lds, st, ka);
@@ -747,6 +796,14 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     const GrpShape sh = grp_sh[ri] = grp_shape(run);
     const long chains = static_cast<long>(run.count) * p.noChains;
     int G = 64;
+    if (run.wide) {   // one chain per workgroup (launch_grp): the score table joins the slice when four of them fit
+      GrpShape w{0, 0};
+      w.ts = run.kmax * il2;
+      if (fp_bytes_of(run) + 4 * static_cast<size_t>(grp_slice_bytes(run.kmax, 0, w.ts)) + 64 > LDS_MAX) w.ts = 0;
+      grp_sh[ri] = w;
+      grp_G[ri] = 64;
+      continue;
+    }
     if (const char *env = std::getenv("MISO_GENERAL_LANES")) {
       G = std::atoi(env);
     } else if (run.tuned_G) {
@@ -764,7 +821,9 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       // is more than a round and a half of wavefronts -- K = 9 21.3k -> 26.8k, K = 10 20.8k -> 26.9k, K = 12 19.1k ->
       // 22.5k, K = 16 14.4k -> 16.6k, K = 20 10.7k -> 10.9k events/s; the mix keeps 32: 16.8k vs 14.2k genes/s;
       // profiles/r03_pe_lanes_sweep.txt)
-      const bool pe32 = p.paired && (n_kernels > 1 || (run.kc >= 12 && 2 * ((chains + 3) / 4) < 3 * static_cast<long>(slots_for(chains))) ||
+      int n_classes = 0;
+      for (size_t rj = 0; rj < gen_runs.size(); rj++) if (rj == 0 || gen_runs[rj].kc != gen_runs[rj - 1].kc) n_classes++;
+      const bool pe32 = p.paired && (n_classes + (n_k2 > 0 ? 1 : 0) > 1 || (run.kc >= 12 && 2 * ((chains + 3) / 4) < 3 * static_cast<long>(slots_for(chains))) ||
                                      (chains + 3) / 4 < slots_for(chains));
       for (int g : {2, 4, 8, 16, 32}) {
         if (p.paired && g > 16 && found && !pe32) break;
@@ -784,6 +843,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
         run.tuned_G = G;
       }
     }
+    if (run.force_G && G < run.force_G && std::getenv("MISO_GENERAL_LANES") == nullptr) G = run.force_G;   // size bucket (upload)
     // a forced (or odd) choice never exceeds the LDS budget: fewer chains per wavefront instead
     while (G < 64 && !grp_fits(run, sh, G)) G = (G < 2) ? 2 : ((G & (G - 1)) ? 64 : G * 2);
     grp_G[ri] = G;
@@ -1027,13 +1087,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     const int G = grp_G[ri], C = p.noChains, cpw = flat ? flat_nc[ri] : std::max(1, 64 / G);
     const long chains = static_cast<long>(run.count) * C;
     std::vector<const PackedEvent *> evs;   // the run's events in slot order
-    {
-      std::vector<int> gen;
-      for (size_t i = 0; i < events.size(); i++) if (events[i].K != 2 || k2_general) gen.push_back(static_cast<int>(i));
-      std::stable_sort(gen.begin(), gen.end(), [&](int x, int y) {
-        return events[x].K != events[y].K ? events[x].K > events[y].K : events[x].n_draw > events[y].n_draw; });
-      for (int j = 0; j < run.count; j++) evs.push_back(&events[gen[run.first + j]]);
-    }
+    for (int j = 0; j < run.count; j++) evs.push_back(&events[h_slots[n_k2 + run.first + j]]);   // the list upload made
     const bool cls = !p.paired && grp_sh[ri].qs > 0;
     double trips = 0, words = 0;
     long waves = 0;
@@ -1060,7 +1114,12 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       const int nw = (cls && kmx - 1 <= 3) ? 2 : 1;         // Philox blocks in flight (class path, K <= 4)
       trips += flat ? (units + 63) / 64 : ((G == 64) ? mx : nw * ((mx + nw * G - 1) / (nw * G)));
     }
-    const std::string name = flat ? flat_name(run) : (G == 64 ? std::string("sampler_wave<") : "sampler_grp<" + std::to_string(G) + ", ") +
+    if (run.wide) {   // four wavefronts per chain, the quads dealt over 256 lanes
+      trips = 0; waves = 0;
+      for (long sl = 0; sl < chains; sl++) { trips += 4 * ((((evs[sl / C]->n_draw + 3) / 4) + 255) / 256); waves += 4; }
+    }
+    const std::string name = run.wide ? "sampler_grp<64, true, " + std::to_string(run.kc) + ", true>" :
+                             flat ? flat_name(run) : (G == 64 ? std::string("sampler_wave<") : "sampler_grp<" + std::to_string(G) + ", ") +
                              (p.paired ? "true" : "false") + (G == 64 ? std::string(">") : ", " + std::to_string(run.kc) + ">");
     add_stat(name, static_cast<double>(waves), trips, static_cast<double>(chains), words);
   }
@@ -1113,10 +1172,11 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       continue;
     }
     last_kernels += std::string(last_kernels.empty() ? "" : ",") +
-                    (G == 64 ? std::string("sampler_wave<")
-                             : "sampler_grp<" + std::to_string(G) + ", ") +
-                    (p.paired ? "true" : "false") +
-                    (G == 64 ? std::string(">") : ", " + std::to_string(run.kc) + ">");
+                    (run.wide ? "sampler_grp<64, true, " + std::to_string(run.kc) + ", true>"
+                              : (G == 64 ? std::string("sampler_wave<")
+                                         : "sampler_grp<" + std::to_string(G) + ", ") +
+                                    (p.paired ? "true" : "false") +
+                                    (G == 64 ? std::string(">") : ", " + std::to_string(run.kc) + ">"));
     launch_grp(a, run, grp_sh[ri], G, stream_for_next());
   }
   for (size_t i = 1; i < kernel_no && i <= aux_streams.size() && std::getenv("MISO_SERIAL_KERNELS") == nullptr; i++) {

@@ -160,3 +160,44 @@ def test_two_isoform_paired_end_through_the_general_kernel(orc, sd, forced):
         assert np.array_equal(gpu.samples, r.samples, equal_nan=True), (sd, i)
         assert np.array_equal(gpu.loglik, r.loglik, equal_nan=True), (sd, i)
         assert (gpu.assignment == r.assignment).all(), (sd, i)
+
+
+@pytest.mark.parametrize("K,chains", [(3, 2), (5, 1), (10, 1)])
+def test_mixed_pair_counts_three_or_more_isoforms_paired_end_bit_exact(orc, K, chains):
+    """sampler_grp, paired-end: genes of very different sizes are split into size buckets per isoform-count class
+    (runtime.hip upload) -- the mean-sized on the rule's lanes per chain, the several-times-larger on at least 32, the
+    largest one per WORKGROUP (kernels_grp.inl WIDE: 256 lanes, totals through LDS) -- launched side by side.
+    Against the single launch per class (MISO_NO_PE_BUCKETS=1) and the oracle."""
+    sizes = [30, 22000, 200, 5, 0, 1800, 9000, 60, 700, 120, 90, 200, 35, 400, 150, 80]
+    evs = []
+    for j, n in enumerate(sizes):
+        exons, isoforms = se_gene(K, exlen=500 + 11 * j, gap=300)
+        g = orc.gene(flat(exons), isoforms)
+        orc.rng_seed(7000 + j)
+        rc, _, pos, cig = orc.simulate_paired_reads(g, expr_for(K), max(n, 1), 36, 250.0, 900.0)
+        assert rc == 0
+        evs.append((exons, isoforms, g, pos[:2 * n], cig[:2 * n]))
+    kw = dict(iters=50, burn=10, lag=2, chains=chains)
+    cpu = []
+    for i, (exons, isoforms, g, pos, cig) in enumerate(evs):
+        r = orc.miso_paired(g, pos, cig, 36, 250.0, 900.0, mode=OrcLib.COUNTER, seed=17, event_id=300 + i, trace=True, **kw)
+        assert r.rc == 0
+        cpu.append(r)
+    names = []
+    for v in (dict(), dict(MISO_NO_PE_BUCKETS="1"), dict(MISO_PE_FORCE_EXACT="1")):
+        with _env(**v):
+            b = miso_amd.Batch(36, paired=True, mean=250.0, var=900.0, device_match=True, **kw)
+            for exons, isoforms, g, pos, cig in evs:
+                b.add_event(miso_amd.Gene(exons, isoforms), pos, cig)
+            b.run(seed=17, first_event_id=300)
+            names.append(b.last_kernels())
+            for i, r in enumerate(cpu):
+                gpu = b.result(i)
+                where = (v, K, sizes[i], b.last_kernels())
+                assert (gpu.counts_hash == r.trace["counts_hash"]).all(), where
+                assert np.array_equal(gpu.samples, r.samples, equal_nan=True), where
+                assert np.array_equal(gpu.loglik, r.loglik, equal_nan=True), where
+                assert (gpu.assignment == r.assignment).all(), where
+                assert gpu.rundata.noAccepted == r.accepted, where
+    assert ", true>" in names[0] and names[0].count("sampler_grp") >= 3, names     # workgroup-wide + 32-lane + normal launches
+    assert names[1].count("sampler_grp") == 1, names
