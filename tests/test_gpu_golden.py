@@ -53,6 +53,54 @@ def test_golden_inputs_bit_exact(orc, name):
     assert (np.abs(a.mean(0) - r.mean(0)) < tol).all(), (a.mean(0), r.mean(0), tol)
 
 
+@pytest.mark.parametrize("K,paired,n", [(5, True, 600), (10, True, 700), (10, False, 800), (3, True, 500)])
+def test_device_posterior_within_monte_carlo_error_of_the_real_reference(ref, K, paired, n):
+    """The GPU against the REAL reference C core (oracle/_ref, independent random streams), every kernel family with
+    three or more isoforms, ALL isoforms, posterior mean and both Chen-Shao bounds: 6 genes x 8 reference seeds give
+    the Monte-Carlo standard error of one run's summaries gene by gene; the device's summaries (summarize_kernel) must
+    lie within 4 x MCSE x sqrt(1 + 1/8) of the seeds' mean -- P(|t_7| > 4) = 5e-3 per check, so a few of the 18 K
+    checks may exceed 4, none may exceed 9.  (The fixed tolerance of test_golden_inputs_bit_exact with its guessed
+    effective sample size stays as a smoke check; this is the measured one.  bench.py runs the same check at the
+    benchmark's sizes for every matrix row.)"""
+    from _problems import se_gene, expr_for
+    kw = dict(iters=3000, burn=1000, lag=2, chains=1)
+    b = miso_amd.Batch(36, paired=paired, mean=250.0 if paired else 0.0, var=900.0 if paired else 0.0, device_match=True, **kw)
+    probs = []
+    for j in range(6):
+        exons, isoforms = se_gene(K, exlen=(500 if paired else 110) + 9 * j, gap=300 if paired else 100)
+        g = ref.gene(flat(exons), isoforms)
+        ref.rng_seed(8000 + j)
+        if paired:
+            rc, _, pos, cig = ref.simulate_paired_reads(g, expr_for(K), n, 36, 250.0, 900.0)
+        else:
+            rc, _, pos, cig = ref.simulate_reads(g, expr_for(K), n, 36)
+        assert rc == 0
+        b.add_event(miso_amd.Gene(exons, isoforms), pos, cig)
+        probs.append((g, pos, cig))
+    b.run(seed=77, first_event_id=0)
+    b.summarize(0.95)
+
+    def stats(samples):
+        x = np.sort(samples, axis=0)
+        m = len(x)
+        return np.stack([x.mean(0), x[int(round(0.025 * m)) - 1], x[int(round(0.975 * m)) - 1]])
+    z = []
+    for j, (g, pos, cig) in enumerate(probs):
+        runs = []
+        for s in range(8):
+            ref.rng_seed(9000 + 17 * j + s)
+            r = ref.miso_paired(g, pos, cig, 36, 250.0, 900.0, **kw) if paired else ref.miso(g, pos, cig, 36, **kw)
+            assert r.rc == 0
+            runs.append(stats(r.samples))
+        runs = np.array(runs)                      # [8, 3, K]
+        gpu = np.stack(b.summary(j))               # [3, K]
+        mcse = runs.std(0, ddof=1)
+        d = np.abs(gpu - runs.mean(0))
+        z.append(np.where((mcse < 1e-12) & (d < 1e-9), 0.0, d / np.maximum(mcse * np.sqrt(1 + 1 / 8.0), 1e-12)))
+    z = np.array(z).ravel()
+    assert (z > 4).sum() <= max(2, int(0.03 * len(z))) and z.max() < 9, (K, paired, np.sort(z)[-5:])
+
+
 def test_per_event_entry_points(orc):
     """miso_run / miso_run_paired: the splicing_miso signatures + seed, a batch of one."""
     g = _golden.load("se_k3")

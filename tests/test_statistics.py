@@ -90,6 +90,36 @@ def test_paired_end_stream_vs_counter(orc):
     assert abs(np.mean(a) - np.mean(b)) < 4 * mcse + 1e-3, (np.mean(a), np.mean(b), mcse)
 
 
+@pytest.mark.parametrize("K,n_pairs", [(3, 500), (5, 600), (10, 700)])
+def test_paired_end_multi_isoform_stream_vs_counter_and_reference(orc, ref, K, n_pairs):
+    """The paired-end contract changes the arithmetic of the read score (2^-26 fixed point, order-free, where
+    miso_paired.c:133-174, 393-419 sums doubles read by read) as well as the random stream: three or more isoforms,
+    ALL isoforms, posterior means AND both Chen-Shao bounds (credible_intervals.py:31-55), 8 seeds each way --
+    the oracle's stream mode, its counter mode (= the GPU bit for bit) and the REAL reference must agree within
+    4 x MCSE.  (Two isoforms: test_paired_end_stream_vs_counter.)"""
+    exons, isoforms, g, pos, cig = simulate_pe(orc, K, n_pairs, seed=170 + K)
+    gr = ref.gene(flat(exons), isoforms)
+
+    def stats(samples):
+        x = np.sort(samples, axis=0)
+        n = len(x)
+        return np.concatenate([x.mean(0), x[int(round(0.025 * n)) - 1], x[int(round(0.975 * n)) - 1]])
+    kw = dict(iters=3000, burn=1000, lag=2, chains=1)
+    a, b, c = [], [], []
+    for s in range(8):
+        orc.rng_seed(5000 + s)
+        a.append(stats(orc.miso_paired(g, pos, cig, 36, 250.0, 900.0, **kw).samples))
+        b.append(stats(orc.miso_paired(g, pos, cig, 36, 250.0, 900.0, mode=OrcLib.COUNTER, seed=31 + s, event_id=4, **kw).samples))
+        ref.rng_seed(6000 + s)
+        c.append(stats(ref.miso_paired(gr, pos, cig, 36, 250.0, 900.0, **kw).samples))
+    a, b, c = np.array(a), np.array(b), np.array(c)
+    for x, y, what in ((a, b, "stream vs counter"), (c, b, "reference vs counter")):
+        mcse = np.sqrt(x.var(0, ddof=1) / 8 + y.var(0, ddof=1) / 8)
+        d = np.abs(x.mean(0) - y.mean(0))
+        # 3 K statistics, P(|t_14| > 4) ~ 1e-3 each: at most one just beyond 4 x MCSE (+ 1e-3 absolute), none beyond 6.5
+        assert (d > 4 * mcse + 1e-3).sum() <= 1 and (d <= 6.5 * mcse + 1e-3).all(), (what, K, d / np.maximum(mcse, 1e-12))
+
+
 def test_count_sums_equal_per_read_sums_up_to_rounding(orc):
     """The contract sums scores from per-isoform counts; the reference sums per read. Same
     assignments -> same psi trajectory, log scores equal to ~1e-10."""
