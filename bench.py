@@ -328,7 +328,9 @@ def roofline_for(batch, kernel_ms, key, sh):
     chain_iters = sum(k["chains"] * k["iterations"] for k in stats["kernels"])
     chains = sum(k["chains"] for k in stats["kernels"])
     draws = sum(k["words"] for k in stats["kernels"]) / max(chains, 1.0)
-    profiled = None if m is None else sorted(re.search(r"miso::(sampler_[^(]+)\(", k).group(1) for k in m["kernels"])
+    # (rocprofv3 prints every template argument, the library's names leave a defaulted `false` out)
+    profiled = None if m is None else sorted(re.search(r"miso::(sampler_[^(]+)\(", k).group(1).replace(", false>", ">")
+                                             for k in m["kernels"])
     launched = sorted(re.findall(r"sampler_\w+<[^>]*>", name))
     if m is not None and profiled == launched:
         cyc = m["valu_per_chain_iteration"] * chain_iters * m["issue_cycles_per_valu"]
