@@ -30,6 +30,7 @@ struct miso_batch {
   // device
   int device = -1;
   bool uploaded = false, launched = false, downloaded = false;
+  bool pool_cleared = false;      // the output pool has been zeroed since the upload
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::vector<hipStream_t> aux_streams;   // kernels 2.. of a mixed batch run beside the first

@@ -146,7 +146,10 @@ class GenesDispatcher(object):
         return batches
 
     def run(self):
+        t_run0 = time.time()
         batches = self.output_batch_files()
+        if os.environ.get("MISO_TIMING"):
+            print("[miso] batch files written in %.2f s" % (time.time() - t_run0))
         print("Preparing to run %d batches of jobs..." % len(batches))
         procs = []
         jobs = []
@@ -222,6 +225,8 @@ class GenesDispatcher(object):
             sam_utils._PRELOADED.clear()
             os.environ["MISO_DISPATCH"] = "subprocess"
             return self.run()
+        if os.environ.get("MISO_TIMING"):
+            print("[miso] alignment file(s) decoded %.2f s after run() started" % (time.time() - t_run0))
         ctx = multiprocessing.get_context("fork")
         sys.stdout.flush()
         waits = []
@@ -264,6 +269,7 @@ def compute_all_genes_psi(gff_dir, bam_filename, read_len, output_dir, overhang_
 
 def main(argv=None):
     import argparse
+    t_main0 = time.time()
     ap = argparse.ArgumentParser(description="MISO (Mixture of Isoforms model) on MI355X")
     ap.add_argument("--run", nargs=2, metavar=("INDEXED_GFF_DIR", "BAM"))
     ap.add_argument("--event-type", default=None)
@@ -304,6 +310,8 @@ def main(argv=None):
                                    compare_bam=None if a.compare is None else
                                    os.path.abspath(os.path.expanduser(a.compare)),
                                    labels=tuple(a.labels))
+    if os.environ.get("MISO_TIMING"):
+        print("[miso] main() %.2f s" % (time.time() - t_main0))
     return 1 if failed else 0
 
 

@@ -83,7 +83,8 @@ def main():
         t0 = time.time()
         rc = subprocess.call([sys.executable, "-m", "miso_amd.miso", "--run", idx, sam, "--output-dir", out,
                               "--read-len", "36", "--settings-filename", settings, "-p", str(procs),
-                              "--seed", "1"], env=dict(env, MISO_DISPATCH=dispatch), stdout=subprocess.DEVNULL)
+                              "--seed", "1"], env=dict(env, MISO_DISPATCH=dispatch),
+                             stdout=None if os.environ.get("MISO_TIMING") else subprocess.DEVNULL)
         t_run = time.time() - t0
         n_files = sum(len([f for f in fs if f.endswith(".miso")]) for _, _, fs in os.walk(out))
         size = sum(os.path.getsize(os.path.join(d, f)) for d, _, fs in os.walk(out) for f in fs) / 1e6
