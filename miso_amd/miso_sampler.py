@@ -308,8 +308,11 @@ class MISOSampler:
         if not slots:
             return written
         dev = int(os.environ.get("MISO_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        timing = os.environ.get("MISO_TIMING")
+        t0 = time.time()
         batch.run(device=dev, seed=seed if seed is not None else random.getrandbits(64),
                   first_event_id=first_event_id)
+        t1 = time.time()
         if summary_file is not None:
             batch.summarize(confidence_level, as_text=True)     # summarize_miso summarises the file's text
         idxs, paths, headers, rows = [], [], [], []
@@ -329,9 +332,13 @@ class MISOSampler:
                 name = os.path.basename(out)[:-len(".miso")]
                 hdr = dict(kv.split("=", 1) for kv in header[1:].rstrip("\n").split("\t"))
                 rows.append((name,) + tuple(batch.summary(idx)) + (hdr,))
+        t2 = time.time()
         batch.write_miso_files(idxs, paths, headers, threads)
         if summary_file is not None:
             summary.write_summary(summary_file, rows)
+        if timing:
+            print("[miso] batch of %d events: upload + sample + download %.2f s, headers %.2f s, .miso files %.2f s"
+                  % (len(slots), t1 - t0, t2 - t1, time.time() - t2))
         return written
 
     # -- two RNA-seq samples over the same events + Bayes factors (compare_miso) ----------------

@@ -94,6 +94,9 @@ def main():
         for f in sorted(os.listdir(logs))[:2]:
             lines = open(os.path.join(logs, f)).read().strip().split("\n")
             print("  " + f + ": " + " | ".join(lines[-2:]))
+            for ln in lines:
+                if ln.startswith("[miso]"):
+                    print("    " + ln)
     if not a.keep:
         shutil.rmtree(work, ignore_errors=True)
 
