@@ -927,6 +927,24 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   {
     const int count = n_k2 - n_k2w;
     const char *off = std::getenv("MISO_K2_MULTI");
+    // paired-end events that keep MODE 1 (a drawing read touches a non-finite score): the same, 4-wavefront workgroups,
+    // 4 ... 64 lanes as far as the chains' tables (2 il int32 each) fit the LDS, 256-lane chains
+    const long pe1_left = static_cast<long>(LDS_MAX) - static_cast<long>(k2_fp) - K2_RED_BYTES;
+    const int pe1_cpw = p.paired ? static_cast<int>(std::max<long>(0, pe1_left / static_cast<long>(4 * std::max<size_t>(k2_tab, 1)))) : 64;
+    if (p.paired && count > 0 && pe1_cpw >= 1 && std::getenv("MISO_LANES_PER_CHAIN") == nullptr && !(off && std::atoi(off) == 0)) {
+      const int resident = std::max(1, slots_for(static_cast<long>(count) * p.noChains) / 4);
+      const long key = static_cast<long>(resident) * 64 + p.noChains;
+      if (k2_plan_key != key || std::getenv("MISO_K2_TARGET") || std::getenv("MISO_K2_COST")) {
+        static const int widths[] = {4, 8, 16, 32, 64};
+        LaneCost cost = k2_cost_paired();
+        std::vector<int> nd(count);
+        for (int i = 0; i < count; i++) nd[i] = events[h_slots[n_k2w + i]].n_draw;
+        const double forced = std::getenv("MISO_K2_TARGET") ? std::atof(std::getenv("MISO_K2_TARGET")) : 0.0;
+        k2_plan = plan_lanes(nd.data(), count, p.noChains, widths, 5, 4, 4, resident, pe1_cpw, cost, forced);
+        k2_plan_key = key;
+      }
+      k2_multi = k2_plan.n_segs > 0;
+    }
     if (!p.paired && count > 0 && std::getenv("MISO_LANES_PER_CHAIN") == nullptr && !(off && std::atoi(off) == 0)) {
       const int resident = std::max(1, slots_for(static_cast<long>(count) * p.noChains) / 8);
       const long key = static_cast<long>(resident) * 64 + p.noChains;
@@ -1019,6 +1037,19 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     for (int i = 0; i <= k2_plan.n_segs; i++) { ka.seg_block[i] = k2_plan.seg_block[i]; ka.seg_slot[i] = k2_plan.seg_slot[i]; }
     for (int i = 0; i < k2_plan.n_segs; i++) ka.seg_lanes[i] = k2_plan.seg_lanes[i];
     const dim3 grid(static_cast<unsigned>(k2_plan.seg_block[k2_plan.n_segs]));
+    if (p.paired) {   // MODE 1
+      int cpw = 1;
+      for (int i = 0; i < k2_plan.n_segs; i++) if (k2_plan.seg_lanes[i] != K2_WIDE) cpw = std::max(cpw, 64 / k2_plan.seg_lanes[i]);
+      const size_t tabs = align_up(k2_fp + 4 * static_cast<size_t>(cpw) * k2_tab, 16);
+      ka.pair_waves = 0;
+      ka.red_off = static_cast<int32_t>(tabs);
+      const int lds = static_cast<int>(tabs + K2_RED_BYTES);
+      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sampler_k2_multi<1, 4>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      hipLaunchKernelGGL((sampler_k2_multi<1, 4>), grid, dim3(256), lds, st, ka);
+      HIP_OK(hipGetLastError());
+      return;
+    }
     switch (k2_plan.wpb) {
     case 8: hipLaunchKernelGGL((sampler_k2_multi<0, 8>), grid, dim3(512), K2_RED_BYTES, st, ka); break;
     case 4: hipLaunchKernelGGL((sampler_k2_multi<0, 4>), grid, dim3(256), K2_RED_BYTES, st, ka); break;
@@ -1085,7 +1116,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
           }
         } else slice(c0, c1, pl.seg_lanes[sg]);
       }
-      add_stat("sampler_k2_multi<" + std::string(wpart ? "2, " : "0, ") + std::to_string(pl.wpb) + ">", static_cast<double>(waves), trips,
+      add_stat("sampler_k2_multi<" + std::string(wpart ? "2, " : (p.paired ? "1, " : "0, ")) + std::to_string(pl.wpb) + ">", static_cast<double>(waves), trips,
                static_cast<double>(chains), words);
     } else if (!wpart && k2_mix > 0) {
       slice(0, static_cast<long>(k2_mix) * C, k2G + 1);
@@ -1168,7 +1199,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     lanes_per_chain = k2_G;
     if (k2_multi) {
       lanes_per_chain = k2_plan.seg_lanes[k2_plan.n_segs - 1];
-      last_kernels += std::string(last_kernels.empty() ? "" : ",") + "sampler_k2_multi<0, " + std::to_string(k2_plan.wpb) + ">";
+      last_kernels += std::string(last_kernels.empty() ? "" : ",") + "sampler_k2_multi<" + (p.paired ? "1, " : "0, ") + std::to_string(k2_plan.wpb) + ">";
       launch_k2_multi(a, stream_for_next());
     } else if (k2_mix > 0) {
       last_kernels += std::string(last_kernels.empty() ? "" : ",") + k2_mix_name(k2_G);
