@@ -31,6 +31,9 @@ struct miso_batch {
   int device = -1;
   bool uploaded = false, launched = false, downloaded = false;
   bool pool_cleared = false;      // the output pool has been zeroed since the upload
+  bool launched_once = false;     // since the upload
+  std::vector<int> coop_n;        // per event: workgroups of a workgroup-wide paired-end chain (upload: by its share of the batch's work)
+  int coop_wgs_used = 0;          // cooperative workgroups handed out to this batch's wide runs (<= COOP_MAX_WGS)
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::vector<hipStream_t> aux_streams;   // kernels 2.. of a mixed batch run beside the first
@@ -58,6 +61,11 @@ struct miso_batch {
     bool dense = true;            // paired-end: every event has dense quad records (pe_dense)
     int force_G = 0;              // paired-end size bucket: at least this many lanes per chain (events several times the class's mean size)
     bool wide = false;            // paired-end size bucket: one chain per workgroup (sampler_grp<64, true, KC, true>)
+    // wide runs: which chain every workgroup works on, alone or as one of several (coop.hpp; runtime.hip launch_grp)
+    std::vector<int32_t> coop_tab;
+    int32_t *d_coop_tab = nullptr;
+    uint32_t *d_coop_mem = nullptr;
+    int coop_chains = 0;          // chains on more than one workgroup
     int tuned_G = 0;              // lanes per chain picked by the first launch's trial runs
     int tuned_flat = -1;          // sampler_flat (1) or sampler_grp (0) by the first launch's trial runs, -1 = not tried
     // sampler_flat: which chains every wavefront owns (runtime.hip flat_waves; two words per wavefront)

@@ -100,6 +100,9 @@ struct KernelArgs {
   int32_t mix_blocks;       // sampler_k2_mix<GA, GB>: the first mix_blocks workgroups run the first mix_slots events
   int32_t mix_slots;        // with GA lanes per chain, the rest the remaining events with GB (runtime.hip)
   const int32_t *wave_tab;  // sampler_flat: two words per wavefront: first chain of the launch's list, chains | FLAT_WIDE (runtime.hip)
+  const int32_t *coop_tab;  // workgroup-wide chains on SEVERAL workgroups (coop.hpp): per workgroup {chain (slot of the launch's
+                            // list), rank among the chain's workgroups, their number, the chain's scratch index}; null = one each
+  uint32_t *coop_mem;       // COOP_WORDS dwords of exchange scratch per cooperative chain, zeroed before the launch
   int32_t red_off;          // sampler_k2_multi: byte offset of the workgroup-wide chains' reduction scratch in the dynamic LDS
   uint64_t seed;
   // sampler_k2_multi (kernels_k2m.hip): the launch's events (ordered by drawing reads, most first) cut into runs

@@ -35,6 +35,7 @@
 #include "miso_detmath.h"
 #include "miso_philox.h"
 #include "gibbs_rng.hpp"
+#include "coop.hpp"
 
 #pragma clang fp contract(off)
 
@@ -584,12 +585,13 @@ __device__ __forceinline__ void pe_all_tests(int64_t rb, const int64_t (&cb)[KK]
 // The loop.  fq: the event's records, n_quads of them followed by one quad of padding reads, which the lanes
 // beyond the event's last quad process instead (it changes nothing: no range test in the loop).
 // STAB_LDS: the score table is the chain's LDS copy at byte address stab_lds, else stab_glob in global memory.
-template <int KK, int G, bool WRITE, bool BADCHK, bool STAB_LDS>
+template <int KK, int GT, bool WRITE, bool BADCHK, bool STAB_LDS>
 __device__ __forceinline__ void pe_dense(const uint32_t *fq, const double *psi, const double *fp_rep,
                                          uint32_t stab_lds, const int32_t *stab_glob, int il2, int *dl, uint8_t *drawass,
                                          bool write_ass, int nqw, int n_quads, int n_draw, int sub,
                                          const GibbsRng &rng, uint32_t n0r0, bool force_exact,
-                                         int64_t &acc_out, int &bad_out) {
+                                         int64_t &acc_out, int &bad_out, int stride_rt = 0) {
+  const int G = GT > 0 ? GT : stride_rt;   // lanes striding over the chain's quads (GT = 0: known at run time only -- chains on several workgroups)
   constexpr int ND = KK + 1;   // dwords per quad: 4 KK index bytes, one dword of flags
   double ps[KK];
 #pragma unroll
@@ -763,7 +765,7 @@ __global__ __launch_bounds__(256, PE ? MISO_GRP_PE_BLOCKS : (KC <= 8 ? MISO_GRP_
   constexpr int KLO = KC == 4 ? 3 : (KC == 8 ? 5 : (KC == 12 ? 9 : (KC == 16 ? 13 : 17)));   // the class holds K in [KLO, KC]
   constexpr int MH_CH = PE ? (KC <= 8 ? KC : 4) : 1;   // chunk width of the Metropolis-Hastings step's serial chains (seq_sum_u)
   static_assert(!WIDE || (PE && G == 64), "workgroup-wide chains: paired-end, whole wavefronts");
-  constexpr int GS = WIDE ? 256 : G;       // lanes striding over one chain's quads
+  constexpr int GS = WIDE ? 0 : G;         // lanes striding over one chain's quads (WIDE: 256 x the chain's workgroups, known at run time)
   constexpr bool MH_ONE = PE && KC <= 4;   // a single pass without the loop around it (K=3 57.2k -> 60.6k; at five to eight isoforms the loop form is faster: 39.5k against 35.9k at K=5)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int CPW = 64 / G;
@@ -784,13 +786,24 @@ __global__ __launch_bounds__(256, PE ? MISO_GRP_PE_BLOCKS : (KC <= 8 ? MISO_GRP_
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int grp = lane / G, sub = lane - grp * G;
   const long n_chains = static_cast<long>(a.n_slots) * a.C;
-  const long wave_id = WIDE ? static_cast<long>(blockIdx.x) : static_cast<long>(blockIdx.x) * 4 + wave;
+  // WIDE: which chain this workgroup works on, alone or as one of several (coop.hpp)
+  CoopGroup cg{0, 1, nullptr};
+  long wide_slot = blockIdx.x;
+  if (WIDE && a.coop_tab) {
+    const int32_t *t = a.coop_tab + 4 * static_cast<size_t>(blockIdx.x);
+    wide_slot = __builtin_amdgcn_readfirstlane(t[0]);
+    cg.rank = __builtin_amdgcn_readfirstlane(t[1]); cg.n = __builtin_amdgcn_readfirstlane(t[2]);
+    cg.mem = a.coop_mem + static_cast<size_t>(__builtin_amdgcn_readfirstlane(t[3])) * COOP_WORDS;
+  }
+  uint32_t coop_step = 0; bool coop_ok = true;
+  const long wave_id = WIDE ? wide_slot : static_cast<long>(blockIdx.x) * 4 + wave;
   if (wave_id * CPW >= n_chains) return;  // no block-level barrier below (WIDE: the whole workgroup leaves)
   long slot = wave_id * CPW + grp;
   const bool live_all = slot < n_chains;
-  const bool live = live_all && (!WIDE || wave == 0);   // who stores the chain's outputs
+  const bool live = live_all && (!WIDE || (wave == 0 && cg.rank == 0));   // who stores the chain's outputs
   if (!live_all) slot = n_chains - 1;       // shadow a real chain, store nothing
-  const int sub_r = WIDE ? static_cast<int>(threadIdx.x) : sub;   // this lane's place among the chain's GS lanes
+  const int sub_r = WIDE ? cg.rank * 256 + static_cast<int>(threadIdx.x) : sub;   // this lane's place among the chain's lanes
+  const int stride_r = WIDE ? 256 * cg.n : G;
   const int ks = a.kstride, cs = a.cstride;
   Slice S = carve(smem + fp_bytes + (static_cast<size_t>(wave) * CPW + grp) * grp_slice_bytes(ks, cs, a.tstride),
                   ks, cs);
@@ -1014,9 +1027,9 @@ __global__ __launch_bounds__(256, PE ? MISO_GRP_PE_BLOCKS : (KC <= 8 ? MISO_GRP_
       wave_sync();
 #define MISO_PED2(KK, LDS)                                                                            \
   {                                                                                                   \
-    if (__any(write_ass)) pe_dense<KK, GS, true, true, LDS>(dq, S.psi, lds_fp, stab_lds, sfixd_glob, il2, S.dl, drawass, write_ass, nqw, n_quads, n_draw, sub_r, rng, n0r0, a.pe_force_exact != 0, acc, bad); \
-    else if (dense_nobad) pe_dense<KK, GS, false, false, LDS>(dq, S.psi, lds_fp, stab_lds, sfixd_glob, il2, S.dl, drawass, write_ass, nqw, n_quads, n_draw, sub_r, rng, n0r0, a.pe_force_exact != 0, acc, bad); \
-    else pe_dense<KK, GS, false, true, LDS>(dq, S.psi, lds_fp, stab_lds, sfixd_glob, il2, S.dl, drawass, write_ass, nqw, n_quads, n_draw, sub_r, rng, n0r0, a.pe_force_exact != 0, acc, bad); \
+    if (__any(write_ass)) pe_dense<KK, GS, true, true, LDS>(dq, S.psi, lds_fp, stab_lds, sfixd_glob, il2, S.dl, drawass, write_ass, nqw, n_quads, n_draw, sub_r, rng, n0r0, a.pe_force_exact != 0, acc, bad, stride_r); \
+    else if (dense_nobad) pe_dense<KK, GS, false, false, LDS>(dq, S.psi, lds_fp, stab_lds, sfixd_glob, il2, S.dl, drawass, write_ass, nqw, n_quads, n_draw, sub_r, rng, n0r0, a.pe_force_exact != 0, acc, bad, stride_r); \
+    else pe_dense<KK, GS, false, true, LDS>(dq, S.psi, lds_fp, stab_lds, sfixd_glob, il2, S.dl, drawass, write_ass, nqw, n_quads, n_draw, sub_r, rng, n0r0, a.pe_force_exact != 0, acc, bad, stride_r); \
   }
 #define MISO_PED(KK) { if (a.tstride > 0) MISO_PED2(KK, true) else MISO_PED2(KK, false) }
       if constexpr (KC == 4) { if (K == 3) MISO_PED(3) else MISO_PED(4) }
@@ -1042,6 +1055,24 @@ __global__ __launch_bounds__(256, PE ? MISO_GRP_PE_BLOCKS : (KC <= 8 ? MISO_GRP_
           ta += red[w].acc; tb |= red[w].bad;
         }
         __syncthreads();
+        if (cg.n > 1) {   // ... and the chain's other workgroups' (coop.hpp): accumulator coop_step % 3, one barrier
+          uint32_t *accp = coop_acc(cg, coop_step);
+          if (wave == 0) {
+            if (lane < K - 1 && tot) atomicAdd(&accp[4 + lane], static_cast<uint32_t>(tot));
+            if (lane == 0) {
+              atomicAdd(reinterpret_cast<unsigned long long *>(accp), static_cast<unsigned long long>(ta));
+              if (tb) atomicOr(&accp[2], 1u);
+            }
+            if (cg.rank == 0 && lane < COOP_ACC) atomicExch(&coop_acc(cg, coop_step + 1)[lane], 0u);   // next step's, read last two steps ago
+            __threadfence();   // this wavefront's atomics are at the L2 before the workgroup announces its arrival
+          }
+          int *flag = reinterpret_cast<int *>(smem + a.red_off + 64);
+          coop_ok = coop_barrier(cg, coop_step, flag) && coop_ok;
+          tot = lane < K - 1 ? static_cast<int>(coop_load(&accp[4 + lane])) : 0;
+          ta = static_cast<int64_t>((static_cast<uint64_t>(coop_load(&accp[1])) << 32) | coop_load(&accp[0]));
+          tb = static_cast<int>(coop_load(&accp[2]));
+          coop_step++;
+        }
         if (lane < K - 1) S.dl[lane] = tot;
         acc = ta; bad = tb;
         wave_sync();
@@ -1260,6 +1291,7 @@ __global__ __launch_bounds__(256, PE ? MISO_GRP_PE_BLOCKS : (KC <= 8 ? MISO_GRP_
   int accepted = 0, lagCounter = 0, noS = 0;
 
   for (int m = 0; m < a.M; m++) {
+    if (WIDE && !coop_ok) return;   // the chain's workgroups gave up waiting for each other (coop.hpp): the host reports it
 #pragma unroll 1
     for (int k0 = 0; k0 < (MH_ONE ? 1 : Kw); k0 += MH_CH) {
       int ck[MH_CH];

@@ -16,6 +16,7 @@
 #include <thread>
 
 #include "batch.hpp"
+#include "coop.hpp"
 
 namespace miso {
 
@@ -87,7 +88,12 @@ void miso_batch::release() {
   d_slots = nullptr;
   if (ev0) (void) hipEventDestroy(ev0);
   if (ev1) (void) hipEventDestroy(ev1);
-  for (GenRun &run : gen_runs) { if (run.d_wave_tab) (void) hipFree(run.d_wave_tab); run.d_wave_tab = nullptr; run.wave_key = -1; }
+  for (GenRun &run : gen_runs) {
+    if (run.d_wave_tab) (void) hipFree(run.d_wave_tab);
+    if (run.d_coop_tab) (void) hipFree(run.d_coop_tab);
+    if (run.d_coop_mem) (void) hipFree(run.d_coop_mem);
+    run.d_wave_tab = nullptr; run.d_coop_tab = nullptr; run.d_coop_mem = nullptr; run.wave_key = -1;
+  }
   for (hipStream_t st : aux_streams) (void) hipStreamDestroy(st);
   for (hipEvent_t e : aux_done) (void) hipEventDestroy(e);
   aux_streams.clear(); aux_done.clear();
@@ -345,27 +351,32 @@ void miso_batch::upload(int dev) {
   // the general kernel's wavefronts loop to their largest K and longest draw list: group alike.
   // Paired-end (sampler_grp gives every chain of a launch the same lanes): genes of very different sizes -- real
   // read counts, 20 ... 10^5 pairs per gene; the reference costs O(reads) per gene, miso_paired.c:393-552 -- are
-  // split into size buckets per isoform-count class, each its own launch beside the others: genes of >= 8 x the
-  // class's median drawing pairs take at least 32 lanes per chain, genes of >= 32 x (and >= 4096 pairs) a whole
-  // workgroup (256 lanes, kernels_grp.inl WIDE).  MISO_NO_PE_BUCKETS=1: one launch per class as before (A/B, tests).
+  // split into size buckets per isoform-count class, each its own launch beside the others.  How many lanes a gene
+  // needs follows from its SHARE of the batch's work (drawing quads x isoforms): the batch takes W / (lanes of the
+  // device) at best, a chain on L lanes w / L, and a chain should be done in half of that -- L >= 2 x device lanes x
+  // w / W.  Up to 1.5 x the rule's 16 lanes: the class's normal launch; up to 48: at least 32 lanes; beyond: one
+  // chain per workgroup (256 lanes, kernels_grp.inl WIDE); beyond 384: several workgroups (coop.hpp), one per 256
+  // lanes needed.  Never more lanes than the gene has pairs of quads.  MISO_NO_PE_BUCKETS=1: one launch per class as
+  // before (A/B, tests).
   auto kc_of = [](int K) { return K <= 4 ? 4 : (K <= 8 ? 8 : (K <= 12 ? 12 : (K <= 16 ? 16 : 32))); };
-  std::vector<int> bucket(n, 0);   // 0 normal, 1 at least 32 lanes, 2 workgroup-wide
+  std::vector<int> bucket(n, 0);   // 0 normal, 1 at least 32 lanes, 2 workgroup-wide (coop_n[event] workgroups)
+  coop_n.assign(n, 1);
   if (p.paired && std::getenv("MISO_NO_PE_BUCKETS") == nullptr) {
-    std::vector<int> sizes[33];
-    for (int i : gen) sizes[kc_of(events[i].K)].push_back(events[i].n_draw);
-    double median[33] = {0};
-    for (int kc : {4, 8, 12, 16, 32})
-      if (!sizes[kc].empty()) {
-        std::nth_element(sizes[kc].begin(), sizes[kc].begin() + sizes[kc].size() / 2, sizes[kc].end());
-        median[kc] = std::max(1, sizes[kc][sizes[kc].size() / 2]);
-      }
+    double W = 0;
+    for (int i : gen) W += static_cast<double>((events[i].n_draw + 3) / 4) * events[i].K;
+    const double device_lanes = 2048.0 * 64.0;
     const bool dense_ok = std::getenv("MISO_NO_PE_DENSE") == nullptr;
+    const bool coop_on = std::getenv("MISO_NO_COOP") == nullptr;
     for (int i : gen) {
       const PackedEvent &e = events[i];
-      const double med = median[kc_of(e.K)];
+      const int nq = (e.n_draw + 3) / 4;
+      const double need = W > 0 ? 2.0 * device_lanes * (static_cast<double>(nq) * e.K) / W : 0.0;
       const bool can_wide = dense_ok && !e.draw_dense.empty() && e.K >= 3 && e.K <= PE_DENSE_KMAX;
-      if (can_wide && e.n_draw >= 4096 && e.n_draw >= 32.0 * med) bucket[i] = 2;
-      else if (e.n_draw >= 256 && e.n_draw >= 8.0 * med) bucket[i] = 1;
+      if (can_wide && need > 48.0 && nq >= 512) {
+        bucket[i] = 2;
+        if (coop_on && need > 384.0)
+          coop_n[i] = std::max(1, std::min({COOP_MAX_N, static_cast<int>(std::ceil(need / 256.0)), nq / 512}));
+      } else if (need > 24.0 && nq >= 64) bucket[i] = 1;
     }
   }
   std::stable_sort(gen.begin(), gen.end(), [&](int x, int y) {
@@ -400,7 +411,7 @@ void miso_batch::upload(int dev) {
     HIP_OK(hipMemcpy(d_fp, fd.prob.data(), fd.prob.size() * 8, hipMemcpyHostToDevice));
   }
   uploaded = true;
-  pool_cleared = false;
+  pool_cleared = false; launched_once = false;
 }
 
 void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
@@ -421,6 +432,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   }
   lanes_per_chain = 0;
   last_kernels.clear();
+  if (!launched_once) coop_wgs_used = 0;
 
   // ---- two-isoform events: sampler_k2<G> ----
   const size_t k2_fp = p.paired ? align_up(fd.prob.size() * 8, 16) : 0;
@@ -505,7 +517,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     return G >= 2 && G <= 32 && !(G & (G - 1)) &&
            fp_bytes + 4 * static_cast<size_t>(64 / G) * grp_slice_bytes(run.kmax, sh.qs, sh.ts) <= LDS_MAX;
   };
-  auto launch_grp = [&](KernelArgs ka, const GenRun &run, const GrpShape &sh, int G, hipStream_t st) {
+  auto launch_grp = [&](KernelArgs ka, GenRun &run, const GrpShape &sh, int G, hipStream_t st) {
     const long chains = static_cast<long>(run.count) * p.noChains;
     ka.slot_event = d_slots + n_k2 + run.first; ka.n_slots = run.count;
     ka.kstride = run.kmax; ka.cstride = sh.qs; ka.tstride = sh.ts;
@@ -517,8 +529,33 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       if (!ka.pe_dense) MISO_FAIL(MISO_EINTERNAL, "workgroup-wide paired-end chains need the dense records");
       const size_t lds0 = align_up(fp_bytes + 4 * static_cast<size_t>(grp_slice_bytes(run.kmax, 0, sh.ts)), 16);
       ka.red_off = static_cast<int32_t>(lds0);
-      const size_t lds = lds0 + 64;
-      const unsigned grid = static_cast<unsigned>(chains);
+      const size_t lds = lds0 + 96;
+      // Workgroups per chain: what upload() derived from the gene's share of the batch's work (coop_n), at most
+      // COOP_MAX_N, all cooperative workgroups of the batch together at most COOP_MAX_WGS (coop.hpp: they must all be
+      // resident at once).  MISO_NO_COOP=1: one workgroup per chain; MISO_COOP_DRAWS=n: one per n drawing pairs (tests).
+      if (!run.d_coop_tab) {
+        run.coop_tab.clear(); run.coop_chains = 0;
+        const bool coop_on = std::getenv("MISO_NO_COOP") == nullptr;
+        const int per_wg = std::getenv("MISO_COOP_DRAWS") ? std::max(256, std::atoi(std::getenv("MISO_COOP_DRAWS"))) : 8192;
+        for (long c = 0; c < chains; c++) {
+          const int ev_i = h_slots[n_k2 + run.first + c / p.noChains];
+          const int nd = events[ev_i].n_draw;
+          int nw = !coop_on ? 1 : (std::getenv("MISO_COOP_DRAWS") ? std::min(COOP_MAX_N, std::max(1, (nd + per_wg - 1) / per_wg)) : coop_n[ev_i]);
+          if (nw > 1 && coop_wgs_used + nw > COOP_MAX_WGS) nw = std::max(1, COOP_MAX_WGS - coop_wgs_used);
+          if (nw > 1) coop_wgs_used += nw;
+          for (int r = 0; r < nw; r++) {
+            run.coop_tab.push_back(static_cast<int32_t>(c)); run.coop_tab.push_back(r); run.coop_tab.push_back(nw);
+            run.coop_tab.push_back(nw > 1 ? run.coop_chains : 0);
+          }
+          if (nw > 1) run.coop_chains++;
+        }
+        HIP_OK(hipMalloc(reinterpret_cast<void **>(&run.d_coop_tab), run.coop_tab.size() * sizeof(int32_t)));
+        HIP_OK(hipMemcpy(run.d_coop_tab, run.coop_tab.data(), run.coop_tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_OK(hipMalloc(reinterpret_cast<void **>(&run.d_coop_mem), std::max(1, run.coop_chains) * COOP_WORDS * sizeof(uint32_t)));
+      }
+      HIP_OK(hipMemsetAsync(run.d_coop_mem, 0, std::max(1, run.coop_chains) * COOP_WORDS * sizeof(uint32_t), st));
+      ka.coop_tab = run.d_coop_tab; ka.coop_mem = run.d_coop_mem;
+      const unsigned grid = static_cast<unsigned>(run.coop_tab.size() / 4);
 #define MISO_GRP_WIDE(KC)                                                                                  \
   {                                                                                                        \
     HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sampler_grp<64, true, KC, true>),           \
@@ -1186,6 +1223,25 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     HIP_OK(hipStreamWaitEvent(aux_streams[i - 1], ev0, 0));
     return aux_streams[i - 1];
   };
+  // chains on several workgroups first: their workgroups must all be resident at once (coop.hpp), which the idle
+  // device guarantees; what is launched after them never waits for them
+  auto launch_gen_run = [&](size_t ri) {
+    GenRun &run = gen_runs[ri];
+    const int G = grp_G[ri];
+    if (flat_nc[ri] > 0) {
+      last_kernels += std::string(last_kernels.empty() ? "" : ",") + flat_name(run);
+      launch_flat(a, run, flat_nc[ri], flat_nc_max[ri], stream_for_next());
+      return;
+    }
+    last_kernels += std::string(last_kernels.empty() ? "" : ",") +
+                    (run.wide ? "sampler_grp<64, true, " + std::to_string(run.kc) + ", true>"
+                              : (G == 64 ? std::string("sampler_wave<")
+                                         : "sampler_grp<" + std::to_string(G) + ", ") +
+                                    (p.paired ? "true" : "false") +
+                                    (G == 64 ? std::string(">") : ", " + std::to_string(run.kc) + ">"));
+    launch_grp(a, run, grp_sh[ri], G, stream_for_next());
+  };
+  for (size_t ri = 0; ri < gen_runs.size(); ri++) if (gen_runs[ri].wide) launch_gen_run(ri);
   if (n_k2w > 0 && k2w_multi) {
     lanes_per_chain = k2w_plan.seg_lanes[k2w_plan.n_segs - 1];
     last_kernels = "sampler_k2_multi<2, " + std::to_string(k2w_plan.wpb) + ">";
@@ -1209,28 +1265,13 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       launch_k2(a, k2_G, stream_for_next());
     }
   }
-  for (size_t ri = 0; ri < gen_runs.size(); ri++) {
-    const GenRun &run = gen_runs[ri];
-    const int G = grp_G[ri];
-    if (flat_nc[ri] > 0) {
-      last_kernels += std::string(last_kernels.empty() ? "" : ",") + flat_name(run);
-      launch_flat(a, gen_runs[ri], flat_nc[ri], flat_nc_max[ri], stream_for_next());
-      continue;
-    }
-    last_kernels += std::string(last_kernels.empty() ? "" : ",") +
-                    (run.wide ? "sampler_grp<64, true, " + std::to_string(run.kc) + ", true>"
-                              : (G == 64 ? std::string("sampler_wave<")
-                                         : "sampler_grp<" + std::to_string(G) + ", ") +
-                                    (p.paired ? "true" : "false") +
-                                    (G == 64 ? std::string(">") : ", " + std::to_string(run.kc) + ">"));
-    launch_grp(a, run, grp_sh[ri], G, stream_for_next());
-  }
+  for (size_t ri = 0; ri < gen_runs.size(); ri++) if (!gen_runs[ri].wide) launch_gen_run(ri);
   for (size_t i = 1; i < kernel_no && i <= aux_streams.size() && std::getenv("MISO_SERIAL_KERNELS") == nullptr; i++) {
     HIP_OK(hipEventRecord(aux_done[i - 1], aux_streams[i - 1]));
     HIP_OK(hipStreamWaitEvent(stream, aux_done[i - 1], 0));
   }
   HIP_OK(hipEventRecord(ev1, stream));
-  launched = true; downloaded = false; summarized = false; compared = false;
+  launched = true; launched_once = true; downloaded = false; summarized = false; compared = false;
 }
 
 void miso_batch::sync(float *ms) {
@@ -1239,6 +1280,15 @@ void miso_batch::sync(float *ms) {
   HIP_OK(hipStreamSynchronize(stream));
   HIP_OK(hipEventElapsedTime(&last_ms, ev0, ev1));
   if (ms) *ms = last_ms;
+  // chains on several workgroups: did any group give up waiting for its members (coop.hpp)?
+  for (const GenRun &run : gen_runs) {
+    if (!run.d_coop_mem || run.coop_chains == 0) continue;
+    std::vector<uint32_t> w(static_cast<size_t>(run.coop_chains) * COOP_WORDS);
+    HIP_OK(hipMemcpy(w.data(), run.d_coop_mem, w.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (int c = 0; c < run.coop_chains; c++)
+      if (w[static_cast<size_t>(c) * COOP_WORDS + 1] != 0)
+        MISO_FAIL(MISO_EINTERNAL, "a chain on several workgroups timed out waiting for its workgroups");
+  }
 }
 
 // Posterior mean and Chen-Shao credible interval of every isoform, computed where the samples are

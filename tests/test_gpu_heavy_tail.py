@@ -186,7 +186,10 @@ def test_mixed_pair_counts_three_or_more_isoforms_paired_end_bit_exact(orc, K, c
         assert r.rc == 0
         cpu.append(r)
     names = []
-    for v in (dict(), dict(MISO_NO_PE_BUCKETS="1"), dict(MISO_PE_FORCE_EXACT="1")):
+    # (MISO_COOP_DRAWS: drawing pairs per workgroup of a chain on SEVERAL workgroups, coop.hpp: 1024 puts the two largest
+    # genes on ~10 and ~4 workgroups; MISO_NO_COOP: one workgroup per chain)
+    for v in (dict(), dict(MISO_NO_PE_BUCKETS="1"), dict(MISO_PE_FORCE_EXACT="1"), dict(MISO_COOP_DRAWS="1024"),
+              dict(MISO_NO_COOP="1")):
         with _env(**v):
             b = miso_amd.Batch(36, paired=True, mean=250.0, var=900.0, device_match=True, **kw)
             for exons, isoforms, g, pos, cig in evs:
