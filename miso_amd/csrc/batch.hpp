@@ -47,6 +47,10 @@ struct miso_batch {
   bool use_delta = true;          // paired-end: MODE 2 events first in the list (fixed at upload)
   miso::LanePlan k2_plan;         // sampler_k2_multi: the runs of equal lanes per chain (runtime.hip), valid for k2_plan_key
   long k2_plan_key = -1;
+  struct K2Coop {                 // a plan's chains on several workgroups (coop.hpp): table, scratch
+    int32_t *d_tab = nullptr; uint32_t *d_mem = nullptr; int chains = 0; long key = -1;
+  };
+  K2Coop k2_coop_se, k2w_coop;
   miso::LanePlan k2w_plan;        // the same for the paired-end MODE 2 events (sampler_k2_multi<2, 4>)
   long k2w_plan_key = -1;
   int n_k2 = 0, n_gen = 0;

@@ -73,7 +73,7 @@ struct ChainStats {
 constexpr int FLAT_WIDE = 0x100;  // sampler_flat wave_tab: the workgroup's four wavefronts share ONE chain
 constexpr int K2_MAX_SEGS = 16;
 constexpr int K2_WIDE = 512;   // seg_lanes value: one chain per workgroup
-constexpr int K2_RED_BYTES = 2 * 8 * 16;   // two buffers x (up to) 8 wavefronts x {int64 score sum, int count, int bad}
+constexpr int K2_RED_BYTES = 2 * 8 * 16 + 16;   // two buffers x (up to) 8 wavefronts x {int64 score sum, int count, int bad} + the barrier's flag
 
 struct KernelArgs {
   const DevEvent *events;

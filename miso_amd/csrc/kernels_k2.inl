@@ -30,6 +30,7 @@
 #include "miso_detmath.h"
 #include "miso_philox.h"
 #include "gibbs_rng.hpp"
+#include "coop.hpp"
 
 #pragma clang fp contract(off)
 
@@ -238,7 +239,18 @@ __device__ __forceinline__ int32_t k2_lds_i32(uint32_t addr) { return *reinterpr
 template <int G, int MODE, int WPB, bool WIDE = false>
 __device__ __forceinline__ void k2_body(const KernelArgs &a, unsigned block_x, unsigned grid_x) {
   static_assert(!WIDE || G == 64, "a workgroup-wide chain uses whole wavefronts");
-  constexpr int GE = WIDE ? 64 * WPB : G;          // lanes striding over one chain's draw quads
+  // WIDE: which chain this workgroup works on, alone or as one of several (coop.hpp; a.coop_tab is indexed by the
+  // workgroup's number within its run)
+  CoopGroup cg{0, 1, nullptr};
+  unsigned wide_chain = block_x;
+  if (WIDE && a.coop_tab) {
+    const int32_t *t = a.coop_tab + 4 * static_cast<size_t>(block_x);
+    wide_chain = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(t[0]));
+    cg.rank = __builtin_amdgcn_readfirstlane(t[1]); cg.n = __builtin_amdgcn_readfirstlane(t[2]);
+    cg.mem = a.coop_mem + static_cast<size_t>(__builtin_amdgcn_readfirstlane(t[3])) * COOP_WORDS;
+  }
+  uint32_t coop_step = 0; bool coop_ok = true;
+  const int GE = WIDE ? 64 * WPB * cg.n : G;       // lanes striding over one chain's draw quads
   constexpr bool PE = MODE != 0;
   constexpr bool PEW = MODE == 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_k2[];
@@ -266,11 +278,11 @@ __device__ __forceinline__ void k2_body(const KernelArgs &a, unsigned block_x, u
   const bool lane_used = grp_raw < CPW;            // 64 % G lanes at the top of the wave idle
   const int grp = lane_used ? grp_raw : CPW - 1;
   const int base_lane = grp * G;
-  const int sub = WIDE ? static_cast<int>(threadIdx.x) : (lane_used ? lane - base_lane : 0);
+  const int sub = WIDE ? cg.rank * 64 * WPB + static_cast<int>(threadIdx.x) : (lane_used ? lane - base_lane : 0);
   const int lsub = WIDE ? lane : sub;              // position among the chain's lanes of THIS wavefront
   const int role = lsub % NR;
   const long n_chains = static_cast<long>(a.n_slots) * a.C;
-  long wave_id = WIDE ? static_cast<long>(block_x) : static_cast<long>(block_x) * WPB + (threadIdx.x >> 6);
+  long wave_id = WIDE ? static_cast<long>(wide_chain) : static_cast<long>(block_x) * WPB + (threadIdx.x >> 6);
   if (!WIDE && WPB == 8 && a.pair_waves) {
     const int w = threadIdx.x >> 6;
     const long p = 4 * static_cast<long>(block_x) + (w & 3);             // pair index: heaviest first
@@ -357,8 +369,27 @@ __device__ __forceinline__ void k2_body(const KernelArgs &a, unsigned block_x, u
     int td = 0, tb = 0; int64_t ta = 0;
 #pragma unroll
     for (int w = 0; w < WPB; w++) { const Red r = red[w]; td += r.d0; ta += r.acc; tb |= r.bad; }
-    d0 = td; acc = ta; bad = tb;
     red_par ^= 1;
+    if (cg.n > 1) {   // ... and the chain's other workgroups' (coop.hpp): accumulator coop_step % 3, one barrier
+      uint32_t *accp = coop_acc(cg, coop_step);
+      if (threadIdx.x < 64) {
+        if (lane == 0) {
+          if (td) atomicAdd(&accp[4], static_cast<uint32_t>(td));
+          if (PE) { atomicAdd(reinterpret_cast<unsigned long long *>(accp), static_cast<unsigned long long>(ta)); if (tb) atomicOr(&accp[2], 1u); }
+        }
+        if (cg.rank == 0 && lane < COOP_ACC) atomicExch(&coop_acc(cg, coop_step + 1)[lane], 0u);   // next step's, read last two steps ago
+        __threadfence();   // this wavefront's atomics are at the L2 before the workgroup announces its arrival
+      }
+      int *flag = reinterpret_cast<int *>(smem_k2 + a.red_off + 2 * WPB * 16);
+      coop_ok = coop_barrier(cg, coop_step, flag) && coop_ok;
+      td = static_cast<int>(coop_load(&accp[4]));
+      if (PE) {
+        ta = static_cast<int64_t>((static_cast<uint64_t>(coop_load(&accp[1])) << 32) | coop_load(&accp[0]));
+        tb = static_cast<int>(coop_load(&accp[2]));
+      }
+      coop_step++;
+    }
+    d0 = td; acc = ta; bad = tb;
   };
 
   // Gibbs step for the current psi (miso.c:30-91 restricted to two compatible isoforms)
@@ -588,6 +619,7 @@ __device__ __forceinline__ void k2_body(const KernelArgs &a, unsigned block_x, u
 
   double zbuf = 0.0; uint32_t awbuf = 0u;   // this lane's share of the next NR iterations' MH draws
   for (int m = 0; m < a.M; m++) {
+    if (WIDE && !coop_ok) return;   // the chain's workgroups gave up waiting for each other (coop.hpp): the host reports it
     hash = (hash ^ static_cast<uint32_t>(cnt0)) * 0x100000001B3ull;
     hash = (hash ^ static_cast<uint32_t>(cnt1)) * 0x100000001B3ull;
     if (trace && writer) {

@@ -13,6 +13,19 @@ namespace {
 
 struct Planner {
   const int *nd; int n, C; const int *widths; int nw; int wide_wpb, wpb, resident, max_cpw; const LaneCost &cost;
+  int coop_max;   // most workgroups one chain may use (1 = a chain ends at its workgroup)
+  static constexpr double wide_extra = 150.0;   // barrier + LDS round trip of a workgroup-wide chain's reduction
+  static constexpr double coop_extra = 1200.0;  // + atomics and the barrier between workgroups (~ 2 us)
+
+  // workgroups of a workgroup-wide chain: the fewest that keep its step within D (coop.hpp), each with at least
+  // eight quads per lane
+  int wide_wgs(double D, int ndraw) const {
+    const int lanes = 64 * wide_wpb;
+    if (coop_max <= 1 || cost.smooth_step(lanes, ndraw) + wide_extra <= D) return 1;
+    const int cap = std::max(1, std::min(coop_max, (ndraw >> 2) / (std::max(1, cost.coop_min_quads) * lanes)));
+    for (int m = 2; m <= cap; m++) if (cost.smooth_step(lanes * m, ndraw) + wide_extra + coop_extra <= D) return m;
+    return cap;
+  }
 
   // the narrowest width whose wavefront step stays within D; never more lanes than the chain has pairs of draw
   // quads to stride over; the whole workgroup when even 64 lanes overshoot and the chain has work for all of them
@@ -29,9 +42,13 @@ struct Planner {
     if (wide_wpb > 0 && last == 64 && ndraw >= 64 * wide_wpb * 16 && cost.smooth_step(64, ndraw) > D) return K2_WIDE;
     return last;
   }
-  long wgs_of(int lanes, long events) const {
+  long wgs_of(int lanes, long events, double D = 0, int first = 0) const {
     const long chains = events * C;
-    if (lanes == K2_WIDE) return chains;
+    if (lanes == K2_WIDE) {
+      long w = 0;
+      for (long e = 0; e < events; e++) w += static_cast<long>(C) * wide_wgs(D, nd[first + e]);
+      return w;
+    }
     const int cpw = 64 / lanes;
     return ((chains + cpw - 1) / cpw + wpb - 1) / wpb;
   }
@@ -46,7 +63,7 @@ struct Planner {
       int j = i + 1;
       if (segs == K2_MAX_SEGS - 1) j = n;
       else while (j < n && (nd[j] == nd[j - 1] || pick(D, nd[j]) == G)) j++;
-      const long w = wgs_of(G, j - i);
+      const long w = wgs_of(G, j - i, D, i);
       if (out) {
         out->seg_slot[segs] = i; out->seg_block[segs] = static_cast<int32_t>(wgs); out->seg_lanes[segs] = G;
         out->seg_slot[segs + 1] = j; out->seg_block[segs + 1] = static_cast<int32_t>(wgs + w);
@@ -62,11 +79,12 @@ struct Planner {
 }  // namespace
 
 LanePlan plan_lanes(const int *n_draw, int n_events, int chains, const int *widths, int n_widths, int wide_wpb,
-                    int wpb, int resident_wgs, int max_cpw, const LaneCost &cost, double forced_target) {
+                    int wpb, int resident_wgs, int max_cpw, const LaneCost &cost, double forced_target, int coop_max) {
   LanePlan best;
   if (n_events <= 0 || chains <= 0 || n_widths <= 0) return best;
-  const Planner P{n_draw, n_events, chains, widths, n_widths, wide_wpb, wpb, std::max(1, resident_wgs), max_cpw, cost};
-  const double wide_extra = 150.0;   // barrier + LDS round trip of a workgroup-wide chain's reduction
+  const Planner P{n_draw, n_events, chains, widths, n_widths, wide_wpb, wpb, std::max(1, resident_wgs), max_cpw, cost,
+                  std::max(1, coop_max)};
+  const double wide_extra = Planner::wide_extra;
   // what a bound D costs: the runs, then every wavefront's step (the list is ordered: a wavefront's first chain is
   // its longest)
   auto evaluate = [&](double D) {
@@ -78,12 +96,15 @@ LanePlan plan_lanes(const int *n_draw, int n_events, int chains, const int *widt
       const long c0 = static_cast<long>(plan.seg_slot[s]) * chains, c1 = static_cast<long>(plan.seg_slot[s + 1]) * chains;
       double first = 0;
       if (G == K2_WIDE) {
+        plan.wide_wgs.clear();
         for (long c = c0; c < c1; c++) {
-          const double w = cost.wave_step(64 * wide_wpb, n_draw[c / chains]) + wide_extra;
-          plan.est_total += w * wide_wpb; plan.est_max = std::max(plan.est_max, w); plan.est_last = w;
+          const int m = P.wide_wgs(D, n_draw[c / chains]);
+          if (c % chains == 0) plan.wide_wgs.push_back(m);
+          const double w = cost.wave_step(64 * wide_wpb * m, n_draw[c / chains]) + wide_extra + (m > 1 ? Planner::coop_extra : 0.0);
+          plan.est_total += w * wide_wpb * m; plan.est_max = std::max(plan.est_max, w); plan.est_last = w;
           if (c == c0) first = w;
+          plan.waves += static_cast<long>(wide_wpb) * m;
         }
-        plan.waves += (c1 - c0) * wide_wpb;
         plan.est_pair = std::max(plan.est_pair, 2.0 * first);   // a SIMD's two wavefronts belong to the same chain
         continue;
       }

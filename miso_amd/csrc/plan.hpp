@@ -7,6 +7,7 @@
 #pragma once
 
 #include <cstdint>
+#include <vector>
 
 #include "device.hpp"
 
@@ -21,6 +22,7 @@ struct LaneCost {
   double block = 48;
   int uq = 2;              // blocks per lane and trip of the read loop (trips are whole)
   bool paired = false;     // paired-end loop: 2 x trips + 1 blocks; single-end: uq x trips (+ 1 for a partial quad)
+  int coop_min_quads = 8;  // a chain on several workgroups keeps at least this many quads per lane (tests lower it)
   // exact: what the kernels' loops do (trips are whole, a partial quad costs a block)
   double blocks_per_lane(int lanes, int n_draw) const {
     const int nfq = n_draw >> 2;
@@ -63,6 +65,7 @@ struct LanePlan {
   double est_pair = 0;       // one round: the busiest SIMD = heaviest + lightest wavefront of a run (a.pair_waves)
   int wpb = 8;               // wavefronts per workgroup the plan was made for
   double est = 0;            // the launch's estimated duration in VALU issue slots of one SIMD (what plan_lanes minimises)
+  std::vector<int> wide_wgs; // per event of the K2_WIDE run (the first, if any): workgroups per chain (coop.hpp), 1 = its own only
 };
 
 // n_draw: the launch's events' drawing reads, most first; `chains` chains per event; widths: the instantiated lanes
@@ -70,6 +73,7 @@ struct LanePlan {
 // workgroup; resident_wgs: workgroups the device (or this kernel's share of it) holds at once; max_cpw: most
 // chains per wavefront the kernel's LDS allows (64 = no limit).
 LanePlan plan_lanes(const int *n_draw, int n_events, int chains, const int *widths, int n_widths, int wide_wpb,
-                    int wpb, int resident_wgs, int max_cpw, const LaneCost &cost, double forced_target = 0.0);
+                    int wpb, int resident_wgs, int max_cpw, const LaneCost &cost, double forced_target = 0.0,
+                    int coop_max = 1);
 
 }  // namespace miso

@@ -94,6 +94,11 @@ void miso_batch::release() {
     if (run.d_coop_mem) (void) hipFree(run.d_coop_mem);
     run.d_wave_tab = nullptr; run.d_coop_tab = nullptr; run.d_coop_mem = nullptr; run.wave_key = -1;
   }
+  for (K2Coop *cc : {&k2_coop_se, &k2w_coop}) {
+    if (cc->d_tab) (void) hipFree(cc->d_tab);
+    if (cc->d_mem) (void) hipFree(cc->d_mem);
+    *cc = K2Coop{};
+  }
   for (hipStream_t st : aux_streams) (void) hipStreamDestroy(st);
   for (hipEvent_t e : aux_done) (void) hipEventDestroy(e);
   aux_streams.clear(); aux_done.clear();
@@ -960,6 +965,8 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   // single-width / two-width launches above.  The plan depends on the list, the chains and this kernel's share of
   // the device only: made once per upload.  MISO_K2_COST="block,step1,step2,step3,step4" overrides the cost model,
   // MISO_K2_TARGET=x forces the bound on a wavefront's step (tests: small batches with many widths).
+  // (workgroup-wide chains may use several workgroups, coop.hpp; MISO_NO_COOP=1: their own only)
+  const int coop_max = std::getenv("MISO_NO_COOP") ? 1 : COOP_MAX_N;
   bool k2_multi = false;
   {
     const int count = n_k2 - n_k2w;
@@ -971,13 +978,14 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     if (p.paired && count > 0 && pe1_cpw >= 1 && std::getenv("MISO_LANES_PER_CHAIN") == nullptr && !(off && std::atoi(off) == 0)) {
       const int resident = std::max(1, slots_for(static_cast<long>(count) * p.noChains) / 4);
       const long key = static_cast<long>(resident) * 64 + p.noChains;
-      if (k2_plan_key != key || std::getenv("MISO_K2_TARGET") || std::getenv("MISO_K2_COST")) {
+      if (k2_plan_key != key || std::getenv("MISO_K2_TARGET") || std::getenv("MISO_K2_COST") || std::getenv("MISO_COOP_MIN_QUADS")) {
         static const int widths[] = {4, 8, 16, 32, 64};
         LaneCost cost = k2_cost_paired();
+        if (const char *env = std::getenv("MISO_COOP_MIN_QUADS")) cost.coop_min_quads = std::max(1, std::atoi(env));
         std::vector<int> nd(count);
         for (int i = 0; i < count; i++) nd[i] = events[h_slots[n_k2w + i]].n_draw;
         const double forced = std::getenv("MISO_K2_TARGET") ? std::atof(std::getenv("MISO_K2_TARGET")) : 0.0;
-        k2_plan = plan_lanes(nd.data(), count, p.noChains, widths, 5, 4, 4, resident, pe1_cpw, cost, forced);
+        k2_plan = plan_lanes(nd.data(), count, p.noChains, widths, 5, 4, 4, resident, pe1_cpw, cost, forced, coop_max);
         k2_plan_key = key;
       }
       k2_multi = k2_plan.n_segs > 0;
@@ -985,21 +993,22 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     if (!p.paired && count > 0 && std::getenv("MISO_LANES_PER_CHAIN") == nullptr && !(off && std::atoi(off) == 0)) {
       const int resident = std::max(1, slots_for(static_cast<long>(count) * p.noChains) / 8);
       const long key = static_cast<long>(resident) * 64 + p.noChains;
-      if (k2_plan_key != key || std::getenv("MISO_K2_TARGET") || std::getenv("MISO_K2_COST") || std::getenv("MISO_K2_WPB")) {
+      if (k2_plan_key != key || std::getenv("MISO_K2_TARGET") || std::getenv("MISO_K2_COST") || std::getenv("MISO_COOP_MIN_QUADS") || std::getenv("MISO_K2_WPB")) {
         static const int widths[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 32, 64};
         LaneCost cost = k2_cost_single();
         if (const char *env = std::getenv("MISO_K2_COST"))
           std::sscanf(env, "%lf,%lf,%lf,%lf,%lf", &cost.block, &cost.step[1], &cost.step[2], &cost.step[3], &cost.step[4]);
+        if (const char *env = std::getenv("MISO_COOP_MIN_QUADS")) cost.coop_min_quads = std::max(1, std::atoi(env));
         std::vector<int> nd(count);
         for (int i = 0; i < count; i++) nd[i] = events[h_slots[n_k2w + i]].n_draw;
         const double forced = std::getenv("MISO_K2_TARGET") ? std::atof(std::getenv("MISO_K2_TARGET")) : 0.0;
-        k2_plan = plan_lanes(nd.data(), count, p.noChains, widths, 12, 8, 8, resident, 64, cost, forced);
+        k2_plan = plan_lanes(nd.data(), count, p.noChains, widths, 12, 8, 8, resident, 64, cost, forced, coop_max);
         // several rounds: smaller workgroups (a workgroup starts when ALL its wavefronts' slots are free; with 8 the
         // slots of early finishers idle: MISO defaults on 40 000 events 425 ms, with 4: see profiles/r03_k2_multi_ab.txt)
         int wpb = k2_plan.rounds == 1 ? 8 : 4;
         if (const char *env = std::getenv("MISO_K2_WPB")) wpb = std::atoi(env);
         if (wpb != 8 && wpb != 4 && wpb != 1) MISO_FAIL(MISO_EINVAL, "MISO_K2_WPB must be 8, 4 or 1");
-        if (wpb != 8) k2_plan = plan_lanes(nd.data(), count, p.noChains, widths, 12, wpb >= 4 ? wpb : 0, wpb, resident * 8 / wpb, 64, cost, forced);
+        if (wpb != 8) k2_plan = plan_lanes(nd.data(), count, p.noChains, widths, 12, wpb >= 4 ? wpb : 0, wpb, resident * 8 / wpb, 64, cost, forced, coop_max);
         k2_plan_key = key;
       }
       k2_multi = k2_plan.n_segs > 0;
@@ -1016,21 +1025,22 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       const int max_cpw = static_cast<int>(std::max<long>(0, lds_left / static_cast<long>(4 * k2w_tab)));
       const int resident = std::max(1, slots_for(static_cast<long>(n_k2w) * p.noChains) / 4);
       const long key = static_cast<long>(resident) * 64 + p.noChains;
-      if (max_cpw >= 1 && (k2w_plan_key != key || std::getenv("MISO_K2_TARGET") || std::getenv("MISO_K2_COST") || std::getenv("MISO_K2W_WPB"))) {
+      if (max_cpw >= 1 && (k2w_plan_key != key || std::getenv("MISO_K2_TARGET") || std::getenv("MISO_K2_COST") || std::getenv("MISO_COOP_MIN_QUADS") || std::getenv("MISO_K2W_WPB"))) {
         static const int widths[] = {4, 8, 16, 32, 64};
         LaneCost cost = k2_cost_paired();
         if (const char *env = std::getenv("MISO_K2_COST"))
           std::sscanf(env, "%lf,%lf,%lf,%lf,%lf", &cost.block, &cost.step[1], &cost.step[2], &cost.step[3], &cost.step[4]);
+        if (const char *env = std::getenv("MISO_COOP_MIN_QUADS")) cost.coop_min_quads = std::max(1, std::atoi(env));
         std::vector<int> nd(n_k2w);
         for (int i = 0; i < n_k2w; i++) nd[i] = events[h_slots[i]].n_draw;
         const double forced = std::getenv("MISO_K2_TARGET") ? std::atof(std::getenv("MISO_K2_TARGET")) : 0.0;
-        k2w_plan = plan_lanes(nd.data(), n_k2w, p.noChains, widths, 5, 4, 4, resident, max_cpw, cost, forced);
+        k2w_plan = plan_lanes(nd.data(), n_k2w, p.noChains, widths, 5, 4, 4, resident, max_cpw, cost, forced, coop_max);
         // The widest a chain can be is its workgroup: 256 lanes with 4 wavefronts, 512 with 8 (one workgroup per CU,
         // twice the LDS each: the same chains per CU).  8-wavefront workgroups lose ~19 % when the launch runs in
         // several rounds (a workgroup starts when ALL its slots are free), so they are taken only when the largest
         // events would otherwise outlast the launch (hg19-like read counts: 218 ms -> 175 ms; uniform: 217 ms -> 259 ms, not taken; profiles/r03_pe_k2_wpb.txt).
         {
-          const LanePlan p8 = plan_lanes(nd.data(), n_k2w, p.noChains, widths, 5, 8, 8, std::max(1, resident / 2), max_cpw, cost, forced);
+          const LanePlan p8 = plan_lanes(nd.data(), n_k2w, p.noChains, widths, 5, 8, 8, std::max(1, resident / 2), max_cpw, cost, forced, coop_max);
           const char *env = std::getenv("MISO_K2W_WPB");
           if (env ? std::atoi(env) == 8 : 1.2 * p8.est < k2w_plan.est) k2w_plan = p8;
         }
@@ -1045,7 +1055,37 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       }
     }
   }
+  // which chain every workgroup of a plan's workgroup-wide run works on (coop.hpp); nothing to do when every chain
+  // has its workgroup to itself
+  auto k2_coop = [&](KernelArgs &ka, const LanePlan &pl, K2Coop &cc, hipStream_t st) {
+    ka.coop_tab = nullptr; ka.coop_mem = nullptr;
+    if (pl.n_segs == 0 || pl.seg_lanes[0] != K2_WIDE) return;
+    bool any = false;
+    for (int m : pl.wide_wgs) any |= m > 1;
+    if (!any) return;
+    if (cc.key != pl.seg_block[1] * 131 + static_cast<long>(pl.wide_wgs.size()) || !cc.d_tab) {
+      std::vector<int32_t> tab;
+      cc.chains = 0;
+      for (size_t e = 0; e < pl.wide_wgs.size(); e++)
+        for (int c = 0; c < p.noChains; c++) {
+          const int m = pl.wide_wgs[e];
+          for (int r = 0; r < m; r++) { tab.push_back(static_cast<int32_t>(e * p.noChains + c)); tab.push_back(r); tab.push_back(m); tab.push_back(m > 1 ? cc.chains : 0); }
+          if (m > 1) cc.chains++;
+        }
+      if (static_cast<int>(tab.size() / 4) != pl.seg_block[1]) MISO_FAIL(MISO_EINTERNAL, "lane plan and cooperative table disagree");
+      if (cc.d_tab) (void) hipFree(cc.d_tab);
+      if (cc.d_mem) (void) hipFree(cc.d_mem);
+      cc.d_tab = nullptr; cc.d_mem = nullptr;
+      HIP_OK(hipMalloc(reinterpret_cast<void **>(&cc.d_tab), tab.size() * sizeof(int32_t)));
+      HIP_OK(hipMemcpy(cc.d_tab, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+      HIP_OK(hipMalloc(reinterpret_cast<void **>(&cc.d_mem), std::max(1, cc.chains) * COOP_WORDS * sizeof(uint32_t)));
+      cc.key = pl.seg_block[1] * 131 + static_cast<long>(pl.wide_wgs.size());
+    }
+    HIP_OK(hipMemsetAsync(cc.d_mem, 0, std::max(1, cc.chains) * COOP_WORDS * sizeof(uint32_t), st));
+    ka.coop_tab = cc.d_tab; ka.coop_mem = cc.d_mem;
+  };
   auto launch_k2_multi = [&](KernelArgs ka, hipStream_t st, bool wpart = false) {
+    k2_coop(ka, wpart ? k2w_plan : k2_plan, wpart ? k2w_coop : k2_coop_se, st);
     if (wpart) {
       ka.slot_event = d_slots; ka.n_slots = n_k2w;
       ka.pair_waves = 0;
@@ -1146,10 +1186,12 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
         if (pl.seg_lanes[sg] == K2_WIDE) {
           for (long c = c0; c < c1; c++) {
             const int n = nd[c / C];
-            const int wl = 64 * pl.wpb;
+            const size_t we = static_cast<size_t>(c / C - pl.seg_slot[sg]);
+            const int m = we < pl.wide_wgs.size() ? pl.wide_wgs[we] : 1;     // workgroups of the chain (coop.hpp)
+            const int wl = 64 * pl.wpb * m;
             const int t = ((n >> 2) + 2 * wl - 1) / (2 * wl);
-            trips += pl.wpb * (p.paired ? 2 * t + 1 : 2 * t + ((n & 3) ? 1 : 0));
-            words += n; waves += pl.wpb;
+            trips += pl.wpb * m * (p.paired ? 2 * t + 1 : 2 * t + ((n & 3) ? 1 : 0));
+            words += n; waves += pl.wpb * m;
           }
         } else slice(c0, c1, pl.seg_lanes[sg]);
       }
@@ -1281,6 +1323,14 @@ void miso_batch::sync(float *ms) {
   HIP_OK(hipEventElapsedTime(&last_ms, ev0, ev1));
   if (ms) *ms = last_ms;
   // chains on several workgroups: did any group give up waiting for its members (coop.hpp)?
+  for (const K2Coop *cc : {&k2_coop_se, &k2w_coop}) {
+    if (!cc->d_mem || cc->chains == 0) continue;
+    std::vector<uint32_t> w(static_cast<size_t>(cc->chains) * COOP_WORDS);
+    HIP_OK(hipMemcpy(w.data(), cc->d_mem, w.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (int c = 0; c < cc->chains; c++)
+      if (w[static_cast<size_t>(c) * COOP_WORDS + 1] != 0)
+        MISO_FAIL(MISO_EINTERNAL, "a chain on several workgroups timed out waiting for its workgroups");
+  }
   for (const GenRun &run : gen_runs) {
     if (!run.d_coop_mem || run.coop_chains == 0) continue;
     std::vector<uint32_t> w(static_cast<size_t>(run.coop_chains) * COOP_WORDS);

@@ -40,8 +40,10 @@ def check_shape(runs, info, nd, chains, wpb):
     assert lanes == sorted(lanes, reverse=True) and len(set(lanes)) == len(lanes)   # wider for larger events, one run per width
     for r in runs:
         ch = r["events"] * chains
-        want = ch if r["lanes"] == WIDE else -(-(-(-ch // (64 // r["lanes"]))) // wpb)
-        assert r["wgs"] == want, r
+        if r["lanes"] == WIDE:      # one workgroup per chain, or several for the very largest (coop.hpp)
+            assert ch <= r["wgs"] <= 32 * ch, r
+        else:
+            assert r["wgs"] == -(-(-(-ch // (64 // r["lanes"]))) // wpb), r
 
 
 def test_uniform_batch_fills_the_device_in_one_round():
