@@ -133,6 +133,7 @@ MATRIX = [  # (id, label, shape overrides, events, reference runs of the row: (e
     ("pe_k10", "PE K=10, 1 chain, 7500 iters", dict(K=10, paired=True), 20000, (64, 8)),
     # BASELINE configs[3]: whole-gene mode, 3-20 isoforms per gene, paired-end; "events" are genes here
     ("pe_mix", "PE K=3..20 per gene (whole-gene mix), 1 chain, 7500 iters", dict(K=(3, 20), paired=True), 16384, (32, 1)),
+    ("pe_mix_hg19", "PE K=3..20 per gene, hg19-like read counts, 1 chain, 7500 iters", dict(K=(3, 20), paired=True, reads="hg19"), 16384, (32, 1)),
 ]
 
 
