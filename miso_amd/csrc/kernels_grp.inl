@@ -784,6 +784,10 @@ __global__ __launch_bounds__(256, PE ? MISO_GRP_PE_BLOCKS : (KC <= 8 ? MISO_GRP_
     __syncthreads();
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#ifdef MISO_GRP_WAVETIME   // tools/wave_time.py mix: how long every chain's wavefront ran (100 MHz), through ChainStats::hw_id
+  uint64_t wt_t0;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wt_t0) : : "memory");
+#endif
   const int grp = lane / G, sub = lane - grp * G;
   const long n_chains = static_cast<long>(a.n_slots) * a.C;
   // WIDE: which chain this workgroup works on, alone or as one of several (coop.hpp)
@@ -1395,6 +1399,12 @@ __global__ __launch_bounds__(256, PE ? MISO_GRP_PE_BLOCKS : (KC <= 8 ? MISO_GRP_
     if (sub == 0) {
       ChainStats *st = reinterpret_cast<ChainStats *>(a.out_pool + E.off_stats) + chain;
       st->counts_hash = hash; st->accepted = accepted; st->hw_id = 0;
+#ifdef MISO_GRP_WAVETIME
+      uint64_t wt_t1;
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wt_t1) : : "memory");
+      st->hw_id = static_cast<uint32_t>(wt_t1 - wt_t0);
+      st->counts_hash = wt_t0;   // when it started
+#endif
     }
   }
 }

@@ -370,12 +370,13 @@ void miso_batch::upload(int dev) {
     double W = 0;
     for (int i : gen) W += static_cast<double>((events[i].n_draw + 3) / 4) * events[i].K;
     const double device_lanes = 2048.0 * 64.0;
+    const double share_factor = std::getenv("MISO_PE_SHARE") ? std::atof(std::getenv("MISO_PE_SHARE")) : 2.0;
     const bool dense_ok = std::getenv("MISO_NO_PE_DENSE") == nullptr;
     const bool coop_on = std::getenv("MISO_NO_COOP") == nullptr;
     for (int i : gen) {
       const PackedEvent &e = events[i];
       const int nq = (e.n_draw + 3) / 4;
-      const double need = W > 0 ? 2.0 * device_lanes * (static_cast<double>(nq) * e.K) / W : 0.0;
+      const double need = W > 0 ? share_factor * device_lanes * (static_cast<double>(nq) * e.K) / W : 0.0;
       const bool can_wide = dense_ok && !e.draw_dense.empty() && e.K >= 3 && e.K <= PE_DENSE_KMAX;
       if (can_wide && need > 48.0 && nq >= 512) {
         bucket[i] = 2;
@@ -553,6 +554,14 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
             run.coop_tab.push_back(nw > 1 ? run.coop_chains : 0);
           }
           if (nw > 1) run.coop_chains++;
+        }
+        if (std::getenv("MISO_TIMING")) {
+          std::fprintf(stderr, "[miso] wide run kc=%d: %ld chains on %zu workgroups (%d on several:", run.kc, chains, run.coop_tab.size() / 4, run.coop_chains);
+          for (size_t i = 0; i < run.coop_tab.size(); i += 4)
+            if (run.coop_tab[i + 1] == 0 && run.coop_tab[i + 2] > 1)
+              std::fprintf(stderr, " %d x %d draws K=%d", run.coop_tab[i + 2], events[h_slots[n_k2 + run.first + run.coop_tab[i] / p.noChains]].n_draw,
+                           events[h_slots[n_k2 + run.first + run.coop_tab[i] / p.noChains]].K);
+          std::fprintf(stderr, ")\n");
         }
         HIP_OK(hipMalloc(reinterpret_cast<void **>(&run.d_coop_tab), run.coop_tab.size() * sizeof(int32_t)));
         HIP_OK(hipMemcpy(run.d_coop_tab, run.coop_tab.data(), run.coop_tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -1267,9 +1276,36 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   };
   // chains on several workgroups first: their workgroups must all be resident at once (coop.hpp), which the idle
   // device guarantees; what is launched after them never waits for them
+  // A size bucket whose lanes came out the same as the class's normal launch joins it: one launch (its chains stay
+  // in front: longest first), one hardware queue less to wait in (kernels of different streams share the process's
+  // hardware queues, and a kernel waits for the one before it in its queue).
+  std::vector<char> merged_into_prev(gen_runs.size(), 0);
+  // (measured, 16 384 genes of 3-20 isoforms: 4 queues 290 -> 254 ms merged; 8 queues 195 ms apart, 241 ms merged --
+  // the separate launches stagger the classes' starts; capi.hip asks for 8 queues)
+  const char *hwq = std::getenv("GPU_MAX_HW_QUEUES");
+  const bool merge_on = std::getenv("MISO_NO_PE_MERGE") == nullptr && (std::getenv("MISO_PE_MERGE") != nullptr || (hwq && std::atoi(hwq) < 8));
   auto launch_gen_run = [&](size_t ri) {
     GenRun &run = gen_runs[ri];
     const int G = grp_G[ri];
+    if (merged_into_prev[ri]) return;
+    if (merge_on && !run.wide && run.force_G && G != 64 && flat_nc[ri] == 0 && ri + 1 < gen_runs.size()) {
+      const GenRun &nx = gen_runs[ri + 1];
+      if (!nx.wide && !nx.force_G && nx.kc == run.kc && grp_G[ri + 1] == G && flat_nc[ri + 1] == 0 &&
+          nx.first == run.first + run.count) {
+        GenRun m;
+        m.first = run.first; m.count = run.count + nx.count; m.kc = run.kc;
+        m.kmax = std::max(run.kmax, nx.kmax); m.kmin = std::min(run.kmin, nx.kmin); m.maxq = std::max(run.maxq, nx.maxq);
+        m.maxcls = std::max(run.maxcls, nx.maxcls); m.nocls = run.nocls || nx.nocls; m.dense = run.dense && nx.dense;
+        const GrpShape msh = grp_shape(m);
+        if (grp_fits(m, msh, G)) {
+          merged_into_prev[ri + 1] = 1;
+          last_kernels += std::string(last_kernels.empty() ? "" : ",") + "sampler_grp<" + std::to_string(G) + ", " +
+                          (p.paired ? "true" : "false") + ", " + std::to_string(run.kc) + ">";
+          launch_grp(a, m, msh, G, stream_for_next());
+          return;
+        }
+      }
+    }
     if (flat_nc[ri] > 0) {
       last_kernels += std::string(last_kernels.empty() ? "" : ",") + flat_name(run);
       launch_flat(a, run, flat_nc[ri], flat_nc_max[ri], stream_for_next());
