@@ -65,6 +65,7 @@ struct miso_batch {
     bool dense = true;            // paired-end: every event has dense quad records (pe_dense)
     int force_G = 0;              // paired-end size bucket: at least this many lanes per chain (events several times the class's mean size)
     bool wide = false;            // paired-end size bucket: one chain per workgroup (sampler_grp<64, true, KC, true>)
+    bool wave64 = false;          // paired-end size bucket: one chain per wavefront (sampler_grp<64, true, KC>)
     // wide runs: which chain every workgroup works on, alone or as one of several (coop.hpp; runtime.hip launch_grp)
     std::vector<int32_t> coop_tab;
     int32_t *d_coop_tab = nullptr;

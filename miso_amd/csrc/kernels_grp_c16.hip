@@ -11,4 +11,5 @@ MISO_INSTANTIATE_GRP(8)
 MISO_INSTANTIATE_GRP(16)
 MISO_INSTANTIATE_GRP(32)
 template __global__ void sampler_grp<64, true, 16, true>(const KernelArgs);   // one chain per workgroup
+template __global__ void sampler_grp<64, true, 16>(const KernelArgs);         // one chain per wavefront
 }  // namespace miso

@@ -11,4 +11,5 @@ MISO_INSTANTIATE_GRP(8)
 MISO_INSTANTIATE_GRP(16)
 MISO_INSTANTIATE_GRP(32)
 template __global__ void sampler_grp<64, true, 8, true>(const KernelArgs);   // one chain per workgroup
+template __global__ void sampler_grp<64, true, 8>(const KernelArgs);         // one chain per wavefront
 }  // namespace miso

@@ -359,18 +359,22 @@ void miso_batch::upload(int dev) {
   // split into size buckets per isoform-count class, each its own launch beside the others.  How many lanes a gene
   // needs follows from its SHARE of the batch's work (drawing quads x isoforms): the batch takes W / (lanes of the
   // device) at best, a chain on L lanes w / L, and a chain should be done in half of that -- L >= 2 x device lanes x
-  // w / W.  Up to 1.5 x the rule's 16 lanes: the class's normal launch; up to 48: at least 32 lanes; beyond: one
-  // chain per workgroup (256 lanes, kernels_grp.inl WIDE); beyond 384: several workgroups (coop.hpp), one per 256
-  // lanes needed.  Never more lanes than the gene has pairs of quads.  MISO_NO_PE_BUCKETS=1: one launch per class as
-  // before (A/B, tests).
+  // w / W.  Up to 1.5 x the rule's 16 lanes: the class's normal launch; up to 64: at least 32 lanes; up to 256: a
+  // wavefront of its own (sampler_grp<64, true, KC>); beyond: one chain per workgroup (256 lanes, kernels_grp.inl WIDE
+  // -- its four wavefronts each repeat the chain's Metropolis-Hastings step, so only where the read loop dominates);
+  // beyond 384: several workgroups (coop.hpp), one per 256 lanes needed.  Never more lanes than the gene has pairs of
+  // quads.  Thresholds measured: profiles/r03_pe_buckets.txt.  MISO_NO_PE_BUCKETS=1: one launch per class as before
+  // (A/B, tests); MISO_PE_T_WAVE / MISO_PE_T_WIDE: the two thresholds (experiments, tests).
   auto kc_of = [](int K) { return K <= 4 ? 4 : (K <= 8 ? 8 : (K <= 12 ? 12 : (K <= 16 ? 16 : 32))); };
-  std::vector<int> bucket(n, 0);   // 0 normal, 1 at least 32 lanes, 2 workgroup-wide (coop_n[event] workgroups)
+  std::vector<int> bucket(n, 0);   // 0 normal, 1 at least 32 lanes, 2 a wavefront, 3 workgroup-wide (coop_n[event] workgroups)
   coop_n.assign(n, 1);
   if (p.paired && std::getenv("MISO_NO_PE_BUCKETS") == nullptr) {
     double W = 0;
     for (int i : gen) W += static_cast<double>((events[i].n_draw + 3) / 4) * events[i].K;
     const double device_lanes = 2048.0 * 64.0;
     const double share_factor = std::getenv("MISO_PE_SHARE") ? std::atof(std::getenv("MISO_PE_SHARE")) : 2.0;
+    const double t_wave = std::getenv("MISO_PE_T_WAVE") ? std::atof(std::getenv("MISO_PE_T_WAVE")) : 64.0;
+    const double t_wide = std::getenv("MISO_PE_T_WIDE") ? std::atof(std::getenv("MISO_PE_T_WIDE")) : 256.0;
     const bool dense_ok = std::getenv("MISO_NO_PE_DENSE") == nullptr;
     const bool coop_on = std::getenv("MISO_NO_COOP") == nullptr;
     for (int i : gen) {
@@ -378,11 +382,12 @@ void miso_batch::upload(int dev) {
       const int nq = (e.n_draw + 3) / 4;
       const double need = W > 0 ? share_factor * device_lanes * (static_cast<double>(nq) * e.K) / W : 0.0;
       const bool can_wide = dense_ok && !e.draw_dense.empty() && e.K >= 3 && e.K <= PE_DENSE_KMAX;
-      if (can_wide && need > 48.0 && nq >= 512) {
-        bucket[i] = 2;
+      if (can_wide && need > t_wide && nq >= 512) {
+        bucket[i] = 3;
         if (coop_on && need > 384.0)
           coop_n[i] = std::max(1, std::min({COOP_MAX_N, static_cast<int>(std::ceil(need / 256.0)), nq / 512}));
-      } else if (need > 24.0 && nq >= 64) bucket[i] = 1;
+      } else if (can_wide && need > t_wave && nq >= 128) bucket[i] = 2;
+      else if (need > 24.0 && nq >= 64) bucket[i] = 1;
     }
   }
   std::stable_sort(gen.begin(), gen.end(), [&](int x, int y) {
@@ -394,8 +399,8 @@ void miso_batch::upload(int dev) {
   for (size_t j = 0; j < gen.size(); j++) {
     const PackedEvent &e = events[gen[j]];
     const int kc = kc_of(e.K), bk = bucket[gen[j]];
-    if (gen_runs.empty() || gen_runs.back().kc != kc || (gen_runs.back().wide ? 2 : (gen_runs.back().force_G ? 1 : 0)) != bk) {
-      GenRun r; r.first = static_cast<int>(j); r.kc = kc; r.wide = bk == 2; r.force_G = bk == 1 ? 32 : 0;
+    if (gen_runs.empty() || gen_runs.back().kc != kc || (gen_runs.back().wide ? 3 : (gen_runs.back().wave64 ? 2 : (gen_runs.back().force_G ? 1 : 0))) != bk) {
+      GenRun r; r.first = static_cast<int>(j); r.kc = kc; r.wide = bk == 3; r.wave64 = bk == 2; r.force_G = bk == 1 ? 32 : (bk == 2 ? 64 : 0);
       gen_runs.push_back(r);
     }
     GenRun &r = gen_runs.back();
@@ -527,9 +532,10 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     const long chains = static_cast<long>(run.count) * p.noChains;
     ka.slot_event = d_slots + n_k2 + run.first; ka.n_slots = run.count;
     ka.kstride = run.kmax; ka.cstride = sh.qs; ka.tstride = sh.ts;
-    ka.pe_dense = G == 64 ? 0 : fp_rows(run);
+    const bool wave_kernel = G == 64 && !run.wide && !(run.wave64 && fp_rows(run));   // sampler_wave, not sampler_grp<64, ..>
+    ka.pe_dense = wave_kernel ? 0 : fp_rows(run);
     ka.pe_force_exact = std::getenv("MISO_PE_FORCE_EXACT") != nullptr;
-    const size_t fp_bytes = (G == 64 && !run.wide) ? fp_plain : fp_bytes_of(run);
+    const size_t fp_bytes = wave_kernel ? fp_plain : fp_bytes_of(run);
     if (run.wide) {   // one chain per workgroup: four slices (one per wavefront) + the reduction scratch behind them
       ka.pe_dense = fp_rows(run);
       if (!ka.pe_dense) MISO_FAIL(MISO_EINTERNAL, "workgroup-wide paired-end chains need the dense records");
@@ -584,6 +590,23 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       default: MISO_GRP_WIDE(32) break;
       }
 #undef MISO_GRP_WIDE
+    } else if (G == 64 && !wave_kernel) {   // a wavefront per chain, dense records (size bucket between 32 lanes and a workgroup)
+      const unsigned grid = static_cast<unsigned>((chains + 3) / 4);
+      const size_t lds = fp_bytes + 4 * static_cast<size_t>(grp_slice_bytes(run.kmax, sh.qs, sh.ts));
+#define MISO_GRP_WAVE64(KC)                                                                                \
+  {                                                                                                        \
+    HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sampler_grp<64, true, KC>),                 \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));        \
+    hipLaunchKernelGGL((sampler_grp<64, true, KC>), dim3(grid), dim3(256), lds, st, ka);                   \
+  }
+      switch (run.kc) {
+      case 4: MISO_GRP_WAVE64(4) break;
+      case 8: MISO_GRP_WAVE64(8) break;
+      case 12: MISO_GRP_WAVE64(12) break;
+      case 16: MISO_GRP_WAVE64(16) break;
+      default: MISO_GRP_WAVE64(32) break;
+      }
+#undef MISO_GRP_WAVE64
     } else if (G == 64) {
       const unsigned grid = static_cast<unsigned>((chains + 3) / 4);
       const size_t lds = fp_bytes + 4 * 32 * sizeof(int);
@@ -1219,6 +1242,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     const GenRun &run = gen_runs[ri];
     const bool flat = flat_nc[ri] > 0;
     const int G = grp_G[ri], C = p.noChains, cpw = flat ? flat_nc[ri] : std::max(1, 64 / G);
+    const bool w64 = G == 64 && run.wave64 && p.paired && run.dense;
     const long chains = static_cast<long>(run.count) * C;
     std::vector<const PackedEvent *> evs;   // the run's events in slot order
     for (int j = 0; j < run.count; j++) evs.push_back(&events[h_slots[n_k2 + run.first + j]]);   // the list upload made
@@ -1246,15 +1270,15 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
         words += e.n_draw;
       }
       const int nw = (cls && kmx - 1 <= 3) ? 2 : 1;         // Philox blocks in flight (class path, K <= 4)
-      trips += flat ? (units + 63) / 64 : ((G == 64) ? mx : nw * ((mx + nw * G - 1) / (nw * G)));
+      trips += flat ? (units + 63) / 64 : ((G == 64 && !w64) ? mx : nw * ((mx + nw * G - 1) / (nw * G)));
     }
     if (run.wide) {   // four wavefronts per chain, the quads dealt over 256 lanes
       trips = 0; waves = 0;
       for (long sl = 0; sl < chains; sl++) { trips += 4 * ((((evs[sl / C]->n_draw + 3) / 4) + 255) / 256); waves += 4; }
     }
     const std::string name = run.wide ? "sampler_grp<64, true, " + std::to_string(run.kc) + ", true>" :
-                             flat ? flat_name(run) : (G == 64 ? std::string("sampler_wave<") : "sampler_grp<" + std::to_string(G) + ", ") +
-                             (p.paired ? "true" : "false") + (G == 64 ? std::string(">") : ", " + std::to_string(run.kc) + ">");
+                             flat ? flat_name(run) : ((G == 64 && !w64) ? std::string("sampler_wave<") : "sampler_grp<" + std::to_string(G) + ", ") +
+                             (p.paired ? "true" : "false") + ((G == 64 && !w64) ? std::string(">") : ", " + std::to_string(run.kc) + ">");
     add_stat(name, static_cast<double>(waves), trips, static_cast<double>(chains), words);
   }
   };   // stats_builder
@@ -1288,6 +1312,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     GenRun &run = gen_runs[ri];
     const int G = grp_G[ri];
     if (merged_into_prev[ri]) return;
+    const bool wave_k = G == 64 && !(run.wave64 && p.paired && run.dense);
     if (merge_on && !run.wide && run.force_G && G != 64 && flat_nc[ri] == 0 && ri + 1 < gen_runs.size()) {
       const GenRun &nx = gen_runs[ri + 1];
       if (!nx.wide && !nx.force_G && nx.kc == run.kc && grp_G[ri + 1] == G && flat_nc[ri + 1] == 0 &&
@@ -1313,10 +1338,10 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     }
     last_kernels += std::string(last_kernels.empty() ? "" : ",") +
                     (run.wide ? "sampler_grp<64, true, " + std::to_string(run.kc) + ", true>"
-                              : (G == 64 ? std::string("sampler_wave<")
-                                         : "sampler_grp<" + std::to_string(G) + ", ") +
+                              : (wave_k ? std::string("sampler_wave<")
+                                        : "sampler_grp<" + std::to_string(G) + ", ") +
                                     (p.paired ? "true" : "false") +
-                                    (G == 64 ? std::string(">") : ", " + std::to_string(run.kc) + ">"));
+                                    (wave_k ? std::string(">") : ", " + std::to_string(run.kc) + ">"));
     launch_grp(a, run, grp_sh[ri], G, stream_for_next());
   };
   for (size_t ri = 0; ri < gen_runs.size(); ri++) if (gen_runs[ri].wide) launch_gen_run(ri);

@@ -172,7 +172,8 @@ def test_two_isoform_paired_end_through_the_general_kernel(orc, sd, forced):
 def test_mixed_pair_counts_three_or_more_isoforms_paired_end_bit_exact(orc, K, chains):
     """sampler_grp, paired-end: genes of very different sizes are split into size buckets per isoform-count class
     (runtime.hip upload) -- the mean-sized on the rule's lanes per chain, the several-times-larger on at least 32, the
-    largest one per WORKGROUP (kernels_grp.inl WIDE: 256 lanes, totals through LDS) -- launched side by side.
+    next a WAVEFRONT each (sampler_grp<64, true, KC>), the largest one per WORKGROUP (kernels_grp.inl WIDE: 256 lanes,
+    totals through LDS) -- launched side by side.
     Against the single launch per class (MISO_NO_PE_BUCKETS=1) and the oracle."""
     sizes = [30, 22000, 200, 5, 0, 1800, 9000, 60, 700, 120, 90, 200, 35, 400, 150, 80]
     evs = []
@@ -193,7 +194,7 @@ def test_mixed_pair_counts_three_or_more_isoforms_paired_end_bit_exact(orc, K, c
     # (MISO_COOP_DRAWS: drawing pairs per workgroup of a chain on SEVERAL workgroups, coop.hpp: 1024 puts the two largest
     # genes on ~10 and ~4 workgroups; MISO_NO_COOP: one workgroup per chain)
     for v in (dict(), dict(MISO_NO_PE_BUCKETS="1"), dict(MISO_PE_FORCE_EXACT="1"), dict(MISO_COOP_DRAWS="1024"),
-              dict(MISO_NO_COOP="1")):
+              dict(MISO_NO_COOP="1"), dict(MISO_PE_T_WAVE="1", MISO_PE_T_WIDE="1e9"), dict(MISO_PE_T_WAVE="64", MISO_PE_T_WIDE="1500")):
         with _env(**v):
             b = miso_amd.Batch(36, paired=True, mean=250.0, var=900.0, device_match=True, **kw)
             for exons, isoforms, g, pos, cig in evs:
@@ -210,3 +211,6 @@ def test_mixed_pair_counts_three_or_more_isoforms_paired_end_bit_exact(orc, K, c
                 assert gpu.rundata.noAccepted == r.accepted, where
     assert ", true>" in names[0] and names[0].count("sampler_grp") >= 3, names     # workgroup-wide + 32-lane + normal launches
     assert names[1].count("sampler_grp") == 1, names
+    kc = {3: 4, 5: 8, 10: 12}[K]
+    assert "sampler_grp<64, true, %d>" % kc in names[5] and ", true>" not in names[5], names   # a wavefront per large gene, none workgroup-wide
+    assert "sampler_grp<64, true, %d>" % kc in names[6] and "sampler_grp<64, true, %d, true>" % kc in names[6], names
