@@ -108,11 +108,12 @@ def workload_key(events, sh):
         events, k, sh["reads"], sh["iters"], sh["chains"], int(sh["paired"]))
 
 
-def build(first, n, sh, device_match=True):
+def build(first, n, sh, device_match=True, collapsed=False):
     from miso_amd import workload
     return workload.build_batch(first, n, K=sh["K"], n_reads=reads_spec(sh), read_len=sh["read_len"],
                                 iters=sh["iters"], burn=sh["burn"], lag=sh["lag"], chains=sh["chains"],
-                                paired=sh["paired"], mean=sh["mean"], var=sh["var"], device_match=device_match)
+                                paired=sh["paired"], mean=sh["mean"], var=sh["var"], device_match=device_match,
+                                collapsed=collapsed)
 
 
 MATRIX = [  # (id, label, shape overrides, events, reference runs of the row: (events, seeds) or None)
@@ -418,34 +419,54 @@ def stream_rows(batch, n_events, sh, first, seed, device):
     return out
 
 
-def run_matrix(a, local_rank, studies):
+# Opt-in mode (miso_batch_set_collapsed, csrc/kernels_lane.hip): the single-end two-isoform workloads once more with the
+# COLLAPSED Gibbs step -- the count of the exchangeable reads drawn as one exact binomial per iteration instead of one
+# uniform per read (same Markov chain on (psi, counts), different draws).  Same workload, same reference runs, same
+# |delta psi| test as the row it shadows; "main" = the headline workload.  The headline `value` stays the default mode.
+COLLAPSED_ROWS = ("main", "se_k2_hg19", "se_k2_defaults")
+
+
+def matrix_row(a, local_rank, wid, label, sh, n, st, collapsed=False):
     from miso_amd import workload
+    spec = reads_spec(sh)
+    total_reads = sum(workload.event_n_reads(e, spec) for e in range(n))
+    b = build(0, n, sh, collapsed=collapsed)
+    b.upload(local_rank)
+    elapsed, kms = time_batch(b, a.seed, 0, 2, 1)
+    avg = sum(kms) / len(kms)
+    r = roofline_for(b, avg, workload_key(n, sh) + ("|collapsed" if collapsed else ""), sh)
+    row = {"id": wid, "workload": label, "events": n, "events_per_s": round(2 * n / elapsed, 1),
+           "reads_iter_per_s": round(2.0 * total_reads * sh["chains"] * sh["iters"] / elapsed, 1),
+           "kernel": r["kernel"], "kernel_ms": r["kernel_ms"], "valu_frac": r["frac"], "floor_frac": r.get("floor_frac"),
+           "frac_source": r["frac_source"], "rng_frac": r["rng_frac"], "hbm_measured_frac": r["hbm_measured_frac"],
+           "algorithmic_GBs": r["algorithmic_GBs"]}
+    if collapsed:
+        row["mode"] = "collapsed Gibbs step (opt-in): counts drawn as exact binomials, include/miso_binomial.h"
+        row["rng_frac"] = None   # (reads x iterations are not Philox words here)
+    if st:
+        row["cpu_baseline"] = st["baseline"]
+        if len(st["study"]) >= 2 * len(set(r_[0] for r_ in st["study"])):   # at least two reference seeds per event
+            row["delta_psi"] = delta_psi(b, st["study"])
+    del b
+    return row
+
+
+def run_matrix(a, local_rank, studies, main_sh=None):
     rows = []
     only = set(a.matrix_only.split(",")) if a.matrix_only else None
+    if main_sh is not None and not main_sh["paired"] and main_sh["K"] == 2 and "main" in COLLAPSED_ROWS and not only:
+        rows.append(matrix_row(a, local_rank, "main_collapsed", "the headline workload, collapsed Gibbs step", main_sh,
+                               min(a.matrix_events, a.events), studies.get("main") if studies else None, collapsed=True))
     for wid, label, ov, events, _ in MATRIX:
-        if only and wid not in only:
+        if only and wid not in only and wid + "_collapsed" not in only:
             continue
         sh = dict(BASE_SHAPE, **ov)
         n = min(a.matrix_events, events)
-        spec = reads_spec(sh)
-        total_reads = sum(workload.event_n_reads(e, spec) for e in range(n))
-        b = build(0, n, sh)
-        b.upload(local_rank)
-        elapsed, kms = time_batch(b, a.seed, 0, 2, 1)
-        avg = sum(kms) / len(kms)
-        r = roofline_for(b, avg, workload_key(n, sh), sh)
-        row = {"id": wid, "workload": label, "events": n, "events_per_s": round(2 * n / elapsed, 1),
-               "reads_iter_per_s": round(2.0 * total_reads * sh["chains"] * sh["iters"] / elapsed, 1),
-               "kernel": r["kernel"], "kernel_ms": r["kernel_ms"], "valu_frac": r["frac"], "floor_frac": r.get("floor_frac"),
-               "frac_source": r["frac_source"], "rng_frac": r["rng_frac"], "hbm_measured_frac": r["hbm_measured_frac"],
-               "algorithmic_GBs": r["algorithmic_GBs"]}
         st = studies.get(wid) if studies else None
-        if st:
-            row["cpu_baseline"] = st["baseline"]
-            if len(st["study"]) >= 2 * len(set(r_[0] for r_ in st["study"])):   # at least two reference seeds per event
-                row["delta_psi"] = delta_psi(b, st["study"])
-        rows.append(row)
-        del b
+        if not only or wid in only:
+            rows.append(matrix_row(a, local_rank, wid, label, sh, n, st))
+        if wid in COLLAPSED_ROWS and (not only or wid + "_collapsed" in only):
+            rows.append(matrix_row(a, local_rank, wid + "_collapsed", label + ", collapsed Gibbs step", sh, n, st, collapsed=True))
     return rows
 
 
@@ -627,7 +648,7 @@ def main():
             out["stub"] = True
         elif want_matrix:
             del batch
-            out["matrix"] = run_matrix(a, local_rank, studies)
+            out["matrix"] = run_matrix(a, local_rank, studies, sh)
             if any(r.get("delta_psi", {}).get("pass") is False for r in out["matrix"]):
                 rc = 3
         print(json.dumps(out), flush=True)

@@ -176,6 +176,15 @@ int miso_batch_size(const miso_batch_t *batch, int *n_events);
  * batching (skip rules) pins the id here instead, so results do not depend on batch composition,
  * chunk size or the number of GPUs.  Before miso_batch_upload. */
 int miso_batch_set_event_id(miso_batch_t *batch, int event_index, uint32_t event_id);
+/* Single-end batches: on != 0 selects the COLLAPSED Gibbs step for the two-isoform events (csrc/kernels_lane.hip).
+   The reference reassigns every read by itself (miso.c:30-91 inside miso.c:493-552) and then uses the per-isoform
+   counts only (miso.c:243-307); reads compatible with the same isoforms are exchangeable, so their counts are drawn
+   directly -- Binomial(n, psi_0 / (psi_0 + psi_1)) from the counter RNG, include/miso_binomial.h -- which is the same
+   Markov chain on (psi, counts) at O(1) instead of O(reads) per iteration.  The run's last reassignment is made per
+   read, so the returned assignment is a per-read draw.  Different draws than the default mode (same distribution):
+   checked bit for bit against the checker's collapsed mode and statistically against the reference.  Events with
+   more than two isoforms of such a batch run as always.  Before miso_batch_launch; MISO_EINVAL for paired-end. */
+int miso_batch_set_collapsed(miso_batch_t *batch, int on);
 int miso_batch_upload(miso_batch_t *batch, int device);
 /* enqueue the sampler kernels for every event on the batch's stream; returns immediately */
 int miso_batch_launch(miso_batch_t *batch, uint64_t seed, uint32_t first_event_id);

@@ -179,12 +179,18 @@ class Batch:
 
     def __init__(self, read_len, iters=5000, burn=500, lag=10, chains=6, overhang=1, paired=False,
                  mean=0.0, var=0.0, num_devs=4.0, start=MISO_START_AUTO, stop=MISO_STOP_FIXEDNO,
-                 algo=MISO_ALGO_REASSIGN, max_iters=100000, counts_trace=False, device_match=False):
+                 algo=MISO_ALGO_REASSIGN, max_iters=100000, counts_trace=False, device_match=False,
+                 collapsed=False):
+        """collapsed (single-end): the two-isoform events draw their assignment COUNTS directly (one exact binomial
+        per iteration instead of one uniform per read; miso_batch_set_collapsed in include/miso_amd.h)."""
         self.params = Params(int(paired), read_len, overhang, chains, iters, max_iters, burn, lag,
                              algo, start, stop, mean, var, num_devs, int(counts_trace),
                              int(device_match))
         self.handle = C.c_void_p()
         check(lib().miso_batch_create(C.byref(self.params), C.byref(self.handle)))
+        self.collapsed = bool(collapsed)
+        if collapsed:
+            check(lib().miso_batch_set_collapsed(self.handle, 1))
 
     def __del__(self):
         h, self.handle = getattr(self, "handle", None), None

@@ -45,6 +45,9 @@ struct miso_batch {
   std::vector<int32_t> h_slots;   // the same list on the host
   bool k2_general = false;        // paired-end, tables too wide for the two-isoform kernel's LDS: K = 2 events take sampler_grp
   bool use_delta = true;          // paired-end: MODE 2 events first in the list (fixed at upload)
+  double *d_logfact = nullptr;    // collapsed: log factorials up to the largest two-isoform event's drawing reads
+  int logfact_n = 0;
+  bool collapsed = false;         // single-end two-isoform events: the collapsed Gibbs step (kernels_lane.hip); miso_batch_set_collapsed
   miso::LanePlan k2_plan;         // sampler_k2_multi: the runs of equal lanes per chain (runtime.hip), valid for k2_plan_key
   long k2_plan_key = -1;
   struct K2Coop {                 // a plan's chains on several workgroups (coop.hpp): table, scratch

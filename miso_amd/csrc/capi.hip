@@ -672,6 +672,15 @@ int miso_plan_lanes(const int *n_draw, int n_events, int chains, int paired, int
   });
 }
 
+int miso_batch_set_collapsed(miso_batch_t *b, int on) {
+  return guarded([&] {
+    need(b, "batch");
+    if (on && b->p.paired) MISO_FAIL(MISO_EINVAL, "the collapsed Gibbs step needs exchangeable reads: single-end only");
+    b->collapsed = on != 0;
+    b->k2_plan_key = -1;
+  });
+}
+
 int miso_batch_get_placement(const miso_batch_t *b, int i, uint32_t *hw_id) {
   return guarded([&] {
     need(b, "batch"); need(hw_id, "hw_id");

@@ -17,6 +17,7 @@
 
 #include "batch.hpp"
 #include "coop.hpp"
+#include "miso_binomial.h"
 
 namespace miso {
 
@@ -24,6 +25,7 @@ template <bool PE> __global__ void sampler_wave(const KernelArgs a);
 template <int G, int MODE, int WPB> __global__ void sampler_k2(const KernelArgs a);
 template <int GA, int GB> __global__ void sampler_k2_mix(const KernelArgs a);
 template <int MODE, int WPB> __global__ void sampler_k2_multi(const KernelArgs a);
+__global__ void sampler_lane(const KernelArgs a);   // kernels_lane.hip: collapsed Gibbs step, one chain per lane
 __global__ void compare_kernel(const DevEvent *, const unsigned char *, const DevEvent *, const unsigned char *, int, int,
                                double, const uint64_t *, double *);
 __global__ void match_kernel(const MatchEvent *, const int2 *, const int *, const int *, const int *, const int *,
@@ -85,6 +87,7 @@ void miso_batch::release() {
   if (d_out) (void) hipFree(d_out);
   if (d_fp) (void) hipFree(d_fp);
   if (d_slots) (void) hipFree(d_slots);
+  if (d_logfact) (void) hipFree(d_logfact);
   d_slots = nullptr;
   if (ev0) (void) hipEventDestroy(ev0);
   if (ev1) (void) hipEventDestroy(ev1);
@@ -1000,6 +1003,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   // (workgroup-wide chains may use several workgroups, coop.hpp; MISO_NO_COOP=1: their own only)
   const int coop_max = std::getenv("MISO_NO_COOP") ? 1 : COOP_MAX_N;
   bool k2_multi = false;
+  const bool lane_route = collapsed && !p.paired && n_k2 > 0;   // miso_batch_set_collapsed
   {
     const int count = n_k2 - n_k2w;
     const char *off = std::getenv("MISO_K2_MULTI");
@@ -1211,7 +1215,10 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
         trips += p.paired ? 2 * t + 1 : 2 * t + (any_rem ? 1 : 0);   // counted in blocks per lane
       }
     };
-    if (wpart ? k2w_multi : k2_multi) {
+    if (!wpart && lane_route) {
+      for (int n : nd) words += static_cast<double>(n) * C;
+      add_stat("sampler_lane", static_cast<double>((chains + 63) / 64), 0.0, static_cast<double>(chains), words);
+    } else if (wpart ? k2w_multi : k2_multi) {
       const LanePlan &pl = wpart ? planw_copy : plan_copy;
       for (int sg = 0; sg < pl.n_segs; sg++) {
         const long c0 = static_cast<long>(pl.seg_slot[sg]) * C, c1 = static_cast<long>(pl.seg_slot[sg + 1]) * C;
@@ -1356,7 +1363,26 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   }
   if (n_k2 - n_k2w > 0) {
     lanes_per_chain = k2_G;
-    if (k2_multi) {
+    if (lane_route) {   // collapsed single-end batch: one chain per lane, no read loop (kernels_lane.hip)
+      lanes_per_chain = 1;
+      last_kernels += std::string(last_kernels.empty() ? "" : ",") + "sampler_lane";
+      KernelArgs ka = a;
+      ka.slot_event = d_slots; ka.n_slots = n_k2;
+      int need = 2;
+      for (int i = 0; i < n_k2; i++) need = std::max(need, events[h_slots[i]].n_draw + 2);
+      if (need > logfact_n) {   // log factorials (miso_binomial.h), once per batch
+        std::vector<double> lf(static_cast<size_t>(need));
+        miso_logfact_fill(lf.data(), need);
+        if (d_logfact) HIP_OK(hipFree(d_logfact));
+        HIP_OK(hipMalloc(reinterpret_cast<void **>(&d_logfact), lf.size() * sizeof(double)));
+        HIP_OK(hipMemcpy(d_logfact, lf.data(), lf.size() * sizeof(double), hipMemcpyHostToDevice));
+        logfact_n = need;
+      }
+      ka.logfact = d_logfact;
+      const long chains = static_cast<long>(n_k2) * p.noChains;
+      hipLaunchKernelGGL(sampler_lane, dim3(static_cast<unsigned>((chains + 255) / 256)), dim3(256), 0, stream_for_next(), ka);
+      HIP_OK(hipGetLastError());
+    } else if (k2_multi) {
       lanes_per_chain = k2_plan.seg_lanes[k2_plan.n_segs - 1];
       last_kernels += std::string(last_kernels.empty() ? "" : ",") + "sampler_k2_multi<" + (p.paired ? "1, " : "0, ") + std::to_string(k2_plan.wpb) + ">";
       launch_k2_multi(a, stream_for_next());

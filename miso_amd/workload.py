@@ -60,12 +60,12 @@ def event_n_reads(event_id, n_reads):
 
 def build_batch(first_event_id, n_events, K=2, n_reads=1000, read_len=36, iters=7500, burn=2500,
                 lag=1, chains=1, paired=False, mean=250.0, var=900.0, counts_trace=False,
-                device_match=False):
+                device_match=False, collapsed=False):
     """Batch holding events [first_event_id, first_event_id + n_events)."""
     kw = dict(min_len=400, max_len=800, gap=300) if paired else {}
     b = capi.Batch(read_len, iters=iters, burn=burn, lag=lag, chains=chains, paired=paired,
                    mean=mean if paired else 0.0, var=var if paired else 0.0,
-                   counts_trace=counts_trace, device_match=device_match)
+                   counts_trace=counts_trace, device_match=device_match, collapsed=collapsed)
     for i in range(n_events):
         gid = first_event_id + i
         exons, isoforms, expr = event_gene(gid, mixed_k(gid, K), **kw)

@@ -24,6 +24,7 @@
 
 #include "miso_detmath.h"
 #include "miso_philox.h"
+#include "miso_binomial.h"
 
 /* ------------------------------------------------------------------------------------ */
 /* MT19937 stream generator: Matsumoto & Nishimura 1998, 2002 seeding (the reference's   */
@@ -145,6 +146,27 @@ double orc_qnorm_det(double p) { return as241(p, &MATH_DET); }
 double orc_det_exp(double x) { return miso_det_exp(x); }
 double orc_det_log(double x) { return miso_det_log(x); }
 double orc_det_sqrt(double x) { return miso_det_sqrt(x); }
+/* log factorials for miso_binomial (include/miso_binomial.h), grown on demand */
+static double *g_lf = NULL; static int g_lf_n = 0;
+static const double *logfact(int n) { /* at least n + 1 entries */
+  if (n + 1 > g_lf_n) {
+    int cap = n + 1 < 4096 ? 4096 : 2 * (n + 1);
+    g_lf = realloc(g_lf, sizeof(double) * (size_t) cap);
+    miso_logfact_fill(g_lf, cap);
+    g_lf_n = cap;
+  }
+  return g_lf;
+}
+
+/* test hook: `count` draws of Binomial(n, p) from the word stream (seed, event_id, chain 0, iteration i, MISO_SITE_COUNTS) */
+void orc_binomial(uint64_t seed, uint32_t event_id, int32_t n, double p, int count, int32_t *out) {
+  int i;
+  for (i = 0; i < count; i++) {
+    miso_ustream us;
+    miso_ustream_init(&us, seed, event_id, 0, (uint32_t) i, MISO_SITE_COUNTS);
+    out[i] = miso_binomial(&us, n, p, logfact(n));
+  }
+}
 void orc_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
                 uint32_t *out4) {
   miso_u32x4 o = miso_philox4x32_10(c0, c1, c2, c3, k0, k1);
@@ -621,7 +643,8 @@ typedef struct {
   int K, N, C;
   const orc_opts_t *opts;
   const orc_math_t *M;
-  int counter;           /* opts->mode == ORC_MODE_COUNTER */
+  int counter;           /* opts->mode == ORC_MODE_COUNTER or ORC_MODE_COLLAPSED */
+  int collapsed;         /* opts->mode == ORC_MODE_COLLAPSED: reassign_collapsed() except for the run's last reassignment */
   int count_sums;        /* use count-based score sums */
   const double *match;   /* K x N */
   const int *order;      /* N (stream mode draw order) */
@@ -716,6 +739,51 @@ static void counter_order(orc_state_t *S) {
   S->corder = malloc(sizeof(int) * (size_t) (S->N > 0 ? S->N : 1));
   for (i = 0; i < S->N; i++) S->corder[i] = i;
   if (!S->paired) { co_match = S->match; co_K = S->K; qsort(S->corder, (size_t) S->N, sizeof(int), co_cmp); }
+}
+
+/* The collapsed Gibbs step (single-end).  The reads in counter order (sorted by compatibility column) fall into
+   runs of equal columns = classes; a class of n reads with compatible isoforms v_0 < v_1 < ... < v_{nv-1} gets
+   counts Multinomial(n; psi_v / sum psi_v) (the per-read law of miso.c:30-91 for each of its exchangeable reads),
+   drawn as x_w ~ Binomial(n - x_0 - ... - x_{w-1}, psi_{v_w} / S_w), S_w = psi_{v_{nv-1}} + ... + psi_{v_w} summed in
+   that order.  The assignment vector is filled in class order (first x_0 reads -> v_0, ...): only its counts are
+   used until the run's last reassignment, which is per read (reassign). */
+static void reassign_collapsed(orc_state_t *S, uint32_t iter) {
+  int k, K = S->K, N = S->N;
+  if (!S->corder) counter_order(S);
+  for (k = 0; k < S->C; k++) {
+    const double *psi = S->psi + k * K;
+    int *ass = S->ass + (size_t) k * N;
+    miso_ustream us;
+    int ii = 0;
+    miso_ustream_init(&us, S->opts->seed, S->opts->event_id, (uint32_t) k, iter, MISO_SITE_COUNTS);
+    while (ii < N) {
+      const double *col = S->match + (size_t) S->corder[ii] * K;
+      int jj = ii + 1, n, nv = 0, valid[64], j, w;
+      double suffix[64];
+      while (jj < N) {
+        const double *c2 = S->match + (size_t) S->corder[jj] * K;
+        int same = 1;
+        for (j = 0; j < K && same; j++) same = (col[j] != 0) == (c2[j] != 0);
+        if (!same) break;
+        jj++;
+      }
+      n = jj - ii;
+      for (j = 0; j < K; j++) if (col[j] != 0) valid[nv++] = j;
+      if (nv == 0) { for (j = ii; j < jj; j++) ass[S->corder[j]] = -1; }
+      else if (nv == 1) { for (j = ii; j < jj; j++) ass[S->corder[j]] = valid[0]; }
+      else {
+        int rem = n, at = ii;
+        double acc = 0.0;
+        for (w = nv - 1; w >= 0; w--) { acc = acc + psi[valid[w]]; suffix[w] = acc; }
+        for (w = 0; w < nv; w++) {
+          int x = (w == nv - 1) ? rem : miso_binomial(&us, rem, psi[valid[w]] / suffix[w], logfact(rem));
+          for (j = 0; j < x; j++) ass[S->corder[at + j]] = valid[w];
+          at += x; rem -= x;
+        }
+      }
+      ii = jj;
+    }
+  }
 }
 
 static void reassign(orc_state_t *S, uint32_t iter) {
@@ -889,7 +957,7 @@ static void run_chains(orc_state_t *S, int noIterations, int noBurnIn, int noLag
         lagCounter++;
       }
     }
-    reassign(S, (uint32_t) m);
+    if (S->collapsed && m != noIterations - 1) reassign_collapsed(S, (uint32_t) m); else reassign(S, (uint32_t) m);
   }
   for (j = 0; j < C; j++) {
     counts_of(S, j, cnt);
@@ -944,7 +1012,8 @@ static void fill_common(orc_state_t *S, const orc_gene_t *g, const orc_opts_t *o
   int K = g->K, i; double asum = 0.0, lge = 0.0;
   memset(S, 0, sizeof(*S));
   S->K = K; S->N = N; S->C = C; S->opts = opts;
-  S->counter = opts && opts->mode == ORC_MODE_COUNTER;
+  S->collapsed = opts && opts->mode == ORC_MODE_COLLAPSED;
+  S->counter = opts && (opts->mode == ORC_MODE_COUNTER || S->collapsed);
   S->M = S->counter ? &MATH_DET : &MATH_LIBM;
   S->count_sums = S->counter && !(opts->per_read_sums);
   S->hyper = hyper;
@@ -1009,7 +1078,9 @@ int orc_miso(const orc_gene_t *g, const int *pos, const char **cigar, int nreads
   memset(logLik, 0, sizeof(double) * noSamples);
 
   init_chains(&S, start);            /* miso.c:827-835 */
-  if (nreads > 0) reassign(&S, MISO_ITER_INIT); /* miso.c:841 */
+  if (nreads > 0) { /* miso.c:841 */
+    if (S.collapsed && noIterations > 0) reassign_collapsed(&S, MISO_ITER_INIT); else reassign(&S, MISO_ITER_INIT);
+  }
   run_chains(&S, noIterations, noBurnIn, noLag, samples, logLik, rundata, trace);
 
   for (i = 0; i < nreads; i++) assignment[i] = S.ass[i]; /* chain 0: miso.c:943-946 */
@@ -1039,6 +1110,7 @@ int orc_miso_paired(const orc_gene_t *g, const int *pos, const char **cigar, int
   if (rc) return rc;
   rc = check_common(g, &overHang, readLength, noChains, noIterations, noBurnIn, noLag, nhyper,
                     start, stop);
+  if (!rc && opts->mode == ORC_MODE_COLLAPSED) rc = ORC_EINVAL;   /* paired-end reads are not exchangeable */
   if (rc) { free(fp); return rc; }
   K = g->K;
   noSamples = noChains * (noIterations - noBurnIn) / noLag;

@@ -37,6 +37,10 @@ extern "C" {
 
 #define ORC_MODE_STREAM 0  /* MT19937 sequential stream, libm, per-read sums: == reference */
 #define ORC_MODE_COUNTER 1 /* Philox addressed draws, miso_detmath, count sums: == device  */
+#define ORC_MODE_COLLAPSED 2 /* counter mode with the COLLAPSED Gibbs step (single-end): per compatibility class the
+                                counts are drawn as a chain of binomials (include/miso_binomial.h) instead of one
+                                uniform per read; the run's LAST reassignment is per read, so that the returned
+                                assignment is a per-read draw as in the reference: == device, collapsed batches */
 
 typedef struct orc_gene orc_gene_t;
 
@@ -111,6 +115,7 @@ double orc_qnorm_det(double p);
 double orc_det_exp(double x);
 double orc_det_log(double x);
 double orc_det_sqrt(double x);
+void orc_binomial(uint64_t seed, uint32_t event_id, int32_t n, double p, int count, int32_t *out);
 void orc_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
                 uint32_t *out4);
 

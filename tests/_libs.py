@@ -228,7 +228,7 @@ class OrcTrace(C.Structure):
 
 class OrcLib(_Base):
     prefix = "orc_"
-    STREAM, COUNTER = 0, 1
+    STREAM, COUNTER, COLLAPSED = 0, 1, 2
 
     def __init__(self, path=None):
         super().__init__(path or ensure_oracle_built())
@@ -242,6 +242,12 @@ class OrcLib(_Base):
         out = np.zeros(4, np.uint32)
         self.lib.orc_philox(C.c_uint32(ctr[0]), C.c_uint32(ctr[1]), C.c_uint32(ctr[2]),
                             C.c_uint32(ctr[3]), C.c_uint32(key[0]), C.c_uint32(key[1]), _p(out))
+        return out
+
+    def binomial(self, n, p, count, seed=1, event_id=0):
+        """`count` draws of include/miso_binomial.h's Binomial(n, p) (word streams of iterations 0 .. count-1)."""
+        out = np.zeros(count, np.int32)
+        self.lib.orc_binomial(C.c_uint64(seed), C.c_uint32(event_id), C.c_int32(n), C.c_double(p), C.c_int(count), _p(out))
         return out
 
     def _opts(self, mode, seed, event_id, per_read_sums):
