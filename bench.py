@@ -349,7 +349,8 @@ def roofline_for(batch, kernel_ms, key, sh):
                         "profiled_wave_slot_occupancy": {k: (None if v["wave_slot_occupancy"] is None else round(v["wave_slot_occupancy"], 4))
                                                          for k, v in m["kernels"].items()}}
         if not isinstance(sh["K"], (tuple, list)):
-            fl = valu_floor(sh["K"], sh["paired"], draws)
+            # collapsed Gibbs step: no read sweep; one BTRS trial (sqrt, a logarithm, ~5 divisions, half a Philox block)
+            fl = valu_floor(sh["K"], sh["paired"], 0.0) + 150.0 / 64.0 if key.endswith("|collapsed") else valu_floor(sh["K"], sh["paired"], draws)
             out["floor_valu_per_chain_iteration"] = round(fl, 1)
             out["floor_frac"] = round(fl / m["valu_per_chain_iteration"], 4)
     else:
@@ -454,7 +455,7 @@ def matrix_row(a, local_rank, wid, label, sh, n, st, collapsed=False):
 def run_matrix(a, local_rank, studies, main_sh=None):
     rows = []
     only = set(a.matrix_only.split(",")) if a.matrix_only else None
-    if main_sh is not None and not main_sh["paired"] and main_sh["K"] == 2 and "main" in COLLAPSED_ROWS and not only:
+    if main_sh is not None and not main_sh["paired"] and main_sh["K"] == 2 and "main" in COLLAPSED_ROWS and not only and not a.collapsed:
         rows.append(matrix_row(a, local_rank, "main_collapsed", "the headline workload, collapsed Gibbs step", main_sh,
                                min(a.matrix_events, a.events), studies.get("main") if studies else None, collapsed=True))
     for wid, label, ov, events, _ in MATRIX:
@@ -489,6 +490,8 @@ def main():
     ap.add_argument("--lag", type=int, default=1)
     ap.add_argument("--chains", type=int, default=1)
     ap.add_argument("--paired", action="store_true")
+    ap.add_argument("--collapsed", type=int, default=0, choices=[0, 1, 2],
+                    help="single-end, opt-in: the collapsed Gibbs step (miso_batch_set_collapsed): 1 two-isoform events, 2 all")
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--cpu-events", type=int, default=150,
                     help="reference events per host process (~12 s of CPU work per core at the default shape)")
@@ -563,7 +566,7 @@ def main():
     first, last = workload.shard_bounds_by_cost(costs, world, rank)
     n_local = last - first
     t_build = time.perf_counter()
-    batch = build(first, n_local, sh, device_match=not a.host_match and not a.stub)
+    batch = build(first, n_local, sh, device_match=not a.host_match and not a.stub, collapsed=a.collapsed)
     t_up = time.perf_counter()
     if not a.stub:
         batch.upload(local_rank)   # device_match: read x isoform compatibility on the GPU, then packing
@@ -600,7 +603,7 @@ def main():
             roof = {"bound": "valu", "achieved": None, "peak": VALU_PEAK_GCYC, "unit": "Gcycle/s", "frac": None,
                     "traffic": None}
         else:
-            roof = roofline_for(batch, avg_ms, workload_key(n_local, sh), sh)
+            roof = roofline_for(batch, avg_ms, workload_key(n_local, sh) + ("|collapsed" if a.collapsed else ""), sh)
         cpu = delta = None
         if studies and "main" in studies:
             cpu = studies["main"]["baseline"]
@@ -629,7 +632,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": wl, "events_per_gpu": a.events,
                        "K": a.K if not a.K_range else list(a.K_range), "reads": sh["reads"], "iters": a.iters,
-                       "burn_in": a.burn, "lag": a.lag, "chains": a.chains,
+                       "burn_in": a.burn, "lag": a.lag, "chains": a.chains, "collapsed": a.collapsed,
                        "parallelism": "%d contiguous cost-balanced event shards, one process per GPU, "
                                       "no collective on the data path" % world,
                        "shards": [[r, lo, hi] for r, lo, hi, _ in shards],

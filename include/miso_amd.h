@@ -183,7 +183,10 @@ int miso_batch_set_event_id(miso_batch_t *batch, int event_index, uint32_t event
    Markov chain on (psi, counts) at O(1) instead of O(reads) per iteration.  The run's last reassignment is made per
    read, so the returned assignment is a per-read draw.  Different draws than the default mode (same distribution):
    checked bit for bit against the checker's collapsed mode and statistically against the reference.  Events with
-   more than two isoforms of such a batch run as always.  Before miso_batch_launch; MISO_EINVAL for paired-end. */
+   more than two isoforms of such a batch run as always -- unless on == 2: then they draw, per compatibility class, a
+   chain of binomials (sampler_lane_k; same contract, same checker).  That pays from ~10^4 reads per event only: with
+   ~1000 reads spread over the classes of a five- or ten-isoform event it is slower than the per-read sweep
+   (profiles/r03_collapsed.txt).  Before miso_batch_launch; MISO_EINVAL for paired-end. */
 int miso_batch_set_collapsed(miso_batch_t *batch, int on);
 int miso_batch_upload(miso_batch_t *batch, int device);
 /* enqueue the sampler kernels for every event on the batch's stream; returns immediately */

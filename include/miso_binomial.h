@@ -35,6 +35,7 @@
 #else
 #define MISO_LF_PTR const double *
 #endif
+#define MISO_LF_AT(lf, i) ((lf)[(i)])
 
 typedef struct {
   uint64_t seed;
@@ -112,7 +113,7 @@ MISO_HD int32_t miso_binomial_btrs(miso_ustream *s, int32_t n, double r, MISO_LF
   const double alpha = (2.83 + 5.1 / b) * spq;
   const double m = __builtin_floor((dn + 1.0) * r);
   const double lpq = miso_det_log(r / q);
-  const double h = lf[(int32_t) m] + lf[n - (int32_t) m];
+  const double h = MISO_LF_AT(lf, (int32_t) m) + MISO_LF_AT(lf, n - (int32_t) m);
   int trial;
   for (trial = 0; trial < 4096; trial++) {
     const double u = miso_ustream_next(s) - 0.5;
@@ -123,7 +124,7 @@ MISO_HD int32_t miso_binomial_btrs(miso_ustream *s, int32_t n, double r, MISO_LF
     if (us >= 0.07 && v <= vr) return (int32_t) k;  /* the squeeze: most trials end here */
     if (v == 0.0) return (int32_t) k;               /* log(0) = -inf passes every test */
     v = v * alpha / (a / (us * us) + b);
-    if (miso_det_log(v) <= (h - lf[(int32_t) k] - lf[n - (int32_t) k]) + (k - m) * lpq) return (int32_t) k;
+    if (miso_det_log(v) <= (h - MISO_LF_AT(lf, (int32_t) k) - MISO_LF_AT(lf, n - (int32_t) k)) + (k - m) * lpq) return (int32_t) k;
   }
   return (int32_t) m;   /* cannot happen for finite inputs (acceptance > 0.85 per trial); never loop forever */
 }

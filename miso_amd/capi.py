@@ -188,9 +188,9 @@ class Batch:
                              int(device_match))
         self.handle = C.c_void_p()
         check(lib().miso_batch_create(C.byref(self.params), C.byref(self.handle)))
-        self.collapsed = bool(collapsed)
+        self.collapsed = int(collapsed)     # True / 1: two-isoform events; 2: events of any isoform count
         if collapsed:
-            check(lib().miso_batch_set_collapsed(self.handle, 1))
+            check(lib().miso_batch_set_collapsed(self.handle, int(collapsed)))
 
     def __del__(self):
         h, self.handle = getattr(self, "handle", None), None

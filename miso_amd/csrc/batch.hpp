@@ -47,6 +47,7 @@ struct miso_batch {
   bool use_delta = true;          // paired-end: MODE 2 events first in the list (fixed at upload)
   double *d_logfact = nullptr;    // collapsed: log factorials up to the largest two-isoform event's drawing reads
   int logfact_n = 0;
+  int collapsed_level = 0;        // 1: two-isoform events; 2: also the events with more isoforms (sampler_lane_k)
   bool collapsed = false;         // single-end two-isoform events: the collapsed Gibbs step (kernels_lane.hip); miso_batch_set_collapsed
   miso::LanePlan k2_plan;         // sampler_k2_multi: the runs of equal lanes per chain (runtime.hip), valid for k2_plan_key
   long k2_plan_key = -1;

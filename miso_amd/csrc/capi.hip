@@ -677,6 +677,7 @@ int miso_batch_set_collapsed(miso_batch_t *b, int on) {
     need(b, "batch");
     if (on && b->p.paired) MISO_FAIL(MISO_EINVAL, "the collapsed Gibbs step needs exchangeable reads: single-end only");
     b->collapsed = on != 0;
+    b->collapsed_level = on;
     b->k2_plan_key = -1;
   });
 }

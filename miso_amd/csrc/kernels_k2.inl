@@ -31,6 +31,7 @@
 #include "miso_philox.h"
 #include "gibbs_rng.hpp"
 #include "coop.hpp"
+#include "miso_binomial.h"
 
 #pragma clang fp contract(off)
 
@@ -207,6 +208,68 @@ __device__ __forceinline__ void vec_eval4(F f, double a0, double a1, double a2, 
   o2 = role_bcast<NR, QUAD, 2>(y, base); o3 = role_bcast<NR, QUAD, 3>(y, base);
 }
 
+// Binomial(n, p) of miso_binomial.h by the G lanes of one chain (lanes base .. base + G - 1, this one is `sub`): the
+// same draw, bit for bit, as the sequential routine.  Its rejection sampler (BTRS) tries trial t with words 2t, 2t + 1 of
+// the chain's word stream and returns the first trial that is accepted: here lane `sub` evaluates trial j G + sub of
+// round j and the lowest accepting lane's candidate is the result -- with 4 lanes nearly always one round instead of
+// the ~2.5 a wavefront of independent chains needs until its last lane is through.  Small n min(p, q) (inversion):
+// every lane for itself.  All lanes of a chain call this together.
+template <int G>
+__device__ __forceinline__ int32_t binomial_coop(uint64_t seed, uint32_t event_id, uint32_t chain, uint32_t iter,
+                                                 int32_t n, double p, const double *__restrict__ lf, int sub, int base) {
+  if (G == 1) {
+    miso_ustream us;
+    miso_ustream_init(&us, seed, event_id, chain, iter, MISO_SITE_COUNTS);
+    return miso_binomial(&us, n, p, lf);
+  }
+  if (n <= 0 || !(p > 0.0)) return 0;
+  if (p >= 1.0) return n;
+  const double r = p > 0.5 ? 1.0 - p : p;
+  int32_t y;
+  if (static_cast<double>(n) * r < 10.0) {
+    miso_ustream us;
+    miso_ustream_init(&us, seed, event_id, chain, iter, MISO_SITE_COUNTS);
+    y = miso_binomial_inversion(&us, n, r);
+  } else {   // miso_binomial_btrs, G trials per round
+    const double q = 1.0 - r, dn = static_cast<double>(n);
+    const double spq = miso_det_sqrt(dn * r * q);
+    const double b = 1.15 + 2.53 * spq;
+    const double aa = -0.0873 + 0.0248 * b + 0.01 * r;
+    const double c = dn * r + 0.5;
+    const double vr = 0.92 - 4.2 / b;
+    const double alpha = (2.83 + 5.1 / b) * spq;
+    const double m = __builtin_floor((dn + 1.0) * r);
+    const double lpq = miso_det_log(r / q);
+    const double h = MISO_LF_AT(lf, static_cast<int32_t>(m)) + MISO_LF_AT(lf, n - static_cast<int32_t>(m));
+    const unsigned long long group = (G >= 64 ? ~0ull : ((1ull << G) - 1ull)) << base;
+    y = static_cast<int32_t>(m);
+    for (int round = 0; round < 4096 / G; round++) {
+      const uint32_t t = static_cast<uint32_t>(round * G + sub);
+      const miso_u32x4 blk = miso_draw_block(seed, event_id, chain, iter, MISO_SITE_COUNTS, t >> 1);
+      const double u = miso_u01((t & 1u) ? blk.v[2] : blk.v[0]) - 0.5;
+      double v = miso_u01((t & 1u) ? blk.v[3] : blk.v[1]);
+      const double us = 0.5 - __builtin_fabs(u);
+      const double k = __builtin_floor((2.0 * aa / us + b) * u + c);
+      bool ok = false;
+      if (k >= 0.0 && k <= dn) {
+        if ((us >= 0.07 && v <= vr) || v == 0.0) ok = true;
+        else {
+          v = v * alpha / (aa / (us * us) + b);
+          ok = miso_det_log(v) <= (h - MISO_LF_AT(lf, static_cast<int32_t>(k)) - MISO_LF_AT(lf, n - static_cast<int32_t>(k))) + (k - m) * lpq;
+        }
+      }
+      const unsigned long long hit = __ballot(ok) & group;
+      if (hit) {
+        y = __shfl(static_cast<int32_t>(k), __builtin_ctzll(hit));
+        break;
+      }
+    }
+  }
+  if (y < 0) y = 0;
+  if (y > n) y = n;
+  return p > 0.5 ? n - y : y;
+}
+
 }  // namespace
 
 // WPB = wavefronts per workgroup.  WPB = 8 (single-end): one workgroup fills a CU's eight resident
@@ -236,8 +299,13 @@ __device__ __forceinline__ int32_t k2_lds_i32(uint32_t addr) { return *reinterpr
 // state and runs the MH step redundantly (same inputs, same routines, same bits), the lanes of all wavefronts stride
 // over the draw quads, and the per-wavefront counts meet in LDS once per Gibbs step (a.red_off: byte offset of the
 // scratch in the dynamic LDS; two buffers, so one barrier per step).
-template <int G, int MODE, int WPB, bool WIDE = false>
+// COLLAPSED (single-end; kernels_lane.hip sampler_k2c): the Gibbs step draws the COUNT of the chain's exchangeable reads
+// on isoform 0 as one exact binomial (include/miso_binomial.h) instead of sweeping the reads; the run's last step is
+// the sweep, so the returned assignment is a per-read draw.  The chain's G lanes share the work: the Metropolis-Hastings
+// step as always, the binomial's rejection trials G at a time (binomial_coop).
+template <int G, int MODE, int WPB, bool WIDE = false, bool COLLAPSED = false>
 __device__ __forceinline__ void k2_body(const KernelArgs &a, unsigned block_x, unsigned grid_x) {
+  static_assert(!COLLAPSED || (MODE == 0 && !WIDE && (G & (G - 1)) == 0), "collapsed: single-end, 1, 2, 4 ... lanes per chain");
   static_assert(!WIDE || G == 64, "a workgroup-wide chain uses whole wavefronts");
   // WIDE: which chain this workgroup works on, alone or as one of several (coop.hpp; a.coop_tab is indexed by the
   // workgroup's number within its run)
@@ -522,6 +590,15 @@ __device__ __forceinline__ void k2_body(const KernelArgs &a, unsigned block_x, u
       rfix = E.base_sfix + acc;
       rbad = bad | E.base_bad;
       return;
+    }
+    if constexpr (COLLAPSED) {
+      if (iter != (a.M > 0 ? static_cast<uint32_t>(a.M - 1) : MISO_ITER_INIT)) {   // every step but the run's last
+        const int d0 = binomial_coop<G>(a.seed, event_id, chain, iter, n_draw, cur.x0 / ((0.0 + cur.x1) + cur.x0),
+                                        a.logfact, sub, base_lane);
+        cnt0 = base0 + d0;
+        cnt1 = base1 + (n_draw - d0);
+        return;
+      }
     }
     PROF_T(g0);
     const uint64_t t = k2_threshold(cur.x0, (0.0 + cur.x0) + cur.x1);

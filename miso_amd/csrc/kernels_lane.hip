@@ -17,6 +17,8 @@
 
 namespace miso {
 
+// (Tried: the head of the log-factorial table in LDS -- 60.5 ms against 61.2 ms from global memory with workgroups of one
+// wavefront, 56.4 ms with these workgroups of four: the table's few hundred hot entries sit in the L1 anyway.)
 __global__ __launch_bounds__(256) void sampler_lane(const KernelArgs a) {
   const long n_chains = static_cast<long>(a.n_slots) * a.C;
   const long slot = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
@@ -153,6 +155,229 @@ __global__ __launch_bounds__(256) void sampler_lane(const KernelArgs a) {
   st->counts_hash = hash;
   st->accepted = accepted;
   st->hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+}
+
+// The same step with G lanes per chain (k2_body COLLAPSED, kernels_k2.inl): a batch of fewer chains than the device has
+// lanes -- 40 000 chains are 625 wavefronts of sampler_lane, one per SIMD on 60 % of the SIMDs, every dependent
+// instruction exposed -- spreads each chain over 2 or 4 lanes: the Metropolis-Hastings step's transcendentals one per lane
+// (vec_eval), the binomial's rejection trials G at a time.  Same results bit for bit.
+template <int G> __global__ __launch_bounds__(256) void sampler_k2c(const KernelArgs a) {
+  k2_body<G, 0, 4, false, true>(a, blockIdx.x, gridDim.x);
+}
+template __global__ void sampler_k2c<2>(const KernelArgs);
+template __global__ void sampler_k2c<4>(const KernelArgs);
+template __global__ void sampler_k2c<8>(const KernelArgs);
+
+// ---- three and more isoforms (single-end): the same idea, per compatibility class ----
+// A class of n reads compatible with isoforms v_0 < ... < v_{nv-1} gets counts Multinomial(n; psi_v / sum psi_v), drawn
+// as a chain of binomials x_w ~ Binomial(n - x_0 - ... - x_{w-1}, psi_{v_w} / S_w), S_w = psi_{v_{nv-1}} + ... + psi_{v_w}
+// summed in that order; classes in the order of the event's class table (= the counter order of the reads), one word
+// stream per (chain, iteration).  One chain per lane; the chain's vectors live in LDS, [vector][isoform][lane], so
+// that isoform loops need no unrolling and lanes never collide on a bank.  The Metropolis-Hastings step is the
+// reference's arithmetic written out per chain (miso.c:97-163, 243-307, 449-552), terms of the current psi cached.
+constexpr int LANEK_VECTORS = 9;   // alpha, alpha', psi, psi', log psi, log psi', log ratios, log ratios', scratch
+// (LDS bytes per workgroup: LANEK_VECTORS x ks x 64 doubles + ks x 64 ints for the counts; runtime.hip lanek_lds_bytes)
+
+__global__ __launch_bounds__(64) void sampler_lane_k(const KernelArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_lane[];
+  const long n_chains = static_cast<long>(a.n_slots) * a.C;
+  const long slot = static_cast<long>(blockIdx.x) * 64 + threadIdx.x;
+  if (slot >= n_chains) return;   // no barrier below
+  const int lane = threadIdx.x, KS = a.kstride;
+  double *vec = reinterpret_cast<double *>(smem_lane);
+  int *cnt_base = reinterpret_cast<int *>(smem_lane + static_cast<size_t>(LANEK_VECTORS) * KS * 64 * 8);
+#define LV(v, k) vec[(static_cast<size_t>(v) * KS + (k)) * 64 + lane]
+#define CNT(k) cnt_base[(k) * 64 + lane]
+  enum { ALPHA, ALPHAN, PSI, PSIN, LP, LPN, LR, LRN, TMP };
+  const int ev = a.slot_event[slot / a.C];
+  const uint32_t chain = static_cast<uint32_t>(slot % a.C);
+  const DevEvent E = a.events[ev];
+  const int K = E.K, len = K - 1;
+  const uint32_t event_id = E.has_id ? E.explicit_id : a.first_event_id + static_cast<uint32_t>(ev);
+  const double *consts = reinterpret_cast<const double *>(a.in_pool + E.off_consts);
+  const double *cst = consts, *isc = consts + K, *hm1 = consts + 2 * K;
+  const double lg_sum = consts[3 * K], lg_each = consts[3 * K + 1], sigma = consts[3 * K + 2], sd = consts[3 * K + 3],
+               covar = consts[3 * K + 4];
+  const int *base = reinterpret_cast<const int *>(a.in_pool + E.off_base);
+  const uint32_t *ctab = reinterpret_cast<const uint32_t *>(a.in_pool + E.off_cls);
+  const uint32_t *masks = reinterpret_cast<const uint32_t *>(a.in_pool + E.off_draw);
+  const int n_draw = E.n_draw, n_dcls = E.n_dcls;
+  double *samples = reinterpret_cast<double *>(a.out_pool + E.off_samples);
+  double *loglik = reinterpret_cast<double *>(a.out_pool + E.off_loglik);
+  uint8_t *drawass = a.out_pool + E.off_drawass;
+  int32_t *trace = (E.off_trace == NO_TRACE) ? nullptr : reinterpret_cast<int32_t *>(a.out_pool + E.off_trace);
+  const uint32_t k0 = static_cast<uint32_t>(a.seed), k1 = static_cast<uint32_t>(a.seed >> 32);
+  const uint32_t c2_gibbs = MISO_SITE_GIBBS | (chain << 8);
+
+  // first drawing read of class c (device.hpp / host.cpp: row = {mask, units before, units before - first block, head | tail << 4})
+  auto class_start = [&](int c) {
+    if (c >= n_dcls) return n_draw;
+    const uint32_t *row = ctab + CLS_WORDS * c;
+    return static_cast<int>(4u * (row[1] - row[2]) + static_cast<uint32_t>(__builtin_ctz(row[3] & 0xFu)));
+  };
+  auto gibbs_collapsed = [&](uint32_t iter) {
+    for (int k = 0; k < K; k++) CNT(k) = base[k];
+    miso_ustream us;
+    miso_ustream_init(&us, a.seed, event_id, chain, iter, MISO_SITE_COUNTS);
+    int r0 = class_start(0);
+    for (int c = 0; c < n_dcls; c++) {
+      const uint32_t mask = ctab[CLS_WORDS * c];
+      const int r1 = class_start(c + 1);
+      int rem = r1 - r0;
+      r0 = r1;
+      double acc = 0.0;
+      for (int k = K - 1; k >= 0; k--)
+        if ((mask >> k) & 1u) { acc = acc + LV(PSI, k); LV(TMP, k) = acc; }
+      const int last = 31 - __builtin_clz(mask);
+      for (int k = 0; k < K; k++) {
+        if (!((mask >> k) & 1u)) continue;
+        const int x = (k == last) ? rem : miso_binomial(&us, rem, LV(PSI, k) / LV(TMP, k), a.logfact);
+        CNT(k) += x;
+        rem -= x;
+      }
+    }
+  };
+  // miso.c:30-91 read by read, word r of the Gibbs site for the r-th drawing read; chain 0's picks go back to the caller
+  auto gibbs_per_read = [&](uint32_t iter) {
+    for (int k = 0; k < K; k++) CNT(k) = base[k];
+    miso_u32x4 u{};
+    for (int r = 0; r < n_draw; r++) {
+      if ((r & 3) == 0) u = miso_philox4x32_10(static_cast<uint32_t>(r >> 2), iter, c2_gibbs, event_id, k0, k1);
+      const uint32_t word = (r & 3) == 0 ? u.v[0] : ((r & 3) == 1 ? u.v[1] : ((r & 3) == 2 ? u.v[2] : u.v[3]));
+      const uint32_t mask = masks[r];
+      const int nv = __builtin_popcount(mask);
+      double total = 0.0;
+      for (int k = 0; k < K; k++) if ((mask >> k) & 1u) total += LV(PSI, k);
+      const double rnd = miso_u01(word) * total;
+      const int lastk = 31 - __builtin_clz(mask);
+      int sel = lastk;
+      double acc = 0.0;
+      for (int k = 0; k < K; k++) {
+        if (!((mask >> k) & 1u)) continue;
+        acc += LV(PSI, k);
+        if (nv == 2) { if (rnd < acc) sel = k; break; }
+        if (!(rnd > acc)) { sel = k; break; }
+      }
+      CNT(sel) += 1;
+      if (chain == 0) drawass[r] = static_cast<uint8_t>(sel);
+    }
+  };
+  // alpha' = alpha + sd z; psi' = logit_inv(alpha') (miso.c:184-241, 449-471)
+  auto propose = [&](int from, int to_alpha, int to_psi, uint32_t iter, uint32_t &accept_word) {
+    {
+      const miso_u32x4 b0 = miso_draw_block(a.seed, event_id, chain, iter, MISO_SITE_MH, 0u);
+      accept_word = b0.v[0];
+    }
+    double sumexp = 0.0;
+    for (int i = 0; i < len; i++) {
+      const int w = 2 + 2 * i;
+      const miso_u32x4 b = miso_draw_block(a.seed, event_id, chain, iter, MISO_SITE_MH, static_cast<uint32_t>(w >> 2));
+      const uint32_t w0 = (w & 3) == 0 ? b.v[0] : b.v[2], w1 = (w & 3) == 0 ? b.v[1] : b.v[3];
+      const double z = miso_det_norm_from_unif(miso_u01(w0), miso_u01(w1));
+      const double an = LV(from, i) + sd * z;
+      LV(to_alpha, i) = an;
+      const double e = miso_det_exp(an);
+      LV(TMP, i) = e;
+      sumexp += e;
+    }
+    sumexp += 1.0;
+    double sumpsi = 0.0;
+    for (int i = 0; i < len; i++) { const double x = LV(TMP, i) / sumexp; LV(to_psi, i) = x; sumpsi += x; }
+    LV(to_psi, len) = 1 - sumpsi;
+  };
+  // what the two scores need of a psi and not of the counts: log psi_k, log(psi_k / (1 - sum)), 1 / prod / (1 - sum),
+  // the log-sum-exp of log psi_k + cst_k (miso.c:104-113, 136-149)
+  auto psi_cache = [&](int psi, int lp, int lr, double &jac, double &lse) {
+    double ltheta = 1.0, prod = 1.0;
+    for (int i = 0; i < len; i++) { const double t = LV(psi, i); ltheta -= t; prod *= t; }
+    jac = 1.0 / prod / ltheta;
+    for (int i = 0; i < len; i++) LV(lr, i) = miso_det_log(LV(psi, i) / ltheta);
+    double maxv = 0.0;
+    for (int i = 0; i < K; i++) {
+      const double l = miso_det_log(LV(psi, i));
+      LV(lp, i) = l;
+      const double t = l + cst[i];
+      maxv = (i == 0 || t > maxv) ? t : maxv;
+    }
+    double sum = 0.0;
+    for (int i = 0; i < K; i++) sum += miso_det_exp((LV(lp, i) + cst[i]) - maxv);
+    lse = miso_det_log(sum) + maxv;
+  };
+  auto joint = [&](int lp, double lse) {   // miso.c:243-307 from the counts
+    double readProb = 0.0, assProb = 0.0, psiProb = 0.0;
+    for (int i = 0; i < K; i++) {
+      const int ci = CNT(i);
+      if (ci != 0) {
+        readProb = readProb + static_cast<double>(ci) * isc[i];
+        assProb = assProb + static_cast<double>(ci) * ((LV(lp, i) + cst[i]) - lse);
+      }
+    }
+    for (int i = 0; i < K; i++) psiProb += hm1[i] * LV(lp, i);
+    psiProb += lg_sum;
+    psiProb -= lg_each;
+    return readProb + assProb + psiProb;
+  };
+  auto prop_score = [&](int lr, int mu, double jac) {   // miso.c:97-122
+    double expPart = 0.0;
+    for (int i = 0; i < len; i++) { const double t = LV(lr, i) - LV(mu, i); expPart += (-0.5) * t * t / sigma; }
+    return miso_det_log(covar * jac * miso_det_exp(expPart));
+  };
+
+  // ---- initial state: miso.c:330-447, 834, 841 ----
+  for (int i = 0; i < len; i++) LV(ALPHA, i) = (a.start == MISO_START_AUTO) ? 1.0 / (K - 1) : 0.0;
+  uint32_t accept_word = 0;
+  propose(ALPHA, ALPHA, PSI, MISO_ITER_INIT, accept_word);
+  double jac = 0.0, lse = 0.0;
+  psi_cache(PSI, LP, LR, jac, lse);
+  if (a.M > 0) gibbs_collapsed(MISO_ITER_INIT); else gibbs_per_read(MISO_ITER_INIT);
+
+  uint64_t hash = 0xCBF29CE484222325ull;
+  int accepted = 0, lagCounter = 0, noS = 0;
+  for (int m = 0; m < a.M; m++) {
+    for (int i = 0; i < K; i++) {
+      const int ci = CNT(i);
+      hash = (hash ^ static_cast<uint32_t>(ci)) * 0x100000001B3ull;
+      if (trace) trace[(static_cast<size_t>(m) * a.C + chain) * K + i] = ci;
+    }
+    propose(ALPHA, ALPHAN, PSIN, static_cast<uint32_t>(m), accept_word);
+    double jacN, lseN;
+    psi_cache(PSIN, LPN, LRN, jacN, lseN);
+    const double pp = joint(LPN, lseN);
+    const double pc = joint(LP, lse);
+    const double ptoCS = prop_score(LR, ALPHAN, jac);      // theta = psi,  mu = alpha'
+    const double ctoPS = prop_score(LRN, ALPHA, jacN);     // theta = psi', mu = alpha
+    const double acceptP = (m > 0) ? miso_det_exp(pp + ptoCS - (pc + ctoPS)) : miso_det_exp(pp - pc);
+    const bool acc = (acceptP >= 1) || (miso_u01(accept_word) < acceptP);
+    double cJS = pc;
+    if (acc) {
+      for (int i = 0; i < K; i++) { LV(PSI, i) = LV(PSIN, i); LV(LP, i) = LV(LPN, i); }
+      for (int i = 0; i < len; i++) { LV(ALPHA, i) = LV(ALPHAN, i); LV(LR, i) = LV(LRN, i); }
+      jac = jacN; lse = lseN; cJS = pp; accepted++;
+    }
+    if (m >= a.B) {  // miso.c:882-893
+      if (lagCounter == a.lag - 1) {
+        const size_t col = static_cast<size_t>(noS) + chain;
+        for (int i = 0; i < K; i++) samples[col * K + i] = LV(PSI, i);
+        loglik[col] = cJS;
+        noS += a.C;
+        lagCounter = 0;
+      } else {
+        lagCounter++;
+      }
+    }
+    if (m != a.M - 1) gibbs_collapsed(static_cast<uint32_t>(m)); else gibbs_per_read(static_cast<uint32_t>(m));
+  }
+  for (int i = 0; i < K; i++) {
+    const int ci = CNT(i);
+    hash = (hash ^ static_cast<uint32_t>(ci)) * 0x100000001B3ull;
+    if (trace) trace[(static_cast<size_t>(a.M) * a.C + chain) * K + i] = ci;
+  }
+  ChainStats *st = reinterpret_cast<ChainStats *>(a.out_pool + E.off_stats) + chain;
+  st->counts_hash = hash;
+  st->accepted = accepted;
+  st->hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+#undef LV
+#undef CNT
 }
 
 }  // namespace miso

@@ -26,6 +26,10 @@ template <int G, int MODE, int WPB> __global__ void sampler_k2(const KernelArgs 
 template <int GA, int GB> __global__ void sampler_k2_mix(const KernelArgs a);
 template <int MODE, int WPB> __global__ void sampler_k2_multi(const KernelArgs a);
 __global__ void sampler_lane(const KernelArgs a);   // kernels_lane.hip: collapsed Gibbs step, one chain per lane
+template <int G> __global__ void sampler_k2c(const KernelArgs a);   // ... G lanes per chain (k2_body COLLAPSED)
+__global__ void sampler_lane_k(const KernelArgs a); // ... three and more isoforms (vectors in LDS)
+constexpr int LANEK_VECTORS = 9;
+inline size_t lanek_lds_bytes(int ks) { return static_cast<size_t>(LANEK_VECTORS) * ks * 64 * 8 + static_cast<size_t>(ks) * 64 * 4; }
 __global__ void compare_kernel(const DevEvent *, const unsigned char *, const DevEvent *, const unsigned char *, int, int,
                                double, const uint64_t *, double *);
 __global__ void match_kernel(const MatchEvent *, const int2 *, const int *, const int *, const int *, const int *,
@@ -732,9 +736,16 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   // per wavefront, as many as fit the wavefront's share of the LDS (two workgroups of four wavefronts
   // per CU: 20 KB each), fewer when the batch would not fill the device otherwise.
   // MISO_NO_FLAT=1: sampler_grp as in round 1 (A/B, tests); MISO_FLAT_NC=n forces the chains per wavefront.
+  // collapsed single-end batches (miso_batch_set_collapsed): the events with three and more isoforms in ONE launch of
+  // sampler_lane_k (kernels_lane.hip), provided every one of them has its class table
+  // (level 2 only: with the classes of a five- or ten-isoform event sharing ~1000 reads the chains of small binomials
+  // cost more than the read sweep they replace -- profiles/r03_collapsed.txt; it pays from ~10^4 reads per event)
+  bool lane_gen = collapsed && collapsed_level >= 2 && !p.paired && n_gen > 0;
+  for (const GenRun &run : gen_runs) if (run.nocls) lane_gen = false;
   std::vector<int> flat_nc(gen_runs.size(), 0), flat_nc_max(gen_runs.size(), 0);
   for (size_t ri = 0; ri < gen_runs.size(); ri++) {
     const GenRun &run = gen_runs[ri];
+    if (lane_gen) break;
     if (p.paired || run.nocls || std::getenv("MISO_NO_FLAT") != nullptr) continue;
     const int slice = flat_layout(run.kmax, std::max(run.maxcls, 1)).bytes;
     // workgroups per CU: 3 for K <= 4 (kernels_flat.inl's register budget allows it up to K = 8), else 2; MISO_FLAT_WGS overrides
@@ -870,6 +881,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   std::vector<GrpShape> grp_sh(gen_runs.size());
   for (size_t ri = 0; ri < gen_runs.size(); ri++) {
     GenRun &run = gen_runs[ri];
+    if (lane_gen) break;
     // sampler_flat or sampler_grp?  Measured on the batch's first launch like the lanes per chain below
     // (flat wins at every isoform count of profiles/r02_flat_vs_grp_sweep.txt but 5); a small or untuned
     // batch takes sampler_flat.
@@ -1004,6 +1016,14 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   const int coop_max = std::getenv("MISO_NO_COOP") ? 1 : COOP_MAX_N;
   bool k2_multi = false;
   const bool lane_route = collapsed && !p.paired && n_k2 > 0;   // miso_batch_set_collapsed
+  // lanes per chain of the collapsed step: one (sampler_lane).  Sharing a chain between 2, 4 or 8 lanes (sampler_k2c:
+  // the Metropolis-Hastings step's transcendentals one per lane, the binomial's rejection trials G at a time) brings more
+  // wavefronts but the same instructions per wavefront -- 40 000 chains: 56.4 ms on one lane, 58.5 / 59.1 / 86.3 ms on
+  // 2 / 4 / 8 (profiles/r03_collapsed.txt); MISO_COLLAPSED_LANES forces (experiments, tests)
+  int lane_G = 1;
+  if (lane_route) {
+    if (const char *f = std::getenv("MISO_COLLAPSED_LANES")) { const int g = std::atoi(f); if (g == 1 || g == 2 || g == 4 || g == 8) lane_G = g; }
+  }
   {
     const int count = n_k2 - n_k2w;
     const char *off = std::getenv("MISO_K2_MULTI");
@@ -1217,7 +1237,8 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     };
     if (!wpart && lane_route) {
       for (int n : nd) words += static_cast<double>(n) * C;
-      add_stat("sampler_lane", static_cast<double>((chains + 63) / 64), 0.0, static_cast<double>(chains), words);
+      add_stat(lane_G == 1 ? std::string("sampler_lane") : "sampler_k2c<" + std::to_string(lane_G) + ">",
+               static_cast<double>((chains * lane_G + 63) / 64), 0.0, static_cast<double>(chains), words);
     } else if (wpart ? k2w_multi : k2_multi) {
       const LanePlan &pl = wpart ? planw_copy : plan_copy;
       for (int sg = 0; sg < pl.n_segs; sg++) {
@@ -1245,7 +1266,14 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       add_stat(k2_name(k2G, wpart), static_cast<double>(waves), trips, static_cast<double>(chains), words);
     }
   }
+  if (lane_gen) {
+    double words = 0;
+    for (int i = 0; i < n_gen; i++) words += static_cast<double>(events[h_slots[n_k2 + i]].n_draw) * p.noChains;
+    const long chains = static_cast<long>(n_gen) * p.noChains;
+    add_stat("sampler_lane_k", static_cast<double>((chains + 63) / 64), 0.0, static_cast<double>(chains), words);
+  }
   for (size_t ri = 0; ri < gen_runs.size(); ri++) {
+    if (lane_gen) break;
     const GenRun &run = gen_runs[ri];
     const bool flat = flat_nc[ri] > 0;
     const int G = grp_G[ri], C = p.noChains, cpw = flat ? flat_nc[ri] : std::max(1, 64 / G);
@@ -1351,7 +1379,33 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
                                     (wave_k ? std::string(">") : ", " + std::to_string(run.kc) + ">"));
     launch_grp(a, run, grp_sh[ri], G, stream_for_next());
   };
-  for (size_t ri = 0; ri < gen_runs.size(); ri++) if (gen_runs[ri].wide) launch_gen_run(ri);
+  auto ensure_logfact = [&](int first, int count) {   // log factorials (miso_binomial.h) up to the largest event's drawing reads
+    int need = 2;
+    for (int i = 0; i < count; i++) need = std::max(need, events[h_slots[first + i]].n_draw + 2);
+    if (need > logfact_n) {
+      std::vector<double> lf(static_cast<size_t>(need));
+      miso_logfact_fill(lf.data(), need);
+      HIP_OK(hipStreamSynchronize(stream));   // (an earlier launch of this batch may still read the old table)
+      if (d_logfact) HIP_OK(hipFree(d_logfact));
+      HIP_OK(hipMalloc(reinterpret_cast<void **>(&d_logfact), lf.size() * sizeof(double)));
+      HIP_OK(hipMemcpy(d_logfact, lf.data(), lf.size() * sizeof(double), hipMemcpyHostToDevice));
+      logfact_n = need;
+    }
+  };
+  if (lane_route || lane_gen) ensure_logfact(0, n_k2 + n_gen);
+  if (lane_gen) {
+    int ks = 2;
+    for (const GenRun &run : gen_runs) ks = std::max(ks, run.kmax);
+    KernelArgs ka = a;
+    ka.slot_event = d_slots + n_k2; ka.n_slots = n_gen; ka.kstride = ks; ka.logfact = d_logfact;
+    const long chains = static_cast<long>(n_gen) * p.noChains;
+    const size_t lds = lanek_lds_bytes(ks);
+    HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sampler_lane_k), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    last_kernels += std::string(last_kernels.empty() ? "" : ",") + "sampler_lane_k";
+    hipLaunchKernelGGL(sampler_lane_k, dim3(static_cast<unsigned>((chains + 63) / 64)), dim3(64), lds, stream_for_next(), ka);
+    HIP_OK(hipGetLastError());
+  }
+  for (size_t ri = 0; ri < gen_runs.size(); ri++) if (gen_runs[ri].wide && !lane_gen) launch_gen_run(ri);
   if (n_k2w > 0 && k2w_multi) {
     lanes_per_chain = k2w_plan.seg_lanes[k2w_plan.n_segs - 1];
     last_kernels = "sampler_k2_multi<2, " + std::to_string(k2w_plan.wpb) + ">";
@@ -1364,23 +1418,21 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   if (n_k2 - n_k2w > 0) {
     lanes_per_chain = k2_G;
     if (lane_route) {   // collapsed single-end batch: one chain per lane, no read loop (kernels_lane.hip)
-      lanes_per_chain = 1;
-      last_kernels += std::string(last_kernels.empty() ? "" : ",") + "sampler_lane";
       KernelArgs ka = a;
-      ka.slot_event = d_slots; ka.n_slots = n_k2;
-      int need = 2;
-      for (int i = 0; i < n_k2; i++) need = std::max(need, events[h_slots[i]].n_draw + 2);
-      if (need > logfact_n) {   // log factorials (miso_binomial.h), once per batch
-        std::vector<double> lf(static_cast<size_t>(need));
-        miso_logfact_fill(lf.data(), need);
-        if (d_logfact) HIP_OK(hipFree(d_logfact));
-        HIP_OK(hipMalloc(reinterpret_cast<void **>(&d_logfact), lf.size() * sizeof(double)));
-        HIP_OK(hipMemcpy(d_logfact, lf.data(), lf.size() * sizeof(double), hipMemcpyHostToDevice));
-        logfact_n = need;
-      }
+      ka.slot_event = d_slots; ka.n_slots = n_k2; ka.pair_waves = 0;
       ka.logfact = d_logfact;
       const long chains = static_cast<long>(n_k2) * p.noChains;
-      hipLaunchKernelGGL(sampler_lane, dim3(static_cast<unsigned>((chains + 255) / 256)), dim3(256), 0, stream_for_next(), ka);
+      const int G = lane_G;
+      lanes_per_chain = G;
+      last_kernels += std::string(last_kernels.empty() ? "" : ",") + (G == 1 ? std::string("sampler_lane") : "sampler_k2c<" + std::to_string(G) + ">");
+      const unsigned grid = static_cast<unsigned>(((chains + 64 / G - 1) / (64 / G) + 3) / 4);
+      hipStream_t st = stream_for_next();
+      switch (G) {
+      case 1: hipLaunchKernelGGL(sampler_lane, dim3(static_cast<unsigned>((chains + 255) / 256)), dim3(256), 0, st, ka); break;
+      case 2: hipLaunchKernelGGL(sampler_k2c<2>, dim3(grid), dim3(256), 0, st, ka); break;
+      case 4: hipLaunchKernelGGL(sampler_k2c<4>, dim3(grid), dim3(256), 0, st, ka); break;
+      default: hipLaunchKernelGGL(sampler_k2c<8>, dim3(grid), dim3(256), 0, st, ka); break;
+      }
       HIP_OK(hipGetLastError());
     } else if (k2_multi) {
       lanes_per_chain = k2_plan.seg_lanes[k2_plan.n_segs - 1];
@@ -1394,7 +1446,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       launch_k2(a, k2_G, stream_for_next());
     }
   }
-  for (size_t ri = 0; ri < gen_runs.size(); ri++) if (!gen_runs[ri].wide) launch_gen_run(ri);
+  for (size_t ri = 0; ri < gen_runs.size(); ri++) if (!gen_runs[ri].wide && !lane_gen) launch_gen_run(ri);
   for (size_t i = 1; i < kernel_no && i <= aux_streams.size() && std::getenv("MISO_SERIAL_KERNELS") == nullptr; i++) {
     HIP_OK(hipEventRecord(aux_done[i - 1], aux_streams[i - 1]));
     HIP_OK(hipStreamWaitEvent(stream, aux_done[i - 1], 0));

@@ -190,7 +190,10 @@ class MISOSampler:
                            var=float(self.frag_variance) if self.paired_end else 0.0,
                            num_devs=4.0,                                  # miso_sampler.py:289
                            start=start_cond, stop=stop_cond, algo=pysplicing.MISO_ALGO_REASSIGN,
-                           device_match=True)
+                           device_match=True,
+                           # opt-in, single-end: the collapsed Gibbs step (include/miso_amd.h miso_batch_set_collapsed);
+                           # params["collapsed"] or MISO_COLLAPSED=1|2 in the environment
+                           collapsed=0 if self.paired_end else int(self.params.get("collapsed", os.environ.get("MISO_COLLAPSED", 0)) or 0))
         written = [None] * len(events)
         slots = []
         from sam_utils import STRAND_RULES

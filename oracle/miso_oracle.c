@@ -14,6 +14,11 @@
  *                     per-isoform counts (single-end: miso.c:265-271 / 152-156 summed per read
  *                     equal sum_k count_k*score_k up to rounding) and, paired-end, the per-read
  *                     fragment score summed in 2^-26 fixed point (order independent, miso_philox.h).
+ *   ORC_MODE_COLLAPSED counter mode with the Gibbs step collapsed over exchangeable reads (single-end): per
+ *                     compatibility class the counts are Multinomial(n; psi restricted to the class), drawn as a chain
+ *                     of binomials (include/miso_binomial.h) -- the per-read law of miso.c:30-91 summed over the
+ *                     class's reads; the run's last reassignment is per read.  Pinned statistically against
+ *                     counter mode, the quadrature and the real reference (tests/test_collapsed.py).
  */
 #include "miso_oracle.h"
 

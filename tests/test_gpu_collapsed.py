@@ -4,6 +4,9 @@ COUNT of their exchangeable reads on isoform 0 as one exact binomial per iterati
 mode (oracle/miso_oracle.c ORC_MODE_COLLAPSED) -- samples, log scores, per-iteration counts, the final per-read
 assignment -- on events from 0 to 60 000 reads in one launch; the binomial sampler itself and the agreement of the
 collapsed chain with the per-read chain and the real reference are CPU tests (tests/test_collapsed.py)."""
+import contextlib
+import os
+
 import numpy as np
 import pytest
 
@@ -12,6 +15,24 @@ from _libs import OrcLib
 from _problems import flat, se_gene, expr_for
 
 pytestmark = pytest.mark.gpu
+
+
+@contextlib.contextmanager
+def _env(**kw):
+    old = {k: os.environ.get(k) for k in kw}
+    for k, v in kw.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+    try:
+        yield
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 @pytest.fixture(scope="module")
@@ -36,22 +57,84 @@ def test_collapsed_bit_exact_against_the_checker(orc, chains, iters, burn, lag):
     sizes = [700, 60000, 20, 0, 3, 150, 9000, 45, 1000, 64, 65, 2500, 31, 1, 333, 5000]
     evs = _events(orc, sizes)
     kw = dict(iters=iters, burn=burn, lag=lag, chains=chains)
-    b = miso_amd.Batch(36, counts_trace=True, collapsed=True, **kw)
-    for exons, isoforms, g, pos, cig in evs:
-        b.add_event(miso_amd.Gene(exons, isoforms), pos, cig)
-    b.run(seed=77, first_event_id=1200)
-    assert b.last_kernels() == "sampler_lane"
+    cpu = []
     for i, (exons, isoforms, g, pos, cig) in enumerate(evs):
         r = orc.miso(g, pos, cig, 36, mode=OrcLib.COLLAPSED, seed=77, event_id=1200 + i, trace=True, **kw)
         assert r.rc == 0
+        cpu.append(r)
+    # lanes per chain: 1 = sampler_lane; 2, 4, 8 = sampler_k2c (the binomial's rejection trials that many at a time,
+    # the Metropolis-Hastings step's transcendentals one per lane): the same bits
+    for lanes, name in ((1, "sampler_lane"), (2, "sampler_k2c<2>"), (4, "sampler_k2c<4>"), (8, "sampler_k2c<8>"), (None, "sampler_lane")):
+        with _env(MISO_COLLAPSED_LANES=None if lanes is None else str(lanes)):
+            b = miso_amd.Batch(36, counts_trace=True, collapsed=True, **kw)
+            for exons, isoforms, g, pos, cig in evs:
+                b.add_event(miso_amd.Gene(exons, isoforms), pos, cig)
+            b.run(seed=77, first_event_id=1200)
+        assert b.last_kernels() == name
+        for i, r in enumerate(cpu):
+            gpu = b.result(i, trace=True)
+            where = (sizes[i], kw, name)
+            assert np.array_equal(gpu.counts_trace, r.trace["counts_trace"]), where
+            assert (gpu.counts_hash == r.trace["counts_hash"]).all(), where
+            assert np.array_equal(gpu.samples, r.samples, equal_nan=True), where
+            assert np.array_equal(gpu.loglik, r.loglik, equal_nan=True), where
+            assert (gpu.assignment == r.assignment).all(), where
+            assert gpu.rundata.noAccepted == r.accepted, where
+
+
+@pytest.mark.parametrize("K,chains,iters,burn,lag", [(3, 1, 200, 40, 1), (5, 2, 150, 10, 3), (10, 1, 120, 20, 1), (18, 1, 60, 10, 1),
+                                                     (4, 2, 0, 0, 1), (7, 1, 1, 0, 1)])
+def test_collapsed_three_or_more_isoforms_bit_exact_against_the_checker(orc, K, chains, iters, burn, lag):
+    """sampler_lane_k: per compatibility class a chain of binomials (include/miso_binomial.h), classes in the order of
+    the event's class table; events of 0 .. 20 000 reads and of K and K - 1 isoforms in one launch."""
+    sizes = [500, 20000, 12, 0, 3, 150, 4000, 45, 1000, 64, 2500, 31]
+    evs = []
+    for j, n in enumerate(sizes):
+        Kj = K if j % 4 else max(3, K - 1)
+        exons, isoforms = se_gene(Kj, exlen=200 + 13 * j)
+        g = orc.gene(flat(exons), isoforms)
+        orc.rng_seed(5000 + j)
+        rc, _, pos, cig = orc.simulate_reads(g, expr_for(Kj), max(n, 1), 36)
+        assert rc == 0
+        evs.append((exons, isoforms, g, pos[:n], cig[:n], Kj))
+    kw = dict(iters=iters, burn=burn, lag=lag, chains=chains)
+    b = miso_amd.Batch(36, counts_trace=True, collapsed=2, **kw)
+    for exons, isoforms, g, pos, cig, Kj in evs:
+        b.add_event(miso_amd.Gene(exons, isoforms), pos, cig)
+    b.run(seed=91, first_event_id=40)
+    assert b.last_kernels() == "sampler_lane_k"
+    for i, (exons, isoforms, g, pos, cig, Kj) in enumerate(evs):
+        r = orc.miso(g, pos, cig, 36, mode=OrcLib.COLLAPSED, seed=91, event_id=40 + i, trace=True, **kw)
+        assert r.rc == 0
         gpu = b.result(i, trace=True)
-        where = (sizes[i], kw)
+        where = (Kj, sizes[i], kw)
         assert np.array_equal(gpu.counts_trace, r.trace["counts_trace"]), where
         assert (gpu.counts_hash == r.trace["counts_hash"]).all(), where
-        assert np.array_equal(gpu.samples, r.samples, equal_nan=True), where
+        assert np.array_equal(gpu.samples, r.samples.reshape(gpu.samples.shape), equal_nan=True), where
         assert np.array_equal(gpu.loglik, r.loglik, equal_nan=True), where
         assert (gpu.assignment == r.assignment).all(), where
         assert gpu.rundata.noAccepted == r.accepted, where
+
+
+def test_collapsed_mixed_isoform_counts_use_both_kernels(orc):
+    evs = []
+    for j, (K, n) in enumerate([(2, 300), (5, 400), (2, 50), (3, 800)]):
+        exons, isoforms = se_gene(K, exlen=250 + 9 * j)
+        g = orc.gene(flat(exons), isoforms)
+        orc.rng_seed(6000 + j)
+        rc, _, pos, cig = orc.simulate_reads(g, expr_for(K), n, 36)
+        evs.append((exons, isoforms, g, pos, cig))
+    kw = dict(iters=100, burn=20, lag=2, chains=2)
+    b = miso_amd.Batch(36, collapsed=2, **kw)
+    for exons, isoforms, g, pos, cig in evs:
+        b.add_event(miso_amd.Gene(exons, isoforms), pos, cig)
+    b.run(seed=5, first_event_id=7)
+    assert sorted(b.last_kernels().split(",")) == ["sampler_lane", "sampler_lane_k"]
+    for i, (exons, isoforms, g, pos, cig) in enumerate(evs):
+        r = orc.miso(g, pos, cig, 36, mode=OrcLib.COLLAPSED, seed=5, event_id=7 + i, trace=True, **kw)
+        gpu = b.result(i)
+        assert np.array_equal(gpu.samples, r.samples.reshape(gpu.samples.shape), equal_nan=True), i
+        assert (gpu.assignment == r.assignment).all(), i
 
 
 def test_collapsed_differs_from_per_read_draws_but_not_in_distribution(orc):

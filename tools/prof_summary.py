@@ -53,7 +53,8 @@ def bench_key(bench):
     K = c["K"]
     k = "%d-%d" % tuple(K) if isinstance(K, (list, tuple)) else str(K)
     return "events=%d|K=%s|reads=%s|iters=%d|chains=%d|paired=%d" % (
-        c["events_per_gpu"], k, c["reads"], c["iters"], c["chains"], int("paired-end" in c["workload"]))
+        c["events_per_gpu"], k, c["reads"], c["iters"], c["chains"], int("paired-end" in c["workload"])) + \
+        ("|collapsed" if c.get("collapsed") else "")
 
 
 def update_valu_model(prof_dir):
