@@ -81,6 +81,48 @@ def test_miso_run_cli_on_reference_test_data(tmp_path, fmt):
     assert np.array_equal(miso_sampler.load_samples(miso_file)[0], samples)
 
 
+def test_miso_run_cli_collapsed_opt_in(tmp_path):
+    """MISO_COLLAPSED=1: the same command line, the two-isoform gene through the collapsed Gibbs step
+    (sampler_lane): every printed digit equals the checker's collapsed mode, the header and the read classes are the
+    per-read mode's, the posterior mean agrees with the real reference's run of the golden fixture."""
+    import miso_sampler
+    with gzip.open(os.path.join(DATA, "c2c12.Atp2b1.sam.gz"), "rt") as f:
+        sam_text = f.read()
+    aln = str(tmp_path / "c2c12.Atp2b1.sam")
+    open(aln, "w").write(sam_text)
+    idx, out = str(tmp_path / "indexed"), str(tmp_path / "out")
+    settings = tmp_path / "settings.txt"
+    settings.write_text("[data]\nfilter_results = True\nmin_event_reads = 20\n"
+                        "[sampler]\nburn_in = 200\nlag = 4\nnum_iters = 1000\nnum_chains = 2\n")
+    r = run(["-m", "miso_amd.index_gff", "--index", os.path.join(DATA, "Atp2b1.mm9.gff"), idx])
+    assert r.returncode == 0, r.stdout
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), MISO_COLLAPSED="1")
+    r = subprocess.run([sys.executable, "-m", "miso_amd.miso", "--run", idx, aln, "--output-dir", out, "--read-len", "36",
+                        "--settings-filename", str(settings), "-p", "1", "--seed", "31"], env=env, cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout
+    miso_file = os.path.join(out, "10", "ENSMUSG00000019943.miso")
+    assert os.path.isfile(miso_file), r.stdout
+    samples, hdr, scores = miso_sampler.load_samples(miso_file)
+    g = _golden.load("atp2b1")
+    counts = ",".join("(%s):%d" % (",".join(str(int(v)) for v in t), c)
+                      for t, c in zip(g["class_templates"], g["class_counts"]))
+    assert hdr["counts"] == counts and samples.shape == (400, 2)
+    assert abs(samples[:, 0].mean() - g["samples"][:, 0].mean()) < 0.02
+    from miso_amd import gene_utils
+    gene = gene_utils.load_genes_from_gff(os.path.join(DATA, "Atp2b1.mm9.gff"),
+                                          suppress_warnings=True)["ENSMUSG00000019943"]["gene_object"]
+    exons = [(p.start, p.end) for p in gene.parts]
+    isoforms = [[gene.parts.index(p) for p in iso.parts] for iso in gene.isoforms]
+    orc = OrcLib()
+    kw = dict(iters=1000, burn=200, lag=4, chains=2, seed=31, event_id=0)
+    cpu = orc.miso(orc.gene(flat(exons), isoforms), g["pos"], g["cigars"], 36, mode=OrcLib.COLLAPSED, **kw)
+    per_read = orc.miso(orc.gene(flat(exons), isoforms), g["pos"], g["cigars"], 36, mode=OrcLib.COUNTER, **kw)
+    assert cpu.rc == 0
+    assert np.array_equal(samples, np.round(cpu.samples, 4))
+    assert not np.array_equal(samples, np.round(per_read.samples, 4))   # other draws than the default mode's
+
+
 def test_native_writer_and_region_path_equal_the_python_path(tmp_path):
     """One event three ways -- run_sampler (Python row loop, miso_sampler.py:456-464),
     run_sampler_batch with explicit reads and run_sampler_batch with the reads still in the
