@@ -333,7 +333,7 @@ def roofline_for(batch, kernel_ms, key, sh):
     # (rocprofv3 prints every template argument, the library's names leave a defaulted `false` out)
     profiled = None if m is None else sorted(re.search(r"miso::(sampler_[^(]+)\(", k).group(1).replace(", false>", ">")
                                              for k in m["kernels"])
-    launched = sorted(set(re.findall(r"sampler_\w+<[^>]*>", name)))   # (size buckets may launch one kernel twice)
+    launched = sorted(set(re.findall(r"sampler_\w+(?:<[^>]*>)?", name)))   # (size buckets may launch one kernel twice)
     if m is not None and profiled == launched:
         cyc = m["valu_per_chain_iteration"] * chain_iters * m["issue_cycles_per_valu"]
         out["achieved"] = round(cyc / t / 1e9, 1)
