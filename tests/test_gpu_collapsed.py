@@ -160,3 +160,30 @@ def test_collapsed_differs_from_per_read_draws_but_not_in_distribution(orc):
 def test_collapsed_is_refused_for_paired_end():
     with pytest.raises(miso_amd.InternalError):
         miso_amd.Batch(36, paired=True, mean=250.0, var=900.0, collapsed=True)
+
+
+def test_collapsed_results_do_not_depend_on_batching(orc):
+    """Every draw is addressed by (seed, event id, chain, iteration): six events in one batch, in two batches of three
+    with the matching first_event_id, and with explicit ids in another order give the same bits."""
+    evs = _events(orc, [300, 50, 1200, 7, 640, 90])
+    kw = dict(iters=150, burn=30, lag=2, chains=2)
+
+    def batch(items, first):
+        b = miso_amd.Batch(36, collapsed=True, **kw)
+        for exons, isoforms, g, pos, cig in items:
+            b.add_event(miso_amd.Gene(exons, isoforms), pos, cig)
+        b.run(seed=9, first_event_id=first)
+        return b
+    whole = batch(evs, 100)
+    a, c = batch(evs[:3], 100), batch(evs[3:], 103)
+    for i in range(6):
+        part = a.result(i) if i < 3 else c.result(i - 3)
+        assert np.array_equal(whole.result(i).samples, part.samples) and (whole.result(i).assignment == part.assignment).all()
+    b = miso_amd.Batch(36, collapsed=True, **kw)
+    order = [4, 1, 5, 0, 3, 2]
+    for j, i in enumerate(order):
+        exons, isoforms, g, pos, cig = evs[i]
+        b.set_event_id(b.add_event(miso_amd.Gene(exons, isoforms), pos, cig), 100 + i)
+    b.run(seed=9, first_event_id=0)
+    for j, i in enumerate(order):
+        assert np.array_equal(whole.result(i).samples, b.result(j).samples)

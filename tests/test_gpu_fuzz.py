@@ -69,3 +69,43 @@ def test_random_mixed_batches_bit_exact(orc, paired, seed):
         assert (gpu.assignment == cpu.assignment).all()
         assert gpu.rundata.noAccepted == cpu.accepted
     assert "," in b.last_kernels()          # several kernels in this launch
+
+
+@pytest.mark.parametrize("level,seed", [(1, 11), (2, 12), (2, 13)])
+def test_random_mixed_batches_collapsed_bit_exact(orc, level, seed):
+    """The same random single-end batches with the collapsed Gibbs step against the checker's collapsed
+    mode: level 1 collapses the two-isoform events only (the others run their per-read kernels = counter mode), level 2
+    every event (sampler_lane_k: random genes have many more compatibility classes than skip-one-exon genes); random
+    Dirichlet hyper-parameters on some events."""
+    rng = np.random.default_rng(seed)
+    chains, iters = int(rng.integers(1, 4)), int(rng.integers(60, 140))
+    burn, lag = int(rng.integers(0, 30)), int(rng.integers(1, 6))
+    kw = dict(iters=iters, burn=burn, lag=lag, chains=chains)
+    b = miso_amd.Batch(36, counts_trace=True, device_match=bool(seed % 2), collapsed=level, **kw)
+    cases = []
+    ks = [2, 2, 2, 3, 4, 5, 7, 8, 9, 12, 13, 16, 17, 20] + [int(k) for k in rng.integers(2, 12, size=6)]
+    for j, K in enumerate(ks):
+        exons, isoforms = random_gene(rng, K, 90, 80)
+        g = orc.gene(flat(exons), isoforms)
+        n = int(rng.choice([0, 1, 3, 40, 400, 1200, 6000])) if j % 4 == 0 else int(rng.integers(50, 900))
+        orc.rng_seed(1000 * seed + j)
+        rc, iso, pos, cig = orc.simulate_reads(g, expr_for(K), n, 36)
+        assert rc == 0
+        hyper = None if j % 3 else rng.uniform(0.5, 3.0, size=K)
+        idx = b.add_event(miso_amd.Gene(exons, isoforms), pos, cig, hyper=hyper)
+        cases.append((idx, g, pos, cig, K, hyper))
+    b.run(seed=199 + seed, first_event_id=70)
+    for idx, g, pos, cig, K, hyper in cases:
+        mode = OrcLib.COLLAPSED if (K == 2 or level == 2) else OrcLib.COUNTER
+        cpu = orc.miso(g, pos, cig, 36, hyper=hyper, mode=mode, seed=199 + seed, event_id=70 + idx, trace=True, **kw)
+        assert cpu.rc == 0
+        gpu = b.result(idx, trace=True)
+        where = (level, K, len(pos))
+        assert (gpu.counts_trace == cpu.trace["counts_trace"]).all(), where
+        assert (gpu.counts_hash == cpu.trace["counts_hash"]).all(), where
+        assert np.array_equal(gpu.samples, cpu.samples.reshape(gpu.samples.shape), equal_nan=True), where
+        assert np.array_equal(gpu.loglik, cpu.loglik, equal_nan=True), where
+        assert (gpu.assignment == cpu.assignment).all(), where
+        assert gpu.rundata.noAccepted == cpu.accepted, where
+    names = b.last_kernels().split(",")
+    assert "sampler_lane" in names and (("sampler_lane_k" in names) == (level == 2)), names
