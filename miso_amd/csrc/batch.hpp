@@ -104,6 +104,7 @@ struct miso_batch {
   int lanes_per_chain = 0;        // G of the last sampler_k2 launch (0 = none)
   std::string last_kernels;       // names of the kernels of the last launch, comma separated
   std::vector<miso_kernel_stat_t> kernel_stats;   // miso_batch_launch_stats, filled on demand by stats_builder
+  std::vector<char> run_in_multi;                 // gen_runs launched as a segment of sampler_grp_multi (last launch)
   std::function<void()> stats_builder;            // set by launch(): the walk over events and wavefronts is not part of a launch
   int wave_slots = 2048;          // resident sampler_k2 wavefronts on the device
   std::vector<miso::DevEvent> h_events;

@@ -761,7 +761,7 @@ template <int G, bool PE, int KC, bool WIDE = false>
 #ifndef MISO_GRP_PE_BLOCKS
 #define MISO_GRP_PE_BLOCKS 2
 #endif
-__global__ __launch_bounds__(256, PE ? MISO_GRP_PE_BLOCKS : (KC <= 8 ? MISO_GRP_MINBLOCKS : 2)) void sampler_grp(const KernelArgs a) {
+__device__ __forceinline__ void grp_body(const KernelArgs &a, unsigned block_x) {   // workgroup block_x of the run
   constexpr int KLO = KC == 4 ? 3 : (KC == 8 ? 5 : (KC == 12 ? 9 : (KC == 16 ? 13 : 17)));   // the class holds K in [KLO, KC]
   constexpr int MH_CH = PE ? (KC <= 8 ? KC : 4) : 1;   // chunk width of the Metropolis-Hastings step's serial chains (seq_sum_u)
   static_assert(!WIDE || (PE && G == 64), "workgroup-wide chains: paired-end, whole wavefronts");
@@ -792,15 +792,15 @@ __global__ __launch_bounds__(256, PE ? MISO_GRP_PE_BLOCKS : (KC <= 8 ? MISO_GRP_
   const long n_chains = static_cast<long>(a.n_slots) * a.C;
   // WIDE: which chain this workgroup works on, alone or as one of several (coop.hpp)
   CoopGroup cg{0, 1, nullptr};
-  long wide_slot = blockIdx.x;
+  long wide_slot = block_x;
   if (WIDE && a.coop_tab) {
-    const int32_t *t = a.coop_tab + 4 * static_cast<size_t>(blockIdx.x);
+    const int32_t *t = a.coop_tab + 4 * static_cast<size_t>(block_x);
     wide_slot = __builtin_amdgcn_readfirstlane(t[0]);
     cg.rank = __builtin_amdgcn_readfirstlane(t[1]); cg.n = __builtin_amdgcn_readfirstlane(t[2]);
     cg.mem = a.coop_mem + static_cast<size_t>(__builtin_amdgcn_readfirstlane(t[3])) * COOP_WORDS;
   }
   uint32_t coop_step = 0; bool coop_ok = true;
-  const long wave_id = WIDE ? wide_slot : static_cast<long>(blockIdx.x) * 4 + wave;
+  const long wave_id = WIDE ? wide_slot : static_cast<long>(block_x) * 4 + wave;
   if (wave_id * CPW >= n_chains) return;  // no block-level barrier below (WIDE: the whole workgroup leaves)
   long slot = wave_id * CPW + grp;
   const bool live_all = slot < n_chains;
@@ -1406,6 +1406,33 @@ __global__ __launch_bounds__(256, PE ? MISO_GRP_PE_BLOCKS : (KC <= 8 ? MISO_GRP_
       st->counts_hash = wt_t0;   // when it started
 #endif
     }
+  }
+}
+
+template <int G, bool PE, int KC, bool WIDE = false>
+__global__ __launch_bounds__(256, PE ? MISO_GRP_PE_BLOCKS : (KC <= 8 ? MISO_GRP_MINBLOCKS : 2)) void sampler_grp(const KernelArgs a) {
+  grp_body<G, PE, KC, WIDE>(a, blockIdx.x);
+}
+
+// Paired-end, one isoform-count class with its size buckets in ONE launch (runtime.hip): runs of the launch's genes --
+// one chain per workgroup (with the chains on several workgroups in front), per wavefront, on 32 and on 16 lanes --
+// as a.n_segs segments: workgroups [seg_block[s], seg_block[s + 1]), genes (slots) [seg_slot[s], seg_slot[s + 1]) of
+// the launch's list, seg_lanes[s] lanes per chain (K2_WIDE = a workgroup).  One kernel in the hardware queue instead of
+// four, the workgroups start longest chains first across the buckets.
+template <int KC>
+__global__ __launch_bounds__(256, MISO_GRP_PE_BLOCKS) void sampler_grp_multi(const KernelArgs a) {
+  int s = 0;
+  while (s + 1 < a.n_segs && static_cast<int>(blockIdx.x) >= a.seg_block[s + 1]) s++;
+  s = __builtin_amdgcn_readfirstlane(s);
+  KernelArgs b = a;
+  b.slot_event = a.slot_event + a.seg_slot[s];
+  b.n_slots = a.seg_slot[s + 1] - a.seg_slot[s];
+  const unsigned blk = blockIdx.x - static_cast<unsigned>(a.seg_block[s]);
+  switch (a.seg_lanes[s]) {
+  case K2_WIDE: grp_body<64, true, KC, true>(b, blk); break;
+  case 64: grp_body<64, true, KC, false>(b, blk); break;
+  case 32: grp_body<32, true, KC, false>(b, blk); break;
+  default: grp_body<16, true, KC, false>(b, blk); break;
   }
 }
 

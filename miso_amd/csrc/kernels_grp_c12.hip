@@ -12,4 +12,5 @@ MISO_INSTANTIATE_GRP(16)
 MISO_INSTANTIATE_GRP(32)
 template __global__ void sampler_grp<64, true, 12, true>(const KernelArgs);   // one chain per workgroup
 template __global__ void sampler_grp<64, true, 12>(const KernelArgs);         // one chain per wavefront
+template __global__ void sampler_grp_multi<12>(const KernelArgs);             // the class's size buckets in one launch
 }  // namespace miso

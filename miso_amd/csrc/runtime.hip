@@ -36,6 +36,7 @@ __global__ void match_kernel(const MatchEvent *, const int2 *, const int *, cons
                              const int *, const int *, const int *, int, int, int, int, int, uint32_t *, uint16_t *);
 __global__ void summarize_kernel(const DevEvent *, const unsigned char *, int, int, int, int, const uint64_t *, double *, int);
 template <int G, bool PE, int KC, bool WIDE = false> __global__ void sampler_grp(const KernelArgs a);
+template <int KC> __global__ void sampler_grp_multi(const KernelArgs a);
 template <int KC> __global__ void sampler_flat(const KernelArgs a);
 __global__ void selftest_detmath_kernel(const double *, int, double *, double *, double *, double *);
 __global__ void selftest_philox_kernel(const uint32_t *, int, uint32_t *);
@@ -535,20 +536,9 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     return G >= 2 && G <= 32 && !(G & (G - 1)) &&
            fp_bytes + 4 * static_cast<size_t>(64 / G) * grp_slice_bytes(run.kmax, sh.qs, sh.ts) <= LDS_MAX;
   };
-  auto launch_grp = [&](KernelArgs ka, GenRun &run, const GrpShape &sh, int G, hipStream_t st) {
-    const long chains = static_cast<long>(run.count) * p.noChains;
-    ka.slot_event = d_slots + n_k2 + run.first; ka.n_slots = run.count;
-    ka.kstride = run.kmax; ka.cstride = sh.qs; ka.tstride = sh.ts;
-    const bool wave_kernel = G == 64 && !run.wide && !(run.wave64 && fp_rows(run));   // sampler_wave, not sampler_grp<64, ..>
-    ka.pe_dense = wave_kernel ? 0 : fp_rows(run);
-    ka.pe_force_exact = std::getenv("MISO_PE_FORCE_EXACT") != nullptr;
-    const size_t fp_bytes = wave_kernel ? fp_plain : fp_bytes_of(run);
-    if (run.wide) {   // one chain per workgroup: four slices (one per wavefront) + the reduction scratch behind them
-      ka.pe_dense = fp_rows(run);
-      if (!ka.pe_dense) MISO_FAIL(MISO_EINTERNAL, "workgroup-wide paired-end chains need the dense records");
-      const size_t lds0 = align_up(fp_bytes + 4 * static_cast<size_t>(grp_slice_bytes(run.kmax, 0, sh.ts)), 16);
-      ka.red_off = static_cast<int32_t>(lds0);
-      const size_t lds = lds0 + 96;
+  // Workgroup-wide chains of a run: which chain every workgroup works on (coop.hpp), built once per batch; returns the
+  // number of workgroups.
+  auto wide_setup = [&](GenRun &run, long chains, hipStream_t st) -> unsigned {
       // Workgroups per chain: what upload() derived from the gene's share of the batch's work (coop_n), at most
       // COOP_MAX_N, all cooperative workgroups of the batch together at most COOP_MAX_WGS (coop.hpp: they must all be
       // resident at once).  MISO_NO_COOP=1: one workgroup per chain; MISO_COOP_DRAWS=n: one per n drawing pairs (tests).
@@ -581,8 +571,24 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
         HIP_OK(hipMalloc(reinterpret_cast<void **>(&run.d_coop_mem), std::max(1, run.coop_chains) * COOP_WORDS * sizeof(uint32_t)));
       }
       HIP_OK(hipMemsetAsync(run.d_coop_mem, 0, std::max(1, run.coop_chains) * COOP_WORDS * sizeof(uint32_t), st));
+      return static_cast<unsigned>(run.coop_tab.size() / 4);
+  };
+  auto launch_grp = [&](KernelArgs ka, GenRun &run, const GrpShape &sh, int G, hipStream_t st) {
+    const long chains = static_cast<long>(run.count) * p.noChains;
+    ka.slot_event = d_slots + n_k2 + run.first; ka.n_slots = run.count;
+    ka.kstride = run.kmax; ka.cstride = sh.qs; ka.tstride = sh.ts;
+    const bool wave_kernel = G == 64 && !run.wide && !(run.wave64 && fp_rows(run));   // sampler_wave, not sampler_grp<64, ..>
+    ka.pe_dense = wave_kernel ? 0 : fp_rows(run);
+    ka.pe_force_exact = std::getenv("MISO_PE_FORCE_EXACT") != nullptr;
+    const size_t fp_bytes = wave_kernel ? fp_plain : fp_bytes_of(run);
+    if (run.wide) {   // one chain per workgroup: four slices (one per wavefront) + the reduction scratch behind them
+      ka.pe_dense = fp_rows(run);
+      if (!ka.pe_dense) MISO_FAIL(MISO_EINTERNAL, "workgroup-wide paired-end chains need the dense records");
+      const size_t lds0 = align_up(fp_bytes + 4 * static_cast<size_t>(grp_slice_bytes(run.kmax, 0, sh.ts)), 16);
+      ka.red_off = static_cast<int32_t>(lds0);
+      const size_t lds = lds0 + 96;
+      const unsigned grid = wide_setup(run, chains, st);
       ka.coop_tab = run.d_coop_tab; ka.coop_mem = run.d_coop_mem;
-      const unsigned grid = static_cast<unsigned>(run.coop_tab.size() / 4);
 #define MISO_GRP_WIDE(KC)                                                                                  \
   {                                                                                                        \
     HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sampler_grp<64, true, KC, true>),           \
@@ -1311,7 +1317,8 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       trips = 0; waves = 0;
       for (long sl = 0; sl < chains; sl++) { trips += 4 * ((((evs[sl / C]->n_draw + 3) / 4) + 255) / 256); waves += 4; }
     }
-    const std::string name = run.wide ? "sampler_grp<64, true, " + std::to_string(run.kc) + ", true>" :
+    const std::string name = (ri < run_in_multi.size() && run_in_multi[ri]) ? "sampler_grp_multi<" + std::to_string(run.kc) + ">" :
+                             run.wide ? "sampler_grp<64, true, " + std::to_string(run.kc) + ", true>" :
                              flat ? flat_name(run) : ((G == 64 && !w64) ? std::string("sampler_wave<") : "sampler_grp<" + std::to_string(G) + ", ") +
                              (p.paired ? "true" : "false") + ((G == 64 && !w64) ? std::string(">") : ", " + std::to_string(run.kc) + ">");
     add_stat(name, static_cast<double>(waves), trips, static_cast<double>(chains), words);
@@ -1405,7 +1412,82 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     hipLaunchKernelGGL(sampler_lane_k, dim3(static_cast<unsigned>((chains + 63) / 64)), dim3(64), lds, stream_for_next(), ka);
     HIP_OK(hipGetLastError());
   }
-  for (size_t ri = 0; ri < gen_runs.size(); ri++) if (gen_runs[ri].wide && !lane_gen) launch_gen_run(ri);
+  // Paired-end: the size buckets of one isoform-count class in ONE launch (sampler_grp_multi<KC>, kernels_grp.inl):
+  // segments = the class's runs in list order -- workgroup-wide chains (those on several workgroups in front), a
+  // wavefront per chain, 32 lanes, 16 lanes.  MISO_NO_PE_MULTI=1: every run its own launch (A/B, tests).
+  std::vector<char> in_multi(gen_runs.size(), 0);
+  // When: the batch's launches outnumber the hardware queues (a whole-gene mix with real read counts: ~20 launches, 243 ->
+  // 180 ms per 1500 iterations; a single class's three or four buckets run 3 % faster side by side: 149 vs 155 ms at K = 5;
+  // profiles/r03_pe_buckets.txt).  MISO_PE_MULTI=1 forces (tests).
+  const bool multi_on = p.paired && !lane_gen && std::getenv("MISO_NO_PE_MULTI") == nullptr && std::getenv("MISO_GENERAL_LANES") == nullptr &&
+                        (std::getenv("MISO_PE_MULTI") != nullptr || gen_runs.size() + (n_k2 > 0 ? 1 : 0) > 8);
+  for (size_t r0 = 0; multi_on && r0 < gen_runs.size();) {
+    size_t r1 = r0 + 1;
+    while (r1 < gen_runs.size() && gen_runs[r1].kc == gen_runs[r0].kc) r1++;
+    bool ok = r1 - r0 >= 2 && r1 - r0 <= static_cast<size_t>(K2_MAX_SEGS);
+    GenRun m;
+    m.first = gen_runs[r0].first; m.count = 0; m.kc = gen_runs[r0].kc;
+    for (size_t ri = r0; ri < r1 && ok; ri++) {
+      const GenRun &run = gen_runs[ri];
+      const int G = grp_G[ri];
+      ok = flat_nc[ri] == 0 && fp_rows(run) && run.first == m.first + m.count &&
+           (run.wide || G == 16 || G == 32 || (G == 64 && run.wave64));
+      m.count += run.count; m.kmax = std::max(m.kmax, run.kmax); m.kmin = std::min(m.kmin, run.kmin);
+      m.maxq = std::max(m.maxq, run.maxq);
+    }
+    const GrpShape msh = ok ? grp_shape(m) : GrpShape{0, 0};
+    const size_t fp_bytes = fp_bytes_of(m);
+    const size_t slice = ok ? grp_slice_bytes(m.kmax, 0, msh.ts) : 0;
+    for (size_t ri = r0; ri < r1 && ok; ri++)
+      if (!gen_runs[ri].wide) ok = fp_bytes + 4 * static_cast<size_t>(64 / grp_G[ri]) * slice <= LDS_MAX;
+    if (ok) {
+      KernelArgs ka = a;
+      hipStream_t st = stream_for_next();
+      ka.slot_event = d_slots + n_k2 + m.first; ka.n_slots = m.count;
+      ka.kstride = m.kmax; ka.cstride = 0; ka.tstride = msh.ts;
+      ka.pe_dense = 1; ka.pe_force_exact = std::getenv("MISO_PE_FORCE_EXACT") != nullptr;
+      size_t lds = 0; int blocks = 0, segs = 0;
+      for (size_t ri = r0; ri < r1; ri++, segs++) {
+        GenRun &run = gen_runs[ri];
+        const long chains = static_cast<long>(run.count) * p.noChains;
+        ka.seg_slot[segs] = run.first - m.first; ka.seg_block[segs] = blocks;
+        if (run.wide) {
+          const size_t lds0 = align_up(fp_bytes + 4 * slice, 16);
+          ka.red_off = static_cast<int32_t>(lds0);
+          lds = std::max(lds, lds0 + 96);
+          blocks += static_cast<int>(wide_setup(run, chains, st));
+          ka.coop_tab = run.d_coop_tab; ka.coop_mem = run.d_coop_mem;
+          ka.seg_lanes[segs] = K2_WIDE;
+        } else {
+          const int G = grp_G[ri], cpw = 64 / G;
+          lds = std::max(lds, fp_bytes + 4 * static_cast<size_t>(cpw) * slice);
+          blocks += static_cast<int>(((chains + cpw - 1) / cpw + 3) / 4);
+          ka.seg_lanes[segs] = G;
+        }
+        in_multi[ri] = 1;
+      }
+      ka.seg_slot[segs] = m.count; ka.seg_block[segs] = blocks; ka.n_segs = segs;
+      last_kernels += std::string(last_kernels.empty() ? "" : ",") + "sampler_grp_multi<" + std::to_string(m.kc) + ">";
+#define MISO_GRP_MULTI(KC)                                                                                   \
+  {                                                                                                          \
+    HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sampler_grp_multi<KC>),                       \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));          \
+    hipLaunchKernelGGL((sampler_grp_multi<KC>), dim3(static_cast<unsigned>(blocks)), dim3(256), lds, st, ka); \
+  }
+      switch (m.kc) {
+      case 4: MISO_GRP_MULTI(4) break;
+      case 8: MISO_GRP_MULTI(8) break;
+      case 12: MISO_GRP_MULTI(12) break;
+      case 16: MISO_GRP_MULTI(16) break;
+      default: MISO_GRP_MULTI(32) break;
+      }
+#undef MISO_GRP_MULTI
+      HIP_OK(hipGetLastError());
+    }
+    r0 = r1;
+  }
+  run_in_multi = in_multi;
+  for (size_t ri = 0; ri < gen_runs.size(); ri++) if (gen_runs[ri].wide && !lane_gen && !in_multi[ri]) launch_gen_run(ri);
   if (n_k2w > 0 && k2w_multi) {
     lanes_per_chain = k2w_plan.seg_lanes[k2w_plan.n_segs - 1];
     last_kernels = "sampler_k2_multi<2, " + std::to_string(k2w_plan.wpb) + ">";
@@ -1446,7 +1528,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       launch_k2(a, k2_G, stream_for_next());
     }
   }
-  for (size_t ri = 0; ri < gen_runs.size(); ri++) if (!gen_runs[ri].wide && !lane_gen) launch_gen_run(ri);
+  for (size_t ri = 0; ri < gen_runs.size(); ri++) if (!gen_runs[ri].wide && !lane_gen && !in_multi[ri]) launch_gen_run(ri);
   for (size_t i = 1; i < kernel_no && i <= aux_streams.size() && std::getenv("MISO_SERIAL_KERNELS") == nullptr; i++) {
     HIP_OK(hipEventRecord(aux_done[i - 1], aux_streams[i - 1]));
     HIP_OK(hipStreamWaitEvent(stream, aux_done[i - 1], 0));

@@ -194,7 +194,10 @@ def test_mixed_pair_counts_three_or_more_isoforms_paired_end_bit_exact(orc, K, c
     # (MISO_COOP_DRAWS: drawing pairs per workgroup of a chain on SEVERAL workgroups, coop.hpp: 1024 puts the two largest
     # genes on ~10 and ~4 workgroups; MISO_NO_COOP: one workgroup per chain)
     for v in (dict(), dict(MISO_NO_PE_BUCKETS="1"), dict(MISO_PE_FORCE_EXACT="1"), dict(MISO_COOP_DRAWS="1024"),
-              dict(MISO_NO_COOP="1"), dict(MISO_PE_T_WAVE="1", MISO_PE_T_WIDE="1e9"), dict(MISO_PE_T_WAVE="64", MISO_PE_T_WIDE="1500")):
+              dict(MISO_NO_COOP="1"), dict(MISO_PE_T_WAVE="1", MISO_PE_T_WIDE="1e9"),
+              dict(MISO_PE_T_WAVE="64", MISO_PE_T_WIDE="1500"), dict(MISO_PE_MULTI="1"),
+              dict(MISO_PE_MULTI="1", MISO_PE_T_WAVE="1", MISO_PE_T_WIDE="1e9"), dict(MISO_PE_MULTI="1", MISO_PE_T_WAVE="64", MISO_PE_T_WIDE="1500"),
+              dict(MISO_PE_MULTI="1", MISO_PE_T_WAVE="64", MISO_PE_T_WIDE="1500", MISO_COOP_DRAWS="1024")):
         with _env(**v):
             b = miso_amd.Batch(36, paired=True, mean=250.0, var=900.0, device_match=True, **kw)
             for exons, isoforms, g, pos, cig in evs:
@@ -210,6 +213,8 @@ def test_mixed_pair_counts_three_or_more_isoforms_paired_end_bit_exact(orc, K, c
                 assert (gpu.assignment == r.assignment).all(), where
                 assert gpu.rundata.noAccepted == r.accepted, where
     assert ", true>" in names[0] and names[0].count("sampler_grp") >= 3, names     # workgroup-wide + 32-lane + normal launches
+    # MISO_PE_MULTI=1 (what a batch of many classes does by itself): the class's size buckets in ONE launch (sampler_grp_multi)
+    assert all(n == "sampler_grp_multi<%d>" % {3: 4, 5: 8, 10: 12}[K] for n in names[7:]), names
     assert names[1].count("sampler_grp") == 1, names
     kc = {3: 4, 5: 8, 10: 12}[K]
     assert "sampler_grp<64, true, %d>" % kc in names[5] and ", true>" not in names[5], names   # a wavefront per large gene, none workgroup-wide
