@@ -933,7 +933,16 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       // profiles/r03_pe_lanes_sweep.txt)
       int n_classes = 0;
       for (size_t rj = 0; rj < gen_runs.size(); rj++) if (rj == 0 || gen_runs[rj].kc != gen_runs[rj - 1].kc) n_classes++;
-      const bool pe32 = p.paired && (n_classes + (n_k2 > 0 ? 1 : 0) > 1 || (run.kc >= 12 && 2 * ((chains + 3) / 4) < 3 * static_cast<long>(slots_for(chains))) ||
+      // (round 3, 8 hardware queues, 16 384 genes of 3-20 isoforms per 1500 iterations: 16 lanes up to 16 isoforms against 32
+      // everywhere -- 400 pairs per gene 120 vs 150 ms, 1000 pairs 194 vs 206 ms, hg19-like counts 176 vs 175 ms, 2500 pairs
+      // 436 vs 367 ms: small genes share the scalar step four to a wavefront, large ones want the lanes; the switch sits at a
+      // mean of 400 drawing quads per gene of the class; MISO_PE_MIX_LANES=16|32 forces)
+      double mean_q = 0;
+      for (int i = 0; i < run.count; i++) mean_q += (events[h_slots[n_k2 + run.first + i]].n_draw + 3) / 4;
+      mean_q /= std::max(1, run.count);
+      const char *mixl = std::getenv("MISO_PE_MIX_LANES");
+      const bool mix16 = run.kc <= 16 && !run.force_G && (mixl ? std::atoi(mixl) == 16 : mean_q < 400.0);
+      const bool pe32 = p.paired && ((n_classes + (n_k2 > 0 ? 1 : 0) > 1 && !mix16) || (run.kc >= 12 && 2 * ((chains + 3) / 4) < 3 * static_cast<long>(slots_for(chains))) ||
                                      (chains + 3) / 4 < slots_for(chains));
       for (int g : {2, 4, 8, 16, 32}) {
         if (p.paired && g > 16 && found && !pe32) break;
