@@ -1,13 +1,28 @@
-import sys, os
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+"""GPU: more configurations of tests/test_gpu_fuzz.py -- 40 seeds of the random mixed batches, single- and paired-end
+(paired-end also with the buckets of every class in one launch, MISO_PE_MULTI=1), and 20 seeds of the collapsed step at
+both levels."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import test_gpu_fuzz as t
 from _libs import OrcLib
 orc = OrcLib()
 bad = 0
 for seed in range(5, 45):
-    for paired in (False, True):
+    for paired, multi in ((False, False), (True, False), (True, True)):
+        if multi:
+            os.environ["MISO_PE_MULTI"] = "1"
+        else:
+            os.environ.pop("MISO_PE_MULTI", None)
         try:
             t.test_random_mixed_batches_bit_exact(orc, paired, seed)
         except AssertionError as e:
-            bad += 1; print("FAIL seed", seed, "paired", paired, e)
+            bad += 1; print("FAIL seed", seed, "paired", paired, "multi", multi, e)
+os.environ.pop("MISO_PE_MULTI", None)
+for seed in range(20, 40):
+    for level in (1, 2):
+        try:
+            t.test_random_mixed_batches_collapsed_bit_exact(orc, level, seed)
+        except AssertionError as e:
+            bad += 1; print("FAIL collapsed level", level, "seed", seed, e)
 print("done, failures:", bad)
