@@ -104,6 +104,10 @@ struct miso_batch {
   int lanes_per_chain = 0;        // G of the last sampler_k2 launch (0 = none)
   std::string last_kernels;       // names of the kernels of the last launch, comma separated
   std::vector<miso_kernel_stat_t> kernel_stats;   // miso_batch_launch_stats, filled on demand by stats_builder
+  // sampler_k2_multi<0, 8>, one round: the launch's wavefronts paired by estimated duration across the runs (runtime.hip)
+  std::vector<int32_t> k2_pair_tab;
+  int32_t *d_k2_pair_tab = nullptr;
+  int k2_pair_wide_blocks = 0, k2_pair_grid = 0;
   std::vector<char> run_in_multi;                 // gen_runs launched as a segment of sampler_grp_multi (last launch)
   std::function<void()> stats_builder;            // set by launch(): the walk over events and wavefronts is not part of a launch
   int wave_slots = 2048;          // resident sampler_k2 wavefronts on the device

@@ -303,8 +303,10 @@ __device__ __forceinline__ int32_t k2_lds_i32(uint32_t addr) { return *reinterpr
 // on isoform 0 as one exact binomial (include/miso_binomial.h) instead of sweeping the reads; the run's last step is
 // the sweep, so the returned assignment is a per-read draw.  The chain's G lanes share the work: the Metropolis-Hastings
 // step as always, the binomial's rejection trials G at a time (binomial_coop).
+// wave_override >= 0 (sampler_k2_multi with a.wave_tab): which wavefront of the run this one is, instead of the place
+// block_x / pair_waves give it.
 template <int G, int MODE, int WPB, bool WIDE = false, bool COLLAPSED = false>
-__device__ __forceinline__ void k2_body(const KernelArgs &a, unsigned block_x, unsigned grid_x) {
+__device__ __forceinline__ void k2_body(const KernelArgs &a, unsigned block_x, unsigned grid_x, long wave_override = -1) {
   static_assert(!COLLAPSED || (MODE == 0 && !WIDE && (G & (G - 1)) == 0), "collapsed: single-end, 1, 2, 4 ... lanes per chain");
   static_assert(!WIDE || G == 64, "a workgroup-wide chain uses whole wavefronts");
   // WIDE: which chain this workgroup works on, alone or as one of several (coop.hpp; a.coop_tab is indexed by the
@@ -356,6 +358,7 @@ __device__ __forceinline__ void k2_body(const KernelArgs &a, unsigned block_x, u
     const long p = 4 * static_cast<long>(block_x) + (w & 3);             // pair index: heaviest first
     wave_id = (w < 4) ? p : static_cast<long>(grid_x) * 8 - 1 - p;       // ... with the p-th lightest
   }
+  if (!WIDE && wave_override >= 0) wave_id = wave_override;
   if (wave_id * CPW >= n_chains) return;  // whole wavefront idle
   long slot = wave_id * CPW + grp;
   const bool live = lane_used && slot < n_chains;  // dead lanes shadow a chain and store nothing

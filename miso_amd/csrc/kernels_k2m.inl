@@ -20,6 +20,31 @@ namespace miso {
 
 template <int MODE, int WPB>
 __global__ __launch_bounds__(64 * WPB, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void sampler_k2_multi(const KernelArgs a) {
+  // One-round single-end launches (a.wave_tab): behind the workgroup-wide chains' a.mix_blocks workgroups every WAVEFRONT
+  // looks up which run's wavefront it is -- the host pairs the launch's wavefronts by estimated duration ACROSS the runs,
+  // heaviest with lightest on one SIMD (wavefronts w and w + 4), so that every SIMD carries the same work (runtime.hip
+  // k2_pair_table).  Single-end bodies have no workgroup-level step: the eight wavefronts of a workgroup may belong to
+  // different runs.
+  if constexpr (MODE == 0 && WPB == 8) {
+    if (a.wave_tab != nullptr && static_cast<int>(blockIdx.x) >= a.mix_blocks) {
+      const int e = __builtin_amdgcn_readfirstlane(a.wave_tab[(static_cast<size_t>(blockIdx.x) - a.mix_blocks) * 8 + (threadIdx.x >> 6)]);
+      if (e < 0) return;
+      const int sg = e >> 20;
+      const long wid = e & 0xFFFFF;
+      KernelArgs part = a;
+      part.slot_event = a.slot_event + a.seg_slot[sg];
+      part.n_slots = a.seg_slot[sg + 1] - a.seg_slot[sg];
+      part.pair_waves = 0;
+      switch (a.seg_lanes[sg]) {
+#define MISO_K2M_WAVE(GG) case GG: k2_body<GG, 0, 8>(part, 0u, 0u, wid); break;
+      MISO_K2M_WAVE(1) MISO_K2M_WAVE(2) MISO_K2M_WAVE(3) MISO_K2M_WAVE(4) MISO_K2M_WAVE(5) MISO_K2M_WAVE(6)
+      MISO_K2M_WAVE(8) MISO_K2M_WAVE(10) MISO_K2M_WAVE(12) MISO_K2M_WAVE(16) MISO_K2M_WAVE(32) MISO_K2M_WAVE(64)
+#undef MISO_K2M_WAVE
+      default: break;
+      }
+      return;
+    }
+  }
   int s = 0;
   while (s + 1 < a.n_segs && static_cast<int>(blockIdx.x) >= a.seg_block[s + 1]) s++;
   KernelArgs part = a;

@@ -93,6 +93,7 @@ void miso_batch::release() {
   if (d_fp) (void) hipFree(d_fp);
   if (d_slots) (void) hipFree(d_slots);
   if (d_logfact) (void) hipFree(d_logfact);
+  if (d_k2_pair_tab) (void) hipFree(d_k2_pair_tab);
   d_slots = nullptr;
   if (ev0) (void) hipEventDestroy(ev0);
   if (ev1) (void) hipEventDestroy(ev1);
@@ -1081,6 +1082,48 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
         if (wpb != 8 && wpb != 4 && wpb != 1) MISO_FAIL(MISO_EINVAL, "MISO_K2_WPB must be 8, 4 or 1");
         if (wpb != 8) k2_plan = plan_lanes(nd.data(), count, p.noChains, widths, 12, wpb >= 4 ? wpb : 0, wpb, resident * 8 / wpb, 64, cost, forced, coop_max);
         k2_plan_key = key;
+        // One round, 8 wavefronts per workgroup: wavefronts w and w + 4 of a workgroup share a SIMD.  Pair the launch's
+        // wavefronts (all runs but the workgroup-wide chains') by estimated duration, the i-th heaviest with the i-th
+        // lightest ACROSS the runs: within a run the p-th heaviest + p-th lightest (a.pair_waves) give every SIMD of the
+        // run the same work, but the runs' sums differ (a run's first wavefront sits at the planner's bound, its last
+        // wherever the next width takes over) and the SIMDs of the lighter runs idle at the end (wave-slot occupancy
+        // 0.78, profiles/r03_wave_time.txt).  Measured, 40 000 events: hg19-like read counts (13 runs) 73.9 -> 71.4 ms;
+        // 1000 reads each (4 runs) 99.7 -> 100.8 ms, 3000 reads 244.6 -> 250.0 ms (few runs: their sums are close already,
+        // and the kernel with a body per run AND per wavefront is larger): used from seven runs on.
+        // MISO_K2_GLOBAL_PAIR=0 / 1: never / always (A/B, tests).
+        k2_pair_tab.clear(); k2_pair_grid = 0; k2_pair_wide_blocks = 0;
+        const char *gp = std::getenv("MISO_K2_GLOBAL_PAIR");
+        if (k2_plan.n_segs > 0 && k2_plan.rounds == 1 && wpb == 8 && (gp ? std::atoi(gp) != 0 : k2_plan.n_segs >= 7)) {
+          struct W { double cost; int32_t code; };
+          std::vector<W> ws;
+          bool ok = true, seen_narrow = false;
+          for (int sg = 0; sg < k2_plan.n_segs && ok; sg++) {
+            const int G = k2_plan.seg_lanes[sg];
+            if (G == K2_WIDE) { ok = !seen_narrow; k2_pair_wide_blocks = k2_plan.seg_block[sg + 1]; continue; }   // (wide runs come first)
+            seen_narrow = true;
+            const int cpw = 64 / G;
+            const long chains = static_cast<long>(k2_plan.seg_slot[sg + 1] - k2_plan.seg_slot[sg]) * p.noChains;
+            const long waves = (chains + cpw - 1) / cpw;
+            ok = waves < (1L << 20) && sg < 2048;
+            for (long w = 0; w < waves && ok; w++) {
+              const int first = nd[k2_plan.seg_slot[sg] + static_cast<int>((w * cpw) / p.noChains)];   // the wavefront's longest chain
+              ws.push_back(W{cost.wave_step(G, first), static_cast<int32_t>(sg << 20 | static_cast<int32_t>(w))});
+            }
+          }
+          if (ok && !ws.empty()) {
+            std::stable_sort(ws.begin(), ws.end(), [](const W &x, const W &y) { return x.cost > y.cost; });
+            const size_t N = ws.size(), Q = (N + 1) / 2, blocks = (Q + 3) / 4;
+            k2_pair_tab.assign(blocks * 8, -1);
+            for (size_t q = 0; q < Q; q++) {
+              k2_pair_tab[(q / 4) * 8 + q % 4] = ws[q].code;
+              if (N - 1 - q > q) k2_pair_tab[(q / 4) * 8 + q % 4 + 4] = ws[N - 1 - q].code;
+            }
+            k2_pair_grid = k2_pair_wide_blocks + static_cast<int>(blocks);
+            if (d_k2_pair_tab) HIP_OK(hipFree(d_k2_pair_tab));
+            HIP_OK(hipMalloc(reinterpret_cast<void **>(&d_k2_pair_tab), k2_pair_tab.size() * sizeof(int32_t)));
+            HIP_OK(hipMemcpy(d_k2_pair_tab, k2_pair_tab.data(), k2_pair_tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+          }
+        }
       }
       k2_multi = k2_plan.n_segs > 0;
     }
@@ -1184,7 +1227,11 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     ka.n_segs = k2_plan.n_segs;
     for (int i = 0; i <= k2_plan.n_segs; i++) { ka.seg_block[i] = k2_plan.seg_block[i]; ka.seg_slot[i] = k2_plan.seg_slot[i]; }
     for (int i = 0; i < k2_plan.n_segs; i++) ka.seg_lanes[i] = k2_plan.seg_lanes[i];
-    const dim3 grid(static_cast<unsigned>(k2_plan.seg_block[k2_plan.n_segs]));
+    dim3 grid(static_cast<unsigned>(k2_plan.seg_block[k2_plan.n_segs]));
+    if (!p.paired && k2_plan.wpb == 8 && k2_pair_grid > 0 && !k2_pair_tab.empty()) {   // wavefronts paired across the runs
+      ka.wave_tab = d_k2_pair_tab; ka.mix_blocks = k2_pair_wide_blocks; ka.pair_waves = 0;
+      grid = dim3(static_cast<unsigned>(k2_pair_grid));
+    }
     if (p.paired) {   // MODE 1
       int cpw = 1;
       for (int i = 0; i < k2_plan.n_segs; i++) if (k2_plan.seg_lanes[i] != K2_WIDE) cpw = std::max(cpw, 64 / k2_plan.seg_lanes[i]);

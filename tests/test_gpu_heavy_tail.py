@@ -75,6 +75,9 @@ def test_mixed_read_counts_one_launch_bit_exact(orc, paired, chains):
                 dict(MISO_K2_MULTI="0")]
     # chains on several workgroups (coop.hpp): a small bound and one quad per lane put the largest events on 2 ... 8
     variants += [dict(MISO_K2_TARGET="1400", MISO_COOP_MIN_QUADS="1"), dict(MISO_K2_TARGET="1400", MISO_NO_COOP="1")]
+    if not paired:   # one round: the wavefronts paired by estimated duration across the runs (a table entry per wavefront) or within
+        variants += [dict(MISO_K2_GLOBAL_PAIR="1"), dict(MISO_K2_GLOBAL_PAIR="0"), dict(MISO_K2_GLOBAL_PAIR="1", MISO_K2_TARGET="2600"),
+                     dict(MISO_K2_GLOBAL_PAIR="1", MISO_K2_TARGET="1400", MISO_COOP_MIN_QUADS="1")]
     if paired:   # every event through MODE 1 (the kernel for events with non-finite scores) and its many-widths launch
         variants += [dict(MISO_NO_PE_DELTA="1"), dict(MISO_NO_PE_DELTA="1", MISO_K2_TARGET="1400"), dict(MISO_K2W_WPB="8"),
                      dict(MISO_NO_PE_DELTA="1", MISO_K2_TARGET="1400", MISO_COOP_MIN_QUADS="1"),
