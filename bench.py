@@ -39,6 +39,8 @@ import subprocess
 import sys
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before anything initialises HIP (torch in the multi-GPU runs): DESIGN.md 4.3 (iv)
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
