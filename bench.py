@@ -123,7 +123,7 @@ MATRIX = [  # (id, label, shape overrides, events, reference runs of the row: (e
     # event, a handful of 10^4 ... 10^5-read events per 40 000): "reads_iter_per_s" is what to compare with the uniform rows
     ("se_k2_hg19", "SE K=2, hg19-like read counts (20..1e5 per event), 1 chain, 7500 iters", dict(reads="hg19"), 40000, (64, 8)),
     ("se_k2_hg19_defaults", "SE K=2, hg19-like read counts, MISO defaults (6 chains, 5000 iters, 500 burn-in, lag 10)",
-     dict(reads="hg19", chains=6, iters=5000, burn=500, lag=10), 40000, None),
+     dict(reads="hg19", chains=6, iters=5000, burn=500, lag=10), 40000, (64, 8)),
     ("pe_k2_hg19", "PE K=2, hg19-like read counts, 1 chain, 7500 iters", dict(paired=True, reads="hg19"), 40000, (64, 8)),
     ("se_k5_hg19", "SE K=5, hg19-like read counts, 1 chain, 7500 iters", dict(K=5, reads="hg19"), 40000, (64, 8)),
     ("pe_k5_hg19", "PE K=5, hg19-like read counts, 1 chain, 7500 iters", dict(K=5, paired=True, reads="hg19"), 40000, (64, 8)),
@@ -426,7 +426,7 @@ def stream_rows(batch, n_events, sh, first, seed, device):
 # COLLAPSED Gibbs step -- the count of the exchangeable reads drawn as one exact binomial per iteration instead of one
 # uniform per read (same Markov chain on (psi, counts), different draws).  Same workload, same reference runs, same
 # |delta psi| test as the row it shadows; "main" = the headline workload.  The headline `value` stays the default mode.
-COLLAPSED_ROWS = ("main", "se_k2_hg19", "se_k2_defaults")
+COLLAPSED_ROWS = ("main", "se_k2_hg19", "se_k2_hg19_defaults", "se_k2_defaults")
 
 
 def matrix_row(a, local_rank, wid, label, sh, n, st, collapsed=False):

@@ -7,7 +7,7 @@ set -u
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 OUT=$PWD/gpurun_out
 mkdir -p $OUT
-ALL="se_k2: se_k2_defaults:--chains_6_--iters_5000_--burn_500_--lag_10 se_k5:--K_5 se_k10:--K_10 pe_k2:--paired pe_k5:--paired_--K_5 pe_k10:--paired_--K_10_--events_20000 pe_mix:--paired_--K-range_3_20_--events_16384 se_k2_hg19:--reads-dist_hg19 se_k2_hg19_defaults:--reads-dist_hg19_--chains_6_--iters_5000_--burn_500_--lag_10 pe_k2_hg19:--reads-dist_hg19_--paired se_k5_hg19:--reads-dist_hg19_--K_5 pe_k5_hg19:--reads-dist_hg19_--paired_--K_5 pe_mix_hg19:--reads-dist_hg19_--paired_--K-range_3_20_--events_16384 se_k2_collapsed:--collapsed_1 se_k2_defaults_collapsed:--collapsed_1_--chains_6_--iters_5000_--burn_500_--lag_10 se_k2_hg19_collapsed:--collapsed_1_--reads-dist_hg19"
+ALL="se_k2: se_k2_defaults:--chains_6_--iters_5000_--burn_500_--lag_10 se_k5:--K_5 se_k10:--K_10 pe_k2:--paired pe_k5:--paired_--K_5 pe_k10:--paired_--K_10_--events_20000 pe_mix:--paired_--K-range_3_20_--events_16384 se_k2_hg19:--reads-dist_hg19 se_k2_hg19_defaults:--reads-dist_hg19_--chains_6_--iters_5000_--burn_500_--lag_10 pe_k2_hg19:--reads-dist_hg19_--paired se_k5_hg19:--reads-dist_hg19_--K_5 pe_k5_hg19:--reads-dist_hg19_--paired_--K_5 pe_mix_hg19:--reads-dist_hg19_--paired_--K-range_3_20_--events_16384 se_k2_collapsed:--collapsed_1 se_k2_defaults_collapsed:--collapsed_1_--chains_6_--iters_5000_--burn_500_--lag_10 se_k2_hg19_collapsed:--collapsed_1_--reads-dist_hg19 se_k2_hg19_defaults_collapsed:--collapsed_1_--reads-dist_hg19_--chains_6_--iters_5000_--burn_500_--lag_10"
 for tag_args in $ALL; do
   tag=${tag_args%%:*}; args=${tag_args#*:}; args=${args//_/ }
   if [ $# -gt 0 ] && [[ ! " $* " =~ " $tag " ]]; then continue; fi
