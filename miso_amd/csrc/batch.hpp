@@ -64,6 +64,7 @@ struct miso_batch {
     int first = 0, count = 0;     // slice of d_slots (after the n_k2 two-isoform events)
     int kc = 4;                   // 4, 8, 12, 16 or 32
     int kmax = 2, kmin = 64, maxq = 1;   // most / fewest isoforms, most draw quads
+    double sum_q = 0;             // draw quads of all its events (their mean decides the lanes per chain in a batch of several classes)
     int maxcls = 0;               // most drawing-read classes (single-end)
     bool nocls = false;           // some single-end event has no class table (> MAX_DRAW_CLASSES classes)
     bool dense = true;            // paired-end: every event has dense quad records (pe_dense)

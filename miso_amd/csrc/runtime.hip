@@ -417,6 +417,7 @@ void miso_batch::upload(int dev) {
     r.kmax = std::max(r.kmax, e.K);
     r.kmin = std::min(r.kmin, e.K);
     r.maxq = std::max(r.maxq, (e.n_draw + 3) / 4);
+    r.sum_q += (e.n_draw + 3) / 4;
     r.maxcls = std::max(r.maxcls, static_cast<int>(e.dcls_mask.size()));
     if (!e.paired && e.n_draw > 0 && e.dcls_mask.empty()) r.nocls = true;
     if (!e.paired || e.draw_dense.empty() || e.K == 2) r.dense = false;   // (K = 2: draw_dense holds sampler_k2's records)
@@ -938,9 +939,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       // everywhere -- 400 pairs per gene 120 vs 150 ms, 1000 pairs 194 vs 206 ms, hg19-like counts 176 vs 175 ms, 2500 pairs
       // 436 vs 367 ms: small genes share the scalar step four to a wavefront, large ones want the lanes; the switch sits at a
       // mean of 400 drawing quads per gene of the class; MISO_PE_MIX_LANES=16|32 forces)
-      double mean_q = 0;
-      for (int i = 0; i < run.count; i++) mean_q += (events[h_slots[n_k2 + run.first + i]].n_draw + 3) / 4;
-      mean_q /= std::max(1, run.count);
+      const double mean_q = run.sum_q / std::max(1, run.count);
       const char *mixl = std::getenv("MISO_PE_MIX_LANES");
       const bool mix16 = run.kc <= 16 && !run.force_G && (mixl ? std::atoi(mixl) == 16 : mean_q < 400.0);
       const bool pe32 = p.paired && ((n_classes + (n_k2 > 0 ? 1 : 0) > 1 && !mix16) || (run.kc >= 12 && 2 * ((chains + 3) / 4) < 3 * static_cast<long>(slots_for(chains))) ||
