@@ -10,7 +10,9 @@ events already resident in HBM.  Headline workload (BASELINE.json configs[1]): s
 `--gpus N` (N > 1) starts N ranks itself -- one fresh process per GPU through
 `python -m torch.distributed.run`, before anything in this process touches the GPU (the reference's
 dispatcher starts its own workers too, misopy/miso.py:165-187, 205-214) -- unless it is already
-running under a launcher (WORLD_SIZE set).  Rank 0 prints ONE JSON line.  The global event list
+running under a launcher (WORLD_SIZE set).  Rank 0 prints ONE compact JSON line (< 4 KB: the driver keeps the tail of
+stdout) as the LAST line of stdout and writes the full record -- every note, model detail and per-row roofline -- to
+gpurun_out/bench_full.json (`--full-out`).  The global event list
 (N x --events events) is split into N contiguous shards balanced by cost (sum of
 chains x iterations x reads), every event keeps its global id, there is no collective on the data
 path; ranks only meet in a gloo barrier and a max-over-ranks of the elapsed time.
@@ -22,7 +24,8 @@ The line carries, besides the contract's keys:
                       this run's kernel time, and said so), with the share of the instruction floor,
                       the RNG fraction, the measured HBM fraction and SURVEY 8(d)'s algorithmic bytes
   cpu_baseline        the real reference C core (oracle/_ref) on the host cores, bounded sample
-  delta_psi_vs_reference   |delta psi| with a pass/fail: 4 x MCSE from reference seeds, per event
+  delta_psi           |delta psi| with a pass/fail: the GPU under S streams per event against the real reference under S
+                      streams per event, exact permutation tests (tests/_dpsi.py): pooled t^2, largest |t|, signed shifts
   summary_ms / compare_ms  rows f2 / f3 (configs[4]) on the resident samples, outside the timed region
   matrix              the other shapes of the metric (hg19-like read counts; K = 5, 10; MISO default
                       settings; paired-end K = 2, 5, 10; the whole-gene paired-end mix), each timed in
@@ -135,8 +138,8 @@ MATRIX = [  # (id, label, shape overrides, events, reference runs of the row: (e
     ("pe_k5", "PE K=5, 1 chain, 7500 iters", dict(K=5, paired=True), 40000, (64, 8)),
     ("pe_k10", "PE K=10, 1 chain, 7500 iters", dict(K=10, paired=True), 20000, (64, 8)),
     # BASELINE configs[3]: whole-gene mode, 3-20 isoforms per gene, paired-end; "events" are genes here
-    ("pe_mix", "PE K=3..20 per gene (whole-gene mix), 1 chain, 7500 iters", dict(K=(3, 20), paired=True), 16384, (32, 1)),
-    ("pe_mix_hg19", "PE K=3..20 per gene, hg19-like read counts, 1 chain, 7500 iters", dict(K=(3, 20), paired=True, reads="hg19"), 16384, (32, 1)),
+    ("pe_mix", "PE K=3..20 per gene (whole-gene mix), 1 chain, 7500 iters", dict(K=(3, 20), paired=True), 16384, (48, 8)),
+    ("pe_mix_hg19", "PE K=3..20 per gene, hg19-like read counts, 1 chain, 7500 iters", dict(K=(3, 20), paired=True, reads="hg19"), 16384, (48, 8)),
 ]
 
 
@@ -226,69 +229,71 @@ def cpu_studies(wanted):
     return out, wall
 
 
-def delta_psi(batch, study_rows, sample_rows=None):
-    """BASELINE's "|delta psi| vs ref" with a pass/fail, ALL isoforms, posterior mean and both Chen-Shao bounds.
-    GPU = device-side summaries (summarize_kernel); reference = the real C core on the same events under
-    independent random streams, S seeds per event.  For every (event, isoform, statistic) the GPU's value must lie
-    within 4 x MCSE x sqrt(1 + 1/S) of the mean over the reference's seeds, MCSE = the seed-to-seed standard
-    deviation of that statistic in the reference.  MCSE is itself estimated from S seeds, so the ratio is Student-t
-    with S - 1 degrees of freedom: the check fails when more ratios exceed 4 than that explains (binomial tail
-    < 1e-3) or when any ratio exceeds a hard limit set where the whole table would exceed it with probability 1e-3."""
-    import numpy as np
-    from scipy import stats
-    batch.summarize(0.95)
-    n_local = len(batch)
-    out = {}
-    if sample_rows:   # single runs of the reference (the timing sample): plain differences, isoform 0
-        rows = [r for r in sample_rows if r[0] < n_local]
-        d = np.array([[abs(batch.summary(r[0])[j][0] - r[2 + j][0]) for j in range(3)] for r in rows])
-        out.update({"events": len(rows), "mean_abs_dpsi": round(float(d[:, 0].mean()), 6),
-                    "max_abs_dpsi": round(float(d[:, 0].max()), 6),
-                    "mean_abs_dci_low": round(float(d[:, 1].mean()), 6), "mean_abs_dci_high": round(float(d[:, 2].mean()), 6)})
-    by_event = {}
-    for e, _, m, lo, hi, sd in study_rows:
-        if e < n_local:
-            by_event.setdefault(e, []).append((m, lo, hi, sd))
-    if not by_event:
-        return out
-    S = min(len(v) for v in by_event.values())
-    if S < 2:
-        return out
-    z, absd, worst = [], [], None
-    names = ("mean", "ci_low", "ci_high")
-    for e, runs in sorted(by_event.items()):
-        g = batch.summary(e)
-        for j in range(3):
-            ref = np.array([r[j] for r in runs])            # [S, K]
-            mcse = ref.std(0, ddof=1)
-            d = np.abs(np.asarray(g[j]) - ref.mean(0))
-            zz = d / np.maximum(mcse * math.sqrt(1.0 + 1.0 / len(runs)), 1e-12)
-            # a statistic that does not move between seeds and equals the GPU's (psi pinned at a bound) passes
-            zz = np.where((mcse < 1e-12) & (d < 1e-9), 0.0, zz)
-            z.extend(zz.tolist())
-            if j == 0:
-                absd.extend(d.tolist())
-            k = int(np.argmax(zz))
-            if worst is None or zz[k] > worst["z_in_mcse"]:
-                worst = {"event": e, "isoform": k, "statistic": names[j], "abs_delta": round(float(d[k]), 6),
-                         "mcse": round(float(mcse[k]), 6), "z_in_mcse": round(float(zz[k]), 3),
-                         "posterior_sd": round(float(np.mean([r[3][k] for r in runs])), 6),
-                         "ref_seed_range": round(float(np.ptp(ref[:, k])), 6)}
-    z = np.array(z)
-    p1 = 2 * stats.t.sf(4.0, S - 1)
-    allowed = int(stats.binom.isf(1e-3, len(z), p1))
-    hard = float(stats.t.isf(0.5e-3 / len(z), S - 1))     # n x P(|t| > hard) = 1e-3
-    n_fail = int((z > 4.0).sum())
-    out.update({"tolerance": "4*MCSE*sqrt(1+1/S): every isoform, posterior mean and both 95% bounds",
-                "mcse_from": "%d reference seeds per event, %d events, %d (event, isoform, statistic) checks" % (S, len(by_event), len(z)),
-                "mean_abs_dpsi_all_isoforms": round(float(np.mean(absd)), 6), "max_abs_dpsi_all_isoforms": round(float(np.max(absd)), 6),
-                "n_fail": n_fail, "n_fail_allowed": allowed, "expected_exceedances_t%d" % (S - 1): round(len(z) * p1, 2),
-                "max_z_in_mcse": round(float(z.max()), 3), "hard_limit_z": round(hard, 2), "worst": worst,
-                "pass": bool(n_fail <= allowed and float(z.max()) <= hard),
-                "note": "independent random streams, so differences are Monte-Carlo error; the proposal step is small (miso.c:188, "
-                        "328), events with few informative reads mix slowly and two runs of the REFERENCE differ by the same "
-                        "amounts (worst.ref_seed_range)"})
+def gpu_streams(sh, events, n_streams, device, seed, collapsed=False):
+    """The build's side of the two-sample |delta psi| test: every study event under `n_streams` independent random
+    streams in ONE launch -- n_streams copies of the event (same reads: a pure function of its id) whose ids in the Philox
+    counter differ (miso_batch_set_event_id; the counter's event word is what separates two events' streams,
+    include/miso_philox.h) -- summarised on the device.  Returns {event: [(mean, ci_low, ci_high), ...]} and the launch's
+    kernels."""
+    from miso_amd import capi, workload
+    kw = dict(min_len=400, max_len=800, gap=300) if sh["paired"] else {}
+    b = capi.Batch(sh["read_len"], iters=sh["iters"], burn=sh["burn"], lag=sh["lag"], chains=sh["chains"], paired=sh["paired"],
+                   mean=sh["mean"] if sh["paired"] else 0.0, var=sh["var"] if sh["paired"] else 0.0, device_match=True,
+                   collapsed=collapsed)
+    spec = reads_spec(sh)
+    where = []
+    for s in range(n_streams):
+        for e in events:
+            exons, isoforms, expr = workload.event_gene(e, workload.mixed_k(e, sh["K"]), **kw)
+            i = b.add_simulated(capi.Gene(exons, isoforms), expr, workload.event_n_reads(e, spec), workload.GEN_SEED + e)
+            b.set_event_id(i, ((s + 1) << 20) + e)
+            where.append((e, i))
+    b.upload(device)
+    b.launch(seed=seed, first_event_id=0)
+    b.sync()
+    b.summarize(0.95)
+    runs = {}
+    for e, i in where:
+        runs.setdefault(e, []).append(tuple(v.tolist() for v in b.summary(i)))
+    return runs, b.last_kernels()
+
+
+def delta_psi(sh, study_rows, device, seed, collapsed=False, n_streams=None):
+    """BASELINE's "|delta psi| vs ref" with a pass/fail: the build under S random streams per event against the REAL
+    reference C core under S streams per event (posterior mean and both Chen-Shao bounds of every isoform), compared by
+    the exact permutation tests of tests/_dpsi.py -- pooled t^2, largest |t|, signed shifts of the mean and of either
+    bound, shrinkage towards the uniform vector, interval width.  (Round 3 compared one GPU run with S reference runs cell
+    by cell: little power, blind to a systematic shift.)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _dpsi
+    ref = {}
+    for e, _, m, lo, hi, _sd in study_rows:
+        ref.setdefault(e, []).append((m, lo, hi))
+    events = sorted(ref)
+    S = min(len(v) for v in ref.values())
+    if not events or S < 2:
+        return None
+    t0 = time.perf_counter()
+    runs, kernels = gpu_streams(sh, events, n_streams or S, device, seed, collapsed)
+    t_gpu = time.perf_counter() - t0
+    kmax = max(len(ref[e][0][0]) for e in events)
+    out = _dpsi.two_sample(_dpsi.stack_runs(runs, events, kmax), _dpsi.stack_runs(ref, events, kmax))
+    out["build_side"] = "%d events x %d streams in one launch (%s), %.2f s incl. host set-up" % (
+        len(events), n_streams or S, kernels, t_gpu)
+    out["test_s"] = round(time.perf_counter() - t0 - t_gpu, 2)
     return out
+
+
+def single_run_deltas(batch, sample_rows):
+    """Plain differences between the timed batch's own run and single runs of the reference (the timing sample), isoform 0."""
+    import numpy as np
+    rows = [r for r in sample_rows if r[0] < len(batch)]
+    if not rows:
+        return {}
+    batch.summarize(0.95)
+    d = np.array([[abs(batch.summary(r[0])[j][0] - r[2 + j][0]) for j in range(3)] for r in rows])
+    return {"events": len(rows), "mean_abs_dpsi": round(float(d[:, 0].mean()), 6), "max_abs_dpsi": round(float(d[:, 0].max()), 6),
+            "mean_abs_dci_low": round(float(d[:, 1].mean()), 6), "mean_abs_dci_high": round(float(d[:, 2].mean()), 6)}
 
 
 # ------------------------------------------------------------------------------------------------
@@ -448,9 +453,9 @@ def matrix_row(a, local_rank, wid, label, sh, n, st, collapsed=False):
         row["rng_frac"] = None   # (reads x iterations are not Philox words here)
     if st:
         row["cpu_baseline"] = st["baseline"]
-        if len(st["study"]) >= 2 * len(set(r_[0] for r_ in st["study"])):   # at least two reference seeds per event
-            row["delta_psi"] = delta_psi(b, st["study"])
     del b
+    if st and len(st["study"]) >= 2 * len(set(r_[0] for r_ in st["study"])):   # at least two reference seeds per event
+        row["delta_psi"] = delta_psi(sh, st["study"], local_rank, a.seed, collapsed)
     return row
 
 
@@ -471,6 +476,53 @@ def run_matrix(a, local_rank, studies, main_sh=None):
         if wid in COLLAPSED_ROWS and (not only or wid + "_collapsed" in only):
             rows.append(matrix_row(a, local_rank, wid + "_collapsed", label + ", collapsed Gibbs step", sh, n, st, collapsed=True))
     return rows
+
+
+MATRIX_COLS = ["id", "events_per_s", "kernel_ms", "valu_frac", "floor_frac", "hbm_measured_frac", "cpu", "dpsi_pass", "max_z", "p_row"]
+
+
+def _r(x, n):
+    return None if x is None else round(x, n)
+
+
+def compact_line(full):
+    """The one line the driver parses (the contract's keys, `roofline`, `cpu_baseline`, `delta_psi`, one short record per
+    matrix row), kept under 4 KB; everything else is in the full record."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data")
+    out = {k: full[k] for k in keep}
+    c = full["config"]
+    out["config"] = {k: c[k] for k in ("workload", "events_per_gpu", "K", "reads", "iters", "burn_in", "lag", "chains", "collapsed")}
+    out["config"]["parallelism"] = "%d cost-balanced contiguous event shards, one process per GPU, no collective" % full["n_gpus"]
+    r = full["roofline"] or {}
+    kern = r.get("kernel")
+    out["roofline"] = {"bound": r.get("bound"), "kernel": None if kern is None else kern[:96], "kernel_ms": r.get("kernel_ms"),
+                       "achieved": r.get("achieved"), "peak": r.get("peak"), "unit": r.get("unit"), "frac": r.get("frac"),
+                       "floor_frac": r.get("floor_frac"), "traffic": _r(r.get("traffic"), 0), "hbm_measured_frac": r.get("hbm_measured_frac"),
+                       "algorithmic_GBs": r.get("algorithmic_GBs"),
+                       "frac_source": None if r.get("frac") is None else "model: profiles/valu_model.json x this run's kernel time"}
+    b = full.get("cpu_baseline")
+    out["cpu_baseline"] = None if b is None else {
+        "value": b["value"], "unit": b["unit"], "cores": b["cores"], "kind": b["kind"], "value_1core": b["value_1core"],
+        "sample": b["sample"].split(" (")[0] + ", slowest process" + b["sample"].split("slowest process")[-1][:12]}
+    d = full.get("delta_psi")
+    out["delta_psi"] = None if d is None else {k: d.get(k) for k in ("pass", "p_row", "p_pooled", "p_sign", "max_z", "n_fail",
+                                                                     "n_fail_expected", "mean_abs_dpsi", "max_abs_dpsi")}
+    if d is not None:
+        out["delta_psi"]["design"] = d["design"].split(";")[0]
+    for k in ("per_rank_kernel_ms", "per_rank_elapsed_ms", "summary_ms", "compare_ms", "cpu_reference_wall_s", "stub", "full_record"):
+        if full.get(k) is not None:
+            out[k] = full[k]
+    if full.get("matrix"):
+        out["matrix_cols"] = MATRIX_COLS
+        rows = []
+        for m in full["matrix"]:
+            dp = m.get("delta_psi") or {}
+            rows.append([m["id"], round(m["events_per_s"]), _r(m["kernel_ms"], 2), _r(m["valu_frac"], 3), _r(m.get("floor_frac"), 3),
+                         _r(m["hbm_measured_frac"], 3), _r((m.get("cpu_baseline") or {}).get("value"), 1), dp.get("pass"),
+                         _r(dp.get("max_z"), 2), _r(dp.get("p_row"), 4)])
+        out["matrix"] = rows
+    return out
 
 
 def main():
@@ -506,6 +558,7 @@ def main():
     ap.add_argument("--no-streams", action="store_true", help="skip the device-side summaries / Bayes factors (rows f2, f3)")
     ap.add_argument("--host-match", action="store_true",
                     help="compute the read x isoform compatibility on the host instead of the GPU (row f1)")
+    ap.add_argument("--full-out", default="", help="where the full record goes (default gpurun_out/bench_full.json)")
     ap.add_argument("--stub", action="store_true",
                     help="TEST ONLY (tests/test_bench_launch.py): build and shard the events on the host, skip "
                          "every GPU call; the line says \"stub\": true and its value means nothing")
@@ -587,7 +640,7 @@ def main():
         elapsed, kernel_ms = time.perf_counter() - t0, [10.0] * a.steps
     else:
         elapsed, kernel_ms = time_batch(batch, a.seed, first, a.steps, a.warmup, barrier)
-    shard = [rank, first, last, float(costs[first:last].sum())]
+    shard = [rank, first, last, float(costs[first:last].sum()), sum(kernel_ms) / max(len(kernel_ms), 1), 1e3 * elapsed / max(a.steps, 1)]
     if dist is not None:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64)
@@ -609,9 +662,11 @@ def main():
         cpu = delta = None
         if studies and "main" in studies:
             cpu = studies["main"]["baseline"]
-            delta = delta_psi(batch, studies["main"]["study"], studies["main"]["timed"])
-            if delta.get("pass") is False:
-                rc = 3
+            delta = delta_psi(sh, studies["main"]["study"], local_rank, a.seed, bool(a.collapsed))
+            if delta is not None:
+                delta["single_runs"] = single_run_deltas(batch, studies["main"]["timed"])
+                if delta.get("pass") is False:
+                    rc = 3
         streams = {}
         if not a.stub and not a.no_streams and world == 1:
             streams = stream_rows(batch, n_local, sh, first, a.seed, local_rank)
@@ -637,11 +692,15 @@ def main():
                        "burn_in": a.burn, "lag": a.lag, "chains": a.chains, "collapsed": a.collapsed,
                        "parallelism": "%d contiguous cost-balanced event shards, one process per GPU, "
                                       "no collective on the data path" % world,
-                       "shards": [[r, lo, hi] for r, lo, hi, _ in shards],
-                       "shard_cost_share": [round(c / tot, 5) if tot else None for _, _, _, c in shards]},
+                       "shards": [[r, lo, hi] for r, lo, hi, *_ in shards],
+                       "shard_cost_share": [round(s_[3] / tot, 5) if tot else None for s_ in shards]},
             "roofline": roof,
             "cpu_baseline": cpu,
-            "delta_psi_vs_reference": delta,
+            "delta_psi": delta,
+            # every rank's own kernel time (HIP events on its stream) and wall time of the timed region: a scaling run can
+            # tell shard imbalance (kernel_ms differ) from a clock drop under the node's power budget (all grow together)
+            "per_rank_kernel_ms": [round(s_[4], 3) for s_ in shards],
+            "per_rank_elapsed_ms": [round(s_[5], 3) for s_ in shards],
             "host_build_s": round(t_build, 2), "upload_s": round(t_up, 3),
             "match_kernel_ms": None if a.stub else round(batch.match_ms(), 3),
             "summary_ms": streams.get("summary_ms"), "compare_ms": streams.get("compare_ms"),
@@ -654,9 +713,18 @@ def main():
         elif want_matrix:
             del batch
             out["matrix"] = run_matrix(a, local_rank, studies, sh)
-            if any(r.get("delta_psi", {}).get("pass") is False for r in out["matrix"]):
+            if any((r.get("delta_psi") or {}).get("pass") is False for r in out["matrix"]):
                 rc = 3
-        print(json.dumps(out), flush=True)
+        full_path = a.full_out or os.path.join(ROOT, "gpurun_out", "bench_full.json")
+        try:
+            os.makedirs(os.path.dirname(full_path), exist_ok=True)
+            with open(full_path, "w") as f:
+                json.dump(out, f, indent=1)
+            out["full_record"] = os.path.relpath(full_path, ROOT)
+        except OSError as err:
+            print("bench.py: full record not written (%s)" % err, file=sys.stderr, flush=True)
+        sys.stderr.flush()
+        print(json.dumps(compact_line(out), separators=(",", ":")), flush=True)   # the LAST line of stdout
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -263,6 +263,12 @@ int miso_batch_get_match(const miso_batch_t *batch, int event_index, double *mat
 /* names of the kernels the last launch used (for profiles): e.g. "sampler_k2<3, false>" */
 int miso_batch_last_kernels(const miso_batch_t *batch, char *buf, int buflen);
 
+/* How many launches of this batch miso_batch_sync() had to repeat because a chain spread over several workgroups
+   (the events with 10^4 ... 10^5 reads) did not get all of them resident in time on a busy device.  The repeat runs
+   in the same process with one workgroup per chain and returns the same results bit for bit; the batch never fails
+   for it -- the reference's workers share nothing either (misopy/miso.py:165-187).  0 on an idle device. */
+int miso_batch_coop_retries(const miso_batch_t *batch, int *n);
+
 /* Measurement: what the last launch put on the device, kernel by kernel (bench.py's VALU roofline
    prices it with the kernels' instruction counts, tools/isa_count.py): wavefronts launched, the sum
    over wavefronts of the read loop's trips per Gibbs step, Gibbs steps run (noIterations + 1),

@@ -367,6 +367,12 @@ class Batch:
         check(lib().miso_batch_last_kernels(self.handle, buf, 2048))
         return buf.value.decode()
 
+    def coop_retries(self):
+        """Launches sync() repeated with one workgroup per chain after a chain on several workgroups timed out."""
+        n = C.c_int(0)
+        check(lib().miso_batch_coop_retries(self.handle, C.byref(n)))
+        return n.value
+
     def launch_stats(self):
         """{"kernels": [{name, waves, trips, iterations, chains, words}], "uniforms": Philox words the
         read loops consume per launch} of the last launch (miso_batch_launch_stats)."""

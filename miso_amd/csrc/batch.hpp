@@ -33,7 +33,13 @@ struct miso_batch {
   bool pool_cleared = false;      // the output pool has been zeroed since the upload
   bool launched_once = false;     // since the upload
   std::vector<int> coop_n;        // per event: workgroups of a workgroup-wide paired-end chain (upload: by its share of the batch's work)
-  int coop_wgs_used = 0;          // cooperative workgroups handed out to this batch's wide runs (<= COOP_MAX_WGS)
+  int coop_wgs_used = 0;          // cooperative workgroups handed out to this batch's wide runs (<= coop_gen_budget)
+  int coop_gen_budget = 0;        // ... of the COOP_MAX_WGS a launch may hold in all; the two-isoform plans share the rest (launch())
+  bool no_coop = false;           // set by sync() after a chain on several workgroups gave up: every chain on one workgroup from now on
+  int coop_retries = 0;           // launches sync() had to repeat that way (miso_batch_coop_retries)
+  uint64_t last_seed = 0;         // what the last launch() was called with (sync()'s re-run)
+  uint32_t last_first_event_id = 0;
+  bool coop_enabled() const;      // chains may use several workgroups (coop.hpp): not after a time-out, not with MISO_NO_COOP=1
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::vector<hipStream_t> aux_streams;   // kernels 2.. of a mixed batch run beside the first

@@ -630,6 +630,10 @@ int miso_batch_get_match(const miso_batch_t *b, int i, double *match, int *fragm
   });
 }
 
+int miso_batch_coop_retries(const miso_batch_t *b, int *n) {
+  return guarded([&] { need(b, "batch"); need(n, "n"); *n = b->coop_retries; });
+}
+
 int miso_batch_last_kernels(const miso_batch_t *b, char *buf, int buflen) {
   return guarded([&] {
     need(b, "batch"); need(buf, "buf");
@@ -663,8 +667,8 @@ int miso_plan_lanes(const int *n_draw, int n_events, int chains, int paired, int
     static const int pe_widths[] = {4, 8, 16, 32, 64};
     LaneCost cost = paired ? k2_cost_paired() : k2_cost_single();
     if (cost5) { cost.block = cost5[0]; for (int i = 1; i <= 4; i++) cost.step[i] = cost5[i]; }
-    const LanePlan pl = paired ? plan_lanes(n_draw, n_events, chains, pe_widths, 5, 4, 4, resident_workgroups, max_chains_per_wave, cost, forced_target, COOP_MAX_N)
-                               : plan_lanes(n_draw, n_events, chains, se_widths, 12, 8, 8, resident_workgroups, max_chains_per_wave, cost, forced_target, COOP_MAX_N);
+    const LanePlan pl = paired ? plan_lanes(n_draw, n_events, chains, pe_widths, 5, 4, 4, resident_workgroups, max_chains_per_wave, cost, forced_target, COOP_MAX_N, COOP_MAX_WGS)
+                               : plan_lanes(n_draw, n_events, chains, se_widths, 12, 8, 8, resident_workgroups, max_chains_per_wave, cost, forced_target, COOP_MAX_N, COOP_MAX_WGS);
     *n_runs = pl.n_segs;
     for (int i = 0; i <= pl.n_segs; i++) { run_first_event[i] = pl.seg_slot[i]; run_first_workgroup[i] = pl.seg_block[i]; }
     for (int i = 0; i < pl.n_segs; i++) run_lanes[i] = pl.seg_lanes[i];

@@ -6,11 +6,16 @@
 // same routines, same bits); the read loop's lanes of all N workgroups stride over the chain's quads; the partial
 // totals meet in global memory: atomic adds into one of three rotating accumulators, one barrier per Gibbs step.
 //
-// No deadlock by construction: the host launches the cooperative kernel FIRST, on an otherwise idle device, with at
-// most COOP_MAX_WGS workgroups in all (a quarter of what the device holds), so all of them are resident before
-// anything else starts; kernels launched afterwards never wait for it.  Should a workgroup still wait longer than
-// COOP_MAX_POLLS polls (~ seconds), it raises the abort flag, every workgroup leaves, and the host reports
-// MISO_EINTERNAL instead of hanging the device.
+// Progress: a cooperative workgroup waits only for the other workgroups of ITS chain; every launch of a batch hands out at
+// most COOP_MAX_WGS cooperative workgroups in all (runtime.hip counts the two-isoform plans' and the gene runs' together:
+// a quarter of what the device holds), puts them at the front of their grids and starts those kernels first, and no
+// other workgroup ever waits for anything -- so whatever else occupies the device (the batch's other kernels, another
+// batch, another process) drains and the missing members become resident.  That is an argument about schedulers, not a
+// guarantee (HIP promises no dispatch order across queues or processes), hence the second line of defence: a workgroup
+// that has polled `max_polls` times (COOP_MAX_POLLS ~ tens of seconds) raises the chain's abort flag, every workgroup of
+// the chain leaves, and miso_batch_sync() re-runs the launch in the same process with every chain on ONE workgroup
+// (results are layout-independent bit for bit) -- a batch never fails, and never hangs the device, because of this
+// (the reference's workers share nothing either, misopy/miso.py:165-187).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -29,6 +34,7 @@ constexpr int COOP_WORDS = 4 + 3 * COOP_ACC;
 struct CoopGroup {
   int rank, n;          // this workgroup among the chain's n
   uint32_t *mem;        // the chain's COOP_WORDS dwords
+  uint32_t max_polls = COOP_MAX_POLLS;   // (KernelArgs::coop_max_polls overrides: tests)
 };
 
 __device__ __forceinline__ uint32_t coop_load(const uint32_t *p) {
@@ -47,7 +53,7 @@ __device__ __forceinline__ bool coop_barrier(const CoopGroup &g, uint32_t step, 
     int ok = 1;
     while (coop_load(&g.mem[0]) < want) {
       __builtin_amdgcn_s_sleep(8);
-      if (coop_load(&g.mem[1]) != 0u || ++polls > COOP_MAX_POLLS) { atomicExch(&g.mem[1], 1u); ok = 0; break; }
+      if (coop_load(&g.mem[1]) != 0u || ++polls > g.max_polls) { atomicExch(&g.mem[1], 1u); ok = 0; break; }
     }
     if (coop_load(&g.mem[1]) != 0u) ok = 0;
     __threadfence();

@@ -103,6 +103,7 @@ struct KernelArgs {
   const int32_t *coop_tab;  // workgroup-wide chains on SEVERAL workgroups (coop.hpp): per workgroup {chain (slot of the launch's
                             // list), rank among the chain's workgroups, their number, the chain's scratch index}; null = one each
   uint32_t *coop_mem;       // COOP_WORDS dwords of exchange scratch per cooperative chain, zeroed before the launch
+  uint32_t coop_max_polls;  // polls after which a cooperative workgroup gives up on its chain's other workgroups (0 = COOP_MAX_POLLS)
   const double *logfact;    // sampler_lane: log(k!) for k = 0 .. the batch's largest number of drawing reads (miso_binomial.h)
   int32_t red_off;          // sampler_k2_multi: byte offset of the workgroup-wide chains' reduction scratch in the dynamic LDS
   uint64_t seed;

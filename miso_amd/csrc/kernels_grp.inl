@@ -798,6 +798,7 @@ __device__ __forceinline__ void grp_body(const KernelArgs &a, unsigned block_x) 
     wide_slot = __builtin_amdgcn_readfirstlane(t[0]);
     cg.rank = __builtin_amdgcn_readfirstlane(t[1]); cg.n = __builtin_amdgcn_readfirstlane(t[2]);
     cg.mem = a.coop_mem + static_cast<size_t>(__builtin_amdgcn_readfirstlane(t[3])) * COOP_WORDS;
+    if (a.coop_max_polls) cg.max_polls = a.coop_max_polls;
   }
   uint32_t coop_step = 0; bool coop_ok = true;
   const long wave_id = WIDE ? wide_slot : static_cast<long>(block_x) * 4 + wave;

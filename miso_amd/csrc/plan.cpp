@@ -14,6 +14,7 @@ namespace {
 struct Planner {
   const int *nd; int n, C; const int *widths; int nw; int wide_wpb, wpb, resident, max_cpw; const LaneCost &cost;
   int coop_max;   // most workgroups one chain may use (1 = a chain ends at its workgroup)
+  int coop_budget;   // most workgroups ALL chains on several workgroups may use together (coop.hpp: resident at once)
   static constexpr double wide_extra = 150.0;   // barrier + LDS round trip of a workgroup-wide chain's reduction
   static constexpr double coop_extra = 1200.0;  // + atomics and the barrier between workgroups (~ 2 us)
 
@@ -42,13 +43,21 @@ struct Planner {
     if (wide_wpb > 0 && last == 64 && ndraw >= 64 * wide_wpb * 16 && cost.smooth_step(64, ndraw) > D) return K2_WIDE;
     return last;
   }
+  // the workgroups per chain of a workgroup-wide run's events, in list order (largest first), within the budget
+  long wide_list(double D, int first, long events, std::vector<int> *out) const {
+    long w = 0, used = 0;
+    for (long e = 0; e < events; e++) {
+      int m = wide_wgs(D, nd[first + e]);
+      if (m > 1 && used + static_cast<long>(m) * C > coop_budget) m = static_cast<int>(std::max<long>(1, (coop_budget - used) / C));
+      if (m > 1) used += static_cast<long>(m) * C;
+      if (out) out->push_back(m);
+      w += static_cast<long>(C) * m;
+    }
+    return w;
+  }
   long wgs_of(int lanes, long events, double D = 0, int first = 0) const {
     const long chains = events * C;
-    if (lanes == K2_WIDE) {
-      long w = 0;
-      for (long e = 0; e < events; e++) w += static_cast<long>(C) * wide_wgs(D, nd[first + e]);
-      return w;
-    }
+    if (lanes == K2_WIDE) return wide_list(D, first, events, nullptr);
     const int cpw = 64 / lanes;
     return ((chains + cpw - 1) / cpw + wpb - 1) / wpb;
   }
@@ -79,11 +88,12 @@ struct Planner {
 }  // namespace
 
 LanePlan plan_lanes(const int *n_draw, int n_events, int chains, const int *widths, int n_widths, int wide_wpb,
-                    int wpb, int resident_wgs, int max_cpw, const LaneCost &cost, double forced_target, int coop_max) {
+                    int wpb, int resident_wgs, int max_cpw, const LaneCost &cost, double forced_target, int coop_max,
+                    int coop_budget) {
   LanePlan best;
   if (n_events <= 0 || chains <= 0 || n_widths <= 0) return best;
   const Planner P{n_draw, n_events, chains, widths, n_widths, wide_wpb, wpb, std::max(1, resident_wgs), max_cpw, cost,
-                  std::max(1, coop_max)};
+                  std::max(1, coop_max), std::max(0, coop_budget)};
   const double wide_extra = Planner::wide_extra;
   // what a bound D costs: the runs, then every wavefront's step (the list is ordered: a wavefront's first chain is
   // its longest)
@@ -97,9 +107,9 @@ LanePlan plan_lanes(const int *n_draw, int n_events, int chains, const int *widt
       double first = 0;
       if (G == K2_WIDE) {
         plan.wide_wgs.clear();
+        P.wide_list(D, plan.seg_slot[s], plan.seg_slot[s + 1] - plan.seg_slot[s], &plan.wide_wgs);
         for (long c = c0; c < c1; c++) {
-          const int m = P.wide_wgs(D, n_draw[c / chains]);
-          if (c % chains == 0) plan.wide_wgs.push_back(m);
+          const int m = plan.wide_wgs[static_cast<size_t>(c / chains - plan.seg_slot[s])];
           const double w = cost.wave_step(64 * wide_wpb * m, n_draw[c / chains]) + wide_extra + (m > 1 ? Planner::coop_extra : 0.0);
           plan.est_total += w * wide_wpb * m; plan.est_max = std::max(plan.est_max, w); plan.est_last = w;
           if (c == c0) first = w;

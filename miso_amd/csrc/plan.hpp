@@ -71,9 +71,10 @@ struct LanePlan {
 // n_draw: the launch's events' drawing reads, most first; `chains` chains per event; widths: the instantiated lanes
 // per chain, ascending; wide_wpb: wavefronts of a workgroup-wide chain (0 = not available); wpb: wavefronts per
 // workgroup; resident_wgs: workgroups the device (or this kernel's share of it) holds at once; max_cpw: most
-// chains per wavefront the kernel's LDS allows (64 = no limit).
+// chains per wavefront the kernel's LDS allows (64 = no limit); coop_max: most workgroups of one workgroup-wide chain;
+// coop_budget: most workgroups all chains on several workgroups may take together.
 LanePlan plan_lanes(const int *n_draw, int n_events, int chains, const int *widths, int n_widths, int wide_wpb,
                     int wpb, int resident_wgs, int max_cpw, const LaneCost &cost, double forced_target = 0.0,
-                    int coop_max = 1);
+                    int coop_max = 1, int coop_budget = 1 << 30);
 
 }  // namespace miso

@@ -85,6 +85,8 @@ int choose_lanes_per_chain(long chains, int max_quads, int wave_slots, int max_c
 
 using namespace miso;
 
+bool miso_batch::coop_enabled() const { return !no_coop && std::getenv("MISO_NO_COOP") == nullptr; }
+
 void miso_batch::release() {
   if (device >= 0) (void) hipSetDevice(device);
   if (d_events) (void) hipFree(d_events);
@@ -95,6 +97,10 @@ void miso_batch::release() {
   if (d_logfact) (void) hipFree(d_logfact);
   if (d_k2_pair_tab) (void) hipFree(d_k2_pair_tab);
   d_slots = nullptr;
+  // (the next upload may be to another device: nothing may outlive its allocation as a stale pointer or a cached plan)
+  d_logfact = nullptr; logfact_n = 0;
+  d_k2_pair_tab = nullptr; k2_pair_tab.clear(); k2_pair_grid = k2_pair_wide_blocks = 0;
+  k2_plan_key = k2w_plan_key = -1;
   if (ev0) (void) hipEventDestroy(ev0);
   if (ev1) (void) hipEventDestroy(ev1);
   for (GenRun &run : gen_runs) {
@@ -385,7 +391,7 @@ void miso_batch::upload(int dev) {
     const double t_wave = std::getenv("MISO_PE_T_WAVE") ? std::atof(std::getenv("MISO_PE_T_WAVE")) : 64.0;
     const double t_wide = std::getenv("MISO_PE_T_WIDE") ? std::atof(std::getenv("MISO_PE_T_WIDE")) : 256.0;
     const bool dense_ok = std::getenv("MISO_NO_PE_DENSE") == nullptr;
-    const bool coop_on = std::getenv("MISO_NO_COOP") == nullptr;
+    const bool coop_on = coop_enabled();
     for (int i : gen) {
       const PackedEvent &e = events[i];
       const int nq = (e.n_draw + 3) / 4;
@@ -444,6 +450,8 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   a.il = static_cast<int>(fd.prob.size()); a.n_events = n;
   a.C = p.noChains; a.M = p.noIterations; a.B = p.noBurnIn; a.lag = p.noLag;
   a.start = p.start; a.first_event_id = first_event_id; a.seed = seed;
+  last_seed = seed; last_first_event_id = first_event_id;
+  if (const char *env = std::getenv("MISO_COOP_MAX_POLLS")) a.coop_max_polls = static_cast<uint32_t>(std::max(1L, std::atol(env)));   // tests
   // Trailing sample columns stay 0 (miso.c:661, quirk C8) -- they exist only when the lag does not divide the kept
   // iterations; otherwise the kernels overwrite every sample, log score, pick and statistic of the pool, and clearing
   // 4.8 GB per launch (0.75 ms of the headline's 102 ms step) is for the first launch only.
@@ -546,13 +554,13 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       // resident at once).  MISO_NO_COOP=1: one workgroup per chain; MISO_COOP_DRAWS=n: one per n drawing pairs (tests).
       if (!run.d_coop_tab) {
         run.coop_tab.clear(); run.coop_chains = 0;
-        const bool coop_on = std::getenv("MISO_NO_COOP") == nullptr;
+        const bool coop_on = coop_enabled();
         const int per_wg = std::getenv("MISO_COOP_DRAWS") ? std::max(256, std::atoi(std::getenv("MISO_COOP_DRAWS"))) : 8192;
         for (long c = 0; c < chains; c++) {
           const int ev_i = h_slots[n_k2 + run.first + c / p.noChains];
           const int nd = events[ev_i].n_draw;
           int nw = !coop_on ? 1 : (std::getenv("MISO_COOP_DRAWS") ? std::min(COOP_MAX_N, std::max(1, (nd + per_wg - 1) / per_wg)) : coop_n[ev_i]);
-          if (nw > 1 && coop_wgs_used + nw > COOP_MAX_WGS) nw = std::max(1, COOP_MAX_WGS - coop_wgs_used);
+          if (nw > 1 && coop_wgs_used + nw > coop_gen_budget) nw = std::max(1, coop_gen_budget - coop_wgs_used);
           if (nw > 1) coop_wgs_used += nw;
           for (int r = 0; r < nw; r++) {
             run.coop_tab.push_back(static_cast<int32_t>(c)); run.coop_tab.push_back(r); run.coop_tab.push_back(nw);
@@ -1028,7 +1036,23 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   // the device only: made once per upload.  MISO_K2_COST="block,step1,step2,step3,step4" overrides the cost model,
   // MISO_K2_TARGET=x forces the bound on a wavefront's step (tests: small batches with many widths).
   // (workgroup-wide chains may use several workgroups, coop.hpp; MISO_NO_COOP=1: their own only)
-  const int coop_max = std::getenv("MISO_NO_COOP") ? 1 : COOP_MAX_N;
+  const int coop_max = coop_enabled() ? COOP_MAX_N : 1;
+  // All cooperative workgroups of ONE launch() -- the gene runs' (wide_setup) and the two-isoform plans' -- come out of one
+  // budget of COOP_MAX_WGS (coop.hpp): the gene runs take what upload() asked for, at most 5/8 when two-isoform events are
+  // in the batch too; the MODE 2 plan gets two thirds of the rest when both two-isoform kernels run, the other plan the
+  // remainder.  (Single-end batches have one cooperative user, the two-isoform plan: all of it.)
+  int coop_k2_budget = COOP_MAX_WGS, coop_k2w_budget = COOP_MAX_WGS;
+  {
+    long want = 0;
+    for (int i = 0; i < n_gen; i++) { const int ev_i = h_slots[n_k2 + i]; if (coop_n[ev_i] > 1) want += static_cast<long>(coop_n[ev_i]) * p.noChains; }
+    if (std::getenv("MISO_COOP_DRAWS") && p.paired && n_gen > 0) want = COOP_MAX_WGS;   // (tests: the table decides chain by chain)
+    const long cap = n_k2 > 0 ? COOP_MAX_WGS * 5 / 8 : COOP_MAX_WGS;
+    coop_gen_budget = coop_max > 1 ? static_cast<int>(std::min(want, cap)) : 0;
+    const int left = COOP_MAX_WGS - coop_gen_budget;
+    coop_k2w_budget = (n_k2w > 0 && n_k2 - n_k2w > 0) ? left * 2 / 3 : left;
+    coop_k2_budget = n_k2w > 0 ? left - coop_k2w_budget : left;
+    if (!p.paired) coop_k2_budget = left;
+  }
   bool k2_multi = false;
   const bool lane_route = collapsed && !p.paired && n_k2 > 0;   // miso_batch_set_collapsed
   // lanes per chain of the collapsed step: one (sampler_lane).  Sharing a chain between 2, 4 or 8 lanes (sampler_k2c:
@@ -1048,7 +1072,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     const int pe1_cpw = p.paired ? static_cast<int>(std::max<long>(0, pe1_left / static_cast<long>(4 * std::max<size_t>(k2_tab, 1)))) : 64;
     if (p.paired && count > 0 && pe1_cpw >= 1 && std::getenv("MISO_LANES_PER_CHAIN") == nullptr && !(off && std::atoi(off) == 0)) {
       const int resident = std::max(1, slots_for(static_cast<long>(count) * p.noChains) / 4);
-      const long key = static_cast<long>(resident) * 64 + p.noChains;
+      const long key = (static_cast<long>(resident) * 64 + p.noChains) * 256 + coop_k2_budget + (coop_max > 1 ? 0 : 200);
       if (k2_plan_key != key || std::getenv("MISO_K2_TARGET") || std::getenv("MISO_K2_COST") || std::getenv("MISO_COOP_MIN_QUADS")) {
         static const int widths[] = {4, 8, 16, 32, 64};
         LaneCost cost = k2_cost_paired();
@@ -1056,14 +1080,14 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
         std::vector<int> nd(count);
         for (int i = 0; i < count; i++) nd[i] = events[h_slots[n_k2w + i]].n_draw;
         const double forced = std::getenv("MISO_K2_TARGET") ? std::atof(std::getenv("MISO_K2_TARGET")) : 0.0;
-        k2_plan = plan_lanes(nd.data(), count, p.noChains, widths, 5, 4, 4, resident, pe1_cpw, cost, forced, coop_max);
+        k2_plan = plan_lanes(nd.data(), count, p.noChains, widths, 5, 4, 4, resident, pe1_cpw, cost, forced, coop_max, coop_k2_budget);
         k2_plan_key = key;
       }
       k2_multi = k2_plan.n_segs > 0;
     }
     if (!p.paired && count > 0 && std::getenv("MISO_LANES_PER_CHAIN") == nullptr && !(off && std::atoi(off) == 0)) {
       const int resident = std::max(1, slots_for(static_cast<long>(count) * p.noChains) / 8);
-      const long key = static_cast<long>(resident) * 64 + p.noChains;
+      const long key = (static_cast<long>(resident) * 64 + p.noChains) * 256 + coop_k2_budget + (coop_max > 1 ? 0 : 200);
       if (k2_plan_key != key || std::getenv("MISO_K2_TARGET") || std::getenv("MISO_K2_COST") || std::getenv("MISO_COOP_MIN_QUADS") || std::getenv("MISO_K2_WPB")) {
         static const int widths[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 32, 64};
         LaneCost cost = k2_cost_single();
@@ -1073,13 +1097,13 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
         std::vector<int> nd(count);
         for (int i = 0; i < count; i++) nd[i] = events[h_slots[n_k2w + i]].n_draw;
         const double forced = std::getenv("MISO_K2_TARGET") ? std::atof(std::getenv("MISO_K2_TARGET")) : 0.0;
-        k2_plan = plan_lanes(nd.data(), count, p.noChains, widths, 12, 8, 8, resident, 64, cost, forced, coop_max);
+        k2_plan = plan_lanes(nd.data(), count, p.noChains, widths, 12, 8, 8, resident, 64, cost, forced, coop_max, coop_k2_budget);
         // several rounds: smaller workgroups (a workgroup starts when ALL its wavefronts' slots are free; with 8 the
         // slots of early finishers idle: MISO defaults on 40 000 events 425 ms, with 4: see profiles/r03_k2_multi_ab.txt)
         int wpb = k2_plan.rounds == 1 ? 8 : 4;
         if (const char *env = std::getenv("MISO_K2_WPB")) wpb = std::atoi(env);
         if (wpb != 8 && wpb != 4 && wpb != 1) MISO_FAIL(MISO_EINVAL, "MISO_K2_WPB must be 8, 4 or 1");
-        if (wpb != 8) k2_plan = plan_lanes(nd.data(), count, p.noChains, widths, 12, wpb >= 4 ? wpb : 0, wpb, resident * 8 / wpb, 64, cost, forced, coop_max);
+        if (wpb != 8) k2_plan = plan_lanes(nd.data(), count, p.noChains, widths, 12, wpb >= 4 ? wpb : 0, wpb, resident * 8 / wpb, 64, cost, forced, coop_max, coop_k2_budget);
         k2_plan_key = key;
         // One round, 8 wavefronts per workgroup: wavefronts w and w + 4 of a workgroup share a SIMD.  Pair the launch's
         // wavefronts (all runs but the workgroup-wide chains') by estimated duration, the i-th heaviest with the i-th
@@ -1137,7 +1161,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       const long lds_left = static_cast<long>(LDS_MAX) - static_cast<long>(k2w_fp) - K2_RED_BYTES;
       const int max_cpw = static_cast<int>(std::max<long>(0, lds_left / static_cast<long>(4 * k2w_tab)));
       const int resident = std::max(1, slots_for(static_cast<long>(n_k2w) * p.noChains) / 4);
-      const long key = static_cast<long>(resident) * 64 + p.noChains;
+      const long key = (static_cast<long>(resident) * 64 + p.noChains) * 256 + coop_k2w_budget + (coop_max > 1 ? 0 : 200);
       if (max_cpw >= 1 && (k2w_plan_key != key || std::getenv("MISO_K2_TARGET") || std::getenv("MISO_K2_COST") || std::getenv("MISO_COOP_MIN_QUADS") || std::getenv("MISO_K2W_WPB"))) {
         static const int widths[] = {4, 8, 16, 32, 64};
         LaneCost cost = k2_cost_paired();
@@ -1147,13 +1171,13 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
         std::vector<int> nd(n_k2w);
         for (int i = 0; i < n_k2w; i++) nd[i] = events[h_slots[i]].n_draw;
         const double forced = std::getenv("MISO_K2_TARGET") ? std::atof(std::getenv("MISO_K2_TARGET")) : 0.0;
-        k2w_plan = plan_lanes(nd.data(), n_k2w, p.noChains, widths, 5, 4, 4, resident, max_cpw, cost, forced, coop_max);
+        k2w_plan = plan_lanes(nd.data(), n_k2w, p.noChains, widths, 5, 4, 4, resident, max_cpw, cost, forced, coop_max, coop_k2w_budget);
         // The widest a chain can be is its workgroup: 256 lanes with 4 wavefronts, 512 with 8 (one workgroup per CU,
         // twice the LDS each: the same chains per CU).  8-wavefront workgroups lose ~19 % when the launch runs in
         // several rounds (a workgroup starts when ALL its slots are free), so they are taken only when the largest
         // events would otherwise outlast the launch (hg19-like read counts: 218 ms -> 175 ms; uniform: 217 ms -> 259 ms, not taken; profiles/r03_pe_k2_wpb.txt).
         {
-          const LanePlan p8 = plan_lanes(nd.data(), n_k2w, p.noChains, widths, 5, 8, 8, std::max(1, resident / 2), max_cpw, cost, forced, coop_max);
+          const LanePlan p8 = plan_lanes(nd.data(), n_k2w, p.noChains, widths, 5, 8, 8, std::max(1, resident / 2), max_cpw, cost, forced, coop_max, coop_k2w_budget);
           const char *env = std::getenv("MISO_K2W_WPB");
           if (env ? std::atoi(env) == 8 : 1.2 * p8.est < k2w_plan.est) k2w_plan = p8;
         }
@@ -1599,22 +1623,44 @@ void miso_batch::sync(float *ms) {
   HIP_OK(hipEventElapsedTime(&last_ms, ev0, ev1));
   if (ms) *ms = last_ms;
   // chains on several workgroups: did any group give up waiting for its members (coop.hpp)?
+  bool gave_up = false;
   for (const K2Coop *cc : {&k2_coop_se, &k2w_coop}) {
     if (!cc->d_mem || cc->chains == 0) continue;
     std::vector<uint32_t> w(static_cast<size_t>(cc->chains) * COOP_WORDS);
     HIP_OK(hipMemcpy(w.data(), cc->d_mem, w.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    for (int c = 0; c < cc->chains; c++)
-      if (w[static_cast<size_t>(c) * COOP_WORDS + 1] != 0)
-        MISO_FAIL(MISO_EINTERNAL, "a chain on several workgroups timed out waiting for its workgroups");
+    for (int c = 0; c < cc->chains; c++) gave_up |= w[static_cast<size_t>(c) * COOP_WORDS + 1] != 0;
   }
   for (const GenRun &run : gen_runs) {
     if (!run.d_coop_mem || run.coop_chains == 0) continue;
     std::vector<uint32_t> w(static_cast<size_t>(run.coop_chains) * COOP_WORDS);
     HIP_OK(hipMemcpy(w.data(), run.d_coop_mem, w.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    for (int c = 0; c < run.coop_chains; c++)
-      if (w[static_cast<size_t>(c) * COOP_WORDS + 1] != 0)
-        MISO_FAIL(MISO_EINTERNAL, "a chain on several workgroups timed out waiting for its workgroups");
+    for (int c = 0; c < run.coop_chains; c++) gave_up |= w[static_cast<size_t>(c) * COOP_WORDS + 1] != 0;
   }
+  if (!gave_up) return;
+  // A chain's workgroups did not all become resident in time (a busy device: other batches, other processes).  The
+  // batch must not fail for it -- the reference's workers share nothing (misopy/miso.py:165-187) --, so the launch is
+  // repeated here, in this process, with every chain on ONE workgroup: same results bit for bit (the contract's random
+  // numbers do not depend on the layout), no exchange between workgroups left that could wait.
+  if (no_coop) MISO_FAIL(MISO_EINTERNAL, "a chain timed out waiting for its workgroups although every chain has one workgroup");
+  const float first_ms = last_ms;
+  no_coop = true; coop_retries++;
+  std::fill(coop_n.begin(), coop_n.end(), 1);
+  for (GenRun &run : gen_runs) {
+    if (run.d_coop_tab) (void) hipFree(run.d_coop_tab);
+    if (run.d_coop_mem) (void) hipFree(run.d_coop_mem);
+    run.d_coop_tab = nullptr; run.d_coop_mem = nullptr; run.coop_tab.clear(); run.coop_chains = 0;
+  }
+  for (K2Coop *cc : {&k2_coop_se, &k2w_coop}) {
+    if (cc->d_tab) (void) hipFree(cc->d_tab);
+    if (cc->d_mem) (void) hipFree(cc->d_mem);
+    *cc = K2Coop{};
+  }
+  k2_plan_key = k2w_plan_key = -1; coop_wgs_used = 0;
+  pool_cleared = false;   // (the abandoned chains left their sample columns half written)
+  std::fprintf(stderr, "[miso] a chain on several workgroups gave up waiting for its workgroups after %.1f ms (busy device?): "
+                       "re-running the launch with one workgroup per chain\n", first_ms);
+  launch(last_seed, last_first_event_id);
+  sync(ms);
 }
 
 // Posterior mean and Chen-Shao credible interval of every isoform, computed where the samples are

@@ -14,17 +14,23 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_bench_starts_its_own_ranks_and_shards_by_cost():
+def test_bench_starts_its_own_ranks_and_shards_by_cost(tmp_path):
     env = dict(os.environ, OMP_NUM_THREADS="1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub", "--events", "37",
-           "--reads", "60", "--iters", "20", "--burn", "5", "--steps", "2", "--warmup", "0"]
+           "--reads", "60", "--iters", "20", "--burn", "5", "--steps", "2", "--warmup", "0",
+           "--full-out", str(tmp_path / "bench_full.json")]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stdout + out.stderr
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout                      # rank 0 only
+    assert out.stdout.rstrip().splitlines()[-1] == lines[0] and len(lines[0]) < 4096   # the driver keeps the tail of stdout
     d = json.loads(lines[0])
+    assert len(d["per_rank_kernel_ms"]) == 2 and len(d["per_rank_elapsed_ms"]) == 2
+    full = json.load(open(os.path.join(ROOT, d["full_record"])))          # (relative to the repository root)
+    assert full["value"] == d["value"] and "shards" in full["config"]
+    d["config"]["shards"] = full["config"]["shards"]
     assert d["n_gpus"] == 2 and d["stub"] is True and d["scaling"] == "weak"
     assert d["metric"].startswith("AS events/sec") and d["unit"] == "events/s"
     shards = d["config"]["shards"]
@@ -56,7 +62,7 @@ def test_cost_balanced_shards():
     assert c.min() == 3 * 7500 * 1000 and c.max() == 20 * 7500 * 1000
 
 
-def test_eight_ranks_heavy_tailed_events_balanced_by_cost():
+def test_eight_ranks_heavy_tailed_events_balanced_by_cost(tmp_path):
     """`--gpus 8` on real-looking read counts (workload.HG19_LIKE: 20 ... 10^5 reads per event): eight gloo ranks,
     contiguous shards, every shard's cost within one event of an eighth of the total (the reference's count split
     -- cluster_utils.py:23-32 -- would leave the worker that drew the 10^5-read events far behind), every rank's
@@ -67,12 +73,15 @@ def test_eight_ranks_heavy_tailed_events_balanced_by_cost():
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     per = 700
+    full8 = str(tmp_path / "bench_full.json")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--stub", "--events", str(per),
-           "--reads-dist", "hg19", "--iters", "20", "--burn", "5", "--steps", "1", "--warmup", "0"]
+           "--reads-dist", "hg19", "--iters", "20", "--burn", "5", "--steps", "1", "--warmup", "0", "--full-out", full8]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stdout + out.stderr
-    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    d = json.loads(out.stdout.rstrip().splitlines()[-1])
+    assert len(out.stdout.rstrip().splitlines()[-1]) < 4096 and len(d["per_rank_kernel_ms"]) == 8
     assert d["n_gpus"] == 8 and d["stub"] is True and d["config"]["reads"] == "hg19"
+    d["config"].update(json.load(open(full8))["config"])
     shards = d["config"]["shards"]
     assert [s[0] for s in shards] == list(range(8)) and shards[0][1] == 0 and shards[-1][2] == 8 * per
     assert all(shards[r][2] == shards[r + 1][1] for r in range(7))
@@ -82,3 +91,29 @@ def test_eight_ranks_heavy_tailed_events_balanced_by_cost():
     assert share.max() <= 1.0 / 8 + costs.max() / costs.sum() + 1e-6
     counts = np.array([s[2] - s[1] for s in shards])
     assert counts.max() > 1.15 * counts.min()          # equal cost is NOT equal count on such events
+
+
+def test_compact_line_of_a_full_size_record_stays_under_4k():
+    """The full default run's record (17 matrix rows, every note and model detail: 33 KB in round 3, which the driver could
+    not parse from its 8 KB tail) squeezed by bench.compact_line: one line, < 4 KB, the contract's keys + roofline +
+    cpu_baseline + delta_psi + one short record per matrix row."""
+    sys.path.insert(0, ROOT)
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_default.json")))
+    full["delta_psi"] = {"pass": True, "p_row": 0.51234, "p_pooled": 0.12345, "p_sign": 0.05432, "max_z": 3.123, "n_fail": 0,
+                         "n_fail_expected": 0.0486, "mean_abs_dpsi": 0.003865, "max_abs_dpsi": 0.028429,
+                         "design": "16 build streams vs 16 reference streams per event, 128 events, 768 cells; permutation"}
+    for m in full["matrix"]:
+        m["delta_psi"] = {"pass": True, "max_z": 3.21, "p_row": 0.51234}
+    full["per_rank_kernel_ms"] = [101.123] * 8
+    full["per_rank_elapsed_ms"] = [102.123] * 8
+    full["full_record"] = "gpurun_out/bench_full.json"
+    line = json.dumps(bench.compact_line(full), separators=(",", ":"))
+    assert len(line) < 4096 and "\n" not in line
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "delta_psi", "matrix"):
+        assert k in d
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms"} <= set(d["roofline"])
+    assert {"value", "unit", "cores", "kind"} <= set(d["cpu_baseline"]) and "workload" in d["config"]
+    assert len(d["matrix"]) == len(full["matrix"]) and all(len(r) == len(d["matrix_cols"]) for r in d["matrix"])

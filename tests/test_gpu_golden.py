@@ -53,20 +53,24 @@ def test_golden_inputs_bit_exact(orc, name):
     assert (np.abs(a.mean(0) - r.mean(0)) < tol).all(), (a.mean(0), r.mean(0), tol)
 
 
-@pytest.mark.parametrize("K,paired,n", [(5, True, 600), (10, True, 700), (10, False, 800), (3, True, 500)])
+@pytest.mark.parametrize("K,paired,n", [(5, True, 600), (10, True, 700), (10, False, 800), (3, True, 500), (5, False, 700),
+                                        (2, False, 600), (2, True, 500)])
 def test_device_posterior_within_monte_carlo_error_of_the_real_reference(ref, K, paired, n):
-    """The GPU against the REAL reference C core (oracle/_ref, independent random streams), every kernel family with
-    three or more isoforms, ALL isoforms, posterior mean and both Chen-Shao bounds: 6 genes x 8 reference seeds give
-    the Monte-Carlo standard error of one run's summaries gene by gene; the device's summaries (summarize_kernel) must
-    lie within 4 x MCSE x sqrt(1 + 1/8) of the seeds' mean -- P(|t_7| > 4) = 5e-3 per check, so a few of the 18 K
-    checks may exceed 4, none may exceed 9.  (The fixed tolerance of test_golden_inputs_bit_exact with its guessed
-    effective sample size stays as a smoke check; this is the measured one.  bench.py runs the same check at the
-    benchmark's sizes for every matrix row.)"""
+    """The GPU against the REAL reference C core (oracle/_ref, independent random streams), every kernel family, ALL
+    isoforms, posterior mean and both Chen-Shao bounds -- as a TWO-sample test: 10 genes, each under 8 random streams on
+    the GPU (8 copies of the gene with different ids in the Philox counter, one launch) and under 8 seeds of the
+    reference; the two groups of runs are compared by the exact permutation tests of tests/_dpsi.py (pooled t^2, the
+    largest |t|, signed shifts of the mean and of either bound, shrinkage, interval width; Bonferroni over the seven, row
+    level 1e-3).  Round 3 held ONE device run against 4 x MCSE of 8 reference seeds: blind to any bias below ~1 MCSE.
+    bench.py runs the same test at the benchmark's sizes for every matrix row.  Matches miso.c:845-900,
+    miso_paired.c:451-498, credible_intervals.py:31-55."""
+    import _dpsi
     from _problems import se_gene, expr_for
     kw = dict(iters=3000, burn=1000, lag=2, chains=1)
+    n_genes, n_streams = 10, 8
     b = miso_amd.Batch(36, paired=paired, mean=250.0 if paired else 0.0, var=900.0 if paired else 0.0, device_match=True, **kw)
     probs = []
-    for j in range(6):
+    for j in range(n_genes):
         exons, isoforms = se_gene(K, exlen=(500 if paired else 110) + 9 * j, gap=300 if paired else 100)
         g = ref.gene(flat(exons), isoforms)
         ref.rng_seed(8000 + j)
@@ -75,30 +79,30 @@ def test_device_posterior_within_monte_carlo_error_of_the_real_reference(ref, K,
         else:
             rc, _, pos, cig = ref.simulate_reads(g, expr_for(K), n, 36)
         assert rc == 0
-        b.add_event(miso_amd.Gene(exons, isoforms), pos, cig)
-        probs.append((g, pos, cig))
+        probs.append((g, pos, cig, miso_amd.Gene(exons, isoforms)))
+    for s in range(n_streams):
+        for j, (_, pos, cig, G) in enumerate(probs):
+            i = b.add_event(G, pos, cig)
+            b.set_event_id(i, ((s + 1) << 12) + j)
     b.run(seed=77, first_event_id=0)
     b.summarize(0.95)
+    gpu = {j: [b.summary(s * n_genes + j) for s in range(n_streams)] for j in range(n_genes)}
 
     def stats(samples):
         x = np.sort(samples, axis=0)
         m = len(x)
-        return np.stack([x.mean(0), x[int(round(0.025 * m)) - 1], x[int(round(0.975 * m)) - 1]])
-    z = []
-    for j, (g, pos, cig) in enumerate(probs):
-        runs = []
+        return x.mean(0), x[int(round(0.025 * m)) - 1], x[int(round(0.975 * m)) - 1]
+    cpu = {}
+    for j, (g, pos, cig, _) in enumerate(probs):
+        cpu[j] = []
         for s in range(8):
             ref.rng_seed(9000 + 17 * j + s)
             r = ref.miso_paired(g, pos, cig, 36, 250.0, 900.0, **kw) if paired else ref.miso(g, pos, cig, 36, **kw)
             assert r.rc == 0
-            runs.append(stats(r.samples))
-        runs = np.array(runs)                      # [8, 3, K]
-        gpu = np.stack(b.summary(j))               # [3, K]
-        mcse = runs.std(0, ddof=1)
-        d = np.abs(gpu - runs.mean(0))
-        z.append(np.where((mcse < 1e-12) & (d < 1e-9), 0.0, d / np.maximum(mcse * np.sqrt(1 + 1 / 8.0), 1e-12)))
-    z = np.array(z).ravel()
-    assert (z > 4).sum() <= max(2, int(0.03 * len(z))) and z.max() < 9, (K, paired, np.sort(z)[-5:])
+            cpu[j].append(stats(r.samples))
+    ev = list(range(n_genes))
+    res = _dpsi.two_sample(_dpsi.stack_runs(gpu, ev, K), _dpsi.stack_runs(cpu, ev, K))
+    assert res["pass"], (K, paired, res)
 
 
 def test_per_event_entry_points(orc):

@@ -222,3 +222,67 @@ def test_mixed_pair_counts_three_or_more_isoforms_paired_end_bit_exact(orc, K, c
     kc = {3: 4, 5: 8, 10: 12}[K]
     assert "sampler_grp<64, true, %d>" % kc in names[5] and ", true>" not in names[5], names   # a wavefront per large gene, none workgroup-wide
     assert "sampler_grp<64, true, %d>" % kc in names[6] and "sampler_grp<64, true, %d, true>" % kc in names[6], names
+
+
+def _worker(paired, K, rounds, **env):
+    import subprocess
+    import sys
+    e = dict(os.environ, **{k: str(v) for k, v in env.items()})
+    return subprocess.Popen([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "_coop_worker.py"),
+                             str(int(paired)), str(K), str(rounds)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=e)
+
+
+@pytest.mark.parametrize("paired,K,env", [
+    (True, 5, dict(MISO_COOP_DRAWS="1024")),                                   # sampler_grp WIDE, ~10 and ~4 workgroups per chain
+    (True, 5, dict(MISO_COOP_DRAWS="1024", MISO_PE_MULTI="1")),                # the same inside sampler_grp_multi
+    (False, 2, dict(MISO_K2_TARGET="1400", MISO_COOP_MIN_QUADS="1")),          # sampler_k2_multi<0, 8>
+    (True, 2, dict(MISO_K2_TARGET="1400", MISO_COOP_MIN_QUADS="1")),           # sampler_k2_multi<2, 4>
+])
+def test_a_chain_that_times_out_on_its_workgroups_is_rerun_not_failed(paired, K, env):
+    """coop.hpp's second line of defence, forced: with MISO_COOP_MAX_POLLS=1 a cooperative workgroup gives up on its
+    chain's other workgroups after ONE poll (as on a device too busy to make them resident); every workgroup of the
+    chain leaves, miso_batch_sync() repeats the launch in the same process with one workgroup per chain and the caller
+    gets the oracle's results bit for bit -- round 3 failed the WHOLE batch with MISO_EINTERNAL here.  The reference's
+    workers share nothing (misopy/miso.py:165-187): one gene must never cost a batch its results."""
+    p = _worker(paired, K, 1, MISO_COOP_MAX_POLLS="1", **env)
+    out, err = p.communicate(timeout=900)
+    assert p.returncode == 0, out + err
+    assert out.startswith("ok retries=") and int(out.split("retries=")[1].split()[0]) >= 1, out + err
+    assert "re-running the launch with one workgroup per chain" in err
+
+
+def test_two_processes_on_one_gpu_with_cooperative_chains_in_both():
+    """`miso -p N` with more workers than GPUs, or any second tenant: processes sample heavy-tailed batches on ONE device
+    at the same time, all with chains on several workgroups in flight (paired-end genes through sampler_grp's WIDE path,
+    two-isoform events through sampler_k2_multi), several launches each.  All must return the oracle's results bit for
+    bit; a time-out, should the device ever be that busy, is absorbed by the re-run (miso_batch_coop_retries)."""
+    procs = [_worker(True, 5, 6, MISO_COOP_DRAWS="1024"), _worker(False, 2, 6, MISO_K2_TARGET="1400", MISO_COOP_MIN_QUADS="1"),
+             _worker(True, 2, 6, MISO_K2_TARGET="1400", MISO_COOP_MIN_QUADS="1")]
+    for p in procs:
+        out, err = p.communicate(timeout=1500)
+        assert p.returncode == 0, out + err
+        assert out.startswith("ok retries="), out + err
+
+
+def test_collapsed_batch_on_one_device_then_another():
+    """release() between two uploads must leave nothing behind (the log-factorial table of the collapsed step, the
+    cross-run pairing table and the cached plans were kept as stale pointers in round 3: use-after-free on the second
+    device).  Needs two GPUs."""
+    from miso_amd import capi
+    if capi.device_count() < 2:
+        pytest.skip("one GPU visible")
+    orc = OrcLib()
+    evs = _events(orc, False, [300, 5000, 40, 900, 64, 2500, 150, 700])
+    kw = dict(iters=80, burn=20, lag=2, chains=2)
+    for collapsed, env in ((True, {}), (False, dict(MISO_K2_GLOBAL_PAIR="1"))):
+        with _env(**env):
+            b = miso_amd.Batch(36, device_match=True, collapsed=collapsed, **kw)
+            for exons, isoforms, g, pos, cig in evs:
+                b.add_event(miso_amd.Gene(exons, isoforms), pos, cig)
+            res = []
+            for dev in (0, 1, 0):
+                b.run(device=dev, seed=5, first_event_id=10)
+                res.append([b.result(i) for i in range(len(evs))])
+            for i in range(len(evs)):
+                assert np.array_equal(res[0][i].samples, res[1][i].samples) and np.array_equal(res[0][i].samples, res[2][i].samples)
+                assert (res[0][i].counts_hash == res[1][i].counts_hash).all()
