@@ -190,7 +190,10 @@ MISO_DEVHOST inline FlatLayout flat_layout(int ks, int cs) {
   L.misc = o; o += 4 * FLAT_MISC;
   L.thr = o; o += 4 * cs * tr;
   L.ctab = o; o += 4 * (CLS_WORDS * (cs + 1) + ks);
-  L.bytes = (o + 15) & ~15;
+  // slices an ODD number of 8-byte words apart: 64 lanes reading the same entry of 64 consecutive slices (sampler_flatl's
+  // Metropolis-Hastings wavefront, one chain per lane) hit 64 different banks
+  L.bytes = (o + 7) & ~7;
+  if (((L.bytes >> 3) & 1) == 0) L.bytes += 8;
   return L;
 }
 constexpr uint16_t FRAG_NONE = 0xFFFF;

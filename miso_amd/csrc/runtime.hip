@@ -19,6 +19,10 @@
 #include "coop.hpp"
 #include "miso_binomial.h"
 
+#ifndef MISO_FLAT_LANE_MH_DEFAULT
+#define MISO_FLAT_LANE_MH_DEFAULT 0
+#endif
+
 namespace miso {
 
 template <bool PE> __global__ void sampler_wave(const KernelArgs a);
@@ -38,6 +42,7 @@ __global__ void summarize_kernel(const DevEvent *, const unsigned char *, int, i
 template <int G, bool PE, int KC, bool WIDE = false> __global__ void sampler_grp(const KernelArgs a);
 template <int KC> __global__ void sampler_grp_multi(const KernelArgs a);
 template <int KC> __global__ void sampler_flat(const KernelArgs a);
+template <int KC> __global__ void sampler_flatl(const KernelArgs a);   // kernels_flatl.inl: the scalar step by one wavefront per workgroup, one chain per lane
 __global__ void selftest_detmath_kernel(const double *, int, double *, double *, double *, double *);
 __global__ void selftest_philox_kernel(const uint32_t *, int, uint32_t *);
 
@@ -758,6 +763,9 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   // cost more than the read sweep they replace -- profiles/r03_collapsed.txt; it pays from ~10^4 reads per event)
   bool lane_gen = collapsed && collapsed_level >= 2 && !p.paired && n_gen > 0;
   for (const GenRun &run : gen_runs) if (run.nocls) lane_gen = false;
+  // sampler_flatl (kernels_flatl.inl): the Metropolis-Hastings step by ONE wavefront of the workgroup, one chain per lane --
+  // 4 wavefronts x nc chains <= 64 lanes.  MISO_FLAT_LANE_MH=0: sampler_flat (A/B, tests).
+  const bool flat_lmh = std::getenv("MISO_FLAT_LANE_MH") ? std::atoi(std::getenv("MISO_FLAT_LANE_MH")) != 0 : MISO_FLAT_LANE_MH_DEFAULT != 0;
   std::vector<int> flat_nc(gen_runs.size(), 0), flat_nc_max(gen_runs.size(), 0);
   for (size_t ri = 0; ri < gen_runs.size(); ri++) {
     const GenRun &run = gen_runs[ri];
@@ -767,7 +775,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     // workgroups per CU: 3 for K <= 4 (kernels_flat.inl's register budget allows it up to K = 8), else 2; MISO_FLAT_WGS overrides
     const int wgs = std::getenv("MISO_FLAT_WGS") ? std::max(1, std::atoi(std::getenv("MISO_FLAT_WGS"))) : (run.kc <= 4 ? 3 : 2);   // measured: K=3 +2 %, K=4 +4 %; K=5..8 no gain
     const size_t lds_wave = std::getenv("MISO_LDS_MAX_KB") ? LDS_MAX / 4 : static_cast<size_t>(160 * 1024 / (4 * wgs)) - 64;
-    const int nc_max = std::min<int>(64, static_cast<int>(lds_wave) / slice);
+    const int nc_max = std::min<int>(flat_lmh ? 16 : 64, static_cast<int>(lds_wave) / slice);
     if (nc_max < 1) continue;
     const long chains = static_cast<long>(run.count) * p.noChains;
     // the fewest rounds of resident wavefronts that nc_max allows, then the fewest chains per wavefront
@@ -780,12 +788,12 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     // K=6 69.4k / 67.5k / 72.2k / 77.2k / 68.6k, K=7 64.1k / 61.4k / 68.8k / 73.5k / 64.3k, K=8 55.8k / 57.1k /
     // 52.6k / 55.1k / 54.4k; K=5: 8 -> 93.4k, 7 -> 90.3k, 10 -> 86.8k.  (Timing the candidates on the first launch
     // was tried: a 7 % difference is inside the noise of a 200-iteration trial, the choice flipped between runs.)
-    if (run.kc == 8) nc = std::min(nc, run.kmin >= 8 ? 6 : 8);
-    if (run.kc == 4 && run.kmin >= 4) nc = std::min(nc, 8);   // four isoforms, descriptor loop: 8 -> 119.8k, 16 -> 116.1k, 13 -> 85.5k
+    if (run.kc == 8 && !flat_lmh) nc = std::min(nc, run.kmin >= 8 ? 6 : 8);
+    if (run.kc == 4 && run.kmin >= 4 && !flat_lmh) nc = std::min(nc, 8);   // four isoforms, descriptor loop: 8 -> 119.8k, 16 -> 116.1k, 13 -> 85.5k
     if (const char *env = std::getenv("MISO_FLAT_NC")) nc = std::max(1, std::min(nc_max, std::atoi(env)));
     flat_nc[ri] = nc; flat_nc_max[ri] = nc_max;
   }
-  auto flat_name = [&](const GenRun &run) { return "sampler_flat<" + std::to_string(run.kc) + ">"; };
+  auto flat_name = [&](const GenRun &run) { return std::string(flat_lmh ? "sampler_flatl<" : "sampler_flat<") + std::to_string(run.kc) + ">"; };
   // Which chains a wavefront of sampler_flat owns (kernels_flat.inl: a.wave_tab).  Uniform batches: `nc` consecutive
   // chains each.  When the batch's events differ widely in size -- the heaviest wavefront of the uniform rule would
   // carry more than twice the average wavefront's work units -- the wavefronts are packed by UNITS instead: as many
@@ -802,7 +810,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     const long chains = static_cast<long>(run.count) * p.noChains;
     const int C = p.noChains;
     const char *env = std::getenv("MISO_FLAT_PACK");
-    const long key = static_cast<long>(nc) * 4 + (env ? 1 + (std::atoi(env) != 0) : 0);
+    const long key = (static_cast<long>(nc) * 4 + (env ? 1 + (std::atoi(env) != 0) : 0)) * 128 + nc_max;
     if (run.wave_key == key && run.d_wave_tab) return;
     auto units_of = [&](long c) { return static_cast<long>(events[h_slots[n_k2 + run.first + c / C]].n_units); };
     long total = 0, head = 0;
@@ -878,7 +886,11 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     const unsigned grid = static_cast<unsigned>(run.wave_tab.size() / 8);
     const size_t lds = 4 * static_cast<size_t>(run.wave_nc) * flat_layout(ka.kstride, ka.cstride).bytes;
 #define MISO_FLAT_LAUNCH(KC)                                                                            \
-  {                                                                                                     \
+  if (flat_lmh) {                                                                                       \
+    HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sampler_flatl<KC>),                      \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));     \
+    hipLaunchKernelGGL((sampler_flatl<KC>), dim3(grid), dim3(256), lds, st, ka);                        \
+  } else {                                                                                              \
     HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sampler_flat<KC>),                       \
                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));     \
     hipLaunchKernelGGL((sampler_flat<KC>), dim3(grid), dim3(256), lds, st, ka);                         \
@@ -1294,7 +1306,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     return "sampler_k2<" + std::to_string(G) + (p.paired ? (wpart ? ", 2, 4>" : ", 1, 4>") : (k2_pair ? ", 0, 8>" : ", 0, 4>"));
   };
   auto k2_mix_name = [&](int G) { return "sampler_k2_mix<" + std::to_string(G + 1) + ", " + std::to_string(G) + ">"; };
-  auto flat_name = [&](const GenRun &run) { return "sampler_flat<" + std::to_string(run.kc) + ">"; };
+  auto flat_name = [&](const GenRun &run) { return std::string(flat_lmh ? "sampler_flatl<" : "sampler_flat<") + std::to_string(run.kc) + ">"; };
   for (int part = 0; part < 2; part++) {
     const bool wpart = part == 0;
     const int count = wpart ? n_k2w : n_k2 - n_k2w, k2G = wpart ? k2w_G : k2_G;
