@@ -105,7 +105,7 @@ struct miso_batch {
   std::vector<Pending> pending;
   float match_ms = 0.f;          // kernel time of the last resolve
   // tests (want_counts_trace): the kernel's raw outputs, per resolved event
-  std::vector<std::vector<uint32_t>> kept_masks;   // single-end: N masks
+  std::vector<std::vector<uint64_t>> kept_masks;   // single-end: N masks
   std::vector<std::vector<uint16_t>> kept_frags;   // paired-end: N x K fragment indices
   void resolve_pending();        // runs match_kernel for all pending events, packs them
   int lanes_per_chain = 0;        // G of the last sampler_k2 launch (0 = none)

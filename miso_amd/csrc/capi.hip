@@ -25,8 +25,28 @@ extern "C" int miso_usable_threads(void);   // alnio.cpp: affinity mask capped b
 // kernel waits for the one before it in its queue.  Measured (16 384 genes of 3-20 isoforms, heavy-tailed read
 // counts, 1 500 iterations): 1 queue 811 ms, 2: 506, 4: 290, 8: 198, 16: 195.  The runtime reads the variable when it
 // initialises, at the first HIP call: loading this library early enough sets 8 unless the host chose a value.
+// If the host process has ALREADY initialised the GPU runtime (torch imported and used first), the variable would be read
+// by nobody and only mislead this library (and any other HIP user of the process) about what is in effect: then it is
+// left alone and miso_hw_queues_in_effect() says "unknown" (0).  MISO_HW_QUEUES_IN_EFFECT=n: a host that knows tells.
 #include <cstdlib>
-__attribute__((constructor(101))) static void miso_amd_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+#include <dlfcn.h>
+namespace miso { int g_hw_queues_in_effect = 0; }
+__attribute__((constructor(101))) static void miso_amd_runtime_defaults() {
+  bool runtime_up = false;
+  // hsa_system_get_info answers HSA_STATUS_ERROR_NOT_INITIALIZED before hsa_init and initialises nothing itself
+  if (void *h = dlopen("libhsa-runtime64.so.1", RTLD_NOW | RTLD_NOLOAD)) {
+    using info_fn = int (*)(int, void *);
+    if (auto fn = reinterpret_cast<info_fn>(dlsym(h, "hsa_system_get_info"))) {
+      uint16_t major = 0;
+      runtime_up = fn(0 /* HSA_SYSTEM_INFO_VERSION_MAJOR */, &major) == 0;
+    }
+    dlclose(h);
+  }
+  if (const char *told = std::getenv("MISO_HW_QUEUES_IN_EFFECT")) { miso::g_hw_queues_in_effect = std::atoi(told); return; }
+  if (runtime_up) return;   // too late to choose, and what was chosen cannot be asked: unknown
+  setenv("GPU_MAX_HW_QUEUES", "8", 0);
+  miso::g_hw_queues_in_effect = std::atoi(std::getenv("GPU_MAX_HW_QUEUES"));
+}
 // alnio.cpp: one event's reads into growing buffers (the C entry point wraps it)
 int miso_aln_collect_reads(const miso_alnfile_t *f, int ref, int64_t start, int64_t end, int paired,
                            int strand_rule, int target_strand, int given_read_len,
@@ -201,7 +221,7 @@ int miso_batch_add_event(miso_batch_t *b, const miso_gene_t *gene, const int *po
     const int N = b->p.paired ? n_positions / 2 : n_positions;
     if (b->p.device_match) {   // row f1: parse now (errors surface here), match on the GPU at upload
       if (g.K < 2) MISO_FAIL(MISO_EINVAL, "At least two isoforms are needed");
-      if (g.K > MISO_MAX_ISOFORMS) MISO_FAIL(MISO_UNIMPLEMENTED, "More than 32 isoforms");
+      if (g.K > MISO_MAX_ISOFORMS) MISO_FAIL(MISO_UNIMPLEMENTED, "More than 64 isoforms");
       if (b->p.overHang < 0) MISO_FAIL(MISO_EINVAL, "Overhang length invalid. Must be positive");
       if (b->p.readLength < 0) MISO_FAIL(MISO_EINVAL, "Read length cannot be negative");
       miso_batch::Pending pe;
@@ -426,7 +446,7 @@ int miso_batch_add_events_aln(miso_batch_t *b, int n, const miso_gene_t *const *
           if (!genes[i]) MISO_FAIL(MISO_EINVAL, "gene must not be NULL");
           const Gene &g = genes[i]->g;
           if (g.K < 2) MISO_FAIL(MISO_EINVAL, "At least two isoforms are needed");
-          if (g.K > MISO_MAX_ISOFORMS) MISO_FAIL(MISO_UNIMPLEMENTED, "More than 32 isoforms");
+          if (g.K > MISO_MAX_ISOFORMS) MISO_FAIL(MISO_UNIMPLEMENTED, "More than 64 isoforms");
           int64_t k = 0;
           if (miso_aln_collect_reads(f, ref[i], start[i], end[i], paired, strand_rule, target_strand[i],
                                      given_read_len, pos, cig, &k, nullptr))
@@ -623,9 +643,9 @@ int miso_batch_get_match(const miso_batch_t *b, int i, double *match, int *fragm
         if (fragmentLength) fragmentLength[j] = ok ? b->fd.start + f[j] : -1;
       }
     } else {
-      const std::vector<uint32_t> &m = b->kept_masks.at(i);
+      const std::vector<uint64_t> &m = b->kept_masks.at(i);
       for (int r = 0; r < e.N; r++)
-        for (int k = 0; k < e.K; k++) match[static_cast<size_t>(r) * e.K + k] = (m[r] >> k) & 1u ? 1.0 : 0.0;
+        for (int k = 0; k < e.K; k++) match[static_cast<size_t>(r) * e.K + k] = (m[r] >> k) & 1ull ? 1.0 : 0.0;
     }
   });
 }

@@ -158,7 +158,7 @@ MISO_DEVHOST inline int grp_slice_bytes(int ks, int cs, int ts) {
 }
 // ---- sampler_flat (kernels_flat.inl): one chain's LDS slice, byte offsets.  ks = isoform stride
 // (the launch's largest K), cs = most drawing-read classes of any event of the launch. ----
-constexpr int FLAT_SX = 16;     // per-chain double scalars
+constexpr int FLAT_SX = 24;     // per-chain double scalars (16 of the Metropolis-Hastings passes + the leader lane's state between iterations)
 constexpr int FLAT_MISC = 24;   // per-chain int scalars
 struct FlatLayout {
   int psi, alpha, lp, tb, lr;   // double[2][ks]: buffer `parity` = current state and its cached logs, the other = proposal
@@ -190,10 +190,7 @@ MISO_DEVHOST inline FlatLayout flat_layout(int ks, int cs) {
   L.misc = o; o += 4 * FLAT_MISC;
   L.thr = o; o += 4 * cs * tr;
   L.ctab = o; o += 4 * (CLS_WORDS * (cs + 1) + ks);
-  // slices an ODD number of 8-byte words apart: 64 lanes reading the same entry of 64 consecutive slices (sampler_flatl's
-  // Metropolis-Hastings wavefront, one chain per lane) hit 64 different banks
-  L.bytes = (o + 7) & ~7;
-  if (((L.bytes >> 3) & 1) == 0) L.bytes += 8;
+  L.bytes = (o + 15) & ~15;
   return L;
 }
 constexpr uint16_t FRAG_NONE = 0xFFFF;

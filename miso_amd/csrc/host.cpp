@@ -339,21 +339,21 @@ PackedEvent pack_event(const miso_params_t &p, const FragmentDist *fd, int K, in
                        const double *match, const int *fraglen, const int *isolen,
                        const int *noexons, const double *hyper) {
   if (K < 2) MISO_FAIL(MISO_EINVAL, "At least two isoforms are needed");
-  if (K > MISO_MAX_ISOFORMS) MISO_FAIL(MISO_UNIMPLEMENTED, "More than 32 isoforms");
+  if (K > MISO_MAX_ISOFORMS) MISO_FAIL(MISO_UNIMPLEMENTED, "More than 64 isoforms");
   if (p.paired && (!fd || !fraglen)) MISO_FAIL(MISO_EINTERNAL, "Paired event without fragments");
   // the packed form only needs which isoforms a read is compatible with (and, paired-end, the
   // fragment length in each); a caller-made single-end matrix with values other than 0/1 keeps
   // its values for the header's read classes
-  std::vector<uint32_t> masks(N > 0 ? N : 1, 0u);
+  std::vector<uint64_t> masks(N > 0 ? N : 1, 0u);
   std::vector<uint16_t> frags;
   bool binary = true;
   if (p.paired) frags.assign(static_cast<size_t>(N) * K, FRAG_NONE);
   for (int i = 0; i < N; i++) {
-    uint32_t m = 0;
+    uint64_t m = 0;
     for (int k = 0; k < K; k++) {
       const size_t j = static_cast<size_t>(i) * K + k;
       if (match[j] != 0) {
-        m |= 1u << k;
+        m |= 1ull << k;
         if (p.paired) {
           // the fragment length indexes the fragment-probability and score tables: a caller-made problem
           // outside [start, start + il) would read out of bounds on the host and on the device
@@ -372,10 +372,11 @@ PackedEvent pack_event(const miso_params_t &p, const FragmentDist *fd, int K, in
 }
 
 PackedEvent pack_event_masks(const miso_params_t &p, const FragmentDist *fd, int K, int N,
-                             const uint32_t *masks, const uint16_t *frags, const double *se_values,
+                             const uint64_t *masks, const uint16_t *frags, const double *se_values,
                              const int *isolen, const int *noexons, const double *hyper) {
   if (K < 2) MISO_FAIL(MISO_EINVAL, "At least two isoforms are needed");
-  if (K > MISO_MAX_ISOFORMS) MISO_FAIL(MISO_UNIMPLEMENTED, "More than 32 isoforms");
+  if (K > MISO_MAX_ISOFORMS) MISO_FAIL(MISO_UNIMPLEMENTED, "More than 64 isoforms");
+  const bool small = K <= 32;   // the class tables, work units and dense records of the kernels for up to 32 isoforms
   if (p.paired && (!fd || (N > 0 && !frags))) MISO_FAIL(MISO_EINTERNAL, "Paired event without fragments");
   const int ov = p.overHang == 0 ? 1 : p.overHang;
   PackedEvent e;
@@ -434,16 +435,16 @@ PackedEvent pack_event_masks(const miso_params_t &p, const FragmentDist *fd, int
   // paired-end classes are binarised by definition) are keyed by their bit pattern, isoform 0 most
   // significant; anything else (a caller-made single-end matrix) takes the general map.
   std::map<std::vector<double>, double> cls;
-  std::vector<std::pair<uint32_t, double>> bcls;   // (bit-reversed mask, count), small
+  std::vector<std::pair<uint64_t, double>> bcls;   // (bit-reversed mask, count), small
   const bool binary = se_values == nullptr;
-  auto reversed = [K](uint32_t m) { uint32_t r = 0; for (int k = 0; k < K; k++) r = (r << 1) | ((m >> k) & 1u); return r; };
-  uint32_t last_mask = ~0u; size_t last_cls = 0;
+  auto reversed = [K](uint64_t m) { uint64_t r = 0; for (int k = 0; k < K; k++) r = (r << 1) | ((m >> k) & 1u); return r; };
+  uint64_t last_mask = ~0ull; size_t last_cls = 0;
   for (int i = 0; i < N; i++) {
-    const uint32_t mask = masks[i];
-    const int nv = __builtin_popcount(mask);
+    const uint64_t mask = masks[i];
+    const int nv = __builtin_popcountll(mask);
     if (binary) {
       if (mask != last_mask) {   // reads of one class tend to come in runs
-        const uint32_t rev = reversed(mask);
+        const uint64_t rev = reversed(mask);
         size_t c = 0;
         while (c < bcls.size() && bcls[c].first != rev) c++;
         if (c == bcls.size()) bcls.emplace_back(rev, 0.0);
@@ -455,7 +456,7 @@ PackedEvent pack_event_masks(const miso_params_t &p, const FragmentDist *fd, int
     }
     if (nv == 0) continue;
     if (nv == 1) {
-      const int first = __builtin_ctz(mask);
+      const int first = __builtin_ctzll(mask);
       e.fixed_ass[i] = first;
       e.base_count[first]++;
       if (p.paired) {
@@ -518,12 +519,12 @@ PackedEvent pack_event_masks(const miso_params_t &p, const FragmentDist *fd, int
   if (!p.paired) {
     // draw order: by column (isoform 0 most significant, 0 < 1), ties by read index
     // (a stable counting sort over the distinct masks: usually a handful, at most n_draw)
-    std::vector<std::pair<uint32_t, uint32_t>> dm;   // (reversed mask, mask) of the distinct drawing masks
+    std::vector<std::pair<uint64_t, uint64_t>> dm;   // (reversed mask, mask) of the distinct drawing masks
     std::vector<int32_t> cid(e.n_draw);
     {
-      uint32_t lm = ~0u; int32_t lc = 0;
+      uint64_t lm = ~0ull; int32_t lc = 0;
       for (int r = 0; r < e.n_draw; r++) {
-        const uint32_t m = e.draw_mask[r];
+        const uint64_t m = e.draw_mask[r];
         if (m != lm) {
           size_t c = 0;
           while (c < dm.size() && dm[c].second != m) c++;
@@ -542,16 +543,16 @@ PackedEvent pack_event_masks(const miso_params_t &p, const FragmentDist *fd, int
     }
     for (int r = 0; r < e.n_draw; r++) start[rank[cid[r]] + 1]++;
     for (size_t c = 0; c < dm.size(); c++) start[c + 1] += start[c];
-    std::vector<int32_t> idx(e.n_draw); std::vector<uint32_t> msk(e.n_draw);
+    std::vector<int32_t> idx(e.n_draw); std::vector<uint64_t> msk(e.n_draw);
     for (int r = 0; r < e.n_draw; r++) {
       const int32_t at = start[rank[cid[r]]]++;
       idx[at] = e.draw_index[r]; msk[at] = e.draw_mask[r];
     }
     e.draw_index.swap(idx); e.draw_mask.swap(msk);
-    for (int r = 0; r < e.n_draw; r++)
-      if (r == 0 || e.draw_mask[r] != e.draw_mask[r - 1]) { e.dcls_mask.push_back(e.draw_mask[r]); e.dcls_start.push_back(r); }
+    for (int r = 0; r < e.n_draw && small; r++)
+      if (r == 0 || e.draw_mask[r] != e.draw_mask[r - 1]) { e.dcls_mask.push_back(static_cast<uint32_t>(e.draw_mask[r])); e.dcls_start.push_back(r); }
     e.dcls_start.push_back(e.n_draw);
-    if (e.dcls_mask.size() > MAX_DRAW_CLASSES) {
+    if (e.dcls_mask.size() > MAX_DRAW_CLASSES || !small) {
       e.dcls_mask.clear(); e.dcls_start.clear();
     } else {
       // one unit = the words of one Philox block (draws 4q .. 4q+3) that belong to one class; a
@@ -585,7 +586,7 @@ PackedEvent pack_event_masks(const miso_params_t &p, const FragmentDist *fd, int
   if (binary) {
     std::sort(bcls.begin(), bcls.end());
     for (const auto &kv : bcls) {
-      for (int k = 0; k < K; k++) e.class_templates.push_back((kv.first >> (K - 1 - k)) & 1u ? 1.0 : 0.0);
+      for (int k = 0; k < K; k++) e.class_templates.push_back((kv.first >> (K - 1 - k)) & 1ull ? 1.0 : 0.0);
       e.class_counts.push_back(kv.second);
     }
   }

@@ -82,7 +82,7 @@ SimReads simulate_paired_reads(const Gene &g, const double *expr, int npairs, in
 //   * "fixed" reads (0 or 1 compatible isoform): folded into base_count[k] (and, paired-end,
 //     into base_sfix), never touched again by the device;
 //   * "drawing" reads, kept in read order (their rank is their RNG address, miso_philox.h):
-//     single-end: one u32 bit mask per read (bit k = compatible with isoform k);
+//     single-end: one bit mask per read (bit k = compatible with isoform k; two u32 words from 33 isoforms on);
 //     paired-end: K u16 fragment-length indices per read (0xFFFF = incompatible).
 struct PackedEvent {
   int K = 0, N = 0, n_draw = 0;
@@ -97,7 +97,7 @@ struct PackedEvent {
   // compared lexicographically like the reference's own read order (matrix.pmt:546-562), so that
   // the reads of one class are consecutive.
   std::vector<int32_t> draw_index;      // n_draw: read index of draw r
-  std::vector<uint32_t> draw_mask;      // single-end: n_draw
+  std::vector<uint64_t> draw_mask;      // single-end: n_draw (the device gets the low words, then -- K > 32 -- the high words)
   std::vector<uint32_t> dcls_mask;      // single-end: distinct masks among the drawing reads, in draw order
   std::vector<int32_t> dcls_start;      // ... first draw of each class (+ n_draw at the end)
   std::vector<uint32_t> dcls_tab;       // ... device class table, CLS_WORDS per class + sentinel (device.hpp)
@@ -135,7 +135,9 @@ PackedEvent pack_event(const miso_params_t &p, const FragmentDist *fd, int K, in
 // K u16 fragment-length indices (FRAG_NONE = incompatible); se_values (single-end, optional): the
 // match matrix when it holds values other than 0/1, for the header's read classes only
 PackedEvent pack_event_masks(const miso_params_t &p, const FragmentDist *fd, int K, int N,
-                             const uint32_t *masks, const uint16_t *frags, const double *se_values,
+                             const uint64_t *masks, const uint16_t *frags, const double *se_values,
                              const int *isolen, const int *noexons, const double *hyper);
+// (33 ... MISO_MAX_ISOFORMS isoforms: no read classes, work units or dense records are made -- those serve the kernels
+// for up to 32 isoforms; such an event is sampled by sampler_wave, lane k = isoform k, runtime.hip)
 
 }  // namespace miso

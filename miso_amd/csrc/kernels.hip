@@ -9,7 +9,7 @@
 // Steps 1-2 are O(K) transcendental math, step 4 is O(reads) and is the hot loop.
 //
 // Mapping used by `sampler_wave` (one wavefront = one (event, chain)):
-//   * lane k (< K) owns isoform k: psi_k, alpha_k, log psi_k, count_k.  Transcendentals run
+//   * lane k (< K <= 64) owns isoform k: psi_k, alpha_k, log psi_k, count_k.  Transcendentals run
 //     lane-parallel; the reference's left-to-right sums are reproduced with uniform-lane
 //     broadcasts (v_readlane), so every lane holds the same, reference-ordered total.
 //   * in the Gibbs step lane l owns draw quads l, l+64, ...: one Philox4x32-10 block = the four
@@ -121,7 +121,7 @@ __device__ __forceinline__ void propose(double alpha, double &alphaN, double &ps
 template <bool PE>
 __global__ __launch_bounds__(256) void sampler_wave(const KernelArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // LDS: [0, il*8) fragment probabilities (PE); then 4 x 32 ints of count scratch
+  // LDS: [0, il*8) fragment probabilities (PE); then 4 x 64 ints of count scratch
   double *lds_fp = reinterpret_cast<double *>(smem);
   const int fp_bytes = PE ? ((a.il * 8 + 15) & ~15) : 0;
   int *lds_cnt_all = reinterpret_cast<int *>(smem + fp_bytes);
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void sampler_wave(const KernelArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long slot = static_cast<long>(blockIdx.x) * 4 + wave;
   if (slot >= static_cast<long>(a.n_slots) * a.C) return;  // no block barrier below this line
-  int *lds_cnt = lds_cnt_all + wave * 32;
+  int *lds_cnt = lds_cnt_all + wave * 64;
 
   const int ev = a.slot_event[slot / a.C];
   const uint32_t chain = static_cast<uint32_t>(slot % a.C);
@@ -151,6 +151,9 @@ __global__ __launch_bounds__(256) void sampler_wave(const KernelArgs a) {
   const int base_cnt = (lane < K) ? base[lane] : 0;
 
   const uint32_t *masks = reinterpret_cast<const uint32_t *>(a.in_pool + E.off_draw);
+  // from 33 isoforms on a mask has two words: the high words follow the (quad-padded) low words (runtime.hip upload)
+  const uint32_t *masks_hi = masks + ((static_cast<size_t>(E.n_draw) + 3) & ~static_cast<size_t>(3));
+  const bool wide_masks = K > 32;
   const uint16_t *frags = reinterpret_cast<const uint16_t *>(a.in_pool + E.off_draw);
   const int32_t *sfix = reinterpret_cast<const int32_t *>(a.in_pool + E.off_sfix);
   double *samples = reinterpret_cast<double *>(a.out_pool + E.off_samples);
@@ -170,16 +173,21 @@ __global__ __launch_bounds__(256) void sampler_wave(const KernelArgs a) {
     int my_cnt = 0;  // lane k accumulates count_k (ballot path)
     int64_t acc = 0; int bad = 0;
     const bool use_lds = K > 4;
-    if (use_lds) { if (lane < 32) lds_cnt[lane] = 0; __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); }
+    if (use_lds) { lds_cnt[lane] = 0; __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); }
     for (int q0 = 0; q0 < n_quads; q0 += 64) {
       const int q = q0 + lane;
       const bool active = q < n_quads;
       miso_u32x4 u = miso_draw_block(a.seed, event_id, chain, iter, MISO_SITE_GIBBS,
                                      static_cast<uint32_t>(q));
-      uint32_t m4[4] = {0, 0, 0, 0};
+      uint64_t m4[4] = {0, 0, 0, 0};
       if (!PE && active) {
         const uint4 v = *reinterpret_cast<const uint4 *>(masks + 4 * static_cast<size_t>(q));
         m4[0] = v.x; m4[1] = v.y; m4[2] = v.z; m4[3] = v.w;
+        if (wide_masks) {
+          const uint4 h = *reinterpret_cast<const uint4 *>(masks_hi + 4 * static_cast<size_t>(q));
+          m4[0] |= static_cast<uint64_t>(h.x) << 32; m4[1] |= static_cast<uint64_t>(h.y) << 32;
+          m4[2] |= static_cast<uint64_t>(h.z) << 32; m4[3] |= static_cast<uint64_t>(h.w) << 32;
+        }
       }
       int sel[4];
 #pragma unroll
@@ -194,7 +202,7 @@ __global__ __launch_bounds__(256) void sampler_wave(const KernelArgs a) {
           if (PE) {
             const uint16_t f = live ? frags[static_cast<size_t>(r) * K + k] : FRAG_NONE;
             if (f != FRAG_NONE) { T = T + pk * lds_fp[f]; nv++; }
-          } else if (live && ((m4[j] >> k) & 1u)) { T = T + pk; nv++; }
+          } else if (live && ((m4[j] >> k) & 1ull)) { T = T + pk; nv++; }
         }
         const double rnd = miso_u01(u.v[j]) * T;
         // pass 2: first valid isoform whose cumulative weight stops the scan (miso.c:69-80)
@@ -207,7 +215,7 @@ __global__ __launch_bounds__(256) void sampler_wave(const KernelArgs a) {
             valid = f != FRAG_NONE;
             if (valid) cum = cum + pk * lds_fp[f];
           } else {
-            valid = live && ((m4[j] >> k) & 1u);
+            valid = live && ((m4[j] >> k) & 1ull);
             if (valid) cum = cum + pk;
           }
           if (valid) {
@@ -237,7 +245,7 @@ __global__ __launch_bounds__(256) void sampler_wave(const KernelArgs a) {
     }
     if (use_lds) {
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      my_cnt = (lane < 32) ? lds_cnt[lane] : 0;
+      my_cnt = lds_cnt[lane];
     }
     cnt = base_cnt + ((lane < K) ? my_cnt : 0);
     if (PE) {

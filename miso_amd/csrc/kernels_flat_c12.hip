@@ -1,7 +1,6 @@
 // sampler_flat for single-end events of the isoform-count class K <= 12 (see kernels_flat.inl)
-#include "kernels_flatl.inl"   // (includes kernels_flat.inl)
+#include "kernels_flat.inl"
 
 namespace miso {
 template __global__ void sampler_flat<12>(const KernelArgs);
-template __global__ void sampler_flatl<12>(const KernelArgs);
 }  // namespace miso

@@ -489,20 +489,22 @@ __device__ __forceinline__ void pe_quads(const uint16_t *frags, const double *ps
 //   * all of this is exact whenever rnd < T (then T > 0 and the scan cannot run past the last compatible
 //     isoform).  Anything else -- T = 0, subnormal or non-finite weights -- takes pe_pick_exact, the
 //     reference's scan as written (cold; MISO_PE_FORCE_EXACT=1 sends every read there, tests).
-__device__ __attribute__((noinline)) int pe_pick_exact(const uint16_t *rec, int K, int il2, const double *psi,
+__device__ __attribute__((noinline)) int pe_pick_exact(const uint8_t *rec8, int K, int il2, const double *psi,
                                                        const double *fp_rep, bool two, uint32_t word) {
+  // rec8[k] = the read's fragment-length index for isoform k, il2 - 2 (PE_ZERO) = incompatible: straight from the record
+  // (no per-lane copy: a K-sized array indexed by a loop counter lives in scratch memory)
   const int zero = il2 - 2;
   double T = 0.0; int nv = 0;
   for (int k = 0; k < K; k++) {
-    const int idx = rec[k];
-    if (idx - k * il2 != zero) { T = T + psi[k] * fp_rep[idx - k * il2]; nv++; }
+    const int f = rec8[k];
+    if (f != zero) { T = T + psi[k] * fp_rep[f]; nv++; }
   }
   const double rnd = miso_u01(word) * T;
   double cum = 0.0; int seen = 0, sel = -1;
   for (int k = 0; k < K; k++) {
-    const int idx = rec[k];
-    if (idx - k * il2 == zero) continue;
-    cum = cum + psi[k] * fp_rep[idx - k * il2];
+    const int f = rec8[k];
+    if (f == zero) continue;
+    cum = cum + psi[k] * fp_rep[f];
     const bool stop = two ? (seen == 0 ? (rnd < cum) : true) : !(rnd > cum);
     seen++;
     if (sel < 0 && (stop || seen == nv)) sel = k;
@@ -691,21 +693,18 @@ __device__ __forceinline__ void pe_dense(const uint32_t *fq, const double *psi, 
       for (int j = 0; j < 4; j++) {
         if (okj[j]) continue;   // the reference's scan as written
         const uint8_t *rec8 = reinterpret_cast<const uint8_t *>(fq + static_cast<size_t>(min(q, n_quads)) * ND) + j * KK;
-        uint16_t rec[KK];   // k il2 + f, the index space of pe_pick_exact and the score table
-#pragma unroll 1
-        for (int k = 0; k < KK; k++) rec[k] = static_cast<uint16_t>(k * il2 + rec8[k]);
-        const int sel = pe_pick_exact(rec, KK, il2, psi, fp_rep, ((flags >> j) & 1u) == 0, u.v[j]);
+        const int sel = pe_pick_exact(rec8, KK, il2, psi, fp_rep, ((flags >> j) & 1u) == 0, u.v[j]);
         // what the loop above did with rb = INT64_MIN: passed over the incompatible isoforms in front of the
         // first compatible one (their c is -0.0 = INT64_MIN) and took the score there
         int lead = 0;
-        while (lead < KK - 1 && rec[lead] == lead * il2 + il2 - 2) lead++;
+        while (lead < KK - 1 && rec8[lead] == il2 - 2) lead++;
 #pragma unroll
         for (int k = 0; k < KK - 1; k++) over[k] += ((k < sel) ? 1 : 0) - ((k < lead) ? 1 : 0);
-        const int32_t vx = score(rec[sel]);
+        const int32_t vx = score(static_cast<uint32_t>(sel * il2 + rec8[sel]));
         if (BADCHK) {
           if (vx == SFIX_BAD) bad = 1; else acc += vx;
         } else {
-          acc += static_cast<int64_t>(vx) - score(rec[lead]);
+          acc += static_cast<int64_t>(vx) - score(static_cast<uint32_t>(lead * il2 + rec8[lead]));
         }
         if (WRITE) { if (write_ass && 4 * q + j < n_draw) drawass[4 * q + j] = static_cast<uint8_t>(sel); }
       }

@@ -19,11 +19,9 @@
 #include "coop.hpp"
 #include "miso_binomial.h"
 
-#ifndef MISO_FLAT_LANE_MH_DEFAULT
-#define MISO_FLAT_LANE_MH_DEFAULT 0
-#endif
-
 namespace miso {
+
+extern int g_hw_queues_in_effect;   // capi.hip: GPU_MAX_HW_QUEUES as the runtime read (or will read) it, 0 = unknown
 
 template <bool PE> __global__ void sampler_wave(const KernelArgs a);
 template <int G, int MODE, int WPB> __global__ void sampler_k2(const KernelArgs a);
@@ -42,7 +40,6 @@ __global__ void summarize_kernel(const DevEvent *, const unsigned char *, int, i
 template <int G, bool PE, int KC, bool WIDE = false> __global__ void sampler_grp(const KernelArgs a);
 template <int KC> __global__ void sampler_grp_multi(const KernelArgs a);
 template <int KC> __global__ void sampler_flat(const KernelArgs a);
-template <int KC> __global__ void sampler_flatl(const KernelArgs a);   // kernels_flatl.inl: the scalar step by one wavefront per workgroup, one chain per lane
 __global__ void selftest_detmath_kernel(const double *, int, double *, double *, double *, double *);
 __global__ void selftest_philox_kernel(const uint32_t *, int, uint32_t *);
 
@@ -70,6 +67,8 @@ static inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a
 // mostly empty round starts.  Hence: the smallest supported G whose wavefront count still fills
 // the slots once, i.e. the largest G with ceil(chains / (64 / G)) <= slots; G = 1 for batches that
 // overflow anyway; never more lanes than a chain has pairs of draw quads to stride over.
+static inline int flat_wgs_for(int kc) { return kc <= 4 ? 4 : (kc == 12 ? 3 : 2); }
+
 int choose_lanes_per_chain(long chains, int max_quads, int wave_slots, int max_cpw) {
   static const int kG[] = {64, 32, 21, 16, 12, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1};
   const int cap = std::max(1, max_quads / 2);
@@ -161,7 +160,7 @@ void miso_batch::resolve_pending() {
     const size_t slot = pe ? (out_frags + K - 1) / K : o_out[i];
     frag_off[i] = slot * K;
     if (pe) out_frags = frag_off[i] + static_cast<size_t>(N) * K;
-    o_out[i + 1] = o_out[i] + N;
+    o_out[i + 1] = o_out[i] + static_cast<size_t>(N) * (!pe && K > 32 ? 2 : 1);   // single-end masks: two words per read from 33 isoforms on
     MatchEvent &m = mev[i];
     m.K = q.gene.K; m.n_reads = N;
     m.exidx_off = static_cast<int32_t>(o_xi[i]); m.ex_off = static_cast<int32_t>(o_ex[i]);
@@ -243,15 +242,18 @@ void miso_batch::resolve_pending() {
       for (int i = t; i < n; i += nthreads) {
         const Pending &q = pending[i];
         const int K = q.gene.K, N = mev[i].n_reads;
-        const uint32_t *mk = pe ? nullptr : h_masks.data() + mev[i].out_off;
+        const uint32_t *mk32 = pe ? nullptr : h_masks.data() + mev[i].out_off;
         const uint16_t *f = pe ? h_frags.data() + frag_off[i] : nullptr;
-        std::vector<uint32_t> pm;
+        std::vector<uint64_t> pm(std::max(N, 1), 0u);
         if (pe) {   // a pair's mask = the isoforms with a fragment length inside the distribution
-          pm.assign(std::max(N, 1), 0u);
           for (int r = 0; r < N; r++)
-            for (int k = 0; k < K; k++) if (f[static_cast<size_t>(r) * K + k] != FRAG_NONE) pm[r] |= 1u << k;
-          mk = pm.data();
+            for (int k = 0; k < K; k++) if (f[static_cast<size_t>(r) * K + k] != FRAG_NONE) pm[r] |= 1ull << k;
+        } else if (K > 32) {
+          for (int r = 0; r < N; r++) pm[r] = mk32[2 * r] | static_cast<uint64_t>(mk32[2 * r + 1]) << 32;
+        } else {
+          for (int r = 0; r < N; r++) pm[r] = mk32[r];
         }
+        const uint64_t *mk = pm.data();
         if (p.want_counts_trace) {
           if (pe) kept_frags[q.event].assign(f, f + static_cast<size_t>(N) * K);
           else kept_masks[q.event].assign(mk, mk + N);
@@ -293,9 +295,9 @@ void miso_batch::upload(int dev) {
     }
     d.off_consts = in_off; in_off = align_up(in_off + e.consts.size() * 8, 16);
     d.off_base = in_off; in_off = align_up(in_off + e.base_count.size() * 4, 16);
-    d.off_draw = in_off;
+    d.off_draw = in_off;   // (single-end: the masks' low words, whole quads; from 33 isoforms on the high words behind them)
     in_off = align_up(in_off + (e.paired ? e.draw_frag.size() * 2
-                                         : align_up(e.draw_mask.size(), 4) * 4), 16);
+                                         : align_up(e.draw_mask.size(), 4) * 4 * (e.K > 32 ? 2 : 1)), 16);
     d.n_dcls = static_cast<int32_t>(e.dcls_mask.size());
     d.n_units = e.n_units;
     d.max_cls = e.max_cls_size;
@@ -331,7 +333,13 @@ void miso_batch::upload(int dev) {
     std::memcpy(h_in.data() + d.off_consts, e.consts.data(), e.consts.size() * 8);
     std::memcpy(h_in.data() + d.off_base, e.base_count.data(), e.base_count.size() * 4);
     if (e.paired) std::memcpy(h_in.data() + d.off_draw, e.draw_frag.data(), e.draw_frag.size() * 2);
-    else std::memcpy(h_in.data() + d.off_draw, e.draw_mask.data(), e.draw_mask.size() * 4);
+    else {
+      uint32_t *lo = reinterpret_cast<uint32_t *>(h_in.data() + d.off_draw), *hi = lo + align_up(e.draw_mask.size(), 4);
+      for (size_t r = 0; r < e.draw_mask.size(); r++) {
+        lo[r] = static_cast<uint32_t>(e.draw_mask[r]);
+        if (e.K > 32) hi[r] = static_cast<uint32_t>(e.draw_mask[r] >> 32);
+      }
+    }
     if (!e.unit_desc.empty()) std::memcpy(h_in.data() + d.off_units, e.unit_desc.data(), e.unit_desc.size() * 4);
     if (!e.dcls_tab.empty()) {
       std::memcpy(h_in.data() + d.off_cls, e.dcls_tab.data(), e.dcls_tab.size() * 4);
@@ -349,6 +357,7 @@ void miso_batch::upload(int dev) {
     hipDeviceProp_t prop;
     HIP_OK(hipGetDeviceProperties(&prop, dev));
     wave_slots = prop.multiProcessorCount * 4 * 2;  // CUs x SIMDs x resident sampler_k2 waves
+    if (const char *env = std::getenv("MISO_WAVE_SLOTS")) wave_slots = std::max(64, std::atoi(env));   // experiments: what the planners take as resident
   }
   HIP_OK(hipStreamCreate(&stream));
   HIP_OK(hipEventCreate(&ev0));
@@ -385,7 +394,8 @@ void miso_batch::upload(int dev) {
   // beyond 384: several workgroups (coop.hpp), one per 256 lanes needed.  Never more lanes than the gene has pairs of
   // quads.  Thresholds measured: profiles/r03_pe_buckets.txt.  MISO_NO_PE_BUCKETS=1: one launch per class as before
   // (A/B, tests); MISO_PE_T_WAVE / MISO_PE_T_WIDE: the two thresholds (experiments, tests).
-  auto kc_of = [](int K) { return K <= 4 ? 4 : (K <= 8 ? 8 : (K <= 12 ? 12 : (K <= 16 ? 16 : 32))); };
+  // (64: 33 ... MISO_MAX_ISOFORMS isoforms -- sampler_wave only, lane k = isoform k; the reference has no limit, miso.c:696)
+  auto kc_of = [](int K) { return K <= 4 ? 4 : (K <= 8 ? 8 : (K <= 12 ? 12 : (K <= 16 ? 16 : (K <= 32 ? 32 : 64)))); };
   std::vector<int> bucket(n, 0);   // 0 normal, 1 at least 32 lanes, 2 a wavefront, 3 workgroup-wide (coop_n[event] workgroups)
   coop_n.assign(n, 1);
   if (p.paired && std::getenv("MISO_NO_PE_BUCKETS") == nullptr) {
@@ -637,7 +647,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
 #undef MISO_GRP_WAVE64
     } else if (G == 64) {
       const unsigned grid = static_cast<unsigned>((chains + 3) / 4);
-      const size_t lds = fp_bytes + 4 * 32 * sizeof(int);
+      const size_t lds = fp_bytes + 4 * 64 * sizeof(int);
       if (p.paired) hipLaunchKernelGGL(sampler_wave<true>, dim3(grid), dim3(256), lds, st, ka);
       else hipLaunchKernelGGL(sampler_wave<false>, dim3(grid), dim3(256), lds, st, ka);
     } else {
@@ -763,19 +773,18 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   // cost more than the read sweep they replace -- profiles/r03_collapsed.txt; it pays from ~10^4 reads per event)
   bool lane_gen = collapsed && collapsed_level >= 2 && !p.paired && n_gen > 0;
   for (const GenRun &run : gen_runs) if (run.nocls) lane_gen = false;
-  // sampler_flatl (kernels_flatl.inl): the Metropolis-Hastings step by ONE wavefront of the workgroup, one chain per lane --
-  // 4 wavefronts x nc chains <= 64 lanes.  MISO_FLAT_LANE_MH=0: sampler_flat (A/B, tests).
-  const bool flat_lmh = std::getenv("MISO_FLAT_LANE_MH") ? std::atoi(std::getenv("MISO_FLAT_LANE_MH")) != 0 : MISO_FLAT_LANE_MH_DEFAULT != 0;
   std::vector<int> flat_nc(gen_runs.size(), 0), flat_nc_max(gen_runs.size(), 0);
   for (size_t ri = 0; ri < gen_runs.size(); ri++) {
     const GenRun &run = gen_runs[ri];
     if (lane_gen) break;
-    if (p.paired || run.nocls || std::getenv("MISO_NO_FLAT") != nullptr) continue;
+    if (p.paired || run.nocls || run.kc == 64 || std::getenv("MISO_NO_FLAT") != nullptr) continue;
     const int slice = flat_layout(run.kmax, std::max(run.maxcls, 1)).bytes;
-    // workgroups per CU: 3 for K <= 4 (kernels_flat.inl's register budget allows it up to K = 8), else 2; MISO_FLAT_WGS overrides
-    const int wgs = std::getenv("MISO_FLAT_WGS") ? std::max(1, std::atoi(std::getenv("MISO_FLAT_WGS"))) : (run.kc <= 4 ? 3 : 2);   // measured: K=3 +2 %, K=4 +4 %; K=5..8 no gain
+    // workgroups per CU the chains per wavefront are sized for: kernels_flat.inl's register budgets -- 4 up to four isoforms,
+    // 3 for nine to twelve (measured round 4, profiles/r04_occupancy.txt), 2 otherwise (five to eight isoforms: the kernel
+    // allows 3, sizing for 3 gained nothing); MISO_FLAT_WGS overrides
+    const int wgs = std::getenv("MISO_FLAT_WGS") ? std::max(1, std::atoi(std::getenv("MISO_FLAT_WGS"))) : flat_wgs_for(run.kc);
     const size_t lds_wave = std::getenv("MISO_LDS_MAX_KB") ? LDS_MAX / 4 : static_cast<size_t>(160 * 1024 / (4 * wgs)) - 64;
-    const int nc_max = std::min<int>(flat_lmh ? 16 : 64, static_cast<int>(lds_wave) / slice);
+    const int nc_max = std::min<int>(64, static_cast<int>(lds_wave) / slice);
     if (nc_max < 1) continue;
     const long chains = static_cast<long>(run.count) * p.noChains;
     // the fewest rounds of resident wavefronts that nc_max allows, then the fewest chains per wavefront
@@ -788,12 +797,12 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     // K=6 69.4k / 67.5k / 72.2k / 77.2k / 68.6k, K=7 64.1k / 61.4k / 68.8k / 73.5k / 64.3k, K=8 55.8k / 57.1k /
     // 52.6k / 55.1k / 54.4k; K=5: 8 -> 93.4k, 7 -> 90.3k, 10 -> 86.8k.  (Timing the candidates on the first launch
     // was tried: a 7 % difference is inside the noise of a 200-iteration trial, the choice flipped between runs.)
-    if (run.kc == 8 && !flat_lmh) nc = std::min(nc, run.kmin >= 8 ? 6 : 8);
-    if (run.kc == 4 && run.kmin >= 4 && !flat_lmh) nc = std::min(nc, 8);   // four isoforms, descriptor loop: 8 -> 119.8k, 16 -> 116.1k, 13 -> 85.5k
+    if (run.kc == 8) nc = std::min(nc, run.kmin >= 8 ? 6 : 8);
+    if (run.kc == 4 && run.kmin >= 4) nc = std::min(nc, 8);   // four isoforms, descriptor loop: 8 -> 119.8k, 16 -> 116.1k, 13 -> 85.5k
     if (const char *env = std::getenv("MISO_FLAT_NC")) nc = std::max(1, std::min(nc_max, std::atoi(env)));
     flat_nc[ri] = nc; flat_nc_max[ri] = nc_max;
   }
-  auto flat_name = [&](const GenRun &run) { return std::string(flat_lmh ? "sampler_flatl<" : "sampler_flat<") + std::to_string(run.kc) + ">"; };
+  auto flat_name = [&](const GenRun &run) { return "sampler_flat<" + std::to_string(run.kc) + ">"; };
   // Which chains a wavefront of sampler_flat owns (kernels_flat.inl: a.wave_tab).  Uniform batches: `nc` consecutive
   // chains each.  When the batch's events differ widely in size -- the heaviest wavefront of the uniform rule would
   // carry more than twice the average wavefront's work units -- the wavefronts are packed by UNITS instead: as many
@@ -873,7 +882,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   auto launch_flat = [&](KernelArgs ka, GenRun &run, int nc, int nc_max, hipStream_t st) {
     {
       const long chains = static_cast<long>(run.count) * p.noChains;
-      const int wgs = std::getenv("MISO_FLAT_WGS") ? std::max(1, std::atoi(std::getenv("MISO_FLAT_WGS"))) : (run.kc <= 4 ? 3 : 2);
+      const int wgs = std::getenv("MISO_FLAT_WGS") ? std::max(1, std::atoi(std::getenv("MISO_FLAT_WGS"))) : flat_wgs_for(run.kc);
       flat_waves(run, nc, nc_max, std::max<long>(1, static_cast<long>(slots_for(chains)) * wgs / 2));
     }
     ka.slot_event = d_slots + n_k2 + run.first; ka.n_slots = run.count;
@@ -886,11 +895,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     const unsigned grid = static_cast<unsigned>(run.wave_tab.size() / 8);
     const size_t lds = 4 * static_cast<size_t>(run.wave_nc) * flat_layout(ka.kstride, ka.cstride).bytes;
 #define MISO_FLAT_LAUNCH(KC)                                                                            \
-  if (flat_lmh) {                                                                                       \
-    HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sampler_flatl<KC>),                      \
-                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));     \
-    hipLaunchKernelGGL((sampler_flatl<KC>), dim3(grid), dim3(256), lds, st, ka);                        \
-  } else {                                                                                              \
+  {                                                                                                     \
     HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sampler_flat<KC>),                       \
                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));     \
     hipLaunchKernelGGL((sampler_flat<KC>), dim3(grid), dim3(256), lds, st, ka);                         \
@@ -910,6 +915,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   for (size_t ri = 0; ri < gen_runs.size(); ri++) {
     GenRun &run = gen_runs[ri];
     if (lane_gen) break;
+    if (run.kc == 64) { flat_nc[ri] = 0; grp_G[ri] = 64; grp_sh[ri] = GrpShape{0, 0}; continue; }   // more than 32 isoforms: one wavefront per chain
     // sampler_flat or sampler_grp?  Measured on the batch's first launch like the lanes per chain below
     // (flat wins at every isoform count of profiles/r02_flat_vs_grp_sweep.txt but 5); a small or untuned
     // batch takes sampler_flat.
@@ -1306,7 +1312,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     return "sampler_k2<" + std::to_string(G) + (p.paired ? (wpart ? ", 2, 4>" : ", 1, 4>") : (k2_pair ? ", 0, 8>" : ", 0, 4>"));
   };
   auto k2_mix_name = [&](int G) { return "sampler_k2_mix<" + std::to_string(G + 1) + ", " + std::to_string(G) + ">"; };
-  auto flat_name = [&](const GenRun &run) { return std::string(flat_lmh ? "sampler_flatl<" : "sampler_flat<") + std::to_string(run.kc) + ">"; };
+  auto flat_name = [&](const GenRun &run) { return "sampler_flat<" + std::to_string(run.kc) + ">"; };
   for (int part = 0; part < 2; part++) {
     const bool wpart = part == 0;
     const int count = wpart ? n_k2w : n_k2 - n_k2w, k2G = wpart ? k2w_G : k2_G;
@@ -1439,8 +1445,10 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   std::vector<char> merged_into_prev(gen_runs.size(), 0);
   // (measured, 16 384 genes of 3-20 isoforms: 4 queues 290 -> 254 ms merged; 8 queues 195 ms apart, 241 ms merged --
   // the separate launches stagger the classes' starts; capi.hip asks for 8 queues)
-  const char *hwq = std::getenv("GPU_MAX_HW_QUEUES");
-  const bool merge_on = std::getenv("MISO_NO_PE_MERGE") == nullptr && (std::getenv("MISO_PE_MERGE") != nullptr || (hwq && std::atoi(hwq) < 8));
+  // (what is IN EFFECT, not what the environment says now: capi.hip's constructor records it; 0 = unknown -- the runtime was
+  // up before this library was loaded -- counts as the runtime's default of 4)
+  const int hwq = g_hw_queues_in_effect > 0 ? g_hw_queues_in_effect : 4;
+  const bool merge_on = std::getenv("MISO_NO_PE_MERGE") == nullptr && (std::getenv("MISO_PE_MERGE") != nullptr || hwq < 8);
   auto launch_gen_run = [&](size_t ri) {
     GenRun &run = gen_runs[ri];
     const int G = grp_G[ri];

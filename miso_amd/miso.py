@@ -151,7 +151,6 @@ class GenesDispatcher(object):
         if os.environ.get("MISO_TIMING"):
             print("[miso] batch files written in %.2f s" % (time.time() - t_run0))
         print("Preparing to run %d batches of jobs..." % len(batches))
-        procs = []
         jobs = []
         parts = []
         if self.compare_bam is not None:
@@ -203,14 +202,7 @@ class GenesDispatcher(object):
         # index (run_miso.py:86,100); round 1 decoded the whole file in every worker (`-p 4` on one GPU was
         # slower than `-p 1`).  MISO_DISPATCH=subprocess: fresh interpreters that decode for themselves.
         if os.environ.get("MISO_DISPATCH", "fork") == "subprocess" or not jobs:
-            env = dict(os.environ)
-            root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-            env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
-            for batch_num, cmd, log in jobs:
-                procs.append((batch_num, subprocess.Popen(cmd, stdout=open(log, "a"),
-                                                          stderr=subprocess.STDOUT, env=env), log))
-            waits = [(b, p.wait, lambda p=p: p.returncode, log) for b, p, log in procs]
-            return self._finish(waits, parts, table)
+            return self._run_subprocesses(jobs, parts, table)
         import multiprocessing
         from . import sam_utils
         try:
@@ -221,10 +213,10 @@ class GenesDispatcher(object):
                     sam_utils._PRELOADED[full] = sam_utils.Samfile(full, "rb")
         except (ImportError, OSError, RuntimeError, ValueError) as e:
             # no reader library (a partial build) or the one decode failed: the workers decode for themselves
+            # (the jobs are built; nothing is re-done and the process's environment is left alone)
             print("One decode per node not possible (%s): starting workers that read the alignment file themselves" % e)
             sam_utils._PRELOADED.clear()
-            os.environ["MISO_DISPATCH"] = "subprocess"
-            return self.run()
+            return self._run_subprocesses(jobs, parts, table)
         if os.environ.get("MISO_TIMING"):
             print("[miso] alignment file(s) decoded %.2f s after run() started" % (time.time() - t_run0))
         ctx = multiprocessing.get_context("fork")
@@ -234,6 +226,18 @@ class GenesDispatcher(object):
             p = ctx.Process(target=_forked_worker, args=(cmd[3:], log, k, len(jobs)))
             p.start()
             waits.append((batch_num, p.join, lambda p=p: p.exitcode, log))
+        return self._finish(waits, parts, table)
+
+    def _run_subprocesses(self, jobs, parts, table):
+        """One fresh interpreter per job, each decoding the alignment file itself (MISO_DISPATCH=subprocess, and the
+        fall-back when the one decode per node is not possible)."""
+        env = dict(os.environ)
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+        procs = []
+        for batch_num, cmd, log in jobs:
+            procs.append((batch_num, subprocess.Popen(cmd, stdout=open(log, "a"), stderr=subprocess.STDOUT, env=env), log))
+        waits = [(b, p.wait, lambda p=p: p.returncode, log) for b, p, log in procs]
         return self._finish(waits, parts, table)
 
     def _finish(self, waits, parts, table):

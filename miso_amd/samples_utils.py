@@ -45,13 +45,26 @@ def parse_miso_file(path):
     return os.path.basename(path)[:-len(".miso")], np.ascontiguousarray(rows[:, :K]), fields
 
 
+def _parse_or_skip(path):
+    """A file that cannot be parsed (a header without sample rows, a truncated write) costs the run that event, not the
+    directory: the reference skips what it cannot load (samples_utils.py:282-292 `Skipping ...`)."""
+    try:
+        return parse_miso_file(path)
+    except (ValueError, IndexError, OSError) as err:
+        print("Skipping %s: %s" % (os.path.basename(path), err))
+        return None
+
+
 def _load_all(paths, processes=None):
+    """Every file parsed on the host cores, in THREADS: the parsing is numpy's C code (the GIL is released where the
+    time goes) and a thread pool never forks a process that has already initialised the GPU runtime -- the caller may
+    have summarised another directory on the device a moment ago."""
     if len(paths) < 64:
-        return [parse_miso_file(p) for p in paths]
-    import multiprocessing as mp
+        return [e for e in (_parse_or_skip(p) for p in paths) if e is not None]
+    from concurrent.futures import ThreadPoolExecutor
     n = processes or max(1, len(os.sched_getaffinity(0)))
-    with mp.get_context("fork").Pool(n) as pool:
-        return pool.map(parse_miso_file, paths, chunksize=max(1, len(paths) // (8 * n)))
+    with ThreadPoolExecutor(n) as pool:
+        return [e for e in pool.map(_parse_or_skip, paths, chunksize=max(1, len(paths) // (8 * n))) if e is not None]
 
 
 def _by_sample_count(events):
@@ -87,8 +100,10 @@ def output_samples_comparison(sample1_dir, sample2_dir, output_dir, confidence_l
     f2 = {os.path.basename(p): p for p in get_samples_dir_filenames(sample2_dir)}
     common = sorted(set(f1) & set(f2))
     print("Given %d events in %s and %d in %s: %d in both" % (len(f1), sample1_dir, len(f2), sample2_dir, len(common)))
-    ev1 = _load_all([f1[c] for c in common])
-    ev2 = _load_all([f2[c] for c in common])
+    ev1 = {e[0]: e for e in _load_all([f1[c] for c in common])}
+    ev2 = {e[0]: e for e in _load_all([f2[c] for c in common])}
+    both = sorted(set(ev1) & set(ev2))                    # (a file that could not be parsed drops its event from the pairing)
+    ev1, ev2 = [ev1[n] for n in both], [ev2[n] for n in both]
     rows = []
     groups = {}
     for a, b2 in zip(ev1, ev2):

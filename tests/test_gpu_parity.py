@@ -9,6 +9,7 @@ import pytest
 
 import miso_amd
 from _libs import OrcLib
+import _problems
 from _problems import simulate_pe, simulate_se
 
 pytestmark = pytest.mark.gpu
@@ -195,6 +196,41 @@ def test_large_event_and_thirty_two_isoforms(orc):
     cpu32 = orc.miso(g32, pos32, cig32, 36, iters=60, burn=10, lag=1, chains=1, mode=OrcLib.COUNTER,
                      seed=3, event_id=1, trace=True)
     _compare(b.result(1, trace=True), cpu32, 1)
-    with pytest.raises(NotImplementedError):
-        e33, i33, *_ = simulate_se(orc, 33, 10, seed=902, exlen=60, gap=50)
-        miso_amd.Batch(36).add_event(miso_amd.Gene(e33, i33), pos32[:5], cig32[:5])
+    with pytest.raises(NotImplementedError, match="More than 64 isoforms"):
+        e65, i65 = _problems.se_gene(65, exlen=60, gap=50)
+        miso_amd.Batch(36).add_event(miso_amd.Gene(e65, i65), pos32[:5], cig32[:5])
+    with pytest.raises(NotImplementedError, match="More than 64 isoforms"):
+        miso_amd.Batch(36, device_match=True).add_event(miso_amd.Gene(e65, i65), pos32[:5], cig32[:5])
+
+
+@pytest.mark.parametrize("K,paired,device_match", [(33, False, False), (33, False, True), (48, False, True), (64, False, True),
+                                                   (64, False, False), (33, True, True), (48, True, False), (64, True, True)])
+def test_more_than_thirty_two_isoforms_bit_exact(orc, K, paired, device_match):
+    """Genes of 33 ... 64 isoforms (whole-gene mode on a real annotation has them; the reference has no limit, miso.c:696,
+    gff.c:684; rounds 1 - 3 skipped them): a read's compatibility mask has two words, the chain runs on one wavefront with
+    lane k = isoform k (sampler_wave).  Host and device matching, single- and paired-end, in a batch with smaller genes;
+    every output against the oracle's counter mode."""
+    kw = dict(iters=50, burn=10, lag=2, chains=2)
+    evs = []
+    for j, (k, n) in enumerate([(K, 400), (5, 300), (K, 90), (2, 200)]):
+        if paired:
+            exons, isoforms, g, pos, cig = simulate_pe(orc, k, n, seed=700 + j, exlen=420, gap=250)
+        else:
+            exons, isoforms, g, pos, cig = simulate_se(orc, k, n, seed=700 + j, exlen=60, gap=50)
+        evs.append((exons, isoforms, g, pos, cig))
+    b = miso_amd.Batch(36, paired=paired, mean=250.0 if paired else 0.0, var=900.0 if paired else 0.0, counts_trace=True,
+                       device_match=device_match, **kw)
+    for exons, isoforms, g, pos, cig in evs:
+        b.add_event(miso_amd.Gene(exons, isoforms), pos, cig)
+    b.run(seed=SEED, first_event_id=40)
+    assert "sampler_wave" in b.last_kernels(), b.last_kernels()
+    for i, (exons, isoforms, g, pos, cig) in enumerate(evs):
+        if paired:
+            cpu = orc.miso_paired(g, pos, cig, 36, 250.0, 900.0, mode=OrcLib.COUNTER, seed=SEED, event_id=40 + i, trace=True, **kw)
+        else:
+            cpu = orc.miso(g, pos, cig, 36, mode=OrcLib.COUNTER, seed=SEED, event_id=40 + i, trace=True, **kw)
+        assert cpu.rc == 0
+        _compare(b.result(i, trace=True), cpu, 2)
+        if device_match and i == 0:   # what the match kernel wrote for the wide gene = the oracle's match matrix
+            m, fl = b.device_match_of(0)
+            assert np.array_equal(m != 0, cpu.match != 0)

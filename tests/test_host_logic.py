@@ -156,3 +156,28 @@ def test_add_problem_rejects_fragment_lengths_outside_the_distribution():
     fl[1, 0] = -1
     m2 = match.copy(); m2[1, 0] = 0            # incompatible: its fragment length is not looked at
     assert b.add_problem(m2, [1000, 900], [3, 2], fraglen=fl) == 0
+
+
+@pytest.mark.parametrize("K,paired", [(33, False), (64, False), (40, True)])
+def test_read_classes_of_genes_with_more_than_32_isoforms(orc, ref, K, paired):
+    """Host packing with two-word compatibility masks (33 ... 64 isoforms; the reference has no limit, miso.c:696,
+    gff.c:684): the read classes the header reports equal the REAL reference's (miso.c:762, miso_paired.c:386-391 through
+    oracle/_ref), 65 isoforms are refused."""
+    from _problems import se_gene, expr_for, flat
+    exons, isoforms = se_gene(K, exlen=420 if paired else 60, gap=250 if paired else 50)
+    g = ref.gene(flat(exons), isoforms)
+    ref.rng_seed(31)
+    if paired:
+        rc, _, pos, cig = ref.simulate_paired_reads(g, expr_for(K), 300, 36, 250.0, 900.0)
+        r = ref.miso_paired(g, pos, cig, 36, 250.0, 900.0, iters=10, burn=2, lag=1, chains=1)
+    else:
+        rc, _, pos, cig = ref.simulate_reads(g, expr_for(K), 500, 36)
+        r = ref.miso(g, pos, cig, 36, iters=10, burn=2, lag=1, chains=1)
+    assert rc == 0 and r.rc == 0
+    b = miso_amd.Batch(36, paired=paired, mean=250.0 if paired else 0.0, var=900.0 if paired else 0.0)
+    i = b.add_event(miso_amd.Gene(exons, isoforms), pos, cig)
+    ct, cc = b.classes(i)
+    assert np.array_equal(ct, r.class_templates) and np.array_equal(cc, r.class_counts)
+    e65, i65 = se_gene(65, exlen=60, gap=50)
+    with pytest.raises(NotImplementedError, match="More than 64 isoforms"):
+        miso_amd.Batch(36).add_event(miso_amd.Gene(e65, i65), pos[:4], cig[:4])

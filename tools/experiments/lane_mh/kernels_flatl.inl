@@ -17,6 +17,7 @@
 // wavefronts' lanes add into its D_k.  Same arithmetic, orders, tie rules and RNG addresses: bit-identical results.
 #pragma once
 #include "kernels_flat.inl"
+#include "lane_mh.hpp"
 
 #pragma clang fp contract(off)
 
@@ -170,98 +171,28 @@ __global__ __launch_bounds__(256, KC <= 8 ? MISO_FLATL_WGS_SMALL : 2) void sampl
       if (mh && !wide) mb = smem_flat + (static_cast<size_t>(cw) * NC + csl) * L.bytes;
     }
   }
-#define MD(off) reinterpret_cast<double *>(mb + (off))
-#define MI_(off) reinterpret_cast<int *>(mb + (off))
-  int lK = 1; uint32_t lchain = 0, levid = 0;
-  double l_lg_sum = 0.0, l_lg_each = 0.0, l_covar = 0.0, l_sd = 0.0, l_sigma = 0.0;
-  double *l_samples = nullptr, *l_loglik = nullptr;
-  ChainStats *l_stats = nullptr;
-  if (mh) {
-    const int *mi = MI_(L.misc);
-    lK = mi[MI_K]; lchain = static_cast<uint32_t>(mi[MI_CHAIN]); levid = static_cast<uint32_t>(mi[MI_EVID]);
-    const DevEvent LE_ = a.events[mi[MI_EV]];
-    const double *consts = reinterpret_cast<const double *>(a.in_pool + LE_.off_consts);
-    l_lg_sum = consts[3 * lK + 0]; l_lg_each = consts[3 * lK + 1]; l_sigma = consts[3 * lK + 2]; l_sd = consts[3 * lK + 3];
-    l_covar = consts[3 * lK + 4];
-    l_samples = reinterpret_cast<double *>(a.out_pool + LE_.off_samples);
-    l_loglik = reinterpret_cast<double *>(a.out_pool + LE_.off_loglik);
-    l_stats = reinterpret_cast<ChainStats *>(a.out_pool + LE_.off_stats) + lchain;
-  }
   // the wavefront's largest isoform count (a scalar loop bound; lanes with fewer isoforms are switched off inside)
   int Kmh = 1;
   if (mh_wv) {
-    int kk = mh ? lK : 1;
+    int kk = mh ? reinterpret_cast<const int *>(mb + L.misc)[MI_K] : 1;
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) kk = max(kk, __shfl_xor(kk, o));
     Kmh = __builtin_amdgcn_readfirstlane(kk);
   }
-  double l_jac = 0.0, l_lse = 0.0;
-  uint64_t hash = 0xCBF29CE484222325ull;
-  int accepted = 0, lagCounter = 0, noS = 0;
-
-  // alpha' = alpha + sd z ; psi' = logit_inv(alpha') (miso.c:449-471, 184-241), then what both scores need of the new
-  // point and not of the counts: lp = log x, tb = lp + cst, lr = log(x_k / x_K') (miso.c:104-113, 136-138), the
-  // jacobian, the largest tb (miso.c:137-140).  SRC / DST: buffer offsets (0 = current, PR = proposal) of alpha read /
-  // everything written.  With DST = PR also the Gaussian exponents of the two proposal densities (miso.c:110-117):
-  // e1: current psi's log ratios against alpha', e2: the proposal's against alpha.
-  auto mh_propose = [&](uint32_t iter, int SRC, int DST, double &jac_out, double &max_out, double &e1, double &e2, uint32_t &accw) {
-    double *al = MD(L.alpha), *psi = MD(L.psi), *lp = MD(L.lp), *tb = MD(L.tb), *lr = MD(L.lr), *tc = MD(L.tc);
-    const double *cst = MD(L.cst);
-    miso_u32x4 b = miso_draw_block(a.seed, levid, lchain, iter, MISO_SITE_MH, 0u);
-    accw = b.v[0];   // block 0, word 0 (miso.c:870)
-    double acc = 0.0;
-    for (int j = 0; j < Kmh - 1; j++) {
-      const bool odd = (j & 1) != 0;   // normal j uses words 2 + 2j, 3 + 2j of the site: block (1 + j) / 2
-      if (odd) b = miso_draw_block(a.seed, levid, lchain, iter, MISO_SITE_MH, static_cast<uint32_t>((2 + 2 * j) >> 2));
-      if (j < lK - 1) {
-        const double z = miso_det_norm_from_unif(miso_u01(odd ? b.v[0] : b.v[2]), miso_u01(odd ? b.v[1] : b.v[3]));
-        const double an = al[SRC + j] + l_sd * z;
-        const double ex = miso_det_exp(an);
-        al[DST + j] = an; tc[j] = ex;
-        acc = acc + ex;
-      }
-    }
-    const double sumexp = acc + 1.0;
-    double sumpsi = 0.0, ltheta = 1.0, prod = 1.0;
-    for (int j = 0; j < Kmh - 1; j++) {
-      if (j < lK - 1) {
-        const double q = tc[j] / sumexp;
-        psi[DST + j] = q;
-        sumpsi = sumpsi + q; ltheta = ltheta - q; prod = prod * q;
-      }
-    }
-    psi[DST + lK - 1] = 1 - sumpsi;
-    jac_out = 1.0 / prod / ltheta;
-    double maxv = 0.0;
-    e1 = 0.0; e2 = 0.0;
-    for (int k = 0; k < Kmh; k++) {
-      if (k < lK) {
-        const double xv = psi[DST + k];
-        const double r = miso_det_log(xv);
-        const double t = r + cst[k];
-        lp[DST + k] = r; tb[DST + k] = t;
-        maxv = (k == 0 || t > maxv) ? t : maxv;
-        if (k < lK - 1) {
-          const double r2 = miso_det_log(xv / ltheta);
-          if (DST != 0) {
-            const double t1 = lr[k] - al[PR + k];
-            const double t2 = r2 - al[k];
-            e1 = e1 + (-0.5) * t1 * t1 / l_sigma;
-            e2 = e2 + (-0.5) * t2 * t2 / l_sigma;
-          }
-          lr[DST + k] = r2;
-        }
-      }
-    }
-    max_out = maxv;
+  // (lane_mh.hpp: the reference's step written out for one chain per lane; vectors AND state in the chain's slice)
+  auto mh_ctx = [&]() {
+    LaneMh c{};
+    c.mb = mb;
+    c.o = LaneMhOff{L.alpha, L.psi, L.lp, L.tb, L.lr, L.tc, L.cst, L.isc, L.hm1, L.bas, L.cnt, L.sx};
+    const int *mi = reinterpret_cast<const int *>(mb + L.misc);
+    c.PR = PR; c.lK = mh ? mi[MI_K] : 1; c.Kmh = Kmh;
+    c.seed = a.seed; c.evid = static_cast<uint32_t>(mi[MI_EVID]); c.chain = static_cast<uint32_t>(mi[MI_CHAIN]);
+    return c;
   };
-  // log-sum-exp part: sum_k exp(tb_k - maxv) (miso.c:141-149)
-  auto mh_sumexp = [&](int BUF, double maxv) {
-    const double *tb = MD(L.tb);
-    double acc = 0.0;
-    for (int k = 0; k < Kmh; k++) if (k < lK) acc = acc + miso_det_exp(tb[BUF + k] - maxv);
-    return acc;
-  };
+  int lagCounter = 0, noS = 0;
+#ifdef MISO_K2_PROFILE   // per-phase cycles of the Metropolis-Hastings wavefront (tools/phase_prof_flat.py): MH, thresholds, read loop + resolve, all
+  uint64_t fp_mh = 0, fp_thr = 0, fp_loop = 0, fp_all = 0;
+#endif
 
   auto count_of = [&](int s, int k) { return FI(s, L.bas)[k] + FI(s, L.cnt)[k]; };
   const float inv_k = 1.0f / static_cast<float>(ks), inv_cs = 1.0f / static_cast<float>(max(cs, 1));
@@ -313,6 +244,7 @@ __global__ __launch_bounds__(256, KC <= 8 ? MISO_FLATL_WGS_SMALL : 2) void sampl
   auto gibbs = [&](uint32_t iter) {
     // thresholds: one lane per (chain, class); a workgroup-wide chain's four wavefronts each compute the same rows
     // (so that each knows `slow` by itself) and write the same words
+    FPROF_T(g0);
     bool slow = false;
     FLAT_BEGIN(cs, inv_cs)
       const int *mi = FI(s, L.misc);
@@ -351,6 +283,8 @@ __global__ __launch_bounds__(256, KC <= 8 ? MISO_FLATL_WGS_SMALL : 2) void sampl
       }
     FLAT_END
     if (wide) __syncthreads(); else fsync();
+    FPROF_T(g1);
+    FPROF_ADD(fp_thr, g0, g1);
     if (__any(slow)) {   // a non-final threshold of 2^32 cannot be held in 32 bits: direct path this time
       if (writes) {
         FLAT_BEGIN(ks, inv_k)
@@ -394,14 +328,16 @@ __global__ __launch_bounds__(256, KC <= 8 ? MISO_FLATL_WGS_SMALL : 2) void sampl
         if (on) { FI(s, L.dl)[j] = 0; if (j == 0) for (int x = ks; x <= trow; x++) FI(s, L.dl)[x] = 0; }
       FLAT_END
     }
+    FPROF_T(g2);
+    FPROF_ADD(fp_loop, g1, g2);
     __syncthreads();
   };
 
   // ---- initial state: miso.c:834 (alpha + sd z in place), cached logs, log-sum-exp, miso.c:841 ----
   if (mh) {
-    double maxv, e1, e2; uint32_t accw;
-    mh_propose(MISO_ITER_INIT, 0, 0, l_jac, maxv, e1, e2, accw);
-    l_lse = miso_det_log(mh_sumexp(0, maxv)) + maxv;
+    LaneMh c = mh_ctx();
+    const DevEvent LE_ = a.events[reinterpret_cast<const int *>(mb + L.misc)[MI_EV]];
+    lane_mh_init(c, reinterpret_cast<const double *>(a.in_pool + LE_.off_consts) + 3 * c.lK);
   }
   __syncthreads();
   gibbs(MISO_ITER_INIT);
@@ -419,70 +355,35 @@ __global__ __launch_bounds__(256, KC <= 8 ? MISO_FLATL_WGS_SMALL : 2) void sampl
       FLAT_END
     }
     const bool rec = m >= a.B && lagCounter == a.lag - 1;
+    FPROF_T(m0);
     if (mh) {
-      double jacN, maxN, e1, e2; uint32_t accw;
-      mh_propose(static_cast<uint32_t>(m), 0, PR, jacN, maxN, e1, e2, accw);                 // miso.c:449-471
-      const double sumtc = mh_sumexp(PR, maxN);
-      const double x1 = miso_det_exp(e1), x2 = miso_det_exp(e2);
-      const double lseN = miso_det_log(sumtc) + maxN;
-      const double ptoCS = miso_det_log(l_covar * l_jac * x1);                               // miso.c:97-122: theta = psi,  mu = alpha'
-      const double ctoPS = miso_det_log(l_covar * jacN * x2);                                //                theta = psi', mu = alpha
-      // joint log score of the proposal ([0]) and of the current point ([1]) for the current counts (miso.c:243-307):
-      // rp / ap = the two count-weighted sums, pq = the Dirichlet part; the counts' hash on the way
-      double rp[2] = {0.0, 0.0}, ap[2] = {0.0, 0.0}, pq[2] = {0.0, 0.0};
-      {
-        const double *isc = MD(L.isc), *hm1 = MD(L.hm1), *lp = MD(L.lp), *tb = MD(L.tb);
-        const int *bas = MI_(L.bas), *cnt = MI_(L.cnt);
-        for (int k = 0; k < Kmh; k++) {
-          if (k < lK) {
-            const int cn = bas[k] + cnt[k];
-            hash = (hash ^ static_cast<uint32_t>(cn)) * 0x100000001B3ull;
-            const bool nz = cn != 0;
-            const double ck = static_cast<double>(cn), is = isc[k], hm = hm1[k];
-            rp[0] = nz ? rp[0] + ck * is : rp[0];
-            ap[0] = nz ? ap[0] + ck * (tb[PR + k] - lseN) : ap[0];
-            pq[0] = pq[0] + hm * lp[PR + k];
-            rp[1] = nz ? rp[1] + ck * is : rp[1];
-            ap[1] = nz ? ap[1] + ck * (tb[k] - l_lse) : ap[1];
-            pq[1] = pq[1] + hm * lp[k];
-          }
-        }
-      }
-      double pj[2];
-#pragma unroll
-      for (int which = 0; which < 2; which++) {
-        double psiProb = pq[which];
-        psiProb = psiProb + l_lg_sum;
-        psiProb = psiProb - l_lg_each;
-        pj[which] = rp[which] + ap[which] + psiProb;
-      }
-      const double pp = pj[0], pc = pj[1];
-      const double acceptP = (m > 0) ? miso_det_exp(pp + ptoCS - (pc + ctoPS)) : miso_det_exp(pp - pc);   // miso.c:493-552, 865
-      const bool acc = (acceptP >= 1) || (miso_u01(accw) < acceptP);                                       // miso.c:869-880
-      double cJS = pc;
-      if (acc) {   // the proposal and its cached logs become the current state
-        double *al = MD(L.alpha), *psi = MD(L.psi), *lp = MD(L.lp), *tb = MD(L.tb), *lr = MD(L.lr);
-        for (int k = 0; k < lK; k++) {
-          psi[k] = psi[PR + k]; al[k] = al[PR + k]; lp[k] = lp[PR + k]; tb[k] = tb[PR + k]; lr[k] = lr[PR + k];
-        }
-        l_jac = jacN; l_lse = lseN; cJS = pp; accepted++;
-      }
+      LaneMh c = mh_ctx();
+      const double cJS = lane_mh_step<false>(c, m, 0.0);   // miso.c:449-552, 243-307, 869-880
       if (rec) {   // miso.c:882-893
-        const double *psi = MD(L.psi);
-        const size_t col = static_cast<size_t>(noS) + lchain;
-        for (int k = 0; k < lK; k++) l_samples[col * lK + k] = psi[k];
-        l_loglik[col] = cJS;
+        const DevEvent LE_ = a.events[reinterpret_cast<const int *>(mb + L.misc)[MI_EV]];
+        double *l_samples = reinterpret_cast<double *>(a.out_pool + LE_.off_samples);
+        const size_t col = static_cast<size_t>(noS) + c.chain;
+        const LaneVec<double> psi = c.D(c.o.psi);
+        for (int k = 0; k < c.lK; k++) l_samples[col * c.lK + k] = psi[k];
+        reinterpret_cast<double *>(a.out_pool + LE_.off_loglik)[col] = cJS;
       }
     }
     if (m >= a.B) {
       if (rec) { noS += a.C; lagCounter = 0; } else lagCounter++;
     }
+    FPROF_T(m1);
+    FPROF_ADD(fp_mh, m0, m1);
     __syncthreads();
     gibbs(static_cast<uint32_t>(m));
+    FPROF_T(m2);
+    FPROF_ADD(fp_all, m0, m2);
   }
   if (mh) {
-    const int *bas = MI_(L.bas), *cnt = MI_(L.cnt);
-    for (int k = 0; k < lK; k++) hash = (hash ^ static_cast<uint32_t>(bas[k] + cnt[k])) * 0x100000001B3ull;
+    LaneMh c = mh_ctx();
+    lane_mh_begin(c);
+    const LaneVec<int> bas = c.I(c.o.bas), cnt = c.I(c.o.cnt);
+    for (int k = 0; k < c.lK; k++) c.hash = (c.hash ^ static_cast<uint32_t>(bas[k] + cnt[k])) * 0x100000001B3ull;
+    lane_mh_end(c);
   }
   if (tracing && writes) {
     FLAT_BEGIN(ks, inv_k)
@@ -499,14 +400,22 @@ __global__ __launch_bounds__(256, KC <= 8 ? MISO_FLATL_WGS_SMALL : 2) void sampl
     if (FI(s, L.misc)[MI_CHAIN] == 0 && writes)
       direct_chain(s, a.M > 0 ? static_cast<uint32_t>(a.M - 1) : MISO_ITER_INIT, false, true);
   if (mh) {
-    l_stats->counts_hash = hash; l_stats->accepted = accepted;
+    LaneMh c = mh_ctx();
+    lane_mh_begin(c);
+    const DevEvent LE_ = a.events[reinterpret_cast<const int *>(mb + L.misc)[MI_EV]];
+#ifdef MISO_K2_PROFILE
+    if (c.chain == 0 && a.M > 8) {
+      double *l_loglik = reinterpret_cast<double *>(a.out_pool + LE_.off_loglik);
+      l_loglik[0] = static_cast<double>(fp_mh); l_loglik[1] = static_cast<double>(fp_thr); l_loglik[2] = static_cast<double>(fp_loop); l_loglik[3] = static_cast<double>(fp_all);
+    }
+#endif
+    ChainStats *l_stats = reinterpret_cast<ChainStats *>(a.out_pool + LE_.off_stats) + c.chain;
+    l_stats->counts_hash = c.hash; l_stats->accepted = c.accepted;
     l_stats->hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4);
   }
 #undef FD
 #undef FI
 #undef FU
-#undef MD
-#undef MI_
 #undef FLAT_BEGIN
 #undef FLAT_END
 }

@@ -1,0 +1,7 @@
+// sampler_pel for paired-end genes of the isoform-count class K <= 12 (see kernels_pel.inl)
+#include "kernels_pel.inl"
+
+namespace miso {
+template __global__ void sampler_pel<16, 12>(const KernelArgs);
+template __global__ void sampler_pel<32, 12>(const KernelArgs);
+}  // namespace miso
