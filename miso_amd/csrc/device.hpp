@@ -97,6 +97,7 @@ struct KernelArgs {
                             // probability table carries the two extra entries PE_ZERO, PE_ONE (0 = the quad loops of pe_quads)
   int32_t pe_force_exact;   // tests: every read through pe_dense's exact (cold) scan
   int32_t flat_desc;        // sampler_flat: read loop over the unit descriptors (flat_units_desc), 0 = the walking loop
+  int32_t flat_thr_skip;    // sampler_flat: thresholds only for the chains whose psi changed in the last Metropolis-Hastings step
   int32_t mix_blocks;       // sampler_k2_mix<GA, GB>: the first mix_blocks workgroups run the first mix_slots events
   int32_t mix_slots;        // with GA lanes per chain, the rest the remaining events with GB (runtime.hip)
   const int32_t *wave_tab;  // sampler_flat: two words per wavefront: first chain of the launch's list, chains | FLAT_WIDE (runtime.hip)
@@ -158,7 +159,7 @@ MISO_DEVHOST inline int grp_slice_bytes(int ks, int cs, int ts) {
 }
 // ---- sampler_flat (kernels_flat.inl): one chain's LDS slice, byte offsets.  ks = isoform stride
 // (the launch's largest K), cs = most drawing-read classes of any event of the launch. ----
-constexpr int FLAT_SX = 24;     // per-chain double scalars (16 of the Metropolis-Hastings passes + the leader lane's state between iterations)
+constexpr int FLAT_SX = 16;     // per-chain double scalars
 constexpr int FLAT_MISC = 24;   // per-chain int scalars
 struct FlatLayout {
   int psi, alpha, lp, tb, lr;   // double[2][ks]: buffer `parity` = current state and its cached logs, the other = proposal

@@ -59,17 +59,12 @@ __device__ __forceinline__ void fsync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_RE
 
 // indices into a chain's double scalars (FlatLayout::sx) ...
 enum { SX_SUMEXP = 0, SX_LTHETA, SX_MAXV, SX_E1, SX_E2, SX_X1, SX_X2, SX_LA0, SX_LA1, SX_LA2, SX_LR0, SX_LR1,
-       SX_LR2, SX_SD, SX_SIGMA, SX_COVAR,
-       // what the chain's leader lane keeps from one iteration to the next: HERE, not in registers -- everything live across
-       // the read loop's call was spilled to scratch memory and fetched back every iteration (35 VGPRs, 144 bytes per lane,
-       // the 283 GB of "HBM traffic" round 3's profile showed for 11 GB of compulsory bytes)
-       SX_JAC, SX_LSE, SX_LGSUM, SX_LGEACH, SX_HASH, SX_ACCEPTED, SX_LLOFF, SX_SPARE };
-static_assert(SX_SPARE < FLAT_SX, "FlatLayout::sx");
+       SX_LR2, SX_SD, SX_SIGMA, SX_COVAR };
 // ... and int scalars (FlatLayout::misc)
 enum { MI_K = 0, MI_NDRAW, MI_NCLS, MI_NUNITS, MI_EVID, MI_CHAIN, MI_ACC, MI_ACCW, MI_C3K1, MI_P1LO, MI_P1HIK0,
        MI_EV, MI_SAMP_LO, MI_SAMP_HI, MI_TRACE_LO, MI_TRACE_HI, MI_USTART, MI_NEXT, MI_LANE0, MI_LANES, MI_DESC,
-       MI_SLOW };   // MI_SLOW: one of the chain's current thresholds does not fit 32 bits (the direct path until psi changes)
-static_assert(MI_SLOW < FLAT_MISC, "FlatLayout::misc");
+       MI_SLOW, MI_NWHOLE };   // MI_NWHOLE: the chain's first so many unit descriptors are whole Philox blocks (host.cpp); MI_SLOW: one of the chain's current thresholds does not fit 32 bits (the direct path until psi changes)
+static_assert(MI_NWHOLE < FLAT_MISC, "FlatLayout::misc");
 
 // The reference's draw compares rnd = fl(fl(u 2^-32) T) with a cumulative weight c: `rnd < c` when two
 // isoforms are compatible, `!(rnd > c)` otherwise (miso.c:69-79).  Both are monotone in the 32-bit word
@@ -138,11 +133,8 @@ struct FlatUnitsArgs {
   int slice, off_ctab, off_thr, off_misc, off_dl, trow, trips;
   uint32_t iter, k0, k1;
 };
-#ifndef MISO_FLAT_UNITS_ATTR
-#define MISO_FLAT_UNITS_ATTR __attribute__((noinline))
-#endif
 template <int TW>
-__device__ MISO_FLAT_UNITS_ATTR void flat_units(const FlatUnitsArgs A, int s0, int c0, int i0, int n_mine) {
+__device__ __attribute__((noinline)) void flat_units(const FlatUnitsArgs A, int s0, int c0, int i0, int n_mine) {
   if (A.trips == 0) return;
   unsigned char *wbase = smem_flat + A.woff;
   const int slice = __builtin_amdgcn_readfirstlane(A.slice), off_ctab = __builtin_amdgcn_readfirstlane(A.off_ctab),
@@ -255,7 +247,7 @@ __device__ MISO_FLAT_UNITS_ATTR void flat_units(const FlatUnitsArgs A, int s0, i
 #define MISO_FLAT_DESC_UQ 2   // units per lane and trip
 #endif
 template <int TW>
-__device__ MISO_FLAT_UNITS_ATTR void flat_units_desc(const FlatUnitsArgs A, const uint32_t *pool_words, int ms, int r, int g) {
+__device__ __attribute__((noinline)) void flat_units_desc(const FlatUnitsArgs A, const uint32_t *pool_words, int ms, int r, int g) {
   if (A.trips == 0 || g <= 0) return;
   unsigned char *wbase = smem_flat + A.woff;
   const int slice = __builtin_amdgcn_readfirstlane(A.slice), off_thr = __builtin_amdgcn_readfirstlane(A.off_thr),
@@ -278,6 +270,7 @@ __device__ MISO_FLAT_UNITS_ATTR void flat_units_desc(const FlatUnitsArgs A, cons
   uint32_t dn[UQ];   // the next trip's descriptors (0 = no unit: no word counts)
 #pragma unroll
   for (int b = 0; b < UQ; b++) { const int u = r + b * g; dn[b] = (u < nu) ? desc[u] : 0u; }
+  const int nwhole = mi[MI_NWHOLE];
   for (int u0 = r; __any(u0 < nu); u0 += UQ * g) {
     uint32_t d[UQ];
 #pragma unroll
@@ -288,15 +281,23 @@ __device__ MISO_FLAT_UNITS_ATTR void flat_units_desc(const FlatUnitsArgs A, cons
                                            //  address-space-1 pointer 87.1k; that plus a clamped, branch-free load 91.1k)
     }
     uint32_t T[UQ][TW], w[UQ][4];
+    // the trip's units are all WHOLE Philox blocks for every lane of the wavefront (the chains' descriptors are ordered:
+    // whole units first): no word masks -- two instructions per word saved, ~8 % of the trip at five isoforms
+    const bool whole = __all(u0 + (UQ - 1) * g < nwhole);
 #pragma unroll
     for (int b = 0; b < UQ; b++) {
       const uint32_t *row = reinterpret_cast<const uint32_t *>(thr + ((d[b] >> 4) & 0xFFu) * trow4);
 #pragma unroll
       for (int j = 0; j < TW; j++) T[b][j] = row[j];
       const miso_u32x4 u = philox_gibbs<true>(rng, d[b] >> 12, n0r0);
-      const int nm = static_cast<int>(~d[b]);   // a word outside the class becomes 0xFFFFFFFF (never below a 32-bit threshold)
+      if (whole) {
 #pragma unroll
-      for (int x = 0; x < 4; x++) w[b][x] = u.v[x] | static_cast<uint32_t>(__builtin_amdgcn_sbfe(nm, x, 1));
+        for (int x = 0; x < 4; x++) w[b][x] = u.v[x];
+      } else {
+        const int nm = static_cast<int>(~d[b]);   // a word outside the class becomes 0xFFFFFFFF (never below a 32-bit threshold)
+#pragma unroll
+        for (int x = 0; x < 4; x++) w[b][x] = u.v[x] | static_cast<uint32_t>(__builtin_amdgcn_sbfe(nm, x, 1));
+      }
     }
 #pragma unroll
     for (int j = 0; j < TW; j++) {
@@ -312,12 +313,12 @@ __device__ MISO_FLAT_UNITS_ATTR void flat_units_desc(const FlatUnitsArgs A, cons
 }  // namespace
 
 // Workgroups per CU the register budget is set for (runtime.hip sizes the chains per wavefront by the same rule).  Measured
-// round 4, 40 000 events (profiles/r04_occupancy.txt): up to four isoforms FOUR workgroups (128 registers) beat three --
-// K = 3 128.5 k -> 135.5 k events/s -- while five to eight isoforms spill at 128 and gain nothing (94.1 k -> 93.3 k: three,
-// 168 registers); nine to twelve isoforms THREE instead of two (206 -> 168 registers, no spills): K = 10 47.7 k -> 49.1 k
-// with five chains per wavefront instead of seven; beyond twelve two.
+// round 4, 40 000 events (profiles/r04_occupancy.txt): nine to twelve isoforms THREE instead of two (206 -> 168 registers, no
+// spills): K = 10 47.7 k -> 49.1 k events/s with five chains per wavefront instead of seven; beyond twelve two.  Up to
+// eight isoforms three as before: FOUR (128 registers) gave K = 3 128.5 k -> 135.5 k but K = 4 115.7 k -> 112.4 k (one
+// kernel serves both) and nothing at five to eight, where 128 registers spill (94.1 k -> 93.3 k).
 #ifndef MISO_FLAT_WGS_4
-#define MISO_FLAT_WGS_4 4
+#define MISO_FLAT_WGS_4 3
 #endif
 #ifndef MISO_FLAT_WGS_SMALL
 #define MISO_FLAT_WGS_SMALL 3
@@ -391,6 +392,7 @@ __global__ __launch_bounds__(256, KC <= 4 ? MISO_FLAT_WGS_4 : (KC <= 8 ? MISO_FL
       mi[MI_ACC] = 1; mi[MI_SLOW] = 0;   // (the first Gibbs step computes every chain's thresholds)
       mi[MI_ACCW] = 0; mi[MI_EV] = ev; mi[MI_NEXT] = -1;
       mi[MI_DESC] = static_cast<int>(static_cast<uint32_t>(E.off_units >> 2));   // dword offset of the event's unit descriptors in the input pool
+      mi[MI_NWHOLE] = E.n_units > 0 ? static_cast<int>(reinterpret_cast<const uint32_t *>(a.in_pool + E.off_units)[E.n_units]) : 0;
       mi[MI_LANE0] = 0; mi[MI_LANES] = 0;
       const GibbsRng g = gibbs_rng_init(a.seed, event_id, chain);
       mi[MI_C3K1] = static_cast<int>(g.c3k1); mi[MI_P1LO] = static_cast<int>(g.p1lo);
@@ -475,22 +477,16 @@ __global__ __launch_bounds__(256, KC <= 4 ? MISO_FLAT_WGS_4 : (KC <= 8 ? MISO_FL
   const bool leader = lane < ncw;
   const int ls = leader ? lane : 0;
   const int lK = FI(ls, L.misc)[MI_K];
-  bool tracing = false;
+  const DevEvent LE_ = a.events[FI(ls, L.misc)[MI_EV]];
+  const uint32_t lchain = static_cast<uint32_t>(FI(ls, L.misc)[MI_CHAIN]);
+  double l_lg_sum = 0.0, l_lg_each = 0.0, l_covar = 0.0;
   {
-    const DevEvent LE_ = a.events[FI(ls, L.misc)[MI_EV]];
     const double *consts = reinterpret_cast<const double *>(a.in_pool + LE_.off_consts);
-    tracing = LE_.off_trace != NO_TRACE;
-    if (leader) {
-      double *sx = FD(ls, L.sx);
-      sx[SX_LGSUM] = consts[3 * lK + 0]; sx[SX_LGEACH] = consts[3 * lK + 1];
-      sx[SX_JAC] = 0.0; sx[SX_LSE] = 0.0;
-      *reinterpret_cast<uint64_t *>(&sx[SX_HASH]) = 0xCBF29CE484222325ull;
-      *reinterpret_cast<int *>(&sx[SX_ACCEPTED]) = 0;
-      *reinterpret_cast<uint64_t *>(&sx[SX_LLOFF]) = LE_.off_loglik;
-    }
+    l_lg_sum = consts[3 * lK + 0]; l_lg_each = consts[3 * lK + 1]; l_covar = consts[3 * lK + 4];
   }
-  tracing = __any(tracing);   // all events of a batch trace or none
-  int lagCounter = 0, noS = 0;
+  double l_jac = 0.0, l_lse = 0.0;   // of the chain's current psi
+  uint64_t hash = 0xCBF29CE484222325ull;
+  int accepted = 0, lagCounter = 0, noS = 0;
   const float inv_k1 = 1.0f / static_cast<float>(tws), inv_k = 1.0f / static_cast<float>(ks),
               inv_2k = 1.0f / static_cast<float>(2 * ks - 1), inv_k2 = 1.0f / static_cast<float>(ks + 2),
               inv_cs = 1.0f / static_cast<float>(max(cs, 1));
@@ -652,7 +648,9 @@ __global__ __launch_bounds__(256, KC <= 4 ? MISO_FLAT_WGS_4 : (KC <= 8 ? MISO_FL
     // (measured acceptance rates 0.32 - 0.47 / 0.55 / 0.68 at K = 3 - 5 / 10 / 16): a chain that rejected its proposal keeps
     // its rows -- and its MI_SLOW flag -- from the step before.  The chains that accepted are numbered through a bit mask.
     uint64_t accmask = 0;
-    for (int s = 0; s < ncw; s++) accmask |= static_cast<uint64_t>(FI(s, L.misc)[MI_ACC] != 0) << s;
+    // (the host turns it on where the thresholds weigh enough -- from six isoforms on and for small events, a.flat_thr_skip,
+    // runtime.hip launch_flat; measured: + 4.5 ... 6.4 % there, - 1 ... 2 % at three to five isoforms x 1000 reads)
+    for (int s = 0; s < ncw; s++) accmask |= static_cast<uint64_t>(!a.flat_thr_skip || FI(s, L.misc)[MI_ACC] != 0) << s;
     const int n_acc = __popcll(accmask);
 #ifdef MISO_FLAT_SKIP_THR
     if (a.M < 0)
@@ -662,9 +660,12 @@ __global__ __launch_bounds__(256, KC <= 4 ? MISO_FLAT_WGS_4 : (KC <= 8 ? MISO_FL
       const bool on = idx_ < n_acc * cs;
       const int ai = on ? static_cast<int>((static_cast<float>(idx_) + 0.5f) * inv_cs) : 0;
       const int j = on ? idx_ - ai * cs : 0;
-      uint64_t rest = accmask;
-      for (int t = 0; t < ai; t++) rest &= rest - 1;   // the ai-th chain that accepted
-      const int s = on ? static_cast<int>(__builtin_ctzll(rest | (1ull << 63))) : 0;
+      int s = on ? ai : 0;
+      if (a.flat_thr_skip) {   // the ai-th chain that accepted
+        uint64_t rest = accmask;
+        for (int t = 0; t < ai; t++) rest &= rest - 1;
+        s = on ? static_cast<int>(__builtin_ctzll(rest | (1ull << 63))) : 0;
+      }
       const int *mi = FI(s, L.misc);
       const int K = mi[MI_K], ncls = mi[MI_NCLS];
       const uint32_t m = FU(s, L.ctab)[CLS_WORDS * j];
@@ -767,11 +768,7 @@ __global__ __launch_bounds__(256, KC <= 4 ? MISO_FLAT_WGS_4 : (KC <= 8 ? MISO_FL
   };
 
   // ---- initial state: miso.c:834 (alpha + sd z in place), cached logs, log-sum-exp, miso.c:841 ----
-  {
-    double jac0 = 0.0;
-    propose_and_logs(MISO_ITER_INIT, 0, 0, jac0);
-    if (leader) FD(ls, L.sx)[SX_JAC] = jac0;
-  }
+  propose_and_logs(MISO_ITER_INIT, 0, 0, l_jac);
   {
     const double maxv = leader_max(0);
     fsync();
@@ -787,12 +784,13 @@ __global__ __launch_bounds__(256, KC <= 4 ? MISO_FLAT_WGS_4 : (KC <= 8 ? MISO_FL
         LOADC(tc, FD(ls, L.tc))
         EACH(k) acc = (k < lK) ? acc + tc[i_] : acc;
       CHUNKS_END
-      FD(ls, L.sx)[SX_LSE] = miso_det_log(acc) + maxv;
+      l_lse = miso_det_log(acc) + maxv;
     }
     fsync();
   }
   gibbs(MISO_ITER_INIT);
 
+  const bool tracing = __any(LE_.off_trace != NO_TRACE);   // all events of a batch trace or none
   for (int m = 0; m < a.M; m++) {
     // this iteration's view of the counts: the leader's registers (hash, both joint scores)
     int cn[KC];
@@ -800,12 +798,9 @@ __global__ __launch_bounds__(256, KC <= 4 ? MISO_FLAT_WGS_4 : (KC <= 8 ? MISO_FL
       const int *bas = FI(ls, L.bas), *cnt = FI(ls, L.cnt);
 #pragma unroll
       for (int k = 0; k < KC; k++) cn[k] = (k < Kw) ? bas[k] + cnt[k] : 0;
-      uint64_t *hp = reinterpret_cast<uint64_t *>(&FD(ls, L.sx)[SX_HASH]);
-      uint64_t hash = *hp;
 #pragma unroll
       for (int k = 0; k < KC; k++)
         if (k < Kw) hash = (k < lK) ? (hash ^ static_cast<uint32_t>(cn[k])) * 0x100000001B3ull : hash;
-      *hp = hash;
     }
     if (tracing) {
       FLAT_BEGIN(ks, inv_k)
@@ -850,8 +845,7 @@ __global__ __launch_bounds__(256, KC <= 4 ? MISO_FLAT_WGS_4 : (KC <= 8 ? MISO_FL
         LOADC(tc, FD(ls, L.tc))
         EACH(k) sumtc = (k < lK) ? sumtc + tc[i_] : sumtc;
       CHUNKS_END
-      const double l_covar = sx[SX_COVAR];
-      sx[SX_LA0] = sumtc; sx[SX_LA1] = l_covar * sx[SX_JAC] * x1; sx[SX_LA2] = l_covar * jacN * x2;
+      sx[SX_LA0] = sumtc; sx[SX_LA1] = l_covar * l_jac * x1; sx[SX_LA2] = l_covar * jacN * x2;
     }
     fsync();
     for (int base_ = 0; base_ < ncw * 3; base_ += 64) {                                // pass 5: log
@@ -870,7 +864,7 @@ __global__ __launch_bounds__(256, KC <= 4 ? MISO_FLAT_WGS_4 : (KC <= 8 ? MISO_FL
       const uint32_t accw = static_cast<uint32_t>(FI(ls, L.misc)[MI_ACCW]);
       // both scores in one walk: rp / ap = the two count-weighted sums, pq = the Dirichlet part; [0] proposal, [1] current
       double rp[2] = {0.0, 0.0}, ap[2] = {0.0, 0.0}, pq[2] = {0.0, 0.0};
-      const double lse2[2] = {lseN, sx[SX_LSE]};
+      const double lse2[2] = {lseN, l_lse};
       CHUNKS_BEGIN
         LOADC(isc, FD(ls, L.isc))
         LOADC(hm1, FD(ls, L.hm1))
@@ -893,8 +887,8 @@ __global__ __launch_bounds__(256, KC <= 4 ? MISO_FLAT_WGS_4 : (KC <= 8 ? MISO_FL
 #pragma unroll
       for (int which = 0; which < 2; which++) {
         double psiProb = pq[which];
-        psiProb = psiProb + sx[SX_LGSUM];
-        psiProb = psiProb - sx[SX_LGEACH];
+        psiProb = psiProb + l_lg_sum;
+        psiProb = psiProb - l_lg_each;
         pj[which] = rp[which] + ap[which] + psiProb;
       }
       const double pp = pj[0], pc = pj[1];
@@ -903,11 +897,7 @@ __global__ __launch_bounds__(256, KC <= 4 ? MISO_FLAT_WGS_4 : (KC <= 8 ? MISO_FL
       cJS = pc;
       FI(ls, L.misc)[MI_ACC] = acc ? 1 : 0;
       if (acc) FI(ls, L.misc)[MI_SLOW] = 0;   // new psi: the next Gibbs step recomputes this chain's thresholds
-      if (acc) {
-        double *sxw = FD(ls, L.sx);
-        sxw[SX_JAC] = jacN; sxw[SX_LSE] = lseN; cJS = pp;
-        *reinterpret_cast<int *>(&sxw[SX_ACCEPTED]) += 1;
-      }
+      if (acc) { l_jac = jacN; l_lse = lseN; cJS = pp; accepted++; }
     }
     fsync();
     // accepted: the proposal and its cached logs become the current state; the same lanes record the
@@ -933,10 +923,7 @@ __global__ __launch_bounds__(256, KC <= 4 ? MISO_FLAT_WGS_4 : (KC <= 8 ? MISO_FL
     FPROF_ADD(fp_mh, m0, m1);
     if (m >= a.B) {
       if (rec) {
-        if (leader && writes) {
-          const uint64_t lo = *reinterpret_cast<const uint64_t *>(&FD(ls, L.sx)[SX_LLOFF]);
-          reinterpret_cast<double *>(a.out_pool + lo)[static_cast<size_t>(noS) + static_cast<uint32_t>(FI(ls, L.misc)[MI_CHAIN])] = cJS;
-        }
+        if (leader && writes) reinterpret_cast<double *>(a.out_pool + LE_.off_loglik)[static_cast<size_t>(noS) + lchain] = cJS;
         noS += a.C;
         lagCounter = 0;
       } else {
@@ -945,13 +932,9 @@ __global__ __launch_bounds__(256, KC <= 4 ? MISO_FLAT_WGS_4 : (KC <= 8 ? MISO_FL
     }
     gibbs(static_cast<uint32_t>(m));
   }
-  uint64_t hash = 0; int accepted = 0;
-  if (leader) {
-    hash = *reinterpret_cast<const uint64_t *>(&FD(ls, L.sx)[SX_HASH]);
-    accepted = *reinterpret_cast<const int *>(&FD(ls, L.sx)[SX_ACCEPTED]);
+  if (leader)
     for (int k = 0; k < Kw; k++)
       if (k < lK) hash = (hash ^ static_cast<uint32_t>(count_of(ls, k))) * 0x100000001B3ull;
-  }
   if (tracing) {
     FLAT_BEGIN(ks, inv_k)
       const int *mi = FI(s, L.misc);
@@ -967,18 +950,12 @@ __global__ __launch_bounds__(256, KC <= 4 ? MISO_FLAT_WGS_4 : (KC <= 8 ? MISO_FL
     if (FI(s, L.misc)[MI_CHAIN] == 0 && writes)
       direct_chain(s, a.M > 0 ? static_cast<uint32_t>(a.M - 1) : MISO_ITER_INIT, false, true);
 #ifdef MISO_K2_PROFILE
-  const DevEvent LE_ = a.events[FI(ls, L.misc)[MI_EV]];
-  const uint32_t lchain = static_cast<uint32_t>(FI(ls, L.misc)[MI_CHAIN]);
   if (leader && lchain == 0 && a.M > 8) {
     double *loglik = reinterpret_cast<double *>(a.out_pool + LE_.off_loglik);
     loglik[0] = static_cast<double>(fp_mh); loglik[1] = static_cast<double>(fp_thr); loglik[2] = static_cast<double>(fp_loop);
   }
 #endif
   if (leader && writes) {
-#ifndef MISO_K2_PROFILE
-    const DevEvent LE_ = a.events[FI(ls, L.misc)[MI_EV]];
-    const uint32_t lchain = static_cast<uint32_t>(FI(ls, L.misc)[MI_CHAIN]);
-#endif
     ChainStats *st = reinterpret_cast<ChainStats *>(a.out_pool + LE_.off_stats) + lchain;
     st->counts_hash = hash; st->accepted = accepted;
     st->hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4);

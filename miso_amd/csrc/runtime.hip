@@ -67,7 +67,7 @@ static inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a
 // mostly empty round starts.  Hence: the smallest supported G whose wavefront count still fills
 // the slots once, i.e. the largest G with ceil(chains / (64 / G)) <= slots; G = 1 for batches that
 // overflow anyway; never more lanes than a chain has pairs of draw quads to stride over.
-static inline int flat_wgs_for(int kc) { return kc <= 4 ? 4 : (kc == 12 ? 3 : 2); }
+static inline int flat_wgs_for(int kc) { return kc <= 4 ? 3 : (kc == 12 ? 3 : 2); }
 
 int choose_lanes_per_chain(long chains, int max_quads, int wave_slots, int max_cpw) {
   static const int kG[] = {64, 32, 21, 16, 12, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1};
@@ -779,8 +779,8 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     if (lane_gen) break;
     if (p.paired || run.nocls || run.kc == 64 || std::getenv("MISO_NO_FLAT") != nullptr) continue;
     const int slice = flat_layout(run.kmax, std::max(run.maxcls, 1)).bytes;
-    // workgroups per CU the chains per wavefront are sized for: kernels_flat.inl's register budgets -- 4 up to four isoforms,
-    // 3 for nine to twelve (measured round 4, profiles/r04_occupancy.txt), 2 otherwise (five to eight isoforms: the kernel
+    // workgroups per CU the chains per wavefront are sized for: kernels_flat.inl's register budgets -- 3 up to four isoforms
+    // and for nine to twelve (measured round 4, profiles/r04_occupancy.txt), 2 otherwise (five to eight isoforms: the kernel
     // allows 3, sizing for 3 gained nothing); MISO_FLAT_WGS overrides
     const int wgs = std::getenv("MISO_FLAT_WGS") ? std::max(1, std::atoi(std::getenv("MISO_FLAT_WGS"))) : flat_wgs_for(run.kc);
     const size_t lds_wave = std::getenv("MISO_LDS_MAX_KB") ? LDS_MAX / 4 : static_cast<size_t>(160 * 1024 / (4 * wgs)) - 64;
@@ -892,6 +892,17 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     // little to save) and whenever a chain owns a whole workgroup; MISO_FLAT_NO_DESC=1: the walking loop everywhere
     // (A/B, tests; not with workgroup-wide chains)
     ka.flat_desc = ((std::getenv("MISO_FLAT_NO_DESC") == nullptr && run.kmax >= 4) || run.wave_wide > 0) ? 1 : 0;
+    // Thresholds only for the chains whose psi changed (kernels_flat.inl): the pass is one lane per (chain, class) and the
+    // Metropolis-Hastings step rejects 45 - 65 % of the proposals, but numbering the chains that accepted costs every lane
+    // a few instructions -- it pays where the thresholds weigh enough: from six isoforms on (K = 6 ... 12: + 4.5 ... 6.4 %)
+    // and for small events (hg19-like read counts at K = 5: + 5.5 %; 1000 reads per event at K = 3 ... 5: - 1 ... 2 %,
+    // profiles/r04_occupancy.txt).  MISO_FLAT_THR_SKIP=0 / 1: never / always (A/B, tests).
+    {
+      double units = 0;
+      for (int j = 0; j < run.count; j++) units += events[h_slots[n_k2 + run.first + j]].n_units;
+      const char *env = std::getenv("MISO_FLAT_THR_SKIP");
+      ka.flat_thr_skip = env ? (std::atoi(env) != 0) : (run.kmax >= 6 || units < 150.0 * run.count);
+    }
     const unsigned grid = static_cast<unsigned>(run.wave_tab.size() / 8);
     const size_t lds = 4 * static_cast<size_t>(run.wave_nc) * flat_layout(ka.kstride, ka.cstride).bytes;
 #define MISO_FLAT_LAUNCH(KC)                                                                            \

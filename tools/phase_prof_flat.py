@@ -18,8 +18,8 @@ for K in Ks:
             os.environ.pop("MISO_FLAT_NC", None)
         b.launch(seed=42); ms = b.sync(); b.download()
         st = b.launch_stats()["kernels"][0]
-        acc = np.zeros(4); idx = list(range(0, E, 257))
-        for i in idx: acc += b.result(i).loglik[:4]
+        acc = np.zeros(3); idx = list(range(0, E, 257))
+        for i in idx: acc += b.result(i).loglik[:3]
         acc /= len(idx) * iters
-        print("K=%d NC=%s %s %7.1f ms waves %d trips/wave %.1f | cycles/wave-iteration: MH %7.0f thresholds %7.0f read-loop+resolve %7.0f all (sampler_flatl: incl. barrier waits) %7.0f"
+        print("K=%d NC=%s %s %7.1f ms waves %d trips/wave %.1f | cycles/wave-iteration: MH %7.0f thresholds %7.0f read-loop+resolve %7.0f"
               % ((K, nc or "auto", b.last_kernels(), ms, st["waves"], st["trips"] / st["waves"]) + tuple(acc)), flush=True)

@@ -143,7 +143,9 @@ def update_traffic(prof_dir):
     table[key] = {"fetch_size_kb": fetch_kb, "write_size_kb": write_kb,
                   "hbm_bytes_per_launch": 2 * fetch_kb * 1024 + write_kb * 1024,
                   "source": os.path.basename(prof_dir.rstrip("/")),
-                  "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"]}
+                  # (the compact bench line carries the rate; bytes = rate x the run's kernel time)
+                  "algorithmic_bytes_per_launch": bench["roofline"].get("algorithmic_bytes_per_launch",
+                      bench["roofline"]["algorithmic_GBs"] * 1e9 * bench["roofline"]["kernel_ms"] * 1e-3)}
     json.dump(table, open(path, "w"), indent=1, sort_keys=True)
     print("traffic:", key, table[key])
 
