@@ -574,14 +574,6 @@ PackedEvent pack_event_masks(const miso_params_t &p, const FragmentDist *fd, int
         for (int k = 0, j = 0; j < nv - 1; k++)   // every member but the last
           if ((e.dcls_mask[c] >> k) & 1u) { e.dcls_pairs.push_back(static_cast<uint16_t>(c << 8 | k)); j++; }
       }
-      // sampler_flat's descriptor read loop (kernels_flat.inl) takes the units in this order: the WHOLE units first (all four
-      // words of the Philox block belong to the class: no word masks to apply), the class edges after them; the word behind
-      // the last descriptor says how many are whole.  (The counts are sums over units: their order is free.)
-      {
-        const auto mid = std::stable_partition(e.unit_desc.begin(), e.unit_desc.end(), [](uint32_t d) { return (d & 0xFu) == 0xFu; });
-        const uint32_t n_whole = static_cast<uint32_t>(mid - e.unit_desc.begin());
-        e.unit_desc.push_back(n_whole);
-      }
       const uint32_t last[CLS_WORDS] = {0u, static_cast<uint32_t>(e.n_units), 0u, 0xFFu};
       e.dcls_tab.insert(e.dcls_tab.end(), last, last + CLS_WORDS);
       for (int k = 0; k < K; k++) {   // A_k: every read of a class whose last isoform is <= k picks <= k

@@ -63,8 +63,8 @@ enum { SX_SUMEXP = 0, SX_LTHETA, SX_MAXV, SX_E1, SX_E2, SX_X1, SX_X2, SX_LA0, SX
 // ... and int scalars (FlatLayout::misc)
 enum { MI_K = 0, MI_NDRAW, MI_NCLS, MI_NUNITS, MI_EVID, MI_CHAIN, MI_ACC, MI_ACCW, MI_C3K1, MI_P1LO, MI_P1HIK0,
        MI_EV, MI_SAMP_LO, MI_SAMP_HI, MI_TRACE_LO, MI_TRACE_HI, MI_USTART, MI_NEXT, MI_LANE0, MI_LANES, MI_DESC,
-       MI_SLOW, MI_NWHOLE };   // MI_NWHOLE: the chain's first so many unit descriptors are whole Philox blocks (host.cpp); MI_SLOW: one of the chain's current thresholds does not fit 32 bits (the direct path until psi changes)
-static_assert(MI_NWHOLE < FLAT_MISC, "FlatLayout::misc");
+       MI_SLOW };   // MI_SLOW: one of the chain's current thresholds does not fit 32 bits (the direct path until psi changes)
+static_assert(MI_SLOW < FLAT_MISC, "FlatLayout::misc");
 
 // The reference's draw compares rnd = fl(fl(u 2^-32) T) with a cumulative weight c: `rnd < c` when two
 // isoforms are compatible, `!(rnd > c)` otherwise (miso.c:69-79).  Both are monotone in the 32-bit word
@@ -270,7 +270,6 @@ __device__ __attribute__((noinline)) void flat_units_desc(const FlatUnitsArgs A,
   uint32_t dn[UQ];   // the next trip's descriptors (0 = no unit: no word counts)
 #pragma unroll
   for (int b = 0; b < UQ; b++) { const int u = r + b * g; dn[b] = (u < nu) ? desc[u] : 0u; }
-  const int nwhole = mi[MI_NWHOLE];
   for (int u0 = r; __any(u0 < nu); u0 += UQ * g) {
     uint32_t d[UQ];
 #pragma unroll
@@ -281,23 +280,17 @@ __device__ __attribute__((noinline)) void flat_units_desc(const FlatUnitsArgs A,
                                            //  address-space-1 pointer 87.1k; that plus a clamped, branch-free load 91.1k)
     }
     uint32_t T[UQ][TW], w[UQ][4];
-    // the trip's units are all WHOLE Philox blocks for every lane of the wavefront (the chains' descriptors are ordered:
-    // whole units first): no word masks -- two instructions per word saved, ~8 % of the trip at five isoforms
-    const bool whole = __all(u0 + (UQ - 1) * g < nwhole);
+    // (tried round 4: the chains' whole units first and a trip without word masks when every lane's units are whole -- two
+    // instructions per word fewer on paper, no gain measured: profiles/r04_occupancy.txt)
 #pragma unroll
     for (int b = 0; b < UQ; b++) {
       const uint32_t *row = reinterpret_cast<const uint32_t *>(thr + ((d[b] >> 4) & 0xFFu) * trow4);
 #pragma unroll
       for (int j = 0; j < TW; j++) T[b][j] = row[j];
       const miso_u32x4 u = philox_gibbs<true>(rng, d[b] >> 12, n0r0);
-      if (whole) {
+      const int nm = static_cast<int>(~d[b]);   // a word outside the class becomes 0xFFFFFFFF (never below a 32-bit threshold)
 #pragma unroll
-        for (int x = 0; x < 4; x++) w[b][x] = u.v[x];
-      } else {
-        const int nm = static_cast<int>(~d[b]);   // a word outside the class becomes 0xFFFFFFFF (never below a 32-bit threshold)
-#pragma unroll
-        for (int x = 0; x < 4; x++) w[b][x] = u.v[x] | static_cast<uint32_t>(__builtin_amdgcn_sbfe(nm, x, 1));
-      }
+      for (int x = 0; x < 4; x++) w[b][x] = u.v[x] | static_cast<uint32_t>(__builtin_amdgcn_sbfe(nm, x, 1));
     }
 #pragma unroll
     for (int j = 0; j < TW; j++) {
@@ -392,7 +385,6 @@ __global__ __launch_bounds__(256, KC <= 4 ? MISO_FLAT_WGS_4 : (KC <= 8 ? MISO_FL
       mi[MI_ACC] = 1; mi[MI_SLOW] = 0;   // (the first Gibbs step computes every chain's thresholds)
       mi[MI_ACCW] = 0; mi[MI_EV] = ev; mi[MI_NEXT] = -1;
       mi[MI_DESC] = static_cast<int>(static_cast<uint32_t>(E.off_units >> 2));   // dword offset of the event's unit descriptors in the input pool
-      mi[MI_NWHOLE] = E.n_units > 0 ? static_cast<int>(reinterpret_cast<const uint32_t *>(a.in_pool + E.off_units)[E.n_units]) : 0;
       mi[MI_LANE0] = 0; mi[MI_LANES] = 0;
       const GibbsRng g = gibbs_rng_init(a.seed, event_id, chain);
       mi[MI_C3K1] = static_cast<int>(g.c3k1); mi[MI_P1LO] = static_cast<int>(g.p1lo);
