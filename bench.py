@@ -51,6 +51,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 SIMDS = 256 * 4              # 256 CUs x 4 SIMDs
 CLOCK_GHZ = 2.4              # max shader clock (MI355X_MICROARCH.md)
 VALU_PEAK_GCYC = SIMDS * CLOCK_GHZ   # VALU issue cycles per ns of wall time, whole chip
+PHILOX_ROUNDS = 7            # include/miso_philox.h MISO_PHILOX_ROUNDS
 
 
 # ------------------------------------------------------------------------------------------------
@@ -308,12 +309,13 @@ def load_json(name):
 
 def valu_floor(K, paired, draws_per_chain):
     """VALU wave-instructions one chain-iteration cannot avoid in this formulation: one
-    Philox4x32-10 block per four draws (36 once round 0 is hoisted), per draw K - 1 compare-and-count pairs
+    Philox4x32 block per four draws (4 x (rounds - 1) = 24 at the contract's 7 rounds, round 0 hoisted), per draw K - 1 compare-and-count pairs
     (single-end; paired-end ~15 per read and compatible isoform for weights, compare, select, score gather), and the
     scalar step's 5K + 3 transcendentals at ~55 instructions each if every lane of a wavefront has one to do, plus
     its ~3K divisions."""
     K = float(K)
-    per_block = 36.0 + (8.0 * (K - 1.0) if not paired else 30.0 * K)
+    philox = 4.0 * (PHILOX_ROUNDS - 1)    # 2 multiplies + 2 three-input xors per round, round 0 hoisted
+    per_block = philox + (8.0 * (K - 1.0) if not paired else 30.0 * K)
     return draws_per_chain / 256.0 * per_block + ((5.0 * K + 3.0) * 55.0 + 3.0 * K * 10.0) / 64.0
 
 
@@ -366,9 +368,10 @@ def roofline_for(batch, kernel_ms, key, sh):
         out["frac_source"] = ("no rocprofv3 PMC pass committed for this workload (%s)" % key) if m is None else \
             ("the committed profile of this workload is of other kernels (%s): re-profile" % ",".join(profiled))
     out["draws_per_chain"] = round(draws, 1)
-    rng_ceiling = load_json("rng_ceiling.json").get("philox4x32_10_outputs_per_s", 2885e9)
+    # (tools/rng_bench.hip, MI355X: philox4x32-10 2885 G words/s, philox4x32-7 the same generator at 7 / 10 of the rounds)
+    rng_ceiling = load_json("rng_ceiling.json").get("philox4x32_7_outputs_per_s", 2885e9 * 10.0 / 7.0)
     out["rng_frac"] = round(stats["uniforms"] / t / rng_ceiling, 4)
-    out["rng_note"] = "Philox4x32-10 words consumed / s over the chip's measured ceiling (tools/rng_bench.hip)"
+    out["rng_note"] = "Philox4x32-7 words consumed / s over the chip's ceiling for that generator (tools/rng_bench.hip)"
     traffic = load_json("traffic.json").get(key)
     out["traffic"] = None if traffic is None else traffic["hbm_bytes_per_launch"]
     out["hbm_measured_frac"] = None if traffic is None else round(

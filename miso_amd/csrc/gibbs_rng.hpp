@@ -1,4 +1,4 @@
-// gibbs_rng.hpp -- the Gibbs-site Philox4x32-10 block with round 0 split into chain and iteration
+// gibbs_rng.hpp -- the Gibbs-site Philox4x32 block (MISO_PHILOX_ROUNDS rounds, include/miso_philox.h) with round 0 split into chain and iteration
 // constants (the counter is (block, iteration, site | chain << 8, event): only `block` changes inside
 // a read loop).  Output identical to miso_draw_block(seed, event, chain, iter, MISO_SITE_GIBBS, q).
 #pragma once
@@ -40,7 +40,7 @@ __device__ __forceinline__ miso_u32x4 philox_gibbs(const GibbsRng &g, uint32_t q
   }
   uint32_t k0 = gk0 + MISO_PHILOX_W0, k1 = gk1 + MISO_PHILOX_W1;
 #pragma unroll
-  for (int r = 1; r < 10; r++) {
+  for (int r = 1; r < MISO_PHILOX_ROUNDS; r++) {
     const uint64_t a = static_cast<uint64_t>(MISO_PHILOX_M0) * c0;
     const uint64_t b = static_cast<uint64_t>(MISO_PHILOX_M1) * c2;
     const uint32_t n0 = MISO_XOR3(static_cast<uint32_t>(b >> 32), c1, k0);

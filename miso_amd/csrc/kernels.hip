@@ -331,7 +331,7 @@ __global__ void selftest_philox_kernel(const uint32_t *in6, int n, uint32_t *out
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint32_t *p = in6 + 6 * static_cast<size_t>(i);
-  const miso_u32x4 o = miso_philox4x32_10(p[0], p[1], p[2], p[3], p[4], p[5]);
+  const miso_u32x4 o = miso_philox4x32(p[0], p[1], p[2], p[3], p[4], p[5]);
   for (int j = 0; j < 4; j++) out4[4 * static_cast<size_t>(i) + j] = o.v[j];
 }
 

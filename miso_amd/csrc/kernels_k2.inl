@@ -653,7 +653,7 @@ __device__ __forceinline__ void k2_body(const KernelArgs &a, unsigned block_x, u
     const uint64_t t = PE ? 0 : k2_threshold(cur.x0, (0.0 + cur.x0) + cur.x1);
     const int nq = (n_draw + 3) >> 2;
     for (int q = sub; q < nq; q += GE) {
-      const miso_u32x4 u = miso_philox4x32_10(static_cast<uint32_t>(q), iter, c2_gibbs, event_id, k0, k1);
+      const miso_u32x4 u = miso_philox4x32(static_cast<uint32_t>(q), iter, c2_gibbs, event_id, k0, k1);
       const uint4 f = PE ? fragq[q] : make_uint4(0, 0, 0, 0);
       const uint32_t ff[4] = {f.x, f.y, f.z, f.w};
       for (int j = 0; j < 4; j++) {
@@ -670,7 +670,7 @@ __device__ __forceinline__ void k2_body(const KernelArgs &a, unsigned block_x, u
   // chain compute them for NR consecutive iterations at once (lane role r: iteration m0 + r) -- one
   // Philox block + qnorm per NR iterations per lane instead of one per iteration on every lane.
   auto mh_draws = [&](uint32_t iter, double &z, uint32_t &accept_word) {
-    const miso_u32x4 b = miso_philox4x32_10(0u, iter, c2_mh, event_id, k0, k1);
+    const miso_u32x4 b = miso_philox4x32(0u, iter, c2_mh, event_id, k0, k1);
     accept_word = b.v[0];
     z = miso_det_norm_from_unif(miso_u01(b.v[2]), miso_u01(b.v[3]));
   };

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void sampler_lane(const KernelArgs a) {
     const int nq = (n_draw + 3) >> 2;
     int d0 = 0;
     for (int q = 0; q < nq; q++) {
-      const miso_u32x4 u = miso_philox4x32_10(static_cast<uint32_t>(q), iter, c2_gibbs, event_id, k0, k1);
+      const miso_u32x4 u = miso_philox4x32(static_cast<uint32_t>(q), iter, c2_gibbs, event_id, k0, k1);
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         if (4 * q + j < n_draw) {
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void sampler_lane(const KernelArgs a) {
     cnt1 = base1 + (n_draw - d0);
   };
   auto mh_draws = [&](uint32_t iter, double &z, uint32_t &accept_word) {
-    const miso_u32x4 b = miso_philox4x32_10(0u, iter, c2_mh, event_id, k0, k1);
+    const miso_u32x4 b = miso_philox4x32(0u, iter, c2_mh, event_id, k0, k1);
     accept_word = b.v[0];
     z = miso_det_norm_from_unif(miso_u01(b.v[2]), miso_u01(b.v[3]));
   };
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(64) void sampler_lane_k(const KernelArgs a) {
     for (int k = 0; k < K; k++) CNT(k) = base[k];
     miso_u32x4 u{};
     for (int r = 0; r < n_draw; r++) {
-      if ((r & 3) == 0) u = miso_philox4x32_10(static_cast<uint32_t>(r >> 2), iter, c2_gibbs, event_id, k0, k1);
+      if ((r & 3) == 0) u = miso_philox4x32(static_cast<uint32_t>(r >> 2), iter, c2_gibbs, event_id, k0, k1);
       const uint32_t word = (r & 3) == 0 ? u.v[0] : ((r & 3) == 1 ? u.v[1] : ((r & 3) == 2 ? u.v[2] : u.v[3]));
       const uint32_t mask = masks[r];
       const int nv = __builtin_popcount(mask);

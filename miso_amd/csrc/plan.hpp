@@ -42,12 +42,14 @@ struct LaneCost {
 // The measured models (profiles/r03_k2_cost_model.txt).  Single-end: step = MH + threshold + reduction + recording
 // with 1, 2, 3, >= 4 lanes sharing the transcendentals; block = one Philox4x32-10 block + four compares.  Paired-end
 // (MODE 2, dense records): block = generator + four reads' weights, compares and score gathers.
+// (round 4: the generator has 7 rounds instead of 10, include/miso_philox.h: three rounds x four instructions fewer per block
+// than the 52 / 115 measured in round 3)
 inline LaneCost k2_cost_single() {
-  LaneCost c; c.step[1] = 1750; c.step[2] = 1170; c.step[3] = 840; c.step[4] = 720; c.block = 52; c.uq = 2; c.paired = false;
+  LaneCost c; c.step[1] = 1750; c.step[2] = 1170; c.step[3] = 840; c.step[4] = 720; c.block = 40; c.uq = 2; c.paired = false;
   return c;
 }
 inline LaneCost k2_cost_paired() {
-  LaneCost c; c.step[1] = c.step[2] = c.step[3] = c.step[4] = 650; c.block = 115; c.uq = 2; c.paired = true;
+  LaneCost c; c.step[1] = c.step[2] = c.step[3] = c.step[4] = 650; c.block = 103; c.uq = 2; c.paired = true;
   return c;
 }
 

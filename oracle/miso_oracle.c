@@ -174,9 +174,16 @@ void orc_binomial(uint64_t seed, uint32_t event_id, int32_t n, double p, int cou
 }
 void orc_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
                 uint32_t *out4) {
-  miso_u32x4 o = miso_philox4x32_10(c0, c1, c2, c3, k0, k1);
+  miso_u32x4 o = miso_philox4x32(c0, c1, c2, c3, k0, k1);
   memcpy(out4, o.v, 16);
 }
+/* the same round function at any number of rounds (the published known-answer vectors exist for 7 and for 10) */
+void orc_philox_r(int rounds, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                  uint32_t *out4) {
+  miso_u32x4 o = miso_philox4x32_r(rounds, c0, c1, c2, c3, k0, k1);
+  memcpy(out4, o.v, 16);
+}
+int orc_philox_rounds(void) { return MISO_PHILOX_ROUNDS; }
 
 /* random.c:1543-1551 splicing_norm_rand: u = (int)(2^27 u1) + u2; qnorm(u / 2^27) */
 static double norm_from_unif(double u1, double u2, const orc_math_t *M) {

@@ -118,6 +118,9 @@ double orc_det_sqrt(double x);
 void orc_binomial(uint64_t seed, uint32_t event_id, int32_t n, double p, int count, int32_t *out);
 void orc_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
                 uint32_t *out4);
+void orc_philox_r(int rounds, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                  uint32_t *out4);
+int orc_philox_rounds(void);
 
 #ifdef __cplusplus
 }

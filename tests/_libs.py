@@ -238,11 +238,19 @@ class OrcLib(_Base):
             getattr(L, name).restype = C.c_double
             getattr(L, name).argtypes = [C.c_double]
 
-    def philox(self, ctr, key):
+    def philox(self, ctr, key, rounds=None):
+        """One Philox4x32 block at the contract's rounds (include/miso_philox.h) or at `rounds`."""
         out = np.zeros(4, np.uint32)
-        self.lib.orc_philox(C.c_uint32(ctr[0]), C.c_uint32(ctr[1]), C.c_uint32(ctr[2]),
-                            C.c_uint32(ctr[3]), C.c_uint32(key[0]), C.c_uint32(key[1]), _p(out))
+        a = (C.c_uint32(ctr[0]), C.c_uint32(ctr[1]), C.c_uint32(ctr[2]), C.c_uint32(ctr[3]), C.c_uint32(key[0]),
+             C.c_uint32(key[1]), _p(out))
+        if rounds is None:
+            self.lib.orc_philox(*a)
+        else:
+            self.lib.orc_philox_r(C.c_int(rounds), *a)
         return out
+
+    def philox_rounds(self):
+        return self.lib.orc_philox_rounds()
 
     def binomial(self, n, p, count, seed=1, event_id=0):
         """`count` draws of include/miso_binomial.h's Binomial(n, p) (word streams of iterations 0 .. count-1)."""

@@ -235,7 +235,7 @@ def _worker(paired, K, rounds, **env):
 @pytest.mark.parametrize("paired,K,env", [
     (True, 5, dict(MISO_COOP_DRAWS="1024")),                                   # sampler_grp WIDE, ~10 and ~4 workgroups per chain
     (True, 5, dict(MISO_COOP_DRAWS="1024", MISO_PE_MULTI="1")),                # the same inside sampler_grp_multi
-    (False, 2, dict(MISO_K2_TARGET="1400", MISO_COOP_MIN_QUADS="1")),          # sampler_k2_multi<0, 8>
+    (False, 2, dict(MISO_K2_TARGET="1000", MISO_COOP_MIN_QUADS="1")),          # sampler_k2_multi<0, 8>
     (True, 2, dict(MISO_K2_TARGET="1400", MISO_COOP_MIN_QUADS="1")),           # sampler_k2_multi<2, 4>
 ])
 def test_a_chain_that_times_out_on_its_workgroups_is_rerun_not_failed(paired, K, env):
@@ -256,7 +256,7 @@ def test_two_processes_on_one_gpu_with_cooperative_chains_in_both():
     at the same time, all with chains on several workgroups in flight (paired-end genes through sampler_grp's WIDE path,
     two-isoform events through sampler_k2_multi), several launches each.  All must return the oracle's results bit for
     bit; a time-out, should the device ever be that busy, is absorbed by the re-run (miso_batch_coop_retries)."""
-    procs = [_worker(True, 5, 6, MISO_COOP_DRAWS="1024"), _worker(False, 2, 6, MISO_K2_TARGET="1400", MISO_COOP_MIN_QUADS="1"),
+    procs = [_worker(True, 5, 6, MISO_COOP_DRAWS="1024"), _worker(False, 2, 6, MISO_K2_TARGET="1000", MISO_COOP_MIN_QUADS="1"),
              _worker(True, 2, 6, MISO_K2_TARGET="1400", MISO_COOP_MIN_QUADS="1")]
     for p in procs:
         out, err = p.communicate(timeout=1500)

@@ -86,3 +86,22 @@ def test_lag_remainder_leaves_zero_columns(orc):
     r = orc.miso(gene, g["pos"], g["cigars"], g["read_len"], iters=g["iters"], burn=g["burn"],
                  lag=g["lag"], chains=g["chains"])
     assert filled < S and (r.samples[filled:] == 0).all() and (r.samples[:filled] != 0).all()
+
+
+def test_philox_known_answers(orc):
+    """include/miso_philox.h against the Random123 distribution's known-answer vectors (kat_vectors: philox4x32 at 7 and
+    at 10 rounds; Salmon et al., SC'11): zero, all ones, digits of pi.  The contract draws with 7 rounds -- the fewest at
+    which the paper's Table 2 lists Philox4x32 as Crush-resistant -- and the same round function reproduces the
+    10-round vectors, so it is the published generator, not a look-alike."""
+    inputs = [([0, 0, 0, 0], [0, 0]), ([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2),
+              ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0])]
+    kat = {7: [[0x5f6fb709, 0x0d893f64, 0x4f121f81, 0x4f730a48], [0x5207ddc2, 0x45165e59, 0x4d8ee751, 0x8c52f662],
+               [0x4dfccaba, 0x190a87f0, 0xc47362ba, 0xb6b5242a]],
+           10: [[0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8], [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd],
+                [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]]}
+    for rounds, want in kat.items():
+        for (ctr, key), w in zip(inputs, want):
+            assert list(orc.philox(ctr, key, rounds=rounds)) == w, (rounds, ctr)
+    assert orc.philox_rounds() == 7
+    for (ctr, key), w in zip(inputs, kat[7]):
+        assert list(orc.philox(ctr, key)) == w
