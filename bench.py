@@ -52,6 +52,10 @@ SIMDS = 256 * 4              # 256 CUs x 4 SIMDs
 CLOCK_GHZ = 2.4              # max shader clock (MI355X_MICROARCH.md)
 VALU_PEAK_GCYC = SIMDS * CLOCK_GHZ   # VALU issue cycles per ns of wall time, whole chip
 PHILOX_ROUNDS = 7            # include/miso_philox.h MISO_PHILOX_ROUNDS
+# Every row's |delta psi| test reports pass / fail at its level of 1e-3 in the line.  The PROCESS fails (exit 3) when the
+# headline's test fails or when two or more matrix rows fail: a defect in a kernel family fails its rows together, while
+# seventeen honest rows at 1e-3 each would fail one of them once in sixty runs
+ROWS_TO_FAIL = 2
 
 
 # ------------------------------------------------------------------------------------------------
@@ -716,7 +720,7 @@ def main():
         elif want_matrix:
             del batch
             out["matrix"] = run_matrix(a, local_rank, studies, sh)
-            if any((r.get("delta_psi") or {}).get("pass") is False for r in out["matrix"]):
+            if sum((r.get("delta_psi") or {}).get("pass") is False for r in out["matrix"]) >= ROWS_TO_FAIL:
                 rc = 3
         full_path = a.full_out or os.path.join(ROOT, "gpurun_out", "bench_full.json")
         try:
