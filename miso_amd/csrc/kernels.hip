@@ -12,7 +12,7 @@
 //   * lane k (< K <= 64) owns isoform k: psi_k, alpha_k, log psi_k, count_k.  Transcendentals run
 //     lane-parallel; the reference's left-to-right sums are reproduced with uniform-lane
 //     broadcasts (v_readlane), so every lane holds the same, reference-ordered total.
-//   * in the Gibbs step lane l owns draw quads l, l+64, ...: one Philox4x32-10 block = the four
+//   * in the Gibbs step lane l owns draw quads l, l+64, ...: one Philox4x32 block = the four
 //     uniforms of four consecutive drawing reads (include/miso_philox.h), whose packed
 //     compatibility masks (SE) / fragment indices (PE) it loads as one coalesced vector.
 //   * the per-isoform counts come back through wave ballots (K <= 4) or LDS atomics.

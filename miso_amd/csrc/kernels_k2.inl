@@ -13,7 +13,7 @@
 //     of 11.  Every value is still produced by the same miso_detmath routine on the same input,
 //     so the bits are unchanged.  Terms that depend only on the CURRENT psi are cached and
 //     swapped on acceptance.
-//   * Gibbs step: the G lanes stride over the chain's draw quads (one Philox4x32-10 block = the
+//   * Gibbs step: the G lanes stride over the chain's draw quads (one Philox4x32 block = the
 //     uniforms of four consecutive ambiguous reads, two blocks in flight per trip).  With two
 //     compatible isoforms the reference's test  U * (psi0 + psi1) < psi0  (miso.c:69-73) is
 //     monotone in the 32-bit uniform, so it becomes ONE u32 compare against the threshold

@@ -40,7 +40,7 @@ struct LaneCost {
 };
 
 // The measured models (profiles/r03_k2_cost_model.txt).  Single-end: step = MH + threshold + reduction + recording
-// with 1, 2, 3, >= 4 lanes sharing the transcendentals; block = one Philox4x32-10 block + four compares.  Paired-end
+// with 1, 2, 3, >= 4 lanes sharing the transcendentals; block = one Philox4x32 block + four compares.  Paired-end
 // (MODE 2, dense records): block = generator + four reads' weights, compares and score gathers.
 // (round 4: the generator has 7 rounds instead of 10, include/miso_philox.h: three rounds x four instructions fewer per block
 // than the 52 / 115 measured in round 3)
