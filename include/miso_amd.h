@@ -218,6 +218,10 @@ int miso_batch_write_miso_files(const miso_batch_t *batch, int n, const int *eve
 /* tests: the writer's number formatter on its own ("%.2f" / "%.4f"), NUL-terminated strings `stride`
  * bytes apart */
 int miso_selftest_format(const double *x, int n, int decimals, char *out, int stride);
+/* tests: the stopping rule of stop = MISO_STOP_CONVERGENT_MEAN on its own (splicing_i_check_convergent_mean,
+ * miso.c:556-636): samples = noSamples columns of noiso values, column i from chain i % noChains; *stop = 1 converged.
+ * Host arithmetic, no device needed. */
+int miso_selftest_convergent_mean(const double *samples, int noiso, int noChains, int noSamples, int *stop);
 /* parity instrumentation: FNV-1a over every chain's per-iteration assignment counts
    (counts_hash: noChains words) and, if want_counts_trace, the counts themselves
    ((noIterations+1) x noChains x noiso int32, row m = counts the MH step of iteration m saw,
@@ -271,6 +275,16 @@ int miso_batch_last_kernels(const miso_batch_t *batch, char *buf, int buflen);
    in the same process with one workgroup per chain and returns the same results bit for bit; the batch never fails
    for it -- the reference's workers share nothing either (misopy/miso.py:165-187).  0 on an idle device. */
 int miso_batch_coop_retries(const miso_batch_t *batch, int *n);
+
+/* stop = MISO_STOP_CONVERGENT_MEAN (miso.c:903-925, miso_paired.c:501-523): after a launch whose chains have not
+   converged for some events -- splicing_i_check_convergent_mean on their kept samples --, miso_batch_sync() runs those
+   events again with noIterations' = 3 noIterations - 2 noBurnIn, noBurnIn' = noIterations (while noIterations <
+   maxIterations), and the LAST noSamples of that round replace the event's samples (miso.c:976-983): every getter,
+   the summaries and the file writer see a batch of noSamples samples per event, as the reference returns them.
+   rundata.noAccepted / noRejected count the last round (paired-end: all rounds), as the reference's do.
+   *rounds = rounds the slowest event of the last launch took (1: every event converged on its own schedule, and
+   always with MISO_STOP_FIXEDNO). */
+int miso_batch_rounds(const miso_batch_t *batch, int *rounds);
 
 /* Measurement: what the last launch put on the device, kernel by kernel (bench.py's VALU roofline
    prices it with the kernels' instruction counts, tools/isa_count.py): wavefronts launched, the sum

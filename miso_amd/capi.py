@@ -367,6 +367,12 @@ class Batch:
         check(lib().miso_batch_last_kernels(self.handle, buf, 2048))
         return buf.value.decode()
 
+    def rounds(self):
+        """stop=CONVERGENT_MEAN: rounds the last launch took (include/miso_amd.h miso_batch_rounds)"""
+        n = C.c_int(0)
+        check(lib().miso_batch_rounds(self.handle, C.byref(n)))
+        return n.value
+
     def coop_retries(self):
         """Launches sync() repeated with one workgroup per chain after a chain on several workgroups timed out."""
         n = C.c_int(0)
@@ -464,6 +470,14 @@ def selftest_detmath(x):
     outs = [np.zeros_like(x) for _ in range(4)]
     check(lib().miso_selftest_detmath(_p(x), len(x), *[_p(o) for o in outs]))
     return outs
+
+
+def selftest_convergent_mean(samples, chains):
+    """samples: S x K (row i from chain i % chains) -> True if stop=CONVERGENT_MEAN would stop (miso.c:556-636)"""
+    a = np.ascontiguousarray(samples, dtype=np.float64)
+    stop = C.c_int(-1)
+    check(lib().miso_selftest_convergent_mean(_p(a), a.shape[1], int(chains), a.shape[0], C.byref(stop)))
+    return bool(stop.value)
 
 
 def selftest_philox(ctr_key6):

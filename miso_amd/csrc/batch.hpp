@@ -39,6 +39,11 @@ struct miso_batch {
   int coop_retries = 0;           // launches sync() had to repeat that way (miso_batch_coop_retries)
   uint64_t last_seed = 0;         // what the last launch() was called with (sync()'s re-run)
   uint32_t last_first_event_id = 0;
+  // stop = CONVERGENT_MEAN (miso.c:903-925): sync() runs the events that have not converged again on the longer
+  // schedule (runtime.hip converge_rounds) and puts the tail of their samples where the first round's were
+  std::vector<int64_t> iters_counted;   // per event: iterations behind its accept count (empty: noIterations each)
+  int rounds = 1;                 // rounds the last launch took (1 = the events' own schedule sufficed)
+  void converge_rounds(float *ms);
   bool coop_enabled() const;      // chains may use several workgroups (coop.hpp): not after a time-out, not with MISO_NO_COOP=1
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;

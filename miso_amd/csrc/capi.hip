@@ -83,10 +83,10 @@ void need(const void *p, const char *what) {
   if (!p) MISO_FAIL(MISO_EINVAL, std::string(what) + " must not be NULL");
 }
 
-void fill_rundata(const miso_batch &b, int K, int accepted, miso_rundata_t *rd) {
+void fill_rundata(const miso_batch &b, int K, int accepted, int64_t iterations, miso_rundata_t *rd) {
   rd->noIso = K; rd->noIters = b.p.noIterations; rd->maxIters = 0; rd->noBurnIn = b.p.noBurnIn;
   rd->noLag = b.p.noLag; rd->noAccepted = accepted;
-  rd->noRejected = b.p.noChains * b.p.noIterations - accepted;
+  rd->noRejected = static_cast<int>(b.p.noChains * iterations - accepted);
   rd->noChains = b.p.noChains; rd->noSamples = b.S();
 }
 
@@ -374,7 +374,8 @@ int miso_batch_get_result(const miso_batch_t *b, int i, double *samples, double 
       const ChainStats *st = reinterpret_cast<const ChainStats *>(out + d.off_stats);
       int acc = 0;
       for (int c = 0; c < b->p.noChains; c++) acc += st[c].accepted;
-      fill_rundata(*b, e.K, acc, rundata);
+      // (stop = CONVERGENT_MEAN: the counts of the last round, paired-end of all rounds -- batch.hpp iters_counted)
+      fill_rundata(*b, e.K, acc, b->iters_counted.empty() ? b->p.noIterations : b->iters_counted[i], rundata);
     }
   });
 }
@@ -492,6 +493,18 @@ int miso_batch_add_events_aln(miso_batch_t *b, int n, const miso_gene_t *const *
       event_index[i] = static_cast<int>(b->events.size()) - 1;
     }
   });
+}
+
+int miso_selftest_convergent_mean(const double *samples, int noiso, int noChains, int noSamples, int *stop) {
+  return guarded([&] {
+    need(samples, "samples"); need(stop, "stop");
+    if (noiso < 1 || noChains < 2 || noSamples < noChains) MISO_FAIL(MISO_EINVAL, "needs two chains and a sample of each");
+    *stop = convergent_mean(samples, noiso, noChains, noSamples) ? 1 : 0;
+  });
+}
+
+int miso_batch_rounds(const miso_batch_t *b, int *rounds) {
+  return guarded([&] { need(b, "batch"); need(rounds, "rounds"); *rounds = b->rounds; });
 }
 
 int miso_selftest_format(const double *x, int n, int decimals, char *out, int stride) {

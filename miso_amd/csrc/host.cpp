@@ -329,11 +329,40 @@ void validate_params(const miso_params_t &p) {
   if (p.noChains < 1) MISO_FAIL(MISO_EINVAL, "Number of chains must be at least one.");
   if (p.stop == MISO_STOP_CONVERGENT_MEAN && p.noChains == 1)
     MISO_FAIL(MISO_EINVAL, "Cannot access convergence with one chain only");
-  if (p.stop == MISO_STOP_CONVERGENT_MEAN)
-    MISO_FAIL(MISO_UNIMPLEMENTED, "Only STOP_FIXEDNO runs on the GPU");
-  if (p.stop != MISO_STOP_FIXEDNO) MISO_FAIL(MISO_EINVAL, "`stop` is invalid");
+  if (p.stop != MISO_STOP_FIXEDNO && p.stop != MISO_STOP_CONVERGENT_MEAN) MISO_FAIL(MISO_EINVAL, "`stop` is invalid");
   if (p.noLag < 1 || p.noBurnIn < 0 || p.noIterations < p.noBurnIn)
     MISO_FAIL(MISO_EINVAL, "Invalid iteration / burn-in / lag combination");
+}
+
+// miso.c:556-636, as it stands: per chain a running mean whose divisor is 1 again for the chain's second sample and a
+// running SUM of squares (never divided), W = the mean over chains of those sums squared, B from the chain means with
+// noSamples (all chains' samples) as n; converged when sqrt(((n - 1) / n W + B / n) / W) <= 1.1 for every isoform (a NaN
+// -- W = 0 -- is "not converged").  Same operations in the same order as the CPU checker's restatement: the decision
+// is part of the counter contract.
+bool convergent_mean(const double *samples, int K, int C, int noSamples) {
+  std::vector<double> mean(samples, samples + static_cast<size_t>(K) * C), ssq(static_cast<size_t>(K) * C, 0.0);
+  for (int i = C, j = 0, l = 1; i < noSamples; i++, j = (j + 1) % C) {
+    for (int k = 0; k < K; k++) {
+      const double x = samples[static_cast<size_t>(i) * K + k], m0 = mean[j * K + k];
+      const double mk = m0 + (x - m0) / l;
+      ssq[j * K + k] = ssq[j * K + k] + (x - m0) * (x - mk);
+      mean[j * K + k] = mk;
+    }
+    if (j == C - 1) l++;
+  }
+  bool stop = true;
+  for (int k = 0; k < K; k++) {
+    double all = 0.0, B = 0.0, W = 0.0;
+    for (int j = 0; j < C; j++) all += mean[j * K + k];
+    all /= C;
+    for (int j = 0; j < C; j++) { const double t = mean[j * K + k] - all; B += t * t; }
+    B *= noSamples / (C - 1.0);
+    for (int j = 0; j < C; j++) { const double t = ssq[j * K + k]; W += t * t; }
+    W /= C;
+    const double rhat = std::sqrt(((noSamples - 1.0) / noSamples * W + B / noSamples) / W);
+    stop = stop && rhat <= 1.1;
+  }
+  return stop;
 }
 
 PackedEvent pack_event(const miso_params_t &p, const FragmentDist *fd, int K, int N,

@@ -127,6 +127,9 @@ struct SamplerParams {
 };
 
 void validate_params(const miso_params_t &p);
+// stop = CONVERGENT_MEAN: the reference's test on the kept samples of one event (miso.c:556-636); samples: noSamples
+// columns of K values, column i from chain i % C.  true = stop.
+bool convergent_mean(const double *samples, int K, int C, int noSamples);
 
 PackedEvent pack_event(const miso_params_t &p, const FragmentDist *fd, int K, int N,
                        const double *match, const int *fraglen, const int *isolen,

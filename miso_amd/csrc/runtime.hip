@@ -1667,7 +1667,7 @@ void miso_batch::sync(float *ms) {
     HIP_OK(hipMemcpy(w.data(), run.d_coop_mem, w.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
     for (int c = 0; c < run.coop_chains; c++) gave_up |= w[static_cast<size_t>(c) * COOP_WORDS + 1] != 0;
   }
-  if (!gave_up) return;
+  if (!gave_up) { converge_rounds(ms); return; }
   // A chain's workgroups did not all become resident in time (a busy device: other batches, other processes).  The
   // batch must not fail for it -- the reference's workers share nothing (misopy/miso.py:165-187) --, so the launch is
   // repeated here, in this process, with every chain on ONE workgroup: same results bit for bit (the contract's random
@@ -1692,6 +1692,78 @@ void miso_batch::sync(float *ms) {
                        "re-running the launch with one workgroup per chain\n", first_ms);
   launch(last_seed, last_first_event_id);
   sync(ms);
+}
+
+// stop = CONVERGENT_MEAN: what the reference does after every round of its iteration loop (miso.c:903-925,
+// miso_paired.c:501-523).  Events whose chains have not converged -- and whose schedule is still below maxIterations --
+// run again with noIterations' = 3 noIterations - 2 noBurnIn, noBurnIn' = noIterations, and of that round's samples the
+// LAST noSamples replace the first round's (miso.c:976-983), here in the device pool, so that the summaries, the file
+// writer and the getters see one finished batch.  The reference continues its chains; the device keeps no chain state
+// between launches and runs the longer schedule from the start instead: iteration m of a chain draws from the same
+// addresses whatever the schedule, so the first noIterations iterations repeat the previous round bit for bit -- the
+// same chain, extended (the CPU checker's counter mode does the same; its stream mode continues, and is pinned to the
+// reference that way).  The next round is a batch of its own (only the unconverged events; its sync() recurses).
+void miso_batch::converge_rounds(float *ms) {
+  rounds = 1;
+  iters_counted.clear();
+  if (p.stop != MISO_STOP_CONVERGENT_MEAN || p.maxIterations <= p.noIterations || events.empty()) return;
+  const int S0 = S(), C = p.noChains;
+  if (S0 < C) return;                        // fewer kept samples than chains: nothing to assess
+  std::vector<unsigned char> out(out_bytes);
+  HIP_OK(hipMemcpy(out.data(), d_out, out_bytes, hipMemcpyDeviceToHost));
+  std::vector<int> again;
+  for (size_t i = 0; i < events.size(); i++)
+    if (!convergent_mean(reinterpret_cast<const double *>(out.data() + h_events[i].off_samples), events[i].K, C, S0))
+      again.push_back(static_cast<int>(i));
+  if (again.empty()) return;
+  miso_params_t p2 = p;
+  p2.noIterations = 3 * p.noIterations - 2 * p.noBurnIn; p2.noBurnIn = p.noIterations;
+  p2.want_counts_trace = 0; p2.device_match = 0;
+  std::unique_ptr<miso_batch> next(batch_new(p2));
+  for (int i : again) {
+    next->events.push_back(events[i]);
+    const bool pinned = i < static_cast<int>(event_ids.size()) && event_ids[i] >= 0;
+    next->event_ids.push_back(pinned ? event_ids[i] : static_cast<int64_t>(last_first_event_id + static_cast<uint32_t>(i)));
+  }
+  next->collapsed = collapsed; next->collapsed_level = collapsed_level; next->no_coop = no_coop;
+  float next_ms = 0.f;
+  next->upload(device);
+  next->launch(last_seed, 0);
+  next->sync(&next_ms);
+  const int Sn = next->S();
+  std::vector<unsigned char> nout(next->out_bytes);
+  HIP_OK(hipMemcpy(nout.data(), next->d_out, next->out_bytes, hipMemcpyDeviceToHost));
+  iters_counted.assign(events.size(), p.noIterations);
+  for (size_t j = 0; j < again.size(); j++) {
+    const int i = again[j];
+    const DevEvent &d = h_events[i], &n = next->h_events[j];
+    const PackedEvent &e = events[i];
+    const size_t skip = static_cast<size_t>(Sn - S0);
+    HIP_OK(hipMemcpyAsync(d_out + d.off_samples, next->d_out + n.off_samples + skip * e.K * 8, static_cast<size_t>(S0) * e.K * 8,
+                          hipMemcpyDeviceToDevice, stream));
+    HIP_OK(hipMemcpyAsync(d_out + d.off_loglik, next->d_out + n.off_loglik + skip * 8, static_cast<size_t>(S0) * 8,
+                          hipMemcpyDeviceToDevice, stream));
+    if (e.n_draw > 0)
+      HIP_OK(hipMemcpyAsync(d_out + d.off_drawass, next->d_out + n.off_drawass, e.n_draw, hipMemcpyDeviceToDevice, stream));
+    // accept counts: the single-end loop starts them afresh every round, the paired-end one never does
+    // (miso.c:847 against miso_paired.c:345, 453)
+    const int64_t next_iters = next->iters_counted.empty() ? p2.noIterations : next->iters_counted[j];
+    ChainStats *mine = reinterpret_cast<ChainStats *>(out.data() + d.off_stats);
+    const ChainStats *theirs = reinterpret_cast<const ChainStats *>(nout.data() + n.off_stats);
+    for (int c = 0; c < C; c++) {
+      const int32_t before = mine[c].accepted;
+      mine[c] = theirs[c];
+      if (p.paired) mine[c].accepted += before;
+    }
+    iters_counted[i] = p.paired ? p.noIterations + next_iters : next_iters;
+    HIP_OK(hipMemcpyAsync(d_out + d.off_stats, mine, sizeof(ChainStats) * C, hipMemcpyHostToDevice, stream));
+  }
+  HIP_OK(hipStreamSynchronize(stream));
+  rounds = 1 + next->rounds;
+  last_ms += next_ms;
+  if (ms) *ms = last_ms;
+  coop_retries += next->coop_retries;
+  last_kernels += "," + next->last_kernels;
 }
 
 // Posterior mean and Chen-Shao credible interval of every isoform, computed where the samples are

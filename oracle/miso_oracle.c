@@ -1001,6 +1001,80 @@ static void init_chains(orc_state_t *S, int start) {
   propose(S, MISO_ITER_INIT, S->alpha, S->psi, S->alpha);
 }
 
+/* miso.c:556-636 (splicing_i_check_convergent_mean), line by line -- including what a textbook R-hat would not do:
+   the running mean's divisor l starts at 1 for a chain's SECOND sample, chainVars holds sums of squares (not
+   variances) and W averages their squares.  samples: K x noSamples, column i belongs to chain i % C. */
+static int convergent_mean(const double *samples, int K, int C, int noSamples) {
+  double *means = malloc(sizeof(double) * K * C), *vars = calloc((size_t) K * C, sizeof(double));
+  int i, j, k, l, stop = 1;
+  memcpy(means, samples, sizeof(double) * K * C);
+  for (i = C, j = 0, l = 1; i < noSamples; i++, j = (j + 1) % C) {
+    for (k = 0; k < K; k++) {
+      double x = samples[(size_t) i * K + k], m0 = means[j * K + k];
+      double mk = m0 + (x - m0) / l;
+      double sk = vars[j * K + k] + (x - m0) * (x - mk);
+      means[j * K + k] = mk; vars[j * K + k] = sk;
+    }
+    if (j == C - 1) l++;
+  }
+  for (k = 0; k < K; k++) {
+    double mean = 0.0, B = 0.0, W = 0.0, rhat;
+    for (j = 0; j < C; j++) mean += means[j * K + k];
+    mean /= C;
+    for (j = 0; j < C; j++) { double t = means[j * K + k] - mean; B += t * t; }
+    B *= noSamples / (C - 1.0);
+    for (j = 0; j < C; j++) { double t = vars[j * K + k]; W += t * t; }
+    W /= C;
+    rhat = sqrt(((noSamples - 1.0) / noSamples * W + B / noSamples) / W);
+    stop = stop && rhat <= 1.1;
+  }
+  free(means); free(vars);
+  return stop;
+}
+
+int orc_convergent_mean(const double *samples, int K, int C, int noSamples) {
+  return convergent_mean(samples, K, C, noSamples);
+}
+
+/* The chains from their start to the stopping rule: miso.c:827-934 / miso_paired.c:431-532.
+   STOP_FIXEDNO: one round.  STOP_CONVERGENT_MEAN: after a round that has not converged (and while noIterations <
+   maxIterations) the schedule becomes noIterations' = 3 noIterations - 2 noBurnIn, noBurnIn' = noIterations, the
+   samples are collected afresh, and of the last round the LAST noSamples (of the first round) are returned
+   (miso.c:976-983).  Stream mode continues the chains where they are, with the iteration counter back at 0, as the
+   reference does.  Counter mode runs the longer schedule FROM THE START: iteration m of chain j draws from the same
+   addresses whatever the schedule, so its first noIterations iterations repeat the previous round bit for bit and
+   the run is the same chain extended -- which is what a device that keeps no chain state between launches can do. */
+static void run_rounds(orc_state_t *S, int start, int stop, int noIterations, int maxIterations, int noBurnIn,
+                       int noLag, double *samples, double *logLik, int *rundata, orc_trace_t *trace) {
+  int K = S->K, C = S->C, S0 = C * (noIterations - noBurnIn) / noLag, nS = S0, round = 0;
+  double *buf = samples, *lbuf = logLik;
+  int acc = 0, rej = 0;
+  for (;; round++) {
+    if (round == 0 || S->counter) {
+      init_chains(S, start);            /* miso.c:827-835 */
+      if (S->N > 0) {                   /* miso.c:841 */
+        if (S->collapsed && noIterations > 0) reassign_collapsed(S, MISO_ITER_INIT); else reassign(S, MISO_ITER_INIT);
+      }
+    }
+    run_chains(S, noIterations, noBurnIn, noLag, buf, lbuf, rundata, round == 0 ? trace : NULL);
+    /* the single-end loop resets the two counters every round (miso.c:847), the paired-end one never does
+       (miso_paired.c:345, 453) */
+    if (S->paired) { acc += rundata[5]; rej += rundata[6]; rundata[5] = acc; rundata[6] = rej; }
+    if (stop != 1 || maxIterations <= noIterations) break;      /* miso.c:903-912 */
+    if (nS < C || convergent_mean(buf, K, C, nS)) break;         /* fewer samples than chains: nothing to assess */
+    { int next = 3 * noIterations - 2 * noBurnIn; noBurnIn = noIterations; noIterations = next; } /* miso.c:921-924 */
+    nS = C * (noIterations - noBurnIn) / noLag;
+    if (buf != samples) { free(buf); free(lbuf); }
+    buf = calloc((size_t) K * (nS > 0 ? nS : 1), sizeof(double));
+    lbuf = calloc((size_t) (nS > 0 ? nS : 1), sizeof(double));
+  }
+  if (buf != samples) {                                         /* miso.c:976-983 */
+    memcpy(samples, buf + (size_t) (nS - S0) * K, sizeof(double) * (size_t) K * S0);
+    memcpy(logLik, lbuf + (nS - S0), sizeof(double) * S0);
+    free(buf); free(lbuf);
+  }
+}
+
 static int check_common(const orc_gene_t *g, int *overHang, int readLength, int noChains,
                         int noIterations, int noBurnIn, int noLag, int nhyper, int start,
                         int stop) {
@@ -1012,8 +1086,7 @@ static int check_common(const orc_gene_t *g, int *overHang, int readLength, int 
   if (nhyper != g->K) return ORC_EINVAL;        /* miso.c:698-701 */
   if (noChains < 1) return ORC_EINVAL;          /* miso.c:703-706 */
   if (stop == 1 && noChains == 1) return ORC_EINVAL; /* miso.c:708-711 */
-  if (stop == 1) return ORC_UNIMPLEMENTED;      /* CONVERGENT_MEAN: not restated */
-  if (stop != 0) return ORC_EINVAL;
+  if (stop != 0 && stop != 1) return ORC_EINVAL;
   if (noLag < 1 || noIterations < noBurnIn || noBurnIn < 0) return ORC_EINVAL;
   if (g->K < 2 || g->K > 64) return ORC_EINVAL;
   return ORC_SUCCESS;
@@ -1089,17 +1162,12 @@ int orc_miso(const orc_gene_t *g, const int *pos, const char **cigar, int nreads
   memset(samples, 0, sizeof(double) * (size_t) K * noSamples);
   memset(logLik, 0, sizeof(double) * noSamples);
 
-  init_chains(&S, start);            /* miso.c:827-835 */
-  if (nreads > 0) { /* miso.c:841 */
-    if (S.collapsed && noIterations > 0) reassign_collapsed(&S, MISO_ITER_INIT); else reassign(&S, MISO_ITER_INIT);
-  }
-  run_chains(&S, noIterations, noBurnIn, noLag, samples, logLik, rundata, trace);
+  run_rounds(&S, start, stop, noIterations, maxIterations, noBurnIn, noLag, samples, logLik, rundata, trace);
 
   for (i = 0; i < nreads; i++) assignment[i] = S.ass[i]; /* chain 0: miso.c:943-946 */
   if (match_out) memcpy(match_out, match, sizeof(double) * (size_t) K * nreads);
   free_common(&S);
   free(match); free(order); free(eff); free(logeff); free(isoscores);
-  (void) maxIterations;
   return ORC_SUCCESS;
 }
 
@@ -1174,14 +1242,11 @@ int orc_miso_paired(const orc_gene_t *g, const int *pos, const char **cigar, int
   memset(samples, 0, sizeof(double) * (size_t) K * noSamples);
   memset(logLik, 0, sizeof(double) * noSamples);
 
-  init_chains(&S, start);                    /* :431-439 */
-  if (N > 0) reassign(&S, MISO_ITER_INIT);   /* :443-447 */
-  run_chains(&S, noIterations, noBurnIn, noLag, samples, logLik, rundata, trace);
+  run_rounds(&S, start, stop, noIterations, maxIterations, noBurnIn, noLag, samples, logLik, rundata, trace);
 
   for (i = 0; i < N; i++) assignment[i] = S.ass[i];
   if (match_out) memcpy(match_out, match, sizeof(double) * (size_t) K * N);
   free_common(&S);
   free(fp); free(match); free(fraglen); free(order); free(pisoscores); free(assscores); free(sfix);
-  (void) maxIterations;
   return ORC_SUCCESS;
 }

@@ -121,6 +121,7 @@ void orc_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
 void orc_philox_r(int rounds, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
                   uint32_t *out4);
 int orc_philox_rounds(void);
+int orc_convergent_mean(const double *samples, int K, int C, int noSamples);
 
 #ifdef __cplusplus
 }

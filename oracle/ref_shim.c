@@ -203,6 +203,16 @@ int ref_simulate_paired_reads(void *g, const double *expr, int K, int npairs,
   return rc;
 }
 
+/* the stopping rule of STOP_CONVERGENT_MEAN on its own (miso.c:556): samples K x n col-major */
+int ref_convergent_mean(const double *samples, int K, int C, int n) {
+  splicing_matrix_t s, means, vars; int stop = -1;
+  splicing_matrix_init(&s, K, n); splicing_matrix_init(&means, K, C); splicing_matrix_init(&vars, K, C);
+  memcpy(&MATRIX(s, 0, 0), samples, sizeof(double) * K * n);
+  if (splicing_i_check_convergent_mean(&means, &vars, &s, &stop)) stop = -1;
+  splicing_matrix_destroy(&vars); splicing_matrix_destroy(&means); splicing_matrix_destroy(&s);
+  return stop;
+}
+
 /* ---- the samplers --------------------------------------------------------- */
 
 /* samples: K x S col-major, S = C*(M-B)/lag; class_templates: K x ncls col-major

@@ -29,6 +29,7 @@ def load(name):
         else:
             cur.append(int(v))
     d["isoform_list"] = iso
-    for k in ("seed", "read_len", "overhang", "iters", "burn", "lag", "chains"):
-        d[k] = int(d[k])
+    for k in ("seed", "read_len", "overhang", "iters", "burn", "lag", "chains", "stop", "max_iters"):
+        if k in d:
+            d[k] = int(d[k])
     return d

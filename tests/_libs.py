@@ -99,6 +99,11 @@ class _Base:
     def integer(self, lo, hi):
         return self.f("integer")(lo, hi)
 
+    def convergent_mean(self, samples, chains):
+        """stop=CONVERGENT_MEAN's test (miso.c:556-636): samples S x K, row i from chain i % chains -> 1 stop / 0"""
+        a = np.ascontiguousarray(samples, dtype=np.float64)
+        return int(self.f("convergent_mean")(_p(a), a.shape[1], int(chains), a.shape[0]))
+
     # --- gene ---
     def gene(self, exons, isoforms):
         ex = np.asarray(exons, dtype=np.int32).reshape(-1)

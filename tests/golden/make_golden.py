@@ -81,6 +81,28 @@ def pe_case(R, name, K, N, seed, iters, burn, lag, chains, mean=250.0, var=900.0
          sim_isoform=iso, fraglen=fl, **pack_result(r))
 
 
+def convergent_case(R, name, paired, K, N, seed, iters, burn, lag, chains, max_iters, mean=250.0, var=900.0,
+                    read_len=36):
+    """stop=CONVERGENT_MEAN (miso.c:903-925 / miso_paired.c:501-523): schedules short enough that the first rounds do
+    not converge, so the fixture holds the LAST noSamples of a later round (miso.c:976-983)."""
+    exons, isoforms = se_gene(K, exlen=500, gap=300) if paired else se_gene(K)
+    g = R.gene(flat(exons), isoforms)
+    R.rng_seed(seed)
+    kw = dict(iters=iters, burn=burn, lag=lag, chains=chains)
+    if paired:
+        rc, iso, pos, cig = R.simulate_paired_reads(g, expr_for(K), N, read_len, mean, var)
+        r = R.miso_paired(g, pos, cig, read_len, mean, var, stop=1, max_iters=max_iters, **kw)
+        extra = dict(mean=mean, var=var)
+    else:
+        rc, iso, pos, cig = R.simulate_reads(g, expr_for(K), N, read_len)
+        r = R.miso(g, pos, cig, read_len, stop=1, max_iters=max_iters, **kw)
+        extra = {}
+    assert rc == 0 and r.rc == 0
+    save(name, kind="pe_conv" if paired else "se_conv", exons=np.asarray(exons, np.int32),
+         isoforms=iso_array(isoforms), expr=expr_for(K), seed=seed, read_len=read_len, overhang=1, stop=1,
+         max_iters=max_iters, pos=pos, cigars=np.array(cig), **kw, **extra, **pack_result(r))
+
+
 def cigar_edge_case(R):
     """Hand-written alignments exercising solve.c:220-306 / 8-108: clips, =, X, D, I, skips that
     do and do not match the annotation, overhang violations, short reads, reads off the gene."""
@@ -153,6 +175,12 @@ def main():
     saved = os.dup(1)
     os.dup2(devnull, 1)  # the reference prints "no chains: %d" (miso.c:837)
     try:
+        if sys.argv[1:] == ["convergent"]:   # only the fixtures added in round 4 (the others are unchanged)
+            convergent_case(R, "se_k3_convergent", False, 3, 200, 37, 50, 10, 1, 4, 700)
+            convergent_case(R, "se_k2_convergent", False, 2, 300, 41, 60, 20, 2, 3, 2000)
+            convergent_case(R, "pe_k2_convergent", True, 2, 200, 43, 60, 20, 2, 3, 1500)
+            convergent_case(R, "pe_k4_convergent", True, 4, 200, 47, 80, 30, 2, 2, 100000)
+            return
         se_case(R, "se_k2", 2, 400, 42, 1000, 200, 2, 1)
         se_case(R, "se_k2_default", 2, 300, 7, 1000, 100, 10, 6)
         se_case(R, "se_k3", 3, 300, 11, 600, 100, 5, 3, overhang=4)
@@ -164,6 +192,10 @@ def main():
         pe_case(R, "pe_k5", 5, 200, 31, 300, 50, 3, 1)
         cigar_edge_case(R)
         atp2b1_case(R)
+        convergent_case(R, "se_k3_convergent", False, 3, 200, 37, 50, 10, 1, 4, 700)
+        convergent_case(R, "se_k2_convergent", False, 2, 300, 41, 60, 20, 2, 3, 2000)
+        convergent_case(R, "pe_k2_convergent", True, 2, 200, 43, 60, 20, 2, 3, 1500)
+        convergent_case(R, "pe_k4_convergent", True, 4, 200, 47, 80, 30, 2, 2, 100000)
     finally:
         os.dup2(saved, 1)
     print("done")

@@ -66,8 +66,9 @@ def test_parameter_errors():
         miso_amd.Batch(36, chains=0)
     with pytest.raises(miso_amd.InternalError, match="one chain only"):
         miso_amd.Batch(36, chains=1, stop=capi.MISO_STOP_CONVERGENT_MEAN)
-    with pytest.raises(NotImplementedError):
-        miso_amd.Batch(36, chains=2, stop=capi.MISO_STOP_CONVERGENT_MEAN)
+    miso_amd.Batch(36, chains=2, stop=capi.MISO_STOP_CONVERGENT_MEAN)
+    with pytest.raises(miso_amd.InternalError, match="`stop` is invalid"):
+        miso_amd.Batch(36, chains=2, stop=2)
     with pytest.raises(NotImplementedError):
         miso_amd.Batch(36, algo=capi.MISO_ALGO_CLASSES)
     with pytest.raises(miso_amd.InternalError, match="start_psi"):
@@ -181,3 +182,29 @@ def test_read_classes_of_genes_with_more_than_32_isoforms(orc, ref, K, paired):
     e65, i65 = se_gene(65, exlen=60, gap=50)
     with pytest.raises(NotImplementedError, match="More than 64 isoforms"):
         miso_amd.Batch(36).add_event(miso_amd.Gene(e65, i65), pos[:4], cig[:4])
+
+
+def test_convergent_mean_rule_matches_the_checker_and_the_reference(orc):
+    """The stopping rule of stop=CONVERGENT_MEAN (miso.c:556-636) as the library's host code computes it, against the
+    checker's restatement and -- where oracle/_ref travelled -- the reference's own function: chains that agree, chains
+    apart, few samples, constant samples (W = 0 -> NaN -> not converged)."""
+    from _libs import RefLib
+    ref = RefLib() if RefLib.available() else None
+    rng = np.random.default_rng(5)
+    cases = []
+    for K, Cn, S, spread in [(2, 3, 60, 0.0), (2, 3, 60, 0.2), (3, 4, 160, 0.0), (5, 2, 40, 0.05), (2, 6, 2400, 0.0),
+                             (4, 2, 4, 0.0), (2, 2, 2, 0.0), (10, 6, 120, 0.3)]:
+        x = rng.dirichlet(np.ones(K) * 20, size=S)
+        x += spread * (np.arange(S) % Cn)[:, None] * np.eye(K)[0]      # chain j shifted by j * spread in isoform 0
+        cases.append((x, Cn))
+    cases.append((np.full((30, 2), 0.5), 3))                            # constant
+    seen = set()
+    for x, Cn in cases:
+        got = capi.selftest_convergent_mean(x, Cn)
+        assert int(got) == orc.convergent_mean(x, Cn)
+        if ref is not None:
+            assert int(got) == ref.convergent_mean(x, Cn)
+        seen.add(got)
+    assert seen == {True, False}
+    with pytest.raises(miso_amd.InternalError):
+        capi.selftest_convergent_mean(np.zeros((1, 2)), 2)

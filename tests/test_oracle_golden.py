@@ -58,6 +58,36 @@ def test_paired_end_golden(orc, name):
     assert np.array_equal(r.assignment, g["assignment"])
 
 
+@pytest.mark.parametrize("name", _golden.names("se_conv") + _golden.names("pe_conv"))
+def test_convergent_mean_golden(orc, name):
+    """stop=CONVERGENT_MEAN (miso.c:556-636, 903-925, 976-983; miso_paired.c:501-523): the oracle's rounds against the
+    real reference's -- the schedules are short enough that the first round does not converge, so what is compared is
+    the tail of a later round of the continued chains (and, paired-end, accept counts summed over the rounds)."""
+    g = _golden.load(name)
+    paired = str(g["kind"]) == "pe_conv"
+    kw = dict(iters=g["iters"], burn=g["burn"], lag=g["lag"], chains=g["chains"])
+
+    def run(stop):
+        gene = _replay(orc, g)
+        if paired:
+            mean, var = float(g["mean"]), float(g["var"])
+            orc.simulate_paired_reads(gene, g["expr"], len(g["pos"]) // 2, g["read_len"], mean, var)
+            return orc.miso_paired(gene, g["pos"], g["cigars"], g["read_len"], mean, var, stop=stop,
+                                   max_iters=g["max_iters"], **kw)
+        orc.simulate_reads(gene, g["expr"], len(g["pos"]), g["read_len"])
+        return orc.miso(gene, g["pos"], g["cigars"], g["read_len"], stop=stop, max_iters=g["max_iters"], **kw)
+
+    r = run(1)
+    assert r.rc == 0
+    filled = g["chains"] * ((g["iters"] - g["burn"]) // g["lag"])
+    assert np.array_equal(r.rundata, g["rundata"])
+    assert np.array_equal(r.samples[:filled], g["samples"][:filled])
+    assert np.array_equal(r.loglik[:filled], g["loglik"][:filled])
+    assert np.array_equal(r.assignment, g["assignment"])
+    fixed = run(0)                                    # more than one round ran: not the FIXEDNO answer
+    assert not np.array_equal(fixed.samples[:filled], g["samples"][:filled])
+
+
 def test_rng_stream_golden(orc):
     """MT19937 + inversion normal (random.c:301-448, 1543-1551): first draws after seeding."""
     g = _golden.load("se_k2")

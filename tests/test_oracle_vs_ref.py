@@ -73,6 +73,32 @@ def test_paired_end_bit_exact(ref, orc, K, N, chains, iters, burn, lag, mean, va
     _same(rR, rO, chains, iters, burn, lag)
 
 
+@pytest.mark.parametrize("K,N,chains,iters,burn,lag,max_iters,paired", [
+    (2, 300, 3, 60, 20, 2, 2000, False), (3, 200, 4, 50, 10, 1, 700, False), (5, 400, 2, 100, 40, 3, 100000, False),
+    (2, 300, 6, 500, 100, 10, 100000, False),        # converges in the first round
+    (2, 300, 2, 100, 40, 3, 100, False),             # maxIterations <= noIterations: one round (miso.c:908)
+    (2, 200, 3, 60, 20, 2, 1500, True), (4, 200, 2, 80, 30, 2, 100000, True)])
+def test_convergent_mean_bit_exact(ref, orc, K, N, chains, iters, burn, lag, max_iters, paired):
+    """stop=CONVERGENT_MEAN: the rounds of miso.c:903-925 / miso_paired.c:501-523 on the live reference."""
+    exons, isoforms = se_gene(K, exlen=500, gap=300) if paired else se_gene(K)
+    gR, gO = _pair(ref, orc, exons, isoforms)
+    ref.rng_seed(300 + K)
+    orc.rng_seed(300 + K)
+    kw = dict(iters=iters, burn=burn, lag=lag, chains=chains, stop=1, max_iters=max_iters)
+    if paired:
+        a = ref.simulate_paired_reads(gR, expr_for(K), N, 36, 250.0, 900.0)
+        b = orc.simulate_paired_reads(gO, expr_for(K), N, 36, 250.0, 900.0)
+        rR = ref.miso_paired(gR, a[2], a[3], 36, 250.0, 900.0, **kw)
+        rO = orc.miso_paired(gO, b[2], b[3], 36, 250.0, 900.0, **kw)
+    else:
+        a = ref.simulate_reads(gR, expr_for(K), N, 36)
+        b = orc.simulate_reads(gO, expr_for(K), N, 36)
+        rR = ref.miso(gR, a[2], a[3], 36, **kw)
+        rO = orc.miso(gO, b[2], b[3], 36, **kw)
+    assert rR.rc == rO.rc == 0
+    _same(rR, rO, chains, iters, burn, lag)
+
+
 def test_error_codes_match(ref, orc):
     exons, isoforms = se_gene(2)
     gR, gO = _pair(ref, orc, exons, isoforms)

@@ -55,7 +55,7 @@ def test_tuple_only_arguments_and_errors():
     with pytest.raises(pysplicing.InternalError, match="Unsupported CIGAR"):
         pysplicing.MISO(g, 0, (10,), ("36Q",), 36, 100, 10, 1, (1.0, 1.0), 1, 1)
     with pytest.raises(NotImplementedError):
-        pysplicing.MISO(g, 0, (10,), ("36M",), 36, 100, 10, 1, (1.0, 1.0), 1, 2, 0, 1)   # CONVERGENT_MEAN
+        pysplicing.MISO(g, 0, (10,), ("36M",), 36, 100, 10, 1, (1.0, 1.0), 1, 2, 2)      # START_RANDOM
     random.seed(5)
     a = pysplicing.simulateReads(g, 0, (0.3, 0.7), 20, 36)
     random.seed(5)
