@@ -314,9 +314,11 @@ SimReads simulate_paired_reads(const Gene &g, const double *expr, int npairs, in
 void validate_params(const miso_params_t &p) {
   // miso.c:674-717 / miso_paired.c:285-339, plus what this build does not restate
   if (!p.paired) {
-    if (p.algorithm == MISO_ALGO_MARGINAL || p.algorithm == MISO_ALGO_CLASSES)
-      MISO_FAIL(MISO_UNIMPLEMENTED, "Only the REASSIGN algorithm runs on the GPU");
-    if (p.algorithm != MISO_ALGO_REASSIGN) MISO_FAIL(MISO_EINVAL, "`algorithm` is invalid");
+    // (CLASSES: miso.c:790 sizes its `matches` vector with the still uninitialised noClasses and needs
+    // splicing_assignment_matrix's enumeration of every possible read class of the gene: not restated)
+    if (p.algorithm == MISO_ALGO_CLASSES)
+      MISO_FAIL(MISO_UNIMPLEMENTED, "The CLASSES algorithm is not implemented (REASSIGN and MARGINAL are)");
+    if (p.algorithm != MISO_ALGO_REASSIGN && p.algorithm != MISO_ALGO_MARGINAL) MISO_FAIL(MISO_EINVAL, "`algorithm` is invalid");
   }
   if (p.start == MISO_START_GIVEN)
     MISO_FAIL(MISO_EINVAL, "`start_psi' must be given when starting from a given PSI");
@@ -420,12 +422,17 @@ PackedEvent pack_event_masks(const miso_params_t &p, const FragmentDist *fd, int
   e.consts.assign(3 * K + CONST_EXTRA, 0.0);
   const int il = p.paired ? static_cast<int>(fd->prob.size()) : 0;
   std::vector<double> isoscore_tab;  // paired: il x K
+  const bool marginal = !p.paired && p.algorithm == MISO_ALGO_MARGINAL;
+  if (marginal && se_values) MISO_FAIL(MISO_UNIMPLEMENTED, "The MARGINAL algorithm needs a 0/1 match matrix");
   if (!p.paired) {
+    if (marginal) e.consts.resize(4 * K + CONST_EXTRA, 1.0);
     for (int k = 0; k < K; k++) {
       const int l = isolen[k] - p.readLength + 1 - 2 * (noexons[k] - 1) * (ov - 1);
       const int eff = l > 0 ? l : 0;
       e.consts[k] = std::log(static_cast<double>(eff));
       e.consts[K + k] = -std::log(static_cast<double>(l));
+      // miso.c:800-808: the marginal algorithm's match matrix is divided by the effective length where that is not 0
+      if (marginal && eff != 0) e.consts[3 * K + CONST_EXTRA + k] = 1.0 / eff;
     }
   } else {
     isoscore_tab.resize(static_cast<size_t>(il) * K);
@@ -618,6 +625,12 @@ PackedEvent pack_event_masks(const miso_params_t &p, const FragmentDist *fd, int
     for (const auto &kv : bcls) {
       for (int k = 0; k < K; k++) e.class_templates.push_back((kv.first >> (K - 1 - k)) & 1ull ? 1.0 : 0.0);
       e.class_counts.push_back(kv.second);
+      if (marginal && kv.first != 0) {   // the classes the marginal likelihood sums over, in this order (device.hpp)
+        uint64_t m = 0;
+        for (int k = 0; k < K; k++) m |= ((kv.first >> (K - 1 - k)) & 1ull) << k;
+        e.mcls_tab.insert(e.mcls_tab.end(), {static_cast<uint32_t>(m), static_cast<uint32_t>(m >> 32),
+                                            static_cast<uint32_t>(kv.second), 0u});
+      }
     }
   }
   for (const auto &kv : cls) {

@@ -115,6 +115,7 @@ struct PackedEvent {
   std::vector<uint16_t> draw_dense;     // raw little-endian storage; empty = not available
   std::vector<int32_t> sfix_dense;      // K x (il + 2)
   bool dense_nobad = false;             // no compatible (read, isoform) of a drawing read has a non-finite score
+  std::vector<uint32_t> mcls_tab;       // algorithm = MARGINAL: MCLS_WORDS per read class with a compatible isoform (device.hpp)
   std::vector<int32_t> fixed_ass;       // N: -1 / isoform for fixed reads, -2 for drawing reads
   // header material for the caller (miso.c:762, miso_paired.c:386-391)
   std::vector<double> class_templates;  // K x ncls

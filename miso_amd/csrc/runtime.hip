@@ -30,6 +30,7 @@ template <int MODE, int WPB> __global__ void sampler_k2_multi(const KernelArgs a
 __global__ void sampler_lane(const KernelArgs a);   // kernels_lane.hip: collapsed Gibbs step, one chain per lane
 template <int G> __global__ void sampler_k2c(const KernelArgs a);   // ... G lanes per chain (k2_body COLLAPSED)
 __global__ void sampler_lane_k(const KernelArgs a); // ... three and more isoforms (vectors in LDS)
+__global__ void sampler_marginal(const KernelArgs a); // kernels_marginal.hip: algorithm = MARGINAL, one chain per lane
 constexpr int LANEK_VECTORS = 9;
 inline size_t lanek_lds_bytes(int ks) { return static_cast<size_t>(LANEK_VECTORS) * ks * 64 * 8 + static_cast<size_t>(ks) * 64 * 4; }
 __global__ void compare_kernel(const DevEvent *, const unsigned char *, const DevEvent *, const unsigned char *, int, int,
@@ -313,6 +314,8 @@ void miso_batch::upload(int dev) {
       d.off_dense = in_off; in_off = align_up(in_off + e.draw_dense.size() * 2, 16);
       d.off_sfixd = in_off; in_off = align_up(in_off + e.sfix_dense.size() * 4, 16);
     }
+    d.n_mcls = static_cast<int32_t>(e.mcls_tab.size() / MCLS_WORDS);
+    d.off_mcls = in_off; in_off = align_up(in_off + e.mcls_tab.size() * 4, 16);
     d.off_samples = out_off; out_off = align_up(out_off + static_cast<uint64_t>(Sn) * e.K * 8, 16);
     d.off_loglik = out_off; out_off = align_up(out_off + static_cast<uint64_t>(Sn) * 8, 16);
     d.off_drawass = out_off; out_off = align_up(out_off + static_cast<uint64_t>(e.n_draw), 16);
@@ -346,6 +349,7 @@ void miso_batch::upload(int dev) {
       if (!e.dcls_pairs.empty())
         std::memcpy(h_in.data() + d.off_clsmask, e.dcls_pairs.data(), e.dcls_pairs.size() * 2);
     }
+    if (!e.mcls_tab.empty()) std::memcpy(h_in.data() + d.off_mcls, e.mcls_tab.data(), e.mcls_tab.size() * 4);
     if (!e.sfix_table.empty())
       std::memcpy(h_in.data() + d.off_sfix, e.sfix_table.data(), e.sfix_table.size() * 4);
     if (!e.draw_dense.empty()) {
@@ -477,6 +481,30 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   lanes_per_chain = 0;
   last_kernels.clear();
   if (!launched_once) coop_wgs_used = 0;
+
+  // ---- algorithm = MARGINAL (miso.c:272-283, 800-808): Metropolis-Hastings on psi alone, no reads to reassign ----
+  // One chain per lane, every event of the batch in one launch (kernels_marginal.hip); its vectors live in LDS,
+  // [vector][isoform][lane], 64 lanes per workgroup up to 32 isoforms, 32 beyond.
+  if (!p.paired && p.algorithm == MISO_ALGO_MARGINAL) {
+    int ks = 2;
+    for (const PackedEvent &e : events) ks = std::max(ks, e.K);
+    const int lanes = ks <= 32 ? 64 : 32;
+    KernelArgs ka = a;
+    ka.slot_event = d_slots; ka.n_slots = n; ka.kstride = ks;
+    const long chains = static_cast<long>(n) * p.noChains;
+    const size_t lds = marginal_lds_bytes(ks, lanes);
+    stats_builder = nullptr; kernel_stats.clear();
+    HIP_OK(hipEventRecord(ev0, stream));
+    if (chains > 0) {
+      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sampler_marginal), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+      hipLaunchKernelGGL(sampler_marginal, dim3(static_cast<unsigned>((chains + lanes - 1) / lanes)), dim3(lanes), lds, stream, ka);
+      HIP_OK(hipGetLastError());
+    }
+    HIP_OK(hipEventRecord(ev1, stream));
+    last_kernels = "sampler_marginal";
+    launched = true; launched_once = true; downloaded = false; summarized = false; compared = false;
+    return;
+  }
 
   // ---- two-isoform events: sampler_k2<G> ----
   const size_t k2_fp = p.paired ? align_up(fd.prob.size() * 8, 16) : 0;

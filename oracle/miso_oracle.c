@@ -658,6 +658,7 @@ typedef struct {
   int counter;           /* opts->mode == ORC_MODE_COUNTER or ORC_MODE_COLLAPSED */
   int collapsed;         /* opts->mode == ORC_MODE_COLLAPSED: reassign_collapsed() except for the run's last reassignment */
   int count_sums;        /* use count-based score sums */
+  int marginal;          /* SPLICING_ALGO_MARGINAL: no assignments, the reads enter through the marginal likelihood */
   const double *match;   /* K x N */
   const int *order;      /* N (stream mode draw order) */
   int *corder;           /* N (counter mode draw order, single-end): see counter_order() */
@@ -858,6 +859,34 @@ static double score_joint(const orc_state_t *S, int chain, const double *psi) {
   const int *ass = S->ass + (size_t) chain * N;
   double logpsi[64] = { 0 }, maxv, sum, readProb = 0.0, assProb = 0.0;
   int32_t cnt[64];
+  if (S->marginal) { /* miso.c:272-283; S->match holds match / effective length (miso.c:800-808) */
+    int k;
+    if (!S->count_sums) {
+      for (i = 0; i < N; i++) {
+        double isoscore = 0.0;
+        for (k = 0; k < K; k++) isoscore += S->match[(size_t) i * K + k] * psi[k];
+        if (isoscore != 0) readProb += S->M->log(isoscore);
+      }
+    } else { /* counter contract: class by class in counter order (= the order of the header's classes), count x log */
+      int ii = 0;
+      while (ii < N) {
+        const double *col = S->match + (size_t) S->corder[ii] * K;
+        int jj = ii + 1, nv = 0;
+        double isoscore = 0.0;
+        while (jj < N) {
+          const double *c2 = S->match + (size_t) S->corder[jj] * K;
+          int same = 1;
+          for (k = 0; k < K && same; k++) same = (col[k] != 0) == (c2[k] != 0);
+          if (!same) break;
+          jj++;
+        }
+        for (k = 0; k < K; k++) if (col[k] != 0) { isoscore += col[k] * psi[k]; nv++; }
+        if (nv > 0 && isoscore != 0) readProb = readProb + (double) (jj - ii) * S->M->log(isoscore);
+        ii = jj;
+      }
+    }
+    return readProb + assProb + ldirichlet(S, psi);
+  }
   for (i = 0; i < K; i++)
     logpsi[i] = S->M->log(psi[i]) + (S->paired ? S->assscores[i] : S->logeff[i]);
   maxv = logpsi[0];
@@ -969,6 +998,7 @@ static void run_chains(orc_state_t *S, int noIterations, int noBurnIn, int noLag
         lagCounter++;
       }
     }
+    if (S->marginal) continue;   /* miso.c:895: only the REASSIGN algorithm reassigns */
     if (S->collapsed && m != noIterations - 1) reassign_collapsed(S, (uint32_t) m); else reassign(S, (uint32_t) m);
   }
   for (j = 0; j < C; j++) {
@@ -1052,7 +1082,11 @@ static void run_rounds(orc_state_t *S, int start, int stop, int noIterations, in
   for (;; round++) {
     if (round == 0 || S->counter) {
       init_chains(S, start);            /* miso.c:827-835 */
-      if (S->N > 0) {                   /* miso.c:841 */
+      if (S->marginal) {                /* miso.c:839-842: no assignment to start from */
+        size_t i;
+        for (i = 0; i < (size_t) (S->N > 0 ? S->N : 1) * C; i++) S->ass[i] = -1;
+        if (S->counter && !S->corder) counter_order(S);
+      } else if (S->N > 0) {            /* miso.c:841 */
         if (S->collapsed && noIterations > 0) reassign_collapsed(S, MISO_ITER_INIT); else reassign(S, MISO_ITER_INIT);
       }
     }
@@ -1132,8 +1166,9 @@ int orc_miso(const orc_gene_t *g, const int *pos, const char **cigar, int nreads
   double *match; int *order, *eff; double *logeff, *isoscores;
   static const orc_opts_t stream_opts = { ORC_MODE_STREAM, 0, 0, 0 };
   if (!opts) opts = &stream_opts;
-  if (algorithm == 1 || algorithm == 2) return ORC_UNIMPLEMENTED; /* MARGINAL, CLASSES */
-  if (algorithm != ORC_ALGO_REASSIGN) return ORC_EINVAL;          /* miso.c:674-678 */
+  if (algorithm == 2) return ORC_UNIMPLEMENTED;                   /* CLASSES: not restated */
+  if (algorithm != ORC_ALGO_REASSIGN && algorithm != 1) return ORC_EINVAL; /* miso.c:674-678 */
+  if (algorithm == 1 && opts->mode == ORC_MODE_COLLAPSED) return ORC_EINVAL; /* nothing to collapse: no assignments */
   rc = check_common(g, &overHang, readLength, noChains, noIterations, noBurnIn, noLag, nhyper,
                     start, stop);
   if (rc) return rc;
@@ -1157,13 +1192,23 @@ int orc_miso(const orc_gene_t *g, const int *pos, const char **cigar, int nreads
     isoscores[i] = -log((double) l);
     logeff[i] = log((double) eff[i]); /* miso.c:136-138 */
   }
+  if (algorithm == 1) { /* miso.c:800-808: "probabilities divided by effective isoform length" (after the classes and
+                           the read order were taken from the 0/1 matrix) */
+    int j;
+    for (i = 0; i < K; i++) for (j = 0; j < nreads; j++)
+      if (eff[i] != 0) match[(size_t) j * K + i] /= eff[i];
+  }
   fill_common(&S, g, opts, hyper, noChains, nreads);
+  S.marginal = algorithm == 1;
   S.match = match; S.order = order; S.effisolen = eff; S.logeff = logeff; S.isoscores = isoscores;
   memset(samples, 0, sizeof(double) * (size_t) K * noSamples);
   memset(logLik, 0, sizeof(double) * noSamples);
 
   run_rounds(&S, start, stop, noIterations, maxIterations, noBurnIn, noLag, samples, logLik, rundata, trace);
 
+  /* miso.c:936-942: "This might not have been calculated, so we calculate it now" -- every chain, from the final psi;
+     counter mode: the Gibbs words of MISO_ITER_INIT, which this algorithm has not used */
+  if (S.marginal && nreads > 0) reassign(&S, MISO_ITER_INIT);
   for (i = 0; i < nreads; i++) assignment[i] = S.ass[i]; /* chain 0: miso.c:943-946 */
   if (match_out) memcpy(match_out, match, sizeof(double) * (size_t) K * nreads);
   free_common(&S);

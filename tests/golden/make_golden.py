@@ -103,6 +103,28 @@ def convergent_case(R, name, paired, K, N, seed, iters, burn, lag, chains, max_i
          max_iters=max_iters, pos=pos, cigars=np.array(cig), **kw, **extra, **pack_result(r))
 
 
+def marginal_case(R, name, K, N, seed, iters, burn, lag, chains, overhang=1, read_len=36, stop=0, max_iters=100000):
+    """algorithm=MARGINAL (miso.c:272-283, 800-808): no assignments, the match matrix divided by the effective lengths
+    (which is also how the reference hands it back), one reassignment at the end for the returned vector."""
+    exons, isoforms = se_gene(K)
+    g = R.gene(flat(exons), isoforms)
+    R.rng_seed(seed)
+    rc, iso, pos, cig = R.simulate_reads(g, expr_for(K), N, read_len)
+    r = R.miso(g, pos, cig, read_len, iters=iters, burn=burn, lag=lag, chains=chains, overhang=overhang, algo=1,
+               stop=stop, max_iters=max_iters)
+    assert rc == 0 and r.rc == 0
+    save(name, kind="se_marginal", exons=np.asarray(exons, np.int32), isoforms=iso_array(isoforms), expr=expr_for(K),
+         seed=seed, read_len=read_len, overhang=overhang, iters=iters, burn=burn, lag=lag, chains=chains, stop=stop,
+         max_iters=max_iters, pos=pos, cigars=np.array(cig), **pack_result(r))
+
+
+def marginal_cases(R):
+    marginal_case(R, "se_k2_marginal", 2, 300, 53, 600, 100, 2, 2)
+    marginal_case(R, "se_k3_marginal", 3, 300, 59, 500, 100, 5, 3, overhang=4)
+    marginal_case(R, "se_k6_marginal", 6, 500, 61, 400, 100, 3, 2)
+    marginal_case(R, "se_k3_marginal_convergent", 3, 200, 67, 50, 10, 1, 4, stop=1, max_iters=700)
+
+
 def cigar_edge_case(R):
     """Hand-written alignments exercising solve.c:220-306 / 8-108: clips, =, X, D, I, skips that
     do and do not match the annotation, overhang violations, short reads, reads off the gene."""
@@ -175,6 +197,9 @@ def main():
     saved = os.dup(1)
     os.dup2(devnull, 1)  # the reference prints "no chains: %d" (miso.c:837)
     try:
+        if sys.argv[1:] == ["marginal"]:     # likewise
+            marginal_cases(R)
+            return
         if sys.argv[1:] == ["convergent"]:   # only the fixtures added in round 4 (the others are unchanged)
             convergent_case(R, "se_k3_convergent", False, 3, 200, 37, 50, 10, 1, 4, 700)
             convergent_case(R, "se_k2_convergent", False, 2, 300, 41, 60, 20, 2, 3, 2000)
@@ -196,6 +221,7 @@ def main():
         convergent_case(R, "se_k2_convergent", False, 2, 300, 41, 60, 20, 2, 3, 2000)
         convergent_case(R, "pe_k2_convergent", True, 2, 200, 43, 60, 20, 2, 3, 1500)
         convergent_case(R, "pe_k4_convergent", True, 4, 200, 47, 80, 30, 2, 2, 100000)
+        marginal_cases(R)
     finally:
         os.dup2(saved, 1)
     print("done")

@@ -78,7 +78,7 @@ def test_batch_where_some_events_converge_and_some_do_not(orc, paired):
     equals the checker's run of it alone (its random stream is addressed by its id, not by the round's batch), the
     summaries are those of the returned samples, and a second launch of the same batch repeats the rounds."""
     rng = np.random.default_rng(3)
-    iters, burn, lag, chains, max_iters = 90, 30, 2, 3, 3000
+    iters, burn, lag, chains, max_iters = 200, 50, 2, 3, 3000
     kw = dict(iters=iters, burn=burn, lag=lag, chains=chains, stop=1, max_iters=max_iters)
     if paired:
         b = miso_amd.Batch(36, paired=True, mean=250.0, var=900.0, **kw)

@@ -15,7 +15,7 @@ from miso_amd import capi
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", _golden.names())
+@pytest.mark.parametrize("name", _golden.names("se") + _golden.names("pe"))
 def test_golden_inputs_bit_exact(orc, name):
     g = _golden.load(name)
     paired = str(g["kind"]) == "pe"

@@ -71,6 +71,9 @@ def test_parameter_errors():
         miso_amd.Batch(36, chains=2, stop=2)
     with pytest.raises(NotImplementedError):
         miso_amd.Batch(36, algo=capi.MISO_ALGO_CLASSES)
+    miso_amd.Batch(36, algo=capi.MISO_ALGO_MARGINAL)
+    with pytest.raises(miso_amd.InternalError, match="`algorithm` is invalid"):
+        miso_amd.Batch(36, algo=3)
     with pytest.raises(miso_amd.InternalError, match="start_psi"):
         miso_amd.Batch(36, start=capi.MISO_START_GIVEN)
     G = miso_amd.Gene([(1, 100), (201, 300), (401, 500)], [[0, 1, 2], [0, 2]])

@@ -88,6 +88,25 @@ def test_convergent_mean_golden(orc, name):
     assert not np.array_equal(fixed.samples[:filled], g["samples"][:filled])
 
 
+@pytest.mark.parametrize("name", _golden.names("se_marginal"))
+def test_marginal_algorithm_golden(orc, name):
+    """algorithm=MARGINAL (miso.c:272-283, 800-808, 936-946) against the real reference's run: samples, log scores,
+    accept counts, the match matrix as the reference returns it (divided by the effective lengths) and the one
+    reassignment made after the run."""
+    g = _golden.load(name)
+    gene = _replay(orc, g)
+    orc.simulate_reads(gene, g["expr"], len(g["pos"]), g["read_len"])
+    r = orc.miso(gene, g["pos"], g["cigars"], g["read_len"], iters=g["iters"], burn=g["burn"], lag=g["lag"],
+                 chains=g["chains"], overhang=g["overhang"], algo=1, stop=g["stop"], max_iters=g["max_iters"])
+    assert r.rc == 0
+    for f in ("match", "class_templates", "class_counts", "rundata", "assignment"):
+        assert np.array_equal(getattr(r, f), g[f]), f
+    assert not np.isin(g["match"], (0.0, 1.0)).all()
+    filled = g["chains"] * ((g["iters"] - g["burn"]) // g["lag"])
+    assert np.array_equal(r.samples[:filled], g["samples"][:filled])
+    assert np.array_equal(r.loglik[:filled], g["loglik"][:filled])
+
+
 def test_rng_stream_golden(orc):
     """MT19937 + inversion normal (random.c:301-448, 1543-1551): first draws after seeding."""
     g = _golden.load("se_k2")

@@ -99,6 +99,24 @@ def test_convergent_mean_bit_exact(ref, orc, K, N, chains, iters, burn, lag, max
     _same(rR, rO, chains, iters, burn, lag)
 
 
+@pytest.mark.parametrize("K,N,ov,chains,iters,burn,lag,stop", [
+    (2, 300, 1, 2, 400, 100, 2, 0), (3, 300, 4, 3, 500, 100, 5, 0), (5, 400, 1, 2, 300, 50, 3, 0),
+    (8, 500, 2, 1, 300, 60, 1, 0), (12, 600, 1, 2, 200, 40, 2, 0), (3, 200, 1, 4, 50, 10, 1, 1), (2, 20, 1, 3, 200, 50, 2, 0)])
+def test_marginal_algorithm_bit_exact(ref, orc, K, N, ov, chains, iters, burn, lag, stop):
+    """algorithm=MARGINAL on the live reference (miso.c:272-283, 800-808, 936-946), also under stop=CONVERGENT_MEAN."""
+    exons, isoforms = se_gene(K)
+    gR, gO = _pair(ref, orc, exons, isoforms)
+    ref.rng_seed(400 + K)
+    orc.rng_seed(400 + K)
+    a = ref.simulate_reads(gR, expr_for(K), N, 36)
+    b = orc.simulate_reads(gO, expr_for(K), N, 36)
+    kw = dict(iters=iters, burn=burn, lag=lag, chains=chains, overhang=ov, algo=1, stop=stop, max_iters=700)
+    rR = ref.miso(gR, a[2], a[3], 36, **kw)
+    rO = orc.miso(gO, b[2], b[3], 36, **kw)
+    assert rR.rc == rO.rc == 0
+    _same(rR, rO, chains, iters, burn, lag)
+
+
 def test_error_codes_match(ref, orc):
     exons, isoforms = se_gene(2)
     gR, gO = _pair(ref, orc, exons, isoforms)
