@@ -95,3 +95,25 @@ def test_marginal_differs_from_reassign_and_needs_single_end(orc):
     assert np.abs(out[0] - out[1]).max() > 1e-3      # another model (miso.c:272-283 has no length-normalised prior)
     with pytest.raises(NotImplementedError):
         miso_amd.Batch(36, algo=capi.MISO_ALGO_CLASSES)
+
+
+def test_the_module_call_takes_both_switches(orc):
+    """pysplicing.MISO(gene, 0, positions, cigars, readLength, noIterations, noBurnIn, noLag, hyperp, overhang,
+    no_chains, start, stop, algo) (pysplicing.c:41-131) with stop=CONVERGENT_MEAN and algo=MARGINAL: the tuple the
+    reference's module returns, from the same run as the checker's."""
+    from miso_amd import pysplicing
+    g = _golden.load("se_k3_marginal_convergent")
+    gene = pysplicing.createGene(tuple(g["exon_list"]), tuple(tuple(i) for i in g["isoform_list"]))
+    res = pysplicing.MISO(gene, 0, tuple(int(p) for p in g["pos"]), tuple(c.decode() for c in g["cigars"]), g["read_len"],
+                          g["iters"], g["burn"], g["lag"], (1.0,) * 3, g["overhang"], g["chains"],
+                          pysplicing.MISO_START_AUTO, pysplicing.MISO_STOP_CONVERGENT_MEAN, pysplicing.MISO_ALGO_MARGINAL,
+                          seed=11)
+    og = orc.gene(flat(g["exon_list"]), g["isoform_list"])
+    # (the module's maxIterations is the reference's 100000, pysplicing.c:43)
+    cpu = orc.miso(og, g["pos"], g["cigars"], g["read_len"], iters=g["iters"], burn=g["burn"], lag=g["lag"],
+                   chains=g["chains"], overhang=g["overhang"], algo=1, stop=1, max_iters=100000, mode=OrcLib.COUNTER,
+                   seed=11, event_id=0)
+    assert cpu.rc == 0
+    assert np.array_equal(np.transpose(np.array(res[0])), cpu.samples)
+    assert np.array_equal(np.array(res[1]), cpu.loglik)
+    assert list(res[4]) == list(cpu.assignment)
