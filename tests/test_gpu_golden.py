@@ -53,9 +53,16 @@ def test_golden_inputs_bit_exact(orc, name):
     assert (np.abs(a.mean(0) - r.mean(0)) < tol).all(), (a.mean(0), r.mean(0), tol)
 
 
-@pytest.mark.parametrize("K,paired,n", [(5, True, 600), (10, True, 700), (10, False, 800), (3, True, 500), (5, False, 700),
-                                        (2, False, 600), (2, True, 500)])
-def test_device_posterior_within_monte_carlo_error_of_the_real_reference(ref, K, paired, n):
+@pytest.mark.parametrize("K,paired,n,switches", [
+    (5, True, 600, {}), (10, True, 700, {}), (10, False, 800, {}), (3, True, 500, {}), (5, False, 700, {}),
+    (2, False, 600, {}), (2, True, 500, {}),
+    # algorithm = MARGINAL (sampler_marginal) and stop = CONVERGENT_MEAN (the device re-runs the longer schedule from the
+    # start where the reference continues its chains: the same law, tested as such)
+    (3, False, 500, dict(algo=1)), (6, False, 700, dict(algo=1)),
+    (2, False, 500, dict(stop=1, iters=200, burn=50, lag=2, chains=3, max_iters=3000)),
+    (3, True, 400, dict(stop=1, iters=200, burn=50, lag=2, chains=3, max_iters=3000)),
+    (4, False, 500, dict(algo=1, stop=1, iters=200, burn=50, lag=2, chains=3, max_iters=3000))])
+def test_device_posterior_within_monte_carlo_error_of_the_real_reference(ref, K, paired, n, switches):
     """The GPU against the REAL reference C core (oracle/_ref, independent random streams), every kernel family, ALL
     isoforms, posterior mean and both Chen-Shao bounds -- as a TWO-sample test: 10 genes, each under 8 random streams on
     the GPU (8 copies of the gene with different ids in the Philox counter, one launch) and under 8 seeds of the
@@ -66,7 +73,7 @@ def test_device_posterior_within_monte_carlo_error_of_the_real_reference(ref, K,
     miso_paired.c:451-498, credible_intervals.py:31-55."""
     import _dpsi
     from _problems import se_gene, expr_for
-    kw = dict(iters=3000, burn=1000, lag=2, chains=1)
+    kw = dict(dict(iters=3000, burn=1000, lag=2, chains=1), **switches)
     n_genes, n_streams = 10, 8
     b = miso_amd.Batch(36, paired=paired, mean=250.0 if paired else 0.0, var=900.0 if paired else 0.0, device_match=True, **kw)
     probs = []

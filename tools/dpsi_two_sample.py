@@ -28,7 +28,10 @@ def work(job):
     import bench
     L = RefLib() if kind == "reference" else OrcLib()
     out = []
-    kw = dict(iters=sh["iters"], burn=sh["burn"], lag=sh["lag"], chains=sh["chains"])
+    kw = dict(iters=sh["iters"], burn=sh["burn"], lag=sh["lag"], chains=sh["chains"], stop=sh.get("stop", 0),
+              max_iters=sh.get("max_iters", 100000))
+    if not sh["paired"]:
+        kw["algo"] = sh.get("algo", 0)
     cache = {}
     for e, seed in ev_seeds:
         if e not in cache:
@@ -64,11 +67,15 @@ def main():
     ap.add_argument("--burn", type=int, default=2500)
     ap.add_argument("--lag", type=int, default=1)
     ap.add_argument("--perm", type=int, default=9999)
+    ap.add_argument("--algo", type=int, default=0, help="1 = MARGINAL (single-end)")
+    ap.add_argument("--stop", type=int, default=0, help="1 = CONVERGENT_MEAN")
+    ap.add_argument("--max-iters", type=int, default=100000)
     a = ap.parse_args()
     import bench
     import _dpsi
     sh = dict(bench.BASE_SHAPE, K=tuple(a.K_range) if a.K_range else a.K, reads=("hg19" if a.reads == "hg19" else int(a.reads)),
-              paired=a.paired, chains=a.chains, iters=a.iters, burn=a.burn, lag=a.lag)
+              paired=a.paired, chains=a.chains, iters=a.iters, burn=a.burn, lag=a.lag, algo=a.algo, stop=a.stop,
+              max_iters=a.max_iters)
     cores = bench.usable_cores()
     ref = [(e, 1000003 * (s + 1) + e) for e in range(a.events) for s in range(a.seeds)]
     oth = [(e, 7000003 * (s + 1) + e) for e in range(a.events) for s in range(a.seeds)]
@@ -85,7 +92,7 @@ def main():
     events = sorted(runs_ref)
     kmax = max(len(runs_ref[e][0][0]) for e in events)
     r = _dpsi.two_sample(_dpsi.stack_runs(runs_oth, events, kmax), _dpsi.stack_runs(runs_ref, events, kmax), n_perm=a.perm)
-    r["shape"] = {k: sh[k] for k in ("K", "reads", "paired", "chains", "iters", "burn", "lag")}
+    r["shape"] = {k: sh[k] for k in ("K", "reads", "paired", "chains", "iters", "burn", "lag", "algo", "stop", "max_iters")}
     r["mode"] = a.mode
     r["cpu_wall_s"] = round(wall, 1)
     print(json.dumps(r))
