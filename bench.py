@@ -313,14 +313,19 @@ def load_json(name):
 
 def valu_floor(K, paired, draws_per_chain):
     """VALU wave-instructions one chain-iteration cannot avoid in this formulation: one
-    Philox4x32 block per four draws (4 x (rounds - 1) = 24 at the contract's 7 rounds, round 0 hoisted), per draw K - 1 compare-and-count pairs
+    Philox4x32 block per four draws -- per EIGHT for single-end two-isoform events -- (4 x (rounds - 1) = 24 at the contract's 7 rounds, round 0 hoisted), per draw K - 1 compare-and-count pairs
     (single-end; paired-end ~15 per read and compatible isoform for weights, compare, select, score gather), and the
     scalar step's 5K + 3 transcendentals at ~55 instructions each if every lane of a wavefront has one to do, plus
     its ~3K divisions."""
     K = float(K)
     philox = 4.0 * (PHILOX_ROUNDS - 1)    # 2 multiplies + 2 three-input xors per round, round 0 hoisted
+    scalar = ((5.0 * K + 3.0) * 55.0 + 3.0 * K * 10.0) / 64.0
+    if not paired and K == 2:
+        # lazy low bits (include/miso_philox.h): one block per EIGHT draws; per draw a compare-and-count pair on the
+        # high half-word and the test for equality with the threshold's
+        return draws_per_chain / 512.0 * (philox + 8.0 * 3.0) + scalar
     per_block = philox + (8.0 * (K - 1.0) if not paired else 30.0 * K)
-    return draws_per_chain / 256.0 * per_block + ((5.0 * K + 3.0) * 55.0 + 3.0 * K * 10.0) / 64.0
+    return draws_per_chain / 256.0 * per_block + scalar
 
 
 def roofline_for(batch, kernel_ms, key, sh):
@@ -374,7 +379,9 @@ def roofline_for(batch, kernel_ms, key, sh):
     out["draws_per_chain"] = round(draws, 1)
     # (tools/rng_bench.hip, MI355X: philox4x32-10 2885 G words/s, philox4x32-7 the same generator at 7 / 10 of the rounds)
     rng_ceiling = load_json("rng_ceiling.json").get("philox4x32_7_outputs_per_s", 2885e9 * 10.0 / 7.0)
-    out["rng_frac"] = round(stats["uniforms"] / t / rng_ceiling, 4)
+    # (single-end two-isoform events draw half-words: two reads per generated word, include/miso_philox.h)
+    halves = (not sh["paired"]) and sh["K"] == 2 and not key.endswith("|collapsed")
+    out["rng_frac"] = round(stats["uniforms"] * (0.5 if halves else 1.0) / t / rng_ceiling, 4)
     out["rng_note"] = "Philox4x32-7 words consumed / s over the chip's ceiling for that generator (tools/rng_bench.hip)"
     traffic = load_json("traffic.json").get(key)
     out["traffic"] = None if traffic is None else traffic["hbm_bytes_per_launch"]

@@ -18,11 +18,23 @@
  *                           (words continue into block 1, 2, ... for K-1 > 1 normals)
  *   site MISO_SITE_GIBBS (2): word r (block r/4, lane r%4) = the uniform of the r-th read that
  *                           has >= 2 compatible isoforms, counted in read order (miso.c:69-80)
+ *                           -- except single-end events with TWO isoforms (LAZY LOW BITS, below): there
+ *                           half-word r (block r/8, half r%8; half h = bits 16 (h & 1) .. + 15 of word h / 2)
+ *                           is the HIGH half of the read's 32-bit uniform and the same half-word of site
+ *   site MISO_SITE_GIBBS_LOW (4)  its LOW half
  *   iteration = m for the main loop (miso.c:847), MISO_ITER_INIT for the set-up draws
  *   (initial proposal miso.c:834 and initial assignment miso.c:841).
  *
  * A uniform is u32 * 2^-32, the same 32-bit resolution as the reference's stand-alone
  * generator (random.c:382 splicing_rng_mt19937_get_real).
+ *
+ * LAZY LOW BITS (round 4).  A two-isoform single-end read picks isoform 0 iff its uniform u (32 bits) is below a
+ * threshold t that is the same for all reads of the chain in that step (miso.c:65-72: rand * sumpsi < cumsum[0]).
+ * With u = hi * 2^16 + lo:  u < t  <=>  hi < (t >> 16)  or  (hi == (t >> 16) and lo < (t & 0xFFFF)).  The high halves
+ * decide all but one read in 65 536, so the device generates ONE block per EIGHT reads and evaluates the second
+ * stream only for a block in which some high half equals t >> 16; the checker assembles both halves for every read.
+ * Same 32-bit uniforms, same law, the same picks on both sides bit for bit -- and half the generator work in the loop
+ * that is nothing but generator work (24 of 32 instructions per four reads).
  *
  * Philox4x32: Salmon, Moraes, Dror, Shaw, "Parallel random numbers: as easy as 1, 2, 3", SC'11 -- constants and round
  * function as published there; pinned to the Random123 distribution's known-answer vectors at 7 AND at 10 rounds
@@ -53,6 +65,7 @@
 
 #define MISO_SITE_MH    0u
 #define MISO_SITE_GIBBS 2u
+#define MISO_SITE_GIBBS_LOW 4u   /* (3 = MISO_SITE_COUNTS, miso_binomial.h) */
 #define MISO_ITER_INIT  0xFFFFFFFFu
 
 #define MISO_PHILOX_M0 0xD2511F53u
@@ -109,6 +122,18 @@ MISO_HD miso_u32x4 miso_draw_block(uint64_t seed, uint32_t event_id, uint32_t ch
                                    uint32_t iteration, uint32_t site, uint32_t block) {
   return miso_philox4x32(block, iteration, site | (chain << 8), event_id,
                             (uint32_t) seed, (uint32_t) (seed >> 32));
+}
+
+/* Half-word h (0..7) of a block: the lazy-low-bits uniforms of single-end two-isoform events (header comment). */
+MISO_HD uint32_t miso_block_half(miso_u32x4 b, uint32_t h) {
+  const uint32_t w = (h >> 1) == 0 ? b.v[0] : ((h >> 1) == 1 ? b.v[1] : ((h >> 1) == 2 ? b.v[2] : b.v[3]));
+  return (w >> (16u * (h & 1u))) & 0xFFFFu;
+}
+/* ... and the 32-bit uniform word of the r-th drawing read of such an event */
+MISO_HD uint32_t miso_split_word(uint64_t seed, uint32_t event_id, uint32_t chain, uint32_t iteration, uint32_t r) {
+  const miso_u32x4 hi = miso_draw_block(seed, event_id, chain, iteration, MISO_SITE_GIBBS, r >> 3);
+  const miso_u32x4 lo = miso_draw_block(seed, event_id, chain, iteration, MISO_SITE_GIBBS_LOW, r >> 3);
+  return (miso_block_half(hi, r & 7u) << 16) | miso_block_half(lo, r & 7u);
 }
 
 /* Paired-end fragment scores (miso_paired.c:157-163) are summed in fixed point so that the sum does

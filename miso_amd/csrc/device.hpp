@@ -106,7 +106,7 @@ struct KernelArgs {
                             // take the heaviest and the lightest remaining chain group (runtime.hip)
   int32_t pe_dense;         // sampler_grp PE: every event of the launch has dense records (pe_dense) and the LDS
                             // probability table carries the two extra entries PE_ZERO, PE_ONE (0 = the quad loops of pe_quads)
-  int32_t pe_force_exact;   // tests: every read through pe_dense's exact (cold) scan
+  int32_t pe_force_exact;   // tests: every read through pe_dense's exact (cold) scan; the single-end two-isoform loop: every lane rescans its blocks for high halves on the threshold
   int32_t flat_desc;        // sampler_flat: read loop over the unit descriptors (flat_units_desc), 0 = the walking loop
   int32_t flat_thr_skip;    // sampler_flat: thresholds only for the chains whose psi changed in the last Metropolis-Hastings step
   int32_t mix_blocks;       // sampler_k2_mix<GA, GB>: the first mix_blocks workgroups run the first mix_slots events

@@ -377,7 +377,9 @@ __device__ __forceinline__ void k2_body(const KernelArgs &a, unsigned block_x, u
   c.sigma = consts[8]; c.sd = consts[9]; c.covar = consts[10];
   const int base0 = base[0], base1 = base[1];
   const int n_draw = E.n_draw;
-  const int nfq = n_draw >> 2, rem = n_draw & 3;  // full draw quads, draws in the partial one
+  // full blocks of draws and the draws of the partial one: a Philox block is four reads paired-end, EIGHT single-end (one
+  // half-word each: the lazy low bits of include/miso_philox.h)
+  const int nfq = PE ? n_draw >> 2 : n_draw >> 3, rem = PE ? n_draw & 3 : n_draw & 7;
   // trips of the Gibbs loop (UQ quads per lane per trip); must be wave-uniform
   constexpr int UQ = PE ? 2 : MISO_K2_UQ;
   int trips = (nfq + UQ * GE - 1) / (UQ * GE);
@@ -605,31 +607,96 @@ __device__ __forceinline__ void k2_body(const KernelArgs &a, unsigned block_x, u
       }
     }
     PROF_T(g0);
+    // u < t with u = hi 2^16 + lo:  hi < t >> 16, or hi == t >> 16 and lo < (t & 0xFFFF).  The loop looks at the high
+    // halves only -- eight reads per Philox block -- and notes the block in which one of them EQUALS t >> 16 (one read
+    // in 65 536); that block's low halves (site MISO_SITE_GIBBS_LOW) are drawn behind the loop, by the lane that owns it.
     const uint64_t t = k2_threshold(cur.x0, (0.0 + cur.x0) + cur.x1);
-    const uint32_t tm = static_cast<uint32_t>(t - 1);  // u < t  <=>  t != 0 && u <= t - 1
+    const uint32_t th = static_cast<uint32_t>(t >> 16), tl = static_cast<uint32_t>(t) & 0xFFFFu;   // th <= 65536
     const uint32_t n0r0 = rng.p1hi ^ iter ^ k0;
-    int d0 = 0;
+    int d0 = 0, amb_n = 0; uint32_t amb_q = 0;
     PROF_T(g1);
     PROF_ADD(pf_thr, g0, g1);
+    auto halves = [&](const miso_u32x4 &u, int nh, int &below, int &equal) __attribute__((always_inline)) {
+      below = 0; equal = 0;
+#pragma unroll
+      for (int h = 0; h < 8; h++) {
+        const uint32_t x = (h & 1) ? (u.v[h >> 1] >> 16) : (u.v[h >> 1] & 0xFFFFu);
+        below += (h < nh && x < th) ? 1 : 0;
+        equal |= (h < nh && x == th) ? 1 : 0;
+      }
+    };
+    // Both half-words of a generator word at once (packed 16-bit arithmetic, no per-half compare into a lane mask):
+    //   below: saturating th - x is non-zero iff x < th; min(.., 1) is the count;   equal: x ^ th is zero iff x == th,
+    // kept as the running minimum over the block's words and tested once per block (a 32-bit word has a zero half iff
+    // (m - 0x00010001) & ~m & 0x80008000).  th = 65536 (t = 2^32: every read picks isoform 0) does not fit a half:
+    // counted in closed form behind the loop.
+    // (inline assembly: written with vector types the compiler recognises the idiom and goes back to one compare per half.
+    // Measured, same box, 40 000 events x 1000 reads: one SDWA compare per half into a lane mask + add-with-carry, 110
+    // VALU per 16 reads, 74.6 ms; this form, 108 VALU but no lane masks, 71.0 ms; MISO defaults 235.9 -> 219.1 ms,
+    // hg19-like read counts 66.4 -> 59.4 ms; profiles/r04_lazy_low_bits.txt)
+    const uint32_t thc = th > 0xFFFFu ? 0xFFFFu : th;
+    const uint32_t T2 = thc | (thc << 16), one2 = 0x00010001u;
+    uint32_t accv = 0;
     for (int j = 0; j < trips; j++) {
-      // UQ independent Philox blocks in flight per lane: the 9 dependent rounds of one block leave
-      // the multiplier pipe idle between rounds; interleaved blocks fill it
       miso_u32x4 u[UQ];
 #pragma unroll
       for (int i = 0; i < UQ; i++)
         u[i] = philox_gibbs(rng, static_cast<uint32_t>(sub + (UQ * j + i) * GE), n0r0);
 #pragma unroll
       for (int i = 0; i < UQ; i++) {
-        const int ci = (u[i].v[0] <= tm) + (u[i].v[1] <= tm) + (u[i].v[2] <= tm) + (u[i].v[3] <= tm);
-        d0 += (sub + (UQ * j + i) * GE < nfq) ? ci : 0;
+        const int q = sub + (UQ * j + i) * GE;
+        uint32_t c = 0, m = 0xFFFFFFFFu;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+          uint32_t d;
+          const uint32_t y = u[i].v[w] ^ T2;
+          asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(d) : "v"(T2), "v"(u[i].v[w]));
+          asm("v_pk_min_u16 %0, %1, %2" : "=v"(d) : "v"(d), "v"(one2));
+          asm("v_pk_add_u16 %0, %1, %2" : "=v"(c) : "v"(c), "v"(d));
+          asm("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(m), "v"(y));
+        }
+        const bool mine = q < nfq;
+        const bool eq = ((m - 0x00010001u) & ~m & 0x80008000u) != 0u;
+        uint32_t cm = mine ? c : 0u;
+        asm("v_pk_add_u16 %0, %1, %2" : "=v"(accv) : "v"(accv), "v"(cm));
+        if (mine && eq) { amb_q = static_cast<uint32_t>(q); amb_n++; }
       }
     }
-    if (any_rem) {  // the partial quad, owned by one lane of the group
+    d0 = static_cast<int>(accv & 0xFFFFu) + static_cast<int>(accv >> 16);
+    if (th > 0xFFFFu) d0 = (sub < nfq) ? 8 * ((nfq - 1 - sub) / GE + 1) : 0;
+    if (any_rem) {  // the partial block, owned by one lane of the group
       const miso_u32x4 u = philox_gibbs(rng, static_cast<uint32_t>(nfq), n0r0);
-      const int cp = (rem > 0 && u.v[0] <= tm) + (rem > 1 && u.v[1] <= tm) + (rem > 2 && u.v[2] <= tm);
-      d0 += (sub == (nfq % GE)) ? cp : 0;
+      int cp, eq;
+      halves(u, rem, cp, eq);
+      const bool mine = sub == (nfq % GE);
+      d0 += mine ? cp : 0;
+      if (mine && eq) { amb_q = static_cast<uint32_t>(nfq); amb_n++; }
     }
-    if (t == 0 || !lane_used) d0 = 0;
+    if (!lane_used) { d0 = 0; amb_n = 0; }
+    const bool settle_all = a.pe_force_exact != 0;   // tests: every lane takes the rescan below at every step
+    if (tl != 0 && __builtin_expect(settle_all || __any(amb_n != 0), 0)) {
+      // the reads whose high half sits ON the threshold: their low halves decide (one wavefront step in four at 1000
+      // reads and 16 chains per wavefront; two Philox blocks then)
+      auto settle = [&](uint32_t q) {
+        const miso_u32x4 hi = miso_philox4x32(q, iter, c2_gibbs, event_id, k0, k1);
+        const miso_u32x4 lo = miso_philox4x32(q, iter, MISO_SITE_GIBBS_LOW | (chain << 8), event_id, k0, k1);
+        const int nh = (static_cast<int>(q) == nfq) ? rem : 8;
+        int more = 0;
+        for (int h = 0; h < nh; h++)
+          more += (miso_block_half(hi, h) == th && miso_block_half(lo, h) < tl) ? 1 : 0;
+        return more;
+      };
+      if (amb_n == 1 && !settle_all) d0 += settle(amb_q);
+      else if ((amb_n > 1 || settle_all) && lane_used) {   // several of the lane's blocks: all of them again
+        for (int q = sub; q < nfq + (rem ? 1 : 0); q += GE) {
+          const miso_u32x4 hi = miso_philox4x32(static_cast<uint32_t>(q), iter, c2_gibbs, event_id, k0, k1);
+          const int nh = (q == nfq) ? rem : 8;
+          bool on = false;
+          for (int h = 0; h < nh; h++) on |= miso_block_half(hi, h) == th;
+          if (on) d0 += settle(static_cast<uint32_t>(q));
+        }
+      }
+    }
     PROF_T(g2);
     PROF_ADD(pf_loop, g1, g2);
     if (POW2) {
@@ -651,6 +718,11 @@ __device__ __forceinline__ void k2_body(const KernelArgs &a, unsigned block_x, u
   // the per-read picks of one Gibbs step, written once for the caller (miso.c:943-946)
   auto gibbs_write = [&](uint32_t iter) {
     const uint64_t t = PE ? 0 : k2_threshold(cur.x0, (0.0 + cur.x0) + cur.x1);
+    if (!PE) {   // the same picks read by read, both halves of every uniform (include/miso_philox.h miso_split_word)
+      for (int r = sub; r < n_draw; r += GE)
+        drawass[r] = (static_cast<uint64_t>(miso_split_word(a.seed, event_id, chain, iter, static_cast<uint32_t>(r))) < t) ? 0 : 1;
+      return;
+    }
     const int nq = (n_draw + 3) >> 2;
     for (int q = sub; q < nq; q += GE) {
       const miso_u32x4 u = miso_philox4x32(static_cast<uint32_t>(q), iter, c2_gibbs, event_id, k0, k1);

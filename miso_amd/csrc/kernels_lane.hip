@@ -63,20 +63,23 @@ __global__ __launch_bounds__(256) void sampler_lane(const KernelArgs a) {
     cnt0 = base0 + d0;
     cnt1 = base1 + (n_draw - d0);
   };
-  // ... and read by read (miso.c:69-73: U (psi_0 + psi_1) < psi_0 picks isoform 0), word r of the Gibbs site for the
-  // r-th drawing read; chain 0's picks are what the caller gets back
+  // ... and read by read (miso.c:69-73: U (psi_0 + psi_1) < psi_0 picks isoform 0), the r-th drawing read's uniform from
+  // the Gibbs sites; chain 0's picks are what the caller gets back
   auto gibbs_per_read = [&](uint32_t iter) {
     const double p0 = 0.0 + cur.x0, T = p0 + cur.x1;
-    const int nq = (n_draw + 3) >> 2;
+    // (a two-isoform read's uniform comes in two half-words, eight reads per block: include/miso_philox.h, lazy low bits)
+    const int nb = (n_draw + 7) >> 3;
     int d0 = 0;
-    for (int q = 0; q < nq; q++) {
-      const miso_u32x4 u = miso_philox4x32(static_cast<uint32_t>(q), iter, c2_gibbs, event_id, k0, k1);
+    for (int q = 0; q < nb; q++) {
+      const miso_u32x4 hi = miso_philox4x32(static_cast<uint32_t>(q), iter, c2_gibbs, event_id, k0, k1);
+      const miso_u32x4 lo = miso_philox4x32(static_cast<uint32_t>(q), iter, MISO_SITE_GIBBS_LOW | (chain << 8), event_id, k0, k1);
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        if (4 * q + j < n_draw) {
-          const bool pick0 = miso_u01(u.v[j]) * T < p0;
+      for (int h = 0; h < 8; h++) {
+        if (8 * q + h < n_draw) {
+          const uint32_t word = (miso_block_half(hi, h) << 16) | miso_block_half(lo, h);
+          const bool pick0 = miso_u01(word) * T < p0;
           d0 += pick0 ? 1 : 0;
-          if (chain == 0) drawass[4 * q + j] = pick0 ? 0 : 1;
+          if (chain == 0) drawass[8 * q + h] = pick0 ? 0 : 1;
         }
       }
     }

@@ -154,8 +154,13 @@ __global__ __launch_bounds__(64) void sampler_marginal(const KernelArgs a) {
     const uint32_t c2 = MISO_SITE_GIBBS;   // | chain 0 << 8
     miso_u32x4 u{};
     for (int r = 0; r < n_draw; r++) {
-      if ((r & 3) == 0) u = miso_philox4x32(static_cast<uint32_t>(r >> 2), MISO_ITER_INIT, c2, event_id, k0, k1);
-      const uint32_t word = (r & 3) == 0 ? u.v[0] : ((r & 3) == 1 ? u.v[1] : ((r & 3) == 2 ? u.v[2] : u.v[3]));
+      uint32_t word;
+      if (K == 2) {   // two isoforms: the uniform's two half-words (include/miso_philox.h, lazy low bits)
+        word = miso_split_word(a.seed, event_id, 0u, MISO_ITER_INIT, static_cast<uint32_t>(r));
+      } else {
+        if ((r & 3) == 0) u = miso_philox4x32(static_cast<uint32_t>(r >> 2), MISO_ITER_INIT, c2, event_id, k0, k1);
+        word = (r & 3) == 0 ? u.v[0] : ((r & 3) == 1 ? u.v[1] : ((r & 3) == 2 ? u.v[2] : u.v[3]));
+      }
       const uint64_t mask = static_cast<uint64_t>(lo[r]) | (K > 32 ? static_cast<uint64_t>(hi[r]) << 32 : 0ull);
       const int nv = __builtin_popcountll(mask);
       double total = 0.0;

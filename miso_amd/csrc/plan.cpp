@@ -23,7 +23,7 @@ struct Planner {
   int wide_wgs(double D, int ndraw) const {
     const int lanes = 64 * wide_wpb;
     if (coop_max <= 1 || cost.smooth_step(lanes, ndraw) + wide_extra <= D) return 1;
-    const int cap = std::max(1, std::min(coop_max, (ndraw >> 2) / (std::max(1, cost.coop_min_quads) * lanes)));
+    const int cap = std::max(1, std::min(coop_max, (ndraw / cost.draws) / (std::max(1, cost.coop_min_quads) * lanes)));
     for (int m = 2; m <= cap; m++) if (cost.smooth_step(lanes * m, ndraw) + wide_extra + coop_extra <= D) return m;
     return cap;
   }
@@ -31,7 +31,7 @@ struct Planner {
   // the narrowest width whose wavefront step stays within D; never more lanes than the chain has pairs of draw
   // quads to stride over; the whole workgroup when even 64 lanes overshoot and the chain has work for all of them
   int pick(double D, int ndraw) const {
-    const int cap = std::max(1, (ndraw >> 2) / 2);
+    const int cap = std::max(1, (ndraw / cost.draws) / 2);
     int last = 0;
     for (int i = 0; i < nw; i++) {
       const int G = widths[i];

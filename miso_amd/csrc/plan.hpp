@@ -22,12 +22,13 @@ struct LaneCost {
   double block = 48;
   int uq = 2;              // blocks per lane and trip of the read loop (trips are whole)
   bool paired = false;     // paired-end loop: 2 x trips + 1 blocks; single-end: uq x trips (+ 1 for a partial quad)
-  int coop_min_quads = 8;  // a chain on several workgroups keeps at least this many quads per lane (tests lower it)
-  // exact: what the kernels' loops do (trips are whole, a partial quad costs a block)
+  int coop_min_quads = 8;  // a chain on several workgroups keeps at least this many blocks per lane (tests lower it)
+  int draws = 4;           // draws per Philox block: four words; single-end EIGHT half-words (miso_philox.h, lazy low bits)
+  // exact: what the kernels' loops do (trips are whole, a partial block costs a block)
   double blocks_per_lane(int lanes, int n_draw) const {
-    const int nfq = n_draw >> 2;
+    const int nfq = n_draw / draws;
     const int trips = (nfq + uq * lanes - 1) / (uq * lanes);
-    return paired ? 2.0 * trips + 1.0 : static_cast<double>(uq) * trips + ((n_draw & 3) ? 1.0 : 0.0);
+    return paired ? 2.0 * trips + 1.0 : static_cast<double>(uq) * trips + ((n_draw % draws) ? 1.0 : 0.0);
   }
   double wave_step(int lanes, int n_draw) const {   // lanes = lanes striding over the chain's draws (K2_WIDE: 64 x wpb)
     return step[lanes >= 4 ? 4 : lanes] + block * blocks_per_lane(lanes, n_draw);
@@ -35,7 +36,7 @@ struct LaneCost {
   // smooth in n_draw (no rounding to whole trips): what the widths are chosen by, so that the choice never flips
   // back and forth between neighbouring events of the ordered list
   double smooth_step(int lanes, int n_draw) const {
-    return step[lanes >= 4 ? 4 : lanes] + block * (n_draw / (4.0 * lanes) + 0.5 * uq + (paired ? 1.0 : 0.5));
+    return step[lanes >= 4 ? 4 : lanes] + block * (n_draw / (static_cast<double>(draws) * lanes) + 0.5 * uq + (paired ? 1.0 : 0.5));
   }
 };
 
@@ -44,8 +45,12 @@ struct LaneCost {
 // (MODE 2, dense records): block = generator + four reads' weights, compares and score gathers.
 // (round 4: the generator has 7 rounds instead of 10, include/miso_philox.h: three rounds x four instructions fewer per block
 // than the 52 / 115 measured in round 3)
+// (single-end since the lazy low bits: a block is EIGHT reads -- 24 generator instructions + 5 per word for the packed
+// below / equal arithmetic + the loop's share: 108 per two blocks; the launch time hardly moves between 44 and 96,
+// profiles/r04_lazy_low_bits.txt)
 inline LaneCost k2_cost_single() {
-  LaneCost c; c.step[1] = 1750; c.step[2] = 1170; c.step[3] = 840; c.step[4] = 720; c.block = 40; c.uq = 2; c.paired = false;
+  LaneCost c; c.step[1] = 1750; c.step[2] = 1170; c.step[3] = 840; c.step[4] = 720; c.block = 54; c.uq = 2; c.paired = false;
+  c.draws = 8;
   return c;
 }
 inline LaneCost k2_cost_paired() {

@@ -470,6 +470,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   a.C = p.noChains; a.M = p.noIterations; a.B = p.noBurnIn; a.lag = p.noLag;
   a.start = p.start; a.first_event_id = first_event_id; a.seed = seed;
   last_seed = seed; last_first_event_id = first_event_id;
+  a.pe_force_exact = std::getenv("MISO_K2_SETTLE_ALL") != nullptr;   // tests (kernels_k2.inl: the rescan for high halves on the threshold)
   if (const char *env = std::getenv("MISO_COOP_MAX_POLLS")) a.coop_max_polls = static_cast<uint32_t>(std::max(1L, std::atol(env)));   // tests
   // Trailing sample columns stay 0 (miso.c:661, quirk C8) -- they exist only when the lag does not divide the kept
   // iterations; otherwise the kernels overwrite every sample, log score, pick and statistic of the pool, and clearing
@@ -759,7 +760,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   int k2_G = 0, k2w_G = 0;
   if (n_k2 - n_k2w > 0) {
     const long chains = static_cast<long>(n_k2 - n_k2w) * p.noChains;
-    const int maxq = (events[k2_first_event()].n_draw + 3) / 4;
+    const int maxq = p.paired ? (events[k2_first_event()].n_draw + 3) / 4 : (events[k2_first_event()].n_draw + 7) / 8;   // Philox blocks
     const int max_cpw = p.paired ? std::max<int>(1, static_cast<int>((60 * 1024 - k2_fp) / (4 * k2_tab))) : 64;
     if (const char *env = std::getenv("MISO_LANES_PER_CHAIN")) k2_G = std::atoi(env);
     else if (tuned_k2_G) k2_G = tuned_k2_G;
@@ -1364,13 +1365,14 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     const long chains = static_cast<long>(count) * C;
     double trips = 0, words = 0;
     long waves = 0;
+    const int bshift = p.paired ? 2 : 3;   // draws per Philox block: four, single-end eight (half-words, miso_philox.h)
     auto slice = [&](long c0, long c1, int G) {   // chains [c0, c1) of the list with G lanes per chain
       const int cpw = 64 / G;
       for (long s0 = c0; s0 < c1; s0 += cpw, waves++) {
         int mx = 0, any_rem = 0;
         for (long sl = s0; sl < std::min(c1, s0 + cpw); sl++) {
           const int n = nd[sl / C];
-          mx = std::max(mx, n >> 2); any_rem |= n & 3;
+          mx = std::max(mx, n >> bshift); any_rem |= n & ((1 << bshift) - 1);
           words += n;
         }
         const int t = (mx + 2 * G - 1) / (2 * G);             // trips of two Philox blocks per lane
@@ -1391,8 +1393,8 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
             const size_t we = static_cast<size_t>(c / C - pl.seg_slot[sg]);
             const int m = we < pl.wide_wgs.size() ? pl.wide_wgs[we] : 1;     // workgroups of the chain (coop.hpp)
             const int wl = 64 * pl.wpb * m;
-            const int t = ((n >> 2) + 2 * wl - 1) / (2 * wl);
-            trips += pl.wpb * m * (p.paired ? 2 * t + 1 : 2 * t + ((n & 3) ? 1 : 0));
+            const int t = ((n >> bshift) + 2 * wl - 1) / (2 * wl);
+            trips += pl.wpb * m * (p.paired ? 2 * t + 1 : 2 * t + ((n & 7) ? 1 : 0));
             words += n; waves += pl.wpb * m;
           }
         } else slice(c0, c1, pl.seg_lanes[sg]);

@@ -805,8 +805,9 @@ static void reassign(orc_state_t *S, uint32_t iter) {
     const double *psi = S->psi + k * K;
     int *ass = S->ass + (size_t) k * N;
     if (S->counter) {
-      uint32_t rank = 0; miso_u32x4 blk; uint32_t have = 0xFFFFFFFFu; int ii;
-      memset(&blk, 0, sizeof(blk));
+      uint32_t rank = 0; miso_u32x4 blk, blk_lo; uint32_t have = 0xFFFFFFFFu; int ii;
+      const int split = !S->paired && K == 2;   /* lazy low bits (miso_philox.h): two half-words per read */
+      memset(&blk, 0, sizeof(blk)); memset(&blk_lo, 0, sizeof(blk_lo));
       if (!S->corder) counter_order(S);
       for (ii = 0; ii < N; ii++) {
         const double *col;
@@ -815,7 +816,15 @@ static void reassign(orc_state_t *S, uint32_t iter) {
         int first = -1, nv = count_valid(col, K, &first);
         if (nv == 0) ass[i] = -1;
         else if (nv == 1) ass[i] = first;
-        else {
+        else if (split) { /* = miso_split_word(seed, event, chain, iter, rank), the two blocks kept for their eight reads */
+          if (rank / 8 != have) {
+            have = rank / 8;
+            blk = miso_draw_block(S->opts->seed, S->opts->event_id, (uint32_t) k, iter, MISO_SITE_GIBBS, have);
+            blk_lo = miso_draw_block(S->opts->seed, S->opts->event_id, (uint32_t) k, iter, MISO_SITE_GIBBS_LOW, have);
+          }
+          ass[i] = draw_read(S, col, psi, miso_u01((miso_block_half(blk, rank & 7u) << 16) | miso_block_half(blk_lo, rank & 7u)));
+          rank++;
+        } else {
           if (rank / 4 != have) {
             have = rank / 4;
             blk = miso_draw_block(S->opts->seed, S->opts->event_id, (uint32_t) k, iter,

@@ -234,3 +234,45 @@ def test_more_than_thirty_two_isoforms_bit_exact(orc, K, paired, device_match):
         if device_match and i == 0:   # what the match kernel wrote for the wide gene = the oracle's match matrix
             m, fl = b.device_match_of(0)
             assert np.array_equal(m != 0, cpu.match != 0)
+
+
+def test_two_isoform_reads_whose_high_half_sits_on_the_threshold(orc):
+    """Single-end events with two isoforms draw a read's uniform in two half-words (include/miso_philox.h, lazy low bits):
+    the device decides from the high halves, eight reads per Philox block, and draws a block's low halves only when a
+    high half EQUALS the threshold's -- one read in 65 536.  Enough read-draws here (3.4e7) for some five hundred such
+    reads, half of which change a count, on every lane layout (1 .. 64 lanes per chain and a workgroup per chain), with
+    read counts that leave partial blocks; then the same batch with every lane forced through the rescan that serves a
+    lane with SEVERAL such blocks in one step (MISO_K2_SETTLE_ALL=1): all bit for bit the checker's, which assembles
+    both halves for every read."""
+    import os
+    kw = dict(iters=1200, burn=200, lag=5, chains=4)
+    sizes = [3001, 1999, 1203, 777, 250, 61, 9, 8, 7, 1]
+    b = miso_amd.Batch(36, counts_trace=True, **kw)
+    keep = []
+    for i, n in enumerate(sizes):
+        exons, isoforms, g, pos, cig = simulate_se(orc, 2, n, seed=700 + i)
+        b.add_event(miso_amd.Gene(exons, isoforms), pos, cig)
+        keep.append((g, pos, cig))
+    cpu = [orc.miso(g, pos, cig, 36, mode=OrcLib.COUNTER, seed=31, event_id=40 + i, trace=True, **kw)
+           for i, (g, pos, cig) in enumerate(keep)]
+    saved = {k: os.environ.pop(k, None) for k in ("MISO_LANES_PER_CHAIN", "MISO_K2_SETTLE_ALL", "MISO_K2_TARGET")}
+    try:
+        # (the planner's widths; a bound on a wavefront's step so small that the largest events take a whole workgroup;
+        # single-width launches)
+        for env in (dict(), dict(MISO_K2_SETTLE_ALL="1"), dict(MISO_K2_TARGET="900"), dict(MISO_K2_TARGET="900", MISO_K2_SETTLE_ALL="1"),
+                    dict(MISO_LANES_PER_CHAIN="1"), dict(MISO_LANES_PER_CHAIN="3", MISO_K2_SETTLE_ALL="1"),
+                    dict(MISO_LANES_PER_CHAIN="8"), dict(MISO_LANES_PER_CHAIN="64")):
+            for k in saved:
+                os.environ.pop(k, None)
+            os.environ.update(env)
+            b.run(seed=31, first_event_id=40)
+            for i in range(len(sizes)):
+                got = b.result(i, trace=True)
+                assert np.array_equal(got.counts_trace, cpu[i].trace["counts_trace"]), (env, i)
+                assert np.array_equal(got.samples, cpu[i].samples), (env, i)
+                assert np.array_equal(got.assignment, cpu[i].assignment), (env, i)
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v

@@ -60,7 +60,7 @@ def test_heavy_tail_no_wavefront_outlasts_the_launch():
     for chains, wpb in ((1, 8), (6, 8)):
         runs, info = plan(nd, chains=chains)
         check_shape(runs, info, nd, chains, wpb)
-        assert runs[0]["lanes"] == WIDE and runs[-1]["lanes"] <= 2
+        assert runs[0]["lanes"] in (64, WIDE) and runs[-1]["lanes"] <= 2   # (a whole workgroup only when 64 lanes overshoot the bound)
         # time of the launch >= total work / SIMDs that have work; a wavefront shares its SIMD with another one and
         # advances at half speed, so twice the longest wavefront must stay near that share ("kernel duration <= 2 x
         # the mean" would be 2.0 here)
