@@ -637,32 +637,39 @@ __device__ __forceinline__ void k2_body(const KernelArgs &a, unsigned block_x, u
     const uint32_t thc = th > 0xFFFFu ? 0xFFFFu : th;
     const uint32_t T2 = thc | (thc << 16), one2 = 0x00010001u;
     uint32_t accv = 0;
-    for (int j = 0; j < trips; j++) {
-      miso_u32x4 u[UQ];
+    // (the two 16-bit counters of a lane take 4 per block each: emptied every 16000 blocks, which only a chain of more
+    // than 10^5 reads forced onto a single lane ever reaches)
+    constexpr int CHUNK = 16000 / UQ;
+    for (int j0 = 0; j0 < trips; j0 += CHUNK) {
+      const int j1 = min(trips, j0 + CHUNK);
+      for (int j = j0; j < j1; j++) {
+        miso_u32x4 u[UQ];
 #pragma unroll
-      for (int i = 0; i < UQ; i++)
-        u[i] = philox_gibbs(rng, static_cast<uint32_t>(sub + (UQ * j + i) * GE), n0r0);
+        for (int i = 0; i < UQ; i++)
+          u[i] = philox_gibbs(rng, static_cast<uint32_t>(sub + (UQ * j + i) * GE), n0r0);
 #pragma unroll
-      for (int i = 0; i < UQ; i++) {
-        const int q = sub + (UQ * j + i) * GE;
-        uint32_t c = 0, m = 0xFFFFFFFFu;
+        for (int i = 0; i < UQ; i++) {
+          const int q = sub + (UQ * j + i) * GE;
+          uint32_t c = 0, m = 0xFFFFFFFFu;
 #pragma unroll
-        for (int w = 0; w < 4; w++) {
-          uint32_t d;
-          const uint32_t y = u[i].v[w] ^ T2;
-          asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(d) : "v"(T2), "v"(u[i].v[w]));
-          asm("v_pk_min_u16 %0, %1, %2" : "=v"(d) : "v"(d), "v"(one2));
-          asm("v_pk_add_u16 %0, %1, %2" : "=v"(c) : "v"(c), "v"(d));
-          asm("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(m), "v"(y));
+          for (int w = 0; w < 4; w++) {
+            uint32_t d;
+            const uint32_t y = u[i].v[w] ^ T2;
+            asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(d) : "v"(T2), "v"(u[i].v[w]));
+            asm("v_pk_min_u16 %0, %1, %2" : "=v"(d) : "v"(d), "v"(one2));
+            asm("v_pk_add_u16 %0, %1, %2" : "=v"(c) : "v"(c), "v"(d));
+            asm("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(m), "v"(y));
+          }
+          const bool mine = q < nfq;
+          const bool eq = ((m - 0x00010001u) & ~m & 0x80008000u) != 0u;
+          uint32_t cm = mine ? c : 0u;
+          asm("v_pk_add_u16 %0, %1, %2" : "=v"(accv) : "v"(accv), "v"(cm));
+          if (mine && eq) { amb_q = static_cast<uint32_t>(q); amb_n++; }
         }
-        const bool mine = q < nfq;
-        const bool eq = ((m - 0x00010001u) & ~m & 0x80008000u) != 0u;
-        uint32_t cm = mine ? c : 0u;
-        asm("v_pk_add_u16 %0, %1, %2" : "=v"(accv) : "v"(accv), "v"(cm));
-        if (mine && eq) { amb_q = static_cast<uint32_t>(q); amb_n++; }
       }
+      d0 += static_cast<int>(accv & 0xFFFFu) + static_cast<int>(accv >> 16);
+      accv = 0;
     }
-    d0 = static_cast<int>(accv & 0xFFFFu) + static_cast<int>(accv >> 16);
     if (th > 0xFFFFu) d0 = (sub < nfq) ? 8 * ((nfq - 1 - sub) / GE + 1) : 0;
     if (any_rem) {  // the partial block, owned by one lane of the group
       const miso_u32x4 u = philox_gibbs(rng, static_cast<uint32_t>(nfq), n0r0);

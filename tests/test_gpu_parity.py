@@ -276,3 +276,29 @@ def test_two_isoform_reads_whose_high_half_sits_on_the_threshold(orc):
             os.environ.pop(k, None)
             if v is not None:
                 os.environ[k] = v
+
+
+def test_two_isoform_chain_of_150000_reads_on_one_lane(orc):
+    """A lane of the two-isoform read loop counts in two 16-bit halves of one register (kernels_k2.inl) and empties them
+    every 16 000 generator blocks: 150 001 reads forced onto ONE lane (MISO_LANES_PER_CHAIN=1) are 18 750 blocks."""
+    import os
+    kw = dict(iters=12, burn=2, lag=1, chains=2)
+    exons, isoforms, g, pos, cig = simulate_se(orc, 2, 150001, seed=811)
+    b = miso_amd.Batch(36, counts_trace=True, **kw)
+    b.add_event(miso_amd.Gene(exons, isoforms), pos, cig)
+    cpu = orc.miso(g, pos, cig, 36, mode=OrcLib.COUNTER, seed=3, event_id=9, trace=True, **kw)
+    old = os.environ.pop("MISO_LANES_PER_CHAIN", None)
+    try:
+        for lanes in ("1", None):
+            if lanes:
+                os.environ["MISO_LANES_PER_CHAIN"] = lanes
+            else:
+                os.environ.pop("MISO_LANES_PER_CHAIN", None)
+            b.run(seed=3, first_event_id=9)
+            got = b.result(0, trace=True)
+            assert np.array_equal(got.counts_trace, cpu.trace["counts_trace"]), lanes
+            assert np.array_equal(got.samples, cpu.samples) and np.array_equal(got.assignment, cpu.assignment), lanes
+    finally:
+        os.environ.pop("MISO_LANES_PER_CHAIN", None)
+        if old is not None:
+            os.environ["MISO_LANES_PER_CHAIN"] = old
