@@ -608,12 +608,12 @@ __device__ __forceinline__ void k2_body(const KernelArgs &a, unsigned block_x, u
     }
     PROF_T(g0);
     // u < t with u = hi 2^16 + lo:  hi < t >> 16, or hi == t >> 16 and lo < (t & 0xFFFF).  The loop looks at the high
-    // halves only -- eight reads per Philox block -- and notes the block in which one of them EQUALS t >> 16 (one read
-    // in 65 536); that block's low halves (site MISO_SITE_GIBBS_LOW) are drawn behind the loop, by the lane that owns it.
+    // halves only -- eight reads per Philox block -- and notes the trip in which one of them EQUALS t >> 16 (one read
+    // in 65 536); that trip's blocks' low halves (site MISO_SITE_GIBBS_LOW) are drawn behind the loop, by the lane that owns them.
     const uint64_t t = k2_threshold(cur.x0, (0.0 + cur.x0) + cur.x1);
     const uint32_t th = static_cast<uint32_t>(t >> 16), tl = static_cast<uint32_t>(t) & 0xFFFFu;   // th <= 65536
     const uint32_t n0r0 = rng.p1hi ^ iter ^ k0;
-    int d0 = 0, amb_n = 0; uint32_t amb_q = 0;
+    int d0 = 0, amb_n = 0; uint32_t amb_t = 0; bool amb_p = false;   // trips of this lane with a high half on the threshold, the last of them; the partial block
     PROF_T(g1);
     PROF_ADD(pf_thr, g0, g1);
     auto halves = [&](const miso_u32x4 &u, int nh, int &below, int &equal) __attribute__((always_inline)) {
@@ -627,13 +627,14 @@ __device__ __forceinline__ void k2_body(const KernelArgs &a, unsigned block_x, u
     };
     // Both half-words of a generator word at once (packed 16-bit arithmetic, no per-half compare into a lane mask):
     //   below: saturating th - x is non-zero iff x < th; min(.., 1) is the count;   equal: x ^ th is zero iff x == th,
-    // kept as the running minimum over the block's words and tested once per block (a 32-bit word has a zero half iff
+    // kept as the running minimum over the trip's words and tested once per trip (a 32-bit word has a zero half iff
     // (m - 0x00010001) & ~m & 0x80008000).  th = 65536 (t = 2^32: every read picks isoform 0) does not fit a half:
     // counted in closed form behind the loop.
     // (inline assembly: written with vector types the compiler recognises the idiom and goes back to one compare per half.
     // Measured, same box, 40 000 events x 1000 reads: one SDWA compare per half into a lane mask + add-with-carry, 110
     // VALU per 16 reads, 74.6 ms; this form, 108 VALU but no lane masks, 71.0 ms; MISO defaults 235.9 -> 219.1 ms,
-    // hg19-like read counts 66.4 -> 59.4 ms; profiles/r04_lazy_low_bits.txt)
+    // hg19-like read counts 66.4 -> 59.4 ms; the equal test once per trip instead of once per block: 70.9 -> 69.3 ms,
+    // defaults 219.5 -> 207.9 ms; profiles/r04_lazy_low_bits.txt)
     const uint32_t thc = th > 0xFFFFu ? 0xFFFFu : th;
     const uint32_t T2 = thc | (thc << 16), one2 = 0x00010001u;
     uint32_t accv = 0;
@@ -647,25 +648,26 @@ __device__ __forceinline__ void k2_body(const KernelArgs &a, unsigned block_x, u
 #pragma unroll
         for (int i = 0; i < UQ; i++)
           u[i] = philox_gibbs(rng, static_cast<uint32_t>(sub + (UQ * j + i) * GE), n0r0);
+        uint32_t m = u[0].v[0] ^ T2;   // the trip's running minimum of x ^ th, both halves (blocks beyond the chain's
+                                       // last included: a flag too many only costs the look behind the loop)
 #pragma unroll
         for (int i = 0; i < UQ; i++) {
           const int q = sub + (UQ * j + i) * GE;
-          uint32_t c = 0, m = 0xFFFFFFFFu;
+          uint32_t c = 0;
 #pragma unroll
           for (int w = 0; w < 4; w++) {
             uint32_t d;
-            const uint32_t y = u[i].v[w] ^ T2;
             asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(d) : "v"(T2), "v"(u[i].v[w]));
             asm("v_pk_min_u16 %0, %1, %2" : "=v"(d) : "v"(d), "v"(one2));
             asm("v_pk_add_u16 %0, %1, %2" : "=v"(c) : "v"(c), "v"(d));
+            if (i == 0 && w == 0) continue;
+            const uint32_t y = u[i].v[w] ^ T2;
             asm("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(m), "v"(y));
           }
-          const bool mine = q < nfq;
-          const bool eq = ((m - 0x00010001u) & ~m & 0x80008000u) != 0u;
-          uint32_t cm = mine ? c : 0u;
+          uint32_t cm = (q < nfq) ? c : 0u;
           asm("v_pk_add_u16 %0, %1, %2" : "=v"(accv) : "v"(accv), "v"(cm));
-          if (mine && eq) { amb_q = static_cast<uint32_t>(q); amb_n++; }
         }
+        if (((m - 0x00010001u) & ~m & 0x80008000u) != 0u) { amb_t = static_cast<uint32_t>(j); amb_n++; }
       }
       d0 += static_cast<int>(accv & 0xFFFFu) + static_cast<int>(accv >> 16);
       accv = 0;
@@ -677,11 +679,11 @@ __device__ __forceinline__ void k2_body(const KernelArgs &a, unsigned block_x, u
       halves(u, rem, cp, eq);
       const bool mine = sub == (nfq % GE);
       d0 += mine ? cp : 0;
-      if (mine && eq) { amb_q = static_cast<uint32_t>(nfq); amb_n++; }
+      amb_p = mine && eq;
     }
-    if (!lane_used) { d0 = 0; amb_n = 0; }
+    if (!lane_used) { d0 = 0; amb_n = 0; amb_p = false; }
     const bool settle_all = a.pe_force_exact != 0;   // tests: every lane takes the rescan below at every step
-    if (tl != 0 && __builtin_expect(settle_all || __any(amb_n != 0), 0)) {
+    if (tl != 0 && __builtin_expect(settle_all || __any(amb_n != 0 || amb_p), 0)) {
       // the reads whose high half sits ON the threshold: their low halves decide (one wavefront step in four at 1000
       // reads and 16 chains per wavefront; two Philox blocks then)
       auto settle = [&](uint32_t q) {
@@ -693,15 +695,20 @@ __device__ __forceinline__ void k2_body(const KernelArgs &a, unsigned block_x, u
           more += (miso_block_half(hi, h) == th && miso_block_half(lo, h) < tl) ? 1 : 0;
         return more;
       };
-      if (amb_n == 1 && !settle_all) d0 += settle(amb_q);
-      else if ((amb_n > 1 || settle_all) && lane_used) {   // several of the lane's blocks: all of them again
-        for (int q = sub; q < nfq + (rem ? 1 : 0); q += GE) {
-          const miso_u32x4 hi = miso_philox4x32(static_cast<uint32_t>(q), iter, c2_gibbs, event_id, k0, k1);
-          const int nh = (q == nfq) ? rem : 8;
-          bool on = false;
-          for (int h = 0; h < nh; h++) on |= miso_block_half(hi, h) == th;
-          if (on) d0 += settle(static_cast<uint32_t>(q));
-        }
+      // a full block of this lane: its low halves if one of its high halves is on the threshold
+      auto look = [&](int q) {
+        if (q >= nfq) return 0;
+        const miso_u32x4 hi = miso_philox4x32(static_cast<uint32_t>(q), iter, c2_gibbs, event_id, k0, k1);
+        bool on = false;
+        for (int h = 0; h < 8; h++) on |= miso_block_half(hi, h) == th;
+        return on ? settle(static_cast<uint32_t>(q)) : 0;
+      };
+      // the partial block (its owner only; settle() counts nothing when no high half is on the threshold)
+      if (lane_used && rem != 0 && sub == (nfq % GE) && (amb_p || settle_all)) d0 += settle(static_cast<uint32_t>(nfq));
+      if (amb_n == 1 && !settle_all) {        // the full blocks: one trip's ...
+        for (int i = 0; i < UQ; i++) d0 += look(sub + (UQ * static_cast<int>(amb_t) + i) * GE);
+      } else if ((amb_n > 1 || settle_all) && lane_used) {   // ... or, with several such trips, all of the lane's
+        for (int q = sub; q < nfq; q += GE) d0 += look(q);
       }
     }
     PROF_T(g2);
