@@ -302,3 +302,30 @@ def test_two_isoform_chain_of_150000_reads_on_one_lane(orc):
         os.environ.pop("MISO_LANES_PER_CHAIN", None)
         if old is not None:
             os.environ["MISO_LANES_PER_CHAIN"] = old
+
+
+@pytest.mark.parametrize("event,lanes,iters", [(1444, "4", 200), (1007, "3", 1400)])
+def test_a_read_on_the_threshold_in_a_full_block_and_one_in_the_partial_block_of_the_same_lane(orc, event, lanes, iters):
+    """Regression (found by tests/test_gpu_scale.py at full size, one chain-step in 10^7): the chain's partial generator
+    block is also the non-owned tail of one of its lane's regular trips, so a high half on the threshold in it flags
+    that trip too -- two flagged trips, the lane rescans its full blocks -- and the partial block must then be settled
+    once, not by the rescan as well.  Events of the benchmark's generator and the lane widths at which it happened."""
+    import os
+    from miso_amd import workload
+    exons, isoforms, pos, cig = workload.event_reads(event, 2, 1000, 36, False, 0.0, 0.0)
+    kw = dict(iters=iters, burn=0, lag=10, chains=1)
+    b = miso_amd.Batch(36, counts_trace=True, **kw)
+    b.set_event_id(b.add_event(miso_amd.Gene(exons, isoforms), pos, cig), event)
+    g = orc.gene(flat(exons), isoforms)
+    cpu = orc.miso(g, pos, cig, 36, mode=OrcLib.COUNTER, seed=42, event_id=event, trace=True, **kw)
+    old = os.environ.pop("MISO_LANES_PER_CHAIN", None)
+    try:
+        os.environ["MISO_LANES_PER_CHAIN"] = lanes
+        b.run(seed=42, first_event_id=0)
+    finally:
+        os.environ.pop("MISO_LANES_PER_CHAIN", None)
+        if old is not None:
+            os.environ["MISO_LANES_PER_CHAIN"] = old
+    got = b.result(0, trace=True)
+    assert np.array_equal(got.counts_trace, cpu.trace["counts_trace"])
+    assert np.array_equal(got.samples, cpu.samples)
