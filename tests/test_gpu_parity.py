@@ -316,7 +316,7 @@ def test_a_read_on_the_threshold_in_a_full_block_and_one_in_the_partial_block_of
     kw = dict(iters=iters, burn=0, lag=10, chains=1)
     b = miso_amd.Batch(36, counts_trace=True, **kw)
     b.set_event_id(b.add_event(miso_amd.Gene(exons, isoforms), pos, cig), event)
-    g = orc.gene(flat(exons), isoforms)
+    g = orc.gene(_problems.flat(exons), isoforms)
     cpu = orc.miso(g, pos, cig, 36, mode=OrcLib.COUNTER, seed=42, event_id=event, trace=True, **kw)
     old = os.environ.pop("MISO_LANES_PER_CHAIN", None)
     try:
