@@ -1071,6 +1071,10 @@ static int convergent_mean(const double *samples, int K, int C, int noSamples) {
   return stop;
 }
 
+uint32_t orc_split_word(uint64_t seed, uint32_t event_id, uint32_t chain, uint32_t iteration, uint32_t r) {
+  return miso_split_word(seed, event_id, chain, iteration, r);
+}
+
 int orc_convergent_mean(const double *samples, int K, int C, int noSamples) {
   return convergent_mean(samples, K, C, noSamples);
 }

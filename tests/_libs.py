@@ -254,6 +254,11 @@ class OrcLib(_Base):
             self.lib.orc_philox_r(C.c_int(rounds), *a)
         return out
 
+    def split_word(self, seed, event_id, chain, iteration, r):
+        """the 32-bit uniform word of the r-th drawing read of a single-end two-isoform event (miso_philox.h, lazy low bits)"""
+        self.lib.orc_split_word.restype = C.c_uint32
+        return int(self.lib.orc_split_word(C.c_uint64(seed), C.c_uint32(event_id), C.c_uint32(chain), C.c_uint32(iteration), C.c_uint32(r)))
+
     def philox_rounds(self):
         return self.lib.orc_philox_rounds()
 

@@ -154,3 +154,17 @@ def test_philox_known_answers(orc):
     assert orc.philox_rounds() == 7
     for (ctr, key), w in zip(inputs, kat[7]):
         assert list(orc.philox(ctr, key)) == w
+
+
+def test_two_isoform_uniforms_are_two_half_words_of_two_streams(orc):
+    """The addressing of the lazy low bits as include/miso_philox.h states it, written out here from the generator alone:
+    read r's uniform = (half-word r % 8 of block r // 8 at site 2) << 16 | (the same half-word at site 4), half-word h =
+    bits 16 (h & 1) .. + 15 of word h // 2; counter = (block, iteration, site | chain << 8, event), key = the seed's halves."""
+    seed, event, chain, iteration = 0x1234567890ABCDEF, 777, 3, 41
+    key = [seed & 0xFFFFFFFF, seed >> 32]
+    for r in (0, 1, 7, 8, 9, 15, 16, 1000, 65537):
+        hi = orc.philox([r // 8, iteration, 2 | (chain << 8), event], key)
+        lo = orc.philox([r // 8, iteration, 4 | (chain << 8), event], key)
+        h = r % 8
+        want = (((int(hi[h // 2]) >> (16 * (h & 1))) & 0xFFFF) << 16) | ((int(lo[h // 2]) >> (16 * (h & 1))) & 0xFFFF)
+        assert orc.split_word(seed, event, chain, iteration, r) == want, r
