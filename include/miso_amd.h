@@ -95,6 +95,14 @@ void miso_gene_destroy(miso_gene_t *gene);
 int miso_gene_noiso(const miso_gene_t *gene, int *noiso);
 int miso_gene_isolength(const miso_gene_t *gene, int *isolength /* noiso */);
 
+/* The gene's possible read classes (splicing_assignment_matrix, assignment.c:90-276; the module's assignmentMatrix,
+   pysplicing.c:324-349): one column per distinct set of isoforms that share an alignment of a readLength-base read at some
+   start position, its entries that number of positions for the set's isoforms and 0 for the others; columns ordered as the
+   reference orders them.  matrix: noiso x max_cols doubles, column-major; *n_cols = columns (MISO_EINVAL if more than
+   max_cols).  overHang > 1: MISO_UNIMPLEMENTED, as in the reference.  What algorithm = MISO_ALGO_CLASSES sums over. */
+int miso_gene_assignment_matrix(const miso_gene_t *gene, int readLength, int overHang, double *matrix, int max_cols,
+                                int *n_cols);
+
 /* ---- problem construction on the host (input builder of the path) ---- */
 /* match: noiso x n_reads, 1.0 / 0.0 */
 int miso_match_iso(const miso_gene_t *gene, const int *position, const char *const *cigarstr,

@@ -132,6 +132,14 @@ class Gene:
         check(lib().miso_gene_isolength(self.handle, _p(out)))
         return out
 
+    def assignment_matrix(self, read_len, overhang=1, max_cols=4096):
+        """The gene's possible read classes (assignment.c:90-276): ncls x K, a class per row (include/miso_amd.h)."""
+        K = self.noiso
+        m = np.zeros(K * max_cols)
+        n = C.c_int(0)
+        check(lib().miso_gene_assignment_matrix(self.handle, int(read_len), int(overhang), _p(m), max_cols, C.byref(n)))
+        return m[:K * n.value].reshape(n.value, K).copy()
+
     def match_iso(self, pos, cigars, read_len, overhang=1):
         pos = np.asarray(pos, dtype=np.int32)
         m = np.zeros((max(len(pos), 1), self.noiso))

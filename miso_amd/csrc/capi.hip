@@ -249,6 +249,7 @@ int miso_batch_add_event(miso_batch_t *b, const miso_gene_t *gene, const int *po
     b->events.push_back(pack_event(b->p, b->p.paired ? &b->fd : nullptr, g.K, N, match.data(),
                                    b->p.paired ? fraglen.data() : nullptr, g.isolen.data(),
                                    g.noexons.data(), hyperp));
+    attach_gene_classes(b->events.back(), b->p, g);   // algorithm = CLASSES only
     if (event_index) *event_index = static_cast<int>(b->events.size()) - 1;
   });
 }
@@ -262,6 +263,8 @@ int miso_batch_add_problem(miso_batch_t *b, int noiso, int n_reads, const double
     if (n_reads > 0) need(match, "match");
     if (b->p.paired && n_reads > 0) need(fragmentLength, "fragmentLength");
     if (b->uploaded) MISO_FAIL(MISO_EINVAL, "batch already uploaded");
+    if (!b->p.paired && b->p.algorithm == MISO_ALGO_CLASSES)
+      MISO_FAIL(MISO_UNIMPLEMENTED, "The CLASSES algorithm needs the gene's structure (miso_batch_add_event)");
     b->events.push_back(pack_event(b->p, b->p.paired ? &b->fd : nullptr, noiso, n_reads, match,
                                    fragmentLength, isolength, noexons, hyperp));
     if (event_index) *event_index = static_cast<int>(b->events.size()) - 1;
@@ -492,6 +495,18 @@ int miso_batch_add_events_aln(miso_batch_t *b, int n, const miso_gene_t *const *
       b->events.push_back(std::move(ph));
       event_index[i] = static_cast<int>(b->events.size()) - 1;
     }
+  });
+}
+
+int miso_gene_assignment_matrix(const miso_gene_t *gene, int readLength, int overHang, double *matrix, int max_cols,
+                                int *n_cols) {
+  return guarded([&] {
+    need(gene, "gene"); need(matrix, "matrix"); need(n_cols, "n_cols");
+    const std::vector<double> m = assignment_matrix(gene->g, readLength, overHang == 0 ? 1 : overHang);
+    const int nc = static_cast<int>(m.size() / std::max(1, gene->g.K));
+    if (nc > max_cols) MISO_FAIL(MISO_EINVAL, "more read classes than the caller's matrix holds");
+    std::memcpy(matrix, m.data(), m.size() * sizeof(double));
+    *n_cols = nc;
   });
 }
 

@@ -14,7 +14,6 @@ namespace miso {
 //   [3K + 0]    lgamma(sum hyper)   [3K + 1] sum lgamma(hyper_k)   (miso.c:172-178)
 //   [3K + 2]    sigma = 0.2/K^2     [3K + 3] proposal sd           (miso.c:328, 188)
 //   [3K + 4]    (2 pi sigma)^(-(K-1)/2)                            (miso.c:101)
-//   [3K + 5, 4K + 5)  algorithm = MARGINAL only: 1 / effective length_k, 1 where that length is 0 (miso.c:800-808)
 constexpr int CONST_EXTRA = 5;
 
 struct DevEvent {
@@ -48,14 +47,15 @@ struct DevEvent {
   uint64_t off_drawass; // uint8[n_draw]: chain 0's final pick for every drawing read
   uint64_t off_stats;   // per chain: {uint64 counts_hash; int32 accepted; int32 pad}
   uint64_t off_trace;   // int32[(M+1) x C x K] or ~0 when not requested
-  // algorithm = MARGINAL (single-end; sampler_marginal, kernels_marginal.hip): every read class with a compatible
-  // isoform, in the column order of the header's classes: MCLS_WORDS u32 each {mask low, mask high, reads, 0};
-  // the constants carry K more doubles behind the 3K + CONST_EXTRA: 1 / effective length (miso.c:800-808)
+  // algorithm = MARGINAL / CLASSES (single-end; sampler_marginal, kernels_marginal.hip): the classes the marginal
+  // likelihood sums over, K + 1 doubles each: a weight per isoform and the number of reads.  MARGINAL: every read
+  // class with a compatible isoform, in the column order of the header's classes, weight 1 / effective length for its
+  // isoforms (miso.c:800-808), 0 for the others; CLASSES: the gene's possible read classes that have reads, weight =
+  // the class's share of the isoform's read start positions (miso.c:788-803)
   uint64_t off_mcls;
   int32_t n_mcls;
   int32_t pad_mcls;
 };
-constexpr int MCLS_WORDS = 4;
 constexpr int MARGINAL_VECTORS = 9;   // sampler_marginal: alpha, alpha', psi, psi', log psi (2), log(psi / last) (2), scratch
 inline std::size_t marginal_lds_bytes(int ks, int lanes) { return static_cast<std::size_t>(MARGINAL_VECTORS) * ks * lanes * 8; }
 

@@ -314,11 +314,10 @@ SimReads simulate_paired_reads(const Gene &g, const double *expr, int npairs, in
 void validate_params(const miso_params_t &p) {
   // miso.c:674-717 / miso_paired.c:285-339, plus what this build does not restate
   if (!p.paired) {
-    // (CLASSES: miso.c:790 sizes its `matches` vector with the still uninitialised noClasses and needs
-    // splicing_assignment_matrix's enumeration of every possible read class of the gene: not restated)
-    if (p.algorithm == MISO_ALGO_CLASSES)
-      MISO_FAIL(MISO_UNIMPLEMENTED, "The CLASSES algorithm is not implemented (REASSIGN and MARGINAL are)");
-    if (p.algorithm != MISO_ALGO_REASSIGN && p.algorithm != MISO_ALGO_MARGINAL) MISO_FAIL(MISO_EINVAL, "`algorithm` is invalid");
+    if (p.algorithm != MISO_ALGO_REASSIGN && p.algorithm != MISO_ALGO_MARGINAL && p.algorithm != MISO_ALGO_CLASSES)
+      MISO_FAIL(MISO_EINVAL, "`algorithm` is invalid");
+    if (p.algorithm == MISO_ALGO_CLASSES && p.overHang > 1)   // assignment.c:103-106
+      MISO_FAIL(MISO_UNIMPLEMENTED, "Overhang is not implemented in assignment matrix yet.");
   }
   if (p.start == MISO_START_GIVEN)
     MISO_FAIL(MISO_EINVAL, "`start_psi' must be given when starting from a given PSI");
@@ -424,15 +423,15 @@ PackedEvent pack_event_masks(const miso_params_t &p, const FragmentDist *fd, int
   std::vector<double> isoscore_tab;  // paired: il x K
   const bool marginal = !p.paired && p.algorithm == MISO_ALGO_MARGINAL;
   if (marginal && se_values) MISO_FAIL(MISO_UNIMPLEMENTED, "The MARGINAL algorithm needs a 0/1 match matrix");
+  std::vector<double> invlen(K, 1.0);
   if (!p.paired) {
-    if (marginal) e.consts.resize(4 * K + CONST_EXTRA, 1.0);
     for (int k = 0; k < K; k++) {
       const int l = isolen[k] - p.readLength + 1 - 2 * (noexons[k] - 1) * (ov - 1);
       const int eff = l > 0 ? l : 0;
       e.consts[k] = std::log(static_cast<double>(eff));
       e.consts[K + k] = -std::log(static_cast<double>(l));
       // miso.c:800-808: the marginal algorithm's match matrix is divided by the effective length where that is not 0
-      if (marginal && eff != 0) e.consts[3 * K + CONST_EXTRA + k] = 1.0 / eff;
+      if (marginal && eff != 0) invlen[k] = 1.0 / eff;
     }
   } else {
     isoscore_tab.resize(static_cast<size_t>(il) * K);
@@ -626,10 +625,8 @@ PackedEvent pack_event_masks(const miso_params_t &p, const FragmentDist *fd, int
       for (int k = 0; k < K; k++) e.class_templates.push_back((kv.first >> (K - 1 - k)) & 1ull ? 1.0 : 0.0);
       e.class_counts.push_back(kv.second);
       if (marginal && kv.first != 0) {   // the classes the marginal likelihood sums over, in this order (device.hpp)
-        uint64_t m = 0;
-        for (int k = 0; k < K; k++) m |= ((kv.first >> (K - 1 - k)) & 1ull) << k;
-        e.mcls_tab.insert(e.mcls_tab.end(), {static_cast<uint32_t>(m), static_cast<uint32_t>(m >> 32),
-                                            static_cast<uint32_t>(kv.second), 0u});
+        for (int k = 0; k < K; k++) e.mcls_tab.push_back(((kv.first >> (K - 1 - k)) & 1ull) ? invlen[k] : 0.0);
+        e.mcls_tab.push_back(kv.second);
       }
     }
   }
@@ -638,6 +635,102 @@ PackedEvent pack_event_masks(const miso_params_t &p, const FragmentDist *fd, int
     e.class_counts.push_back(kv.second);
   }
   return e;
+}
+
+
+// ---- algorithm = CLASSES: the gene's possible read classes (assignment.c:90-276, stated as WHAT it computes) ----
+// A read of readLength bases starting at genomic position p lies on isoform k with a definite alignment (exon pieces and
+// the gaps between them) or not at all; the isoforms sharing one alignment at p are a class; one column per distinct
+// class = its 0/1 pattern times the number of such positions; columns ordered patterns with a 0 in an earlier isoform
+// first (splicing_i_assignmat_simplify).  Equal to the reference's matrix on random gene structures (the CPU checker's
+// restatement is tested against the reference's function, this one against the checker's).
+namespace {
+std::vector<std::pair<uint64_t, double>> gene_classes(const Gene &g, int readLength) {
+  const int K = g.K;
+  std::vector<std::pair<uint64_t, double>> cls;
+  if (g.exstart.empty()) return cls;
+  const int gs = *std::min_element(g.exstart.begin(), g.exstart.end()), ge = *std::max_element(g.exend.begin(), g.exend.end());
+  std::vector<std::vector<int>> sig(K);
+  for (int p = gs; p <= ge - readLength + 1; p++) {
+    bool any = false;
+    for (int k = 0; k < K; k++) {
+      sig[k].clear();
+      for (int i = g.exidx[k]; i < g.exidx[k + 1]; i++) {
+        if (g.exstart[i] <= p && p <= g.exend[i]) {
+          int rem = readLength, cur = p, j = i;
+          for (;;) {
+            const int avail = g.exend[j] - cur + 1;
+            if (rem <= avail) { sig[k].push_back(rem); rem = 0; break; }
+            sig[k].push_back(avail); rem -= avail;
+            if (j + 1 >= g.exidx[k + 1]) break;
+            sig[k].push_back(-(g.exstart[j + 1] - g.exend[j] - 1));
+            j++; cur = g.exstart[j];
+          }
+          if (rem != 0) sig[k].clear(); else any = true;
+          break;
+        }
+      }
+    }
+    if (!any) continue;
+    uint64_t done = 0;
+    for (int k = 0; k < K; k++) {
+      if (sig[k].empty() || ((done >> k) & 1ull)) continue;
+      uint64_t m = 1ull << k;
+      for (int k2 = k + 1; k2 < K; k2++) if (sig[k2] == sig[k]) m |= 1ull << k2;
+      done |= m;
+      size_t c = 0;
+      while (c < cls.size() && cls[c].first != m) c++;
+      if (c == cls.size()) cls.emplace_back(m, 0.0);
+      cls[c].second += 1.0;
+    }
+  }
+  std::sort(cls.begin(), cls.end(), [](const std::pair<uint64_t, double> &x, const std::pair<uint64_t, double> &y) {
+    const uint64_t d = x.first ^ y.first;
+    return d != 0 && !((x.first >> __builtin_ctzll(d)) & 1ull);   // 0 at the first isoform where they differ: first
+  });
+  return cls;
+}
+}  // namespace
+
+std::vector<double> assignment_matrix(const Gene &g, int readLength, int overHang) {
+  if (overHang > 1) MISO_FAIL(MISO_UNIMPLEMENTED, "Overhang is not implemented in assignment matrix yet.");
+  const auto cls = gene_classes(g, readLength);
+  std::vector<double> m(cls.size() * static_cast<size_t>(g.K), 0.0);
+  for (size_t c = 0; c < cls.size(); c++)
+    for (int k = 0; k < g.K; k++) if ((cls[c].first >> k) & 1ull) m[c * g.K + k] = cls[c].second;
+  return m;
+}
+
+void attach_gene_classes(PackedEvent &e, const miso_params_t &p, const Gene &g) {
+  if (p.paired || p.algorithm != MISO_ALGO_CLASSES) return;
+  const int K = g.K;
+  const int ov = p.overHang == 0 ? 1 : p.overHang;
+  std::vector<double> a = assignment_matrix(g, p.readLength, ov);
+  const size_t nc = a.size() / K;
+  for (int k = 0; k < K; k++) {   // matrix.pmt:1525-1541: every isoform's row sums to 1
+    double rowsum = 0.0;
+    for (size_t c = 0; c < nc; c++) rowsum += a[c * K + k];
+    for (size_t c = 0; c < nc; c++) a[c * K + k] /= rowsum;
+  }
+  // solve.c:122-134 read by read = the event's own read classes (pattern, reads), each to the first column with its pattern
+  std::vector<double> reads(nc, 0.0);
+  const size_t nrc = e.class_counts.size();
+  for (size_t r = 0; r < nrc; r++) {
+    for (size_t c = 0; c < nc; c++) {
+      bool same = true;
+      for (int k = 0; k < K && same; k++) {
+        const double m1 = e.class_templates[r * K + k], m2 = a[c * K + k];
+        same = (m1 > 0 && m2 > 0) || (m1 == 0 && m2 == 0);
+      }
+      if (same) { reads[c] += e.class_counts[r]; break; }
+    }
+  }
+  e.mcls_tab.clear();
+  for (size_t c = 0; c < nc; c++) {   // a class without reads adds log(score) * 0 (miso.c:293): nothing
+    if (reads[c] == 0.0) continue;
+    e.mcls_tab.insert(e.mcls_tab.end(), a.begin() + c * K, a.begin() + (c + 1) * K);
+    e.mcls_tab.push_back(reads[c]);
+  }
 }
 
 }  // namespace miso

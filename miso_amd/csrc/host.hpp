@@ -115,7 +115,7 @@ struct PackedEvent {
   std::vector<uint16_t> draw_dense;     // raw little-endian storage; empty = not available
   std::vector<int32_t> sfix_dense;      // K x (il + 2)
   bool dense_nobad = false;             // no compatible (read, isoform) of a drawing read has a non-finite score
-  std::vector<uint32_t> mcls_tab;       // algorithm = MARGINAL: MCLS_WORDS per read class with a compatible isoform (device.hpp)
+  std::vector<double> mcls_tab;         // algorithm = MARGINAL / CLASSES: K + 1 doubles per class (device.hpp DevEvent::off_mcls)
   std::vector<int32_t> fixed_ass;       // N: -1 / isoform for fixed reads, -2 for drawing reads
   // header material for the caller (miso.c:762, miso_paired.c:386-391)
   std::vector<double> class_templates;  // K x ncls
@@ -141,6 +141,12 @@ PackedEvent pack_event(const miso_params_t &p, const FragmentDist *fd, int K, in
 PackedEvent pack_event_masks(const miso_params_t &p, const FragmentDist *fd, int K, int N,
                              const uint64_t *masks, const uint16_t *frags, const double *se_values,
                              const int *isolen, const int *noexons, const double *hyper);
+// algorithm = CLASSES (miso.c:788-803): the event's table of the gene's possible read classes (splicing_assignment_matrix,
+// assignment.c:90-276; rows normalised; the reads of every class, solve.c:110-137) from the gene's structure and the
+// event's own read classes.  After pack_event*; MISO_UNIMPLEMENTED with an overhang above 1, as the reference.
+void attach_gene_classes(PackedEvent &e, const miso_params_t &p, const Gene &g);
+// the matrix itself (tests): K x (returned) columns, column-major
+std::vector<double> assignment_matrix(const Gene &g, int readLength, int overHang);
 // (33 ... MISO_MAX_ISOFORMS isoforms: no read classes, work units or dense records are made -- those serve the kernels
 // for up to 32 isoforms; such an event is sampled by sampler_wave, lane k = isoform k, runtime.hip)
 

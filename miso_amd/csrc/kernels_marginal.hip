@@ -1,4 +1,4 @@
-// kernels_marginal.hip -- sampler_marginal: algorithm = MISO_ALGO_MARGINAL (single-end), one chain per LANE.
+// kernels_marginal.hip -- sampler_marginal: algorithm = MISO_ALGO_MARGINAL and MISO_ALGO_CLASSES (single-end), one chain per LANE.
 //
 // The reference's second algorithm (splicing_miso with SPLICING_ALGO_MARGINAL: miso.c:272-283 inside the score,
 // 800-808 for the match matrix, 841 / 895-898 for what it leaves out) keeps no assignment of reads to isoforms: the
@@ -6,8 +6,12 @@
 //     sum over reads of log( sum_k match[k, read] / effective length_k * psi_k ),
 // with the same Dirichlet prior, drift proposal and acceptance rule as the default algorithm (miso.c:97-241, 449-552).
 // Reads compatible with the same isoforms contribute the same term, so the sum runs over the event's read CLASSES
-// (device.hpp MCLS_WORDS: mask, number of reads; the order of the header's classes), count x log -- the counter
-// contract's "sums over reads by counts", as for the default algorithm's scores.  An iteration is a few dozen
+// (device.hpp DevEvent::off_mcls: a weight per isoform and the number of reads; the order of the header's classes),
+// count x log -- the counter contract's "sums over reads by counts", as for the default algorithm's scores.
+// SPLICING_ALGO_CLASSES (miso.c:284-295, 788-803) is the same chain with other weights: the classes are the gene's
+// POSSIBLE read classes (every start position of a read along every isoform, assignment.c:90-276), the weight of
+// isoform k in class c the share of k's start positions that give c -- the table is made by the host (host.cpp
+// attach_gene_classes) and this kernel does not know the difference.  An iteration is a few dozen
 // transcendentals and no read loop at all: one chain per lane, the chain's vectors in LDS as [vector][isoform][lane]
 // (sampler_lane_k's layout; 64 lanes per workgroup up to 32 isoforms, 32 lanes beyond: runtime.hip).
 //
@@ -41,10 +45,10 @@ __global__ __launch_bounds__(64) void sampler_marginal(const KernelArgs a) {
   const int K = E.K, len = K - 1;
   const uint32_t event_id = E.has_id ? E.explicit_id : a.first_event_id + static_cast<uint32_t>(ev);
   const double *consts = reinterpret_cast<const double *>(a.in_pool + E.off_consts);
-  const double *hm1 = consts + 2 * K, *invlen = consts + 3 * K + CONST_EXTRA;
+  const double *hm1 = consts + 2 * K;
   const double lg_sum = consts[3 * K], lg_each = consts[3 * K + 1], sigma = consts[3 * K + 2], sd = consts[3 * K + 3],
                covar = consts[3 * K + 4];
-  const uint32_t *mcls = reinterpret_cast<const uint32_t *>(a.in_pool + E.off_mcls);
+  const double *mcls = reinterpret_cast<const double *>(a.in_pool + E.off_mcls);   // K + 1 doubles per class (device.hpp)
   const int n_mcls = E.n_mcls;
   double *samples = reinterpret_cast<double *>(a.out_pool + E.off_samples);
   double *loglik = reinterpret_cast<double *>(a.out_pool + E.off_loglik);
@@ -87,11 +91,10 @@ __global__ __launch_bounds__(64) void sampler_marginal(const KernelArgs a) {
   auto joint = [&](int psi, int lp) {
     double readProb = 0.0, psiProb = 0.0;
     for (int c = 0; c < n_mcls; c++) {
-      const uint32_t *row = mcls + MCLS_WORDS * c;
-      const uint64_t mask = static_cast<uint64_t>(row[0]) | (static_cast<uint64_t>(row[1]) << 32);
+      const double *row = mcls + static_cast<size_t>(K + 1) * c;
       double s = 0.0;
-      for (int k = 0; k < K; k++) if ((mask >> k) & 1ull) s += invlen[k] * LV(psi, k);
-      if (s != 0) readProb = readProb + static_cast<double>(row[2]) * miso_det_log(s);
+      for (int k = 0; k < K; k++) s += row[k] * LV(psi, k);   // (the reference adds the other isoforms' zeros too)
+      if (s != 0) readProb = readProb + row[K] * miso_det_log(s);
     }
     for (int i = 0; i < K; i++) psiProb += hm1[i] * LV(lp, i);
     psiProb += lg_sum;

@@ -261,6 +261,7 @@ void miso_batch::resolve_pending() {
         }
         events[q.event] = pack_event_masks(p, pe ? &fd : nullptr, K, N, mk, f, nullptr, q.gene.isolen.data(),
                                            q.gene.noexons.data(), q.hyper.empty() ? nullptr : q.hyper.data());
+        attach_gene_classes(events[q.event], p, q.gene);   // algorithm = CLASSES only
       }
     } catch (const Error &e) { codes[t] = e.code; errors[t] = e.text;
     } catch (const std::bad_alloc &) { codes[t] = MISO_ENOMEM; errors[t] = "Error at runtime.hip:0: allocation failed, Out of memory";
@@ -314,8 +315,8 @@ void miso_batch::upload(int dev) {
       d.off_dense = in_off; in_off = align_up(in_off + e.draw_dense.size() * 2, 16);
       d.off_sfixd = in_off; in_off = align_up(in_off + e.sfix_dense.size() * 4, 16);
     }
-    d.n_mcls = static_cast<int32_t>(e.mcls_tab.size() / MCLS_WORDS);
-    d.off_mcls = in_off; in_off = align_up(in_off + e.mcls_tab.size() * 4, 16);
+    d.n_mcls = static_cast<int32_t>(e.mcls_tab.size() / (e.K + 1));
+    d.off_mcls = in_off; in_off = align_up(in_off + e.mcls_tab.size() * 8, 16);
     d.off_samples = out_off; out_off = align_up(out_off + static_cast<uint64_t>(Sn) * e.K * 8, 16);
     d.off_loglik = out_off; out_off = align_up(out_off + static_cast<uint64_t>(Sn) * 8, 16);
     d.off_drawass = out_off; out_off = align_up(out_off + static_cast<uint64_t>(e.n_draw), 16);
@@ -349,7 +350,7 @@ void miso_batch::upload(int dev) {
       if (!e.dcls_pairs.empty())
         std::memcpy(h_in.data() + d.off_clsmask, e.dcls_pairs.data(), e.dcls_pairs.size() * 2);
     }
-    if (!e.mcls_tab.empty()) std::memcpy(h_in.data() + d.off_mcls, e.mcls_tab.data(), e.mcls_tab.size() * 4);
+    if (!e.mcls_tab.empty()) std::memcpy(h_in.data() + d.off_mcls, e.mcls_tab.data(), e.mcls_tab.size() * 8);
     if (!e.sfix_table.empty())
       std::memcpy(h_in.data() + d.off_sfix, e.sfix_table.data(), e.sfix_table.size() * 4);
     if (!e.draw_dense.empty()) {
@@ -483,10 +484,10 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   last_kernels.clear();
   if (!launched_once) coop_wgs_used = 0;
 
-  // ---- algorithm = MARGINAL (miso.c:272-283, 800-808): Metropolis-Hastings on psi alone, no reads to reassign ----
+  // ---- algorithm = MARGINAL / CLASSES (miso.c:272-295, 788-808): Metropolis-Hastings on psi alone, no reads to reassign ----
   // One chain per lane, every event of the batch in one launch (kernels_marginal.hip); its vectors live in LDS,
   // [vector][isoform][lane], 64 lanes per workgroup up to 32 isoforms, 32 beyond.
-  if (!p.paired && p.algorithm == MISO_ALGO_MARGINAL) {
+  if (!p.paired && (p.algorithm == MISO_ALGO_MARGINAL || p.algorithm == MISO_ALGO_CLASSES)) {
     int ks = 2;
     for (const PackedEvent &e : events) ks = std::max(ks, e.K);
     const int lanes = ks <= 32 ? 64 : 32;

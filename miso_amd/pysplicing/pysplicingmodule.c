@@ -568,10 +568,30 @@ static PyObject *py_simulate_paired_reads(PyObject *self, PyObject *args, PyObje
   return simulate_common(gff, expression, n, readLength, mean, var, devs, seedobj);
 }
 
+/* assignmentMatrix(gff, gene, readLength[, overhang]) (pysplicing.c:324-349): K tuples (one per isoform) of ncls floats */
+static PyObject *py_assignment_matrix(PyObject *self, PyObject *args) {
+  PyObject *gff, *rows; int gene, readLength, overhang = 1, K, nc = 0, rc, i, j; miso_gene_t *g; double *m;
+  if (!PyArg_ParseTuple(args, "Oii|i", &gff, &gene, &readLength, &overhang)) return NULL;
+  if (!(g = as_gene(gff))) return NULL;
+  if ((rc = miso_gene_noiso(g, &K))) return raise_miso(rc);
+  m = (double *) PyMem_Malloc(sizeof(double) * (size_t) K * 8192);
+  if (!m) return PyErr_NoMemory();
+  rc = miso_gene_assignment_matrix(g, readLength, overhang, m, 8192, &nc);
+  if (rc) { PyMem_Free(m); return raise_miso(rc); }
+  rows = PyTuple_New(K);
+  for (i = 0; rows && i < K; i++) {
+    PyObject *r = PyTuple_New(nc);
+    for (j = 0; r && j < nc; j++) PyTuple_SET_ITEM(r, j, PyFloat_FromDouble(m[(size_t) j * K + i]));
+    PyTuple_SET_ITEM(rows, i, r);
+  }
+  PyMem_Free(m);
+  return rows;
+}
+
 static PyObject *py_not_on_path(PyObject *self, PyObject *args) {
   PyErr_SetString(PyExc_NotImplementedError,
                   "this pysplicing function is not on the MISO sampler path and is not provided by "
-                  "the MI355X build (only createGene, MISO, MISOPaired, noIso, isoLength, "
+                  "the MI355X build (only createGene, MISO, MISOPaired, noIso, isoLength, assignmentMatrix, "
                   "simulateReads, simulatePairedReads and the *Batch entry points are)");
   return NULL;
 }
@@ -596,7 +616,7 @@ static PyMethodDef methods[] = {
   {"deviceCount", py_device_count, METH_NOARGS, "Number of usable HIP devices"},
   {"readGFF", py_not_on_path, METH_VARARGS, "not provided"},
   {"writeGFF", py_not_on_path, METH_VARARGS, "not provided"},
-  {"assignmentMatrix", py_not_on_path, METH_VARARGS, "not provided"},
+  {"assignmentMatrix", py_assignment_matrix, METH_VARARGS, "The gene's possible read classes and their numbers of start positions"},
   {"solveIsoGene", py_not_on_path, METH_VARARGS, "not provided"},
   {"geneComplexity", py_not_on_path, METH_VARARGS, "not provided"},
   {"noGenes", py_not_on_path, METH_VARARGS, "not provided"},

@@ -647,6 +647,78 @@ static void classes(const double *m, int K, int n, const int *order, int bin,
   *ncls = nc;
 }
 
+/* The gene's POSSIBLE read classes with the number of start positions of each (splicing_assignment_matrix,
+   assignment.c:90-276, as a statement of WHAT it computes rather than of its walk over run-length encoded isoforms):
+   a read of readLength bases starting at genomic position p lies on isoform k with a definite alignment (exon pieces
+   and the gaps between them) or not at all; the isoforms that share one alignment at p form a class, and the matrix
+   has one column per distinct class = its 0/1 pattern times the number of positions, the columns ordered patterns with
+   a 0 in an earlier isoform first (splicing_i_assignmat_simplify).  Checked against the reference's own function on
+   random gene structures (tests/test_oracle_vs_ref.py).  out: K x (returned columns), column-major; at most max_cols. */
+static int assignment_classes(const orc_gene_t *g, int readLength, double *out, int max_cols) {
+  int K = g->K, k, i, nc = 0, gs = 0, ge = 0, first = 1, p;
+  int sig[64][130], siglen[64];
+  uint64_t *masks; double *cnt;
+  if (K < 1 || K > 64 || max_cols < 1) return -1;
+  masks = malloc(sizeof(uint64_t) * (size_t) max_cols);
+  cnt = calloc((size_t) max_cols, sizeof(double));
+  for (k = 0; k < K; k++) for (i = g->exidx[k]; i < g->exidx[k + 1]; i++) {
+    if (first || g->exstart[i] < gs) gs = g->exstart[i];
+    if (first || g->exend[i] > ge) ge = g->exend[i];
+    first = 0;
+  }
+  for (p = gs; p <= ge - readLength + 1; p++) {
+    int any = 0;
+    uint64_t done = 0;
+    for (k = 0; k < K; k++) {
+      siglen[k] = 0;
+      for (i = g->exidx[k]; i < g->exidx[k + 1]; i++) {
+        if (g->exstart[i] <= p && p <= g->exend[i]) {
+          int rem = readLength, cur = p, j = i, n = 0;
+          for (;;) {
+            int avail = g->exend[j] - cur + 1;
+            if (rem <= avail) { sig[k][n++] = rem; rem = 0; break; }
+            sig[k][n++] = avail; rem -= avail;
+            if (j + 1 >= g->exidx[k + 1] || n > 126) break;
+            sig[k][n++] = -(g->exstart[j + 1] - g->exend[j] - 1);
+            j++; cur = g->exstart[j];
+          }
+          if (rem == 0) { siglen[k] = n; any = 1; }
+          break;
+        }
+      }
+    }
+    if (!any) continue;
+    for (k = 0; k < K; k++) {
+      uint64_t m; int k2, c;
+      if (!siglen[k] || ((done >> k) & 1)) continue;
+      m = 1ull << k;
+      for (k2 = k + 1; k2 < K; k2++)
+        if (siglen[k2] == siglen[k] && !memcmp(sig[k], sig[k2], sizeof(int) * (size_t) siglen[k])) m |= 1ull << k2;
+      done |= m;
+      for (c = 0; c < nc && masks[c] != m; c++) ;
+      if (c == nc) { if (nc == max_cols) { free(masks); free(cnt); return -1; } masks[nc++] = m; }
+      cnt[c] += 1.0;
+    }
+  }
+  { /* column order: a pattern with 0 where the other has 1, at the first isoform where they differ, comes first */
+    int a, b;
+    for (a = 1; a < nc; a++) for (b = a; b > 0; b--) {
+      uint64_t x = masks[b - 1], y = masks[b], d = x ^ y;
+      if (!d || !((x >> __builtin_ctzll(d)) & 1)) break;
+      masks[b - 1] = y; masks[b] = x;
+      { double t = cnt[b - 1]; cnt[b - 1] = cnt[b]; cnt[b] = t; }
+    }
+  }
+  for (i = 0; i < nc; i++) for (k = 0; k < K; k++) out[(size_t) i * K + k] = ((masks[i] >> k) & 1) ? cnt[i] : 0.0;
+  free(masks); free(cnt);
+  return nc;
+}
+
+int orc_assignment_matrix(const orc_gene_t *g, int readLength, int overHang, double *out, int max_cols) {
+  if (overHang > 1) return -1 - ORC_UNIMPLEMENTED;   /* assignment.c:103-106 */
+  return assignment_classes(g, readLength, out, max_cols);
+}
+
 /* ------------------------------------------------------------------------------------ */
 /* Sampler pieces shared by single-end and paired-end                                    */
 /* ------------------------------------------------------------------------------------ */
@@ -659,6 +731,9 @@ typedef struct {
   int collapsed;         /* opts->mode == ORC_MODE_COLLAPSED: reassign_collapsed() except for the run's last reassignment */
   int count_sums;        /* use count-based score sums */
   int marginal;          /* SPLICING_ALGO_MARGINAL: no assignments, the reads enter through the marginal likelihood */
+  int ncls_a;            /* SPLICING_ALGO_CLASSES (marginal is set too): the gene's possible read classes ... */
+  const double *amat;    /* ... K x ncls_a, rows normalised (miso.c:794-797), and ... */
+  const double *amatches; /* ... the reads of every class (solve.c:110-137) */
   const double *match;   /* K x N */
   const int *order;      /* N (stream mode draw order) */
   int *corder;           /* N (counter mode draw order, single-end): see counter_order() */
@@ -868,6 +943,15 @@ static double score_joint(const orc_state_t *S, int chain, const double *psi) {
   const int *ass = S->ass + (size_t) chain * N;
   double logpsi[64] = { 0 }, maxv, sum, readProb = 0.0, assProb = 0.0;
   int32_t cnt[64];
+  if (S->marginal && S->amat) { /* miso.c:284-295: the gene's classes, reads per class */
+    int c, k;
+    for (c = 0; c < S->ncls_a; c++) {
+      double score = 0.0;
+      for (k = 0; k < K; k++) score += S->amat[(size_t) c * K + k] * psi[k];
+      if (score != 0) readProb += S->M->log(score) * S->amatches[c];
+    }
+    return readProb + assProb + ldirichlet(S, psi);
+  }
   if (S->marginal) { /* miso.c:272-283; S->match holds match / effective length (miso.c:800-808) */
     int k;
     if (!S->count_sums) {
@@ -1071,6 +1155,18 @@ static int convergent_mean(const double *samples, int K, int C, int noSamples) {
   return stop;
 }
 
+/* score_joint's CLASSES branch on caller-made inputs (tests: against ref_shim.c ref_score_classes), libm */
+double orc_score_classes(int K, const double *psi, const double *hyper, const double *amat, int ncls,
+                         const double *matches) {
+  orc_state_t S; int i; double asum = 0.0, lge = 0.0;
+  memset(&S, 0, sizeof(S));
+  S.K = K; S.N = 0; S.C = 1; S.M = &MATH_LIBM; S.marginal = 1; S.amat = amat; S.amatches = matches; S.ncls_a = ncls;
+  S.hyper = hyper;
+  for (i = 0; i < K; i++) { asum += hyper[i]; lge += lgamma(hyper[i]); }
+  S.lg_sum = lgamma(asum); S.lg_each = lge;
+  return score_joint(&S, 0, psi);
+}
+
 uint32_t orc_split_word(uint64_t seed, uint32_t event_id, uint32_t chain, uint32_t iteration, uint32_t r) {
   return miso_split_word(seed, event_id, chain, iteration, r);
 }
@@ -1175,13 +1271,12 @@ int orc_miso(const orc_gene_t *g, const int *pos, const char **cigar, int nreads
              int start, int stop, const orc_opts_t *opts, double *samples, double *logLik,
              double *match_out, double *class_templates, double *class_counts, int *ncls,
              int *assignment, int *rundata, orc_trace_t *trace) {
-  orc_state_t S; int K, i, rc, noSamples;
-  double *match; int *order, *eff; double *logeff, *isoscores;
+  orc_state_t S; int K, i, rc, noSamples, ncls_a = 0;
+  double *match, *amat = 0, *amatches = 0; int *order, *eff; double *logeff, *isoscores;
   static const orc_opts_t stream_opts = { ORC_MODE_STREAM, 0, 0, 0 };
   if (!opts) opts = &stream_opts;
-  if (algorithm == 2) return ORC_UNIMPLEMENTED;                   /* CLASSES: not restated */
-  if (algorithm != ORC_ALGO_REASSIGN && algorithm != 1) return ORC_EINVAL; /* miso.c:674-678 */
-  if (algorithm == 1 && opts->mode == ORC_MODE_COLLAPSED) return ORC_EINVAL; /* nothing to collapse: no assignments */
+  if (algorithm != ORC_ALGO_REASSIGN && algorithm != 1 && algorithm != 2) return ORC_EINVAL; /* miso.c:674-678 */
+  if (algorithm != ORC_ALGO_REASSIGN && opts->mode == ORC_MODE_COLLAPSED) return ORC_EINVAL; /* nothing to collapse: no assignments */
   rc = check_common(g, &overHang, readLength, noChains, noIterations, noBurnIn, noLag, nhyper,
                     start, stop);
   if (rc) return rc;
@@ -1211,8 +1306,32 @@ int orc_miso(const orc_gene_t *g, const int *pos, const char **cigar, int nreads
     for (i = 0; i < K; i++) for (j = 0; j < nreads; j++)
       if (eff[i] != 0) match[(size_t) j * K + i] /= eff[i];
   }
+  if (algorithm == 2) { /* miso.c:788-803: the assignment matrix, rows normalised, and the reads of every class */
+    int c, r, kk;
+    if (overHang > 1) { free(match); free(order); free(eff); free(logeff); free(isoscores); return ORC_UNIMPLEMENTED; } /* assignment.c:103 */
+    amat = malloc(sizeof(double) * (size_t) K * 4096);
+    ncls_a = assignment_classes(g, readLength, amat, 4096);
+    if (ncls_a < 0) { free(amat); free(match); free(order); free(eff); free(logeff); free(isoscores); return ORC_EINVAL; }
+    for (kk = 0; kk < K; kk++) { /* matrix.pmt:1525-1541 */
+      double rowsum = 0.0;
+      for (c = 0; c < ncls_a; c++) rowsum += amat[(size_t) c * K + kk];
+      for (c = 0; c < ncls_a; c++) amat[(size_t) c * K + kk] /= rowsum;
+    }
+    amatches = calloc((size_t) (ncls_a > 0 ? ncls_a : 1), sizeof(double));
+    for (r = 0; r < nreads; r++) { /* solve.c:122-134: the first class with the read's pattern */
+      for (c = 0; c < ncls_a; c++) {
+        int same = 1;
+        for (kk = 0; kk < K && same; kk++) {
+          double m1 = match[(size_t) r * K + kk], m2 = amat[(size_t) c * K + kk];
+          same = (m1 > 0 && m2 > 0) || (m1 == 0 && m2 == 0);
+        }
+        if (same) { amatches[c] += 1; break; }
+      }
+    }
+  }
   fill_common(&S, g, opts, hyper, noChains, nreads);
-  S.marginal = algorithm == 1;
+  S.marginal = algorithm == 1 || algorithm == 2;
+  S.amat = amat; S.amatches = amatches; S.ncls_a = ncls_a;
   S.match = match; S.order = order; S.effisolen = eff; S.logeff = logeff; S.isoscores = isoscores;
   memset(samples, 0, sizeof(double) * (size_t) K * noSamples);
   memset(logLik, 0, sizeof(double) * noSamples);
@@ -1225,7 +1344,7 @@ int orc_miso(const orc_gene_t *g, const int *pos, const char **cigar, int nreads
   for (i = 0; i < nreads; i++) assignment[i] = S.ass[i]; /* chain 0: miso.c:943-946 */
   if (match_out) memcpy(match_out, match, sizeof(double) * (size_t) K * nreads);
   free_common(&S);
-  free(match); free(order); free(eff); free(logeff); free(isoscores);
+  free(match); free(order); free(eff); free(logeff); free(isoscores); free(amat); free(amatches);
   return ORC_SUCCESS;
 }
 

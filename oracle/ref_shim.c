@@ -213,6 +213,40 @@ int ref_convergent_mean(const double *samples, int K, int C, int n) {
   return stop;
 }
 
+/* splicing_assignment_matrix (assignment.c:90-276): noiso x ncol, column-major; returns ncol or -1 - code */
+int ref_assignment_matrix(void *g, int readLength, int overHang, double *out, int max_cols) {
+  splicing_matrix_t m; int rc, nc, K;
+  splicing_matrix_init(&m, 0, 0);
+  rc = splicing_assignment_matrix((splicing_gff_t *) g, 0, readLength, overHang, &m);
+  if (rc) { splicing_matrix_destroy(&m); return -1 - rc; }
+  nc = (int) splicing_matrix_ncol(&m); K = (int) splicing_matrix_nrow(&m);
+  if (nc <= max_cols) memcpy(out, &MATRIX(m, 0, 0), sizeof(double) * (size_t) K * nc);
+  splicing_matrix_destroy(&m);
+  return nc;
+}
+
+/* splicing_score_joint for SPLICING_ALGO_CLASSES (miso.c:243-307, branch :284-295) on caller-made inputs -- the
+   sampler itself reads its per-class read counts before initialising them (miso.c:790), so the formula is pinned here:
+   amat K x ncls column-major (rows already normalised), matches ncls, one chain */
+double ref_score_classes(int K, const double *psi, const double *hyper, const double *amat, int ncls,
+                         const double *matches) {
+  splicing_matrix_t mpsi, ma, mm; splicing_vector_t h, m, sc, iso; splicing_vector_int_t eff; splicing_matrix_int_t ass;
+  double out; int i;
+  ref_init();
+  splicing_matrix_init(&mpsi, K, 1); splicing_matrix_init(&ma, K, ncls); splicing_matrix_init(&mm, K, 1);
+  fill_vec(&h, hyper, K); fill_vec(&m, matches, ncls);
+  splicing_vector_init(&sc, 1); splicing_vector_init(&iso, K); splicing_vector_int_init(&eff, K);
+  splicing_matrix_int_init(&ass, 1, 1);
+  for (i = 0; i < K; i++) MATRIX(mpsi, i, 0) = psi[i];
+  memcpy(&MATRIX(ma, 0, 0), amat, sizeof(double) * (size_t) K * ncls);
+  splicing_score_joint(SPLICING_ALGO_CLASSES, &ass, 0, 1, &mpsi, &h, &eff, &iso, &mm, &ma, &m, &sc);
+  out = VECTOR(sc)[0];
+  splicing_matrix_int_destroy(&ass); splicing_vector_int_destroy(&eff); splicing_vector_destroy(&iso);
+  splicing_vector_destroy(&sc); splicing_vector_destroy(&m); splicing_vector_destroy(&h);
+  splicing_matrix_destroy(&mm); splicing_matrix_destroy(&ma); splicing_matrix_destroy(&mpsi);
+  return out;
+}
+
 /* ---- the samplers --------------------------------------------------------- */
 
 /* samples: K x S col-major, S = C*(M-B)/lag; class_templates: K x ncls col-major

@@ -99,6 +99,21 @@ class _Base:
     def integer(self, lo, hi):
         return self.f("integer")(lo, hi)
 
+    def assignment_matrix(self, g, read_len, overhang=1, max_cols=4096):
+        """splicing_assignment_matrix (assignment.c:90-276): ncls x K, one class per row; None on an error code"""
+        K = self.noiso(g)
+        out = np.zeros(K * max_cols)
+        n = self.f("assignment_matrix")(g, int(read_len), int(overhang), _p(out), max_cols)
+        return None if n < 0 else out[:K * n].reshape(n, K).copy()
+
+    def score_classes(self, psi, hyper, amat, matches):
+        """the joint score of algorithm=CLASSES (miso.c:284-295 + the Dirichlet prior) for one psi; amat: ncls x K"""
+        psi, hyper = np.ascontiguousarray(psi, np.float64), np.ascontiguousarray(hyper, np.float64)
+        amat, matches = np.ascontiguousarray(amat, np.float64), np.ascontiguousarray(matches, np.float64)
+        f = self.f("score_classes")
+        f.restype = C.c_double
+        return float(f(len(psi), _p(psi), _p(hyper), _p(amat), len(matches), _p(matches)))
+
     def convergent_mean(self, samples, chains):
         """stop=CONVERGENT_MEAN's test (miso.c:556-636): samples S x K, row i from chain i % chains -> 1 stop / 0"""
         a = np.ascontiguousarray(samples, dtype=np.float64)

@@ -93,15 +93,50 @@ def test_marginal_differs_from_reassign_and_needs_single_end(orc):
         b.run(seed=3)
         out.append(b.result(0).samples.mean(0))
     assert np.abs(out[0] - out[1]).max() > 1e-3      # another model (miso.c:272-283 has no length-normalised prior)
+    with pytest.raises(miso_amd.InternalError):
+        miso_amd.Batch(36, paired=True, mean=250.0, var=900.0, algo=7)
+
+
+@pytest.mark.parametrize("device_match", [False, True])
+def test_classes_algorithm_bit_exact(orc, device_match):
+    """algorithm = CLASSES (miso.c:284-295, 788-803): the gene's possible read classes with the reads that fall into
+    them -- the host's table (csrc/host.cpp attach_gene_classes) through sampler_marginal against the checker's run,
+    whose matrix and score are pinned to the reference's own functions (tests/test_oracle_vs_ref.py; the reference's
+    sampler itself reads its per-class counts uninitialised, miso.c:790).  Twenty events of 2 .. 40 isoforms, also under
+    stop = CONVERGENT_MEAN; a caller-made problem has no gene structure to enumerate: NotImplementedError."""
+    rng = np.random.default_rng(12)
+    for stop, iters, burn in ((0, 160, 40), (1, 90, 30)):
+        kw = dict(iters=iters, burn=burn, lag=3, chains=3, algo=capi.MISO_ALGO_CLASSES, stop=stop, max_iters=1500)
+        b = miso_amd.Batch(36, device_match=device_match, **kw)
+        cases = []
+        for e in range(20):
+            K = int(rng.choice([2, 2, 3, 4, 5, 7, 10, 16, 33, 40]))
+            exons, isoforms = se_gene(K)
+            og = orc.gene(flat(exons), isoforms)
+            orc.rng_seed(600 + e)
+            n = int(rng.choice([1, 5, 60, 300, 800]))
+            rc, _, pos, cig = orc.simulate_reads(og, expr_for(K), n, 36)
+            assert rc == 0
+            b.add_event(miso_amd.Gene(exons, isoforms), pos, cig)
+            cases.append((og, pos, cig))
+        b.run(seed=23, first_event_id=500)
+        assert b.last_kernels().split(",")[0] == "sampler_marginal"
+        for e, (og, pos, cig) in enumerate(cases):
+            cpu = orc.miso(og, pos, cig, 36, mode=OrcLib.COUNTER, seed=23, event_id=500 + e, **kw)
+            _equal(b.result(e), cpu)
+    b = miso_amd.Batch(36, algo=capi.MISO_ALGO_CLASSES)
     with pytest.raises(NotImplementedError):
-        miso_amd.Batch(36, algo=capi.MISO_ALGO_CLASSES)
+        b.add_problem(np.ones((3, 2)), isolength=[300, 200], noexons=[3, 2])
 
 
 def test_the_module_call_takes_both_switches(orc):
     """pysplicing.MISO(gene, 0, positions, cigars, readLength, noIterations, noBurnIn, noLag, hyperp, overhang,
     no_chains, start, stop, algo) (pysplicing.c:41-131) with stop=CONVERGENT_MEAN and algo=MARGINAL: the tuple the
     reference's module returns, from the same run as the checker's."""
-    from miso_amd import pysplicing
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "miso_amd"))
+    import pysplicing   # (the one module object tests/test_pysplicing_module.py and miso_sampler use)
     g = _golden.load("se_k3_marginal_convergent")
     gene = pysplicing.createGene(tuple(g["exon_list"]), tuple(tuple(i) for i in g["isoform_list"]))
     res = pysplicing.MISO(gene, 0, tuple(int(p) for p in g["pos"]), tuple(c.decode() for c in g["cigars"]), g["read_len"],

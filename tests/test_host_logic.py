@@ -69,8 +69,9 @@ def test_parameter_errors():
     miso_amd.Batch(36, chains=2, stop=capi.MISO_STOP_CONVERGENT_MEAN)
     with pytest.raises(miso_amd.InternalError, match="`stop` is invalid"):
         miso_amd.Batch(36, chains=2, stop=2)
-    with pytest.raises(NotImplementedError):
-        miso_amd.Batch(36, algo=capi.MISO_ALGO_CLASSES)
+    miso_amd.Batch(36, algo=capi.MISO_ALGO_CLASSES)
+    with pytest.raises(NotImplementedError, match="Overhang is not implemented in assignment matrix"):
+        miso_amd.Batch(36, algo=capi.MISO_ALGO_CLASSES, overhang=2)      # assignment.c:103-106
     miso_amd.Batch(36, algo=capi.MISO_ALGO_MARGINAL)
     with pytest.raises(miso_amd.InternalError, match="`algorithm` is invalid"):
         miso_amd.Batch(36, algo=3)
@@ -211,3 +212,23 @@ def test_convergent_mean_rule_matches_the_checker_and_the_reference(orc):
     assert seen == {True, False}
     with pytest.raises(miso_amd.InternalError):
         capi.selftest_convergent_mean(np.zeros((1, 2)), 2)
+
+
+def test_assignment_matrix_of_the_host_library(orc):
+    """include/miso_amd.h miso_gene_assignment_matrix (what algorithm=CLASSES sums over; the module's assignmentMatrix)
+    against the checker's, which is tested against the reference's own function (tests/test_oracle_vs_ref.py)."""
+    from test_oracle_vs_ref import _random_genes
+    from _problems import flat, se_gene
+    for exons, isoforms in [se_gene(K) for K in (2, 3, 5, 8, 12, 40)] + _random_genes(np.random.default_rng(6), 30):
+        G = miso_amd.Gene(exons, isoforms)
+        og = orc.gene(flat(exons), isoforms)
+        for read_len in (36, 75):
+            assert np.array_equal(G.assignment_matrix(read_len), orc.assignment_matrix(og, read_len)), (exons, isoforms)
+    with pytest.raises(NotImplementedError):
+        G.assignment_matrix(36, overhang=2)
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "miso_amd"))
+    import pysplicing   # (the one module object tests/test_pysplicing_module.py and miso_sampler use)
+    g = pysplicing.createGene(((1, 100), (201, 300), (401, 500)), ((0, 1, 2), (0, 2)))
+    assert pysplicing.assignmentMatrix(g, 0, 36) == ((0.0, 135.0, 130.0), (35.0, 0.0, 130.0))

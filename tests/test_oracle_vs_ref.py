@@ -117,6 +117,89 @@ def test_marginal_algorithm_bit_exact(ref, orc, K, N, ov, chains, iters, burn, l
     _same(rR, rO, chains, iters, burn, lag)
 
 
+def _random_genes(rng, n):
+    out = []
+    while len(out) < n:
+        ne = int(rng.integers(3, 8))
+        cur, exons = 1, []
+        for _ in range(ne):
+            length = int(rng.integers(40, 200))
+            exons.append((cur, cur + length - 1))
+            cur += length + int(rng.integers(1, 300))
+        isoforms, want = [], int(rng.integers(2, 6))
+        for _ in range(200):
+            pick = sorted(set(int(x) for x in rng.choice(ne, size=int(rng.integers(2, ne + 1)), replace=False)))
+            if pick not in isoforms:
+                isoforms.append(pick)
+            if len(isoforms) == want:
+                break
+        if len(isoforms) >= 2:
+            out.append((exons, isoforms))
+    return out
+
+
+def test_assignment_matrix_equals_the_reference(ref, orc):
+    """The gene's possible read classes (splicing_assignment_matrix, assignment.c:90-276): the checker states WHAT the
+    reference's walk over run-length encoded isoforms computes -- per start position the sets of isoforms sharing an
+    alignment -- and must give its matrix, column for column, on the skipped-exon family and on random structures."""
+    # (random structures with reads shorter than every exon: with longer ones the reference itself aborts on some)
+    genes = [(g, (36, 75)) for g in (se_gene(K) for K in (2, 3, 5, 8, 12))] + \
+            [(g, (36,)) for g in _random_genes(np.random.default_rng(2), 40)]
+    for (exons, isoforms), read_lens in genes:
+        gR, gO = _pair(ref, orc, exons, isoforms)
+        for read_len in read_lens:
+            a, b = ref.assignment_matrix(gR, read_len), orc.assignment_matrix(gO, read_len)
+            assert a is not None and b is not None and np.array_equal(a, b), (exons, isoforms, read_len)
+    assert ref.assignment_matrix(gR, 36, overhang=2) is None and orc.assignment_matrix(gO, 36, overhang=2) is None
+
+
+def test_classes_score_equals_the_reference(ref, orc):
+    """algorithm=CLASSES, the score (miso.c:284-295 inside splicing_score_joint): sum over the gene's classes of
+    log(sum_k A[k, c] psi_k) x reads of the class, plus the Dirichlet prior -- the reference's own function on inputs
+    made here (normalised assignment matrices of real gene structures, read counts, psi from a Dirichlet)."""
+    rng = np.random.default_rng(4)
+    for exons, isoforms in [se_gene(K) for K in (2, 3, 5, 8, 12)] + _random_genes(rng, 10):
+        gO = orc.gene(flat(exons), isoforms)
+        a = orc.assignment_matrix(gO, 36)
+        a = a / a.sum(0, keepdims=True)              # matrix.pmt:1525-1541 (the checker's run divides the same way)
+        K = a.shape[1]
+        for _ in range(5):
+            psi = rng.dirichlet(np.ones(K))
+            hyper = rng.choice([1.0, 1.0, 2.5, 0.5], K)
+            matches = rng.integers(0, 300, len(a)).astype(float)
+            assert ref.score_classes(psi, hyper, a, matches) == orc.score_classes(psi, hyper, a, matches)
+
+
+@pytest.mark.parametrize("K,N", [(2, 300), (5, 400), (12, 400)])
+def test_classes_algorithm_bit_exact_where_the_reference_is_defined(ref, orc, K, N):
+    """algorithm=CLASSES end to end (miso.c:788-803).  The reference sizes its per-class read counts with a variable it
+    has not assigned yet (miso.c:790 `noClasses`, set at :798) and solve.c:118 resizes without clearing: the counts
+    start from whatever the heap holds, and one and the same call gives different results from one time to the next.
+    The checker starts them at 0 -- what the code means; its pieces are pinned one by one (the matrix, the score, above;
+    solve.c:122-134 is a pattern match) -- and equals the reference bit for bit whenever the reference's heap happened
+    to be clean: looked for in eight identical calls, skipped if it never was."""
+    exons, isoforms = se_gene(K)
+    gR, gO = _pair(ref, orc, exons, isoforms)
+    kw = dict(iters=300, burn=50, lag=3, chains=2, algo=2)
+    orc.rng_seed(500 + K)
+    b = orc.simulate_reads(gO, expr_for(K), N, 36)
+    rO = orc.miso(gO, b[2], b[3], 36, **kw)
+    assert rO.rc == 0
+    hits = 0
+    for _ in range(8):
+        ref.rng_seed(500 + K)
+        a = ref.simulate_reads(gR, expr_for(K), N, 36)
+        rR = ref.miso(gR, a[2], a[3], 36, **kw)
+        assert rR.rc == 0
+        try:
+            _same(rR, rO, 2, 300, 50, 3)
+            hits += 1
+        except AssertionError:
+            pass
+    if hits == 0:
+        pytest.skip("the reference's uninitialised class counts were never clean in this process")
+
+
 def test_error_codes_match(ref, orc):
     exons, isoforms = se_gene(2)
     gR, gO = _pair(ref, orc, exons, isoforms)

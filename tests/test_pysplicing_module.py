@@ -36,7 +36,7 @@ def test_module_surface():
             pysplicing.MISO_START_GIVEN, pysplicing.MISO_START_LINEAR) == (0, 1, 2, 3, 4)
     assert (pysplicing.MISO_STOP_FIXEDNO, pysplicing.MISO_STOP_CONVERGENT_MEAN) == (0, 1)
     assert (pysplicing.MISO_ALGO_REASSIGN, pysplicing.MISO_ALGO_MARGINAL, pysplicing.MISO_ALGO_CLASSES) == (0, 1, 2)
-    for off_path in ("readGFF", "assignmentMatrix", "solveIsoGene", "geneComplexity"):
+    for off_path in ("readGFF", "solveIsoGene", "geneComplexity"):
         with pytest.raises(NotImplementedError):
             getattr(pysplicing, off_path)("x")
 
