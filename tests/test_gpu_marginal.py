@@ -124,7 +124,7 @@ def test_classes_algorithm_bit_exact(orc, device_match):
             _equal(b.result(e), cpu)
     b = miso_amd.Batch(36, algo=capi.MISO_ALGO_CLASSES)
     with pytest.raises(NotImplementedError):
-        b.add_problem(np.ones((3, 2)), isolength=[300, 200], noexons=[3, 2])
+        b.add_problem(np.ones((3, 2)), isolen=[300, 200], noexons=[3, 2])
 
 
 def test_the_module_call_takes_both_switches(orc):
