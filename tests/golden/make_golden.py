@@ -125,6 +125,22 @@ def marginal_cases(R):
     marginal_case(R, "se_k3_marginal_convergent", 3, 200, 67, 50, 10, 1, 4, stop=1, max_iters=700)
 
 
+def assignment_matrix_case(R):
+    """The reference's splicing_assignment_matrix (assignment.c:90-276) for the skipped-exon family and a few irregular
+    structures: what algorithm=CLASSES sums over.  (Its sampler on that path reads uninitialised counts, miso.c:790, so
+    no CLASSES run is stored; the matrix and the score are the pins.)"""
+    genes = [se_gene(K) for K in (2, 3, 5, 8, 12)]
+    genes.append(([(1, 81), (115, 201), (326, 495), (631, 684), (786, 921)], [[1, 3], [1, 2, 4], [0, 1, 2, 3], [0, 4]]))
+    genes.append(([(1, 60), (100, 180), (400, 520), (700, 760)], [[0, 1, 2, 3], [0, 3], [1, 2], [0, 2, 3], [2, 3]]))
+    out = {}
+    for i, (exons, isoforms) in enumerate(genes):
+        g = R.gene(flat(exons), isoforms)
+        out["exons_%d" % i] = np.asarray(exons, np.int32)
+        out["isoforms_%d" % i] = iso_array(isoforms)
+        out["matrix_%d" % i] = R.assignment_matrix(g, 36)
+    save("assignment_matrix", kind="assignment", n=len(genes), **out)
+
+
 def cigar_edge_case(R):
     """Hand-written alignments exercising solve.c:220-306 / 8-108: clips, =, X, D, I, skips that
     do and do not match the annotation, overhang violations, short reads, reads off the gene."""
@@ -197,6 +213,9 @@ def main():
     saved = os.dup(1)
     os.dup2(devnull, 1)  # the reference prints "no chains: %d" (miso.c:837)
     try:
+        if sys.argv[1:] == ["assignment"]:   # likewise
+            assignment_matrix_case(R)
+            return
         if sys.argv[1:] == ["marginal"]:     # likewise
             marginal_cases(R)
             return
@@ -222,6 +241,7 @@ def main():
         convergent_case(R, "pe_k2_convergent", True, 2, 200, 43, 60, 20, 2, 3, 1500)
         convergent_case(R, "pe_k4_convergent", True, 4, 200, 47, 80, 30, 2, 2, 100000)
         marginal_cases(R)
+        assignment_matrix_case(R)
     finally:
         os.dup2(saved, 1)
     print("done")

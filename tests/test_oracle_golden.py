@@ -168,3 +168,20 @@ def test_two_isoform_uniforms_are_two_half_words_of_two_streams(orc):
         h = r % 8
         want = (((int(hi[h // 2]) >> (16 * (h & 1))) & 0xFFFF) << 16) | ((int(lo[h // 2]) >> (16 * (h & 1))) & 0xFFFF)
         assert orc.split_word(seed, event, chain, iteration, r) == want, r
+
+
+def test_assignment_matrix_golden(orc):
+    """The gene's possible read classes (what algorithm=CLASSES sums over) against the reference's own
+    splicing_assignment_matrix, stored (tests/golden/assignment_matrix.npz)."""
+    z = np.load(_golden.GOLDEN_DIR + "/assignment_matrix.npz", allow_pickle=False)
+    for i in range(int(z["n"])):
+        exons = [tuple(int(v) for v in e) for e in z["exons_%d" % i]]
+        isoforms, cur = [], []
+        for v in z["isoforms_%d" % i]:
+            if v < 0:
+                isoforms.append(cur)
+                cur = []
+            else:
+                cur.append(int(v))
+        got = orc.assignment_matrix(orc.gene(flat(exons), isoforms), 36)
+        assert np.array_equal(got, z["matrix_%d" % i]), i
