@@ -141,6 +141,49 @@ def assignment_matrix_case(R):
     save("assignment_matrix", kind="assignment", n=len(genes), **out)
 
 
+# The five two-isoform alternative-splicing classes of BASELINE configs[2]: skipped exon, retained intron, alternative 3'
+# and 5' splice sites, mutually exclusive exons -- exons that overlap or nest inside one gene (solve.c:8-108, 141-218,
+# gff.c:1041-1084), which the skipped-exon family above never has.  `ri_first` lists the spanning exon first.
+AS_GENES = {
+    "ri": ([(1, 150), (351, 500), (1, 500)], [[0, 1], [2]]),
+    "ri_first": ([(1, 500), (1, 150), (351, 500)], [[1, 2], [0]]),
+    "a3ss": ([(1, 150), (401, 600), (451, 600)], [[0, 1], [0, 2]]),
+    "a5ss": ([(1, 200), (1, 150), (401, 600)], [[0, 2], [1, 2]]),
+    "mxe": ([(1, 100), (201, 300), (401, 500), (601, 700)], [[0, 1, 3], [0, 2, 3]]),
+}
+
+
+def as_case(R, name, paired, seed, N=300, iters=600, burn=100, lag=2, chains=2, mean=120.0, var=400.0, read_len=36,
+            overhang=1):
+    exons, isoforms = AS_GENES[name]
+    g = R.gene(flat(exons), isoforms)
+    R.rng_seed(seed)
+    expr = np.array([0.35, 0.65])
+    kw = dict(iters=iters, burn=burn, lag=lag, chains=chains, overhang=overhang)
+    if paired:
+        rc, iso, pos, cig = R.simulate_paired_reads(g, expr, N, read_len, mean, var)
+        assert rc == 0
+        rcm, m, fl = R.match_iso_paired(g, pos, cig, read_len, mean, var, overhang=overhang)
+        r = R.miso_paired(g, pos, cig, read_len, mean, var, **kw)
+        assert r.rc == 0 and rcm == 0
+        extra = dict(mean=mean, var=var, fraglen=fl)
+    else:
+        rc, iso, pos, cig = R.simulate_reads(g, expr, N, read_len)
+        assert rc == 0
+        r = R.miso(g, pos, cig, read_len, **kw)
+        assert r.rc == 0
+        extra = {}
+    save("as_%s_%s" % (name, "pe" if paired else "se"), kind="pe" if paired else "se",
+         exons=np.asarray(exons, np.int32), isoforms=iso_array(isoforms), expr=expr, seed=seed, read_len=read_len,
+         pos=pos, cigars=np.array(cig), sim_isoform=iso, **kw, **extra, **pack_result(r))
+
+
+def as_cases(R):
+    for j, name in enumerate(AS_GENES):
+        as_case(R, name, False, 101 + j, overhang=1 if j % 2 == 0 else 4)
+        as_case(R, name, True, 151 + j)
+
+
 def cigar_edge_case(R):
     """Hand-written alignments exercising solve.c:220-306 / 8-108: clips, =, X, D, I, skips that
     do and do not match the annotation, overhang violations, short reads, reads off the gene."""
@@ -219,6 +262,9 @@ def main():
         if sys.argv[1:] == ["marginal"]:     # likewise
             marginal_cases(R)
             return
+        if sys.argv[1:] == ["as"]:           # round 5: the AS-class geometries (the others are unchanged)
+            as_cases(R)
+            return
         if sys.argv[1:] == ["convergent"]:   # only the fixtures added in round 4 (the others are unchanged)
             convergent_case(R, "se_k3_convergent", False, 3, 200, 37, 50, 10, 1, 4, 700)
             convergent_case(R, "se_k2_convergent", False, 2, 300, 41, 60, 20, 2, 3, 2000)
@@ -242,6 +288,7 @@ def main():
         convergent_case(R, "pe_k4_convergent", True, 4, 200, 47, 80, 30, 2, 2, 100000)
         marginal_cases(R)
         assignment_matrix_case(R)
+        as_cases(R)
     finally:
         os.dup2(saved, 1)
     print("done")
