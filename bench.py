@@ -52,10 +52,13 @@ SIMDS = 256 * 4              # 256 CUs x 4 SIMDs
 CLOCK_GHZ = 2.4              # max shader clock (MI355X_MICROARCH.md)
 VALU_PEAK_GCYC = SIMDS * CLOCK_GHZ   # VALU issue cycles per ns of wall time, whole chip
 PHILOX_ROUNDS = 7            # include/miso_philox.h MISO_PHILOX_ROUNDS
-# Every row's |delta psi| test reports pass / fail at its level of 1e-3 in the line.  The PROCESS fails (exit 3) when the
-# headline's test fails or when two or more matrix rows fail: a defect in a kernel family fails its rows together, while
-# seventeen honest rows at 1e-3 each would fail one of them once in sixty runs
-ROWS_TO_FAIL = 2
+# Every row's |delta psi| test reports pass / fail at its level of 1e-3 in the line.  A row that fails is tested ONCE more
+# on fresh random streams on BOTH sides (new reference seeds, new Philox seed: `retry`); the PROCESS fails (exit 3) when
+# any single row -- the headline or a matrix row -- fails both times.  (Round 4 asked for two distinct failing rows, which
+# let a defect in a kernel that serves one row only -- sampler_flat<12>, sampler_grp<16, true, 12> -- through; eighteen
+# honest rows at 1e-3 each fail one of them once in sixty runs, hence the second look instead of failing at once: a false
+# alarm needs two independent failures, 1e-6 per row, a real defect fails again.)
+RETRY_SEED_SHIFT = 7919
 
 
 # ------------------------------------------------------------------------------------------------
@@ -192,7 +195,7 @@ def _cpu_worker(job):
     return busy, out
 
 
-def cpu_studies(wanted):
+def cpu_studies(wanted, start="fork"):
     """Everything the host cores do, before anything touches the GPU (fork-safe), in ONE process pool (the
     reference's own parallelism is processes, misopy/miso.py:165-187).  `wanted`: {id: (shape, timed
     [(event, seed)], study [(event, seed)])}.  Timed runs give the cpu_baseline (runs / the slowest process's
@@ -213,7 +216,7 @@ def cpu_studies(wanted):
                     jobs.append((kind, sh, part)); tags.append((wid, which))
     out = {wid: {"timed": [], "study": [], "timed_busy": [], "study_busy": []} for wid in wanted}
     t0 = time.perf_counter()
-    with mp.get_context("fork").Pool(cores) as pool:
+    with mp.get_context(start).Pool(cores) as pool:
         for (wid, which), (busy, rows) in zip(tags, pool.map(_cpu_worker, jobs, chunksize=1)):
             out[wid][which] += rows
             out[wid][which + "_busy"].append(busy)
@@ -287,6 +290,27 @@ def delta_psi(sh, study_rows, device, seed, collapsed=False, n_streams=None):
         len(events), n_streams or S, kernels, t_gpu)
     out["test_s"] = round(time.perf_counter() - t0 - t_gpu, 2)
     return out
+
+
+def delta_psi_with_retry(wid, sh, study_rows, device, seed, collapsed=False):
+    """The row's two-sample test; a failure is looked at once more with fresh streams on both sides (the reference runs in
+    a `spawn` pool: this process has touched the GPU by now, a fork would carry its HIP state along).  Returns the first
+    test's record with `retry` (the second test's) and `confirmed_fail` in it."""
+    d = delta_psi(sh, study_rows, device, seed, collapsed)
+    if d is None or d.get("pass") is not False:
+        return d
+    ev_seeds = sorted(set((r[0], r[1]) for r in study_rows))
+    fresh = [(e, sd + RETRY_SEED_SHIFT * 1000003) for e, sd in ev_seeds]
+    try:
+        st, _ = cpu_studies({wid: (sh, [], fresh)}, start="spawn")
+        d2 = delta_psi(sh, st[wid]["study"], device, seed + RETRY_SEED_SHIFT, collapsed)
+    except Exception as err:   # the retry is evidence, not the measurement: a failure to run it leaves the first verdict
+        d["retry"] = {"error": repr(err)[:200]}
+        d["confirmed_fail"] = True
+        return d
+    d["retry"] = None if d2 is None else {k: d2.get(k) for k in ("pass", "p_row", "p_pooled", "p_sign", "max_z", "n_fail", "tests")}
+    d["confirmed_fail"] = bool(d2 is not None and d2.get("pass") is False)
+    return d
 
 
 def single_run_deltas(batch, sample_rows):
@@ -469,7 +493,7 @@ def matrix_row(a, local_rank, wid, label, sh, n, st, collapsed=False):
         row["cpu_baseline"] = st["baseline"]
     del b
     if st and len(st["study"]) >= 2 * len(set(r_[0] for r_ in st["study"])):   # at least two reference seeds per event
-        row["delta_psi"] = delta_psi(sh, st["study"], local_rank, a.seed, collapsed)
+        row["delta_psi"] = delta_psi_with_retry(wid, sh, st["study"], local_rank, a.seed, collapsed)
     return row
 
 
@@ -521,7 +545,7 @@ def compact_line(full):
         "sample": b["sample"].split(" (")[0] + ", slowest process" + b["sample"].split("slowest process")[-1][:12]}
     d = full.get("delta_psi")
     out["delta_psi"] = None if d is None else {k: d.get(k) for k in ("pass", "p_row", "p_pooled", "p_sign", "max_z", "n_fail",
-                                                                     "n_fail_expected", "mean_abs_dpsi", "max_abs_dpsi")}
+                                                                     "n_fail_expected", "mean_abs_dpsi", "max_abs_dpsi", "confirmed_fail")}
     if d is not None:
         out["delta_psi"]["design"] = d["design"].split(";")[0]
     for k in ("per_rank_kernel_ms", "per_rank_elapsed_ms", "summary_ms", "compare_ms", "cpu_reference_wall_s", "stub", "full_record"):
@@ -533,7 +557,8 @@ def compact_line(full):
         for m in full["matrix"]:
             dp = m.get("delta_psi") or {}
             rows.append([m["id"], round(m["events_per_s"]), _r(m["kernel_ms"], 2), _r(m["valu_frac"], 3), _r(m.get("floor_frac"), 3),
-                         _r(m["hbm_measured_frac"], 3), _r((m.get("cpu_baseline") or {}).get("value"), 1), dp.get("pass"),
+                         _r(m["hbm_measured_frac"], 3), _r((m.get("cpu_baseline") or {}).get("value"), 1),
+                         "retry_pass" if (dp.get("pass") is False and dp.get("confirmed_fail") is False) else dp.get("pass"),
                          _r(dp.get("max_z"), 2), _r(dp.get("p_row"), 4)])
         out["matrix"] = rows
     return out
@@ -676,10 +701,10 @@ def main():
         cpu = delta = None
         if studies and "main" in studies:
             cpu = studies["main"]["baseline"]
-            delta = delta_psi(sh, studies["main"]["study"], local_rank, a.seed, bool(a.collapsed))
+            delta = delta_psi_with_retry("main", sh, studies["main"]["study"], local_rank, a.seed, bool(a.collapsed))
             if delta is not None:
                 delta["single_runs"] = single_run_deltas(batch, studies["main"]["timed"])
-                if delta.get("pass") is False:
+                if delta.get("confirmed_fail"):
                     rc = 3
         streams = {}
         if not a.stub and not a.no_streams and world == 1:
@@ -727,7 +752,7 @@ def main():
         elif want_matrix:
             del batch
             out["matrix"] = run_matrix(a, local_rank, studies, sh)
-            if sum((r.get("delta_psi") or {}).get("pass") is False for r in out["matrix"]) >= ROWS_TO_FAIL:
+            if any((r.get("delta_psi") or {}).get("confirmed_fail") for r in out["matrix"]):
                 rc = 3
         full_path = a.full_out or os.path.join(ROOT, "gpurun_out", "bench_full.json")
         try:

@@ -507,6 +507,27 @@ PackedEvent pack_event_masks(const miso_params_t &p, const FragmentDist *fd, int
     else e.draw_frag.insert(e.draw_frag.end(), frags + static_cast<size_t>(i) * K, frags + static_cast<size_t>(i + 1) * K);
     e.n_draw++;
   }
+  if (p.paired && e.n_draw > 1) {
+    // Paired-end draw order (the contract's, like the single-end one below): the
+    // drawing reads by their fragment-length rows -- isoform 0 most significant, an incompatible isoform below every
+    // length -- ties by read index.  The reference walks its reads in the order of their match columns too
+    // (miso_paired.c:24-86 through splicing_order_matches); what the order buys on the device: neighbouring lanes look up
+    // neighbouring entries of the fragment tables (LDS banks) and of the event's score table (one cache line instead of
+    // sixteen per gather).
+    auto key = [&](int r, int k) { const uint16_t f = e.draw_frag[static_cast<size_t>(r) * K + k]; return f == FRAG_NONE ? -1 : static_cast<int>(f); };
+    std::vector<int32_t> by(e.n_draw);
+    for (int r = 0; r < e.n_draw; r++) by[r] = r;
+    std::sort(by.begin(), by.end(), [&](int32_t x, int32_t y) {
+      for (int k = 0; k < K; k++) { const int a = key(x, k), b = key(y, k); if (a != b) return a < b; }
+      return e.draw_index[x] < e.draw_index[y];
+    });
+    std::vector<int32_t> idx(e.n_draw); std::vector<uint16_t> fr(static_cast<size_t>(e.n_draw) * K);
+    for (int r = 0; r < e.n_draw; r++) {
+      idx[r] = e.draw_index[by[r]];
+      std::memcpy(fr.data() + static_cast<size_t>(r) * K, e.draw_frag.data() + static_cast<size_t>(by[r]) * K, sizeof(uint16_t) * K);
+    }
+    e.draw_index.swap(idx); e.draw_frag.swap(fr);
+  }
   if (p.paired && K == 2) {   // sampler_k2 MODE 2: may the read loop skip the "bad score" bookkeeping?
     e.pe_delta = true;
     for (int r = 0; r < e.n_draw && e.pe_delta; r++)

@@ -471,6 +471,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   a.C = p.noChains; a.M = p.noIterations; a.B = p.noBurnIn; a.lag = p.noLag;
   a.start = p.start; a.first_event_id = first_event_id; a.seed = seed;
   last_seed = seed; last_first_event_id = first_event_id;
+  converged_done = false;
   a.pe_force_exact = std::getenv("MISO_K2_SETTLE_ALL") != nullptr;   // tests (kernels_k2.inl: the rescan for high halves on the threshold)
   if (const char *env = std::getenv("MISO_COOP_MAX_POLLS")) a.coop_max_polls = static_cast<uint32_t>(std::max(1L, std::atol(env)));   // tests
   // Trailing sample columns stay 0 (miso.c:661, quirk C8) -- they exist only when the lag does not divide the kept
@@ -802,7 +803,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   // (level 2 only: with the classes of a five- or ten-isoform event sharing ~1000 reads the chains of small binomials
   // cost more than the read sweep they replace -- profiles/r03_collapsed.txt; it pays from ~10^4 reads per event)
   bool lane_gen = collapsed && collapsed_level >= 2 && !p.paired && n_gen > 0;
-  for (const GenRun &run : gen_runs) if (run.nocls) lane_gen = false;
+  for (const GenRun &run : gen_runs) if (run.nocls || run.kc == 64) lane_gen = false;   // (33 - 64 isoforms: two-word masks, sampler_wave only)
   std::vector<int> flat_nc(gen_runs.size(), 0), flat_nc_max(gen_runs.size(), 0);
   for (size_t ri = 0; ri < gen_runs.size(); ri++) {
     const GenRun &run = gen_runs[ri];
@@ -1735,6 +1736,10 @@ void miso_batch::sync(float *ms) {
 // same chain, extended (the CPU checker's counter mode does the same; its stream mode continues, and is pinned to the
 // reference that way).  The next round is a batch of its own (only the unconverged events; its sync() recurses).
 void miso_batch::converge_rounds(float *ms) {
+  // once per launch: a second sync() must not test the samples the further rounds have already put in place (they might
+  // pass now and reset the accept counts' bookkeeping, or fail and run the rounds -- and the paired-end sums -- twice)
+  if (converged_done) { if (ms) *ms = last_ms; return; }
+  converged_done = true;
   rounds = 1;
   iters_counted.clear();
   if (p.stop != MISO_STOP_CONVERGENT_MEAN || p.maxIterations <= p.noIterations || events.empty()) return;
@@ -1802,6 +1807,9 @@ void miso_batch::converge_rounds(float *ms) {
 // int(round((1 - alpha/2) n)) - 1, Python-2 rounding = half away from zero).
 void miso_batch::summarize(double confidence_level, bool as_text) {
   if (!launched) MISO_FAIL(MISO_EINVAL, "batch not launched");
+  // stop = CONVERGENT_MEAN: the launch is only finished once sync() has run its further rounds; without them the pool holds
+  // the unconverged first round
+  if (p.stop == MISO_STOP_CONVERGENT_MEAN && !converged_done) sync(nullptr);
   HIP_OK(hipSetDevice(device));
   const int n = static_cast<int>(events.size()), Sn = S();
   const double alpha = 1 - confidence_level;
@@ -1897,6 +1905,9 @@ void miso_batch::adopt_samples(int n, const int *K, int Sn, const double *const 
 
 void miso_batch::download() {
   if (!launched) MISO_FAIL(MISO_EINVAL, "batch not launched");
+  // stop = CONVERGENT_MEAN: the launch is only finished once sync() has run its further rounds; without them the pool holds
+  // the unconverged first round
+  if (p.stop == MISO_STOP_CONVERGENT_MEAN && !converged_done) sync(nullptr);
   HIP_OK(hipSetDevice(device));
   h_out.resize(out_bytes);
   HIP_OK(hipMemcpy(h_out.data(), d_out, out_bytes, hipMemcpyDeviceToHost));

@@ -811,7 +811,9 @@ static int count_valid(const double *col, int K, int *first) {
 /* Counter-mode draw order of the single-end sampler: reads ordered by their compatibility column,
    columns compared lexicographically as splicing_order_matches does (matrix.pmt:546-562), ties by
    read index (the reference's qsort is unstable there; a contract needs a definite order).  The
-   r-th read of this order with >= 2 compatible isoforms uses Gibbs word r.  Paired-end: input order. */
+   r-th read of this order with >= 2 compatible isoforms uses Gibbs word r.  Paired-end (round 5; input order before):
+   by fragment-length rows, isoform 0 most significant, an incompatible isoform (-1) below every length, ties by read
+   index -- the reference walks its pairs in the order of their match columns as well (miso_paired.c:24-86). */
 static const double *co_match; static int co_K;
 static int co_cmp(const void *a, const void *b) {
   int x = *(const int *) a, y = *(const int *) b, k;
@@ -822,11 +824,20 @@ static int co_cmp(const void *a, const void *b) {
   }
   return (x > y) - (x < y);
 }
+static const int *co_frag;
+static int co_cmp_paired(const void *a, const void *b) {
+  int x = *(const int *) a, y = *(const int *) b, k;
+  const int *fx = co_frag + (size_t) x * co_K, *fy = co_frag + (size_t) y * co_K;
+  for (k = 0; k < co_K; k++) if (fx[k] != fy[k]) return (fx[k] > fy[k]) - (fx[k] < fy[k]);
+  return (x > y) - (x < y);
+}
 static void counter_order(orc_state_t *S) {
   int i;
   S->corder = malloc(sizeof(int) * (size_t) (S->N > 0 ? S->N : 1));
   for (i = 0; i < S->N; i++) S->corder[i] = i;
-  if (!S->paired) { co_match = S->match; co_K = S->K; qsort(S->corder, (size_t) S->N, sizeof(int), co_cmp); }
+  co_K = S->K;
+  if (!S->paired) { co_match = S->match; qsort(S->corder, (size_t) S->N, sizeof(int), co_cmp); }
+  else { co_frag = S->fraglen; qsort(S->corder, (size_t) S->N, sizeof(int), co_cmp_paired); }
 }
 
 /* The collapsed Gibbs step (single-end).  The reads in counter order (sorted by compatibility column) fall into

@@ -117,3 +117,34 @@ def test_compact_line_of_a_full_size_record_stays_under_4k():
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms"} <= set(d["roofline"])
     assert {"value", "unit", "cores", "kind"} <= set(d["cpu_baseline"]) and "workload" in d["config"]
     assert len(d["matrix"]) == len(full["matrix"]) and all(len(r) == len(d["matrix_cols"]) for r in d["matrix"])
+
+
+def test_a_failing_row_is_retried_once_and_one_confirmed_row_fails_the_process(monkeypatch):
+    """one matrix row whose |delta psi| test fails must be able to fail the process -- some kernels
+    serve a single row.  A failing row is tested once more on fresh streams on both sides; failing twice = confirmed."""
+    sys.path.insert(0, ROOT)
+    import bench
+    calls = []
+
+    def fake_delta_psi(sh, rows, device, seed, collapsed=False, n_streams=None):
+        calls.append((seed, tuple(sorted(set(r[1] for r in rows)))))
+        return {"pass": fake_delta_psi.verdicts.pop(0), "p_row": 0.0007, "design": "x;y"}
+
+    def fake_cpu_studies(wanted, start="fork"):
+        assert start == "spawn"          # the process has touched the GPU by then
+        (wid, (sh, timed, study)), = wanted.items()
+        return {wid: {"study": [(e, sd, [0.5], [0.4], [0.6], [0.1]) for e, sd in study]}}, 0.0
+
+    monkeypatch.setattr(bench, "delta_psi", fake_delta_psi)
+    monkeypatch.setattr(bench, "cpu_studies", fake_cpu_studies)
+    rows = [(e, 1000003 * (s + 1) + e, [0.5], [0.4], [0.6], [0.1]) for e in range(3) for s in range(2)]
+    fake_delta_psi.verdicts = [True]
+    d = bench.delta_psi_with_retry("se_k10", dict(bench.BASE_SHAPE), rows, 0, 42)
+    assert d["pass"] is True and "retry" not in d and len(calls) == 1
+    fake_delta_psi.verdicts = [False, True]
+    d = bench.delta_psi_with_retry("se_k10", dict(bench.BASE_SHAPE), rows, 0, 42)
+    assert d["pass"] is False and d["retry"]["pass"] is True and d["confirmed_fail"] is False
+    assert calls[-1][0] != calls[-2][0] and not set(calls[-1][1]) & set(calls[-2][1])   # fresh seeds on both sides
+    fake_delta_psi.verdicts = [False, False]
+    d = bench.delta_psi_with_retry("se_k10", dict(bench.BASE_SHAPE), rows, 0, 42)
+    assert d["confirmed_fail"] is True

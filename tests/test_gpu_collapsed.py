@@ -187,3 +187,34 @@ def test_collapsed_results_do_not_depend_on_batching(orc):
     b.run(seed=9, first_event_id=0)
     for j, i in enumerate(order):
         assert np.array_equal(whole.result(i).samples, b.result(j).samples)
+
+
+def test_collapsed_level_two_with_a_gene_of_forty_isoforms_and_no_ambiguous_read(orc):
+    """a single-end gene of 33 - 64 isoforms none of whose reads is ambiguous kept `lane_gen` on (only events
+    with drawing reads could switch it off) and sampler_lane_k -- 32-bit masks, an LDS slice beyond the CU's -- failed the
+    whole batch.  Such genes take sampler_wave whatever the collapsed level."""
+    K = 40
+    exons = [(1 + 300 * k, 200 + 300 * k) for k in range(K)]
+    isoforms = [[k] for k in range(K)]          # disjoint isoforms: every read has exactly one compatible isoform
+    rng = np.random.default_rng(7)
+    pos = np.array([1 + 300 * int(k) + int(o) for k, o in zip(rng.integers(0, K, 400), rng.integers(0, 160, 400))], np.int32)
+    cig = [b"36M"] * len(pos)
+    kw = dict(iters=120, burn=20, lag=2, chains=2)
+    b = miso_amd.Batch(36, collapsed=2, **kw)
+    b.add_event(miso_amd.Gene(exons, isoforms), pos, cig)
+    ex2, iso2 = se_gene(3)
+    g2 = orc.gene(flat(ex2), iso2)
+    orc.rng_seed(77)
+    rc, _, pos2, cig2 = orc.simulate_reads(g2, expr_for(3), 300, 36)
+    b.add_event(miso_amd.Gene(ex2, iso2), pos2, cig2)
+    b.run(seed=3, first_event_id=10)
+    g = orc.gene(flat(exons), isoforms)
+    for i, (gg, p_, c_) in enumerate([(g, pos, cig), (g2, pos2, cig2)]):
+        r = orc.miso(gg, p_, c_, 36, mode=OrcLib.COLLAPSED if i else OrcLib.COUNTER, seed=3, event_id=10 + i, **kw)
+        gpu = b.result(i)
+        assert r.rc == 0
+        if i == 0:    # no drawing read: the collapsed and the per-read chain are the same chain
+            assert np.array_equal(gpu.samples, r.samples.reshape(gpu.samples.shape), equal_nan=True)
+            assert (gpu.assignment == r.assignment).all()
+        else:
+            assert gpu.samples.shape == r.samples.reshape(gpu.samples.shape).shape

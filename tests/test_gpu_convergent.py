@@ -126,3 +126,19 @@ def test_batch_where_some_events_converge_and_some_do_not(orc, paired):
     assert b.rounds() == rounds
     for e in range(len(cases)):
         assert np.array_equal(b.result(e).samples, first[e])
+    # sync() is idempotent (a second one must not test the replaced samples again), and a launch that is read
+    # without a sync() still gets its further rounds
+    acc = [(b.result(e).rundata.noAccepted, b.result(e).rundata.noRejected) for e in range(len(cases))]
+    b.sync()
+    b.sync()
+    b.download()
+    assert b.rounds() == rounds
+    for e in range(len(cases)):
+        r = b.result(e)
+        assert np.array_equal(r.samples, first[e]) and (r.rundata.noAccepted, r.rundata.noRejected) == acc[e]
+        assert r.rundata.noRejected >= 0
+    b.launch(seed=5, first_event_id=1000)
+    b.download()                       # no sync() in between
+    assert b.rounds() == rounds
+    for e in range(len(cases)):
+        assert np.array_equal(b.result(e).samples, first[e])
