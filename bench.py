@@ -376,7 +376,17 @@ def roofline_for(batch, kernel_ms, key, sh):
     profiled = None if m is None else sorted(re.search(r"miso::(sampler_[^(]+)\(", k).group(1).replace(", false>", ">")
                                              for k in m["kernels"])
     launched = sorted(set(re.findall(r"sampler_\w+(?:<[^>]*>)?", name)))   # (size buckets may launch one kernel twice)
-    if m is not None and profiled == launched:
+    # the committed profile's own kernel time (rocprofv3 --kernel-trace of the same command; several kernels side by side:
+    # the longest): the model's instructions per chain-iteration only price THIS run if the profiled launch took as long --
+    # a kernel changed since, a box at another clock, a different launch plan all show up here
+    prof_ms = None
+    if m is not None:
+        ns = [v.get("kernel_ns") for v in m["kernels"].values() if v.get("kernel_ns")]
+        prof_ms = max(ns) / 1e6 if ns else None
+    out["profile_kernel_ms"] = None if prof_ms is None else round(prof_ms, 3)
+    tol = 0.05 if m is None or len(m["kernels"]) == 1 else 0.10
+    stale = prof_ms is not None and abs(prof_ms - kernel_ms) > tol * kernel_ms
+    if m is not None and profiled == launched and not stale:
         cyc = m["valu_per_chain_iteration"] * chain_iters * m["issue_cycles_per_valu"]
         out["achieved"] = round(cyc / t / 1e9, 1)
         out["frac"] = round(cyc / t / 1e9 / VALU_PEAK_GCYC, 4)
@@ -399,6 +409,8 @@ def roofline_for(batch, kernel_ms, key, sh):
         out["achieved"] = None
         out["frac"] = None
         out["frac_source"] = ("no rocprofv3 PMC pass committed for this workload (%s)" % key) if m is None else \
+            ("the committed profile's launch took %.3f ms, this run's %.3f ms (more than %d %% apart): the model does not price "
+             "this run, re-profile" % (prof_ms, kernel_ms, round(100 * tol))) if (profiled == launched and stale) else \
             ("the committed profile of this workload is of other kernels (%s): re-profile" % ",".join(profiled))
     out["draws_per_chain"] = round(draws, 1)
     # (tools/rng_bench.hip, MI355X: philox4x32-10 2885 G words/s, philox4x32-7 the same generator at 7 / 10 of the rounds)
@@ -413,6 +425,9 @@ def roofline_for(batch, kernel_ms, key, sh):
         traffic["hbm_bytes_per_launch"] / t / 1e9 / HBM_PEAK_GBS, 5)
     out["algorithmic_bytes_per_launch"] = alg_bytes
     out["algorithmic_GBs"] = round(alg_bytes / t / 1e9, 1)
+    # SURVEY 8(d)'s definition of the fraction, stated for the record: the REFERENCE algorithm's bytes over the HBM peak.
+    # Above 1 means the kernel does not move those bytes (the event lives in registers / LDS); `traffic` is what it moves
+    out["bytes_frac_8d"] = round(alg_bytes / t / 1e9 / HBM_PEAK_GBS, 2)
     out["algorithmic_note"] = ("SURVEY 8(d) accounting of the reference algorithm ((8K+20)N bytes per "
                                "chain-iteration); the kernels keep the event on chip, so this exceeds the "
                                "HBM peak and is not a utilisation figure")
@@ -537,7 +552,8 @@ def compact_line(full):
     out["roofline"] = {"bound": r.get("bound"), "kernel": None if kern is None else kern[:96], "kernel_ms": r.get("kernel_ms"),
                        "achieved": r.get("achieved"), "peak": r.get("peak"), "unit": r.get("unit"), "frac": r.get("frac"),
                        "floor_frac": r.get("floor_frac"), "traffic": _r(r.get("traffic"), 0), "hbm_measured_frac": r.get("hbm_measured_frac"),
-                       "algorithmic_GBs": r.get("algorithmic_GBs"),
+                       "algorithmic_GBs": r.get("algorithmic_GBs"), "bytes_frac_8d": r.get("bytes_frac_8d"),
+                       "profile_kernel_ms": r.get("profile_kernel_ms"),
                        "frac_source": None if r.get("frac") is None else "model: profiles/valu_model.json x this run's kernel time"}
     b = full.get("cpu_baseline")
     out["cpu_baseline"] = None if b is None else {

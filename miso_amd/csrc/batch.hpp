@@ -43,6 +43,7 @@ struct miso_batch {
   // schedule (runtime.hip converge_rounds) and puts the tail of their samples where the first round's were
   std::vector<int64_t> iters_counted;   // per event: iterations behind its accept count (empty: noIterations each)
   int rounds = 1;                 // rounds the last launch took (1 = the events' own schedule sufficed)
+  int prio_lo = 0, prio_hi = 0;   // the device's stream priority range as this batch uses it (equal: priorities off)
   bool converged_done = false;    // stop = CONVERGENT_MEAN: this launch's further rounds have run (sync() is idempotent; launch() clears it)
   void converge_rounds(float *ms);
   bool coop_enabled() const;      // chains may use several workgroups (coop.hpp): not after a time-out, not with MISO_NO_COOP=1

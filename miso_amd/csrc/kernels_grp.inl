@@ -1035,12 +1035,20 @@ __device__ __forceinline__ void grp_body(const KernelArgs &a, unsigned block_x) 
     else if (dense_nobad) pe_dense<KK, GS, false, false, LDS>(dq, S.psi, lds_fp, stab_lds, sfixd_glob, il2, S.dl, drawass, write_ass, nqw, n_quads, n_draw, sub_r, rng, n0r0, a.pe_force_exact != 0, acc, bad, stride_r); \
     else pe_dense<KK, GS, false, true, LDS>(dq, S.psi, lds_fp, stab_lds, sfixd_glob, il2, S.dl, drawass, write_ass, nqw, n_quads, n_draw, sub_r, rng, n0r0, a.pe_force_exact != 0, acc, bad, stride_r); \
   }
+#ifdef MISO_PE_NOLOOP   // experiment: the kernel's registers without the read loop
+#define MISO_PED(KK) { acc = n_draw; }
+#else
 #define MISO_PED(KK) { if (a.tstride > 0) MISO_PED2(KK, true) else MISO_PED2(KK, false) }
+#endif
+#ifdef MISO_PE_ONLY_K   // experiment: a kernel that carries ONE isoform count's loop (register budget of that count alone)
+      MISO_PED(MISO_PE_ONLY_K)
+#else
       if constexpr (KC == 4) { if (K == 3) MISO_PED(3) else MISO_PED(4) }
       else if constexpr (KC == 8) { if (K == 5) MISO_PED(5) else if (K == 6) MISO_PED(6) else if (K == 7) MISO_PED(7) else MISO_PED(8) }
       else if constexpr (KC == 12) { if (K == 9) MISO_PED(9) else if (K == 10) MISO_PED(10) else if (K == 11) MISO_PED(11) else MISO_PED(12) }
       else if constexpr (KC == 16) { if (K == 13) MISO_PED(13) else if (K == 14) MISO_PED(14) else if (K == 15) MISO_PED(15) else MISO_PED(16) }
       else { if (K == 17) MISO_PED(17) else if (K == 18) MISO_PED(18) else if (K == 19) MISO_PED(19) else MISO_PED(20) }
+#endif
 #undef MISO_PED2
 #undef MISO_PED
       wave_sync();
@@ -1102,11 +1110,15 @@ __device__ __forceinline__ void grp_body(const KernelArgs &a, unsigned block_x) 
     else pe_quads<KK, G, false>(frags, S.psi, lds_fp, sfix, a.il, S.cnt, drawass, write_ass, nqw, n_quads, n_draw, sub, rng, n0r0, acc, bad); \
   }
       // per-lane K: divergent only in wavefronts that mix isoform counts
+#ifdef MISO_PE_ONLY_K
+      MISO_PEQ(MISO_PE_ONLY_K)
+#else
       if constexpr (KC == 4) { if (K == 3) MISO_PEQ(3) else MISO_PEQ(4) }
       else if constexpr (KC == 8) { if (K == 5) MISO_PEQ(5) else if (K == 6) MISO_PEQ(6) else if (K == 7) MISO_PEQ(7) else MISO_PEQ(8) }
       else if constexpr (KC == 12) { if (K == 9) MISO_PEQ(9) else if (K == 10) MISO_PEQ(10) else if (K == 11) MISO_PEQ(11) else MISO_PEQ(12) }
       else if constexpr (KC == 16) { if (K == 13) MISO_PEQ(13) else if (K == 14) MISO_PEQ(14) else if (K == 15) MISO_PEQ(15) else MISO_PEQ(16) }
       else { if (K == 17) MISO_PEQ(17) else if (K == 18) MISO_PEQ(18) else if (K == 19) MISO_PEQ(19) else MISO_PEQ(20) }
+#endif
 #undef MISO_PEQ
       wave_sync();
 #pragma unroll

@@ -364,7 +364,22 @@ void miso_batch::upload(int dev) {
     wave_slots = prop.multiProcessorCount * 4 * 2;  // CUs x SIMDs x resident sampler_k2 waves
     if (const char *env = std::getenv("MISO_WAVE_SLOTS")) wave_slots = std::max(64, std::atoi(env));   // experiments: what the planners take as resident
   }
-  HIP_OK(hipStreamCreate(&stream));
+  {
+    // The batch's own stream carries its FIRST kernel -- the longest-running class of a whole-gene batch (runs are
+    // launched heaviest class first) -- at the highest queue priority; the kernels beside it go to streams of falling
+    // priority (launch: stream_for_next), so that whenever a slot frees up the dispatcher takes a workgroup of the longest
+    // class still waiting: longest first ACROSS the classes without one kernel holding all their bodies (that kernel was
+    // built: 28 minutes of compilation, 800 spilled registers -- tools/experiments/grp_all/).  MEASURED, round 5, and OFF
+    // unless MISO_STREAM_PRIO=1: 16 384 genes of 3 - 20 isoforms x 1000 pairs 922 ms with against 917 ms without, hg19-like
+    // pair counts 958 against 865 ms (the chains on several workgroups sit in the high-priority kernel and everything else
+    // waits behind them) -- profiles/r05_stream_priorities.txt.
+    int lo = 0, hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = hi = 0; (void) hipGetLastError(); }
+    const char *env = std::getenv("MISO_STREAM_PRIO");
+    prio_lo = lo; prio_hi = (env && std::atoi(env) != 0) ? hi : lo;
+    if (prio_hi != prio_lo) HIP_OK(hipStreamCreateWithPriority(&stream, hipStreamDefault, prio_hi));
+    else HIP_OK(hipStreamCreate(&stream));
+  }
   HIP_OK(hipEventCreate(&ev0));
   HIP_OK(hipEventCreate(&ev1));
   HIP_OK(hipMalloc(reinterpret_cast<void **>(&d_events), std::max<size_t>(n, 1) * sizeof(DevEvent)));
@@ -422,7 +437,7 @@ void miso_batch::upload(int dev) {
         if (coop_on && need > 384.0)
           coop_n[i] = std::max(1, std::min({COOP_MAX_N, static_cast<int>(std::ceil(need / 256.0)), nq / 512}));
       } else if (can_wide && need > t_wave && nq >= 128) bucket[i] = 2;
-      else if (need > 24.0 && nq >= 64) bucket[i] = 1;
+      else if (need > (std::getenv("MISO_PE_T_32") ? std::atof(std::getenv("MISO_PE_T_32")) : 32.0) && nq >= 64) bucket[i] = 1;   // (round 5: 24 -> 32, see the lanes' rule in launch)
     }
   }
   std::stable_sort(gen.begin(), gen.end(), [&](int x, int y) {
@@ -1009,7 +1024,12 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       // mean of 400 drawing quads per gene of the class; MISO_PE_MIX_LANES=16|32 forces)
       const double mean_q = run.sum_q / std::max(1, run.count);
       const char *mixl = std::getenv("MISO_PE_MIX_LANES");
-      const bool mix16 = run.kc <= 16 && !run.force_G && (mixl ? std::atoi(mixl) == 16 : mean_q < 400.0);
+      // (round 5, same batch on one box, 7500 iterations: the 17 - 20 isoform class on 16 lanes as well -- 1000 pairs per gene
+      // 930 -> 852 ms, hg19-like pair counts 865 -> 820 ms: four chains of a wavefront share the scalar step, and the class
+      // no longer fills the device with half-efficient wavefronts for the launch's first third while the other classes
+      // wait; the bucket of "at least 32 lanes" from a need of 32 lanes instead of 24: a 20-isoform gene of 1000 pairs
+      // needs 28 by the share rule; profiles/r05_pe_mix_lanes.txt)
+      const bool mix16 = run.kc <= 32 && !run.force_G && (mixl ? std::atoi(mixl) == 16 : mean_q < 400.0);
       const bool pe32 = p.paired && ((n_classes + (n_k2 > 0 ? 1 : 0) > 1 && !mix16) || (run.kc >= 12 && 2 * ((chains + 3) / 4) < 3 * static_cast<long>(slots_for(chains))) ||
                                      (chains + 3) / 4 < slots_for(chains));
       for (int g : {2, 4, 8, 16, 32}) {
@@ -1473,7 +1493,12 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     if (i == 0 || std::getenv("MISO_SERIAL_KERNELS") != nullptr) return stream;
     while (aux_streams.size() < i) {
       hipStream_t st; hipEvent_t e;
-      HIP_OK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+      // (numerically lower = higher priority; the range has three levels on this device: the second and third kernel
+      // of a launch at the middle one, the rest at the lowest)
+      const int n_aux = static_cast<int>(aux_streams.size());
+      const int pr = prio_hi == prio_lo ? prio_lo : std::min(prio_lo, prio_hi + 1 + n_aux / 2);
+      if (prio_hi != prio_lo) HIP_OK(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, pr));
+      else HIP_OK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
       HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
       aux_streams.push_back(st); aux_done.push_back(e);
     }
@@ -1652,7 +1677,19 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       const unsigned grid = static_cast<unsigned>(((chains + 64 / G - 1) / (64 / G) + 3) / 4);
       hipStream_t st = stream_for_next();
       switch (G) {
-      case 1: hipLaunchKernelGGL(sampler_lane, dim3(static_cast<unsigned>((chains + 255) / 256)), dim3(256), 0, st, ka); break;
+      case 1: {
+        // One chain per lane, one workgroup = four wavefronts = the four SIMDs of a CU.  A batch of fewer workgroups than the
+        // device has CUs (40 000 chains: 157) must not have two of them on one CU -- their wavefronts would share SIMDs and
+        // run at half speed while a hundred CUs idle, and the launch takes as long as its slowest wavefront (the average
+        // wavefront was alive for 0.73 of the kernel, profiles/r04_se_k2_collapsed_summary.txt).  The dispatcher gives no
+        // such promise; an LDS allocation of more than half a CU's does: at most one workgroup fits.
+        const unsigned wgs = static_cast<unsigned>((chains + 255) / 256);
+        size_t pad = wgs <= static_cast<unsigned>(wave_slots / 8) ? 84 * 1024 : 0;
+        if (const char *env = std::getenv("MISO_LANE_LDS_PAD_KB")) pad = static_cast<size_t>(std::max(0, std::atoi(env))) * 1024;
+        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sampler_lane), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(std::max<size_t>(pad, 1024))));
+        hipLaunchKernelGGL(sampler_lane, dim3(wgs), dim3(256), pad, st, ka);
+        break;
+      }
       case 2: hipLaunchKernelGGL(sampler_k2c<2>, dim3(grid), dim3(256), 0, st, ka); break;
       case 4: hipLaunchKernelGGL(sampler_k2c<4>, dim3(grid), dim3(256), 0, st, ka); break;
       default: hipLaunchKernelGGL(sampler_k2c<8>, dim3(grid), dim3(256), 0, st, ka); break;
