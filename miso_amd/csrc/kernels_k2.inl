@@ -32,9 +32,13 @@
 #include "gibbs_rng.hpp"
 #include "coop.hpp"
 #include "miso_binomial.h"
+#include "detmath_n.hpp"
 
 #pragma clang fp contract(off)
 
+#ifndef MISO_K2_TAB_REGS
+#define MISO_K2_TAB_REGS 0   // 1: the Metropolis-Hastings step's exp / log coefficients in VGPRs instead of scalar loads at every call
+#endif
 #ifndef MISO_K2_UQ
 #define MISO_K2_UQ 2   // Philox blocks in flight per lane in the single-end read loop
 #endif
@@ -761,9 +765,18 @@ __device__ __forceinline__ void k2_body(const KernelArgs &a, unsigned block_x, u
     z = miso_det_norm_from_unif(miso_u01(b.v[2]), miso_u01(b.v[3]));
   };
   // alpha' = alpha + sd z, psi' = logit_inv(alpha') (miso.c:449-471)
+#if MISO_K2_TAB_REGS
+  double TE[12], TL[12];
+  det_tables_to_registers(TE, TL);
+  auto k2_exp = [&](double v) { return det_exp_t(v, TE); };
+  auto k2_log = [&](double v) { return det_log_t(v, TL); };
+#else
+  auto k2_exp = [](double v) { return miso_det_exp(v); };
+  auto k2_log = [](double v) { return miso_det_log(v); };
+#endif
   auto propose = [&](double z, double &alphaN, double &x0, double &x1) {
     alphaN = alpha + c.sd * z;
-    const double e = miso_det_exp(alphaN);
+    const double e = k2_exp(alphaN);
     const double sumexp = (0.0 + e) + 1.0;
     x0 = e / sumexp;
     x1 = 1 - (0.0 + x0);
@@ -811,8 +824,8 @@ __device__ __forceinline__ void k2_body(const KernelArgs &a, unsigned block_x, u
     double ptoCS, ctoPS;
     {
       // NR lanes, one routine, NR arguments per call (see vec_eval)
-      auto f_log = [](double v) { return miso_det_log(v); };
-      auto f_exp = [](double v) { return miso_det_exp(v); };
+      auto f_log = k2_log;
+      auto f_exp = k2_exp;
       const double ltheta = 1.0 - x0;
       double lgtN;
       vec_eval3<NR, QUAD>(f_log, x0, x1, x0 / ltheta, nw.lx0, nw.lx1, lgtN, role, base_lane);
@@ -837,7 +850,7 @@ __device__ __forceinline__ void k2_body(const KernelArgs &a, unsigned block_x, u
                          : 0.0;
     const double pp = joint<PE>(nw, cnt0, cnt1, c, rp);
     const double pc = joint<PE>(cur, cnt0, cnt1, c, rp);
-    const double acceptP = (m > 0) ? miso_det_exp(pp + ptoCS - (pc + ctoPS)) : miso_det_exp(pp - pc);
+    const double acceptP = (m > 0) ? k2_exp(pp + ptoCS - (pc + ctoPS)) : k2_exp(pp - pc);
     const bool acc = (acceptP >= 1) || (miso_u01(accept_word) < acceptP);
     double cJS = pc;
     if (acc) { cur = nw; alpha = alphaN; cJS = pp; accepted++; }

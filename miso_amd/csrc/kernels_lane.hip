@@ -14,6 +14,7 @@
 // Bit for bit against the CPU checker's collapsed mode (tests/test_gpu_collapsed.py).
 #include "kernels_k2.inl"
 #include "miso_binomial.h"
+#include "detmath_n.hpp"
 
 namespace miso {
 
@@ -22,122 +23,6 @@ namespace miso {
 #endif
 
 namespace {
-
-// ---- several arguments through one routine, statement by statement (round 5) ----
-// A chain per lane is ONE dependency chain: with 625 wavefronts on 1024 SIMDs nothing else issues on a wavefront's
-// SIMD, and the eleven transcendental routines of a Metropolis-Hastings step (miso.c:449-552) -- Horner chains of a dozen
-// fused multiply-adds each -- ran one after the other at the latency of a dependent f64 operation, ~10 cycles per
-// instruction (hipcc does not interleave two calls of miso_det_log: each reads its coefficient table behind a volatile
-// barrier).  det_log_n / det_exp_n evaluate N arguments with the operations of miso_det_log / miso_det_exp
-// (include/miso_detmath.h) in the same order PER ARGUMENT -- the same bits -- but step by step across the arguments, so
-// that N independent chains are in flight and every coefficient is loaded once.
-template <int N> __device__ __forceinline__ void det_exp_n(const double (&x)[N], double (&out)[N]) {
-  const double LOG2E = 1.4426950408889634074;
-  const double LN2_HI = 6.93147180369123816490e-01;
-  const double LN2_LO = 1.90821492927058770002e-10;
-  double xm[N], kd[N], r[N], p[N];
-  int k[N];
-#pragma unroll
-  for (int j = 0; j < N; j++) {
-    xm[j] = (x[j] != x[j]) ? 0.0 : x[j];
-    xm[j] = (xm[j] > 710.0) ? 710.0 : xm[j];
-    xm[j] = (xm[j] < -746.0) ? -746.0 : xm[j];
-    kd[j] = __builtin_floor(xm[j] * LOG2E + 0.5);
-    k[j] = static_cast<int>(kd[j]);
-    r[j] = miso_fma(-kd[j], LN2_HI, xm[j]);
-    r[j] = miso_fma(-kd[j], LN2_LO, r[j]);
-  }
-  {
-    MISO_TAB_PTR te = MISO_TAB_REF(miso_tab_exp);
-    const double c0 = te[0];
-#pragma unroll
-    for (int j = 0; j < N; j++) p[j] = c0;
-#pragma unroll
-    for (int i = 1; i < 12; i++) {
-      const double ci = te[i];
-#pragma unroll
-      for (int j = 0; j < N; j++) p[j] = miso_fma_tab(p[j], r[j], ci);
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < N; j++) {
-    p[j] = miso_fma(p[j], r[j], 1.0);
-    p[j] = miso_fma(p[j], r[j], 1.0);
-    const int k1 = k[j] / 2, k2 = k[j] - k1;
-    double res = p[j] * miso_pow2i(k1) * miso_pow2i(k2);
-    res = (x[j] > 709.782712893384) ? miso_u2d(0x7FF0000000000000ull) : res;
-    res = (x[j] < -745.2) ? 0.0 : res;
-    res = (x[j] != x[j]) ? x[j] : res;
-    out[j] = res;
-  }
-}
-
-template <int N> __device__ __forceinline__ void det_log_n(const double (&x)[N], double (&out)[N]) {
-  const double LN2_HI = 6.93147180369123816490e-01;
-  const double LN2_LO = 1.90821492927058770002e-10;
-  const double SQRT2 = 1.41421356237309504880;
-  double f[N], s[N], z[N], q[N], ed[N];
-#pragma unroll
-  for (int j = 0; j < N; j++) {
-    const int sub = (miso_d2u(x[j]) >> 52) == 0;
-    const double xs = sub ? x[j] * 18014398509481984.0 : x[j];
-    const uint64_t u = miso_d2u(xs);
-    int e = static_cast<int>((u >> 52) & 0x7FF) - 1023 + (sub ? -54 : 0);
-    double m = miso_u2d((u & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull);
-    const int big = m > SQRT2;
-    m = big ? m * 0.5 : m;
-    e += big ? 1 : 0;
-    f[j] = m - 1.0;
-    s[j] = f[j] / (2.0 + f[j]);
-    z[j] = s[j] * s[j];
-    ed[j] = static_cast<double>(e);
-  }
-  {
-    MISO_TAB_PTR tl = MISO_TAB_REF(miso_tab_log);
-    const double c0 = tl[0];
-#pragma unroll
-    for (int j = 0; j < N; j++) q[j] = c0;
-#pragma unroll
-    for (int i = 1; i < 12; i++) {
-      const double ci = tl[i];
-#pragma unroll
-      for (int j = 0; j < N; j++) q[j] = miso_fma_tab(q[j], z[j], ci);
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < N; j++) {
-    const double R = z[j] * q[j];
-    double res = miso_fma(ed[j], LN2_HI, f[j] - (s[j] * (f[j] - R) - ed[j] * LN2_LO));
-    res = (miso_d2u(x[j]) == 0x7FF0000000000000ull) ? x[j] : res;
-    res = (x[j] == 0.0) ? miso_u2d(0xFFF0000000000000ull) : res;
-    res = (x[j] < 0.0) ? miso_u2d(0x7FF8000000000000ull) : res;
-    res = (x[j] != x[j]) ? x[j] : res;
-    out[j] = res;
-  }
-}
-
-// miso_det_sqrt for a positive, normal, finite argument (the only kind the binomial's set-up has: n r q >= 5): the same
-// operations without the special cases' branches, so that it sits in one basic block with what runs beside it
-__device__ __forceinline__ double det_sqrt_pos(double x) {
-  const uint64_t u = miso_d2u(x);
-  int e = static_cast<int>(u >> 52) - 1023;
-  const int odd = e & 1;
-  e = (e - odd) / 2;
-  const double m = miso_u2d((u & 0x000FFFFFFFFFFFFFull) | (static_cast<uint64_t>(1023 + odd) << 52));
-  double y = 1.1547 - 0.1634 * m;
-  y = y * (1.5 - 0.5 * m * y * y);
-  y = y * (1.5 - 0.5 * m * y * y);
-  y = y * (1.5 - 0.5 * m * y * y);
-  y = y * (1.5 - 0.5 * m * y * y);
-  y = y * (1.5 - 0.5 * m * y * y);
-  double g = m * y;
-  const double h = 0.5 * y;
-  double d = miso_fma(-g, g, m);
-  g = miso_fma(d, h, g);
-  d = miso_fma(-g, g, m);
-  g = miso_fma(d, h, g);
-  return g * miso_pow2i(e);
-}
 
 // What miso_binomial_btrs (include/miso_binomial.h) computes before its first trial, for Binomial(n, p): kept for the
 // chain's current psi and made for the proposal's BESIDE the Metropolis-Hastings scores (the proposal is accepted two
@@ -174,7 +59,7 @@ __device__ __forceinline__ void binom_setup_post(BinomSetup &s, int32_t n, doubl
 // draw, exactly as the one-at-a-time loop returns it.  Every lane of the wavefront runs until its own draw is made; a
 // lane that is not on the fast path (s.btrs false) takes no part.
 __device__ __forceinline__ int32_t binom_trials(const BinomSetup &s, int32_t n, uint64_t seed, uint32_t event_id, uint32_t chain,
-                                                uint32_t iter, const double *__restrict__ lf) {
+                                                uint32_t iter, const double *__restrict__ lf, const double (&tl)[12]) {
   const double dn = static_cast<double>(n);
   int32_t y = static_cast<int32_t>(s.m);
   bool done = !s.btrs;
@@ -192,7 +77,7 @@ __device__ __forceinline__ int32_t binom_trials(const BinomSetup &s, int32_t n, 
       quick[t] = (us[t] >= 0.07 && v[t] <= s.vr) || v[t] == 0.0;
       vv[t] = v[t] * s.alpha / (s.a / (us[t] * us[t]) + s.b);
     }
-    det_log_n<2>(vv, lv);
+    det_log_n<2>(vv, lv, tl);
     bool ok[2];
 #pragma unroll
     for (int t = 0; t < 2; t++) {
@@ -212,7 +97,12 @@ __device__ __forceinline__ int32_t binom_trials(const BinomSetup &s, int32_t n, 
 
 // (Tried: the head of the log-factorial table in LDS -- 60.5 ms against 61.2 ms from global memory with workgroups of one
 // wavefront, 56.4 ms with these workgroups of four: the table's few hundred hot entries sit in the L1 anyway.)
-__global__ __launch_bounds__(256) void sampler_lane(const KernelArgs a) {
+// ILP (round 5): the form for batches that leave a wavefront alone, or nearly, on its SIMD (up to two per SIMD: 131 072
+// chains) -- the step's transcendentals in five multi-argument stages, their coefficients in registers, the binomial's
+// set-up beside the scores and its trials two per round; 250 registers.  The plain form (76 registers, six wavefronts per
+// SIMD) for larger batches, where other wavefronts fill the gaps.  Same draws, same bits (tests/test_gpu_collapsed.py).
+template <bool ILP>
+__device__ __forceinline__ void lane_body(const KernelArgs &a) {
   const long n_chains = static_cast<long>(a.n_slots) * a.C;
   const long slot = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
   if (slot >= n_chains) return;   // no barrier below
@@ -299,11 +189,13 @@ __global__ __launch_bounds__(256) void sampler_lane(const KernelArgs a) {
     alpha = aN;
     cur = psi_terms(x0, x1, c.cst0, c.cst1);
   }
-#if MISO_LANE_ILP
-  (void) gibbs_collapsed;   // (the one-call form: MISO_LANE_ILP=0, A/B)
+  // ILP: the exp / log coefficient tables of miso_detmath.h in VGPRs for the whole run (pinned: the empty asm keeps the
+  // compiler from re-reading them from constant memory where they are used)
+  double TE[12], TL[12];
+  if constexpr (ILP) det_tables_to_registers(TE, TL);
   // the binomial's set-up for the chain's CURRENT psi (BinomSetup above); the proposal's is made beside its scores
-  BinomSetup bs_cur;
-  {
+  BinomSetup bs_cur{};
+  if constexpr (ILP) {
     double sq_arg, lg_arg;
     binom_setup_pre(bs_cur, n_draw, cur.x0 / ((0.0 + cur.x1) + cur.x0), sq_arg, lg_arg);
     binom_setup_post(bs_cur, n_draw, det_sqrt_pos(sq_arg), miso_det_log(lg_arg), a.logfact);
@@ -311,7 +203,7 @@ __global__ __launch_bounds__(256) void sampler_lane(const KernelArgs a) {
   auto gibbs_fast = [&](uint32_t iter) {   // gibbs_collapsed with the set-up already made
     int d0 = 0;
     if (n_draw > 0) {
-      d0 = binom_trials(bs_cur, n_draw, a.seed, event_id, chain, iter, a.logfact);
+      d0 = binom_trials(bs_cur, n_draw, a.seed, event_id, chain, iter, a.logfact, TL);
       if (!bs_cur.btrs) {   // few reads or psi near 0 / 1 (inversion, degenerate p): the routine as it stands
         miso_ustream us;
         miso_ustream_init(&us, a.seed, event_id, chain, iter, MISO_SITE_COUNTS);
@@ -321,10 +213,8 @@ __global__ __launch_bounds__(256) void sampler_lane(const KernelArgs a) {
     cnt0 = base0 + d0;
     cnt1 = base1 + (n_draw - d0);
   };
-  if (a.M > 0) gibbs_fast(MISO_ITER_INIT); else gibbs_per_read(MISO_ITER_INIT);
-#else
-  if (a.M > 0) gibbs_collapsed(MISO_ITER_INIT); else gibbs_per_read(MISO_ITER_INIT);
-#endif
+  auto gibbs_step = [&](uint32_t iter) { if constexpr (ILP) gibbs_fast(iter); else gibbs_collapsed(iter); };
+  if (a.M > 0) gibbs_step(MISO_ITER_INIT); else gibbs_per_read(MISO_ITER_INIT);
 
   uint64_t hash = 0xCBF29CE484222325ull;
   int accepted = 0, lagCounter = 0, noS = 0;
@@ -337,79 +227,83 @@ __global__ __launch_bounds__(256) void sampler_lane(const KernelArgs a) {
     }
     double alphaN, x0, x1, z; uint32_t accept_word;
     mh_draws(static_cast<uint32_t>(m), z, accept_word);
-#if MISO_LANE_ILP
-    // The step's eleven transcendentals in FIVE dependent stages (the values and the operations of psi_terms, propose,
-    // prop_exponent above, in their order per value): exp {alpha', the proposal density's kernel around alpha'} -> log
-    // {psi'_0, psi'_1, the logit, p(psi | alpha'), the binomial's log odds} beside the binomial's square root -> exp
-    // {the two softmax terms, the other kernel} -> log {log-sum-exp, p(psi' | alpha)} -> exp {the acceptance ratio}.
-    alphaN = alpha + c.sd * z;
-    double e, xp;
-    {
-      const double in[2] = {alphaN, prop_exponent(cur.lgt, alphaN, c.sigma)};   // theta = psi, mu = alpha'
-      double o[2];
-      det_exp_n<2>(in, o);
-      e = o[0]; xp = o[1];
-    }
-    const double sumexp = (0.0 + e) + 1.0;
-    x0 = e / sumexp;
-    x1 = 1 - (0.0 + x0);
-    BinomSetup bs_new;
-    double sq_arg, lg_arg;
-    binom_setup_pre(bs_new, n_draw, x0 / ((0.0 + x1) + x0), sq_arg, lg_arg);
     PsiTerms nw;
-    nw.x0 = x0; nw.x1 = x1;
-    const double ltheta = 1.0 - x0;
-    double ptoCS, lpq;
-    {
-      const double in[5] = {x0, x1, x0 / ltheta, c.covar * cur.pr * xp, lg_arg};
-      double o[5];
-      det_log_n<5>(in, o);
-      nw.lx0 = o[0]; nw.lx1 = o[1]; nw.lgt = o[2]; ptoCS = o[3]; lpq = o[4];
-    }
-    binom_setup_post(bs_new, n_draw, det_sqrt_pos(sq_arg), lpq, a.logfact);
-    nw.pr = 1.0 / (1.0 * x0) / ltheta;
-    const double lp0 = nw.lx0 + c.cst0, lp1 = nw.lx1 + c.cst1;
-    const bool m1 = lp1 > lp0;  // miso.c:137-140: maxv starts at entry 0
-    const double maxv = m1 ? lp1 : lp0;
-    double ex0, ex1, xc;
-    {
-      const double in[3] = {lp0 - maxv, lp1 - maxv, prop_exponent(nw.lgt, alpha, c.sigma)};   // theta = psi', mu = alpha
-      double o[3];
-      det_exp_n<3>(in, o);
-      ex0 = o[0]; ex1 = o[1]; xc = o[2];
-    }
-    double ctoPS;
-    {
-      const double in[2] = {(0.0 + ex0) + ex1, c.covar * nw.pr * xc};
-      double o[2];
-      det_log_n<2>(in, o);
-      const double lse = o[0] + maxv;
-      nw.lpn0 = lp0 - lse;
-      nw.lpn1 = lp1 - lse;
-      ctoPS = o[1];
-    }
-#else
-    propose(z, alphaN, x0, x1);
+    double ptoCS, ctoPS;
+    BinomSetup bs_new{};
+    if constexpr (ILP) {
+      // The step's eleven transcendentals in FIVE dependent stages (the values and the operations of psi_terms, propose,
+      // prop_exponent above, in their order per value): exp {alpha', the proposal density's kernel around alpha'} -> log
+      // {psi'_0, psi'_1, the logit, p(psi | alpha'), the binomial's log odds} beside the binomial's square root -> exp
+      // {the two softmax terms, the other kernel} -> log {log-sum-exp, p(psi' | alpha)} -> exp {the acceptance ratio}.
+      alphaN = alpha + c.sd * z;
+      double e, xp;
+      {
+        const double in[2] = {alphaN, prop_exponent(cur.lgt, alphaN, c.sigma)};   // theta = psi, mu = alpha'
+        double o[2];
+        det_exp_n<2>(in, o, TE);
+        e = o[0]; xp = o[1];
+      }
+      const double sumexp = (0.0 + e) + 1.0;
+      x0 = e / sumexp;
+      x1 = 1 - (0.0 + x0);
+      double sq_arg, lg_arg;
+      binom_setup_pre(bs_new, n_draw, x0 / ((0.0 + x1) + x0), sq_arg, lg_arg);
+      nw.x0 = x0; nw.x1 = x1;
+      const double ltheta = 1.0 - x0;
+      double lpq;
+      {
+        const double in[5] = {x0, x1, x0 / ltheta, c.covar * cur.pr * xp, lg_arg};
+        double o[5];
+        det_log_n<5>(in, o, TL);
+        nw.lx0 = o[0]; nw.lx1 = o[1]; nw.lgt = o[2]; ptoCS = o[3]; lpq = o[4];
+      }
+      binom_setup_post(bs_new, n_draw, det_sqrt_pos(sq_arg), lpq, a.logfact);
+      nw.pr = 1.0 / (1.0 * x0) / ltheta;
+      const double lp0 = nw.lx0 + c.cst0, lp1 = nw.lx1 + c.cst1;
+      const bool m1 = lp1 > lp0;  // miso.c:137-140: maxv starts at entry 0
+      const double maxv = m1 ? lp1 : lp0;
+      double ex0, ex1, xc;
+      {
+        const double in[3] = {lp0 - maxv, lp1 - maxv, prop_exponent(nw.lgt, alpha, c.sigma)};   // theta = psi', mu = alpha
+        double o[3];
+        det_exp_n<3>(in, o, TE);
+        ex0 = o[0]; ex1 = o[1]; xc = o[2];
+      }
+      {
+        const double in[2] = {(0.0 + ex0) + ex1, c.covar * nw.pr * xc};
+        double o[2];
+        det_log_n<2>(in, o, TL);
+        const double lse = o[0] + maxv;
+        nw.lpn0 = lp0 - lse;
+        nw.lpn1 = lp1 - lse;
+        ctoPS = o[1];
+      }
+    } else {
+      propose(z, alphaN, x0, x1);
 #ifdef MISO_LANE_NO_MH      // timing experiment: no scores
-    PsiTerms nw = cur; nw.x0 = x0; nw.x1 = x1;
+      nw = cur; nw.x0 = x0; nw.x1 = x1;
 #else
-    const PsiTerms nw = psi_terms(x0, x1, c.cst0, c.cst1);
+      nw = psi_terms(x0, x1, c.cst0, c.cst1);
 #endif
-    const double xp = miso_det_exp(prop_exponent(cur.lgt, alphaN, c.sigma));   // theta = psi,  mu = alpha'
-    const double xc = miso_det_exp(prop_exponent(nw.lgt, alpha, c.sigma));     // theta = psi', mu = alpha
-    const double ptoCS = miso_det_log(c.covar * cur.pr * xp);
-    const double ctoPS = miso_det_log(c.covar * nw.pr * xc);
-#endif
+      const double xp = miso_det_exp(prop_exponent(cur.lgt, alphaN, c.sigma));   // theta = psi,  mu = alpha'
+      const double xc = miso_det_exp(prop_exponent(nw.lgt, alpha, c.sigma));     // theta = psi', mu = alpha
+      ptoCS = miso_det_log(c.covar * cur.pr * xp);
+      ctoPS = miso_det_log(c.covar * nw.pr * xc);
+    }
     const double pp = joint<false>(nw, cnt0, cnt1, c, 0.0);
     const double pc = joint<false>(cur, cnt0, cnt1, c, 0.0);
-    const double acceptP = (m > 0) ? miso_det_exp(pp + ptoCS - (pc + ctoPS)) : miso_det_exp(pp - pc);
+    double acceptP;
+    if constexpr (ILP) {
+      const double in[1] = {(m > 0) ? pp + ptoCS - (pc + ctoPS) : pp - pc};
+      double o[1];
+      det_exp_n<1>(in, o, TE);
+      acceptP = o[0];
+    } else {
+      acceptP = (m > 0) ? miso_det_exp(pp + ptoCS - (pc + ctoPS)) : miso_det_exp(pp - pc);
+    }
     const bool acc = (acceptP >= 1) || (miso_u01(accept_word) < acceptP);
     double cJS = pc;
-#if MISO_LANE_ILP
-    if (acc) { cur = nw; alpha = alphaN; cJS = pp; accepted++; bs_cur = bs_new; }
-#else
-    if (acc) { cur = nw; alpha = alphaN; cJS = pp; accepted++; }
-#endif
+    if (acc) { cur = nw; alpha = alphaN; cJS = pp; accepted++; if constexpr (ILP) bs_cur = bs_new; }
     if (m >= a.B) {  // miso.c:882-893
       if (lagCounter == a.lag - 1) {
         const size_t col = static_cast<size_t>(noS) + chain;
@@ -421,11 +315,7 @@ __global__ __launch_bounds__(256) void sampler_lane(const KernelArgs a) {
         lagCounter++;
       }
     }
-#if MISO_LANE_ILP
-    if (m != a.M - 1) gibbs_fast(static_cast<uint32_t>(m)); else gibbs_per_read(static_cast<uint32_t>(m));
-#else
-    if (m != a.M - 1) gibbs_collapsed(static_cast<uint32_t>(m)); else gibbs_per_read(static_cast<uint32_t>(m));
-#endif
+    if (m != a.M - 1) gibbs_step(static_cast<uint32_t>(m)); else gibbs_per_read(static_cast<uint32_t>(m));
   }
   hash = (hash ^ static_cast<uint32_t>(cnt0)) * 0x100000001B3ull;
   hash = (hash ^ static_cast<uint32_t>(cnt1)) * 0x100000001B3ull;
@@ -438,6 +328,9 @@ __global__ __launch_bounds__(256) void sampler_lane(const KernelArgs a) {
   st->accepted = accepted;
   st->hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4);
 }
+
+__global__ __launch_bounds__(256) void sampler_lane(const KernelArgs a) { lane_body<false>(a); }
+__global__ __launch_bounds__(256) void sampler_lane_ilp(const KernelArgs a) { lane_body<MISO_LANE_ILP != 0>(a); }
 
 // The same step with G lanes per chain (k2_body COLLAPSED, kernels_k2.inl): a batch of fewer chains than the device has
 // lanes -- 40 000 chains are 625 wavefronts of sampler_lane, one per SIMD on 60 % of the SIMDs, every dependent

@@ -28,6 +28,7 @@ template <int G, int MODE, int WPB> __global__ void sampler_k2(const KernelArgs 
 template <int GA, int GB> __global__ void sampler_k2_mix(const KernelArgs a);
 template <int MODE, int WPB> __global__ void sampler_k2_multi(const KernelArgs a);
 __global__ void sampler_lane(const KernelArgs a);   // kernels_lane.hip: collapsed Gibbs step, one chain per lane
+__global__ void sampler_lane_ilp(const KernelArgs a);   // ... the form for at most two wavefronts per SIMD
 template <int G> __global__ void sampler_k2c(const KernelArgs a);   // ... G lanes per chain (k2_body COLLAPSED)
 __global__ void sampler_lane_k(const KernelArgs a); // ... three and more isoforms (vectors in LDS)
 __global__ void sampler_marginal(const KernelArgs a); // kernels_marginal.hip: algorithm = MARGINAL, one chain per lane
@@ -427,6 +428,13 @@ void miso_batch::upload(int dev) {
     const double t_wide = std::getenv("MISO_PE_T_WIDE") ? std::atof(std::getenv("MISO_PE_T_WIDE")) : 256.0;
     const bool dense_ok = std::getenv("MISO_NO_PE_DENSE") == nullptr;
     const bool coop_on = coop_enabled();
+    // "at least 32 lanes" from a need of 24 lanes in a batch with a heavy tail (some gene needs a wavefront or more), from 32
+    // in a batch of like-sized genes, where a 20-isoform gene of 1000 pairs needs 28 by the share rule and runs better on
+    // 16 (round 5, 16 384 genes of 3 - 20 isoforms: 1000 pairs each 920 -> 863 ms with 32, hg19-like pair counts 830 -> 927 ms;
+    // profiles/r05_pe_mix_lanes.txt)
+    double max_need = 0.0;
+    for (int i : gen) max_need = std::max(max_need, W > 0 ? share_factor * device_lanes * (static_cast<double>((events[i].n_draw + 3) / 4) * events[i].K) / W : 0.0);
+    const double t_32 = std::getenv("MISO_PE_T_32") ? std::atof(std::getenv("MISO_PE_T_32")) : (max_need > t_wave ? 24.0 : 32.0);
     for (int i : gen) {
       const PackedEvent &e = events[i];
       const int nq = (e.n_draw + 3) / 4;
@@ -437,7 +445,7 @@ void miso_batch::upload(int dev) {
         if (coop_on && need > 384.0)
           coop_n[i] = std::max(1, std::min({COOP_MAX_N, static_cast<int>(std::ceil(need / 256.0)), nq / 512}));
       } else if (can_wide && need > t_wave && nq >= 128) bucket[i] = 2;
-      else if (need > (std::getenv("MISO_PE_T_32") ? std::atof(std::getenv("MISO_PE_T_32")) : 32.0) && nq >= 64) bucket[i] = 1;   // (round 5: 24 -> 32, see the lanes' rule in launch)
+      else if (need > t_32 && nq >= 64) bucket[i] = 1;
     }
   }
   std::stable_sort(gen.begin(), gen.end(), [&](int x, int y) {
@@ -1143,6 +1151,13 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   if (lane_route) {
     if (const char *f = std::getenv("MISO_COLLAPSED_LANES")) { const int g = std::atoi(f); if (g == 1 || g == 2 || g == 4 || g == 8) lane_G = g; }
   }
+  // one chain per lane, up to two wavefronts per SIMD: the form that overlaps a chain's own work (kernels_lane.hip
+  // sampler_lane_ilp); beyond, the lean one (six wavefronts per SIMD hide each other's latencies).  MISO_LANE_ILP=0 / 1 forces.
+  bool lane_ilp = false;
+  if (lane_route && lane_G == 1) {
+    lane_ilp = ((static_cast<long>(n_k2) * p.noChains + 255) / 256) * 4 <= wave_slots;
+    if (const char *env = std::getenv("MISO_LANE_ILP")) lane_ilp = std::atoi(env) != 0;
+  }
   {
     const int count = n_k2 - n_k2w;
     const char *off = std::getenv("MISO_K2_MULTI");
@@ -1403,7 +1418,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     };
     if (!wpart && lane_route) {
       for (int n : nd) words += static_cast<double>(n) * C;
-      add_stat(lane_G == 1 ? std::string("sampler_lane") : "sampler_k2c<" + std::to_string(lane_G) + ">",
+      add_stat(lane_G == 1 ? std::string(lane_ilp ? "sampler_lane_ilp" : "sampler_lane") : "sampler_k2c<" + std::to_string(lane_G) + ">",
                static_cast<double>((chains * lane_G + 63) / 64), 0.0, static_cast<double>(chains), words);
     } else if (wpart ? k2w_multi : k2_multi) {
       const LanePlan &pl = wpart ? planw_copy : plan_copy;
@@ -1673,21 +1688,14 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       const long chains = static_cast<long>(n_k2) * p.noChains;
       const int G = lane_G;
       lanes_per_chain = G;
-      last_kernels += std::string(last_kernels.empty() ? "" : ",") + (G == 1 ? std::string("sampler_lane") : "sampler_k2c<" + std::to_string(G) + ">");
+      last_kernels += std::string(last_kernels.empty() ? "" : ",") + (G == 1 ? std::string(lane_ilp ? "sampler_lane_ilp" : "sampler_lane") : "sampler_k2c<" + std::to_string(G) + ">");
       const unsigned grid = static_cast<unsigned>(((chains + 64 / G - 1) / (64 / G) + 3) / 4);
       hipStream_t st = stream_for_next();
       switch (G) {
       case 1: {
-        // One chain per lane, one workgroup = four wavefronts = the four SIMDs of a CU.  A batch of fewer workgroups than the
-        // device has CUs (40 000 chains: 157) must not have two of them on one CU -- their wavefronts would share SIMDs and
-        // run at half speed while a hundred CUs idle, and the launch takes as long as its slowest wavefront (the average
-        // wavefront was alive for 0.73 of the kernel, profiles/r04_se_k2_collapsed_summary.txt).  The dispatcher gives no
-        // such promise; an LDS allocation of more than half a CU's does: at most one workgroup fits.
         const unsigned wgs = static_cast<unsigned>((chains + 255) / 256);
-        size_t pad = wgs <= static_cast<unsigned>(wave_slots / 8) ? 84 * 1024 : 0;
-        if (const char *env = std::getenv("MISO_LANE_LDS_PAD_KB")) pad = static_cast<size_t>(std::max(0, std::atoi(env))) * 1024;
-        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sampler_lane), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(std::max<size_t>(pad, 1024))));
-        hipLaunchKernelGGL(sampler_lane, dim3(wgs), dim3(256), pad, st, ka);
+        if (lane_ilp) hipLaunchKernelGGL(sampler_lane_ilp, dim3(wgs), dim3(256), 0, st, ka);
+        else hipLaunchKernelGGL(sampler_lane, dim3(wgs), dim3(256), 0, st, ka);
         break;
       }
       case 2: hipLaunchKernelGGL(sampler_k2c<2>, dim3(grid), dim3(256), 0, st, ka); break;

@@ -64,8 +64,11 @@ def test_collapsed_bit_exact_against_the_checker(orc, chains, iters, burn, lag):
         cpu.append(r)
     # lanes per chain: 1 = sampler_lane; 2, 4, 8 = sampler_k2c (the binomial's rejection trials that many at a time,
     # the Metropolis-Hastings step's transcendentals one per lane): the same bits
-    for lanes, name in ((1, "sampler_lane"), (2, "sampler_k2c<2>"), (4, "sampler_k2c<4>"), (8, "sampler_k2c<8>"), (None, "sampler_lane")):
-        with _env(MISO_COLLAPSED_LANES=None if lanes is None else str(lanes)):
+    # one lane per chain has two forms (kernels_lane.hip): sampler_lane_ilp for batches of at most two wavefronts per SIMD
+    # (this one), sampler_lane beyond (MISO_LANE_ILP forces either)
+    for lanes, ilp, name in ((1, "1", "sampler_lane_ilp"), (1, "0", "sampler_lane"), (2, None, "sampler_k2c<2>"), (4, None, "sampler_k2c<4>"),
+                             (8, None, "sampler_k2c<8>"), (None, None, "sampler_lane_ilp")):
+        with _env(MISO_COLLAPSED_LANES=None if lanes is None else str(lanes), MISO_LANE_ILP=ilp):
             b = miso_amd.Batch(36, counts_trace=True, collapsed=True, **kw)
             for exons, isoforms, g, pos, cig in evs:
                 b.add_event(miso_amd.Gene(exons, isoforms), pos, cig)
@@ -129,7 +132,7 @@ def test_collapsed_mixed_isoform_counts_use_both_kernels(orc):
     for exons, isoforms, g, pos, cig in evs:
         b.add_event(miso_amd.Gene(exons, isoforms), pos, cig)
     b.run(seed=5, first_event_id=7)
-    assert sorted(b.last_kernels().split(",")) == ["sampler_lane", "sampler_lane_k"]
+    assert sorted(b.last_kernels().split(",")) == ["sampler_lane_ilp", "sampler_lane_k"]
     for i, (exons, isoforms, g, pos, cig) in enumerate(evs):
         r = orc.miso(g, pos, cig, 36, mode=OrcLib.COLLAPSED, seed=5, event_id=7 + i, trace=True, **kw)
         gpu = b.result(i)

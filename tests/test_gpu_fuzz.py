@@ -108,4 +108,4 @@ def test_random_mixed_batches_collapsed_bit_exact(orc, level, seed):
         assert (gpu.assignment == cpu.assignment).all(), where
         assert gpu.rundata.noAccepted == cpu.accepted, where
     names = b.last_kernels().split(",")
-    assert "sampler_lane" in names and (("sampler_lane_k" in names) == (level == 2)), names
+    assert ("sampler_lane" in names or "sampler_lane_ilp" in names) and (("sampler_lane_k" in names) == (level == 2)), names
