@@ -63,9 +63,10 @@ extern "C" {
 #define MISO_STOP_CONVERGENT_MEAN 1
 
 /* Most isoforms of one gene.  The reference has no limit (miso.c:696, gff.c:684); here an isoform is a bit of a read's
-   compatibility mask and, beyond 32, a lane of the one wavefront that samples the chain (sampler_wave): 64.  A gene
-   with more is reported MISO_UNIMPLEMENTED by the one-event calls and skipped with a message by the batch callers. */
-#define MISO_MAX_ISOFORMS 64
+   compatibility mask ((K + 31) / 32 words per read) and an entry of the chain's vectors; from 65 isoforms on the chain's
+   vectors live in LDS (sampler_big) and a read's pick is returned as one byte: 256.  A gene with more is reported
+   MISO_UNIMPLEMENTED by the one-event calls and skipped with a message by the batch callers. */
+#define MISO_MAX_ISOFORMS 256
 
 /* splicing_miso_rundata_t (splicing.h:143-146), same field order */
 typedef struct miso_rundata {

@@ -61,24 +61,31 @@ MISO_HD double miso_ustream_next(miso_ustream *s) {
   return miso_u01(w);
 }
 
-/* n r < 10: sequential search from 0 (K&S's BINV), restarted with a fresh uniform if it runs past the bound */
+/* n r < 10: sequential search from 0 (K&S's BINV), restarted with a fresh uniform if it runs past the bound.
+   Round 5: the search WITHOUT its division per step.  BINV compares u_x = u - p_0 - ... - p_(x-1) with p_x and moves on by
+   p_(x+1) = p_x (n - x) r / ((x + 1) q); here both sides carry the common factor B_x = prod_(i <= x) i q:
+   U_x = u_x B_x, P_x = p_x B_x, so that  U_(x+1) = (U_x - P_x) (x + 1) q  and  P_(x+1) = P_x (n - x) r  -- the same test
+   u_x > p_x (B_x > 0), four multiplications and a subtraction per step instead of a division (x stays below
+   n r + 10 sqrt(n r q + 1) < 44, so B_x < 44! and nothing overflows).  On the GPU a wavefront that holds ONE chain in this
+   regime runs these steps for all its lanes, and a division is twenty dependent instructions: such wavefronts set the
+   collapsed launch's duration (profiles/r05_sampler_lane_ilp.txt). */
 MISO_HD int32_t miso_binomial_inversion(miso_ustream *s, int32_t n, double r) {
   const double q = 1.0 - r;
   const double qn = miso_det_exp((double) n * miso_det_log(q));
   const double np = (double) n * r;
   double bound = np + 10.0 * miso_det_sqrt(np * q + 1.0);
   int32_t x = 0;
-  double px = qn, u = miso_ustream_next(s);
+  double P = qn, U = miso_ustream_next(s);
   int guard = 0;
   if (bound > (double) n) bound = (double) n;
-  while (u > px) {
+  while (U > P) {
     x++;
     if ((double) x > bound) {
       if (++guard > 64) return (int32_t) np;   /* cannot happen for finite inputs; never loop forever */
-      x = 0; px = qn; u = miso_ustream_next(s);
+      x = 0; P = qn; U = miso_ustream_next(s);
     } else {
-      u = u - px;
-      px = ((double) (n - x + 1) * r * px) / ((double) x * q);
+      U = (U - P) * ((double) x * q);
+      P = P * ((double) (n - x + 1) * r);
     }
   }
   return x;

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("MISO_AMD_LIB", os.path.join(_HERE, "libmiso_amd.so"))
 
 MISO_SUCCESS, MISO_FAILURE, MISO_ENOMEM, MISO_EINVAL = 0, 1, 2, 4
 MISO_UNIMPLEMENTED, MISO_EINTERNAL, MISO_ENODEVICE = 12, 38, 60
-MISO_MAX_ISOFORMS = 64      # include/miso_amd.h
+MISO_MAX_ISOFORMS = 256     # include/miso_amd.h
 
 # pysplicing/pysplicing/__init__.py:2-13
 MISO_START_AUTO, MISO_START_UNIFORM, MISO_START_RANDOM, MISO_START_GIVEN, MISO_START_LINEAR = range(5)

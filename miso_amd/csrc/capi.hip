@@ -221,7 +221,7 @@ int miso_batch_add_event(miso_batch_t *b, const miso_gene_t *gene, const int *po
     const int N = b->p.paired ? n_positions / 2 : n_positions;
     if (b->p.device_match) {   // row f1: parse now (errors surface here), match on the GPU at upload
       if (g.K < 2) MISO_FAIL(MISO_EINVAL, "At least two isoforms are needed");
-      if (g.K > MISO_MAX_ISOFORMS) MISO_FAIL(MISO_UNIMPLEMENTED, "More than 64 isoforms");
+      if (g.K > MISO_MAX_ISOFORMS) MISO_FAIL(MISO_UNIMPLEMENTED, "More than 256 isoforms");
       if (b->p.overHang < 0) MISO_FAIL(MISO_EINVAL, "Overhang length invalid. Must be positive");
       if (b->p.readLength < 0) MISO_FAIL(MISO_EINVAL, "Read length cannot be negative");
       miso_batch::Pending pe;
@@ -450,7 +450,7 @@ int miso_batch_add_events_aln(miso_batch_t *b, int n, const miso_gene_t *const *
           if (!genes[i]) MISO_FAIL(MISO_EINVAL, "gene must not be NULL");
           const Gene &g = genes[i]->g;
           if (g.K < 2) MISO_FAIL(MISO_EINVAL, "At least two isoforms are needed");
-          if (g.K > MISO_MAX_ISOFORMS) MISO_FAIL(MISO_UNIMPLEMENTED, "More than 64 isoforms");
+          if (g.K > MISO_MAX_ISOFORMS) MISO_FAIL(MISO_UNIMPLEMENTED, "More than 256 isoforms");
           int64_t k = 0;
           if (miso_aln_collect_reads(f, ref[i], start[i], end[i], paired, strand_rule, target_strand[i],
                                      given_read_len, pos, cig, &k, nullptr))
@@ -672,8 +672,9 @@ int miso_batch_get_match(const miso_batch_t *b, int i, double *match, int *fragm
       }
     } else {
       const std::vector<uint64_t> &m = b->kept_masks.at(i);
+      const int W = (e.K + 63) / 64;   // mask words per read
       for (int r = 0; r < e.N; r++)
-        for (int k = 0; k < e.K; k++) match[static_cast<size_t>(r) * e.K + k] = (m[r] >> k) & 1ull ? 1.0 : 0.0;
+        for (int k = 0; k < e.K; k++) match[static_cast<size_t>(r) * e.K + k] = (m[static_cast<size_t>(r) * W + (k >> 6)] >> (k & 63)) & 1ull ? 1.0 : 0.0;
     }
   });
 }

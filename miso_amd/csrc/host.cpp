@@ -370,21 +370,22 @@ PackedEvent pack_event(const miso_params_t &p, const FragmentDist *fd, int K, in
                        const double *match, const int *fraglen, const int *isolen,
                        const int *noexons, const double *hyper) {
   if (K < 2) MISO_FAIL(MISO_EINVAL, "At least two isoforms are needed");
-  if (K > MISO_MAX_ISOFORMS) MISO_FAIL(MISO_UNIMPLEMENTED, "More than 64 isoforms");
+  if (K > MISO_MAX_ISOFORMS) MISO_FAIL(MISO_UNIMPLEMENTED, "More than 256 isoforms");
   if (p.paired && (!fd || !fraglen)) MISO_FAIL(MISO_EINTERNAL, "Paired event without fragments");
+  const int W = (K + 63) / 64;   // mask words per read
   // the packed form only needs which isoforms a read is compatible with (and, paired-end, the
   // fragment length in each); a caller-made single-end matrix with values other than 0/1 keeps
   // its values for the header's read classes
-  std::vector<uint64_t> masks(N > 0 ? N : 1, 0u);
+  std::vector<uint64_t> masks(static_cast<size_t>(N > 0 ? N : 1) * W, 0u);
   std::vector<uint16_t> frags;
   bool binary = true;
   if (p.paired) frags.assign(static_cast<size_t>(N) * K, FRAG_NONE);
   for (int i = 0; i < N; i++) {
-    uint64_t m = 0;
+    uint64_t *m = masks.data() + static_cast<size_t>(i) * W;
     for (int k = 0; k < K; k++) {
       const size_t j = static_cast<size_t>(i) * K + k;
       if (match[j] != 0) {
-        m |= 1ull << k;
+        m[k >> 6] |= 1ull << (k & 63);
         if (p.paired) {
           // the fragment length indexes the fragment-probability and score tables: a caller-made problem
           // outside [start, start + il) would read out of bounds on the host and on the device
@@ -396,17 +397,19 @@ PackedEvent pack_event(const miso_params_t &p, const FragmentDist *fd, int K, in
       }
       if (!p.paired && match[j] != 0.0 && match[j] != 1.0) binary = false;
     }
-    masks[i] = m;
   }
   return pack_event_masks(p, fd, K, N, masks.data(), p.paired ? frags.data() : nullptr,
-                          (p.paired || binary) ? nullptr : match, isolen, noexons, hyper);
+                          (p.paired || binary) ? nullptr : match, isolen, noexons, hyper, W);
 }
 
 PackedEvent pack_event_masks(const miso_params_t &p, const FragmentDist *fd, int K, int N,
                              const uint64_t *masks, const uint16_t *frags, const double *se_values,
-                             const int *isolen, const int *noexons, const double *hyper) {
+                             const int *isolen, const int *noexons, const double *hyper, int W) {
   if (K < 2) MISO_FAIL(MISO_EINVAL, "At least two isoforms are needed");
-  if (K > MISO_MAX_ISOFORMS) MISO_FAIL(MISO_UNIMPLEMENTED, "More than 64 isoforms");
+  if (K > MISO_MAX_ISOFORMS) MISO_FAIL(MISO_UNIMPLEMENTED, "More than 256 isoforms");
+  if (W != (K + 63) / 64) MISO_FAIL(MISO_EINTERNAL, "Mask words do not match the isoform count");
+  if (K > 64 && !p.paired && p.algorithm != MISO_ALGO_REASSIGN)
+    MISO_FAIL(MISO_UNIMPLEMENTED, "The MARGINAL and CLASSES algorithms take at most 64 isoforms");
   const bool small = K <= 32;   // the class tables, work units and dense records of the kernels for up to 32 isoforms
   if (p.paired && (!fd || (N > 0 && !frags))) MISO_FAIL(MISO_EINTERNAL, "Paired event without fragments");
   const int ov = p.overHang == 0 ? 1 : p.overHang;
@@ -475,10 +478,22 @@ PackedEvent pack_event_masks(const miso_params_t &p, const FragmentDist *fd, int
   const bool binary = se_values == nullptr;
   auto reversed = [K](uint64_t m) { uint64_t r = 0; for (int k = 0; k < K; k++) r = (r << 1) | ((m >> k) & 1u); return r; };
   uint64_t last_mask = ~0ull; size_t last_cls = 0;
+  // more than 64 isoforms: the classes keyed by the column itself, isoform 0 in the top bit of word 0 -- the keys' order IS
+  // the lexicographic column order
+  std::map<std::vector<uint64_t>, double> big_cls;
+  auto big_key = [K, W](const uint64_t *row) {
+    std::vector<uint64_t> key(W, 0);
+    for (int k = 0; k < K; k++) if ((row[k >> 6] >> (k & 63)) & 1ull) key[k >> 6] |= 1ull << (63 - (k & 63));
+    return key;
+  };
   for (int i = 0; i < N; i++) {
-    const uint64_t mask = masks[i];
-    const int nv = __builtin_popcountll(mask);
-    if (binary) {
+    const uint64_t *mrow = masks + static_cast<size_t>(i) * W;
+    const uint64_t mask = mrow[0];
+    int nv = 0;
+    for (int w = 0; w < W; w++) nv += __builtin_popcountll(mrow[w]);
+    if (binary && W > 1) {
+      big_cls[big_key(mrow)] += 1.0;
+    } else if (binary) {
       if (mask != last_mask) {   // reads of one class tend to come in runs
         const uint64_t rev = reversed(mask);
         size_t c = 0;
@@ -492,7 +507,8 @@ PackedEvent pack_event_masks(const miso_params_t &p, const FragmentDist *fd, int
     }
     if (nv == 0) continue;
     if (nv == 1) {
-      const int first = __builtin_ctzll(mask);
+      int first = 0;
+      for (int w = 0; w < W; w++) if (mrow[w]) { first = 64 * w + __builtin_ctzll(mrow[w]); break; }
       e.fixed_ass[i] = first;
       e.base_count[first]++;
       if (p.paired) {
@@ -503,7 +519,7 @@ PackedEvent pack_event_masks(const miso_params_t &p, const FragmentDist *fd, int
     }
     e.fixed_ass[i] = -2;
     e.draw_index.push_back(i);
-    if (!p.paired) e.draw_mask.push_back(mask);
+    if (!p.paired) { e.draw_mask.push_back(mask); for (int w = 1; w < W; w++) e.draw_mask_x.push_back(mrow[w]); }
     else e.draw_frag.insert(e.draw_frag.end(), frags + static_cast<size_t>(i) * K, frags + static_cast<size_t>(i + 1) * K);
     e.n_draw++;
   }
@@ -573,7 +589,22 @@ PackedEvent pack_event_masks(const miso_params_t &p, const FragmentDist *fd, int
     for (int k = 0; k < K; k++)
       std::memcpy(e.sfix_dense.data() + static_cast<size_t>(k) * il2, e.sfix_table.data() + static_cast<size_t>(k) * il, il * sizeof(int32_t));
   }
-  if (!p.paired) {
+  if (!p.paired && W > 1) {
+    // draw order, more than 64 isoforms: by column (isoform 0 most significant, 0 < 1), ties by read index -- a stable sort
+    // on the columns' keys (no class tables: those serve the kernels for up to 32 isoforms)
+    std::vector<std::vector<uint64_t>> keys(e.n_draw);
+    for (int r = 0; r < e.n_draw; r++) keys[r] = big_key(masks + static_cast<size_t>(e.draw_index[r]) * W);
+    std::vector<int32_t> by(e.n_draw);
+    for (int r = 0; r < e.n_draw; r++) by[r] = r;
+    std::stable_sort(by.begin(), by.end(), [&](int32_t x, int32_t y) { return keys[x] < keys[y]; });
+    std::vector<int32_t> idx(e.n_draw); std::vector<uint64_t> m0(e.n_draw), mx(e.draw_mask_x.size());
+    for (int r = 0; r < e.n_draw; r++) {
+      idx[r] = e.draw_index[by[r]]; m0[r] = e.draw_mask[by[r]];
+      for (int w = 1; w < W; w++) mx[static_cast<size_t>(r) * (W - 1) + w - 1] = e.draw_mask_x[static_cast<size_t>(by[r]) * (W - 1) + w - 1];
+    }
+    e.draw_index.swap(idx); e.draw_mask.swap(m0); e.draw_mask_x.swap(mx);
+  }
+  if (!p.paired && W == 1) {
     // draw order: by column (isoform 0 most significant, 0 < 1), ties by read index
     // (a stable counting sort over the distinct masks: usually a handful, at most n_draw)
     std::vector<std::pair<uint64_t, uint64_t>> dm;   // (reversed mask, mask) of the distinct drawing masks
@@ -640,7 +671,12 @@ PackedEvent pack_event_masks(const miso_params_t &p, const FragmentDist *fd, int
       }
     }
   }
-  if (binary) {
+  if (binary && W > 1) {
+    for (const auto &kv : big_cls) {
+      for (int k = 0; k < K; k++) e.class_templates.push_back((kv.first[k >> 6] >> (63 - (k & 63))) & 1ull ? 1.0 : 0.0);
+      e.class_counts.push_back(kv.second);
+    }
+  } else if (binary) {
     std::sort(bcls.begin(), bcls.end());
     for (const auto &kv : bcls) {
       for (int k = 0; k < K; k++) e.class_templates.push_back((kv.first >> (K - 1 - k)) & 1ull ? 1.0 : 0.0);

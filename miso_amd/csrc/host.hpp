@@ -98,6 +98,7 @@ struct PackedEvent {
   // the reads of one class are consecutive.
   std::vector<int32_t> draw_index;      // n_draw: read index of draw r
   std::vector<uint64_t> draw_mask;      // single-end: n_draw (the device gets the low words, then -- K > 32 -- the high words)
+  std::vector<uint64_t> draw_mask_x;    // ... more than 64 isoforms: mask words 1 .. W - 1 of every draw, n_draw x (W - 1)
   std::vector<uint32_t> dcls_mask;      // single-end: distinct masks among the drawing reads, in draw order
   std::vector<int32_t> dcls_start;      // ... first draw of each class (+ n_draw at the end)
   std::vector<uint32_t> dcls_tab;       // ... device class table, CLS_WORDS per class + sentinel (device.hpp)
@@ -138,9 +139,10 @@ PackedEvent pack_event(const miso_params_t &p, const FragmentDist *fd, int K, in
 // the same from what the packing really needs: per read the u32 compatibility mask, paired-end the
 // K u16 fragment-length indices (FRAG_NONE = incompatible); se_values (single-end, optional): the
 // match matrix when it holds values other than 0/1, for the header's read classes only
+// (W: 64-bit mask words per read, (K + 63) / 64 -- 1 up to 64 isoforms)
 PackedEvent pack_event_masks(const miso_params_t &p, const FragmentDist *fd, int K, int N,
                              const uint64_t *masks, const uint16_t *frags, const double *se_values,
-                             const int *isolen, const int *noexons, const double *hyper);
+                             const int *isolen, const int *noexons, const double *hyper, int W = 1);
 // algorithm = CLASSES (miso.c:788-803): the event's table of the gene's possible read classes (splicing_assignment_matrix,
 // assignment.c:90-276; rows normalised; the reads of every class, solve.c:110-137) from the gene's structure and the
 // event's own read classes.  After pack_event*; MISO_UNIMPLEMENTED with an overhang above 1, as the reference.
@@ -148,6 +150,7 @@ void attach_gene_classes(PackedEvent &e, const miso_params_t &p, const Gene &g);
 // the matrix itself (tests): K x (returned) columns, column-major
 std::vector<double> assignment_matrix(const Gene &g, int readLength, int overHang);
 // (33 ... MISO_MAX_ISOFORMS isoforms: no read classes, work units or dense records are made -- those serve the kernels
-// for up to 32 isoforms; such an event is sampled by sampler_wave, lane k = isoform k, runtime.hip)
+// for up to 32 isoforms; such an event is sampled by sampler_wave, lane k = isoform k -- beyond 64 isoforms by sampler_big,
+// the chain's vectors in LDS -- runtime.hip)
 
 }  // namespace miso

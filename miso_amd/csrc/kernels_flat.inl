@@ -904,7 +904,10 @@ __global__ __launch_bounds__(256, KC <= 4 ? MISO_FLAT_WGS_4 : (KC <= 8 ? MISO_FL
       if (on && acc) {
         FD(s, L.psi)[j] = v0; FD(s, L.alpha)[j] = v1; FD(s, L.lp)[j] = v2; FD(s, L.tb)[j] = v3; FD(s, L.lr)[j] = v4;
       }
-      if (rec && on && j < K && writes) {
+#ifndef MISO_FLAT_STORE_AFTER
+#define MISO_FLAT_STORE_AFTER 0   // 1: the iteration's sample leaves after the Gibbs step's loads (a pass of its own); measured, round 5: K = 5 410.4 vs 415.1 ms, K = 10 743.1 vs 748.0 ms (profiles/r05_store_after.txt); 0: from this pass
+#endif
+      if (!MISO_FLAT_STORE_AFTER && rec && on && j < K && writes) {
         const uint64_t so = (static_cast<uint64_t>(static_cast<uint32_t>(mi[MI_SAMP_HI])) << 32) | static_cast<uint32_t>(mi[MI_SAMP_LO]);
         const size_t col = static_cast<size_t>(noS) + mi[MI_CHAIN];
         reinterpret_cast<double *>(a.out_pool + so)[col * K + j] = acc ? v0 : c0;
@@ -913,9 +916,10 @@ __global__ __launch_bounds__(256, KC <= 4 ? MISO_FLAT_WGS_4 : (KC <= 8 ? MISO_FL
     fsync();
     FPROF_T(m1);
     FPROF_ADD(fp_mh, m0, m1);
+    const int rec_col = noS;
     if (m >= a.B) {
       if (rec) {
-        if (leader && writes) reinterpret_cast<double *>(a.out_pool + LE_.off_loglik)[static_cast<size_t>(noS) + lchain] = cJS;
+        if (!MISO_FLAT_STORE_AFTER && leader && writes) reinterpret_cast<double *>(a.out_pool + LE_.off_loglik)[static_cast<size_t>(noS) + lchain] = cJS;
         noS += a.C;
         lagCounter = 0;
       } else {
@@ -923,6 +927,20 @@ __global__ __launch_bounds__(256, KC <= 4 ? MISO_FLAT_WGS_4 : (KC <= 8 ? MISO_FL
       }
     }
     gibbs(static_cast<uint32_t>(m));
+    // the sample BEHIND the Gibbs step's loads (vmcnt counts loads and stores in order: the step's first descriptor load
+    // used to wait for the sample stored just before it to be acknowledged); psi is not touched by the step
+    if (MISO_FLAT_STORE_AFTER && rec) {
+      FLAT_BEGIN(ks, inv_k)
+        const int *mi = FI(s, L.misc);
+        const int K = mi[MI_K];
+        if (on && j < K && writes) {
+          const uint64_t so = (static_cast<uint64_t>(static_cast<uint32_t>(mi[MI_SAMP_HI])) << 32) | static_cast<uint32_t>(mi[MI_SAMP_LO]);
+          const size_t col = static_cast<size_t>(rec_col) + mi[MI_CHAIN];
+          reinterpret_cast<double *>(a.out_pool + so)[col * K + j] = FD(s, L.psi)[j];
+        }
+      FLAT_END
+      if (leader && writes) reinterpret_cast<double *>(a.out_pool + LE_.off_loglik)[static_cast<size_t>(rec_col) + lchain] = cJS;
+    }
   }
   if (leader)
     for (int k = 0; k < Kw; k++)

@@ -1381,20 +1381,29 @@ __device__ __forceinline__ void grp_body(const KernelArgs &a, unsigned block_x) 
     }
     GPROF_T(m1);
     GPROF_ADD(gp_mh, m0, m1);
-    if (m >= a.B) {  // miso.c:882-893
+#ifndef MISO_GRP_STORE_AFTER
+#define MISO_GRP_STORE_AFTER 0
+#endif
+    // miso.c:882-893.  (MISO_GRP_STORE_AFTER: the stores issued behind the Gibbs step, whose first record load is only "there"
+    // once the stores in front of it have been acknowledged -- vmcnt counts both, in order.  The Gibbs step does not touch psi:
+    // the same values leave either way.  Tried; not the wait.)
+    bool rec = false; size_t rec_col = 0;
+    if (m >= a.B) {
       if (lagCounter == a.lag - 1) {
-        if (live) {
-          const size_t col = static_cast<size_t>(noS) + chain;
-          for (int k0 = 0; k0 < Kw; k0 += G) { const int k = k0 + sub; if (k < K) samples[col * K + k] = S.psi[k]; }
-          if (sub == 0) loglik[col] = cJS;
-        }
+        rec = live; rec_col = static_cast<size_t>(noS) + chain;
         noS += a.C;
         lagCounter = 0;
       } else {
         lagCounter++;
       }
     }
+    auto store_sample = [&]() __attribute__((always_inline)) {
+      for (int k0 = 0; k0 < Kw; k0 += G) { const int k = k0 + sub; if (k < K) samples[rec_col * K + k] = S.psi[k]; }
+      if (sub == 0) loglik[rec_col] = cJS;
+    };
+    if (!MISO_GRP_STORE_AFTER && rec) store_sample();
     gibbs(static_cast<uint32_t>(m), live_all && chain == 0 && m == a.M - 1);
+    if (MISO_GRP_STORE_AFTER && rec) store_sample();
   }
   for (int k = 0; k < K; k++) hash = (hash ^ static_cast<uint32_t>(count_of(k))) * 0x100000001B3ull;
 #ifdef MISO_K2_PROFILE

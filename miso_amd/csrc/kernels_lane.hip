@@ -27,6 +27,18 @@ namespace {
 // What miso_binomial_btrs (include/miso_binomial.h) computes before its first trial, for Binomial(n, p): kept for the
 // chain's current psi and made for the proposal's BESIDE the Metropolis-Hastings scores (the proposal is accepted two
 // times in three, and the wavefront has issue slots to spare), so that the accepted state's draw starts at its trials.
+// log(k!): the head of the batch's table in LDS (sampler_lane_ilp stages it once), the rest in global memory.  Not for the
+// bytes -- the table's hot entries sit in the L1 -- but for the COUNTER: a global load behind the iteration's sample stores
+// waits for those stores to be acknowledged (vmcnt counts both, in order), a third of the average wavefront's time
+// (SQ_WAIT_ANY, profiles/r05_sampler_lane_ilp.txt); an LDS read waits for nothing of the kind.
+constexpr int LANE_LF_LDS = 2048;
+struct LogFact {
+  const double *__restrict__ glob;
+  const double *lds;
+  int n_lds;
+  __device__ __forceinline__ double at(int32_t i) const { return i < n_lds ? lds[i] : glob[i]; }
+};
+
 struct BinomSetup {
   double p, r, spq, b, a, c, vr, alpha, m, lpq, h;
   bool btrs;      // n r >= 10 and 0 < p < 1: the fast path below; otherwise miso_binomial as it stands
@@ -41,7 +53,7 @@ __device__ __forceinline__ void binom_setup_pre(BinomSetup &s, int32_t n, double
   sq_arg = s.btrs ? dn * s.r * q : 4.0;    // (a harmless argument where the fast path is not taken)
   lg_arg = s.btrs ? s.r / q : 1.0;
 }
-__device__ __forceinline__ void binom_setup_post(BinomSetup &s, int32_t n, double spq, double lpq, const double *__restrict__ lf) {
+__device__ __forceinline__ void binom_setup_post(BinomSetup &s, int32_t n, double spq, double lpq, const LogFact &lf) {
   const double dn = static_cast<double>(n);
   s.spq = spq;
   s.b = 1.15 + 2.53 * spq;
@@ -52,14 +64,14 @@ __device__ __forceinline__ void binom_setup_post(BinomSetup &s, int32_t n, doubl
   s.m = __builtin_floor((dn + 1.0) * s.r);
   s.lpq = lpq;
   const int32_t mi = s.btrs ? static_cast<int32_t>(s.m) : 0;
-  s.h = lf[mi] + lf[s.btrs ? n - mi : 0];
+  s.h = lf.at(mi) + lf.at(s.btrs ? n - mi : 0);
 }
 // the trials of miso_binomial_btrs, TWO per round: trials 2j and 2j + 1 are the two halves of block j of the chain's word
 // stream (miso_ustream_next), evaluated side by side; the first that is accepted -- in the sequential order -- is the
 // draw, exactly as the one-at-a-time loop returns it.  Every lane of the wavefront runs until its own draw is made; a
 // lane that is not on the fast path (s.btrs false) takes no part.
 __device__ __forceinline__ int32_t binom_trials(const BinomSetup &s, int32_t n, uint64_t seed, uint32_t event_id, uint32_t chain,
-                                                uint32_t iter, const double *__restrict__ lf, const double (&tl)[12]) {
+                                                uint32_t iter, const LogFact &lf, const double (&tl)[12]) {
   const double dn = static_cast<double>(n);
   int32_t y = static_cast<int32_t>(s.m);
   bool done = !s.btrs;
@@ -82,7 +94,7 @@ __device__ __forceinline__ int32_t binom_trials(const BinomSetup &s, int32_t n, 
 #pragma unroll
     for (int t = 0; t < 2; t++) {
       const int32_t ki = in[t] ? static_cast<int32_t>(k[t]) : 0;
-      const double rhs = (s.h - lf[ki] - lf[n - ki]) + (k[t] - s.m) * s.lpq;
+      const double rhs = (s.h - lf.at(ki) - lf.at(n - ki)) + (k[t] - s.m) * s.lpq;
       ok[t] = in[t] && (quick[t] || lv[t] <= rhs);
     }
     if (ok[0]) { y = static_cast<int32_t>(k[0]); done = true; }
@@ -102,7 +114,13 @@ __device__ __forceinline__ int32_t binom_trials(const BinomSetup &s, int32_t n, 
 // set-up beside the scores and its trials two per round; 250 registers.  The plain form (76 registers, six wavefronts per
 // SIMD) for larger batches, where other wavefronts fill the gaps.  Same draws, same bits (tests/test_gpu_collapsed.py).
 template <bool ILP>
-__device__ __forceinline__ void lane_body(const KernelArgs &a) {
+__device__ __forceinline__ void lane_body(const KernelArgs &a, double *lds_lf) {
+  LogFact LF{a.logfact, lds_lf, 0};
+  if constexpr (ILP) {   // (a.tstride: the table's entries, runtime.hip)
+    LF.n_lds = min(a.tstride, LANE_LF_LDS);
+    for (int i = threadIdx.x; i < LF.n_lds; i += 256) lds_lf[i] = a.logfact[i];
+    __syncthreads();   // the only barrier, before any thread leaves
+  }
   const long n_chains = static_cast<long>(a.n_slots) * a.C;
   const long slot = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
   if (slot >= n_chains) return;   // no barrier below
@@ -198,12 +216,12 @@ __device__ __forceinline__ void lane_body(const KernelArgs &a) {
   if constexpr (ILP) {
     double sq_arg, lg_arg;
     binom_setup_pre(bs_cur, n_draw, cur.x0 / ((0.0 + cur.x1) + cur.x0), sq_arg, lg_arg);
-    binom_setup_post(bs_cur, n_draw, det_sqrt_pos(sq_arg), miso_det_log(lg_arg), a.logfact);
+    binom_setup_post(bs_cur, n_draw, det_sqrt_pos(sq_arg), miso_det_log(lg_arg), LF);
   }
   auto gibbs_fast = [&](uint32_t iter) {   // gibbs_collapsed with the set-up already made
     int d0 = 0;
     if (n_draw > 0) {
-      d0 = binom_trials(bs_cur, n_draw, a.seed, event_id, chain, iter, a.logfact, TL);
+      d0 = binom_trials(bs_cur, n_draw, a.seed, event_id, chain, iter, LF, TL);
       if (!bs_cur.btrs) {   // few reads or psi near 0 / 1 (inversion, degenerate p): the routine as it stands
         miso_ustream us;
         miso_ustream_init(&us, a.seed, event_id, chain, iter, MISO_SITE_COUNTS);
@@ -257,7 +275,7 @@ __device__ __forceinline__ void lane_body(const KernelArgs &a) {
         det_log_n<5>(in, o, TL);
         nw.lx0 = o[0]; nw.lx1 = o[1]; nw.lgt = o[2]; ptoCS = o[3]; lpq = o[4];
       }
-      binom_setup_post(bs_new, n_draw, det_sqrt_pos(sq_arg), lpq, a.logfact);
+      binom_setup_post(bs_new, n_draw, det_sqrt_pos(sq_arg), lpq, LF);
       nw.pr = 1.0 / (1.0 * x0) / ltheta;
       const double lp0 = nw.lx0 + c.cst0, lp1 = nw.lx1 + c.cst1;
       const bool m1 = lp1 > lp0;  // miso.c:137-140: maxv starts at entry 0
@@ -329,8 +347,11 @@ __device__ __forceinline__ void lane_body(const KernelArgs &a) {
   st->hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4);
 }
 
-__global__ __launch_bounds__(256) void sampler_lane(const KernelArgs a) { lane_body<false>(a); }
-__global__ __launch_bounds__(256) void sampler_lane_ilp(const KernelArgs a) { lane_body<MISO_LANE_ILP != 0>(a); }
+__global__ __launch_bounds__(256) void sampler_lane(const KernelArgs a) { lane_body<false>(a, nullptr); }
+__global__ __launch_bounds__(256) void sampler_lane_ilp(const KernelArgs a) {
+  __shared__ double lane_lf[LANE_LF_LDS];
+  lane_body<MISO_LANE_ILP != 0>(a, lane_lf);
+}
 
 // The same step with G lanes per chain (k2_body COLLAPSED, kernels_k2.inl): a batch of fewer chains than the device has
 // lanes -- 40 000 chains are 625 wavefronts of sampler_lane, one per SIMD on 60 % of the SIMDs, every dependent

@@ -27,6 +27,7 @@ template <bool PE> __global__ void sampler_wave(const KernelArgs a);
 template <int G, int MODE, int WPB> __global__ void sampler_k2(const KernelArgs a);
 template <int GA, int GB> __global__ void sampler_k2_mix(const KernelArgs a);
 template <int MODE, int WPB> __global__ void sampler_k2_multi(const KernelArgs a);
+template <bool PE> __global__ void sampler_big(const KernelArgs a);   // kernels_big.hip: 65 ... MISO_MAX_ISOFORMS isoforms
 __global__ void sampler_lane(const KernelArgs a);   // kernels_lane.hip: collapsed Gibbs step, one chain per lane
 __global__ void sampler_lane_ilp(const KernelArgs a);   // ... the form for at most two wavefronts per SIMD
 template <int G> __global__ void sampler_k2c(const KernelArgs a);   // ... G lanes per chain (k2_body COLLAPSED)
@@ -162,7 +163,7 @@ void miso_batch::resolve_pending() {
     const size_t slot = pe ? (out_frags + K - 1) / K : o_out[i];
     frag_off[i] = slot * K;
     if (pe) out_frags = frag_off[i] + static_cast<size_t>(N) * K;
-    o_out[i + 1] = o_out[i] + static_cast<size_t>(N) * (!pe && K > 32 ? 2 : 1);   // single-end masks: two words per read from 33 isoforms on
+    o_out[i + 1] = o_out[i] + static_cast<size_t>(N) * (pe ? 1 : (K + 31) / 32);   // single-end masks: (K + 31) / 32 words per read
     MatchEvent &m = mev[i];
     m.K = q.gene.K; m.n_reads = N;
     m.exidx_off = static_cast<int32_t>(o_xi[i]); m.ex_off = static_cast<int32_t>(o_ex[i]);
@@ -246,22 +247,22 @@ void miso_batch::resolve_pending() {
         const int K = q.gene.K, N = mev[i].n_reads;
         const uint32_t *mk32 = pe ? nullptr : h_masks.data() + mev[i].out_off;
         const uint16_t *f = pe ? h_frags.data() + frag_off[i] : nullptr;
-        std::vector<uint64_t> pm(std::max(N, 1), 0u);
+        const int W = (K + 63) / 64, W32 = (K + 31) / 32;   // mask words per read: 64-bit on the host, 32-bit from the kernel
+        std::vector<uint64_t> pm(static_cast<size_t>(std::max(N, 1)) * W, 0u);
         if (pe) {   // a pair's mask = the isoforms with a fragment length inside the distribution
           for (int r = 0; r < N; r++)
-            for (int k = 0; k < K; k++) if (f[static_cast<size_t>(r) * K + k] != FRAG_NONE) pm[r] |= 1ull << k;
-        } else if (K > 32) {
-          for (int r = 0; r < N; r++) pm[r] = mk32[2 * r] | static_cast<uint64_t>(mk32[2 * r + 1]) << 32;
+            for (int k = 0; k < K; k++) if (f[static_cast<size_t>(r) * K + k] != FRAG_NONE) pm[static_cast<size_t>(r) * W + (k >> 6)] |= 1ull << (k & 63);
         } else {
-          for (int r = 0; r < N; r++) pm[r] = mk32[r];
+          for (int r = 0; r < N; r++)
+            for (int w = 0; w < W32; w++) pm[static_cast<size_t>(r) * W + (w >> 1)] |= static_cast<uint64_t>(mk32[static_cast<size_t>(W32) * r + w]) << (32 * (w & 1));
         }
         const uint64_t *mk = pm.data();
         if (p.want_counts_trace) {
           if (pe) kept_frags[q.event].assign(f, f + static_cast<size_t>(N) * K);
-          else kept_masks[q.event].assign(mk, mk + N);
+          else kept_masks[q.event].assign(mk, mk + static_cast<size_t>(N) * W);
         }
         events[q.event] = pack_event_masks(p, pe ? &fd : nullptr, K, N, mk, f, nullptr, q.gene.isolen.data(),
-                                           q.gene.noexons.data(), q.hyper.empty() ? nullptr : q.hyper.data());
+                                           q.gene.noexons.data(), q.hyper.empty() ? nullptr : q.hyper.data(), W);
         attach_gene_classes(events[q.event], p, q.gene);   // algorithm = CLASSES only
       }
     } catch (const Error &e) { codes[t] = e.code; errors[t] = e.text;
@@ -300,7 +301,7 @@ void miso_batch::upload(int dev) {
     d.off_base = in_off; in_off = align_up(in_off + e.base_count.size() * 4, 16);
     d.off_draw = in_off;   // (single-end: the masks' low words, whole quads; from 33 isoforms on the high words behind them)
     in_off = align_up(in_off + (e.paired ? e.draw_frag.size() * 2
-                                         : align_up(e.draw_mask.size(), 4) * 4 * (e.K > 32 ? 2 : 1)), 16);
+                                         : align_up(e.draw_mask.size(), 4) * 4 * ((e.K + 31) / 32)), 16);   // one plane of whole quads per 32 isoforms
     d.n_dcls = static_cast<int32_t>(e.dcls_mask.size());
     d.n_units = e.n_units;
     d.max_cls = e.max_cls_size;
@@ -339,11 +340,15 @@ void miso_batch::upload(int dev) {
     std::memcpy(h_in.data() + d.off_base, e.base_count.data(), e.base_count.size() * 4);
     if (e.paired) std::memcpy(h_in.data() + d.off_draw, e.draw_frag.data(), e.draw_frag.size() * 2);
     else {
-      uint32_t *lo = reinterpret_cast<uint32_t *>(h_in.data() + d.off_draw), *hi = lo + align_up(e.draw_mask.size(), 4);
-      for (size_t r = 0; r < e.draw_mask.size(); r++) {
-        lo[r] = static_cast<uint32_t>(e.draw_mask[r]);
-        if (e.K > 32) hi[r] = static_cast<uint32_t>(e.draw_mask[r] >> 32);
-      }
+      // plane w = bits 32 w .. 32 w + 31 of every draw's mask, each plane whole quads long
+      uint32_t *pl = reinterpret_cast<uint32_t *>(h_in.data() + d.off_draw);
+      const size_t npad = align_up(e.draw_mask.size(), 4), nd = e.draw_mask.size();
+      const int W32 = (e.K + 31) / 32, Wx = (e.K + 63) / 64 - 1;
+      for (size_t r = 0; r < nd; r++)
+        for (int w = 0; w < W32; w++) {
+          const uint64_t word = (w < 2) ? e.draw_mask[r] : e.draw_mask_x[r * Wx + (w >> 1) - 1];
+          pl[npad * w + r] = static_cast<uint32_t>(word >> (32 * (w & 1)));
+        }
     }
     if (!e.unit_desc.empty()) std::memcpy(h_in.data() + d.off_units, e.unit_desc.data(), e.unit_desc.size() * 4);
     if (!e.dcls_tab.empty()) {
@@ -416,7 +421,8 @@ void miso_batch::upload(int dev) {
   // quads.  Thresholds measured: profiles/r03_pe_buckets.txt.  MISO_NO_PE_BUCKETS=1: one launch per class as before
   // (A/B, tests); MISO_PE_T_WAVE / MISO_PE_T_WIDE: the two thresholds (experiments, tests).
   // (64: 33 ... MISO_MAX_ISOFORMS isoforms -- sampler_wave only, lane k = isoform k; the reference has no limit, miso.c:696)
-  auto kc_of = [](int K) { return K <= 4 ? 4 : (K <= 8 ? 8 : (K <= 12 ? 12 : (K <= 16 ? 16 : (K <= 32 ? 32 : 64)))); };
+  // (256: 65 ... MISO_MAX_ISOFORMS isoforms -- sampler_big, the chain's vectors in LDS, kernels_big.hip)
+  auto kc_of = [](int K) { return K <= 4 ? 4 : (K <= 8 ? 8 : (K <= 12 ? 12 : (K <= 16 ? 16 : (K <= 32 ? 32 : (K <= 64 ? 64 : 256))))); };
   std::vector<int> bucket(n, 0);   // 0 normal, 1 at least 32 lanes, 2 a wavefront, 3 workgroup-wide (coop_n[event] workgroups)
   coop_n.assign(n, 1);
   if (p.paired && std::getenv("MISO_NO_PE_BUCKETS") == nullptr) {
@@ -699,6 +705,16 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       default: MISO_GRP_WAVE64(32) break;
       }
 #undef MISO_GRP_WAVE64
+    } else if (G == 64 && run.kc > 64) {   // 65 ... MISO_MAX_ISOFORMS isoforms: one wavefront = one workgroup per chain, vectors in LDS (kernels_big.hip)
+      const unsigned grid = static_cast<unsigned>(chains);
+      const size_t lds = fp_bytes + static_cast<size_t>(run.kmax) * (11 * sizeof(double) + 2 * sizeof(int));
+      if (p.paired) {
+        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sampler_big<true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        hipLaunchKernelGGL(sampler_big<true>, dim3(grid), dim3(64), lds, st, ka);
+      } else {
+        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sampler_big<false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        hipLaunchKernelGGL(sampler_big<false>, dim3(grid), dim3(64), lds, st, ka);
+      }
     } else if (G == 64) {
       const unsigned grid = static_cast<unsigned>((chains + 3) / 4);
       const size_t lds = fp_bytes + 4 * 64 * sizeof(int);
@@ -826,12 +842,12 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   // (level 2 only: with the classes of a five- or ten-isoform event sharing ~1000 reads the chains of small binomials
   // cost more than the read sweep they replace -- profiles/r03_collapsed.txt; it pays from ~10^4 reads per event)
   bool lane_gen = collapsed && collapsed_level >= 2 && !p.paired && n_gen > 0;
-  for (const GenRun &run : gen_runs) if (run.nocls || run.kc == 64) lane_gen = false;   // (33 - 64 isoforms: two-word masks, sampler_wave only)
+  for (const GenRun &run : gen_runs) if (run.nocls || run.kc >= 64) lane_gen = false;   // (33 isoforms and more: several mask words, sampler_wave / sampler_big only)
   std::vector<int> flat_nc(gen_runs.size(), 0), flat_nc_max(gen_runs.size(), 0);
   for (size_t ri = 0; ri < gen_runs.size(); ri++) {
     const GenRun &run = gen_runs[ri];
     if (lane_gen) break;
-    if (p.paired || run.nocls || run.kc == 64 || std::getenv("MISO_NO_FLAT") != nullptr) continue;
+    if (p.paired || run.nocls || run.kc >= 64 || std::getenv("MISO_NO_FLAT") != nullptr) continue;
     const int slice = flat_layout(run.kmax, std::max(run.maxcls, 1)).bytes;
     // workgroups per CU the chains per wavefront are sized for: kernels_flat.inl's register budgets -- 3 up to four isoforms
     // and for nine to twelve (measured round 4, profiles/r04_occupancy.txt), 2 otherwise (five to eight isoforms: the kernel
@@ -980,7 +996,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   for (size_t ri = 0; ri < gen_runs.size(); ri++) {
     GenRun &run = gen_runs[ri];
     if (lane_gen) break;
-    if (run.kc == 64) { flat_nc[ri] = 0; grp_G[ri] = 64; grp_sh[ri] = GrpShape{0, 0}; continue; }   // more than 32 isoforms: one wavefront per chain
+    if (run.kc >= 64) { flat_nc[ri] = 0; grp_G[ri] = 64; grp_sh[ri] = GrpShape{0, 0}; continue; }   // more than 32 isoforms: one wavefront per chain
     // sampler_flat or sampler_grp?  Measured on the batch's first launch like the lanes per chain below
     // (flat wins at every isoform count of profiles/r02_flat_vs_grp_sweep.txt but 5); a small or untuned
     // batch takes sampler_flat.
@@ -1494,7 +1510,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     }
     const std::string name = (ri < run_in_multi.size() && run_in_multi[ri]) ? "sampler_grp_multi<" + std::to_string(run.kc) + ">" :
                              run.wide ? "sampler_grp<64, true, " + std::to_string(run.kc) + ", true>" :
-                             flat ? flat_name(run) : ((G == 64 && !w64) ? std::string("sampler_wave<") : "sampler_grp<" + std::to_string(G) + ", ") +
+                             flat ? flat_name(run) : ((G == 64 && !w64) ? std::string(run.kc > 64 ? "sampler_big<" : "sampler_wave<") : "sampler_grp<" + std::to_string(G) + ", ") +
                              (p.paired ? "true" : "false") + ((G == 64 && !w64) ? std::string(">") : ", " + std::to_string(run.kc) + ">");
     add_stat(name, static_cast<double>(waves), trips, static_cast<double>(chains), words);
   }
@@ -1562,7 +1578,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     }
     last_kernels += std::string(last_kernels.empty() ? "" : ",") +
                     (run.wide ? "sampler_grp<64, true, " + std::to_string(run.kc) + ", true>"
-                              : (wave_k ? std::string("sampler_wave<")
+                              : (wave_k ? std::string(run.kc > 64 ? "sampler_big<" : "sampler_wave<")
                                         : "sampler_grp<" + std::to_string(G) + ", ") +
                                     (p.paired ? "true" : "false") +
                                     (wave_k ? std::string(">") : ", " + std::to_string(run.kc) + ">"));
@@ -1684,7 +1700,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     if (lane_route) {   // collapsed single-end batch: one chain per lane, no read loop (kernels_lane.hip)
       KernelArgs ka = a;
       ka.slot_event = d_slots; ka.n_slots = n_k2; ka.pair_waves = 0;
-      ka.logfact = d_logfact;
+      ka.logfact = d_logfact; ka.tstride = logfact_n;   // (tstride: the table's entries, for sampler_lane_ilp's LDS copy)
       const long chains = static_cast<long>(n_k2) * p.noChains;
       const int G = lane_G;
       lanes_per_chain = G;

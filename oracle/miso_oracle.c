@@ -788,7 +788,7 @@ static void propose(orc_state_t *S, uint32_t iter, const double *alpha, double *
 
 /* miso.c:11-91 (single-end, weights psi_k) and miso_paired.c:11-86 (weights psi_k*match) */
 static int draw_read(const orc_state_t *S, const double *col, const double *psi, double u) {
-  double cum[64]; int valid[64]; int nv = 0, j, w;
+  double cum[ORC_MAXK]; int valid[ORC_MAXK]; int nv = 0, j, w;
   double sumpsi = 0.0, rnd;
   for (j = 0; j < S->K; j++) {
     if (col[j] != 0) {
@@ -857,8 +857,8 @@ static void reassign_collapsed(orc_state_t *S, uint32_t iter) {
     miso_ustream_init(&us, S->opts->seed, S->opts->event_id, (uint32_t) k, iter, MISO_SITE_COUNTS);
     while (ii < N) {
       const double *col = S->match + (size_t) S->corder[ii] * K;
-      int jj = ii + 1, n, nv = 0, valid[64], j, w;
-      double suffix[64];
+      int jj = ii + 1, n, nv = 0, valid[ORC_MAXK], j, w;
+      double suffix[ORC_MAXK];
       while (jj < N) {
         const double *c2 = S->match + (size_t) S->corder[jj] * K;
         int same = 1;
@@ -952,8 +952,8 @@ static double ldirichlet(const orc_state_t *S, const double *x) {
 static double score_joint(const orc_state_t *S, int chain, const double *psi) {
   int K = S->K, N = S->N, i;
   const int *ass = S->ass + (size_t) chain * N;
-  double logpsi[64] = { 0 }, maxv, sum, readProb = 0.0, assProb = 0.0;
-  int32_t cnt[64];
+  double logpsi[ORC_MAXK] = { 0 }, maxv, sum, readProb = 0.0, assProb = 0.0;
+  int32_t cnt[ORC_MAXK];
   if (S->marginal && S->amat) { /* miso.c:284-295: the gene's classes, reads per class */
     int c, k;
     for (c = 0; c < S->ncls_a; c++) {
@@ -1053,7 +1053,7 @@ static void run_chains(orc_state_t *S, int noIterations, int noBurnIn, int noLag
   double *acceptP = malloc(sizeof(double) * C), *cJS = malloc(sizeof(double) * C),
          *pJS = malloc(sizeof(double) * C);
   uint64_t *hash = malloc(sizeof(uint64_t) * C);
-  int32_t cnt[64];
+  int32_t cnt[ORC_MAXK];
   for (j = 0; j < C; j++) { hash[j] = 0xCBF29CE484222325ull; cJS[j] = 0; if (trace && trace->accepted) trace->accepted[j] = 0; }
 
   for (m = 0; m < noIterations; m++) {
@@ -1242,7 +1242,7 @@ static int check_common(const orc_gene_t *g, int *overHang, int readLength, int 
   if (stop == 1 && noChains == 1) return ORC_EINVAL; /* miso.c:708-711 */
   if (stop != 0 && stop != 1) return ORC_EINVAL;
   if (noLag < 1 || noIterations < noBurnIn || noBurnIn < 0) return ORC_EINVAL;
-  if (g->K < 2 || g->K > 64) return ORC_EINVAL;
+  if (g->K < 2 || g->K > ORC_MAXK) return ORC_EINVAL;
   return ORC_SUCCESS;
 }
 

@@ -23,6 +23,8 @@ extern "C" {
 #endif
 
 /* error codes = the reference's (include/splicing_error.h:314-351) */
+/* most isoforms a gene may have here (fixed-size scratch in the restatement; the reference has no limit, miso.c:696) */
+#define ORC_MAXK 256
 #define ORC_SUCCESS 0
 #define ORC_FAILURE 1
 #define ORC_ENOMEM 2

@@ -402,15 +402,15 @@ print(repr(got))
 
 def test_one_bad_gene_does_not_cost_the_batch_its_other_genes(bam_path, capsys):
     """run_miso.py:205-256 runs every gene in its own try block; prepare_batch must do the same inside one GPU batch:
-    a gene with more isoforms than the kernels hold (66 > MISO_MAX_ISOFORMS = 64), a gene whose reads carry a malformed CIGAR and a gene that
+    a gene with more isoforms than the kernels hold (258 > MISO_MAX_ISOFORMS = 256), a gene whose reads carry a malformed CIGAR and a gene that
     fails inside the batched native add are reported and skipped, every other gene stays in the batch."""
     import miso_sampler as miso
     from miso_sampler import AlnRegion, SimpleGene
     params = miso.get_single_end_sampler_params(2, 36, 1)
     sampler = miso.MISOSampler(params, paired_end=False)
     good = SimpleGene([(1, 100), (201, 300), (401, 500)], [[0, 1, 2], [0, 2]], label="good")
-    wide_exons = [(1 + 200 * i, 100 + 200 * i) for i in range(68)]
-    too_many = SimpleGene(wide_exons, [[0, 67]] + [[0, k, 67] for k in range(1, 66)], label="sixty-six-isoforms")
+    wide_exons = [(1 + 200 * i, 100 + 200 * i) for i in range(260)]
+    too_many = SimpleGene(wide_exons, [[0, 259]] + [[0, k, 259] for k in range(1, 258)], label="sixty-six-isoforms")
     ok_reads = ([10, 220, 60], ["36M", "36M", "36M"])
     bad_reads = ([10, 220], ["36M", "3x6M"])
     gene_obj = gene_utils.load_genes_from_gff(GFF, suppress_warnings=True)["ENSMUSG00000019943"]["gene_object"]

@@ -196,11 +196,11 @@ def test_large_event_and_thirty_two_isoforms(orc):
     cpu32 = orc.miso(g32, pos32, cig32, 36, iters=60, burn=10, lag=1, chains=1, mode=OrcLib.COUNTER,
                      seed=3, event_id=1, trace=True)
     _compare(b.result(1, trace=True), cpu32, 1)
-    with pytest.raises(NotImplementedError, match="More than 64 isoforms"):
-        e65, i65 = _problems.se_gene(65, exlen=60, gap=50)
-        miso_amd.Batch(36).add_event(miso_amd.Gene(e65, i65), pos32[:5], cig32[:5])
-    with pytest.raises(NotImplementedError, match="More than 64 isoforms"):
-        miso_amd.Batch(36, device_match=True).add_event(miso_amd.Gene(e65, i65), pos32[:5], cig32[:5])
+    with pytest.raises(NotImplementedError, match="More than 256 isoforms"):
+        e257, i257 = _problems.se_gene(257, exlen=60, gap=50)
+        miso_amd.Batch(36).add_event(miso_amd.Gene(e257, i257), pos32[:5], cig32[:5])
+    with pytest.raises(NotImplementedError, match="More than 256 isoforms"):
+        miso_amd.Batch(36, device_match=True).add_event(miso_amd.Gene(e257, i257), pos32[:5], cig32[:5])
 
 
 @pytest.mark.parametrize("K,paired,device_match", [(33, False, False), (33, False, True), (48, False, True), (64, False, True),
@@ -231,6 +231,42 @@ def test_more_than_thirty_two_isoforms_bit_exact(orc, K, paired, device_match):
             cpu = orc.miso(g, pos, cig, 36, mode=OrcLib.COUNTER, seed=SEED, event_id=40 + i, trace=True, **kw)
         assert cpu.rc == 0
         _compare(b.result(i, trace=True), cpu, 2)
+        if device_match and i == 0:   # what the match kernel wrote for the wide gene = the oracle's match matrix
+            m, fl = b.device_match_of(0)
+            assert np.array_equal(m != 0, cpu.match != 0)
+
+
+@pytest.mark.parametrize("K,paired,device_match", [(65, False, False), (65, False, True), (100, False, True), (200, False, False),
+                                                   (256, False, True), (65, True, True), (100, True, False), (200, True, True)])
+def test_more_than_sixty_four_isoforms_bit_exact(orc, K, paired, device_match):
+    """Genes of 65 ... 256 isoforms (the reference has no limit, miso.c:696, gff.c:684; rounds 1 - 4 stopped at 64): a read's
+    compatibility mask has (K + 31) / 32 words -- host packing, the match kernel, the upload's planes -- and the chain's vectors
+    live in LDS (sampler_big, kernels_big.hip).  Host and device matching, single- and paired-end, in a batch with smaller
+    genes (one of them of 40 isoforms: sampler_wave beside it); every output against the oracle's counter mode, the read
+    classes against the oracle's (= the real reference's, tests/test_host_logic.py)."""
+    kw = dict(iters=40, burn=10, lag=2, chains=2)
+    evs = []
+    for j, (k, n) in enumerate([(K, 500), (5, 300), (K, 70), (40, 200), (K, 0)]):
+        if paired:
+            exons, isoforms, g, pos, cig = simulate_pe(orc, k, max(n, 1), seed=800 + j, exlen=420, gap=250)
+        else:
+            exons, isoforms, g, pos, cig = simulate_se(orc, k, max(n, 1), seed=800 + j, exlen=60, gap=50)
+        evs.append((exons, isoforms, g, pos[:(2 * n if paired else n)], cig[:(2 * n if paired else n)]))
+    b = miso_amd.Batch(36, paired=paired, mean=250.0 if paired else 0.0, var=900.0 if paired else 0.0, counts_trace=True,
+                       device_match=device_match, **kw)
+    for exons, isoforms, g, pos, cig in evs:
+        b.add_event(miso_amd.Gene(exons, isoforms), pos, cig)
+    b.run(seed=SEED, first_event_id=90)
+    assert "sampler_big" in b.last_kernels() and "sampler_wave" in b.last_kernels(), b.last_kernels()
+    for i, (exons, isoforms, g, pos, cig) in enumerate(evs):
+        if paired:
+            cpu = orc.miso_paired(g, pos, cig, 36, 250.0, 900.0, mode=OrcLib.COUNTER, seed=SEED, event_id=90 + i, trace=True, **kw)
+        else:
+            cpu = orc.miso(g, pos, cig, 36, mode=OrcLib.COUNTER, seed=SEED, event_id=90 + i, trace=True, **kw)
+        assert cpu.rc == 0
+        _compare(b.result(i, trace=True), cpu, 2)
+        ct, cc = b.classes(i)
+        assert np.array_equal(ct, cpu.class_templates) and np.array_equal(cc, cpu.class_counts)
         if device_match and i == 0:   # what the match kernel wrote for the wide gene = the oracle's match matrix
             m, fl = b.device_match_of(0)
             assert np.array_equal(m != 0, cpu.match != 0)

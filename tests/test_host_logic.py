@@ -163,11 +163,11 @@ def test_add_problem_rejects_fragment_lengths_outside_the_distribution():
     assert b.add_problem(m2, [1000, 900], [3, 2], fraglen=fl) == 0
 
 
-@pytest.mark.parametrize("K,paired", [(33, False), (64, False), (40, True)])
+@pytest.mark.parametrize("K,paired", [(33, False), (64, False), (40, True), (65, False), (130, False), (256, False), (100, True), (200, True)])
 def test_read_classes_of_genes_with_more_than_32_isoforms(orc, ref, K, paired):
-    """Host packing with two-word compatibility masks (33 ... 64 isoforms; the reference has no limit, miso.c:696,
+    """Host packing with compatibility masks of several words (33 ... 256 isoforms; the reference has no limit, miso.c:696,
     gff.c:684): the read classes the header reports equal the REAL reference's (miso.c:762, miso_paired.c:386-391 through
-    oracle/_ref), 65 isoforms are refused."""
+    oracle/_ref), 257 isoforms are refused."""
     from _problems import se_gene, expr_for, flat
     exons, isoforms = se_gene(K, exlen=420 if paired else 60, gap=250 if paired else 50)
     g = ref.gene(flat(exons), isoforms)
@@ -183,9 +183,9 @@ def test_read_classes_of_genes_with_more_than_32_isoforms(orc, ref, K, paired):
     i = b.add_event(miso_amd.Gene(exons, isoforms), pos, cig)
     ct, cc = b.classes(i)
     assert np.array_equal(ct, r.class_templates) and np.array_equal(cc, r.class_counts)
-    e65, i65 = se_gene(65, exlen=60, gap=50)
-    with pytest.raises(NotImplementedError, match="More than 64 isoforms"):
-        miso_amd.Batch(36).add_event(miso_amd.Gene(e65, i65), pos[:4], cig[:4])
+    e257, i257 = se_gene(257, exlen=60, gap=50)
+    with pytest.raises(NotImplementedError, match="More than 256 isoforms"):
+        miso_amd.Batch(36).add_event(miso_amd.Gene(e257, i257), pos[:4], cig[:4])
 
 
 def test_convergent_mean_rule_matches_the_checker_and_the_reference(orc):
