@@ -267,11 +267,43 @@ __device__ __attribute__((noinline)) void flat_units_desc(const FlatUnitsArgs A,
   int D[TW];
 #pragma unroll
   for (int j = 0; j < TW; j++) D[j] = 0;
+#ifndef MISO_FLAT_ASM_PREFETCH
+#define MISO_FLAT_ASM_PREFETCH 1
+#endif
   uint32_t dn[UQ];   // the next trip's descriptors (0 = no unit: no word counts)
+#if MISO_FLAT_ASM_PREFETCH
+  // The descriptors are fetched one trip ahead -- and until round 5 were waited for at once: `desc` is a generic pointer in
+  // this (non-inlined) function, a flat_load may return out of order with anything, so the compiler put s_waitcnt vmcnt(0)
+  // lgkmcnt(0) between the prefetch it had just issued and the first use of the CURRENT descriptors -- a global-memory round
+  // trip per trip, 0.43 of a wavefront's cycles in SQ_WAIT_ANY (profiles/r05_wait_counters.txt).  Now the load is a
+  // global_load the compiler does not see, issued at the TOP of a trip, and the wait is written out at the trip's END, in
+  // front of the loop's register copies (the compiler inserts no wait for a load it does not see: the values must have
+  // landed before anything may move them) -- by then the load is a whole trip old.  (Clamped index instead of a branch; the
+  // value of a lane without a unit is zeroed behind the wait.)
+  auto prefetch = [&](int b, int u) __attribute__((always_inline)) {
+    const uint32_t *ptr = desc + max(min(u, nu - 1), 0);
+    asm volatile("global_load_dword %0, %1, off" : "=v"(dn[b]) : "v"(ptr) : "memory");
+  };
+  auto arrive = [&]() __attribute__((always_inline)) {
+    if constexpr (UQ == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(dn[0]) : : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(dn[0]), "+v"(dn[UQ - 1]) : : "memory");
+  };
+  static_assert(UQ <= 2, "arrive() names the first and the last descriptor register");
+#pragma unroll
+  for (int b = 0; b < UQ; b++) prefetch(b, r + b * g);
+  arrive();
+#else
 #pragma unroll
   for (int b = 0; b < UQ; b++) { const int u = r + b * g; dn[b] = (u < nu) ? desc[u] : 0u; }
+#endif
   for (int u0 = r; __any(u0 < nu); u0 += UQ * g) {
     uint32_t d[UQ];
+#if MISO_FLAT_ASM_PREFETCH
+#pragma unroll
+    for (int b = 0; b < UQ; b++) d[b] = (nu > 0 && u0 + b * g < nu) ? dn[b] : 0u;
+#pragma unroll
+    for (int b = 0; b < UQ; b++) prefetch(b, u0 + (UQ + b) * g);
+#else
 #pragma unroll
     for (int b = 0; b < UQ; b++) {
       d[b] = dn[b];
@@ -279,6 +311,7 @@ __device__ __attribute__((noinline)) void flat_units_desc(const FlatUnitsArgs A,
       dn[b] = (un < nu) ? desc[un] : 0u;   // (measured at K=5: this generic-pointer load under a branch 93.7k events/s; an
                                            //  address-space-1 pointer 87.1k; that plus a clamped, branch-free load 91.1k)
     }
+#endif
     uint32_t T[UQ][TW], w[UQ][4];
     // (tried round 4: the chains' whole units first and a trip without word masks when every lane's units are whole -- two
     // instructions per word fewer on paper, no gain measured: profiles/r04_occupancy.txt)
@@ -297,6 +330,9 @@ __device__ __attribute__((noinline)) void flat_units_desc(const FlatUnitsArgs A,
 #pragma unroll
       for (int b = 0; b < UQ; b++) count_below(D[j], w[b][0], w[b][1], w[b][2], w[b][3], T[b][j]);
     }
+#if MISO_FLAT_ASM_PREFETCH
+    arrive();   // the next trip's descriptors: issued at this trip's top
+#endif
   }
   int *dl = reinterpret_cast<int *>(wbase + sl + off_dl);
 #pragma unroll

@@ -616,9 +616,20 @@ __device__ __forceinline__ void pe_dense(const uint32_t *fq, const double *psi, 
 #pragma unroll
     for (int i = 0; i < ND; i++) r[i] = src[i];
   };
-  // the scores of a quad's four picks are fetched when the picks are known and added one trip later: nothing
-  // in the loop waits for a gather it has just issued (the last read's score used to be waited for right away,
-  // and with it -- the counter is in order -- the next quad's records)
+  // The scores of a quad's four picks come from the event's table in global memory (a 64-byte line per pick).  Round 2 issued
+  // the gathers when the picks were known -- at the END of the trip -- and added them one trip later, so that "nothing in the
+  // loop waits for a gather it has just issued".  It did: the loop's header waits for vmcnt(0) (the next quad's records must
+  // be there, and across the back edge the compiler counts conservatively), i.e. for the four gathers issued twenty
+  // instructions earlier -- a full L2 / infinity-cache round trip per trip, the 0.43 of a wavefront's cycles that
+  // SQ_WAIT_ANY shows (profiles/r05_wait_counters.txt).  Round 5 (MISO_PE_LATE_GATHER): a quad's gathers are issued at the
+  // TOP of the NEXT trip, beside that trip's record loads, and added at the top of the trip after: whatever is outstanding
+  // at the header is a whole trip old.  Four registers (the picks' table offsets) live across the back edge.
+  // Up to MISO_PE_LATE_UPTO isoforms (same box, 7500 iterations: K = 5 948 -> 880 ms; K = 8 1079 -> 1105, K = 10 704 -> 724,
+  // K = 16 1039 -> 1052 ms: from eight isoforms on the four registers cost more than the wait, profiles/r05_pe_late_gather.txt).
+#ifndef MISO_PE_LATE_UPTO
+#define MISO_PE_LATE_UPTO 6
+#endif
+#define MISO_PE_LATE_GATHER (KK <= MISO_PE_LATE_UPTO)
   int32_t pend[4] = {0, 0, 0, 0};
   auto settle = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -639,7 +650,13 @@ __device__ __forceinline__ void pe_dense(const uint32_t *fq, const double *psi, 
     }
   };
   const uint32_t neutral = static_cast<uint32_t>(il2 - 1);        // PE_ONE of isoform 0: score 0
+  uint32_t fsp[4] = {neutral, neutral, neutral, neutral};         // the previous quad's picks (table offsets), scores not yet fetched
   auto process = [&](const uint32_t (&cur)[ND], int q) __attribute__((always_inline)) {
+    if constexpr (!STAB_LDS && MISO_PE_LATE_GATHER) {
+      settle();                                                   // the quad before the previous one: fetched a trip ago
+#pragma unroll
+      for (int j = 0; j < 4; j++) pend[j] = score(fsp[j]);        // the previous quad's
+    }
     const miso_u32x4 u = philox_gibbs<true>(rng, static_cast<uint32_t>(q), n0r0);
     const uint32_t flags = cur[KK];
     bool okj[4];
@@ -683,10 +700,15 @@ __device__ __forceinline__ void pe_dense(const uint32_t *fq, const double *psi, 
       }
       fs[j] = BADCHK ? (ok ? fsel : neutral) : fsel;
     }
-    if constexpr (!STAB_LDS) settle();   // the previous quad's
+    if constexpr (!STAB_LDS && MISO_PE_LATE_GATHER) {
 #pragma unroll
-    for (int j = 0; j < 4; j++) pend[j] = score(fs[j]);
-    if constexpr (STAB_LDS) settle();    // an LDS read is not worth the four registers across the trip (K = 3, 4: -4 %)
+      for (int j = 0; j < 4; j++) fsp[j] = fs[j];
+    } else {
+      if constexpr (!STAB_LDS) settle();   // the previous quad's
+#pragma unroll
+      for (int j = 0; j < 4; j++) pend[j] = score(fs[j]);
+      if constexpr (STAB_LDS) settle();    // an LDS read is not worth the four registers across the trip (K = 3, 4: -4 %)
+    }
     const bool okq = okj[0] & okj[1] & okj[2] & okj[3];
     if (__builtin_expect(__any(!okq), 0)) {
 #pragma unroll 1
@@ -735,7 +757,12 @@ __device__ __forceinline__ void pe_dense(const uint32_t *fq, const double *psi, 
       process(cur, q0 + sub);
     }
   }
-  if constexpr (!STAB_LDS) settle();   // the last quad's
+  if constexpr (!STAB_LDS && MISO_PE_LATE_GATHER) {   // drain: the last but one quad's scores, then the last quad's
+    settle();
+#pragma unroll
+    for (int j = 0; j < 4; j++) pend[j] = score(fsp[j]);
+    settle();
+  } else if constexpr (!STAB_LDS) settle();   // the last quad's
 #pragma unroll
   for (int k = 0; k < KK - 1; k++) if (over[k]) atomicAdd(&dl[k], over[k]);
   acc_out = acc; bad_out = bad;
