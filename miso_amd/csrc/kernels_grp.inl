@@ -29,6 +29,7 @@
 //     accumulated in 2^-26 fixed point and reduced over the lanes.
 // Same arithmetic, same order, same RNG addresses as sampler_wave and the CPU checker.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include "device.hpp"
 #include "miso_amd.h"
@@ -630,6 +631,9 @@ __device__ __forceinline__ void pe_dense(const uint32_t *fq, const double *psi, 
 #define MISO_PE_LATE_UPTO 6
 #endif
 #define MISO_PE_LATE_GATHER (KK <= MISO_PE_LATE_UPTO)
+#ifndef MISO_PE_ASM_RECORDS
+#define MISO_PE_ASM_RECORDS 1
+#endif
   int32_t pend[4] = {0, 0, 0, 0};
   auto settle = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -743,6 +747,46 @@ __device__ __forceinline__ void pe_dense(const uint32_t *fq, const double *psi, 
       load(A, q + 2 * G);
       if (q0 + G < nqw) process(B, q + G);
       q += 2 * G;
+    }
+  } else if constexpr (!STAB_LDS && !MISO_PE_LATE_GATHER && MISO_PE_ASM_RECORDS) {
+    // From seven isoforms on (round 5): the NEXT quad's records are fetched by global loads the compiler does not see,
+    // issued at the top of the trip and waited for -- written out -- at its end with vmcnt(4): the records have landed (they
+    // are a trip old), the four score gathers issued just before may stay in flight.  The compiler then has no reason to put
+    // vmcnt(0) at the loop's header (it did: the record registers were copied there), and the gathers are waited for where
+    // they are added, a trip later.  (The late gather above does the same with four more registers across the back edge; here
+    // they are not to be had.)  Every younger memory operation than the records -- the gathers, a spill, the cold path's loads
+    // -- only makes vmcnt(4) wait longer: never too short.
+    constexpr int NQ = ND / 4, NR = ND % 4;   // pieces: NQ x 16 bytes, then 8 and / or 4
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+    u32x4_t r4[NQ > 0 ? NQ : 1]; u32x2_t r2 = {0u, 0u}; uint32_t r1 = 0u;
+    auto issue = [&](int q) __attribute__((always_inline)) {
+      const uint32_t *src = fq + static_cast<uint32_t>(min(q, n_quads)) * static_cast<uint32_t>(ND);
+#pragma unroll
+      for (int i = 0; i < NQ; i++) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r4[i]) : "v"(src + 4 * i) : "memory");
+      if constexpr (NR >= 2) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(r2) : "v"(src + 4 * NQ) : "memory");
+      if constexpr (NR & 1) asm volatile("global_load_dword %0, %1, off" : "=v"(r1) : "v"(src + 4 * NQ + (NR & 2)) : "memory");
+    };
+    auto landed = [&](auto cnt) __attribute__((always_inline)) {
+      // (every piece is named: nothing may read or move it before this point)
+#pragma unroll
+      for (int i = 0; i < NQ; i++) asm volatile("" : "+v"(r4[i]) : : "memory");
+      if constexpr (decltype(cnt)::value == 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(r2), "+v"(r1) : : "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" : "+v"(r2), "+v"(r1) : : "memory");
+#pragma unroll
+      for (int i = 0; i < NQ; i++) asm volatile("" : "+v"(r4[i]) : : "memory");
+    };
+    issue(sub);
+    landed(std::integral_constant<int, 0>{});
+    for (int q0 = 0; q0 < nqw; q0 += G) {
+      uint32_t cur[ND];
+#pragma unroll
+      for (int i = 0; i < 4 * NQ; i++) cur[i] = r4[i >> 2][i & 3];
+      if constexpr (NR >= 2) { cur[4 * NQ] = r2[0]; cur[4 * NQ + 1] = r2[1]; }
+      if constexpr (NR & 1) cur[ND - 1] = r1;
+      issue(q0 + sub + G);
+      process(cur, q0 + sub);
+      landed(std::integral_constant<int, 4>{});
     }
   } else {
     // wider records: one loop body, the next quad fetched into a second set of registers and copied over

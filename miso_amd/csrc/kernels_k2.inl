@@ -857,33 +857,25 @@ __device__ __forceinline__ void k2_body(const KernelArgs &a, unsigned block_x, u
     PROF_T(m1);
     PROF_ADD(pf_mh, m0, m1);
 
-#ifndef MISO_K2_STORE_AFTER
-#define MISO_K2_STORE_AFTER 0   // 1: the iteration's sample leaves after the Gibbs step's loads -- measured, round 5: no gain paired-end (198.4 vs 199.4 ms), 4 % slower at MISO's default settings (profiles/r05_store_after.txt); 0: before
-#endif
-    // miso.c:882-893.  (MISO_K2_STORE_AFTER: the stores issued behind the Gibbs step -- vmcnt counts loads and stores in
-    // order, so a load issued after a store is only "there" once the store has been acknowledged.  Tried; not the wait.)
-    bool rec = false; size_t rec_col = 0;
+    // miso.c:882-893.  (Round 5 tried issuing these stores BEHIND the Gibbs step -- vmcnt counts loads and stores in order,
+    // so a load issued after a store is only "there" once the store has been acknowledged: no gain paired-end (198.4 vs
+    // 199.4 ms), 4 % slower at MISO's default settings, profiles/r05_store_after.txt.)
     if (m >= a.B) {
       if (lagCounter == a.lag - 1) {
-        rec = writer; rec_col = static_cast<size_t>(noS) + chain;
+        if (writer) {
+          const size_t col = static_cast<size_t>(noS) + chain;
+          *reinterpret_cast<double2 *>(samples + col * 2) = make_double2(cur.x0, cur.x1);
+          loglik[col] = cJS;
+        }
         noS += a.C;
         lagCounter = 0;
       } else {
         lagCounter++;
       }
     }
-    const double rx0 = cur.x0, rx1 = cur.x1;
-    if (!MISO_K2_STORE_AFTER && rec) {
-      *reinterpret_cast<double2 *>(samples + rec_col * 2) = make_double2(rx0, rx1);
-      loglik[rec_col] = cJS;
-    }
     PROF_T(m2);
     PROF_ADD(pf_rec, m1, m2);
     gibbs(static_cast<uint32_t>(m));
-    if (MISO_K2_STORE_AFTER && rec) {
-      *reinterpret_cast<double2 *>(samples + rec_col * 2) = make_double2(rx0, rx1);
-      loglik[rec_col] = cJS;
-    }
   }
 #ifdef MISO_K2_PROFILE
   if (writer && chain == 0 && a.M > 8) {  // smuggle the phase cycle counts out through the log scores
