@@ -634,6 +634,9 @@ __device__ __forceinline__ void pe_dense(const uint32_t *fq, const double *psi, 
 #ifndef MISO_PE_ASM_RECORDS
 #define MISO_PE_ASM_RECORDS 1
 #endif
+#ifndef MISO_PE_ASM_RECORDS_UPTO
+#define MISO_PE_ASM_RECORDS_UPTO 8
+#endif
   int32_t pend[4] = {0, 0, 0, 0};
   auto settle = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -748,8 +751,10 @@ __device__ __forceinline__ void pe_dense(const uint32_t *fq, const double *psi, 
       if (q0 + G < nqw) process(B, q + G);
       q += 2 * G;
     }
-  } else if constexpr (!STAB_LDS && !MISO_PE_LATE_GATHER && MISO_PE_ASM_RECORDS) {
-    // From seven isoforms on (round 5): the NEXT quad's records are fetched by global loads the compiler does not see,
+  } else if constexpr (!STAB_LDS && !MISO_PE_LATE_GATHER && MISO_PE_ASM_RECORDS && KK <= MISO_PE_ASM_RECORDS_UPTO) {
+    // Seven and eight isoforms (round 5; same box: K = 7 1112 -> 991 ms, K = 8 1080 -> 1064; K = 10 702 -> 728, K = 16 1051 ->
+    // 1106 ms: beyond eight the long unrolled body schedules worse around the fixed waits than the compiler's own, and the
+    // header's wait stays): the NEXT quad's records are fetched by global loads the compiler does not see,
     // issued at the top of the trip and waited for -- written out -- at its end with vmcnt(4): the records have landed (they
     // are a trip old), the four score gathers issued just before may stay in flight.  The compiler then has no reason to put
     // vmcnt(0) at the loop's header (it did: the record registers were copied there), and the gathers are waited for where

@@ -403,24 +403,12 @@ void miso_batch::upload(int dev) {
   for (int i = 0; i < n; i++) ((events[i].K == 2 && !k2_general) ? k2 : gen).push_back(i);
   // (paired-end: the events sampler_k2's MODE 2 can take come first, MISO_NO_PE_DELTA=1 sends all to MODE 1)
   use_delta = std::getenv("MISO_NO_PE_DELTA") == nullptr;   // fixed here: the slot order depends on it
-  // Collapsed single-end batches (sampler_lane: 64 chains per wavefront, every lane pays for every path any lane takes): the
-  // binomial has two regimes (include/miso_binomial.h: inversion below n min(p, q) = 10, BTRS above), and a wavefront that
-  // holds chains of both runs both every step -- those wavefronts set the launch's duration (3000 reads per event, all
-  // BTRS: 42 ms; 1000 reads: 50 ms, profiles/r05_sampler_lane_ilp.txt).  The chains likely to be in the inversion regime --
-  // by the drawing reads and the share of the unambiguous reads, a guess that only has to group -- go to the END of the
-  // list, among themselves by drawing reads like everybody else.  (Results do not depend on the order: §2.1.)
-  const bool by_regime = collapsed && !p.paired && std::getenv("MISO_LANE_NO_REGIME_ORDER") == nullptr;
-  auto small_regime = [&](int i) {
-    const PackedEvent &e = events[i];
-    const double b0 = e.base_count.size() > 0 ? e.base_count[0] : 0, b1 = e.base_count.size() > 1 ? e.base_count[1] : 0;
-    const double ph = (b0 + 1.0) / (b0 + b1 + 2.0);
-    return by_regime && e.n_draw * std::min(ph, 1.0 - ph) < 16.0;
-  };
+  // (Round 5 tried ordering a collapsed batch's list by the binomial's likely regime -- inversion below n min(p, q) = 10, BTRS
+  // above: a wavefront that holds chains of both runs both -- and measured nothing once the inversion had lost its division:
+  // 50.3 - 50.8 ms against 50.1 - 50.6 ms, profiles/r05_sampler_lane_ilp.txt.)
   std::stable_sort(k2.begin(), k2.end(), [&](int x, int y) {
     const bool dx = use_delta && events[x].pe_delta && !events[x].draw_dense.empty(), dy = use_delta && events[y].pe_delta && !events[y].draw_dense.empty();
-    if (dx != dy) return dx;
-    const bool sx = small_regime(x), sy = small_regime(y);
-    return sx != sy ? sy : events[x].n_draw > events[y].n_draw; });
+    return dx != dy ? dx : events[x].n_draw > events[y].n_draw; });
   n_k2w = 0;
   for (int i : k2) n_k2w += (use_delta && events[i].pe_delta && !events[i].draw_dense.empty()) ? 1 : 0;
   // the general kernel's wavefronts loop to their largest K and longest draw list: group alike.
