@@ -708,7 +708,19 @@ std::vector<std::pair<uint64_t, double>> gene_classes(const Gene &g, int readLen
   if (g.exstart.empty()) return cls;
   const int gs = *std::min_element(g.exstart.begin(), g.exstart.end()), ge = *std::max_element(g.exend.begin(), g.exend.end());
   std::vector<std::vector<int>> sig(K);
-  for (int p = gs; p <= ge - readLength + 1; p++) {
+  // only positions inside some exon can start a read (the walk used to cover the introns too -- a megabase gene
+  // is mostly intron): the union of the exons as sorted, merged intervals
+  std::vector<std::pair<int, int>> iv;
+  for (size_t i = 0; i < g.exstart.size(); i++) iv.emplace_back(g.exstart[i], g.exend[i]);
+  std::sort(iv.begin(), iv.end());
+  std::vector<std::pair<int, int>> merged;
+  for (const auto &x : iv) {
+    if (!merged.empty() && x.first <= merged.back().second + 1) merged.back().second = std::max(merged.back().second, x.second);
+    else merged.push_back(x);
+  }
+  (void) gs;
+  for (const auto &span : merged)
+  for (int p = span.first; p <= std::min(span.second, ge - readLength + 1); p++) {
     bool any = false;
     for (int k = 0; k < K; k++) {
       sig[k].clear();
