@@ -718,11 +718,13 @@ __device__ __forceinline__ void pe_dense(const uint32_t *fq, const double *psi, 
     }
     const bool okq = okj[0] & okj[1] & okj[2] & okj[3];
     if (__builtin_expect(__any(!okq), 0)) {
+      // (the block's words again: kept alive for this cold path they were spilled to scratch in EVERY trip, 16 bytes per lane)
+      const miso_u32x4 uc = philox_gibbs<true>(rng, static_cast<uint32_t>(q), n0r0);
 #pragma unroll 1
       for (int j = 0; j < 4; j++) {
         if (okj[j]) continue;   // the reference's scan as written
         const uint8_t *rec8 = reinterpret_cast<const uint8_t *>(fq + static_cast<size_t>(min(q, n_quads)) * ND) + j * KK;
-        const int sel = pe_pick_exact(rec8, KK, il2, psi, fp_rep, ((flags >> j) & 1u) == 0, u.v[j]);
+        const int sel = pe_pick_exact(rec8, KK, il2, psi, fp_rep, ((flags >> j) & 1u) == 0, uc.v[j]);
         // what the loop above did with rb = INT64_MIN: passed over the incompatible isoforms in front of the
         // first compatible one (their c is -0.0 = INT64_MIN) and took the score there
         int lead = 0;
