@@ -42,7 +42,7 @@ import subprocess
 import sys
 import time
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before anything initialises HIP (torch in the multi-GPU runs): DESIGN.md 4.3 (iv)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before anything initialises HIP (torch in the multi-GPU runs): docs/history.md 4.3 (iv)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -336,7 +336,7 @@ def load_json(name):
 
 
 def valu_floor(K, paired, draws_per_chain):
-    """VALU wave-instructions one chain-iteration cannot avoid in this formulation: one
+    """VALU wave-instructions one chain-iteration cannot avoid in this formulation (docs/history.md 6.1): one
     Philox4x32 block per four draws -- per EIGHT for single-end two-isoform events -- (4 x (rounds - 1) = 24 at the contract's 7 rounds, round 0 hoisted), per draw K - 1 compare-and-count pairs
     (single-end; paired-end ~15 per read and compatible isoform for weights, compare, select, score gather), and the
     scalar step's 5K + 3 transcendentals at ~55 instructions each if every lane of a wavefront has one to do, plus
@@ -476,7 +476,7 @@ def stream_rows(batch, n_events, sh, first, seed, device):
         out["summary_hbm_frac"] = round(sb / (summary_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         out["compare_hbm_frac"] = round(cb / (compare_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         out["stream_note"] = ("wall time of the whole call (allocation, launch, result copy, host sync) over the algorithmic sample "
-                              "bytes (8 K S per event, twice for the comparison) and 8 TB/s; the kernels alone: DESIGN.md 4.6 / 4.7")
+                              "bytes (8 K S per event, twice for the comparison) and 8 TB/s; the kernels alone: DESIGN.md 4.9")
     return out
 
 

@@ -6,7 +6,7 @@ the reference's Python-facing interface (pysplicing module, misopy/miso_sampler.
 import os as _os
 
 # A batch of whole genes is many kernels side by side; the HIP runtime's default of 4 hardware queues serialises them
-# (DESIGN.md 4.3 (iv)).  The library's constructor sets this too, but the runtime reads it at the process's FIRST HIP
+# (docs/history.md 4.3 (iv)).  The library's constructor sets this too, but the runtime reads it at the process's FIRST HIP
 # call: say it as early as the package is imported, unless the host chose a value.
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 

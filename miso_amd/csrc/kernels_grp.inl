@@ -1517,7 +1517,7 @@ __global__ __launch_bounds__(256, PE ? MISO_GRP_PE_BLOCKS : (KC <= 8 ? MISO_GRP_
 // one chain per workgroup (with the chains on several workgroups in front), per wavefront, on 32 and on 16 lanes --
 // as a.n_segs segments: workgroups [seg_block[s], seg_block[s + 1]), genes (slots) [seg_slot[s], seg_slot[s + 1]) of
 // the launch's list, seg_lanes[s] lanes per chain (K2_WIDE = a workgroup).  One kernel in the hardware queue instead of
-// four, the workgroups start longest chains first across the buckets.
+// four, the workgroups start longest chains first across the buckets (docs/history.md 4.3 (iv)).
 template <int KC>
 __global__ __launch_bounds__(256, MISO_GRP_PE_BLOCKS) void sampler_grp_multi(const KernelArgs a) {
   int s = 0;

@@ -73,7 +73,7 @@ def test_random_mixed_batches_bit_exact(orc, paired, seed):
 
 @pytest.mark.parametrize("level,seed", [(1, 11), (2, 12), (2, 13)])
 def test_random_mixed_batches_collapsed_bit_exact(orc, level, seed):
-    """The same random single-end batches with the collapsed Gibbs step (DESIGN.md 4.1c) against the checker's collapsed
+    """The same random single-end batches with the collapsed Gibbs step (DESIGN.md 4.6) against the checker's collapsed
     mode: level 1 collapses the two-isoform events only (the others run their per-read kernels = counter mode), level 2
     every event (sampler_lane_k: random genes have many more compatibility classes than skip-one-exon genes); random
     Dirichlet hyper-parameters on some events."""
