@@ -1067,6 +1067,19 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
         found = true;
         if (!p.paired && (chains + cpw - 1) / cpw >= slots_for(chains)) break;
       }
+      // Round 5, paired-end, ONE isoform-count class in the batch, five to nine isoforms, two rounds of wavefronts and more at
+      // eight lanes: EIGHT lanes per chain -- eight chains of a wavefront share the scalar step instead of four.  Rounds 2 - 4
+      // measured that slower (the read loop waited on memory and more wavefronts hid it); since the draws are ordered by
+      // fragment rows and the loop's header no longer waits for fresh gathers it wins: 40 000 events x 1000 pairs, K = 5 / 6 / 7 /
+      // 8 / 9: 45.3 -> 54.2, 41.5 -> 48.7, 40.5 -> 45.5, 38.0 -> 40.5, 30.2 -> 31.5 k events/s; K = 12: 25.7 -> 21.2 k, four lanes
+      // 33.7 k at K = 5; in a whole-gene mix, where a class is a few thousand genes, 19.2 -> 18.2 k genes/s: not there
+      // (profiles/r05_lanes_sweep.txt).  MISO_PE_LANES8=0 / 1: never / also in a mix and for the size buckets' normal run.
+      {
+        const char *l8 = std::getenv("MISO_PE_LANES8");
+        const bool single = n_classes + (n_k2 > 0 ? 1 : 0) == 1;
+        const bool want8 = l8 ? std::atoi(l8) != 0 : (single && chains >= 8L * 2 * slots_for(chains));
+        if (p.paired && want8 && G == 16 && !run.force_G && run.kmin >= 5 && run.kmax <= 9 && grp_fits(run, sh, 8)) G = 8;
+      }
       if (tune_runs && chains >= 2048 && G != 64) {
         std::vector<int> cand{G};
         // the rule errs on the small side (tail effect when the wavefronts do not fit one round)
