@@ -122,8 +122,12 @@ __device__ __forceinline__ void lane_body(const KernelArgs &a, double *lds_lf) {
     __syncthreads();   // the only barrier, before any thread leaves
   }
   const long n_chains = static_cast<long>(a.n_slots) * a.C;
-  const long slot = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
-  if (slot >= n_chains) return;   // no barrier below
+  // a.pair_waves (runtime.hip): chains per wavefront when the batch has fewer wavefronts than the device has SIMDs -- a
+  // wavefront costs what its slowest lane costs (the binomial's trials, the inversion's steps), fewer lanes are done sooner
+  const int cpw = a.pair_waves > 0 ? a.pair_waves : 64;
+  const int wl = threadIdx.x & 63;
+  const long slot = (static_cast<long>(blockIdx.x) * 4 + (threadIdx.x >> 6)) * cpw + wl;
+  if (wl >= cpw || slot >= n_chains) return;   // no barrier below
   const int ev = a.slot_event[slot / a.C];
   const uint32_t chain = static_cast<uint32_t>(slot % a.C);
   const DevEvent E = a.events[ev];
