@@ -10,6 +10,21 @@ run() {  # label bench-args -- env...
 import json,sys
 d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print('$label $*', d['value'], d['roofline']['kernel'][:40], d['roofline']['kernel_ms'])" >> $out
 }
+# collapsed mode: fewer than 64 chains per wavefront when the batch has fewer wavefronts than the device has SIMDs
+timeout 600 python -m pytest tests/test_gpu_collapsed.py tests/test_gpu_convergent.py -x -q > gpurun_out/r5/spread_tests.log 2>&1
+echo "collapsed tests rc=$? $(tail -1 gpurun_out/r5/spread_tests.log)" >> $out
+for rep in 1 2; do
+  run "spread" --collapsed 1 -- MISO_X=0
+  run "64 per wavefront" --collapsed 1 -- MISO_LANE_SPREAD=0
+done
+run "hg19 spread" --collapsed 1 --reads-dist hg19 -- MISO_X=0
+run "hg19 64" --collapsed 1 --reads-dist hg19 -- MISO_LANE_SPREAD=0
+run "reads=3000 spread" --collapsed 1 --reads 3000 -- MISO_X=0
+run "reads=3000 64" --collapsed 1 --reads 3000 -- MISO_LANE_SPREAD=0
+run "20000 events spread" --collapsed 1 --events 20000 -- MISO_X=0
+run "20000 events 64" --collapsed 1 --events 20000 -- MISO_LANE_SPREAD=0
+run "100000 events spread" --collapsed 1 --events 100000 -- MISO_X=0
+run "100000 events 64" --collapsed 1 --events 100000 -- MISO_LANE_SPREAD=0
 for K in 3 4 5 6 7 8; do
   run "K=$K rule" --K $K -- MISO_X=0
   for nc in 5 6 7 8 9 10 12 14 16; do run "K=$K nc=$nc" --K $K -- MISO_FLAT_NC=$nc; done
