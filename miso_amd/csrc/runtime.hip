@@ -1728,11 +1728,12 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
         unsigned wgs = static_cast<unsigned>((chains + 255) / 256);
         {   // fewer wavefronts than SIMDs (or than two per SIMD): spread the chains over all of them (kernels_lane.hip lane_body)
           const long simds = wave_slots / 2, waves = (chains + 63) / 64;
-          const char *sp = std::getenv("MISO_LANE_SPREAD");
-          if (lane_ilp && !(sp && std::atoi(sp) == 0) && chains >= 64) {
-            const long target = ((waves + simds - 1) / simds) * simds;
+          const char *sp = std::getenv("MISO_LANE_SPREAD");   // 0: never; n: n wavefronts per SIMD (experiments)
+          const int per_simd = sp ? std::atoi(sp) : 1;
+          if (lane_ilp && per_simd > 0 && waves < simds * per_simd && chains >= 64) {
+            const long target = simds * per_simd;
             const int cpw = static_cast<int>((chains + target - 1) / target);
-            if (cpw >= 16 && cpw < 64) { ka.pair_waves = cpw; wgs = static_cast<unsigned>(((chains + cpw - 1) / cpw + 3) / 4); }
+            if (cpw >= 8 && cpw < 64) { ka.pair_waves = cpw; wgs = static_cast<unsigned>(((chains + cpw - 1) / cpw + 3) / 4); }
           }
         }
         if (lane_ilp) hipLaunchKernelGGL(sampler_lane_ilp, dim3(wgs), dim3(256), 0, st, ka);
