@@ -1007,7 +1007,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
                          run.tuned_flat < 0 && std::getenv("MISO_FLAT_NC") == nullptr;
     if (flat_nc[ri] > 0 && run.tuned_flat == 0) flat_nc[ri] = 0;
     if (flat_nc[ri] > 0 && !contest) continue;
-    const GrpShape sh = grp_sh[ri] = grp_shape(run);
+    GrpShape sh = grp_sh[ri] = grp_shape(run);
     const long chains = static_cast<long>(run.count) * p.noChains;
     int G = 64;
     if (run.wide) {   // one chain per workgroup (launch_grp): the score table joins the slice when four of them fit
@@ -1030,6 +1030,11 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       }
     } else if (run.tuned_G) {
       G = run.tuned_G;
+      if (p.paired && sh.ts && !grp_fits(run, sh, G)) {   // chosen with the score tables in global memory (the eight-lane rule below)
+        GrpShape s0 = sh;
+        s0.ts = 0;
+        if (grp_fits(run, s0, G)) sh = grp_sh[ri] = s0;
+      }
     } else {
       // rule of thumb.  single-end: the per-iteration scalar step costs the same per wavefront
       // whatever G is, so pack as many chains per wavefront as still fills the device: the smallest
@@ -1079,6 +1084,15 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
         const bool single = n_classes + (n_k2 > 0 ? 1 : 0) == 1;
         const bool want8 = l8 ? std::atoi(l8) != 0 : (single && chains >= 8L * 2 * slots_for(chains));
         if (p.paired && want8 && G == 16 && !run.force_G && run.kmin >= 5 && run.kmax <= 9 && grp_fits(run, sh, 8)) G = 8;
+        // Three and four isoforms the same -- there the class keeps its score tables in LDS (grp_shape), which holds four
+        // chains per wavefront and no more: eight chains with the tables in global memory (an L2 line per pick) instead,
+        // K = 3 66.6 -> 78.9 k, K = 4 58.1 -> 68.0 k events/s; the tables alone are worth 2 % (16 lanes without them 65.3 /
+        // 57.0 k), four lanes lose (55.9 / 37.6 k) (profiles/r05_lanes_sweep.txt).
+        if (p.paired && want8 && G == 16 && !run.force_G && run.kmax <= 4) {
+          GrpShape sh8 = sh;
+          if (!grp_fits(run, sh8, 8)) sh8.ts = 0;
+          if (grp_fits(run, sh8, 8)) { sh = grp_sh[ri] = sh8; G = 8; }
+        }
       }
       if (tune_runs && chains >= 2048 && G != 64) {
         std::vector<int> cand{G};
