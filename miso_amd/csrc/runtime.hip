@@ -1082,7 +1082,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       {
         const char *l8 = std::getenv("MISO_PE_LANES8");
         const bool single = n_classes + (n_k2 > 0 ? 1 : 0) == 1;
-        const bool want8 = l8 ? std::atoi(l8) != 0 : (single && chains >= 8L * 2 * slots_for(chains));
+        const bool want8 = l8 && std::atoi(l8) != 2 ? std::atoi(l8) != 0 : ((single || l8) && chains >= 8L * 2 * slots_for(chains));   // (2: the rule in a mix of classes too)
         if (p.paired && want8 && G == 16 && !run.force_G && run.kmin >= 5 && run.kmax <= 9 && grp_fits(run, sh, 8)) G = 8;
         // Three and four isoforms the same -- there the class keeps its score tables in LDS (grp_shape), which holds four
         // chains per wavefront and no more: eight chains with the tables in global memory (an L2 line per pick) instead,

@@ -9,10 +9,10 @@ run() {  # label bench-args -- env...
 import json,sys
 d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print('$label $*', d['value'], d['roofline']['kernel'][:60], d['roofline']['kernel_ms'])" >> $out
 }
-for ev in 32768 65536; do
+for ev in 16384 32768 65536; do
   for cfg in "--K-range 3 20 --paired --events $ev" "--K-range 3 20 --paired --events $ev --reads-dist hg19" "--K-range 3 8 --paired --events $ev"; do
     run "rule   $cfg" $cfg -- MISO_X=0
-    run "lanes8 $cfg" $cfg -- MISO_PE_LANES8=1
+    run "rule in mixes $cfg" $cfg -- MISO_PE_LANES8=2
   done
 done
 cat $out
