@@ -358,10 +358,19 @@ __device__ __attribute__((noinline)) void flat_units_desc(const FlatUnitsArgs A,
 #ifndef MISO_FLAT_WGS_LARGE
 #define MISO_FLAT_WGS_LARGE 2
 #endif
-template <int KC>
+// KS > 0 (round 5): the launch's largest isoform count a.kstride as a compile-time constant -- the slice layout (seventeen
+// offsets), the strides and the reciprocals of the flat loops become immediates instead of scalar registers (the kernel spilled
+// 227 of them into VGPR lanes and fetched them back with ~500 v_readlane per iteration, an eighth of the scalar step's
+// instructions), and the unrolled isoform loops end at KS instead of at the class's KC.  Up to twelve isoforms every count has
+// its kernel (kernels_flat_c4 / c8 / c12.hip); KS = 0: the layout at run time (13 - 32 isoforms).  K = 5 110.0 -> 113.5 k,
+// K = 10 58.0 -> 60.7 k events/s with the layout alone (profiles/r05_flat_chunks.txt).
+template <int KC, int KS = 0>
 __global__ __launch_bounds__(256, KC <= 4 ? MISO_FLAT_WGS_4 : (KC <= 8 ? MISO_FLAT_WGS_SMALL : (KC <= 12 ? MISO_FLAT_WGS_12 : MISO_FLAT_WGS_LARGE))) void sampler_flat(const KernelArgs a) {
+  static_assert(KS == 0 || (KS <= KC && KS >= 2), "KS: an isoform count of the class KC");
+  constexpr int KB = KS > 0 ? KS : KC;   // bound of the unrolled isoform loops
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int NC = a.nc, ks = a.kstride, cs = a.cstride, tws = ks - 1, trow = flat_trow(ks);
+  const int ks = KS > 0 ? KS : a.kstride;
+  const int NC = a.nc, cs = a.cstride, tws = ks - 1, trow = flat_trow(ks);
   const FlatLayout L = flat_layout(ks, cs);
   unsigned char *wbase = smem_flat + static_cast<size_t>(wid) * NC * L.bytes;
   // Which chains this wavefront owns comes from the host (runtime.hip: flat_waves): a.wave_tab[wavefront] = {first
@@ -529,9 +538,21 @@ __global__ __launch_bounds__(256, KC <= 4 ? MISO_FLAT_WGS_4 : (KC <= 8 ? MISO_FL
 #define FLAT_END }
   // a leader's vector: all loads first (one LDS latency), then the reference's left-to-right arithmetic
   // (in chunks of CH isoforms, so that the K <= 32 kernel does not hold whole vectors in registers)
-  constexpr int CH = KC <= 8 ? KC : (KC <= 16 ? 8 : 4);
+  // Round 5: chunks of FOUR up to twelve isoforms.  The joint score below holds six vectors of CH doubles at once; with CH = 8
+  // that is where the K <= 8 kernel needs 209 registers, and at the 168 of three workgroups per CU 44 loop-invariant values sat
+  // in scratch (176 bytes per lane, ~30 reloads per iteration, most of the row's HBM traffic).  With four: 183 / 48 bytes /
+  // 5 reloads; K = 5 / 6 / 7 / 8 104.3 -> 109.3 / 95.2 -> 100.0 / 90.0 -> 93.8 / 70.3 -> 72.7 k events/s, K = 10 / 12 55.0 -> 57.7 /
+  // 40.8 -> 42.2 k (192 -> 128 bytes); 13 - 16 isoforms (two workgroups per CU, no scratch either way) keep eight: 29.76 vs
+  // 29.52 k (profiles/r05_flat_chunks.txt).  Same sums in the same order: the chunk is how many operands are loaded at once.
+#ifndef MISO_FLAT_CH_SMALL
+#define MISO_FLAT_CH_SMALL 4   // KC <= 12
+#endif
+#ifndef MISO_FLAT_CH_MID
+#define MISO_FLAT_CH_MID 8     // KC 16
+#endif
+  constexpr int CH = KC <= 12 ? (MISO_FLAT_CH_SMALL < KB ? MISO_FLAT_CH_SMALL : KB) : (KC <= 16 ? MISO_FLAT_CH_MID : 4);
 #define CHUNKS_BEGIN                                                            \
-  _Pragma("unroll") for (int k0 = 0; k0 < KC; k0 += CH) {                       \
+  _Pragma("unroll") for (int k0 = 0; k0 < KB; k0 += CH) {                       \
     if (k0 < Kw) {
 #define CHUNKS_END }}
 #define LOADC(v, p)                                                             \
@@ -698,14 +719,14 @@ __global__ __launch_bounds__(256, KC <= 4 ? MISO_FLAT_WGS_4 : (KC <= 8 ? MISO_FL
       const int K = mi[MI_K], ncls = mi[MI_NCLS];
       const uint32_t m = FU(s, L.ctab)[CLS_WORDS * j];
       const double *psi = FD(s, L.psi);
-      double ps[KC];
+      double ps[KB];
 #pragma unroll
-      for (int k = 0; k < KC; k++) ps[k] = (k < Kw) ? psi[k] : 0.0;
+      for (int k = 0; k < KB; k++) ps[k] = (k < Kw) ? psi[k] : 0.0;
       const bool mine = on && j < ncls;
       // total weight, ascending isoforms (miso.c:11-22); +0.0 for the others leaves the bits alone
       double T = 0.0;
 #pragma unroll
-      for (int k = 0; k < KC; k++) if (k < Kw) T = T + ((k < K && ((m >> k) & 1u)) ? ps[k] : 0.0);
+      for (int k = 0; k < KB; k++) if (k < Kw) T = T + ((k < K && ((m >> k) & 1u)) ? ps[k] : 0.0);
       const double inv = 4294967296.0 / T;
       const bool tnormal = T >= 1e-280 && T <= 1e280;   // products with u 2^-32 stay normal
       const bool le = __popc(m) != 2;
@@ -715,7 +736,7 @@ __global__ __launch_bounds__(256, KC <= 4 ? MISO_FLAT_WGS_4 : (KC <= 8 ? MISO_FL
       uint32_t run = 0u;
       bool slow = false;
 #pragma unroll
-      for (int k = 0; k < KC - 1; k++) {
+      for (int k = 0; k < KB - 1; k++) {
         if (k < Kw - 1) {
           const bool member = k < K && ((m >> k) & 1u);
           cum = cum + (member ? ps[k] : 0.0);
@@ -756,9 +777,10 @@ __global__ __launch_bounds__(256, KC <= 4 ? MISO_FLAT_WGS_4 : (KC <= 8 ? MISO_FL
     ua.woff = wid * NC * L.bytes; ua.slice = L.bytes; ua.off_ctab = L.ctab; ua.off_thr = L.thr; ua.off_misc = L.misc; ua.off_dl = L.dl;
     ua.trow = trow; ua.trips = trips; ua.iter = iter; ua.k0 = k0; ua.k1 = k1;
 #define MISO_FUNITS(TW) { if (use_desc) flat_units_desc<TW>(ua, reinterpret_cast<const uint32_t *>(a.in_pool), d_ms, d_r, d_g); else flat_units<TW>(ua, s0, c0, i0, n_mine); }
-    if constexpr (KC == 4) { if (tww <= 2) MISO_FUNITS(2) else MISO_FUNITS(3) }
-    else if constexpr (KC == 8) { if (tww <= 4) MISO_FUNITS(4) else if (tww == 5) MISO_FUNITS(5) else if (tww == 6) MISO_FUNITS(6) else MISO_FUNITS(7) }
-    else if constexpr (KC == 12) { if (tww <= 9) MISO_FUNITS(9) else MISO_FUNITS(11) }
+    // (tww <= KB - 1: a kernel of one isoform count carries the one read loop it can reach)
+    if constexpr (KC == 4) { if (KB <= 3 || tww <= 2) MISO_FUNITS(2) else MISO_FUNITS(3) }
+    else if constexpr (KC == 8) { if (KB <= 5 || tww <= 4) MISO_FUNITS(4) else if (KB <= 6 || tww == 5) MISO_FUNITS(5) else if (KB <= 7 || tww == 6) MISO_FUNITS(6) else MISO_FUNITS(7) }
+    else if constexpr (KC == 12) { if (KB <= 10 || tww <= 9) MISO_FUNITS(9) else MISO_FUNITS(11) }
     else if constexpr (KC == 16) { MISO_FUNITS(15) }
     else { if (tww <= 19) MISO_FUNITS(19) else if (tww <= 23) MISO_FUNITS(23) else MISO_FUNITS(31) }
 #undef MISO_FUNITS
@@ -821,13 +843,13 @@ __global__ __launch_bounds__(256, KC <= 4 ? MISO_FLAT_WGS_4 : (KC <= 8 ? MISO_FL
   const bool tracing = __any(LE_.off_trace != NO_TRACE);   // all events of a batch trace or none
   for (int m = 0; m < a.M; m++) {
     // this iteration's view of the counts: the leader's registers (hash, both joint scores)
-    int cn[KC];
+    int cn[KB];
     if (leader) {
       const int *bas = FI(ls, L.bas), *cnt = FI(ls, L.cnt);
 #pragma unroll
-      for (int k = 0; k < KC; k++) cn[k] = (k < Kw) ? bas[k] + cnt[k] : 0;
+      for (int k = 0; k < KB; k++) cn[k] = (k < Kw) ? bas[k] + cnt[k] : 0;
 #pragma unroll
-      for (int k = 0; k < KC; k++)
+      for (int k = 0; k < KB; k++)
         if (k < Kw) hash = (k < lK) ? (hash ^ static_cast<uint32_t>(cn[k])) * 0x100000001B3ull : hash;
     }
     if (tracing) {

@@ -2,5 +2,9 @@
 #include "kernels_flat.inl"
 
 namespace miso {
-template __global__ void sampler_flat<12>(const KernelArgs);
+template __global__ void sampler_flat<12, 0>(const KernelArgs);   // the slice layout at run time (fallback)
+template __global__ void sampler_flat<12, 9>(const KernelArgs);   // ... of 9 isoforms at compile time
+template __global__ void sampler_flat<12, 10>(const KernelArgs);   // ... of 10 isoforms at compile time
+template __global__ void sampler_flat<12, 11>(const KernelArgs);   // ... of 11 isoforms at compile time
+template __global__ void sampler_flat<12, 12>(const KernelArgs);   // ... of 12 isoforms at compile time
 }  // namespace miso

@@ -2,5 +2,5 @@
 #include "kernels_flat.inl"
 
 namespace miso {
-template __global__ void sampler_flat<16>(const KernelArgs);
+template __global__ void sampler_flat<16, 0>(const KernelArgs);
 }  // namespace miso

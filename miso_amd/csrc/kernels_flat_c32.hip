@@ -2,5 +2,5 @@
 #include "kernels_flat.inl"
 
 namespace miso {
-template __global__ void sampler_flat<32>(const KernelArgs);
+template __global__ void sampler_flat<32, 0>(const KernelArgs);
 }  // namespace miso

@@ -2,5 +2,9 @@
 #include "kernels_flat.inl"
 
 namespace miso {
-template __global__ void sampler_flat<8>(const KernelArgs);
+template __global__ void sampler_flat<8, 0>(const KernelArgs);   // the slice layout at run time (fallback)
+template __global__ void sampler_flat<8, 5>(const KernelArgs);   // ... of 5 isoforms at compile time
+template __global__ void sampler_flat<8, 6>(const KernelArgs);   // ... of 6 isoforms at compile time
+template __global__ void sampler_flat<8, 7>(const KernelArgs);   // ... of 7 isoforms at compile time
+template __global__ void sampler_flat<8, 8>(const KernelArgs);   // ... of 8 isoforms at compile time
 }  // namespace miso

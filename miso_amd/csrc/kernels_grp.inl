@@ -840,7 +840,10 @@ template <int G, bool PE, int KC, bool WIDE = false>
 #endif
 __device__ __forceinline__ void grp_body(const KernelArgs &a, unsigned block_x) {   // workgroup block_x of the run
   constexpr int KLO = KC == 4 ? 3 : (KC == 8 ? 5 : (KC == 12 ? 9 : (KC == 16 ? 13 : 17)));   // the class holds K in [KLO, KC]
-  constexpr int MH_CH = PE ? (KC <= 8 ? KC : 4) : 1;   // chunk width of the Metropolis-Hastings step's serial chains (seq_sum_u)
+#ifndef MISO_GRP_MH_CH8
+#define MISO_GRP_MH_CH8 8
+#endif
+  constexpr int MH_CH = PE ? (KC <= 8 ? (MISO_GRP_MH_CH8 < KC ? MISO_GRP_MH_CH8 : KC) : 4) : 1;   // chunk width of the Metropolis-Hastings step's serial chains (seq_sum_u)
   static_assert(!WIDE || (PE && G == 64), "workgroup-wide chains: paired-end, whole wavefronts");
   constexpr int GS = WIDE ? 0 : G;         // lanes striding over one chain's quads (WIDE: 256 x the chain's workgroups, known at run time)
   constexpr bool MH_ONE = PE && KC <= 4;   // a single pass without the loop around it (K=3 57.2k -> 60.6k; at five to eight isoforms the loop form is faster: 39.5k against 35.9k at K=5)

@@ -42,7 +42,7 @@ __global__ void match_kernel(const MatchEvent *, const int2 *, const int *, cons
 __global__ void summarize_kernel(const DevEvent *, const unsigned char *, int, int, int, int, const uint64_t *, double *, int);
 template <int G, bool PE, int KC, bool WIDE = false> __global__ void sampler_grp(const KernelArgs a);
 template <int KC> __global__ void sampler_grp_multi(const KernelArgs a);
-template <int KC> __global__ void sampler_flat(const KernelArgs a);
+template <int KC, int KS> __global__ void sampler_flat(const KernelArgs a);   // KS: the launch's largest isoform count at compile time (0: at run time)
 __global__ void selftest_detmath_kernel(const double *, int, double *, double *, double *, double *);
 __global__ void selftest_philox_kernel(const uint32_t *, int, uint32_t *);
 
@@ -875,7 +875,13 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     if (const char *env = std::getenv("MISO_FLAT_NC")) nc = std::max(1, std::min(nc_max, std::atoi(env)));
     flat_nc[ri] = nc; flat_nc_max[ri] = nc_max;
   }
-  auto flat_name = [&](const GenRun &run) { return "sampler_flat<" + std::to_string(run.kc) + ">"; };
+  // up to twelve isoforms the kernel of the launch's largest isoform count (its slice layout at compile time,
+  // kernels_flat.inl); MISO_FLAT_NO_KS=1: the run-time layout everywhere (A/B, tests)
+  auto flat_ks = [&](const GenRun &run) {
+    const int lo = run.kc == 4 ? 3 : (run.kc == 8 ? 5 : 9);
+    return (run.kc <= 12 && run.kmax >= lo && run.kmax <= run.kc && std::getenv("MISO_FLAT_NO_KS") == nullptr) ? run.kmax : 0;
+  };
+  auto flat_name = [&](const GenRun &run) { return "sampler_flat<" + std::to_string(run.kc) + ", " + std::to_string(flat_ks(run)) + ">"; };
   // Which chains a wavefront of sampler_flat owns (kernels_flat.inl: a.wave_tab).  Uniform batches: `nc` consecutive
   // chains each.  When the batch's events differ widely in size -- the heaviest wavefront of the uniform rule would
   // carry more than twice the average wavefront's work units -- the wavefronts are packed by UNITS instead: as many
@@ -978,18 +984,27 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     }
     const unsigned grid = static_cast<unsigned>(run.wave_tab.size() / 8);
     const size_t lds = 4 * static_cast<size_t>(run.wave_nc) * flat_layout(ka.kstride, ka.cstride).bytes;
-#define MISO_FLAT_LAUNCH(KC)                                                                            \
+#define MISO_FLAT_LAUNCH(KC, KS)                                                                        \
   {                                                                                                     \
-    HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sampler_flat<KC>),                       \
+    HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sampler_flat<KC, KS>),                   \
                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));     \
-    hipLaunchKernelGGL((sampler_flat<KC>), dim3(grid), dim3(256), lds, st, ka);                         \
+    hipLaunchKernelGGL((sampler_flat<KC, KS>), dim3(grid), dim3(256), lds, st, ka);                     \
   }
+    const int ksel = flat_ks(run);   // (== ka.kstride or 0)
     switch (run.kc) {
-    case 4: MISO_FLAT_LAUNCH(4) break;
-    case 8: MISO_FLAT_LAUNCH(8) break;
-    case 12: MISO_FLAT_LAUNCH(12) break;
-    case 16: MISO_FLAT_LAUNCH(16) break;
-    default: MISO_FLAT_LAUNCH(32) break;
+    case 4:
+      if (ksel == 3) MISO_FLAT_LAUNCH(4, 3) else if (ksel == 4) MISO_FLAT_LAUNCH(4, 4) else MISO_FLAT_LAUNCH(4, 0)
+      break;
+    case 8:
+      if (ksel == 5) MISO_FLAT_LAUNCH(8, 5) else if (ksel == 6) MISO_FLAT_LAUNCH(8, 6) else if (ksel == 7) MISO_FLAT_LAUNCH(8, 7)
+      else if (ksel == 8) MISO_FLAT_LAUNCH(8, 8) else MISO_FLAT_LAUNCH(8, 0)
+      break;
+    case 12:
+      if (ksel == 9) MISO_FLAT_LAUNCH(12, 9) else if (ksel == 10) MISO_FLAT_LAUNCH(12, 10) else if (ksel == 11) MISO_FLAT_LAUNCH(12, 11)
+      else if (ksel == 12) MISO_FLAT_LAUNCH(12, 12) else MISO_FLAT_LAUNCH(12, 0)
+      break;
+    case 16: MISO_FLAT_LAUNCH(16, 0) break;
+    default: MISO_FLAT_LAUNCH(32, 0) break;
     }
 #undef MISO_FLAT_LAUNCH
     HIP_OK(hipGetLastError());
@@ -1435,7 +1450,13 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     return "sampler_k2<" + std::to_string(G) + (p.paired ? (wpart ? ", 2, 4>" : ", 1, 4>") : (k2_pair ? ", 0, 8>" : ", 0, 4>"));
   };
   auto k2_mix_name = [&](int G) { return "sampler_k2_mix<" + std::to_string(G + 1) + ", " + std::to_string(G) + ">"; };
-  auto flat_name = [&](const GenRun &run) { return "sampler_flat<" + std::to_string(run.kc) + ">"; };
+  // up to twelve isoforms the kernel of the launch's largest isoform count (its slice layout at compile time,
+  // kernels_flat.inl); MISO_FLAT_NO_KS=1: the run-time layout everywhere (A/B, tests)
+  auto flat_ks = [&](const GenRun &run) {
+    const int lo = run.kc == 4 ? 3 : (run.kc == 8 ? 5 : 9);
+    return (run.kc <= 12 && run.kmax >= lo && run.kmax <= run.kc && std::getenv("MISO_FLAT_NO_KS") == nullptr) ? run.kmax : 0;
+  };
+  auto flat_name = [&](const GenRun &run) { return "sampler_flat<" + std::to_string(run.kc) + ", " + std::to_string(flat_ks(run)) + ">"; };
   for (int part = 0; part < 2; part++) {
     const bool wpart = part == 0;
     const int count = wpart ? n_k2w : n_k2 - n_k2w, k2G = wpart ? k2w_G : k2_G;
