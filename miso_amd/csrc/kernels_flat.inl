@@ -361,8 +361,8 @@ __device__ __attribute__((noinline)) void flat_units_desc(const FlatUnitsArgs A,
 // KS > 0 (round 5): the launch's largest isoform count a.kstride as a compile-time constant -- the slice layout (seventeen
 // offsets), the strides and the reciprocals of the flat loops become immediates instead of scalar registers (the kernel spilled
 // 227 of them into VGPR lanes and fetched them back with ~500 v_readlane per iteration, an eighth of the scalar step's
-// instructions), and the unrolled isoform loops end at KS instead of at the class's KC.  Up to twelve isoforms every count has
-// its kernel (kernels_flat_c4 / c8 / c12.hip); KS = 0: the layout at run time (13 - 32 isoforms).  K = 5 110.0 -> 113.5 k,
+// instructions), and the unrolled isoform loops end at KS instead of at the class's KC.  Up to twenty isoforms every count has
+// its kernel (kernels_flat_c*.hip); KS = 0: the layout at run time (21 - 32 isoforms).  K = 5 110.0 -> 113.5 k,
 // K = 10 58.0 -> 60.7 k events/s with the layout alone (profiles/r05_flat_chunks.txt).
 template <int KC, int KS = 0>
 __global__ __launch_bounds__(256, KC <= 4 ? MISO_FLAT_WGS_4 : (KC <= 8 ? MISO_FLAT_WGS_SMALL : (KC <= 12 ? MISO_FLAT_WGS_12 : MISO_FLAT_WGS_LARGE))) void sampler_flat(const KernelArgs a) {
@@ -782,7 +782,7 @@ __global__ __launch_bounds__(256, KC <= 4 ? MISO_FLAT_WGS_4 : (KC <= 8 ? MISO_FL
     else if constexpr (KC == 8) { if (KB <= 5 || tww <= 4) MISO_FUNITS(4) else if (KB <= 6 || tww == 5) MISO_FUNITS(5) else if (KB <= 7 || tww == 6) MISO_FUNITS(6) else MISO_FUNITS(7) }
     else if constexpr (KC == 12) { if (KB <= 10 || tww <= 9) MISO_FUNITS(9) else MISO_FUNITS(11) }
     else if constexpr (KC == 16) { MISO_FUNITS(15) }
-    else { if (tww <= 19) MISO_FUNITS(19) else if (tww <= 23) MISO_FUNITS(23) else MISO_FUNITS(31) }
+    else { if (KB <= 20 || tww <= 19) MISO_FUNITS(19) else if (tww <= 23) MISO_FUNITS(23) else MISO_FUNITS(31) }
 #undef MISO_FUNITS
     fsync();
     if (wide) {

@@ -2,5 +2,9 @@
 #include "kernels_flat.inl"
 
 namespace miso {
-template __global__ void sampler_flat<16, 0>(const KernelArgs);
+template __global__ void sampler_flat<16, 0>(const KernelArgs);   // the slice layout at run time
+template __global__ void sampler_flat<16, 13>(const KernelArgs);   // ... of 13 isoforms at compile time
+template __global__ void sampler_flat<16, 14>(const KernelArgs);   // ... of 14 isoforms at compile time
+template __global__ void sampler_flat<16, 15>(const KernelArgs);   // ... of 15 isoforms at compile time
+template __global__ void sampler_flat<16, 16>(const KernelArgs);   // ... of 16 isoforms at compile time
 }  // namespace miso

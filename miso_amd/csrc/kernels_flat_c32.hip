@@ -2,5 +2,9 @@
 #include "kernels_flat.inl"
 
 namespace miso {
-template __global__ void sampler_flat<32, 0>(const KernelArgs);
+template __global__ void sampler_flat<32, 0>(const KernelArgs);   // the slice layout at run time
+template __global__ void sampler_flat<32, 17>(const KernelArgs);   // ... of 17 isoforms at compile time
+template __global__ void sampler_flat<32, 18>(const KernelArgs);   // ... of 18 isoforms at compile time
+template __global__ void sampler_flat<32, 19>(const KernelArgs);   // ... of 19 isoforms at compile time
+template __global__ void sampler_flat<32, 20>(const KernelArgs);   // ... of 20 isoforms at compile time
 }  // namespace miso

@@ -875,11 +875,11 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     if (const char *env = std::getenv("MISO_FLAT_NC")) nc = std::max(1, std::min(nc_max, std::atoi(env)));
     flat_nc[ri] = nc; flat_nc_max[ri] = nc_max;
   }
-  // up to twelve isoforms the kernel of the launch's largest isoform count (its slice layout at compile time,
+  // up to twenty isoforms the kernel of the launch's largest isoform count (its slice layout at compile time,
   // kernels_flat.inl); MISO_FLAT_NO_KS=1: the run-time layout everywhere (A/B, tests)
   auto flat_ks = [&](const GenRun &run) {
-    const int lo = run.kc == 4 ? 3 : (run.kc == 8 ? 5 : 9);
-    return (run.kc <= 12 && run.kmax >= lo && run.kmax <= run.kc && std::getenv("MISO_FLAT_NO_KS") == nullptr) ? run.kmax : 0;
+    const int lo = run.kc == 4 ? 3 : (run.kc == 8 ? 5 : (run.kc == 12 ? 9 : (run.kc == 16 ? 13 : 17)));
+    return (run.kc <= 32 && run.kmax >= lo && run.kmax <= std::min(run.kc, 20) && std::getenv("MISO_FLAT_NO_KS") == nullptr) ? run.kmax : 0;
   };
   auto flat_name = [&](const GenRun &run) { return "sampler_flat<" + std::to_string(run.kc) + ", " + std::to_string(flat_ks(run)) + ">"; };
   // Which chains a wavefront of sampler_flat owns (kernels_flat.inl: a.wave_tab).  Uniform batches: `nc` consecutive
@@ -1003,8 +1003,14 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       if (ksel == 9) MISO_FLAT_LAUNCH(12, 9) else if (ksel == 10) MISO_FLAT_LAUNCH(12, 10) else if (ksel == 11) MISO_FLAT_LAUNCH(12, 11)
       else if (ksel == 12) MISO_FLAT_LAUNCH(12, 12) else MISO_FLAT_LAUNCH(12, 0)
       break;
-    case 16: MISO_FLAT_LAUNCH(16, 0) break;
-    default: MISO_FLAT_LAUNCH(32, 0) break;
+    case 16:
+      if (ksel == 13) MISO_FLAT_LAUNCH(16, 13) else if (ksel == 14) MISO_FLAT_LAUNCH(16, 14) else if (ksel == 15) MISO_FLAT_LAUNCH(16, 15)
+      else if (ksel == 16) MISO_FLAT_LAUNCH(16, 16) else MISO_FLAT_LAUNCH(16, 0)
+      break;
+    default:
+      if (ksel == 17) MISO_FLAT_LAUNCH(32, 17) else if (ksel == 18) MISO_FLAT_LAUNCH(32, 18) else if (ksel == 19) MISO_FLAT_LAUNCH(32, 19)
+      else if (ksel == 20) MISO_FLAT_LAUNCH(32, 20) else MISO_FLAT_LAUNCH(32, 0)
+      break;
     }
 #undef MISO_FLAT_LAUNCH
     HIP_OK(hipGetLastError());
@@ -1450,11 +1456,11 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     return "sampler_k2<" + std::to_string(G) + (p.paired ? (wpart ? ", 2, 4>" : ", 1, 4>") : (k2_pair ? ", 0, 8>" : ", 0, 4>"));
   };
   auto k2_mix_name = [&](int G) { return "sampler_k2_mix<" + std::to_string(G + 1) + ", " + std::to_string(G) + ">"; };
-  // up to twelve isoforms the kernel of the launch's largest isoform count (its slice layout at compile time,
+  // up to twenty isoforms the kernel of the launch's largest isoform count (its slice layout at compile time,
   // kernels_flat.inl); MISO_FLAT_NO_KS=1: the run-time layout everywhere (A/B, tests)
   auto flat_ks = [&](const GenRun &run) {
-    const int lo = run.kc == 4 ? 3 : (run.kc == 8 ? 5 : 9);
-    return (run.kc <= 12 && run.kmax >= lo && run.kmax <= run.kc && std::getenv("MISO_FLAT_NO_KS") == nullptr) ? run.kmax : 0;
+    const int lo = run.kc == 4 ? 3 : (run.kc == 8 ? 5 : (run.kc == 12 ? 9 : (run.kc == 16 ? 13 : 17)));
+    return (run.kc <= 32 && run.kmax >= lo && run.kmax <= std::min(run.kc, 20) && std::getenv("MISO_FLAT_NO_KS") == nullptr) ? run.kmax : 0;
   };
   auto flat_name = [&](const GenRun &run) { return "sampler_flat<" + std::to_string(run.kc) + ", " + std::to_string(flat_ks(run)) + ">"; };
   for (int part = 0; part < 2; part++) {
