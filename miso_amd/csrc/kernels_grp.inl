@@ -889,7 +889,11 @@ __device__ __forceinline__ void grp_body(const KernelArgs &a, unsigned block_x) 
   if (!live_all) slot = n_chains - 1;       // shadow a real chain, store nothing
   const int sub_r = WIDE ? cg.rank * 256 + static_cast<int>(threadIdx.x) : sub;   // this lane's place among the chain's lanes
   const int stride_r = WIDE ? 256 * cg.n : G;
+#ifdef MISO_GRP_KS_FIXED   // experiment (with MISO_PE_ONLY_K): the slice layout of one isoform count at compile time
+  const int ks = MISO_GRP_KS_FIXED, cs = a.cstride;
+#else
   const int ks = a.kstride, cs = a.cstride;
+#endif
   Slice S = carve(smem + fp_bytes + (static_cast<size_t>(wave) * CPW + grp) * grp_slice_bytes(ks, cs, a.tstride),
                   ks, cs);
 
