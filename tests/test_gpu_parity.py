@@ -45,6 +45,32 @@ def test_single_end_bit_exact(orc, K, N, chains, iters, burn, lag):
     _compare(gpu, cpu, chains)
 
 
+@pytest.mark.parametrize("K", list(range(3, 22)))
+def test_single_end_kernel_of_every_isoform_count(orc, K, monkeypatch):
+    """sampler_flat<KC, KS>: up to twenty isoforms the launch's largest isoform count is a compile-time constant of the
+    kernel (slice layout, loop bounds -- kernels_flat.inl); beyond, and under MISO_FLAT_NO_KS=1, the run-time layout.
+    Both bit-exact against the checker, three chains of different events in one wavefront."""
+    iters, burn, lag, chains = 60, 10, 2, 2
+    cases = []
+    for e in range(3):
+        exons, isoforms, g, pos, cig = simulate_se(orc, K, 250 + 40 * e, seed=700 + 10 * K + e)
+        cases.append((miso_amd.Gene(exons, isoforms), g, pos, cig))
+    kc = 4 if K <= 4 else 8 if K <= 8 else 12 if K <= 12 else 16 if K <= 16 else 32
+    for no_ks in (False, True):
+        if no_ks:
+            monkeypatch.setenv("MISO_FLAT_NO_KS", "1")
+        b = miso_amd.Batch(36, iters=iters, burn=burn, lag=lag, chains=chains, counts_trace=True)
+        for G, g, pos, cig in cases:
+            b.add_event(G, pos, cig)
+        b.run(seed=SEED, first_event_id=40)
+        assert "sampler_flat<%d, %d>" % (kc, 0 if (no_ks or K > 20) else K) in b.last_kernels(), b.last_kernels()
+        for e, (G, g, pos, cig) in enumerate(cases):
+            cpu = orc.miso(g, pos, cig, 36, iters=iters, burn=burn, lag=lag, chains=chains,
+                           mode=OrcLib.COUNTER, seed=SEED, event_id=40 + e, trace=True)
+            assert cpu.rc == 0
+            _compare(b.result(e, trace=True), cpu, chains)
+
+
 @pytest.mark.parametrize("K,N,chains,iters,burn,lag", [
     (2, 500, 1, 400, 100, 1), (2, 300, 3, 300, 50, 4), (3, 400, 2, 300, 50, 5), (5, 300, 1, 200, 20, 2)])
 def test_paired_end_bit_exact(orc, K, N, chains, iters, burn, lag):
