@@ -41,6 +41,31 @@ def test_dense_records_against_the_oracle(orc, K, n_pairs, n_events):
         assert np.array_equal(r.assignment, cpu.assignment), where
 
 
+@pytest.mark.parametrize("K,n_pairs,lanes", [(3, 1000, 8), (4, 1000, 8), (3, 600, 16), (4, 1000, 16), (5, 1000, 8), (8, 1000, 8),
+                                             (9, 1000, 8)])
+def test_eight_lanes_per_chain_and_score_tables_in_global_memory(orc, K, n_pairs, lanes, monkeypatch):
+    """runtime.hip's rule for large batches of one isoform-count class -- eight lanes per chain, and for three and four
+    isoforms the score tables in global memory instead of the LDS slice -- forced on a small batch (MISO_GENERAL_LANES;
+    MISO_LDS_MAX_KB below what the tables need): the same bits as the checker."""
+    monkeypatch.setenv("MISO_GENERAL_LANES", str(lanes))
+    if K <= 4:
+        monkeypatch.setenv("MISO_LDS_MAX_KB", "48" if lanes == 8 else "40")
+    b, (exons, isoforms, pos, cig) = _batch(K, n_pairs, 5)
+    b.run(seed=5, first_event_id=0)
+    kc = 4 if K <= 4 else 8 if K <= 8 else 12
+    assert "sampler_grp<%d, true, %d>" % (lanes, kc) in b.last_kernels(), b.last_kernels()
+    g = orc.gene(flat(exons), isoforms)
+    for e in range(3):
+        cpu = orc.miso_paired(g, pos, cig, 36, 250.0, 900.0, mode=OrcLib.COUNTER, seed=5, event_id=e, trace=True, **KW)
+        assert cpu.rc == 0
+        r = b.result(e, trace=True)
+        where = (K, n_pairs, e, b.last_kernels())
+        assert np.array_equal(r.counts_trace, cpu.trace["counts_trace"]), where
+        assert np.array_equal(r.counts_hash, cpu.trace["counts_hash"]), where
+        assert np.array_equal(r.samples, cpu.samples) and np.array_equal(r.loglik, cpu.loglik, equal_nan=True), where
+        assert np.array_equal(r.assignment, cpu.assignment), where
+
+
 @pytest.mark.parametrize("K", [3, 4, 7, 12, 18])
 def test_exact_scan_equals_fast_path(K):
     """pe_dense's cold path (the reference's scan as written, taken when rnd < T does not hold) on every read."""
