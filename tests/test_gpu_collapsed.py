@@ -192,6 +192,36 @@ def test_collapsed_results_do_not_depend_on_batching(orc):
         assert np.array_equal(whole.result(i).samples, b.result(j).samples)
 
 
+def test_collapsed_chains_dealt_over_all_simds(orc):
+    """A batch of fewer wavefronts than the device has SIMDs gets fewer than 64 chains per wavefront (runtime.hip: the
+    launch of sampler_lane_ilp; kernels_lane.hip lane_body): 9000 chains -> nine per wavefront.  Sixteen events repeated
+    under their own ids: every copy equals the checker's run of the event, with the rule and without (MISO_LANE_SPREAD=0)."""
+    sizes = [300, 20, 0, 3, 150, 45, 64, 65, 31, 1, 333, 250, 120, 7, 90, 200]
+    evs = _events(orc, sizes)
+    kw = dict(iters=60, burn=10, lag=2, chains=1)
+    cpu = []
+    for i, (exons, isoforms, g, pos, cig) in enumerate(evs):
+        r = orc.miso(g, pos, cig, 36, mode=OrcLib.COLLAPSED, seed=31, event_id=500 + i, **kw)
+        assert r.rc == 0
+        cpu.append(r)
+    genes = [miso_amd.Gene(exons, isoforms) for exons, isoforms, g, pos, cig in evs]
+    n = 9000
+    for spread in (None, "0"):
+        with _env(MISO_LANE_SPREAD=spread):
+            b = miso_amd.Batch(36, collapsed=True, **kw)
+            for j in range(n):
+                i = j % 16
+                b.set_event_id(b.add_event(genes[i], evs[i][3], evs[i][4]), 500 + i)
+            b.run(seed=31, first_event_id=0)
+        assert b.last_kernels() == "sampler_lane_ilp"
+        for j in list(range(40)) + list(range(n - 40, n)) + list(range(1000, n, 997)):
+            r, gpu = cpu[j % 16], b.result(j)
+            assert np.array_equal(gpu.samples, r.samples, equal_nan=True), (j, spread)
+            assert np.array_equal(gpu.loglik, r.loglik, equal_nan=True), (j, spread)
+            assert (gpu.assignment == r.assignment).all(), (j, spread)
+            assert gpu.rundata.noAccepted == r.accepted, (j, spread)
+
+
 def test_collapsed_level_two_with_a_gene_of_forty_isoforms_and_no_ambiguous_read(orc):
     """a single-end gene of 33 - 64 isoforms none of whose reads is ambiguous kept `lane_gen` on (only events
     with drawing reads could switch it off) and sampler_lane_k -- 32-bit masks, an LDS slice beyond the CU's -- failed the
