@@ -898,9 +898,18 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     const long chains = static_cast<long>(run.count) * p.noChains;
     const int C = p.noChains;
     const char *env = std::getenv("MISO_FLAT_PACK");
-    const long key = (static_cast<long>(nc) * 4 + (env ? 1 + (std::atoi(env) != 0) : 0)) * 128 + nc_max;
+    const long key = ((static_cast<long>(nc) * 4 + (env ? 1 + (std::atoi(env) != 0) : 0)) * 128 + nc_max) * 2 + (std::getenv("MISO_FLAT_PACK_OV") ? 1 : 0);
     if (run.wave_key == key && run.d_wave_tab) return;
-    auto units_of = [&](long c) { return static_cast<long>(events[h_slots[n_k2 + run.first + c / C]].n_units); };
+    // (round 5) what a chain costs its wavefront, in work units: its units + the scalar step and thresholds, which do not
+    // depend on the reads -- measured per chain-iteration (profiles/r05_flat_chunks.txt): K = 5 238 VALU against 1.33 per
+    // unit, K = 10 641 against 1.96: about 30 K + 25 units.  Packing by units alone gave the wavefronts of many small chains
+    // (hg19-like read counts) up to twice the work of the others.  MISO_FLAT_PACK_OV=0: by units alone (A/B).
+    const char *ov_env = std::getenv("MISO_FLAT_PACK_OV");
+    const bool use_ov = !(ov_env && std::atoi(ov_env) == 0);
+    auto units_of = [&](long c) {
+      const PackedEvent &e = events[h_slots[n_k2 + run.first + c / C]];
+      return static_cast<long>(e.n_units) + (use_ov ? 30L * e.K + 25 : 0L);
+    };
     long total = 0, head = 0;
     for (long c = 0; c < chains; c++) { const long u = units_of(c); total += u; if (c < nc) head += u; }
     long heaviest = head;   // the list is ordered by isoforms first: look at every wavefront of the uniform rule
