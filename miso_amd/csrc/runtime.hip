@@ -898,17 +898,20 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     const long chains = static_cast<long>(run.count) * p.noChains;
     const int C = p.noChains;
     const char *env = std::getenv("MISO_FLAT_PACK");
-    const long key = ((static_cast<long>(nc) * 4 + (env ? 1 + (std::atoi(env) != 0) : 0)) * 128 + nc_max) * 2 + (std::getenv("MISO_FLAT_PACK_OV") ? 1 : 0);
+    const long key = ((static_cast<long>(nc) * 4 + (env ? 1 + (std::atoi(env) != 0) : 0)) * 128 + nc_max) * 1024 + (std::getenv("MISO_FLAT_PACK_OV") ? 1 + std::atol(std::getenv("MISO_FLAT_PACK_OV")) % 1000 : 0);
     if (run.wave_key == key && run.d_wave_tab) return;
     // (round 5) what a chain costs its wavefront, in work units: its units + the scalar step and thresholds, which do not
-    // depend on the reads -- measured per chain-iteration (profiles/r05_flat_chunks.txt): K = 5 238 VALU against 1.33 per
-    // unit, K = 10 641 against 1.96: about 30 K + 25 units.  Packing by units alone gave the wavefronts of many small chains
-    // (hg19-like read counts) up to twice the work of the others.  MISO_FLAT_PACK_OV=0: by units alone (A/B).
+    // depend on the reads.  Measured per chain-iteration at eight / five chains per wavefront (profiles/r05_flat_chunks.txt):
+    // K = 5 238 VALU against 1.33 per unit, K = 10 641 against 1.96, i.e. about 30 K + 25 units -- but the wavefronts this
+    // matters for carry 14 - 18 small chains, whose flat passes and leader sections are shared by twice as many chains:
+    // 16 K + 14.  Swept on hg19-like read counts at 25 ... 300 % of the first figure: K = 3 / 4 / 6 / 8 best at 50 % (208 /
+    // 152 / 107 / 80 k events/s against 153 / 144 / 97 / 74 k at 100 %), K = 5 / 12 at 100 % (122 / 45 k against 114 / 43 k);
+    // by units alone: 151 / 112 / 55 k at K = 3 / 5 / 10.  MISO_FLAT_PACK_OV=<per cent of the rule> (0: by units alone).
     const char *ov_env = std::getenv("MISO_FLAT_PACK_OV");
-    const bool use_ov = !(ov_env && std::atoi(ov_env) == 0);
+    const long ov_pct = ov_env ? std::atol(ov_env) : 100;   // (per cent of the rule: experiments)
     auto units_of = [&](long c) {
       const PackedEvent &e = events[h_slots[n_k2 + run.first + c / C]];
-      return static_cast<long>(e.n_units) + (use_ov ? 30L * e.K + 25 : 0L);
+      return static_cast<long>(e.n_units) + (16L * e.K + 14) * ov_pct / 100;
     };
     long total = 0, head = 0;
     for (long c = 0; c < chains; c++) { const long u = units_of(c); total += u; if (c < nc) head += u; }
@@ -949,8 +952,24 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       const long n_waves = pack_with(std::max(64.0, per_chain * (forced ? nc : cap)));
       if (!forced && n_waves < 3 * resident / 2) {
         const double want = 0.95 * static_cast<double>(n_waves <= resident ? resident : 2 * resident);
-        if (static_cast<double>(n_waves) < want) pack_with(std::max(64.0, static_cast<double>(total) / want));
+        if (static_cast<double>(n_waves) < want) {
+          // (round 5) ... and not a few wavefronts MORE than the round(s): the packing's bound is a target, the count it
+          // makes lands some per cent off, and 3110 wavefronts on 3072 slots cost a second round for 38 of them
+          // (K = 3, hg19-like read counts: 154 k events/s there, 212 k at 2960; profiles/r05_flat_chunks.txt)
+          const long target = n_waves <= resident ? resident : 2 * resident;
+          double U2 = std::max(64.0, static_cast<double>(total) / want);
+          long n2 = pack_with(U2);
+          for (int it = 0; it < 8 && n2 > target; it++) {
+            const long before = n2;
+            U2 *= static_cast<double>(n2) / (0.97 * static_cast<double>(target));
+            n2 = pack_with(U2);
+            if (n2 >= before) break;   // the chains per wavefront are at the LDS's limit: fuller wavefronts are not to be had
+          }
+        }
       }
+      if (std::getenv("MISO_TIMING"))
+        std::fprintf(stderr, "[flat_waves] kc %d chains %ld cost/chain %.1f cap %d resident %ld first pack %ld waves -> %zu waves + %zu wide, most chains %d\n",
+                     run.kc, chains, per_chain, cap, resident, n_waves, waves.size(), wides.size(), most);
       std::stable_sort(wides.begin(), wides.end(), [](const W &x, const W &y) { return x.units > y.units; });
       std::stable_sort(waves.begin(), waves.end(), [](const W &x, const W &y) { return x.units > y.units; });
       run.wave_nc = most;
