@@ -352,13 +352,16 @@ def valu_floor(K, paired, draws_per_chain):
     return draws_per_chain / 256.0 * per_block + scalar
 
 
-def roofline_for(batch, kernel_ms, key, sh):
+def roofline_for(batch, kernel_ms, key, sh, clock=None):
     """The launch against the bound that applies to it.  The sampler kernels are VALU-issue bound (no HBM
     stream, no MFMA): `achieved` = VALU issue cycles the launch needs per second of kernel time.  It is a MODEL
     (`frac_source`): VALU wave-instructions per chain-iteration and the issue cycles one takes come from the
     committed rocprofv3 PMC passes of this very workload and these very kernels (profiles/valu_model.json,
     tools/prof_summary.py), scaled to this run's chains, iterations and MEASURED kernel time; `peak` = 1024 SIMDs
-    x 2.4 GHz.  A profile of other kernels than the ones this run launched is refused (frac null).
+    x the shader clock THIS run's kernels ran at (`clock`: measure_clock below; 2.4 GHz nominal without it).  The
+    model prices a run whose launch took as many shader CYCLES as the profiled one (within 5 %): a box at another
+    clock keeps its figure, a changed kernel or launch plan loses it.  A profile of other kernels than the ones this
+    run launched is refused (frac null).
     `floor_frac` = the instruction floor / the profiled instructions per chain-iteration: useful issue, not busy
     issue.  Beside them: the share of the Philox ceiling, the measured HBM fraction and SURVEY 8(d)'s
     algorithmic-bytes figure."""
@@ -366,7 +369,11 @@ def roofline_for(batch, kernel_ms, key, sh):
     name = batch.last_kernels()
     t = kernel_ms * 1e-3
     alg_bytes = batch.algorithmic_bytes()
-    out = {"bound": "valu", "unit": "Gcycle/s", "peak": round(VALU_PEAK_GCYC, 1),
+    ghz = clock["ghz"] if clock and clock.get("ghz") else None
+    peak = SIMDS * ghz if ghz else VALU_PEAK_GCYC
+    out = {"bound": "valu", "unit": "Gcycle/s", "peak": round(peak, 1), "peak_nominal": round(VALU_PEAK_GCYC, 1),
+           "clock_ghz": None if ghz is None else round(ghz, 4),
+           "clock_source": None if not clock else clock.get("source"),
            "kernel": name, "kernel_ms": round(kernel_ms, 3)}
     m = load_json("valu_model.json").get(key)
     chain_iters = sum(k["chains"] * k["iterations"] for k in stats["kernels"])
@@ -379,17 +386,33 @@ def roofline_for(batch, kernel_ms, key, sh):
     # the committed profile's own kernel time (rocprofv3 --kernel-trace of the same command; several kernels side by side:
     # the longest): the model's instructions per chain-iteration only price THIS run if the profiled launch took as long --
     # a kernel changed since, a box at another clock, a different launch plan all show up here
-    prof_ms = None
+    prof_ms = prof_ghz = None
     if m is not None:
         ns = [v.get("kernel_ns") for v in m["kernels"].values() if v.get("kernel_ns")]
-        prof_ms = max(ns) / 1e6 if ns else None
+        prof_ms = m["launch_span_ns"] / 1e6 if m.get("launch_span_ns") else (max(ns) / 1e6 if ns else None)
+        # the profiled launch's own clock: recorded by the profile pass (tools/prof_summary.py), or -- one kernel alone on
+        # the device -- GRBM_GUI_ACTIVE per XCD over the traced duration
+        prof_ghz = m.get("clock_ghz")
+        if not prof_ghz and len(m["kernels"]) == 1:
+            v = next(iter(m["kernels"].values()))
+            if v.get("kernel_cycles") and v.get("kernel_ns"):
+                prof_ghz = v["kernel_cycles"] / v["kernel_ns"]
     out["profile_kernel_ms"] = None if prof_ms is None else round(prof_ms, 3)
+    out["profile_clock_ghz"] = None if not prof_ghz else round(prof_ghz, 4)
     tol = 0.05 if m is None or len(m["kernels"]) == 1 else 0.10
-    stale = prof_ms is not None and abs(prof_ms - kernel_ms) > tol * kernel_ms
+    if ghz and prof_ghz and prof_ms is not None:     # cycles against cycles
+        out["kernel_Mcycles"] = round(kernel_ms * ghz * 1e3, 2)
+        out["profile_kernel_Mcycles"] = round(prof_ms * prof_ghz * 1e3, 2)
+        stale = abs(prof_ms * prof_ghz - kernel_ms * ghz) > tol * kernel_ms * ghz
+        stale_what = "%.2f M shader cycles, this run's %.2f M" % (prof_ms * prof_ghz * 1e3, kernel_ms * ghz * 1e3)
+    else:                                            # no clock on one side: milliseconds against milliseconds
+        stale = prof_ms is not None and abs(prof_ms - kernel_ms) > tol * kernel_ms
+        stale_what = "%.3f ms, this run's %.3f ms" % (prof_ms or 0.0, kernel_ms)
     if m is not None and profiled == launched and not stale:
         cyc = m["valu_per_chain_iteration"] * chain_iters * m["issue_cycles_per_valu"]
         out["achieved"] = round(cyc / t / 1e9, 1)
-        out["frac"] = round(cyc / t / 1e9 / VALU_PEAK_GCYC, 4)
+        out["frac"] = round(cyc / t / 1e9 / peak, 4)
+        out["frac_nominal_clock"] = round(cyc / t / 1e9 / VALU_PEAK_GCYC, 4)
         out["frac_source"] = ("model: VALU instructions per chain-iteration x issue cycles per instruction from the committed "
                               "rocprofv3 PMC pass of this workload and these kernels (profiles/valu_model.json <- %s), x this "
                               "run's chain-iterations / this run's measured kernel time" % m["source"])
@@ -409,8 +432,8 @@ def roofline_for(batch, kernel_ms, key, sh):
         out["achieved"] = None
         out["frac"] = None
         out["frac_source"] = ("no rocprofv3 PMC pass committed for this workload (%s)" % key) if m is None else \
-            ("the committed profile's launch took %.3f ms, this run's %.3f ms (more than %d %% apart): the model does not price "
-             "this run, re-profile" % (prof_ms, kernel_ms, round(100 * tol))) if (profiled == launched and stale) else \
+            ("the committed profile's launch took %s (more than %d %% apart): the model does not price "
+             "this run, re-profile" % (stale_what, round(100 * tol))) if (profiled == launched and stale) else \
             ("the committed profile of this workload is of other kernels (%s): re-profile" % ",".join(profiled))
     out["draws_per_chain"] = round(draws, 1)
     # (tools/rng_bench.hip, MI355X: philox4x32-10 2885 G words/s, philox4x32-7 the same generator at 7 / 10 of the rounds)
@@ -450,6 +473,26 @@ def time_batch(batch, seed, first, steps, warmup, barrier=None):
     if barrier:
         barrier()
     return time.perf_counter() - t0, kernel_ms
+
+
+def measure_clock(batch, seed, first, kernel_ms):
+    """The shader clock the timed launches ran at: ONE more launch of the same batch right behind them, with the library's
+    clock probe on (include/miso_amd.h miso_batch_set_clock_probe: one sleeping wavefront beside the sampler kernels that
+    reads s_memtime against the constant reference clock over exactly the launch).  Outside the timed region; the probed
+    launch's own kernel time is reported so that it can be seen to be one of the timed ones."""
+    try:
+        batch.set_clock_probe(True)
+        batch.launch(seed=seed, first_event_id=first)
+        ms = batch.sync()
+        ghz, window = batch.last_clock()
+    finally:
+        batch.set_clock_probe(False)
+    # (the probe's wavefront takes registers on one SIMD: a kernel that fills the register file loses a workgroup slot there)
+    ok = ghz > 0.0 and abs(ms - kernel_ms) <= 0.06 * kernel_ms
+    return {"ghz": ghz if ok else None, "probe_kernel_ms": round(ms, 3), "probe_window_ms": round(window, 3),
+            "source": ("s_memtime / wall_clock64 of one wavefront beside the kernels of one more launch behind the timed ones "
+                       "(%.3f ms; the timed launches' average %.3f ms)" % (ms, kernel_ms)) if ok else
+                      ("no clock: probe window %.3f ms, probed launch %.3f ms against %.3f ms timed" % (window, ms, kernel_ms))}
 
 
 def stream_rows(batch, n_events, sh, first, seed, device):
@@ -495,10 +538,11 @@ def matrix_row(a, local_rank, wid, label, sh, n, st, collapsed=False):
     b.upload(local_rank)
     elapsed, kms = time_batch(b, a.seed, 0, 2, 1)
     avg = sum(kms) / len(kms)
-    r = roofline_for(b, avg, workload_key(n, sh) + ("|collapsed" if collapsed else ""), sh)
+    r = roofline_for(b, avg, workload_key(n, sh) + ("|collapsed" if collapsed else ""), sh, measure_clock(b, a.seed, 0, avg))
     row = {"id": wid, "workload": label, "events": n, "events_per_s": round(2 * n / elapsed, 1),
            "reads_iter_per_s": round(2.0 * total_reads * sh["chains"] * sh["iters"] / elapsed, 1),
-           "kernel": r["kernel"], "kernel_ms": r["kernel_ms"], "valu_frac": r["frac"], "floor_frac": r.get("floor_frac"),
+           "kernel": r["kernel"], "kernel_ms": r["kernel_ms"], "clock_ghz": r["clock_ghz"], "valu_frac": r["frac"],
+           "valu_frac_nominal_clock": r.get("frac_nominal_clock"), "floor_frac": r.get("floor_frac"),
            "frac_source": r["frac_source"], "rng_frac": r["rng_frac"], "hbm_measured_frac": r["hbm_measured_frac"],
            "algorithmic_GBs": r["algorithmic_GBs"]}
     if collapsed:
@@ -531,7 +575,7 @@ def run_matrix(a, local_rank, studies, main_sh=None):
     return rows
 
 
-MATRIX_COLS = ["id", "events_per_s", "kernel_ms", "valu_frac", "floor_frac", "hbm_measured_frac", "cpu", "dpsi_pass", "max_z", "p_row"]
+MATRIX_COLS = ["id", "events_per_s", "kernel_ms", "clock_ghz", "valu_frac", "floor_frac", "hbm_measured_frac", "cpu", "dpsi_pass", "max_z", "p_row"]
 
 
 def _r(x, n):
@@ -551,6 +595,8 @@ def compact_line(full):
     kern = r.get("kernel")
     out["roofline"] = {"bound": r.get("bound"), "kernel": None if kern is None else kern[:96], "kernel_ms": r.get("kernel_ms"),
                        "achieved": r.get("achieved"), "peak": r.get("peak"), "unit": r.get("unit"), "frac": r.get("frac"),
+                       "clock_ghz": r.get("clock_ghz"), "kernel_Mcycles": r.get("kernel_Mcycles"),
+                       "profile_kernel_Mcycles": r.get("profile_kernel_Mcycles"),
                        "floor_frac": r.get("floor_frac"), "traffic": _r(r.get("traffic"), 0), "hbm_measured_frac": r.get("hbm_measured_frac"),
                        "algorithmic_GBs": r.get("algorithmic_GBs"), "bytes_frac_8d": r.get("bytes_frac_8d"),
                        "profile_kernel_ms": r.get("profile_kernel_ms"),
@@ -572,7 +618,7 @@ def compact_line(full):
         rows = []
         for m in full["matrix"]:
             dp = m.get("delta_psi") or {}
-            rows.append([m["id"], round(m["events_per_s"]), _r(m["kernel_ms"], 2), _r(m["valu_frac"], 3), _r(m.get("floor_frac"), 3),
+            rows.append([m["id"], round(m["events_per_s"]), _r(m["kernel_ms"], 2), _r(m.get("clock_ghz"), 3), _r(m["valu_frac"], 3), _r(m.get("floor_frac"), 3),
                          _r(m["hbm_measured_frac"], 3), _r((m.get("cpu_baseline") or {}).get("value"), 1),
                          "retry_pass" if (dp.get("pass") is False and dp.get("confirmed_fail") is False) else dp.get("pass"),
                          _r(dp.get("max_z"), 2), _r(dp.get("p_row"), 4)])
@@ -713,7 +759,8 @@ def main():
             roof = {"bound": "valu", "achieved": None, "peak": VALU_PEAK_GCYC, "unit": "Gcycle/s", "frac": None,
                     "traffic": None}
         else:
-            roof = roofline_for(batch, avg_ms, workload_key(n_local, sh) + ("|collapsed" if a.collapsed else ""), sh)
+            roof = roofline_for(batch, avg_ms, workload_key(n_local, sh) + ("|collapsed" if a.collapsed else ""), sh,
+                                measure_clock(batch, a.seed, first, avg_ms))
         cpu = delta = None
         if studies and "main" in studies:
             cpu = studies["main"]["baseline"]

@@ -305,6 +305,14 @@ typedef struct {
 } miso_kernel_stat_t;
 int miso_batch_launch_stats(const miso_batch_t *batch, miso_kernel_stat_t *stats, int max_kernels,
                             int *n_kernels);
+/* Measurement: the shader clock the last launch ran at.  With the probe on, every launch starts ONE extra wavefront on a
+   stream of its own that sleeps beside the sampler kernels and reads the shader-cycle counter (s_memtime) and the
+   constant reference clock (hipDeviceAttributeWallClockRate) at both ends of the launch; miso_batch_sync() turns the pair
+   into cycles per nanosecond.  *shader_ghz = 0 when the probe is off or its window did not cover the launch (its stream
+   shared the batch's hardware queue, a profiler serialised the dispatches); *window_ms = what it covered.  The reference
+   has no counterpart (a CPU's clock is not part of its results either): bench.py prices its VALU roofline with it. */
+int miso_batch_set_clock_probe(miso_batch_t *batch, int on);
+int miso_batch_last_clock(const miso_batch_t *batch, double *shader_ghz, double *window_ms);
 /* Host arithmetic, no device needed: the lanes-per-chain plan of the two-isoform sampler's one-launch-many-widths
    kernel (sampler_k2_multi) for a list of events ordered by drawing reads, most first -- the answer to "events are
    independent and cost O(reads)" (miso.c:845-900) on a machine whose unit of work is a 64-lane wavefront.

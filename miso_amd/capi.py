@@ -381,6 +381,16 @@ class Batch:
         check(lib().miso_batch_rounds(self.handle, C.byref(n)))
         return n.value
 
+    def set_clock_probe(self, on=True):
+        """Measure the shader clock of every following launch (include/miso_amd.h miso_batch_set_clock_probe)."""
+        check(lib().miso_batch_set_clock_probe(self.handle, int(bool(on))))
+
+    def last_clock(self):
+        """(shader clock in GHz, the probe's window in ms) of the last synced launch; (0.0, 0.0) without a valid probe."""
+        ghz, ms = C.c_double(0.0), C.c_double(0.0)
+        check(lib().miso_batch_last_clock(self.handle, C.byref(ghz), C.byref(ms)))
+        return ghz.value, ms.value
+
     def coop_retries(self):
         """Launches sync() repeated with one workgroup per chain after a chain on several workgroups timed out."""
         n = C.c_int(0)

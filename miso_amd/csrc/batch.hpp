@@ -42,6 +42,13 @@ struct miso_batch {
   // stop = CONVERGENT_MEAN (miso.c:903-925): sync() runs the events that have not converged again on the longer
   // schedule (runtime.hip converge_rounds) and puts the tail of their samples where the first round's were
   std::vector<int64_t> iters_counted;   // per event: iterations behind its accept count (empty: noIterations each)
+  // a batch that runs a LATER round (made by converge_rounds): that round's own schedule, the reference's noIterations /
+  // noBurnIn at that point (p holds the device's: everything from the chain's start), and the iterations at which the
+  // rounds after the first open (KernelArgs::round_start)
+  int round_iters = 0, round_burn = 0;
+  std::vector<int> round_starts;
+  std::vector<char> went_on;      // per event: it ran a further round in the last launch's converge_rounds
+  bool event_went_on(int i) const { return i < static_cast<int>(went_on.size()) && went_on[i] != 0; }
   int rounds = 1;                 // rounds the last launch took (1 = the events' own schedule sufficed)
   int prio_lo = 0, prio_hi = 0;   // the device's stream priority range as this batch uses it (equal: priorities off)
   bool converged_done = false;    // stop = CONVERGENT_MEAN: this launch's further rounds have run (sync() is idempotent; launch() clears it)
@@ -49,6 +56,15 @@ struct miso_batch {
   bool coop_enabled() const;      // chains may use several workgroups (coop.hpp): not after a time-out, not with MISO_NO_COOP=1
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // the shader clock of a launch (miso_batch_set_clock_probe; runtime.hip clock_probe_kernel)
+  bool clock_probe = false, probe_armed = false, probe_failed = false;
+  hipStream_t probe_stream = nullptr;
+  unsigned long long *d_probe = nullptr;   // {t0 real, t0 cycles, t1 real, t1 cycles, gave up, -, -, flag}
+  uint32_t probe_gen = 0;                  // the flag's value that ends the current launch's probe
+  double wall_khz = 100000.0;              // hipDeviceAttributeWallClockRate
+  double last_clock_ghz = 0.0, last_probe_ms = 0.0;   // 0: no probe, or its window did not cover the launch
+  void start_clock_probe();
+  void read_clock_probe();
   std::vector<hipStream_t> aux_streams;   // kernels 2.. of a mixed batch run beside the first
   std::vector<hipEvent_t> aux_done;
   miso::DevEvent *d_events = nullptr;

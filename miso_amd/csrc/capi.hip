@@ -679,6 +679,18 @@ int miso_batch_get_match(const miso_batch_t *b, int i, double *match, int *fragm
   });
 }
 
+int miso_batch_set_clock_probe(miso_batch_t *b, int on) {
+  return guarded([&] { need(b, "batch"); b->clock_probe = on != 0; if (on) b->probe_failed = false; });
+}
+
+int miso_batch_last_clock(const miso_batch_t *b, double *shader_ghz, double *window_ms) {
+  return guarded([&] {
+    need(b, "batch");
+    if (shader_ghz) *shader_ghz = b->last_clock_ghz;
+    if (window_ms) *window_ms = b->last_probe_ms;
+  });
+}
+
 int miso_batch_coop_retries(const miso_batch_t *b, int *n) {
   return guarded([&] { need(b, "batch"); need(n, "n"); *n = b->coop_retries; });
 }

@@ -83,6 +83,7 @@ struct ChainStats {
 
 constexpr int FLAT_WIDE = 0x100;  // sampler_flat wave_tab: the workgroup's four wavefronts share ONE chain
 constexpr int K2_MAX_SEGS = 16;
+constexpr int MISO_MAX_ROUNDS = 8;   // stop = CONVERGENT_MEAN: rounds a device launch can reproduce (every round at least doubles the kept window)
 constexpr int K2_WIDE = 512;   // seg_lanes value: one chain per workgroup
 constexpr int K2_RED_BYTES = 2 * 8 * 16 + 16;   // two buffers x (up to) 8 wavefronts x {int64 score sum, int count, int bad} + the barrier's flag
 
@@ -122,11 +123,32 @@ struct KernelArgs {
   // sampler_k2_multi (kernels_k2m.hip): the launch's events (ordered by drawing reads, most first) cut into runs
   // of equal lanes per chain.  Run s: workgroups [seg_block[s], seg_block[s + 1]), events (slots)
   // [seg_slot[s], seg_slot[s + 1]) of the launch's list, seg_lanes[s] lanes per chain (K2_WIDE = the whole workgroup).
+  // stop = CONVERGENT_MEAN (runtime.hip converge_rounds): the iterations that open a later round of the reference's loop,
+  // ascending, unused entries -1 (every launch of stop = FIXEDNO: all -1)
+  int32_t round_start[MISO_MAX_ROUNDS - 1];
   int32_t n_segs;
   int32_t seg_block[K2_MAX_SEGS + 1];
   int32_t seg_slot[K2_MAX_SEGS + 1];
   int32_t seg_lanes[K2_MAX_SEGS];
 };
+
+#ifdef __HIPCC__
+// The reference's loop counter starts at 0 in every round of stop = CONVERGENT_MEAN (miso.c:845 `for (m=0, ...` inside
+// `while (1)`), and with it the rule that a round's first Metropolis-Hastings ratio leaves the proposal terms out
+// (miso.c:866 `m > 0 ? 1 : 0`).  A launch that re-runs a chain from its start through round r (runtime.hip
+// converge_rounds) is told where the later rounds open; at() is called once per iteration, in order.
+struct RoundOpen {
+  int next, i;
+  __device__ explicit RoundOpen(const KernelArgs &a) : next(a.round_start[0]), i(0) {}
+  __device__ bool at(const KernelArgs &a, int m) {
+    if (m == 0) return true;
+    if (m != next) return false;
+    i++;
+    next = i < MISO_MAX_ROUNDS - 1 ? a.round_start[i] : -1;
+    return true;
+  }
+};
+#endif
 
 constexpr uint64_t NO_TRACE = ~0ull;
 constexpr uint64_t NO_DENSE = ~0ull;

@@ -271,7 +271,9 @@ __global__ __launch_bounds__(256) void sampler_wave(const KernelArgs a) {
   uint64_t hash = 0xCBF29CE484222325ull;
   int accepted = 0, lagCounter = 0, noS = 0;
 
+  RoundOpen ro(a);
   for (int m = 0; m < a.M; m++) {
+    const bool opens = ro.at(a, m);   // a round's first iteration: no proposal terms (miso.c:866)
     for (int k = 0; k < K; k++) hash = (hash ^ static_cast<uint32_t>(bcast_i(cnt, k))) * 0x100000001B3ull;
     if (trace && lane < K) trace[(static_cast<size_t>(m) * a.C + chain) * K + lane] = cnt;
 
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(256) void sampler_wave(const KernelArgs a) {
     const double pc = joint_score<PE>(psi, cnt, rp, c, K, lane);
     const double ptoCS = proposal_score(psi, alphaN, c, K, lane);
     const double ctoPS = proposal_score(psiN, alpha, c, K, lane);
-    const double acceptP = (m > 0) ? miso_det_exp(pp + ptoCS - (pc + ctoPS)) : miso_det_exp(pp - pc);
+    const double acceptP = !opens ? miso_det_exp(pp + ptoCS - (pc + ctoPS)) : miso_det_exp(pp - pc);
     const bool acc = (acceptP >= 1) || (miso_u01(accept_word) < acceptP);
     double cJS = pc;
     if (acc) { psi = psiN; alpha = alphaN; cJS = pp; accepted++; }

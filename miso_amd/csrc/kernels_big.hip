@@ -234,7 +234,9 @@ __global__ __launch_bounds__(64) void sampler_big(const KernelArgs a) {
 
   uint64_t hash = 0xCBF29CE484222325ull;
   int accepted = 0, lagCounter = 0, noS = 0;
+  RoundOpen ro(a);
   for (int m = 0; m < a.M; m++) {
+    const bool opens = ro.at(a, m);   // a round's first iteration: no proposal terms (miso.c:866)
     for (int k = 0; k < K; k++) hash = (hash ^ static_cast<uint32_t>(S.cnt[k])) * 0x100000001B3ull;
     if (trace) for (int k = lane; k < K; k += 64) trace[(static_cast<size_t>(m) * a.C + chain) * K + k] = S.cnt[k];
     propose(S.alpha, S.alphaN, S.psiN, static_cast<uint32_t>(m), accept_word);
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(64) void sampler_big(const KernelArgs a) {
     const double pc = big_joint<PE>(S, S.psi, rp, c, K, lane);
     const double ptoCS = big_proposal(S, S.psi, S.alphaN, c, K, lane);
     const double ctoPS = big_proposal(S, S.psiN, S.alpha, c, K, lane);
-    const double acceptP = (m > 0) ? miso_det_exp(pp + ptoCS - (pc + ctoPS)) : miso_det_exp(pp - pc);
+    const double acceptP = !opens ? miso_det_exp(pp + ptoCS - (pc + ctoPS)) : miso_det_exp(pp - pc);
     const bool acc = (acceptP >= 1) || (miso_u01(accept_word) < acceptP);
     double cJS = pc;
     if (acc) {

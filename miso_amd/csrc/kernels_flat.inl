@@ -841,7 +841,9 @@ __global__ __launch_bounds__(256, KC <= 4 ? MISO_FLAT_WGS_4 : (KC <= 8 ? MISO_FL
   gibbs(MISO_ITER_INIT);
 
   const bool tracing = __any(LE_.off_trace != NO_TRACE);   // all events of a batch trace or none
+  RoundOpen ro(a);
   for (int m = 0; m < a.M; m++) {
+    const bool opens = ro.at(a, m);   // a round's first iteration: no proposal terms (miso.c:866)
     // this iteration's view of the counts: the leader's registers (hash, both joint scores)
     int cn[KB];
     if (leader) {
@@ -942,7 +944,7 @@ __global__ __launch_bounds__(256, KC <= 4 ? MISO_FLAT_WGS_4 : (KC <= 8 ? MISO_FL
         pj[which] = rp[which] + ap[which] + psiProb;
       }
       const double pp = pj[0], pc = pj[1];
-      const double acceptP = (m > 0) ? miso_det_exp(pp + ptoCS - (pc + ctoPS)) : miso_det_exp(pp - pc);  // pass 6
+      const double acceptP = !opens ? miso_det_exp(pp + ptoCS - (pc + ctoPS)) : miso_det_exp(pp - pc);  // pass 6
       const bool acc = (acceptP >= 1) || (miso_u01(accw) < acceptP);
       cJS = pc;
       FI(ls, L.misc)[MI_ACC] = acc ? 1 : 0;

@@ -1391,7 +1391,9 @@ __device__ __forceinline__ void grp_body(const KernelArgs &a, unsigned block_x) 
   uint64_t hash = 0xCBF29CE484222325ull;
   int accepted = 0, lagCounter = 0, noS = 0;
 
+  RoundOpen ro(a);
   for (int m = 0; m < a.M; m++) {
+    const bool opens = ro.at(a, m);   // a round's first iteration: no proposal terms (miso.c:866)
     if (WIDE && !coop_ok) return;   // the chain's workgroups gave up waiting for each other (coop.hpp): the host reports it
 #pragma unroll 1
     for (int k0 = 0; k0 < (MH_ONE ? 1 : Kw); k0 += MH_CH) {
@@ -1450,7 +1452,7 @@ __device__ __forceinline__ void grp_body(const KernelArgs &a, unsigned block_x) 
                          : 0.0;
     const double pp = joint_sums(S.lpN, S.tbN, lseN, rp);
     const double pc = joint_sums(S.lp, S.tb, lse, rp);
-    const double acceptP = (m > 0) ? miso_det_exp(pp + ptoCS - (pc + ctoPS)) : miso_det_exp(pp - pc);  // pass 6
+    const double acceptP = !opens ? miso_det_exp(pp + ptoCS - (pc + ctoPS)) : miso_det_exp(pp - pc);  // pass 6
     const bool acc = (acceptP >= 1) || (miso_u01(accept_word) < acceptP);
     double cJS = pc;
     wave_sync();

@@ -798,7 +798,9 @@ __device__ __forceinline__ void k2_body(const KernelArgs &a, unsigned block_x, u
   const bool writer = live && sub == 0;
 
   double zbuf = 0.0; uint32_t awbuf = 0u;   // this lane's share of the next NR iterations' MH draws
+  RoundOpen ro(a);
   for (int m = 0; m < a.M; m++) {
+    const bool opens = ro.at(a, m);   // a round's first iteration: no proposal terms (miso.c:866)
     if (WIDE && !coop_ok) return;   // the chain's workgroups gave up waiting for each other (coop.hpp): the host reports it
     hash = (hash ^ static_cast<uint32_t>(cnt0)) * 0x100000001B3ull;
     hash = (hash ^ static_cast<uint32_t>(cnt1)) * 0x100000001B3ull;
@@ -850,7 +852,7 @@ __device__ __forceinline__ void k2_body(const KernelArgs &a, unsigned block_x, u
                          : 0.0;
     const double pp = joint<PE>(nw, cnt0, cnt1, c, rp);
     const double pc = joint<PE>(cur, cnt0, cnt1, c, rp);
-    const double acceptP = (m > 0) ? k2_exp(pp + ptoCS - (pc + ctoPS)) : k2_exp(pp - pc);
+    const double acceptP = !opens ? k2_exp(pp + ptoCS - (pc + ctoPS)) : k2_exp(pp - pc);
     const bool acc = (acceptP >= 1) || (miso_u01(accept_word) < acceptP);
     double cJS = pc;
     if (acc) { cur = nw; alpha = alphaN; cJS = pp; accepted++; }

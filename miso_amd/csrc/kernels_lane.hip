@@ -240,7 +240,9 @@ __device__ __forceinline__ void lane_body(const KernelArgs &a, double *lds_lf) {
 
   uint64_t hash = 0xCBF29CE484222325ull;
   int accepted = 0, lagCounter = 0, noS = 0;
+  RoundOpen ro(a);
   for (int m = 0; m < a.M; m++) {
+    const bool opens = ro.at(a, m);   // a round's first iteration: no proposal terms (miso.c:866)
     hash = (hash ^ static_cast<uint32_t>(cnt0)) * 0x100000001B3ull;
     hash = (hash ^ static_cast<uint32_t>(cnt1)) * 0x100000001B3ull;
     if (trace) {
@@ -316,12 +318,12 @@ __device__ __forceinline__ void lane_body(const KernelArgs &a, double *lds_lf) {
     const double pc = joint<false>(cur, cnt0, cnt1, c, 0.0);
     double acceptP;
     if constexpr (ILP) {
-      const double in[1] = {(m > 0) ? pp + ptoCS - (pc + ctoPS) : pp - pc};
+      const double in[1] = {!opens ? pp + ptoCS - (pc + ctoPS) : pp - pc};
       double o[1];
       det_exp_n<1>(in, o, TE);
       acceptP = o[0];
     } else {
-      acceptP = (m > 0) ? miso_det_exp(pp + ptoCS - (pc + ctoPS)) : miso_det_exp(pp - pc);
+      acceptP = !opens ? miso_det_exp(pp + ptoCS - (pc + ctoPS)) : miso_det_exp(pp - pc);
     }
     const bool acc = (acceptP >= 1) || (miso_u01(accept_word) < acceptP);
     double cJS = pc;
@@ -536,7 +538,9 @@ __global__ __launch_bounds__(64) void sampler_lane_k(const KernelArgs a) {
 
   uint64_t hash = 0xCBF29CE484222325ull;
   int accepted = 0, lagCounter = 0, noS = 0;
+  RoundOpen ro(a);
   for (int m = 0; m < a.M; m++) {
+    const bool opens = ro.at(a, m);   // a round's first iteration: no proposal terms (miso.c:866)
     for (int i = 0; i < K; i++) {
       const int ci = CNT(i);
       hash = (hash ^ static_cast<uint32_t>(ci)) * 0x100000001B3ull;
@@ -549,7 +553,7 @@ __global__ __launch_bounds__(64) void sampler_lane_k(const KernelArgs a) {
     const double pc = joint(LP, lse);
     const double ptoCS = prop_score(LR, ALPHAN, jac);      // theta = psi,  mu = alpha'
     const double ctoPS = prop_score(LRN, ALPHA, jacN);     // theta = psi', mu = alpha
-    const double acceptP = (m > 0) ? miso_det_exp(pp + ptoCS - (pc + ctoPS)) : miso_det_exp(pp - pc);
+    const double acceptP = !opens ? miso_det_exp(pp + ptoCS - (pc + ctoPS)) : miso_det_exp(pp - pc);
     const bool acc = (acceptP >= 1) || (miso_u01(accept_word) < acceptP);
     double cJS = pc;
     if (acc) {

@@ -118,7 +118,9 @@ __global__ __launch_bounds__(64) void sampler_marginal(const KernelArgs a) {
   // (the parity instrumentation hashes every iteration's assignment counts: this algorithm has none, all zero)
   uint64_t hash = 0xCBF29CE484222325ull;
   int accepted = 0, lagCounter = 0, noS = 0;
+  RoundOpen ro(a);
   for (int m = 0; m < a.M; m++) {
+    const bool opens = ro.at(a, m);   // a round's first iteration: no proposal terms (miso.c:866)
     for (int i = 0; i < K; i++) hash = (hash ^ 0u) * 0x100000001B3ull;
     propose(ALPHA, ALPHAN, PSIN, static_cast<uint32_t>(m), accept_word);
     double jacN;
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(64) void sampler_marginal(const KernelArgs a) {
     const double pp = joint(PSIN, LPN);
     const double ptoCS = prop_score(LR, ALPHAN, jac);      // theta = psi,  mu = alpha'
     const double ctoPS = prop_score(LRN, ALPHA, jacN);     // theta = psi', mu = alpha
-    const double acceptP = (m > 0) ? miso_det_exp(pp + ptoCS - (pc + ctoPS)) : miso_det_exp(pp - pc);
+    const double acceptP = !opens ? miso_det_exp(pp + ptoCS - (pc + ctoPS)) : miso_det_exp(pp - pc);
     const bool acc = (acceptP >= 1) || (miso_u01(accept_word) < acceptP);
     if (acc) {
       for (int i = 0; i < K; i++) { LV(PSI, i) = LV(PSIN, i); LV(LP, i) = LV(LPN, i); }

@@ -53,6 +53,30 @@ __global__ void selftest_philox_kernel(const uint32_t *, int, uint32_t *);
       MISO_FAIL(MISO_ENODEVICE, std::string(#call) + ": " + hipGetErrorString(e_));        \
   } while (0)
 
+// ---- the shader clock a launch ran at (miso_batch_set_clock_probe; bench.py's roofline prices its VALU peak with it) ----
+// ONE wavefront beside the sampler kernels, on a stream of its own: it sleeps, looks at a flag the batch's stream sets
+// behind its last kernel, and leaves with the two counters' values at both ends -- s_memtime counts shader cycles,
+// wall_clock64() the constant reference clock (hipDeviceAttributeWallClockRate: 100 MHz here) -- so cycles / time over exactly the launch.  No VALU work, no LDS: it
+// takes one wave slot of one SIMD.  The flag carries the launch's number (nothing to reset between launches).  It gives up after `max_ticks` of the reference clock (a flag that never comes must
+// not hold the device).  out: {t0 real, t0 cycles, t1 real, t1 cycles, 1 = gave up}.
+__global__ void clock_probe_kernel(const uint32_t *flag, uint32_t want, unsigned long long *out, unsigned long long max_ticks) {
+  if (threadIdx.x != 0) return;
+  const unsigned long long r0 = static_cast<unsigned long long>(wall_clock64()), c0 = __builtin_readcyclecounter();
+  unsigned long long r1 = r0;
+  uint32_t f = 0;
+  do {
+    __builtin_amdgcn_s_sleep(127);
+    f = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    r1 = static_cast<unsigned long long>(wall_clock64());
+  } while (f != want && r1 - r0 < max_ticks);
+  const unsigned long long c1 = __builtin_readcyclecounter();
+  r1 = static_cast<unsigned long long>(wall_clock64());
+  out[0] = r0; out[1] = c0; out[2] = r1; out[3] = c1; out[4] = f != want;
+}
+__global__ void clock_probe_stop(uint32_t *flag, uint32_t value) {
+  if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 int device_count() {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -108,6 +132,9 @@ void miso_batch::release() {
   d_logfact = nullptr; logfact_n = 0;
   d_k2_pair_tab = nullptr; k2_pair_tab.clear(); k2_pair_grid = k2_pair_wide_blocks = 0;
   k2_plan_key = k2w_plan_key = -1;
+  if (probe_stream) { (void) hipStreamSynchronize(probe_stream); (void) hipStreamDestroy(probe_stream); probe_stream = nullptr; }
+  if (d_probe) { (void) hipFree(d_probe); d_probe = nullptr; }
+  probe_armed = false;
   if (ev0) (void) hipEventDestroy(ev0);
   if (ev1) (void) hipEventDestroy(ev1);
   for (GenRun &run : gen_runs) {
@@ -502,8 +529,10 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   a.il = static_cast<int>(fd.prob.size()); a.n_events = n;
   a.C = p.noChains; a.M = p.noIterations; a.B = p.noBurnIn; a.lag = p.noLag;
   a.start = p.start; a.first_event_id = first_event_id; a.seed = seed;
+  for (int i = 0; i < MISO_MAX_ROUNDS - 1; i++) a.round_start[i] = i < static_cast<int>(round_starts.size()) ? round_starts[i] : -1;
   last_seed = seed; last_first_event_id = first_event_id;
   converged_done = false;
+  if (probe_armed) { HIP_OK(hipStreamSynchronize(probe_stream)); probe_armed = false; }   // (a launch nobody waited for)
   a.pe_force_exact = std::getenv("MISO_K2_SETTLE_ALL") != nullptr;   // tests (kernels_k2.inl: the rescan for high halves on the threshold)
   if (const char *env = std::getenv("MISO_COOP_MAX_POLLS")) a.coop_max_polls = static_cast<uint32_t>(std::max(1L, std::atol(env)));   // tests
   // Trailing sample columns stay 0 (miso.c:661, quirk C8) -- they exist only when the lag does not divide the kept
@@ -536,6 +565,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       HIP_OK(hipGetLastError());
     }
     HIP_OK(hipEventRecord(ev1, stream));
+    start_clock_probe();
     last_kernels = "sampler_marginal";
     launched = true; launched_once = true; downloaded = false; summarized = false; compared = false;
     return;
@@ -1832,7 +1862,50 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     HIP_OK(hipStreamWaitEvent(stream, aux_done[i - 1], 0));
   }
   HIP_OK(hipEventRecord(ev1, stream));
+  start_clock_probe();
   launched = true; launched_once = true; downloaded = false; summarized = false; compared = false;
+}
+
+// The clock probe of this launch (clock_probe_kernel above).  First the flag's store, behind the launch's last kernel on the
+// batch's stream; then the probe on a stream of its own: on a hardware queue of its own it starts at once, beside the
+// sampler kernels.  Should its stream share the batch's queue (or a profiler serialise the dispatches) it starts when
+// everything before it is done, finds the flag set and reports a window of no length, which sync() discards -- in no
+// order of execution does it wait for something queued behind it.  Give-up time: 1.5 x the last launch's kernel time + 20 ms.
+void miso_batch::start_clock_probe() {
+  probe_armed = false;
+  if (!clock_probe || probe_failed) return;
+  if (!probe_stream) {
+    HIP_OK(hipStreamCreateWithFlags(&probe_stream, hipStreamNonBlocking));
+    HIP_OK(hipMalloc(&d_probe, 8 * sizeof(unsigned long long)));
+    HIP_OK(hipMemset(d_probe, 0, 8 * sizeof(unsigned long long)));
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) wall_khz = khz;
+  }
+  probe_gen++;
+  uint32_t *flag = reinterpret_cast<uint32_t *>(d_probe + 7);
+  hipLaunchKernelGGL(clock_probe_stop, dim3(1), dim3(64), 0, stream, flag, probe_gen);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipStreamWaitEvent(probe_stream, ev0, 0));
+  const double cap_ms = 1.5 * (last_ms > 0.f ? last_ms : 2000.0) + 20.0;
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, probe_stream, flag, probe_gen, d_probe,
+                     static_cast<unsigned long long>(cap_ms * wall_khz));
+  HIP_OK(hipGetLastError());
+  probe_armed = true;
+}
+
+void miso_batch::read_clock_probe() {
+  last_clock_ghz = 0.0; last_probe_ms = 0.0;
+  if (!probe_armed) return;
+  probe_armed = false;
+  HIP_OK(hipStreamSynchronize(probe_stream));
+  unsigned long long h[5];
+  HIP_OK(hipMemcpy(h, d_probe, sizeof(h), hipMemcpyDeviceToHost));
+  if (h[4] != 0) { probe_failed = true; return; }   // it gave up: never again for this batch (each time would cost its give-up time)
+  const double ms = static_cast<double>(h[2] - h[0]) / wall_khz;
+  // a window much shorter than the launch: the probe ran behind the kernels, not beside them
+  if (ms < 0.5 * last_ms || ms <= 0.0) return;
+  last_probe_ms = ms;
+  last_clock_ghz = static_cast<double>(h[3] - h[1]) / (ms * 1e6);
 }
 
 void miso_batch::sync(float *ms) {
@@ -1841,6 +1914,7 @@ void miso_batch::sync(float *ms) {
   HIP_OK(hipStreamSynchronize(stream));
   HIP_OK(hipEventElapsedTime(&last_ms, ev0, ev1));
   if (ms) *ms = last_ms;
+  read_clock_probe();
   // chains on several workgroups: did any group give up waiting for its members (coop.hpp)?
   bool gave_up = false;
   for (const K2Coop *cc : {&k2_coop_se, &k2w_coop}) {
@@ -1884,21 +1958,30 @@ void miso_batch::sync(float *ms) {
 
 // stop = CONVERGENT_MEAN: what the reference does after every round of its iteration loop (miso.c:903-925,
 // miso_paired.c:501-523).  Events whose chains have not converged -- and whose schedule is still below maxIterations --
-// run again with noIterations' = 3 noIterations - 2 noBurnIn, noBurnIn' = noIterations, and of that round's samples the
-// LAST noSamples replace the first round's (miso.c:976-983), here in the device pool, so that the summaries, the file
-// writer and the getters see one finished batch.  The reference continues its chains; the device keeps no chain state
-// between launches and runs the longer schedule from the start instead: iteration m of a chain draws from the same
-// addresses whatever the schedule, so the first noIterations iterations repeat the previous round bit for bit -- the
-// same chain, extended (the CPU checker's counter mode does the same; its stream mode continues, and is pinned to the
-// reference that way).  The next round is a batch of its own (only the unconverged events; its sync() recurses).
+// run another round, noIterations' = 3 noIterations - 2 noBurnIn with noBurnIn' = noIterations, and of that round's samples
+// the LAST noSamples replace the first round's (miso.c:976-983), here in the device pool, so that the summaries, the file
+// writer and the getters see one finished batch.  The reference CONTINUES its chains: round r keeps the iterations
+// [G_r + B_r, G_r + N_r) of one chain, G_r = the iterations of all earlier rounds.  The device keeps no chain state
+// between launches, so it runs iterations [0, G_r + N_r) from the start with burn-in G_r + B_r: iteration m of a chain
+// draws from the same addresses whatever the schedule, so the first G_r iterations repeat the earlier rounds bit for bit
+// and the kept window is the reference's (round 6; rounds 4 - 5 ran N_r from the start and kept [B_r, N_r): the same law
+// in the limit, half the burn-in).  The reference's loop counter restarts with every round and so does its rule "no
+// proposal terms in a round's first ratio" (miso.c:866): the kernels are told where the later rounds open
+// (KernelArgs::round_start, device.hpp RoundOpen).  The CPU checker's counter mode continues its chains like the
+// reference and addresses the draws by the chain's own iteration number: equal bit for bit (tests/test_gpu_convergent.py).
+// The next round is a batch of its own (only the unconverged events; its sync() recurses).  A launch reproduces at most
+// MISO_MAX_ROUNDS rounds (every round at least doubles the kept window: 2^7 x the first); beyond that the last stands.
 void miso_batch::converge_rounds(float *ms) {
   // once per launch: a second sync() must not test the samples the further rounds have already put in place (they might
   // pass now and reset the accept counts' bookkeeping, or fail and run the rounds -- and the paired-end sums -- twice)
   if (converged_done) { if (ms) *ms = last_ms; return; }
   converged_done = true;
   rounds = 1;
-  iters_counted.clear();
-  if (p.stop != MISO_STOP_CONVERGENT_MEAN || p.maxIterations <= p.noIterations || events.empty()) return;
+  iters_counted.clear(); went_on.clear();
+  // this round's own schedule, the reference's (noIterations, noBurnIn): the batch's for the first round
+  const int N = round_iters > 0 ? round_iters : p.noIterations, B = round_iters > 0 ? round_burn : p.noBurnIn;
+  if (p.stop != MISO_STOP_CONVERGENT_MEAN || p.maxIterations <= N || events.empty()) return;
+  if (static_cast<int>(round_starts.size()) >= MISO_MAX_ROUNDS - 1) return;
   const int S0 = S(), C = p.noChains;
   if (S0 < C) return;                        // fewer kept samples than chains: nothing to assess
   std::vector<unsigned char> out(out_bytes);
@@ -1908,10 +1991,14 @@ void miso_batch::converge_rounds(float *ms) {
     if (!convergent_mean(reinterpret_cast<const double *>(out.data() + h_events[i].off_samples), events[i].K, C, S0))
       again.push_back(static_cast<int>(i));
   if (again.empty()) return;
+  const int64_t N2 = 3LL * N - 2LL * B, total = static_cast<int64_t>(p.noIterations) + N2;
+  if (total > INT32_MAX) return;             // (the kernels count iterations in 32 bits)
   miso_params_t p2 = p;
-  p2.noIterations = 3 * p.noIterations - 2 * p.noBurnIn; p2.noBurnIn = p.noIterations;
+  p2.noIterations = static_cast<int>(total); p2.noBurnIn = p.noIterations + N;   // miso.c:921-923, behind what has been run
   p2.want_counts_trace = 0; p2.device_match = 0;
   std::unique_ptr<miso_batch> next(batch_new(p2));
+  next->round_iters = static_cast<int>(N2); next->round_burn = N;
+  next->round_starts = round_starts; next->round_starts.push_back(p.noIterations);
   for (int i : again) {
     next->events.push_back(events[i]);
     const bool pinned = i < static_cast<int>(event_ids.size()) && event_ids[i] >= 0;
@@ -1925,7 +2012,9 @@ void miso_batch::converge_rounds(float *ms) {
   const int Sn = next->S();
   std::vector<unsigned char> nout(next->out_bytes);
   HIP_OK(hipMemcpy(nout.data(), next->d_out, next->out_bytes, hipMemcpyDeviceToHost));
-  iters_counted.assign(events.size(), p.noIterations);
+  // iterations behind an event's accept count: the single-end loop starts both counters afresh every round, the
+  // paired-end one never does (miso.c:847 against miso_paired.c:345, 453)
+  iters_counted.assign(events.size(), p.paired ? p.noIterations : N);
   for (size_t j = 0; j < again.size(); j++) {
     const int i = again[j];
     const DevEvent &d = h_events[i], &n = next->h_events[j];
@@ -1937,19 +2026,22 @@ void miso_batch::converge_rounds(float *ms) {
                           hipMemcpyDeviceToDevice, stream));
     if (e.n_draw > 0)
       HIP_OK(hipMemcpyAsync(d_out + d.off_drawass, next->d_out + n.off_drawass, e.n_draw, hipMemcpyDeviceToDevice, stream));
-    // accept counts: the single-end loop starts them afresh every round, the paired-end one never does
-    // (miso.c:847 against miso_paired.c:345, 453)
-    const int64_t next_iters = next->iters_counted.empty() ? p2.noIterations : next->iters_counted[j];
+    // accept counts.  The next launch counted from the chain's start: that IS the paired-end number; the single-end one
+    // is what the last round added, i.e. minus this launch's own count (the same chain up to here).  An event that went
+    // through further rounds in `next` comes back already settled.
+    const bool settled = !next->iters_counted.empty() && next->event_went_on(static_cast<int>(j));
     ChainStats *mine = reinterpret_cast<ChainStats *>(out.data() + d.off_stats);
     const ChainStats *theirs = reinterpret_cast<const ChainStats *>(nout.data() + n.off_stats);
     for (int c = 0; c < C; c++) {
       const int32_t before = mine[c].accepted;
       mine[c] = theirs[c];
-      if (p.paired) mine[c].accepted += before;
+      if (!p.paired && !settled) mine[c].accepted -= before;
     }
-    iters_counted[i] = p.paired ? p.noIterations + next_iters : next_iters;
+    iters_counted[i] = !next->iters_counted.empty() ? next->iters_counted[j] : (p.paired ? total : N2);
     HIP_OK(hipMemcpyAsync(d_out + d.off_stats, mine, sizeof(ChainStats) * C, hipMemcpyHostToDevice, stream));
   }
+  went_on.assign(events.size(), 0);
+  for (int i : again) went_on[i] = 1;
   HIP_OK(hipStreamSynchronize(stream));
   rounds = 1 + next->rounds;
   last_ms += next_ms;

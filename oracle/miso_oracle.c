@@ -1046,7 +1046,11 @@ static double proposal_score(const orc_state_t *S, const double *theta, const do
 static uint64_t fnv_step(uint64_t h, uint32_t w) { return (h ^ (uint64_t) w) * 0x100000001B3ull; }
 
 /* The iteration loop common to miso.c:845-900 and miso_paired.c:451-498 */
-static void run_chains(orc_state_t *S, int noIterations, int noBurnIn, int noLag,
+/* m_base: counter mode, stop = CONVERGENT_MEAN -- the iterations of all earlier rounds.  The loop counter m starts at 0
+   in every round as the reference's does (so the round's first Metropolis-Hastings ratio again leaves the proposal
+   terms out, miso.c:866 `m > 0 ? 1 : 0`), the counter-based draws are addressed by the chain's own iteration number
+   m_base + m. */
+static void run_chains(orc_state_t *S, uint32_t m_base, int noIterations, int noBurnIn, int noLag,
                        double *samples, double *logLik, int *rundata, orc_trace_t *trace) {
   int K = S->K, C = S->C, len = K - 1, m, j, i, lagCounter = 0, noS = 0;
   int noAccepted = 0, noRejected = 0;
@@ -1064,7 +1068,7 @@ static void run_chains(orc_state_t *S, int noIterations, int noBurnIn, int noLag
         if (trace && trace->counts_trace) trace->counts_trace[((size_t) m * C + j) * K + i] = cnt[i];
       }
     }
-    propose(S, (uint32_t) m, S->alpha, S->psiNew, S->alphaNew);
+    propose(S, m_base + (uint32_t) m, S->alpha, S->psiNew, S->alphaNew);
     for (j = 0; j < C; j++) { /* miso.c:493-552 */
       double pp = score_joint(S, j, S->psiNew + j * K);
       double pc = score_joint(S, j, S->psi + j * K);
@@ -1076,7 +1080,7 @@ static void run_chains(orc_state_t *S, int noIterations, int noBurnIn, int noLag
     for (j = 0; j < C; j++) { /* miso.c:869-880 */
       int acc;
       if (S->counter) {
-        miso_u32x4 b = miso_draw_block(S->opts->seed, S->opts->event_id, (uint32_t) j, (uint32_t) m,
+        miso_u32x4 b = miso_draw_block(S->opts->seed, S->opts->event_id, (uint32_t) j, m_base + (uint32_t) m,
                                        MISO_SITE_MH, 0);
         acc = (acceptP[j] >= 1) || (miso_u01(b.v[0]) < acceptP[j]);
       } else {
@@ -1103,7 +1107,7 @@ static void run_chains(orc_state_t *S, int noIterations, int noBurnIn, int noLag
       }
     }
     if (S->marginal) continue;   /* miso.c:895: only the REASSIGN algorithm reassigns */
-    if (S->collapsed && m != noIterations - 1) reassign_collapsed(S, (uint32_t) m); else reassign(S, (uint32_t) m);
+    if (S->collapsed && m != noIterations - 1) reassign_collapsed(S, m_base + (uint32_t) m); else reassign(S, m_base + (uint32_t) m);
   }
   for (j = 0; j < C; j++) {
     counts_of(S, j, cnt);
@@ -1190,17 +1194,21 @@ int orc_convergent_mean(const double *samples, int K, int C, int noSamples) {
    STOP_FIXEDNO: one round.  STOP_CONVERGENT_MEAN: after a round that has not converged (and while noIterations <
    maxIterations) the schedule becomes noIterations' = 3 noIterations - 2 noBurnIn, noBurnIn' = noIterations, the
    samples are collected afresh, and of the last round the LAST noSamples (of the first round) are returned
-   (miso.c:976-983).  Stream mode continues the chains where they are, with the iteration counter back at 0, as the
-   reference does.  Counter mode runs the longer schedule FROM THE START: iteration m of chain j draws from the same
-   addresses whatever the schedule, so its first noIterations iterations repeat the previous round bit for bit and
-   the run is the same chain extended -- which is what a device that keeps no chain state between launches can do. */
+   (miso.c:976-983).  Both modes continue the chains where they are, with the loop counter back at 0, as the reference
+   does (miso.c:845-847: `for (m=0, ...`; the chains' psi, alpha and assignments are untouched by :914-925).  Counter mode
+   addresses its draws by the chain's own iteration number (all rounds counted), so a device that keeps no chain state
+   between launches reproduces round r by running iterations [0, G_r + N_r) from the start, G_r = the iterations of
+   the earlier rounds, and keeping [G_r + B_r, G_r + N_r) -- the same chain, the same window
+   (miso_amd/csrc/runtime.hip converge_rounds).  Collapsed mode: a round's last reassignment is per read (the returned
+   vector); when another round follows, the collapsed step of that iteration takes its place (it depends on psi only). */
 static void run_rounds(orc_state_t *S, int start, int stop, int noIterations, int maxIterations, int noBurnIn,
                        int noLag, double *samples, double *logLik, int *rundata, orc_trace_t *trace) {
   int K = S->K, C = S->C, S0 = C * (noIterations - noBurnIn) / noLag, nS = S0, round = 0;
   double *buf = samples, *lbuf = logLik;
   int acc = 0, rej = 0;
+  uint32_t m_base = 0;
   for (;; round++) {
-    if (round == 0 || S->counter) {
+    if (round == 0) {
       init_chains(S, start);            /* miso.c:827-835 */
       if (S->marginal) {                /* miso.c:839-842: no assignment to start from */
         size_t i;
@@ -1210,12 +1218,14 @@ static void run_rounds(orc_state_t *S, int start, int stop, int noIterations, in
         if (S->collapsed && noIterations > 0) reassign_collapsed(S, MISO_ITER_INIT); else reassign(S, MISO_ITER_INIT);
       }
     }
-    run_chains(S, noIterations, noBurnIn, noLag, buf, lbuf, rundata, round == 0 ? trace : NULL);
+    run_chains(S, m_base, noIterations, noBurnIn, noLag, buf, lbuf, rundata, round == 0 ? trace : NULL);
     /* the single-end loop resets the two counters every round (miso.c:847), the paired-end one never does
        (miso_paired.c:345, 453) */
     if (S->paired) { acc += rundata[5]; rej += rundata[6]; rundata[5] = acc; rundata[6] = rej; }
     if (stop != 1 || maxIterations <= noIterations) break;      /* miso.c:903-912 */
     if (nS < C || convergent_mean(buf, K, C, nS)) break;         /* fewer samples than chains: nothing to assess */
+    if (S->collapsed && noIterations > 0 && S->N > 0) reassign_collapsed(S, m_base + (uint32_t) noIterations - 1);
+    m_base += (uint32_t) noIterations;
     { int next = 3 * noIterations - 2 * noBurnIn; noBurnIn = noIterations; noIterations = next; } /* miso.c:921-924 */
     nS = C * (noIterations - noBurnIn) / noLag;
     if (buf != samples) { free(buf); free(lbuf); }

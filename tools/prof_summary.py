@@ -81,6 +81,20 @@ def update_valu_model(prof_dir):
     sq, fe = counters(sdb), counters(fdb)
     _, rows = q(tdb, "select name, avg(end-start) from kernels where name like '%sampler_%' group by name")
     dur = {r[0]: r[1] for r in rows}
+    # a launch of several kernels side by side: what the batch's HIP events bracket is first start -> last end
+    _, iv = q(tdb, "select start, end from kernels where name like '%sampler_%' order by start")
+    spans, cur = [], None
+    for st, en in iv:
+        if cur is None or st > cur[1]:
+            if cur is not None:
+                spans.append(cur[1] - cur[0])
+            cur = [st, en]
+        else:
+            cur[1] = max(cur[1], en)
+    if cur is not None:
+        spans.append(cur[1] - cur[0])
+    # (the first launch of a batch may carry trial runs; the median launch is the one the bench times)
+    span_ns = sorted(spans)[len(spans) // 2] if spans else None
     c = bench["config"]
     chain_iters = float(c["events_per_gpu"]) * c["chains"] * (c["iters"] + 1)
     kernels = {}
@@ -110,6 +124,10 @@ def update_valu_model(prof_dir):
         "valu_per_chain_iteration": tot_valu / chain_iters,
         "issue_cycles_per_valu": 4.0 * tot_act / tot_valu,
         "kernels": kernels,
+        # the traced launch as bench.py's HIP events see it, and the shader clock the library's probe measured in that very
+        # (kernel-trace) pass: bench.py compares shader CYCLES of its run with these
+        "launch_span_ns": span_ns,
+        "clock_ghz": (bench.get("roofline") or {}).get("clock_ghz"),
     }
     json.dump(table, open(path, "w"), indent=1, sort_keys=True)
     print("valu model:", bench_key(bench), {k: round(v, 3) if isinstance(v, float) else v
