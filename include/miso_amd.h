@@ -276,6 +276,14 @@ int miso_batch_get_comparison(const miso_batch_t *sample1, int event_index, doub
 int miso_batch_last_match_ms(const miso_batch_t *batch, float *ms);
 int miso_batch_get_match(const miso_batch_t *batch, int event_index, double *match, int *fragmentLength);
 
+/* The run-dependent fields of the `.miso` header line (misopy/miso_sampler.py:376-454) of n events in one call.  Writes,
+   per event, the line "U<TAB>percent_accept<TAB>counts<TAB>assigned_counts\n" into buf (NUL-terminated): U = 1 when every
+   read of the event is unassigned (the caller skips it, miso_sampler.py:352-354); percent_accept as "%.2f"; counts =
+   "(1,0):12,(0,1):34" (read class : reads); assigned_counts = "0:5,1:41" (reads_utils.py:37-46).  *needed = bytes the
+   text takes incl. the NUL; nothing is written when cap is smaller (call again).  Needs downloaded results. */
+int miso_batch_header_fields(const miso_batch_t *batch, int n, const int *event_index, char *buf, int64_t cap,
+                             int64_t *needed);
+
 /* names of the kernels the last launch used (for profiles): e.g. "sampler_k2<3, false>" */
 int miso_batch_last_kernels(const miso_batch_t *batch, char *buf, int buflen);
 
@@ -305,6 +313,10 @@ typedef struct {
 } miso_kernel_stat_t;
 int miso_batch_launch_stats(const miso_batch_t *batch, miso_kernel_stat_t *stats, int max_kernels,
                             int *n_kernels);
+/* The version of the counter-mode contract this library draws by (include/miso_philox.h MISO_CONTRACT_VERSION): seeded
+   results are comparable between builds -- and with the CPU checker -- only at equal versions.  No device needed. */
+int miso_contract_version(void);
+
 /* Measurement: the shader clock the last launch ran at.  With the probe on, every launch starts ONE extra wavefront on a
    stream of its own that sleeps beside the sampler kernels and reads the shader-cycle counter (s_memtime) and the
    constant reference clock (hipDeviceAttributeWallClockRate) at both ends of the launch; miso_batch_sync() turns the pair

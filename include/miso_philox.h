@@ -88,6 +88,19 @@ typedef struct { uint32_t v[4]; } miso_u32x4;
 #define MISO_PHILOX_ROUNDS 7
 #endif
 
+/* The version of the COUNTER-MODE CONTRACT: which numbers a seeded run draws and in which order.  The device
+   (libmiso_amd.so: miso_contract_version()) and the CPU checker (oracle: orc_contract_version()) are compiled from this
+   header and the tests assert that both report the same number, so a stale prebuilt checker -- or results saved by
+   another version -- are noticed instead of silently disagreeing.  Bumped whenever a seeded counter-mode
+   output can change:
+     1  rounds 1 - 3: Philox4x32-10, draws in input order
+     4  round 4: Philox4x32-7; lazy low half-words for single-end two-isoform events (MISO_SITE_GIBBS_LOW)
+     5  round 5: paired-end draw order by fragment-length rows; division-free binomial inversion (miso_binomial.h)
+     6  round 6: stop = CONVERGENT_MEAN continues its chains -- round r keeps the iterations [G_r + B_r, G_r + N_r) of one
+        chain addressed by its own iteration number, a round's first ratio without the proposal terms (miso.c:866);
+        everything under stop = FIXEDNO as in 5 */
+#define MISO_CONTRACT_VERSION 6
+
 /* `rounds` is a compile-time constant at every call site of the product (the loop unrolls); the checker also calls it
    with 10 to pin the implementation to the published vectors of both round counts */
 MISO_HD miso_u32x4 miso_philox4x32_r(int rounds, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,

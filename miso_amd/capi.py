@@ -89,6 +89,11 @@ def _cigs(cigars):
     return arr
 
 
+def contract_version():
+    """include/miso_philox.h MISO_CONTRACT_VERSION of the loaded library (no device needed)."""
+    return int(lib().miso_contract_version())
+
+
 def device_count():
     n = C.c_int(0)
     check(lib().miso_device_count(C.byref(n)))
@@ -344,6 +349,27 @@ class Batch:
         check(lib().miso_batch_get_result(self.handle, i, None, None, _p(ct), _p(cc), _p(ass),
                                           C.byref(rd)))
         return ct[:ncls.value], cc[:ncls.value], ass[:N.value], rd
+
+    def header_fields(self, indices):
+        """[(all_unassigned, percent_accept, counts, assigned_counts)] -- the run-dependent header fields of the given
+        events as text, formatted natively (include/miso_amd.h miso_batch_header_fields)."""
+        n = len(indices)
+        if n == 0:
+            return []
+        idx = np.asarray(indices, dtype=np.int32)
+        need = C.c_int64(0)
+        cap = 96 * n + 4096
+        for _ in range(2):
+            buf = C.create_string_buffer(cap)
+            check(lib().miso_batch_header_fields(self.handle, n, _p(idx), buf, C.c_int64(cap), C.byref(need)))
+            if need.value <= cap:
+                break
+            cap = need.value
+        out = []
+        for ln in buf.raw[:need.value - 1].decode().split("\n")[:n]:
+            u, pa, counts, assigned = ln.split("\t")
+            out.append((u == "1", pa, counts, assigned))
+        return out
 
     def write_miso_files(self, indices, paths, headers, threads=0):
         """The `.miso` files of the given events, rows formatted and written natively."""

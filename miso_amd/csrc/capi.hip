@@ -14,6 +14,8 @@
 #include <thread>
 #include <vector>
 
+#include "miso_philox.h"
+
 #include "batch.hpp"
 #include "coop.hpp"
 #include "miso_alnio.h"
@@ -574,6 +576,93 @@ int miso_batch_write_miso_files(const miso_batch_t *b, int n, const int *event_i
   });
 }
 
+// The run-dependent fields of the `.miso` header line (miso_sampler.py:376-454), for many events in one call: per event one
+// line "U<TAB>percent_accept<TAB>counts<TAB>assigned_counts\n", U = 1 when every read is unassigned (the caller skips such
+// an event, miso_sampler.py:352-354).  The same text the Python formatting of miso_amd/miso_sampler.py miso_header()
+// produces -- "%.2f", "(1,0):12,(0,1):34", "0:5,1:41" (reads_utils.py:37-46) -- without 30 microseconds of interpreter
+// per event: a whole-genome run's header stage was as long as its sampling.
+int miso_batch_header_fields(const miso_batch_t *b, int n, const int *event_index, char *buf, int64_t cap, int64_t *needed) {
+  return guarded([&] {
+    need(b, "batch"); need(needed, "needed");
+    if (n < 0 || (n > 0 && !event_index)) MISO_FAIL(MISO_EINVAL, "null argument");
+    if (!b->downloaded) MISO_FAIL(MISO_EINVAL, "results not downloaded yet");
+    for (int j = 0; j < n; j++) (void) event_at(b, event_index[j]);
+    std::vector<std::string> lines(static_cast<size_t>(n));
+    int T = std::max(1, std::min(miso_usable_threads(), std::min(n / 64 + 1, 64)));
+    std::atomic<int> next{0};
+    std::atomic<bool> failed{false};
+    auto work = [&] {
+      try {
+      std::vector<int64_t> cnt;
+      char num[64];
+      for (;;) {
+        const int j0 = next.fetch_add(64);
+        if (j0 >= n) return;
+        for (int j = j0; j < std::min(n, j0 + 64); j++) {
+          const int i = event_index[j];
+          const PackedEvent &e = b->events[i];
+          const DevEvent &d = b->h_events[i];
+          const unsigned char *out = b->h_out.data();
+          // assigned counts of chain 0's final state (miso.c:943-946): isoform -> reads, up to the largest isoform seen
+          cnt.assign(static_cast<size_t>(e.K), 0);
+          int top = -1;
+          for (int k = 0; k < e.N; k++) { const int a = e.fixed_ass[k]; if (a >= 0) { cnt[a]++; top = std::max(top, a); } }
+          const uint8_t *da = out + d.off_drawass;
+          // (a drawing read's slot in fixed_ass is overwritten by its pick, as in miso_batch_get_result)
+          for (int r = 0; r < e.n_draw; r++) {
+            const int was = e.fixed_ass[e.draw_index[r]];
+            if (was >= 0) cnt[was]--;
+            const int a = da[r]; cnt[a]++; top = std::max(top, a);
+          }
+          if (top >= 0) { top = -1; for (int k = 0; k < e.K; k++) if (cnt[k] > 0) top = k; }
+          std::string &ln = lines[j];
+          ln += top < 0 ? "1\t" : "0\t";
+          const ChainStats *st = reinterpret_cast<const ChainStats *>(out + d.off_stats);
+          int64_t acc = 0;
+          for (int c = 0; c < b->p.noChains; c++) acc += st[c].accepted;
+          miso_rundata_t rd;
+          fill_rundata(*b, e.K, static_cast<int>(acc), b->iters_counted.empty() ? b->p.noIterations : b->iters_counted[i], &rd);
+          const double pa = static_cast<double>(rd.noAccepted) / static_cast<double>(rd.noAccepted + rd.noRejected) * 100.0;
+          std::snprintf(num, sizeof num, "%.2f", pa);
+          ln += num; ln += '\t';
+          const size_t ncls = e.class_counts.size();
+          for (size_t c = 0; c < ncls; c++) {
+            if (c) ln += ',';
+            ln += '(';
+            for (int k = 0; k < e.K; k++) {
+              if (k) ln += ',';
+              std::snprintf(num, sizeof num, "%d", static_cast<int>(e.class_templates[c * e.K + k]));
+              ln += num;
+            }
+            if (e.K == 1) ln += ',';                       // Python's one-element tuple
+            std::snprintf(num, sizeof num, "):%d", static_cast<int>(e.class_counts[c]));
+            ln += num;
+          }
+          ln += '\t';
+          for (int k = 0; k <= top; k++) {
+            std::snprintf(num, sizeof num, "%s%d:%lld", k ? "," : "", k, static_cast<long long>(cnt[k]));
+            ln += num;
+          }
+          ln += '\n';
+        }
+      }
+      } catch (...) { failed = true; }   // nothing may leave a worker thread (std::terminate)
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; t++) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+    if (failed) MISO_FAIL(MISO_ENOMEM, "allocation failed while formatting header fields");
+    int64_t total = 1;
+    for (const std::string &ln : lines) total += static_cast<int64_t>(ln.size());
+    *needed = total;
+    if (!buf || cap < total) return;
+    char *o = buf;
+    for (const std::string &ln : lines) { std::memcpy(o, ln.data(), ln.size()); o += ln.size(); }
+    *o = 0;
+  });
+}
+
 int miso_batch_get_trace(const miso_batch_t *b, int i, uint64_t *counts_hash, int32_t *counts_trace) {
   return guarded([&] {
     need(b, "batch");
@@ -678,6 +767,8 @@ int miso_batch_get_match(const miso_batch_t *b, int i, double *match, int *fragm
     }
   });
 }
+
+int miso_contract_version(void) { return MISO_CONTRACT_VERSION; }
 
 int miso_batch_set_clock_probe(miso_batch_t *b, int on) {
   return guarded([&] { need(b, "batch"); b->clock_probe = on != 0; if (on) b->probe_failed = false; });

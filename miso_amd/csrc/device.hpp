@@ -126,6 +126,8 @@ struct KernelArgs {
   // stop = CONVERGENT_MEAN (runtime.hip converge_rounds): the iterations that open a later round of the reference's loop,
   // ascending, unused entries -1 (every launch of stop = FIXEDNO: all -1)
   int32_t round_start[MISO_MAX_ROUNDS - 1];
+  // sampler_k2_multi<0, 8>, one round: the two wavefronts of a SIMD keep step by priority (kernels_k2.inl k2_balance)
+  int32_t balance;
   int32_t n_segs;
   int32_t seg_block[K2_MAX_SEGS + 1];
   int32_t seg_slot[K2_MAX_SEGS + 1];
@@ -140,14 +142,34 @@ struct KernelArgs {
 struct RoundOpen {
   int next, i;
   __device__ explicit RoundOpen(const KernelArgs &a) : next(a.round_start[0]), i(0) {}
-  __device__ bool at(const KernelArgs &a, int m) {
+  __device__ __attribute__((always_inline)) bool at(const KernelArgs &a, int m) {
     if (m == 0) return true;
-    if (m != next) return false;
+    if (__builtin_expect(m != next, 1)) return false;
+    // (constant indices only: a run-time index into the kernel's by-value arguments would make the compiler keep a
+    // copy of them in scratch)
     i++;
-    next = i < MISO_MAX_ROUNDS - 1 ? a.round_start[i] : -1;
+    int nx = -1;
+#pragma unroll
+    for (int j = 1; j < MISO_MAX_ROUNDS - 1; j++) nx = (i == j) ? a.round_start[j] : nx;
+    next = nx;
     return true;
   }
 };
+#endif
+
+#ifdef __HIPCC__
+// Launches of several rounds of workgroups (KernelArgs::balance == 2; experiment, round 6): a SIMD's arbiter serves its
+// OLDEST wavefront whenever it can issue, so wavefronts run nearly one after the other and the launch ends with every
+// SIMD's youngest running alone.  A wavefront's priority falls with its progress instead -- by quarters of its iterations:
+// a newcomer catches up with its SIMD's residents, the residents stay within a quarter of each other and finish together.
+__device__ __attribute__((always_inline)) inline void prio_by_progress(const KernelArgs &a, int m) {
+  if (a.balance != 2) return;
+  const int q = a.M >> 2;
+  if (m == 0) __builtin_amdgcn_s_setprio(3);
+  else if (m == q) __builtin_amdgcn_s_setprio(2);
+  else if (m == 2 * q) __builtin_amdgcn_s_setprio(1);
+  else if (m == 3 * q) __builtin_amdgcn_s_setprio(0);
+}
 #endif
 
 constexpr uint64_t NO_TRACE = ~0ull;

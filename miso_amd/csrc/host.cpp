@@ -704,6 +704,8 @@ PackedEvent pack_event_masks(const miso_params_t &p, const FragmentDist *fd, int
 namespace {
 std::vector<std::pair<uint64_t, double>> gene_classes(const Gene &g, int readLength) {
   const int K = g.K;
+  // (a class is a 64-bit pattern of isoforms: ADVICE r5 -- genes of 65 ... 256 isoforms are first-class objects now)
+  if (K > 64) MISO_FAIL(MISO_UNIMPLEMENTED, "the assignment matrix (algorithm = CLASSES) takes at most 64 isoforms");
   std::vector<std::pair<uint64_t, double>> cls;
   if (g.exstart.empty()) return cls;
   const int gs = *std::min_element(g.exstart.begin(), g.exstart.end()), ge = *std::max_element(g.exend.begin(), g.exend.end());

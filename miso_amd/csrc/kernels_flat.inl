@@ -844,6 +844,7 @@ __global__ __launch_bounds__(256, KC <= 4 ? MISO_FLAT_WGS_4 : (KC <= 8 ? MISO_FL
   RoundOpen ro(a);
   for (int m = 0; m < a.M; m++) {
     const bool opens = ro.at(a, m);   // a round's first iteration: no proposal terms (miso.c:866)
+    prio_by_progress(a, m);
     // this iteration's view of the counts: the leader's registers (hash, both joint scores)
     int cn[KB];
     if (leader) {

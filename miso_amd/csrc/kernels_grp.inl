@@ -1394,6 +1394,7 @@ __device__ __forceinline__ void grp_body(const KernelArgs &a, unsigned block_x) 
   RoundOpen ro(a);
   for (int m = 0; m < a.M; m++) {
     const bool opens = ro.at(a, m);   // a round's first iteration: no proposal terms (miso.c:866)
+    prio_by_progress(a, m);
     if (WIDE && !coop_ok) return;   // the chain's workgroups gave up waiting for each other (coop.hpp): the host reports it
 #pragma unroll 1
     for (int k0 = 0; k0 < (MH_ONE ? 1 : Kw); k0 += MH_CH) {

@@ -291,6 +291,21 @@ __device__ __forceinline__ int32_t binomial_coop(uint64_t seed, uint32_t event_i
 #ifndef MISO_K2_PE_IDENT
 #define MISO_K2_PE_IDENT 1
 #endif
+// One-round single-end launches (sampler_k2_multi<0, 8>): wavefronts w and w + 4 of the workgroup share a SIMD and the
+// launch is over when the slower of the two is.  The SIMD's arbiter serves the OLDER wavefront whenever it can issue
+// (profiles/r03_wave_time.txt: it is done at 0.6 of the launch, its partner then runs on alone at a lone wavefront's
+// issue rate), so the pair is told to keep step: every iteration a wavefront posts its iteration number, reads its
+// partner's and raises its own priority when it is behind (s_setprio: the arbiter looks at the user priority before the
+// age).  Chains of one batch run the same number of iterations, so "same iteration" is "same share of the work done".
+__shared__ int k2_prog[8];
+__device__ __forceinline__ void k2_balance(int wv, int m) {
+  __hip_atomic_store(&k2_prog[wv], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  const int d = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&k2_prog[wv ^ 4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) - m;
+  if (d > 0) __builtin_amdgcn_s_setprio(2);
+  else if (d < 0) __builtin_amdgcn_s_setprio(0);
+  else __builtin_amdgcn_s_setprio(1);
+}
+
 typedef const __attribute__((address_space(3))) double *k2_lds_cdp;
 typedef const __attribute__((address_space(3))) int32_t *k2_lds_cip;
 __device__ __forceinline__ double k2_lds_f64(uint32_t addr) { return *reinterpret_cast<k2_lds_cdp>(static_cast<uintptr_t>(addr)); }
@@ -797,10 +812,27 @@ __device__ __forceinline__ void k2_body(const KernelArgs &a, unsigned block_x, u
   int accepted = 0, lagCounter = 0, noS = 0;
   const bool writer = live && sub == 0;
 
-  double zbuf = 0.0; uint32_t awbuf = 0u;   // this lane's share of the next NR iterations' MH draws
+  double zbuf = 0.0; uint32_t awbuf = 0u;   // this lane's share of NR consecutive iterations' MH draws
+  // The proposal of iteration m is made -- alpha' = alpha + sd z_m and exp(alpha') (miso.c:449-471) -- at the END of
+  // iteration m - 1, for both outcomes of that iteration's test, in the routine call that evaluates the test's own
+  // exponential (below): one call of the exponential instead of two per iteration.  Same inputs, same routine, same bits.
+  // Three and more lanes per chain only (SPEC): one or two lanes per chain have no idle lane to give the extra arguments to,
+  // and their step stays as it was -- the proposal at the top of its iteration, four exponentials in the softmax pass
+  // (measured: the merged form on one lane per chain, MISO's default settings, 199.0 -> 206.6 ms).
+  constexpr bool SPEC = NR >= 3;
+  double alphaN_p = 0.0, e_p = 0.0;
+  if constexpr (SPEC) {
+    mh_draws(static_cast<uint32_t>(role), zbuf, awbuf);   // iterations 0 .. NR - 1
+    const double z = lane_bcast(zbuf, base_lane);
+    alphaN_p = alpha + c.sd * z;
+    e_p = k2_exp(alphaN_p);
+  }
+  const double E0 = SPEC ? k2_exp(0.0) : 1.0;   // exp(maxv - maxv) of the log-sum-exp below
   RoundOpen ro(a);
   for (int m = 0; m < a.M; m++) {
     const bool opens = ro.at(a, m);   // a round's first iteration: no proposal terms (miso.c:866)
+    prio_by_progress(a, m);
+    if (MODE == 0 && WPB == 8 && !WIDE && !COLLAPSED && a.balance == 1) k2_balance(threadIdx.x >> 6, m);
     if (WIDE && !coop_ok) return;   // the chain's workgroups gave up waiting for each other (coop.hpp): the host reports it
     hash = (hash ^ static_cast<uint32_t>(cnt0)) * 0x100000001B3ull;
     hash = (hash ^ static_cast<uint32_t>(cnt1)) * 0x100000001B3ull;
@@ -809,8 +841,18 @@ __device__ __forceinline__ void k2_body(const KernelArgs &a, unsigned block_x, u
       row[0] = cnt0; row[1] = cnt1;
     }
     PROF_T(m0);
-    double alphaN, x0, x1; uint32_t accept_word;
-    {
+    double alphaN, x0, x1, zn = 0.0; uint32_t accept_word;
+    if constexpr (SPEC) {
+      const int ph = m % NR;
+      accept_word = static_cast<uint32_t>(__shfl(static_cast<int>(awbuf), base_lane + ph));
+      alphaN = alphaN_p;
+      const double sumexp = (0.0 + e_p) + 1.0;
+      x0 = e_p / sumexp;
+      x1 = 1 - (0.0 + x0);
+      // z of iteration m + 1 (the draws depend on (seed, event, chain, iteration) only)
+      if (ph == NR - 1) mh_draws(static_cast<uint32_t>(m + 1 + role), zbuf, awbuf);   // iterations m + 1 .. m + NR
+      zn = lane_bcast(zbuf, base_lane + (ph == NR - 1 ? 0 : ph + 1));
+    } else {
       double z;
       if (NR == 1) {
         mh_draws(static_cast<uint32_t>(m), z, accept_word);
@@ -835,11 +877,25 @@ __device__ __forceinline__ void k2_body(const KernelArgs &a, unsigned block_x, u
       nw.pr = 1.0 / (1.0 * x0) / ltheta;
       const double lp0 = nw.lx0 + c.cst0, lp1 = nw.lx1 + c.cst1;
       const double maxv = (lp1 > lp0) ? lp1 : lp0;  // miso.c:137-140: maxv starts at entry 0
+      // of exp(lp0 - maxv), exp(lp1 - maxv) one is exp(x - x) = exp(+0) = E0 for every finite x: three exponentials
       double ex0, ex1, xp, xc;
-      vec_eval4<NR, QUAD>(f_exp, lp0 - maxv, lp1 - maxv,
-                          prop_exponent(cur.lgt, alphaN, c.sigma),   // theta = psi,  mu = alpha'
-                          prop_exponent(nw.lgt, alpha, c.sigma),     // theta = psi', mu = alpha
-                          ex0, ex1, xp, xc, role, base_lane);
+      if constexpr (SPEC) {
+        const bool m1 = lp1 > lp0;
+        const double dmin = m1 ? lp0 - maxv : lp1 - maxv, dmax = m1 ? lp1 - maxv : lp0 - maxv;
+        double emin;
+        vec_eval3<NR, QUAD>(f_exp, dmin,
+                            prop_exponent(cur.lgt, alphaN, c.sigma),   // theta = psi,  mu = alpha'
+                            prop_exponent(nw.lgt, alpha, c.sigma),     // theta = psi', mu = alpha
+                            emin, xp, xc, role, base_lane);
+        double emax = E0;
+        if (__builtin_expect(__any(!(dmax == 0.0)), 0)) emax = f_exp(dmax);   // a non-finite log psi (inf - inf): as written
+        ex0 = m1 ? emin : emax; ex1 = m1 ? emax : emin;
+      } else {
+        vec_eval4<NR, QUAD>(f_exp, lp0 - maxv, lp1 - maxv,
+                            prop_exponent(cur.lgt, alphaN, c.sigma),   // theta = psi,  mu = alpha'
+                            prop_exponent(nw.lgt, alpha, c.sigma),     // theta = psi', mu = alpha
+                            ex0, ex1, xp, xc, role, base_lane);
+      }
       double ls;
       vec_eval3<NR, QUAD>(f_log, (0.0 + ex0) + ex1, c.covar * cur.pr * xp, c.covar * nw.pr * xc, ls, ptoCS,
                           ctoPS, role, base_lane);
@@ -852,10 +908,20 @@ __device__ __forceinline__ void k2_body(const KernelArgs &a, unsigned block_x, u
                          : 0.0;
     const double pp = joint<PE>(nw, cnt0, cnt1, c, rp);
     const double pc = joint<PE>(cur, cnt0, cnt1, c, rp);
-    const double acceptP = !opens ? k2_exp(pp + ptoCS - (pc + ctoPS)) : k2_exp(pp - pc);
+    // the test's exponential and -- three and more lanes per chain: in the same call, for both outcomes of the test --
+    // the next proposal's
+    const double targ = !opens ? pp + ptoCS - (pc + ctoPS) : pp - pc;
+    double acceptP, aA = 0.0, aR = 0.0, eA = 0.0, eR = 0.0;
+    if constexpr (SPEC) {
+      aA = alphaN + c.sd * zn; aR = alpha + c.sd * zn;
+      vec_eval3<NR, QUAD>(k2_exp, targ, aA, aR, acceptP, eA, eR, role, base_lane);
+    } else {
+      acceptP = k2_exp(targ);
+    }
     const bool acc = (acceptP >= 1) || (miso_u01(accept_word) < acceptP);
     double cJS = pc;
     if (acc) { cur = nw; alpha = alphaN; cJS = pp; accepted++; }
+    if constexpr (SPEC) { alphaN_p = acc ? aA : aR; e_p = acc ? eA : eR; }
     PROF_T(m1);
     PROF_ADD(pf_mh, m0, m1);
 
@@ -886,6 +952,10 @@ __device__ __forceinline__ void k2_body(const KernelArgs &a, unsigned block_x, u
     loglik[4] = static_cast<double>(pf_rec);
   }
 #endif
+  if (MODE == 0 && WPB == 8 && !WIDE && !COLLAPSED && a.balance == 1) {   // done: the partner is never "behind" again
+    __hip_atomic_store(&k2_prog[threadIdx.x >> 6], 0x7FFFFFFF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __builtin_amdgcn_s_setprio(0);
+  }
   if (a.M > 0 && live && chain == 0) gibbs_write(static_cast<uint32_t>(a.M - 1));
   hash = (hash ^ static_cast<uint32_t>(cnt0)) * 0x100000001B3ull;
   hash = (hash ^ static_cast<uint32_t>(cnt1)) * 0x100000001B3ull;

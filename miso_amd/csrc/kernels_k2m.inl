@@ -18,8 +18,14 @@
 
 namespace miso {
 
+// wavefronts per SIMD the register allocation is made for: two when the launch is one round of eight-wavefront workgroups
+// (one workgroup per CU by construction), three when it runs in several rounds of smaller ones -- the third wavefront is
+// worth more there than the registers (MISO's default settings, 240 000 chains on one lane each: 199.0 ms with three,
+// 206.9 ms with two, same kernel otherwise; the bodies fitted 168 registers by themselves until round 6's
+// Metropolis-Hastings step with both outcomes' proposals in flight needed 177)
+#define K2M_WAVES(M, W) (((W) == 8 || (M) != 0) ? 2 : 3)   // (paired-end: the chains' LDS tables decide, as before)
 template <int MODE, int WPB>
-__global__ __launch_bounds__(64 * WPB, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void sampler_k2_multi(const KernelArgs a) {
+__global__ __launch_bounds__(64 * WPB, K2M_WAVES(MODE, WPB)) void sampler_k2_multi(const KernelArgs a) {
   // One-round single-end launches (a.wave_tab): behind the workgroup-wide chains' a.mix_blocks workgroups every WAVEFRONT
   // looks up which run's wavefront it is -- the host pairs the launch's wavefronts by estimated duration ACROSS the runs,
   // heaviest with lightest on one SIMD (wavefronts w and w + 4), so that every SIMD carries the same work (runtime.hip

@@ -312,6 +312,15 @@ void miso_batch::upload(int dev) {
   device = dev;
   HIP_OK(hipSetDevice(dev));
   resolve_pending();
+  {   // the reference's proposal density overflows beyond about 85 isoforms (miso.c:97-122: linear domain):
+      // such a chain accepts its first proposal and nothing after -- bit-equal to the reference, not a posterior
+    int wide = 0, kmax = 0;
+    for (const PackedEvent &e : events) if (e.K > 80) { wide++; kmax = std::max(kmax, e.K); }
+    if (wide > 0 && std::getenv("MISO_QUIET") == nullptr)
+      std::fprintf(stderr, "[miso] warning: %d gene(s) of more than 80 isoforms (up to %d): as in the reference, the proposal density "
+                           "(miso.c:97-122, linear domain) overflows beyond about 85 isoforms and the chains stop accepting after "
+                           "their first iteration; the samples equal the reference's and are not a posterior\n", wide, kmax);
+  }
   const int n = static_cast<int>(events.size());
   const int C = p.noChains, M = p.noIterations, Sn = S();
   h_events.assign(n, DevEvent{});
@@ -529,6 +538,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   a.il = static_cast<int>(fd.prob.size()); a.n_events = n;
   a.C = p.noChains; a.M = p.noIterations; a.B = p.noBurnIn; a.lag = p.noLag;
   a.start = p.start; a.first_event_id = first_event_id; a.seed = seed;
+  a.balance = (std::getenv("MISO_PRIO_QUARTILES") && std::atoi(std::getenv("MISO_PRIO_QUARTILES")) != 0) ? 2 : 0;   // experiment: device.hpp prio_by_progress
   for (int i = 0; i < MISO_MAX_ROUNDS - 1; i++) a.round_start[i] = i < static_cast<int>(round_starts.size()) ? round_starts[i] : -1;
   last_seed = seed; last_first_event_id = first_event_id;
   converged_done = false;
@@ -874,12 +884,21 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   // sampler_lane_k (kernels_lane.hip), provided every one of them has its class table
   // (level 2 only: with the classes of a five- or ten-isoform event sharing ~1000 reads the chains of small binomials
   // cost more than the read sweep they replace -- profiles/r03_collapsed.txt; it pays from ~10^4 reads per event)
-  bool lane_gen = collapsed && collapsed_level >= 2 && !p.paired && n_gen > 0;
-  for (const GenRun &run : gen_runs) if (run.nocls || run.kc >= 64) lane_gen = false;   // (33 isoforms and more: several mask words, sampler_wave / sampler_big only)
+  // The route is decided per run: a class whose events all have their class tables takes sampler_lane_k, a
+  // run without them -- or of 33 isoforms and more: several mask words, sampler_wave / sampler_big only -- keeps the
+  // per-read kernels: its events are sampled per read, i.e. equal the CPU checker's COUNTER mode
+  // (tests/test_gpu_collapsed.py).
+  std::vector<char> run_lane(gen_runs.size(), 0);
+  bool lane_gen = false;
+  if (collapsed && collapsed_level >= 2 && !p.paired && n_gen > 0)
+    for (size_t ri = 0; ri < gen_runs.size(); ri++) {
+      run_lane[ri] = !(gen_runs[ri].nocls || gen_runs[ri].kc >= 64);
+      lane_gen |= run_lane[ri] != 0;
+    }
   std::vector<int> flat_nc(gen_runs.size(), 0), flat_nc_max(gen_runs.size(), 0);
   for (size_t ri = 0; ri < gen_runs.size(); ri++) {
     const GenRun &run = gen_runs[ri];
-    if (lane_gen) break;
+    if (run_lane[ri]) continue;
     if (p.paired || run.nocls || run.kc >= 64 || std::getenv("MISO_NO_FLAT") != nullptr) continue;
     const int slice = flat_layout(run.kmax, std::max(run.maxcls, 1)).bytes;
     // workgroups per CU the chains per wavefront are sized for: kernels_flat.inl's register budgets -- 3 up to four isoforms
@@ -1077,7 +1096,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   std::vector<GrpShape> grp_sh(gen_runs.size());
   for (size_t ri = 0; ri < gen_runs.size(); ri++) {
     GenRun &run = gen_runs[ri];
-    if (lane_gen) break;
+    if (run_lane[ri]) continue;
     if (run.kc >= 64) { flat_nc[ri] = 0; grp_G[ri] = 64; grp_sh[ri] = GrpShape{0, 0}; continue; }   // more than 32 isoforms: one wavefront per chain
     // sampler_flat or sampler_grp?  Measured on the batch's first launch like the lanes per chain below
     // (flat wins at every isoform count of profiles/r02_flat_vs_grp_sweep.txt but 5); a small or untuned
@@ -1489,7 +1508,11 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       return;
     }
     switch (k2_plan.wpb) {
-    case 8: hipLaunchKernelGGL((sampler_k2_multi<0, 8>), grid, dim3(512), K2_RED_BYTES, st, ka); break;
+    case 8:
+      // the whole launch resident at once: the two wavefronts of a SIMD keep step (kernels_k2.inl k2_balance)
+      if (k2_plan.rounds == 1) ka.balance = (std::getenv("MISO_K2_BALANCE") && std::atoi(std::getenv("MISO_K2_BALANCE")) == 0) ? 0 : 1;
+      hipLaunchKernelGGL((sampler_k2_multi<0, 8>), grid, dim3(512), K2_RED_BYTES, st, ka);
+      break;
     case 4: hipLaunchKernelGGL((sampler_k2_multi<0, 4>), grid, dim3(256), K2_RED_BYTES, st, ka); break;
     default: hipLaunchKernelGGL((sampler_k2_multi<0, 1>), grid, dim3(64), 0, st, ka); break;
     }
@@ -1578,15 +1601,15 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       add_stat(k2_name(k2G, wpart), static_cast<double>(waves), trips, static_cast<double>(chains), words);
     }
   }
-  if (lane_gen) {
-    double words = 0;
-    for (int i = 0; i < n_gen; i++) words += static_cast<double>(events[h_slots[n_k2 + i]].n_draw) * p.noChains;
-    const long chains = static_cast<long>(n_gen) * p.noChains;
-    add_stat("sampler_lane_k", static_cast<double>((chains + 63) / 64), 0.0, static_cast<double>(chains), words);
-  }
   for (size_t ri = 0; ri < gen_runs.size(); ri++) {
-    if (lane_gen) break;
     const GenRun &run = gen_runs[ri];
+    if (run_lane[ri]) {
+      double words = 0;
+      for (int i = 0; i < run.count; i++) words += static_cast<double>(events[h_slots[n_k2 + run.first + i]].n_draw) * p.noChains;
+      const long chains = static_cast<long>(run.count) * p.noChains;
+      add_stat("sampler_lane_k", static_cast<double>((chains + 63) / 64), 0.0, static_cast<double>(chains), words);
+      continue;
+    }
     const bool flat = flat_nc[ri] > 0;
     const int G = grp_G[ri], C = p.noChains, cpw = flat ? flat_nc[ri] : std::max(1, 64 / G);
     const bool w64 = G == 64 && run.wave64 && p.paired && run.dense;
@@ -1713,12 +1736,13 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     }
   };
   if (lane_route || lane_gen) ensure_logfact(0, n_k2 + n_gen);
-  if (lane_gen) {
-    int ks = 2;
-    for (const GenRun &run : gen_runs) ks = std::max(ks, run.kmax);
+  for (size_t ri = 0; ri < gen_runs.size(); ri++) {
+    if (!run_lane[ri]) continue;
+    const GenRun &run = gen_runs[ri];
+    const int ks = std::max(2, run.kmax);
     KernelArgs ka = a;
-    ka.slot_event = d_slots + n_k2; ka.n_slots = n_gen; ka.kstride = ks; ka.logfact = d_logfact;
-    const long chains = static_cast<long>(n_gen) * p.noChains;
+    ka.slot_event = d_slots + n_k2 + run.first; ka.n_slots = run.count; ka.kstride = ks; ka.logfact = d_logfact;
+    const long chains = static_cast<long>(run.count) * p.noChains;
     const size_t lds = lanek_lds_bytes(ks);
     HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sampler_lane_k), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     last_kernels += std::string(last_kernels.empty() ? "" : ",") + "sampler_lane_k";
@@ -1800,7 +1824,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     r0 = r1;
   }
   run_in_multi = in_multi;
-  for (size_t ri = 0; ri < gen_runs.size(); ri++) if (gen_runs[ri].wide && !lane_gen && !in_multi[ri]) launch_gen_run(ri);
+  for (size_t ri = 0; ri < gen_runs.size(); ri++) if (gen_runs[ri].wide && !run_lane[ri] && !in_multi[ri]) launch_gen_run(ri);
   if (n_k2w > 0 && k2w_multi) {
     lanes_per_chain = k2w_plan.seg_lanes[k2w_plan.n_segs - 1];
     last_kernels = "sampler_k2_multi<2, " + std::to_string(k2w_plan.wpb) + ">";
@@ -1856,7 +1880,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       launch_k2(a, k2_G, stream_for_next());
     }
   }
-  for (size_t ri = 0; ri < gen_runs.size(); ri++) if (!gen_runs[ri].wide && !lane_gen && !in_multi[ri]) launch_gen_run(ri);
+  for (size_t ri = 0; ri < gen_runs.size(); ri++) if (!gen_runs[ri].wide && !run_lane[ri] && !in_multi[ri]) launch_gen_run(ri);
   for (size_t i = 1; i < kernel_no && i <= aux_streams.size() && std::getenv("MISO_SERIAL_KERNELS") == nullptr; i++) {
     HIP_OK(hipEventRecord(aux_done[i - 1], aux_streams[i - 1]));
     HIP_OK(hipStreamWaitEvent(stream, aux_done[i - 1], 0));

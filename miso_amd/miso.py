@@ -105,7 +105,8 @@ class GenesDispatcher(object):
     def __init__(self, gff_dir, bam_filename, output_dir, read_len, overhang_len,
                  settings_fname=None, paired_end=None, gene_ids=None, num_proc=None,
                  event_type=None, seed=None, summarize=False, compare_bam=None,
-                 labels=("sample1", "sample2")):
+                 labels=("sample1", "sample2"), summary_only=False):
+        self.summary_only = bool(summary_only)
         self.gff_dir, self.bam_filename, self.output_dir = gff_dir, bam_filename, output_dir
         if not os.path.isfile(self.bam_filename):
             raise IOError("BAM file %s not found." % self.bam_filename)
@@ -178,6 +179,8 @@ class GenesDispatcher(object):
                        self.bam_filename, self.output_dir]
                 if part:
                     cmd += ["--summary-file", part]
+                    if self.summary_only:
+                        cmd += ["--no-miso-files"]
             # more chunks than GPUs (-p above the GPU count) share the GPUs round robin
             cmd += ["--read-len", str(self.read_len), "--device", str(batch_num % self.n_gpus),
                     "--first-event-id", str(first)]
@@ -205,6 +208,15 @@ class GenesDispatcher(object):
             return self._run_subprocesses(jobs, parts, table)
         import multiprocessing
         from . import sam_utils
+        if len(jobs) == 1 and self.compare_bam is None:
+            # one worker: nothing to share -- it opens the file itself, on a thread beside its annotation work
+            # (run_miso.compute_gene_psi), instead of waiting here for a decode it could be working next to
+            ctx = multiprocessing.get_context("fork")
+            sys.stdout.flush()
+            batch_num, cmd, log = jobs[0]
+            p = ctx.Process(target=_forked_worker, args=(cmd[3:], log, 0, 1))
+            p.start()
+            return self._finish([(batch_num, p.join, lambda p=p: p.exitcode, log)], parts, table)
         try:
             sam_utils.use_reader_library()
             for path in (self.bam_filename, self.compare_bam):
@@ -257,7 +269,7 @@ class GenesDispatcher(object):
 def compute_all_genes_psi(gff_dir, bam_filename, read_len, output_dir, overhang_len=1,
                           paired_end=None, settings_fname=None, num_proc=None, event_type=None,
                           seed=None, summarize=False, compare_bam=None,
-                          labels=("sample1", "sample2")):
+                          labels=("sample1", "sample2"), summary_only=False):
     """miso.py:340-420."""
     print("Computing Psi values...")
     print("  - GFF index: %s" % gff_dir)
@@ -267,8 +279,8 @@ def compute_all_genes_psi(gff_dir, bam_filename, read_len, output_dir, overhang_
     os.makedirs(output_dir, exist_ok=True)
     return GenesDispatcher(gff_dir, bam_filename, output_dir, read_len, overhang_len,
                            settings_fname=settings_fname, paired_end=paired_end, num_proc=num_proc,
-                           event_type=event_type, seed=seed, summarize=summarize,
-                           compare_bam=compare_bam, labels=labels).run()
+                           event_type=event_type, seed=seed, summarize=summarize or summary_only,
+                           compare_bam=compare_bam, labels=labels, summary_only=summary_only).run()
 
 
 def main(argv=None):
@@ -288,6 +300,9 @@ def main(argv=None):
     ap.add_argument("--summarize", action="store_true",
                     help="also write OUT/summary/<OUT>.miso_summary (summarize_miso's table) from "
                          "posterior means / credible intervals computed on the GPU during the run")
+    ap.add_argument("--summary-only", action="store_true",
+                    help="--summarize without the per-event .miso files: the run's product is the summary table alone "
+                         "(what summarize_miso needs of a .miso file is its mean and credible interval, samples_utils.py:263-329)")
     ap.add_argument("--compare", metavar="BAM2", default=None,
                     help="second RNA-seq sample: sample both, write OUT/<label1>/, OUT/<label2>/ and the "
                          "compare_miso table OUT/<l1>_vs_<l2>/bayes-factors/<l1>_vs_<l2>.miso_bf")
@@ -311,6 +326,7 @@ def main(argv=None):
                                    overhang_len=a.overhang_len or 1, paired_end=a.paired_end,
                                    settings_fname=settings_filename, num_proc=a.num_proc,
                                    event_type=a.event_type, seed=a.seed, summarize=a.summarize,
+                                   summary_only=a.summary_only,
                                    compare_bam=None if a.compare is None else
                                    os.path.abspath(os.path.expanduser(a.compare)),
                                    labels=tuple(a.labels))

@@ -306,42 +306,85 @@ class MISOSampler:
         return (batch, slots, written, int(num_iters), int(burn_in), int(lag))
 
     def finish_batch(self, state, seed=None, first_event_id=0, verbose=False, summary_file=None,
-                     confidence_level=0.95, threads=0):
-        batch, slots, written, num_iters, burn_in, lag = state
+                     confidence_level=0.95, threads=0, write_files=True):
+        """Launch, then the event's outputs.  write_files=False (with a summary_file): no per-event `.miso` file --
+        the posterior means and credible intervals that `summarize_miso` would compute from those files
+        (samples_utils.py:263-329) come from the device, summarised from the four-decimal text the file WOULD hold.
+        The two halves are callable on their own (`launch_batch`, `output_batch`): run_miso.py runs the next batch's
+        launch beside this one's outputs."""
+        self.launch_batch(state, seed=seed, first_event_id=first_event_id)
+        return self.output_batch(state, verbose=verbose, summary_file=summary_file, confidence_level=confidence_level,
+                                 threads=threads, write_files=write_files)
+
+    def launch_batch(self, state, seed=None, first_event_id=0):
+        """Upload, sample, download (native code, the interpreter lock released throughout)."""
+        batch, slots = state[0], state[1]
         if not slots:
-            return written
+            return
         dev = int(os.environ.get("MISO_DEVICE", os.environ.get("LOCAL_RANK", "0")))
-        timing = os.environ.get("MISO_TIMING")
         t0 = time.time()
         batch.run(device=dev, seed=seed if seed is not None else random.getrandbits(64),
                   first_event_id=first_event_id)
+        if os.environ.get("MISO_TIMING"):
+            print("[miso] batch of %d events: upload + sample + download %.2f s" % (len(slots), time.time() - t0))
+
+    def _static_header(self, gene):
+        """The parts of the header line that depend on the annotation only (miso_sampler.py:376-454)."""
+        iso_delim = "_"
+        if isinstance(gene.isoforms[0].desc, list):
+            str_isoforms = "[" + ",".join("'" + iso_delim.join(iso.desc) + "'" for iso in gene.isoforms) + "]"
+        else:
+            str_isoforms = "[" + ",".join("'" + iso.desc + "'" for iso in gene.isoforms) + "]"
+        exon_lens = ",".join("('%s',%d)" % (p.label, p.len) for p in gene.parts)
+        chrom = gene.chrom if gene.chrom is not None else "NA"
+        strand = gene.strand if gene.strand is not None else "NA"
+        return ("#isoforms=%s\texon_lens=%s" % (str_isoforms, exon_lens),
+                "chrom=%s\tstrand=%s\tmRNA_starts=%s\tmRNA_ends=%s\n"
+                % (chrom, strand, ",".join(str(iso.genomic_start) for iso in gene.isoforms),
+                   ",".join(str(iso.genomic_end) for iso in gene.isoforms)))
+
+    def output_batch(self, state, verbose=False, summary_file=None, confidence_level=0.95, threads=0,
+                     write_files=True):
+        """The `.miso` files and / or the summary table of a launched batch.  The header's run-dependent fields are
+        formatted natively for the whole batch (miso_batch_header_fields); miso_header() below is the same line field
+        by field in Python (the one-event path; tests/test_gpu_frontend.py compares the files byte for byte)."""
+        batch, slots, written, num_iters, burn_in, lag = state
+        if not slots:
+            return written
+        timing = os.environ.get("MISO_TIMING")
         t1 = time.time()
         if summary_file is not None:
             batch.summarize(confidence_level, as_text=True)     # summarize_miso summarises the file's text
         idxs, paths, headers, rows = [], [], [], []
-        for i, idx, gene, out in slots:
-            templates, counts, assignments, rd = batch.result_lite(idx)
-            if np.all(assignments == -1):                                 # miso_sampler.py:352-354
+        fields = batch.header_fields([idx for _, idx, _, _ in slots])
+        middle = "\titers=%d\tburn_in=%d\tlag=%d\tpercent_accept=" % (num_iters, burn_in, lag)
+        dirs = set()
+        for (i, idx, gene, out), (unassigned, pa, counts, assigned) in zip(slots, fields):
+            if unassigned:                                                # miso_sampler.py:352-354
                 if verbose:
                     print("All reads incompatible with annotation, skipping...")
                 continue
-            percent_acceptance = float(rd.noAccepted) / (rd.noAccepted + rd.noRejected) * 100
-            header = self.miso_header(gene, (templates, counts), assignments, num_iters, burn_in,
-                                      lag, percent_acceptance, "drift")
-            os.makedirs(os.path.dirname(os.path.abspath(out)), exist_ok=True)
-            idxs.append(idx); paths.append(out); headers.append(header)
-            written[i] = out
+            head, tail = self._static_header(gene)
+            header = "%s%s%s\tproposal_type=drift\tcounts=%s\tassigned_counts=%s\t%s" % (head, middle, pa, counts, assigned, tail)
+            if write_files:
+                d = os.path.dirname(os.path.abspath(out))
+                if d not in dirs:
+                    os.makedirs(d, exist_ok=True)
+                    dirs.add(d)
+                idxs.append(idx); paths.append(out); headers.append(header)
+                written[i] = out
             if summary_file is not None:
                 name = os.path.basename(out)[:-len(".miso")]
                 hdr = dict(kv.split("=", 1) for kv in header[1:].rstrip("\n").split("\t"))
                 rows.append((name,) + tuple(batch.summary(idx)) + (hdr,))
         t2 = time.time()
-        batch.write_miso_files(idxs, paths, headers, threads)
+        if write_files:
+            batch.write_miso_files(idxs, paths, headers, threads)
         if summary_file is not None:
             summary.write_summary(summary_file, rows)
         if timing:
-            print("[miso] batch of %d events: upload + sample + download %.2f s, headers %.2f s, .miso files %.2f s"
-                  % (len(slots), t1 - t0, t2 - t1, time.time() - t2))
+            print("[miso] batch of %d events: headers %.2f s, .miso files / table %.2f s"
+                  % (len(slots), t2 - t1, time.time() - t2))
         return written
 
     # -- two RNA-seq samples over the same events + Bayes factors (compare_miso) ----------------

@@ -29,25 +29,32 @@ import miso_sampler as miso  # noqa: E402  (flat import: it shares `pysplicing` 
 
 
 def collect_gene_events(gene_entries, bamfile, output_dir, read_len, overhang_len,
-                        paired_end=None, event_type=None, verbose=True, native=False):
+                        paired_end=None, event_type=None, verbose=True, native=False, entry_offset=0, cache=None):
     """run_miso.py:98-206 up to (not including) sampler.run_sampler, for many genes.
     gene_entries: iterable of (gene_id, indexed_gff_filename).
     Returns (events, info): events = [(reads, gene_obj, output_filename, None, index in gene_entries)] for
-    MISOSampler.run_sampler_batch, info = per gene status strings (for logs / tests)."""
+    MISOSampler.run_sampler_batch, info = per gene status strings (for logs / tests).
+    entry_offset / cache: a long gene list collected piece by piece (compute_gene_psi: the next piece is collected while
+    the last one is sampled) -- the entries' numbers go on from entry_offset, the loaded index files are kept in `cache`."""
     settings = Settings.get()
     min_event_reads = Settings.get_min_event_reads()
     strand_rule = Settings.get_strand_param()
     filter_reads = settings.get("filter_reads", True)               # run_miso.py:91-94
     events, info = [], {}
-    loaded = {}
-    bundles = {}      # index root -> {gene_id: gene_info} from genes_bundle.pickle (or None)
-    for entry_no, (gene_id, gff_index_filename) in enumerate(gene_entries):
+    cache = {} if cache is None else cache
+    loaded = cache.setdefault("loaded", {})
+    bundles = cache.setdefault("bundles", {})      # index root -> {gene_id: gene_info} from genes_bundle.pickle (or None)
+    for entry_no, (gene_id, gff_index_filename) in enumerate(gene_entries, entry_offset):
         root = os.path.dirname(os.path.dirname(gff_index_filename))
         if root not in bundles:
             bpath = os.path.join(root, gff_utils.BUNDLE_BASENAME)
             bundles[root] = gff_utils.load_indexed_gff_file(bpath) if os.path.isfile(bpath) else None
         tx_bounds = None
-        if bundles[root] is not None and gene_id in bundles[root]:
+        ready = cache.get("genes", {}).pop((root, gene_id), None)    # made by preload_genes while the alignments were decoded
+        if ready is not None:
+            gene_obj, tx_bounds = ready
+            gff_genes = {gene_id: {"gene_object": gene_obj}}
+        elif bundles[root] is not None and gene_id in bundles[root]:
             gene_obj, tx_bounds = gene_utils.gene_from_compact(bundles[root][gene_id])
             gff_genes = {gene_id: {"gene_object": gene_obj}}
         else:
@@ -56,7 +63,8 @@ def collect_gene_events(gene_entries, bamfile, output_dir, read_len, overhang_le
                 info[gene_id] = "no index"
                 continue
             if gff_index_filename not in loaded:
-                loaded = {gff_index_filename: gff_utils.load_indexed_gff_file(gff_index_filename)}
+                loaded.clear()                                      # one index file at a time, as before
+                loaded[gff_index_filename] = gff_utils.load_indexed_gff_file(gff_index_filename)
             gff_genes = loaded[gff_index_filename]
         if gene_id not in gff_genes:
             info[gene_id] = "not in index"
@@ -110,6 +118,22 @@ def collect_gene_events(gene_entries, bamfile, output_dir, read_len, overhang_le
     return events, info
 
 
+def preload_genes(gene_entries, cache):
+    """The annotation side of collect_gene_events -- index bundles, gene objects, transcript bounds -- for genes that come
+    from a bundle, kept in `cache` for it: none of it needs the alignment file, so compute_gene_psi does it WHILE the file
+    is being decoded (interpreter work beside native work)."""
+    bundles = cache.setdefault("bundles", {})
+    genes = cache.setdefault("genes", {})
+    for gene_id, gff_index_filename in gene_entries:
+        root = os.path.dirname(os.path.dirname(gff_index_filename))
+        if root not in bundles:
+            bpath = os.path.join(root, gff_utils.BUNDLE_BASENAME)
+            bundles[root] = gff_utils.load_indexed_gff_file(bpath) if os.path.isfile(bpath) else None
+        b = bundles[root]
+        if b is not None and gene_id in b:
+            genes[(root, gene_id)] = gene_utils.gene_from_compact(b[gene_id])
+
+
 def _check_device(device):
     """A worker that was handed a device it cannot open (the dispatcher counted GPUs the process may not use) stops
     here with a clear message and a non-zero exit status instead of failing batch by batch."""
@@ -122,7 +146,7 @@ def _check_device(device):
 def compute_gene_psi(gene_ids, gff_index_filename, bam_filename, output_dir, read_len,
                      overhang_len, paired_end=None, event_type=None, verbose=True, bamfile=None,
                      seed=None, first_event_id=0, device=None, gene_entries=None,
-                     max_events_per_launch=8192, summary_file=None):
+                     max_events_per_launch=8192, summary_file=None, write_files=True):
     """run_miso.py:34-206.  `gene_entries` (list of (gene_id, index file)) generalises the
     reference's (gene_ids, one index file) so a whole batch file is one GPU batch."""
     os.makedirs(output_dir, exist_ok=True)
@@ -141,24 +165,75 @@ def compute_gene_psi(gene_ids, gff_index_filename, bam_filename, output_dir, rea
         os.environ["MISO_DEVICE"] = str(int(device))               # read by pysplicing per launch
     t0 = time.time()
     own = bamfile is None
-    if own:
-        bamfile = sam_utils.load_bam_reads(bam_filename)
-    events, info = collect_gene_events(gene_entries, bamfile, output_dir, read_len, overhang_len,
-                                       paired_end=paired_end, event_type=event_type,
-                                       verbose=verbose, native=True)
-    t1 = time.time()
-    written = []
+    import threading
+    opened = {}
+    if own:      # decoded on a thread of its own (native code), the annotation work of the first stage beside it
+        def _open():
+            try:
+                opened["file"] = sam_utils.load_bam_reads(bam_filename)
+            except BaseException as e:
+                opened["error"] = e
+        opener = threading.Thread(target=_open, daemon=True)
+        opener.start()
     if paired_end:
         mean_frag_len = int(paired_end[0])
         frag_variance = np.power(int(paired_end[1]), 2)             # run_miso.py:80-83
-    # batches in flight: while one is on the GPU and its files are being written (native code, GIL
-    # released), the next one's reads are moved from the alignment file into a new batch
+    # Four stages, each on a thread of its own, a chunk of genes in each (round 6; round 5 collected the whole list
+    # first and ran launch -> headers -> files of a batch on one thread: 3.5 of a 40 000-event run's 6.9 s):
+    #   collect   index lookup, gene objects, regions (Python)                          this function's producer thread
+    #   prepare   the regions' reads out of the decoded alignment file into a batch (native, parallel)    main thread
+    #   launch    upload, sample, download (native; the GPU)                                               `gpu` thread
+    #   output    header lines, .miso files, summary rows (native formatting and writing)                   `out` thread
+    # Nothing here changes anybody's random stream: every event carries its number in the caller's gene list.
+    import queue
     from concurrent.futures import ThreadPoolExecutor
+    chunks = queue.Queue(maxsize=2)
+    info, n_events, t_collect = {}, [0], [0.0]
+    failure = []
+
+    t_prepare = [0.0]
+
+    def producer():
+        nonlocal bamfile
+        cache = {}
+        try:
+            if own:
+                tc = time.time()
+                preload_genes(gene_entries, cache)
+                t_collect[0] += time.time() - tc
+                opener.join()
+                if "error" in opened:
+                    raise opened["error"]
+                bamfile = opened["file"]
+                if os.environ.get("MISO_TIMING"):
+                    print("[miso] alignment file open %.2f s after the start, gene objects made beside it in %.2f s"
+                          % (time.time() - t0, t_collect[0]))
+            for lo in range(0, len(gene_entries), max_events_per_launch):
+                tc = time.time()
+                evs, inf = collect_gene_events(gene_entries[lo:lo + max_events_per_launch], bamfile, output_dir, read_len,
+                                               overhang_len, paired_end=paired_end, event_type=event_type,
+                                               verbose=verbose, native=True, entry_offset=lo, cache=cache)
+                t_collect[0] += time.time() - tc
+                info.update(inf)
+                n_events[0] += len(evs)
+                chunks.put((lo, evs))
+        except BaseException as e:       # the consumer must not wait for a chunk that will never come
+            failure.append(e)
+        finally:
+            chunks.put(None)
+
+    threading.Thread(target=producer, daemon=True).start()
+    written = []
     summary_parts = []
-    with ThreadPoolExecutor(1) as finisher:
-        pending = None
-        for lo in range(0, len(events), max_events_per_launch):
-            chunk = events[lo:lo + max_events_per_launch]
+    with ThreadPoolExecutor(1) as gpu, ThreadPoolExecutor(1) as out:
+        in_flight = []       # output futures, oldest first: at most two batches behind the one being prepared
+        while True:
+            item = chunks.get()
+            if item is None:
+                break
+            lo, chunk = item
+            if not chunk:
+                continue
             # sampler parameters as in run_miso.py:151-171 (num_isoforms only sizes an unused matrix)
             if paired_end:
                 params = miso.get_paired_end_sampler_params(2, mean_frag_len, frag_variance, read_len,
@@ -169,24 +244,32 @@ def compute_gene_psi(gene_ids, gff_index_filename, bam_filename, output_dir, rea
             # every event keeps the number it has in the caller's gene list: skipped genes, chunking
             # and the number of GPUs do not change anybody's random stream
             chunk = [ev[:4] + (first_event_id + ev[4],) for ev in chunk]
+            tp = time.time()
             state = sampler.prepare_batch(num_iters, chunk, num_chains=num_chains, burn_in=burn_in,
                                           lag=lag, verbose=verbose)
-            if pending is not None:
-                written += pending.result()
+            t_prepare[0] += time.time() - tp
+            while len(in_flight) >= 2:
+                written += in_flight.pop(0).result()
             part = None if summary_file is None else "%s.part%06d" % (summary_file, lo)
             if part:
                 summary_parts.append(part)
-            pending = finisher.submit(sampler.finish_batch, state, seed=seed,
-                                      first_event_id=first_event_id + lo, verbose=verbose,
-                                      summary_file=part)
-        if pending is not None:
-            written += pending.result()
+            launched = gpu.submit(sampler.launch_batch, state, seed=seed, first_event_id=first_event_id + lo)
+
+            def outputs(sampler=sampler, state=state, launched=launched, part=part):
+                launched.result()
+                return sampler.output_batch(state, verbose=verbose, summary_file=part, write_files=write_files)
+            in_flight.append(out.submit(outputs))
+        for f in in_flight:
+            written += f.result()
+    if failure:
+        raise failure[0]
+    t1 = t0 + t_collect[0]
     if summary_file is not None:
         merge_tables(summary_parts, summary_file)
     t2 = time.time()
     if verbose:
-        print("Collected %d events in %.2f s, sampled in %.2f s"
-              % (len(events), t1 - t0, t2 - t1))
+        print("Collected %d events in %.2f s (beside the decoding / sampling), batches prepared in %.2f s, whole run %.2f s"
+              % (n_events[0], t1 - t0, t_prepare[0], t2 - t0))
     if own:
         bamfile.close()
     return written, info
@@ -280,6 +363,8 @@ def main(argv=None):
                     help="sample both RNA-seq samples and write the Bayes-factor table")
     ap.add_argument("--summary-file", default=None,
                     help="also write the summarize_miso table of this run (device-side summaries)")
+    ap.add_argument("--no-miso-files", action="store_true",
+                    help="with --summary-file: only the table, no per-event .miso files")
     ap.add_argument("--paired-end", nargs=2, type=float, metavar=("MEAN", "SD"))
     ap.add_argument("--read-len", type=int)
     ap.add_argument("--overhang-len", type=int)
@@ -315,7 +400,8 @@ def main(argv=None):
         compute_gene_psi(None, None, bam_filename, output_dir, a.read_len, overhang_len,
                          paired_end=paired_end, event_type=a.event_type, gene_entries=entries,
                          seed=a.seed, first_event_id=a.first_event_id, device=a.device,
-                         summary_file=a.summary_file)
+                         summary_file=a.summary_file,
+                         write_files=not (a.no_miso_files and a.summary_file))
         print("Processed %d genes" % len(entries))
     elif a.compute_gene_psi:
         gene_ids = a.compute_gene_psi[0].split(",")

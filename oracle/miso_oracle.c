@@ -184,6 +184,7 @@ void orc_philox_r(int rounds, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3
   memcpy(out4, o.v, 16);
 }
 int orc_philox_rounds(void) { return MISO_PHILOX_ROUNDS; }
+int orc_contract_version(void) { return MISO_CONTRACT_VERSION; }
 
 /* random.c:1543-1551 splicing_norm_rand: u = (int)(2^27 u1) + u2; qnorm(u / 2^27) */
 static double norm_from_unif(double u1, double u2, const orc_math_t *M) {

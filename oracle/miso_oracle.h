@@ -123,6 +123,7 @@ void orc_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
 void orc_philox_r(int rounds, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
                   uint32_t *out4);
 int orc_philox_rounds(void);
+int orc_contract_version(void);   /* include/miso_philox.h MISO_CONTRACT_VERSION as this checker was built */
 int orc_convergent_mean(const double *samples, int K, int C, int noSamples);
 int orc_assignment_matrix(const orc_gene_t *g, int readLength, int overHang, double *out, int max_cols);
 double orc_score_classes(int K, const double *psi, const double *hyper, const double *amat, int ncls, const double *matches);

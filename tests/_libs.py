@@ -277,6 +277,10 @@ class OrcLib(_Base):
     def philox_rounds(self):
         return self.lib.orc_philox_rounds()
 
+    def contract_version(self):
+        """include/miso_philox.h MISO_CONTRACT_VERSION as this checker was compiled (0: a checker older than the constant)"""
+        return int(self.lib.orc_contract_version()) if hasattr(self.lib, "orc_contract_version") else 0
+
     def binomial(self, n, p, count, seed=1, event_id=0):
         """`count` draws of include/miso_binomial.h's Binomial(n, p) (word streams of iterations 0 .. count-1)."""
         out = np.zeros(count, np.int32)

@@ -2,6 +2,7 @@
 the sampler entry points fail loudly (there is no CPU fallback to fall into)."""
 import ctypes
 import os
+import sys
 import re
 
 import numpy as np
@@ -46,6 +47,18 @@ def test_every_declared_symbol_is_exported():
     lib = ctypes.CDLL(capi.LIB_PATH)
     missing = [n for n in declared_functions() if not hasattr(lib, n)]
     assert not missing, missing
+
+
+def test_library_and_checker_draw_by_the_same_contract_version():
+    """two rounds changed seeded counter-mode outputs without a marker.  The library and the CPU checker are
+    compiled from one header (include/miso_philox.h MISO_CONTRACT_VERSION); a stale prebuilt checker, or results saved by
+    another version, now show up here instead of as a parity failure nobody can explain."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _libs import OrcLib
+    src = open(os.path.join(ROOT, "include", "miso_philox.h")).read()
+    want = int(re.search(r"#define MISO_CONTRACT_VERSION (\d+)", src).group(1))
+    assert capi.contract_version() == want
+    assert OrcLib().contract_version() == want
 
 
 def test_no_cpu_fallback_without_device():

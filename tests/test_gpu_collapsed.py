@@ -105,7 +105,7 @@ def test_collapsed_three_or_more_isoforms_bit_exact_against_the_checker(orc, K, 
     for exons, isoforms, g, pos, cig, Kj in evs:
         b.add_event(miso_amd.Gene(exons, isoforms), pos, cig)
     b.run(seed=91, first_event_id=40)
-    assert b.last_kernels() == "sampler_lane_k"
+    assert set(b.last_kernels().split(",")) == {"sampler_lane_k"}    # (one launch per isoform-count class since round 6)
     for i, (exons, isoforms, g, pos, cig, Kj) in enumerate(evs):
         r = orc.miso(g, pos, cig, 36, mode=OrcLib.COLLAPSED, seed=91, event_id=40 + i, trace=True, **kw)
         assert r.rc == 0
@@ -132,7 +132,7 @@ def test_collapsed_mixed_isoform_counts_use_both_kernels(orc):
     for exons, isoforms, g, pos, cig in evs:
         b.add_event(miso_amd.Gene(exons, isoforms), pos, cig)
     b.run(seed=5, first_event_id=7)
-    assert sorted(b.last_kernels().split(",")) == ["sampler_lane_ilp", "sampler_lane_k"]
+    assert set(b.last_kernels().split(",")) == {"sampler_lane_ilp", "sampler_lane_k"}   # (sampler_lane_k once per isoform-count class)
     for i, (exons, isoforms, g, pos, cig) in enumerate(evs):
         r = orc.miso(g, pos, cig, 36, mode=OrcLib.COLLAPSED, seed=5, event_id=7 + i, trace=True, **kw)
         gpu = b.result(i)
@@ -246,8 +246,39 @@ def test_collapsed_level_two_with_a_gene_of_forty_isoforms_and_no_ambiguous_read
         r = orc.miso(gg, p_, c_, 36, mode=OrcLib.COLLAPSED if i else OrcLib.COUNTER, seed=3, event_id=10 + i, **kw)
         gpu = b.result(i)
         assert r.rc == 0
-        if i == 0:    # no drawing read: the collapsed and the per-read chain are the same chain
-            assert np.array_equal(gpu.samples, r.samples.reshape(gpu.samples.shape), equal_nan=True)
-            assert (gpu.assignment == r.assignment).all()
-        else:
-            assert gpu.samples.shape == r.samples.reshape(gpu.samples.shape).shape
+        # event 0, no drawing read: the collapsed and the per-read chain are the same chain.  Event 1 (round 6, ADVICE r5:
+        # the route is decided per run): the three-isoform gene keeps its collapsed step beside the forty-isoform one
+        assert np.array_equal(gpu.samples, r.samples.reshape(gpu.samples.shape), equal_nan=True), i
+        assert (gpu.assignment == r.assignment).all(), i
+    assert sorted(b.last_kernels().split(",")) == ["sampler_lane_k", "sampler_wave<false>"], b.last_kernels()
+
+
+def test_collapsed_level_two_routes_every_run_on_its_own(orc):
+    """one gene of 33 and more isoforms in a level-2 collapsed batch used to send EVERY general event back to the
+    per-read kernels -- sampled in counter mode while the checker's COLLAPSED mode expects collapsed draws.  Now the classes
+    that have their class tables take sampler_lane_k (= the checker's COLLAPSED mode, bit for bit) and only the wide gene
+    is sampled per read (= the checker's COUNTER mode), ambiguous reads and all."""
+    kw = dict(iters=150, burn=30, lag=2, chains=2)
+    evs = []
+    for j, (K, n) in enumerate([(3, 400), (40, 500), (5, 900), (2, 300), (10, 250), (36, 120)]):
+        exons, isoforms = se_gene(K, exlen=220 + 7 * j)
+        g = orc.gene(flat(exons), isoforms)
+        orc.rng_seed(8100 + j)
+        rc, _, pos, cig = orc.simulate_reads(g, expr_for(K), n, 36)
+        assert rc == 0
+        evs.append((K, exons, isoforms, g, pos, cig))
+    b = miso_amd.Batch(36, collapsed=2, **kw)
+    for K, exons, isoforms, g, pos, cig in evs:
+        b.add_event(miso_amd.Gene(exons, isoforms), pos, cig)
+    b.run(seed=17, first_event_id=300)
+    kernels = b.last_kernels().split(",")
+    assert "sampler_lane_k" in kernels and "sampler_wave<false>" in kernels and "sampler_lane_ilp" in kernels, kernels
+    for i, (K, exons, isoforms, g, pos, cig) in enumerate(evs):
+        mode = OrcLib.COUNTER if K > 32 else OrcLib.COLLAPSED
+        r = orc.miso(g, pos, cig, 36, mode=mode, seed=17, event_id=300 + i, **kw)
+        gpu = b.result(i)
+        assert r.rc == 0
+        assert np.array_equal(gpu.samples, r.samples.reshape(gpu.samples.shape), equal_nan=True), (i, K)
+        assert np.array_equal(gpu.loglik, r.loglik, equal_nan=True), (i, K)
+        assert (gpu.assignment == r.assignment).all(), (i, K)
+        assert gpu.rundata.noAccepted == r.accepted, (i, K)

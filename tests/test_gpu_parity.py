@@ -293,6 +293,15 @@ def test_more_than_sixty_four_isoforms_bit_exact(orc, K, paired, device_match):
         _compare(b.result(i, trace=True), cpu, 2)
         ct, cc = b.classes(i)
         assert np.array_equal(ct, cpu.class_templates) and np.array_equal(cc, cpu.class_counts)
+        if i == 0 and not paired:
+            # ADVICE r5 -- what bit parity alone would hide.  The reference evaluates its proposal density in the linear
+            # domain (miso.c:97-122): beyond about 85 isoforms pow(2 pi sigma, -(K-1)/2) / prod(theta) overflows, the
+            # Metropolis-Hastings ratio is inf - inf = NaN and `u < NaN` rejects: every chain accepts its first proposal
+            # (iteration 0 leaves the proposal terms out, miso.c:866) and nothing after it.  Equal to the reference bit
+            # for bit, and not a posterior: README.md / INTEGRATION.md say so, the library warns at upload.
+            acc = b.result(0).rundata.noAccepted
+            assert cpu.accepted == acc
+            assert (acc > kw["chains"] * 10) if K <= 65 else (acc <= kw["chains"]), (K, acc)
         if device_match and i == 0:   # what the match kernel wrote for the wide gene = the oracle's match matrix
             m, fl = b.device_match_of(0)
             assert np.array_equal(m != 0, cpu.match != 0)

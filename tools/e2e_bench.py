@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--reads", type=int, default=1000)
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--keep", default=None)
+    ap.add_argument("--summary-only", action="store_true", help="also time `miso --run --summary-only` (no .miso files)")
     ap.add_argument("--runs", default=None,
                     help="comma list of P:DISPATCH (e.g. 1:fork,4:fork,4:subprocess): run `miso --run -p P` once per "
                          "entry on the same generated data (DISPATCH = fork: one decode per node; subprocess: "
@@ -78,18 +79,26 @@ def main():
         [(int(r.split(":")[0]), r.split(":")[1]) for r in a.runs.split(",")]
     print("events %d x %d reads, MISO defaults (6 chains, 5000 iterations, lag 10); generate %.1f s | index_gff %.1f s"
           % (a.events, a.reads, t_gen, t_index))
-    for procs, dispatch in runs:
+    if a.summary_only:
+        runs = runs + [(p_, d_, "--summary-only") for p_, d_ in runs[:1]]
+    for run in runs:
+        procs, dispatch = run[:2]
+        extra = list(run[2:])
         shutil.rmtree(out, ignore_errors=True)
         t0 = time.time()
         rc = subprocess.call([sys.executable, "-m", "miso_amd.miso", "--run", idx, sam, "--output-dir", out,
                               "--read-len", "36", "--settings-filename", settings, "-p", str(procs),
-                              "--seed", "1"], env=dict(env, MISO_DISPATCH=dispatch),
+                              "--seed", "1"] + extra, env=dict(env, MISO_DISPATCH=dispatch),
                              stdout=None if os.environ.get("MISO_TIMING") else subprocess.DEVNULL)
         t_run = time.time() - t0
         n_files = sum(len([f for f in fs if f.endswith(".miso")]) for _, _, fs in os.walk(out))
         size = sum(os.path.getsize(os.path.join(d, f)) for d, _, fs in os.walk(out) for f in fs) / 1e6
-        print("miso --run -p %d (%s): %.1f s (rc %d) -> %d .miso files, %.0f MB | %.0f events/s end to end"
-              % (procs, dispatch, t_run, rc, n_files, size, n_files / t_run), flush=True)
+        n_done = n_files
+        if extra:   # no .miso files: the events are the rows of the summary table
+            tables = [os.path.join(d, f) for d, _, fs in os.walk(out) for f in fs if f.endswith(".miso_summary")]
+            n_done = sum(max(0, sum(1 for _ in open(t)) - 1) for t in tables)
+        print("miso --run -p %d (%s)%s: %.1f s (rc %d) -> %d .miso files, %.0f MB, %d events done | %.0f events/s end to end"
+              % (procs, dispatch, " " + " ".join(extra) if extra else "", t_run, rc, n_files, size, n_done, n_done / t_run), flush=True)
         logs = os.path.join(out, "batch-logs")
         for f in sorted(os.listdir(logs))[:2]:
             lines = open(os.path.join(logs, f)).read().strip().split("\n")
