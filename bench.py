@@ -399,7 +399,9 @@ def roofline_for(batch, kernel_ms, key, sh, clock=None):
                 prof_ghz = v["kernel_cycles"] / v["kernel_ns"]
     out["profile_kernel_ms"] = None if prof_ms is None else round(prof_ms, 3)
     out["profile_clock_ghz"] = None if not prof_ghz else round(prof_ghz, 4)
-    tol = 0.05 if m is None or len(m["kernels"]) == 1 else 0.10
+    # (several kernels side by side are placed by the dispatcher as it pleases: the same launch scatters +- 15 % from one
+    # time to the next -- 758 ... 1056 ms for one kernel of the whole-gene mix over four launches, profiles/r06_pe_mix_summary.txt)
+    tol = 0.05 if m is None or len(m["kernels"]) == 1 else 0.20
     if ghz and prof_ghz and prof_ms is not None:     # cycles against cycles
         out["kernel_Mcycles"] = round(kernel_ms * ghz * 1e3, 2)
         out["profile_kernel_Mcycles"] = round(prof_ms * prof_ghz * 1e3, 2)
@@ -488,7 +490,7 @@ def measure_clock(batch, seed, first, kernel_ms):
     finally:
         batch.set_clock_probe(False)
     # (the probe's wavefront takes registers on one SIMD: a kernel that fills the register file loses a workgroup slot there)
-    ok = ghz > 0.0 and abs(ms - kernel_ms) <= 0.06 * kernel_ms
+    ok = ghz > 0.0 and abs(ms - kernel_ms) <= (0.06 if "," not in batch.last_kernels() else 0.25) * kernel_ms
     return {"ghz": ghz if ok else None, "probe_kernel_ms": round(ms, 3), "probe_window_ms": round(window, 3),
             "source": ("s_memtime / wall_clock64 of one wavefront beside the kernels of one more launch behind the timed ones "
                        "(%.3f ms; the timed launches' average %.3f ms)" % (ms, kernel_ms)) if ok else
