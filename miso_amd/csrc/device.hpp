@@ -162,18 +162,7 @@ struct RoundOpen {
 // OLDEST wavefront whenever it can issue, so wavefronts run nearly one after the other and the launch ends with every
 // SIMD's youngest running alone.  A wavefront's priority falls with its progress instead -- by quarters of its iterations:
 // a newcomer catches up with its SIMD's residents, the residents stay within a quarter of each other and finish together.
-// balance 4 ... 7: a constant priority 0 ... 3 for the whole kernel -- a batch of several kernels side by side whose classes
-// differ in length (whole-gene mixes): the longest class's wavefronts are served first wherever they share a SIMD with
-// another class's (runtime.hip).
 __device__ __attribute__((always_inline)) inline void prio_by_progress(const KernelArgs &a, int m) {
-  if (a.balance >= 4) {
-    if (m == 0) {
-      if (a.balance == 7) __builtin_amdgcn_s_setprio(3);
-      else if (a.balance == 6) __builtin_amdgcn_s_setprio(2);
-      else if (a.balance == 5) __builtin_amdgcn_s_setprio(1);
-    }
-    return;
-  }
   if (a.balance != 2) return;
   const int q = a.M >> 2;
   if (m == 0) __builtin_amdgcn_s_setprio(3);

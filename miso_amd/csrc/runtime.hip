@@ -1693,21 +1693,10 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   // up before this library was loaded -- counts as the runtime's default of 4)
   const int hwq = g_hw_queues_in_effect > 0 ? g_hw_queues_in_effect : 4;
   const bool merge_on = std::getenv("MISO_NO_PE_MERGE") == nullptr && (std::getenv("MISO_PE_MERGE") != nullptr || hwq < 8);
-  // whole-gene batches (several isoform-count classes side by side): the wavefronts' issue priority by class, longest class
-  // first (device.hpp prio_by_progress, balance 4 ... 7).  MISO_CLASS_PRIO=0: off (A/B)
-  auto class_prio = [&](int kc) {
-    const char *env = std::getenv("MISO_CLASS_PRIO");
-    const int mode = env ? std::atoi(env) : 0;
-    if (mode == 0 || !p.paired || gen_runs.size() < 2 || a.balance != 0) return a.balance;
-    if (mode == 2) return kc >= 16 ? 7 : (kc == 12 ? 6 : (kc == 8 ? 5 : 4));
-    return kc == 32 ? 7 : (kc >= 12 ? 6 : (kc == 8 ? 5 : 4));
-  };
   auto launch_gen_run = [&](size_t ri) {
     GenRun &run = gen_runs[ri];
     const int G = grp_G[ri];
     if (merged_into_prev[ri]) return;
-    KernelArgs ar = a;
-    ar.balance = class_prio(run.kc);
     const bool wave_k = G == 64 && !(run.wave64 && p.paired && run.dense);
     if (merge_on && !run.wide && run.force_G && G != 64 && flat_nc[ri] == 0 && ri + 1 < gen_runs.size()) {
       const GenRun &nx = gen_runs[ri + 1];
@@ -1722,14 +1711,14 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
           merged_into_prev[ri + 1] = 1;
           last_kernels += std::string(last_kernels.empty() ? "" : ",") + "sampler_grp<" + std::to_string(G) + ", " +
                           (p.paired ? "true" : "false") + ", " + std::to_string(run.kc) + ">";
-          launch_grp(ar, m, msh, G, stream_for_next());
+          launch_grp(a, m, msh, G, stream_for_next());
           return;
         }
       }
     }
     if (flat_nc[ri] > 0) {
       last_kernels += std::string(last_kernels.empty() ? "" : ",") + flat_name(run);
-      launch_flat(ar, run, flat_nc[ri], flat_nc_max[ri], stream_for_next());
+      launch_flat(a, run, flat_nc[ri], flat_nc_max[ri], stream_for_next());
       return;
     }
     last_kernels += std::string(last_kernels.empty() ? "" : ",") +
@@ -1738,7 +1727,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
                                         : "sampler_grp<" + std::to_string(G) + ", ") +
                                     (p.paired ? "true" : "false") +
                                     (wave_k ? std::string(">") : ", " + std::to_string(run.kc) + ">"));
-    launch_grp(ar, run, grp_sh[ri], G, stream_for_next());
+    launch_grp(a, run, grp_sh[ri], G, stream_for_next());
   };
   auto ensure_logfact = [&](int first, int count) {   // log factorials (miso_binomial.h) up to the largest event's drawing reads
     int need = 2;
@@ -1801,7 +1790,6 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       ka.slot_event = d_slots + n_k2 + m.first; ka.n_slots = m.count;
       ka.kstride = m.kmax; ka.cstride = 0; ka.tstride = msh.ts;
       ka.pe_dense = 1; ka.pe_force_exact = std::getenv("MISO_PE_FORCE_EXACT") != nullptr;
-      ka.balance = class_prio(m.kc);
       size_t lds = 0; int blocks = 0, segs = 0;
       for (size_t ri = r0; ri < r1; ri++, segs++) {
         GenRun &run = gen_runs[ri];

@@ -40,3 +40,34 @@ def test_philox_device_equals_host(orc):
     assert list(dev[2]) == [0x4dfccaba, 0x190a87f0, 0xc47362ba, 0xb6b5242a]
     for i in range(0, 5000, 97):
         assert (dev[i] == orc.philox(a[i, :4], a[i, 4:])).all()
+
+
+def test_clock_probe_measures_the_launch_and_changes_nothing():
+    """include/miso_amd.h miso_batch_set_clock_probe: one sleeping wavefront beside the sampler kernels reads s_memtime
+    against the constant reference clock over exactly the launch.  The samples are those of the launch without it, the
+    window is the launch, the clock is a gfx950's (bench.py prices its roofline's peak with it)."""
+    from miso_amd import workload
+    kw = dict(K=2, n_reads=1000, read_len=36, iters=1500, burn=300, lag=3, chains=2, paired=False)
+    plain = workload.build_batch(0, 3000, **kw)
+    plain.upload(0)
+    plain.launch(seed=9, first_event_id=0)
+    ms0 = plain.sync()
+    assert plain.last_clock() == (0.0, 0.0)                       # off: nothing measured
+    probed = workload.build_batch(0, 3000, **kw)
+    probed.upload(0)
+    probed.set_clock_probe(True)
+    for _ in range(2):                                             # (the second launch's give-up time comes from the first's duration)
+        probed.launch(seed=9, first_event_id=0)
+        ms = probed.sync()
+    ghz, window = probed.last_clock()
+    assert 1.0 < ghz < 2.6, ghz
+    assert abs(window - ms) < 0.25 * ms + 0.5, (window, ms)
+    assert ms < 3.0 * ms0 + 1.0
+    plain.download()
+    probed.download()
+    for i in (0, 1234, 2999):
+        assert np.array_equal(plain.result(i).samples, probed.result(i).samples)
+    probed.set_clock_probe(False)
+    probed.launch(seed=9, first_event_id=0)
+    probed.sync()
+    assert probed.last_clock() == (0.0, 0.0)

@@ -17,6 +17,10 @@ def main():
     capi.set_device(0)
     for K in [int(x) for x in sys.argv[1:]] or [5, 10]:
         total = 40000 if K < 10 else 20000
+        # the same kernel and lanes per chain whatever the events' share of the batch (the size buckets would give a gene
+        # that is a hundredth of the batch a wavefront of its own)
+        os.environ["MISO_NO_PE_BUCKETS"] = "1"
+        os.environ["MISO_GENERAL_LANES"] = "8" if K < 10 else "16"
         for events, chains in ((total, 1), (total // 10, 10), (total // 100, 100)):
             sh = dict(bench.BASE_SHAPE, K=K, paired=True, chains=chains)
             b = bench.build(0, events, sh)
