@@ -44,9 +44,10 @@ struct miso_batch {
   std::vector<int64_t> iters_counted;   // per event: iterations behind its accept count (empty: noIterations each)
   // a batch that runs a LATER round (made by converge_rounds): that round's own schedule, the reference's noIterations /
   // noBurnIn at that point (p holds the device's: everything from the chain's start), and the iterations at which the
-  // rounds after the first open (KernelArgs::round_start)
+  // rounds after the first open (KernelArgs::round_tab)
   int round_iters = 0, round_burn = 0;
   std::vector<int> round_starts;
+  int32_t *d_round_tab = nullptr;   // ... on the device (KernelArgs::round_tab)
   std::vector<char> went_on;      // per event: it ran a further round in the last launch's converge_rounds
   bool event_went_on(int i) const { return i < static_cast<int>(went_on.size()) && went_on[i] != 0; }
   int rounds = 1;                 // rounds the last launch took (1 = the events' own schedule sufficed)

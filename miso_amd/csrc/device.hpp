@@ -124,8 +124,9 @@ struct KernelArgs {
   // of equal lanes per chain.  Run s: workgroups [seg_block[s], seg_block[s + 1]), events (slots)
   // [seg_slot[s], seg_slot[s + 1]) of the launch's list, seg_lanes[s] lanes per chain (K2_WIDE = the whole workgroup).
   // stop = CONVERGENT_MEAN (runtime.hip converge_rounds): the iterations that open a later round of the reference's loop,
-  // ascending, unused entries -1 (every launch of stop = FIXEDNO: all -1)
-  int32_t round_start[MISO_MAX_ROUNDS - 1];
+  // ascending, MISO_MAX_ROUNDS - 1 entries in global memory, unused ones -1; null for a launch without later rounds
+  // (every launch of stop = FIXEDNO)
+  const int32_t *round_tab;
   // sampler_k2_multi<0, 8>, one round: the two wavefronts of a SIMD keep step by priority (kernels_k2.inl k2_balance)
   int32_t balance;
   int32_t n_segs;
@@ -141,17 +142,16 @@ struct KernelArgs {
 // converge_rounds) is told where the later rounds open; at() is called once per iteration, in order.
 struct RoundOpen {
   int next, i;
-  __device__ explicit RoundOpen(const KernelArgs &a) : next(a.round_start[0]), i(0) {}
+  __device__ explicit RoundOpen(const KernelArgs &a) : next(a.round_tab ? a.round_tab[0] : -1), i(0) {}
   __device__ __attribute__((always_inline)) bool at(const KernelArgs &a, int m) {
     if (m == 0) return true;
     if (__builtin_expect(m != next, 1)) return false;
-    // (constant indices only: a run-time index into the kernel's by-value arguments would make the compiler keep a
-    // copy of them in scratch)
+    // (a table in global memory behind a pointer that may be null: nothing the compiler can load ahead of the loop and keep
+    // in scalar registers -- seven entries among the kernel's by-value arguments were, and came back through v_readlane in
+    // every iteration of the kernels that are short of scalar registers; a run-time index into the by-value arguments makes
+    // the compiler keep a copy of them in scratch)
     i++;
-    int nx = -1;
-#pragma unroll
-    for (int j = 1; j < MISO_MAX_ROUNDS - 1; j++) nx = (i == j) ? a.round_start[j] : nx;
-    next = nx;
+    next = i < MISO_MAX_ROUNDS - 1 ? a.round_tab[i] : -1;
     return true;
   }
 };

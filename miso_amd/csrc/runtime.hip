@@ -134,6 +134,7 @@ void miso_batch::release() {
   k2_plan_key = k2w_plan_key = -1;
   if (probe_stream) { (void) hipStreamSynchronize(probe_stream); (void) hipStreamDestroy(probe_stream); probe_stream = nullptr; }
   if (d_probe) { (void) hipFree(d_probe); d_probe = nullptr; }
+  if (d_round_tab) { (void) hipFree(d_round_tab); d_round_tab = nullptr; }
   probe_armed = false;
   if (ev0) (void) hipEventDestroy(ev0);
   if (ev1) (void) hipEventDestroy(ev1);
@@ -539,7 +540,14 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   a.C = p.noChains; a.M = p.noIterations; a.B = p.noBurnIn; a.lag = p.noLag;
   a.start = p.start; a.first_event_id = first_event_id; a.seed = seed;
   a.balance = (std::getenv("MISO_PRIO_QUARTILES") && std::atoi(std::getenv("MISO_PRIO_QUARTILES")) != 0) ? 2 : 0;   // experiment: device.hpp prio_by_progress
-  for (int i = 0; i < MISO_MAX_ROUNDS - 1; i++) a.round_start[i] = i < static_cast<int>(round_starts.size()) ? round_starts[i] : -1;
+  a.round_tab = nullptr;
+  if (!round_starts.empty()) {   // a later round of stop = CONVERGENT_MEAN (converge_rounds): where the rounds after the first open
+    int32_t tab[MISO_MAX_ROUNDS];
+    for (int i = 0; i < MISO_MAX_ROUNDS; i++) tab[i] = i < static_cast<int>(round_starts.size()) ? round_starts[i] : -1;
+    if (!d_round_tab) HIP_OK(hipMalloc(reinterpret_cast<void **>(&d_round_tab), sizeof(tab)));
+    HIP_OK(hipMemcpy(d_round_tab, tab, sizeof(tab), hipMemcpyHostToDevice));
+    a.round_tab = d_round_tab;
+  }
   last_seed = seed; last_first_event_id = first_event_id;
   converged_done = false;
   if (probe_armed) { HIP_OK(hipStreamSynchronize(probe_stream)); probe_armed = false; }   // (a launch nobody waited for)
@@ -1998,7 +2006,7 @@ void miso_batch::sync(float *ms) {
 // and the kept window is the reference's (round 6; rounds 4 - 5 ran N_r from the start and kept [B_r, N_r): the same law
 // in the limit, half the burn-in).  The reference's loop counter restarts with every round and so does its rule "no
 // proposal terms in a round's first ratio" (miso.c:866): the kernels are told where the later rounds open
-// (KernelArgs::round_start, device.hpp RoundOpen).  The CPU checker's counter mode continues its chains like the
+// (KernelArgs::round_tab, device.hpp RoundOpen).  The CPU checker's counter mode continues its chains like the
 // reference and addresses the draws by the chain's own iteration number: equal bit for bit (tests/test_gpu_convergent.py).
 // The next round is a batch of its own (only the unconverged events; its sync() recurses).  A launch reproduces at most
 // MISO_MAX_ROUNDS rounds (every round at least doubles the kept window: 2^7 x the first); beyond that the last stands.
