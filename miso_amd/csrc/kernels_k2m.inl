@@ -18,14 +18,14 @@
 
 namespace miso {
 
-// wavefronts per SIMD the register allocation is made for: two when the launch is one round of eight-wavefront workgroups
-// (one workgroup per CU by construction), three when it runs in several rounds of smaller ones -- the third wavefront is
-// worth more there than the registers (MISO's default settings, 240 000 chains on one lane each: 199.0 ms with three,
-// 206.9 ms with two, same kernel otherwise; the bodies fitted 168 registers by themselves until round 6's
-// Metropolis-Hastings step with both outcomes' proposals in flight needed 177)
-#define K2M_WAVES(M, W) (((W) == 8 || (M) != 0) ? 2 : 3)   // (paired-end: the chains' LDS tables decide, as before)
-template <int MODE, int WPB>
-__global__ __launch_bounds__(64 * WPB, K2M_WAVES(MODE, WPB)) void sampler_k2_multi(const KernelArgs a) {
+// NARROW: the plan's runs all have one or two lanes per chain (MISO's default settings on like-sized events: 240 000 chains on
+// one lane each).  Only those two bodies, so that the kernel fits the 168 registers of THREE wavefronts per SIMD -- which the
+// several-rounds layout is worth more than registers (199.0 ms against 206.9 ms at two, same bodies) -- without asking the
+// wider bodies to spill for it: their Metropolis-Hastings step keeps both outcomes' proposals in flight since round 6 and needs
+// 177 (hg19-like read counts at the default settings: 131.3 ms at two wavefronts per SIMD, 137.5 ms at three with 36 bytes of
+// scratch, 137.6 ms in round 5).  __launch_bounds__'s second argument is the minimum wavefronts per SIMD.
+template <int MODE, int WPB, bool NARROW = false>
+__global__ __launch_bounds__(64 * WPB, NARROW ? 3 : 2) void sampler_k2_multi(const KernelArgs a) {
   // One-round single-end launches (a.wave_tab): behind the workgroup-wide chains' a.mix_blocks workgroups every WAVEFRONT
   // looks up which run's wavefront it is -- the host pairs the launch's wavefronts by estimated duration ACROSS the runs,
   // heaviest with lightest on one SIMD (wavefronts w and w + 4), so that every SIMD carries the same work (runtime.hip
@@ -58,6 +58,11 @@ __global__ __launch_bounds__(64 * WPB, K2M_WAVES(MODE, WPB)) void sampler_k2_mul
   part.n_slots = a.seg_slot[s + 1] - a.seg_slot[s];
   const unsigned bx = blockIdx.x - static_cast<unsigned>(a.seg_block[s]);
   const unsigned gx = static_cast<unsigned>(a.seg_block[s + 1] - a.seg_block[s]);
+  if constexpr (NARROW) {
+    if (a.seg_lanes[s] == 1) k2_body<1, MODE, WPB>(part, bx, gx);
+    else if (a.seg_lanes[s] == 2) k2_body<2, MODE, WPB>(part, bx, gx);
+    return;
+  }
   switch (a.seg_lanes[s]) {
 #define MISO_K2M_CASE(GG) case GG: k2_body<GG, MODE, WPB>(part, bx, gx); break;
 #define MISO_K2M_CASE_SE(GG) case GG: if constexpr (MODE == 0) k2_body<GG, MODE, WPB>(part, bx, gx); break;

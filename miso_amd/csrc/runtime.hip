@@ -26,7 +26,7 @@ extern int g_hw_queues_in_effect;   // capi.hip: GPU_MAX_HW_QUEUES as the runtim
 template <bool PE> __global__ void sampler_wave(const KernelArgs a);
 template <int G, int MODE, int WPB> __global__ void sampler_k2(const KernelArgs a);
 template <int GA, int GB> __global__ void sampler_k2_mix(const KernelArgs a);
-template <int MODE, int WPB> __global__ void sampler_k2_multi(const KernelArgs a);
+template <int MODE, int WPB, bool NARROW = false> __global__ void sampler_k2_multi(const KernelArgs a);
 template <bool PE> __global__ void sampler_big(const KernelArgs a);   // kernels_big.hip: 65 ... MISO_MAX_ISOFORMS isoforms
 __global__ void sampler_lane(const KernelArgs a);   // kernels_lane.hip: collapsed Gibbs step, one chain per lane
 __global__ void sampler_lane_ilp(const KernelArgs a);   // ... the form for at most two wavefronts per SIMD
@@ -1446,6 +1446,10 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       }
     }
   }
+  // the several-rounds single-end plan has runs of one and two lanes per chain only: the kernel of three wavefronts per SIMD (kernels_k2m.inl)
+  bool k2_narrow = k2_multi && !p.paired && k2_plan.wpb == 4 && k2_plan.n_segs > 0 && std::getenv("MISO_K2_NO_NARROW") == nullptr;
+  for (int i = 0; i < k2_plan.n_segs && k2_narrow; i++) k2_narrow = k2_plan.seg_lanes[i] <= 2;
+  const std::string k2m_name = "sampler_k2_multi<" + std::string(p.paired ? "1, " : "0, ") + std::to_string(k2_plan.wpb) + (k2_narrow ? ", true>" : ">");
   // which chain every workgroup of a plan's workgroup-wide run works on (coop.hpp); nothing to do when every chain
   // has its workgroup to itself
   auto k2_coop = [&](KernelArgs &ka, const LanePlan &pl, K2Coop &cc, hipStream_t st) {
@@ -1528,7 +1532,10 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       if (k2_plan.rounds == 1) ka.balance = (std::getenv("MISO_K2_BALANCE") && std::atoi(std::getenv("MISO_K2_BALANCE")) == 0) ? 0 : 1;
       hipLaunchKernelGGL((sampler_k2_multi<0, 8>), grid, dim3(512), K2_RED_BYTES, st, ka);
       break;
-    case 4: hipLaunchKernelGGL((sampler_k2_multi<0, 4>), grid, dim3(256), K2_RED_BYTES, st, ka); break;
+    case 4:
+      if (k2_narrow) hipLaunchKernelGGL((sampler_k2_multi<0, 4, true>), grid, dim3(256), K2_RED_BYTES, st, ka);
+      else hipLaunchKernelGGL((sampler_k2_multi<0, 4>), grid, dim3(256), K2_RED_BYTES, st, ka);
+      break;
     default: hipLaunchKernelGGL((sampler_k2_multi<0, 1>), grid, dim3(64), 0, st, ka); break;
     }
     HIP_OK(hipGetLastError());
@@ -1605,7 +1612,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
           }
         } else slice(c0, c1, pl.seg_lanes[sg]);
       }
-      add_stat("sampler_k2_multi<" + std::string(wpart ? "2, " : (p.paired ? "1, " : "0, ")) + std::to_string(pl.wpb) + ">", static_cast<double>(waves), trips,
+      add_stat(wpart ? "sampler_k2_multi<2, " + std::to_string(pl.wpb) + ">" : k2m_name, static_cast<double>(waves), trips,
                static_cast<double>(chains), words);
     } else if (!wpart && k2_mix > 0) {
       slice(0, static_cast<long>(k2_mix) * C, k2G + 1);
@@ -1885,7 +1892,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       HIP_OK(hipGetLastError());
     } else if (k2_multi) {
       lanes_per_chain = k2_plan.seg_lanes[k2_plan.n_segs - 1];
-      last_kernels += std::string(last_kernels.empty() ? "" : ",") + "sampler_k2_multi<" + (p.paired ? "1, " : "0, ") + std::to_string(k2_plan.wpb) + ">";
+      last_kernels += std::string(last_kernels.empty() ? "" : ",") + k2m_name;
       launch_k2_multi(a, stream_for_next());
     } else if (k2_mix > 0) {
       last_kernels += std::string(last_kernels.empty() ? "" : ",") + k2_mix_name(k2_G);

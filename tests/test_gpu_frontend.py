@@ -405,3 +405,32 @@ def test_compare_results_do_not_depend_on_the_number_of_worker_processes(tmp_pat
     assert r.returncode == 0, r.stdout
     for e in kept:
         assert open(os.path.join(plain, "chr1", "gene%d.miso" % e), "rb").read() == outs[1]["a/gene%d.miso" % e], e
+
+
+def test_cli_summary_only_writes_the_same_table_and_no_miso_files(tmp_path):
+    """`miso --run ... --summary-only` (round 6): the `summarize_miso` table of the run without the per-event `.miso`
+    files -- byte for byte the table `--summarize` writes beside its files (both summarise the four-decimal text a file
+    holds, samples_utils.py:263-329, on the device; same seed, same event numbers), through the four-stage pipeline of
+    run_miso.compute_gene_psi with the worker opening the alignment file itself."""
+    with gzip.open(os.path.join(DATA, "c2c12.Atp2b1.sam.gz"), "rt") as f:
+        sam_text = f.read()
+    bam = str(tmp_path / "reads.bam")
+    sam_to_bam(sam_text, bam)
+    idx = str(tmp_path / "indexed")
+    settings = tmp_path / "settings.txt"
+    settings.write_text("[data]\nmin_event_reads = 20\n[sampler]\nburn_in = 200\nlag = 4\nnum_iters = 1000\nnum_chains = 2\n")
+    assert run(["-m", "miso_amd.index_gff", "--index", os.path.join(DATA, "Atp2b1.mm9.gff"), idx]).returncode == 0
+    tables = {}
+    for mode in ("--summarize", "--summary-only"):
+        out = str(tmp_path / ("out" + mode.strip("-")))
+        r = run(["-m", "miso_amd.miso", "--run", idx, bam, "--output-dir", out, "--read-len", "36",
+                 "--settings-filename", str(settings), "-p", "1", "--seed", "31", mode])
+        logs = "".join(open(os.path.join(out, "batch-logs", f)).read() for f in os.listdir(os.path.join(out, "batch-logs")))
+        assert r.returncode == 0, r.stdout + logs
+        table = glob.glob(os.path.join(out, "summary", "*.miso_summary"))
+        assert len(table) == 1, logs
+        tables[mode] = open(table[0]).read()
+        files = glob.glob(os.path.join(out, "**", "*.miso"), recursive=True)
+        assert (len(files) == 1) == (mode == "--summarize"), (mode, files)
+    assert tables["--summarize"] == tables["--summary-only"]
+    assert tables["--summary-only"].count("\n") == 2 and "ENSMUSG00000019943" in tables["--summary-only"]
