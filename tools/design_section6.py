@@ -70,7 +70,7 @@ VERDICT r5's list, item by item:
    4.4 - 5.1 s: the 40 k events/s asked for that mode would need the whole run in 1 s, of which decoding 3.2 GB of SAM text alone
    takes 1.3 (section 4.10, `profiles/r06_e2e_miso_run.txt`).
 7. *`CONVERGENT_MEAN` window* -- done, and the rule of the round's first ratio with it (section 1).
-8. *Hygiene* -- `tools/archive/`, this file 52 KB (round 5's narrative in `docs/history.md`), `oracle/README.md` and section 5 say what
+8. *Hygiene* -- `tools/archive/`, this file 56 KB (round 5's narrative in `docs/history.md`), `oracle/README.md` and section 5 say what
    VERDICT asked them to say.
 ADVICE r5: the hidden loads are checked on the generated assembly at every build (`make check-isa`) and the bit-exact tests pass on
 a build without them (`profiles/r06_noasm_variant.txt`); K > 64 guard, contract version, wide-gene warning + accept-count test,
