@@ -85,7 +85,7 @@ constexpr int FLAT_WIDE = 0x100;  // sampler_flat wave_tab: the workgroup's four
 constexpr int K2_MAX_SEGS = 16;
 constexpr int MISO_MAX_ROUNDS = 8;   // stop = CONVERGENT_MEAN: rounds a device launch can reproduce (every round at least doubles the kept window)
 constexpr int K2_WIDE = 512;   // seg_lanes value: one chain per workgroup
-constexpr int K2_RED_BYTES = 2 * 8 * 16 + 16;   // two buffers x (up to) 8 wavefronts x {int64 score sum, int count, int bad} + the barrier's flag
+constexpr int K2_RED_BYTES = 2 * 8 * 16 + 16 + 16;   // two buffers x (up to) 8 wavefronts x {int64 score sum, int count, int bad} + the barrier's flag + the psi a workgroup-wide chain's first four wavefronts publish (kernels_k2.inl)
 
 struct KernelArgs {
   const DevEvent *events;
@@ -129,6 +129,7 @@ struct KernelArgs {
   const int32_t *round_tab;
   // sampler_k2_multi<0, 8>, one round: the two wavefronts of a SIMD keep step by priority (kernels_k2.inl k2_balance)
   int32_t balance;
+  int32_t wide_dedup;       // sampler_k2 WIDE with eight wavefronts: the Metropolis-Hastings step on the first four only (kernels_k2.inl)
   int32_t n_segs;
   int32_t seg_block[K2_MAX_SEGS + 1];
   int32_t seg_slot[K2_MAX_SEGS + 1];

@@ -811,6 +811,13 @@ __device__ __forceinline__ void k2_body(const KernelArgs &a, unsigned block_x, u
   uint64_t hash = 0xCBF29CE484222325ull;
   int accepted = 0, lagCounter = 0, noS = 0;
   const bool writer = live && sub == 0;
+  // WIDE, eight wavefronts: wavefronts w and w + 4 of the workgroup share a SIMD and belong to the SAME chain.  Both used to run
+  // the Metropolis-Hastings step (same inputs, same bits) -- on a SIMD whose two wavefronts are one chain's that is the step
+  // twice per iteration, and the launch's largest event (80 000 drawing reads on one workgroup) set the launch's duration: 1.33
+  // x every other SIMD's (profiles/r06_wave_time_hg19.txt).  Now the first four wavefronts run the step and publish psi -- all the
+  // Gibbs step needs -- through LDS; the other four wait at a barrier (a waiting wavefront issues nothing) and join the read loop.
+  const bool helper = WIDE && WPB == 8 && a.wide_dedup && (threadIdx.x >> 6) >= 4;
+  double *wide_pub = reinterpret_cast<double *>(smem_k2 + a.red_off + 2 * WPB * 16 + 16);
 
   double zbuf = 0.0; uint32_t awbuf = 0u;   // this lane's share of NR consecutive iterations' MH draws
   // The proposal of iteration m is made -- alpha' = alpha + sd z_m and exp(alpha') (miso.c:449-471) -- at the END of
@@ -834,6 +841,7 @@ __device__ __forceinline__ void k2_body(const KernelArgs &a, unsigned block_x, u
     prio_by_progress(a, m);
     if (MODE == 0 && WPB == 8 && !WIDE && !COLLAPSED && a.balance == 1) k2_balance(threadIdx.x >> 6, m);
     if (WIDE && !coop_ok) return;   // the chain's workgroups gave up waiting for each other (coop.hpp): the host reports it
+    if (!helper) {
     hash = (hash ^ static_cast<uint32_t>(cnt0)) * 0x100000001B3ull;
     hash = (hash ^ static_cast<uint32_t>(cnt1)) * 0x100000001B3ull;
     if (trace && writer) {
@@ -943,6 +951,12 @@ __device__ __forceinline__ void k2_body(const KernelArgs &a, unsigned block_x, u
     }
     PROF_T(m2);
     PROF_ADD(pf_rec, m1, m2);
+    }   // !helper
+    if (WIDE && WPB == 8 && a.wide_dedup) {   // (the next write is behind the Gibbs step's own barrier: one buffer is enough)
+      if (threadIdx.x == 0) { wide_pub[0] = cur.x0; wide_pub[1] = cur.x1; }
+      __syncthreads();
+      if (helper) { cur.x0 = wide_pub[0]; cur.x1 = wide_pub[1]; }
+    }
     gibbs(static_cast<uint32_t>(m));
   }
 #ifdef MISO_K2_PROFILE

@@ -540,6 +540,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   a.C = p.noChains; a.M = p.noIterations; a.B = p.noBurnIn; a.lag = p.noLag;
   a.start = p.start; a.first_event_id = first_event_id; a.seed = seed;
   a.balance = (std::getenv("MISO_PRIO_QUARTILES") && std::atoi(std::getenv("MISO_PRIO_QUARTILES")) != 0) ? 2 : 0;   // experiment: device.hpp prio_by_progress
+  a.wide_dedup = (std::getenv("MISO_K2_WIDE_DEDUP") && std::atoi(std::getenv("MISO_K2_WIDE_DEDUP")) == 0) ? 0 : 1;   // kernels_k2.inl: a workgroup-wide chain's Metropolis-Hastings step on four of its eight wavefronts
   a.round_tab = nullptr;
   if (!round_starts.empty()) {   // a later round of stop = CONVERGENT_MEAN (converge_rounds): where the rounds after the first open
     int32_t tab[MISO_MAX_ROUNDS];
