@@ -27,7 +27,7 @@ def row(i):
 
 print("""`python bench.py --steps 20 --warmup 5` on the round's final build, after `pytest -m gpu` (252 passed, 1 skipped: the two-GPU
 `release()` test on a one-GPU lease) and `smoke()`; the rocprofv3 passes of every row on the same pool (`tools/r6_final.sh`,
-`tools/r6_k.sh` for the two-isoform rows' final kernels): `profiles/r06_bench_default_line.json` = the line as printed (3.1 KB),
+`tools/archive/r6_k.sh`, `r6_p.sh` for the two-isoform rows' final kernels): `profiles/r06_bench_default_line.json` = the line as printed (3.1 KB),
 `profiles/r06_bench_default.json` = the full record, `profiles/r06_<row>_summary.txt` = kernel trace + SQ / FETCH / WRITE counters
 per row, `profiles/valu_model.json` (with the traced launch span and the clock of the traced launch), `profiles/traffic.json`.
 
