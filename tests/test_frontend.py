@@ -426,3 +426,53 @@ def test_one_bad_gene_does_not_cost_the_batch_its_other_genes(bam_path, capsys):
     assert [g for g, _ in sampler.skipped_genes] == ["sixty-six-isoforms", "good", "sixty-six-isoforms"]
     out = capsys.readouterr().out
     assert out.count("Skipping gene") == 3 and "isoforms" in out and "CIGAR" in out.upper()
+
+
+def test_collecting_piece_by_piece_equals_collecting_at_once(tmp_path, bam_path):
+    """run_miso.compute_gene_psi (round 6) collects its gene list in pieces on a thread of its own -- `entry_offset`, one
+    `cache` of loaded index files, the gene objects made ahead of the alignment file (`preload_genes`): the events, their
+    numbers in the caller's list (the id of their random stream) and their output names are those of one call over the whole
+    list, whatever the piece size."""
+    gff = tmp_path / "many.gff"
+    with open(gff, "w") as g:
+        g.write("##gff-version 3\n")
+        for e in range(11):
+            off = 10000 + 5000 * e
+            ex = [(off, off + 120), (off + 400, off + 480), (off + 900, off + 1050)]
+            gid = "ev%02d" % e
+            g.write("10\tSE\tgene\t%d\t%d\t.\t+\t.\tID=%s;Name=%s\n" % (ex[0][0], ex[-1][1], gid, gid))
+            for m, iso in enumerate(([0, 1, 2], [0, 2])):
+                tid = "%s.%s" % (gid, "AB"[m])
+                g.write("10\tSE\tmRNA\t%d\t%d\t.\t+\t.\tID=%s;Parent=%s\n" % (ex[iso[0]][0], ex[iso[-1]][1], tid, gid))
+                for x in iso:
+                    g.write("10\tSE\texon\t%d\t%d\t.\t+\t.\tID=%s.e%d;Parent=%s\n" % (ex[x][0], ex[x][1], tid, x, tid))
+    idx = str(tmp_path / "indexed")
+    index_gff.index_gff(str(gff), idx)
+    entries = sorted(gff_utils.get_gene_ids_to_gff_index(idx).items())
+    assert len(entries) == 11
+    Settings.load(None)
+    bam = sam_utils.Samfile(bam_path)
+    out = str(tmp_path / "out")
+
+    def describe(events):
+        return [(ev[1].label, ev[2], ev[4], (ev[0].chrom, ev[0].start, ev[0].end, ev[0].min_reads), [len(i.desc) for i in ev[1].isoforms])
+                for ev in events]
+    whole, info = run_miso.collect_gene_events(entries, bam, out, 36, 1, verbose=False, native=True)
+    assert [e[4] for e in whole] == list(range(11))
+    for piece in (1, 3, 4, 11, 50):
+        cache, got, infos = {}, [], {}
+        run_miso.preload_genes(entries, cache)
+        made = len(cache.get("genes", {}))
+        for lo in range(0, len(entries), piece):
+            ev, inf = run_miso.collect_gene_events(entries[lo:lo + piece], bam, out, 36, 1, verbose=False, native=True,
+                                                   entry_offset=lo, cache=cache)
+            got += ev
+            infos.update(inf)
+        assert describe(got) == describe(whole) and infos == info, piece
+        assert made in (0, 11) and not cache.get("genes")      # every prepared gene object was used exactly once
+    # without the preload (no bundle, or a caller that did not ask for it): the same again
+    got = []
+    cache = {}
+    for lo in range(0, len(entries), 4):
+        got += run_miso.collect_gene_events(entries[lo:lo + 4], bam, out, 36, 1, verbose=False, native=True, entry_offset=lo, cache=cache)[0]
+    assert describe(got) == describe(whole)
