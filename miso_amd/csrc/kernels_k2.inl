@@ -834,7 +834,7 @@ __device__ __forceinline__ void k2_body(const KernelArgs &a, unsigned block_x, u
     alphaN_p = alpha + c.sd * z;
     e_p = k2_exp(alphaN_p);
   }
-  const double E0 = SPEC ? k2_exp(0.0) : 1.0;   // exp(maxv - maxv) of the log-sum-exp below
+  const double E0 = k2_exp(0.0);   // exp(maxv - maxv) of the log-sum-exp below
   RoundOpen ro(a);
   for (int m = 0; m < a.M; m++) {
     const bool opens = ro.at(a, m);   // a round's first iteration: no proposal terms (miso.c:866)
@@ -887,7 +887,7 @@ __device__ __forceinline__ void k2_body(const KernelArgs &a, unsigned block_x, u
       const double maxv = (lp1 > lp0) ? lp1 : lp0;  // miso.c:137-140: maxv starts at entry 0
       // of exp(lp0 - maxv), exp(lp1 - maxv) one is exp(x - x) = exp(+0) = E0 for every finite x: three exponentials
       double ex0, ex1, xp, xc;
-      if constexpr (SPEC) {
+      {   // (every lanes-per-chain layout: with one lane per chain that is three exponentials instead of four)
         const bool m1 = lp1 > lp0;
         const double dmin = m1 ? lp0 - maxv : lp1 - maxv, dmax = m1 ? lp1 - maxv : lp0 - maxv;
         double emin;
@@ -898,11 +898,6 @@ __device__ __forceinline__ void k2_body(const KernelArgs &a, unsigned block_x, u
         double emax = E0;
         if (__builtin_expect(__any(!(dmax == 0.0)), 0)) emax = f_exp(dmax);   // a non-finite log psi (inf - inf): as written
         ex0 = m1 ? emin : emax; ex1 = m1 ? emax : emin;
-      } else {
-        vec_eval4<NR, QUAD>(f_exp, lp0 - maxv, lp1 - maxv,
-                            prop_exponent(cur.lgt, alphaN, c.sigma),   // theta = psi,  mu = alpha'
-                            prop_exponent(nw.lgt, alpha, c.sigma),     // theta = psi', mu = alpha
-                            ex0, ex1, xp, xc, role, base_lane);
       }
       double ls;
       vec_eval3<NR, QUAD>(f_log, (0.0 + ex0) + ex1, c.covar * cur.pr * xp, c.covar * nw.pr * xc, ls, ptoCS,
