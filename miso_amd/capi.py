@@ -282,6 +282,19 @@ class Batch:
         check(lib().miso_batch_get_summary(self.handle, i, _p(m), _p(lo), _p(hi)))
         return m, lo, hi
 
+    def summaries(self, indices, noiso):
+        """[(mean[K], ci_low[K], ci_high[K])] of the given events after summarize() -- summary() for many events without its
+        per-event allocations (noiso[j] = isoforms of event indices[j], known to the caller from the annotation)."""
+        offs = np.concatenate([[0], np.cumsum(np.asarray(noiso, dtype=np.int64))])
+        buf = np.zeros((3, int(offs[-1])))
+        base = [buf[r].ctypes.data for r in range(3)]
+        f = lib().miso_batch_get_summary
+        h = self.handle
+        for j, i in enumerate(indices):
+            o = 8 * int(offs[j])
+            check(f(h, int(i), C.c_void_p(base[0] + o), C.c_void_p(base[1] + o), C.c_void_p(base[2] + o)))
+        return [(buf[0, offs[j]:offs[j + 1]], buf[1, offs[j]:offs[j + 1]], buf[2, offs[j]:offs[j + 1]]) for j in range(len(indices))]
+
     def compare(self, other, smoothing=0.3):
         """Two-sample comparison with `other` (same events, same order) on the device."""
         check(lib().miso_batch_compare(self.handle, other.handle, C.c_double(smoothing)))

@@ -359,7 +359,10 @@ class MISOSampler:
         fields = batch.header_fields([idx for _, idx, _, _ in slots])
         middle = "\titers=%d\tburn_in=%d\tlag=%d\tpercent_accept=" % (num_iters, burn_in, lag)
         dirs = set()
-        for (i, idx, gene, out), (unassigned, pa, counts, assigned) in zip(slots, fields):
+        sums = None
+        if summary_file is not None:
+            sums = batch.summaries([idx for _, idx, _, _ in slots], [len(gene.isoforms) for _, _, gene, _ in slots])
+        for j, ((i, idx, gene, out), (unassigned, pa, counts, assigned)) in enumerate(zip(slots, fields)):
             if unassigned:                                                # miso_sampler.py:352-354
                 if verbose:
                     print("All reads incompatible with annotation, skipping...")
@@ -375,8 +378,10 @@ class MISOSampler:
                 written[i] = out
             if summary_file is not None:
                 name = os.path.basename(out)[:-len(".miso")]
-                hdr = dict(kv.split("=", 1) for kv in header[1:].rstrip("\n").split("\t"))
-                rows.append((name,) + tuple(batch.summary(idx)) + (hdr,))
+                # the header's fields the table takes (summary.summary_line), as the file's first line spells them
+                hdr = {"isoforms": head[len("#isoforms="):head.index("\texon_lens=")], "counts": counts, "assigned_counts": assigned}
+                hdr.update(kv.split("=", 1) for kv in tail.rstrip("\n").split("\t"))
+                rows.append((name,) + tuple(sums[j]) + (hdr,))
         t2 = time.time()
         if write_files:
             batch.write_miso_files(idxs, paths, headers, threads)
