@@ -297,6 +297,9 @@ __device__ __forceinline__ int32_t binomial_coop(uint64_t seed, uint32_t event_i
 // issue rate), so the pair is told to keep step: every iteration a wavefront posts its iteration number, reads its
 // partner's and raises its own priority when it is behind (s_setprio: the arbiter looks at the user priority before the
 // age).  Chains of one batch run the same number of iterations, so "same iteration" is "same share of the work done".
+// Results do not depend on any of this: where wavefronts sit is the hardware's choice (wavefronts w and w + 4 of an eight-wavefront
+// workgroup on one SIMD is what this device does, tools/archive/placement_check.py); on another placement the priorities are a
+// no-op between wavefronts that do not compete, and the LDS word of a wavefront that left early only makes its partner "ahead".
 __shared__ int k2_prog[8];
 __device__ __forceinline__ void k2_balance(int wv, int m) {
   __hip_atomic_store(&k2_prog[wv], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
