@@ -380,6 +380,10 @@ __global__ __launch_bounds__(256, KC <= 4 ? MISO_FLAT_WGS_4 : (KC <= 8 ? MISO_FL
   // WORKGROUP (FLAT_WIDE: the four wavefronts each keep the chain's state in their own slice and run the scalar step
   // redundantly -- same inputs, same bits --, the read loop's units are dealt over all 256 lanes, the per-wavefront
   // counts meet through LDS, two barriers per Gibbs step; wavefront 0 writes the outputs).
+#ifdef MISO_FLAT_WAVETIME   // tools/archive/wave_time_flat.py: when every chain's wavefront started and how long it ran (100 MHz), diagnostic build
+  uint64_t wt_t0;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wt_t0) : : "memory");
+#endif
   const long wave_id = static_cast<long>(blockIdx.x) * 4 + wid;
   const int wt_first = __builtin_amdgcn_readfirstlane(a.wave_tab[2 * wave_id]), wt_n = __builtin_amdgcn_readfirstlane(a.wave_tab[2 * wave_id + 1]);
   const bool wide = (wt_n & FLAT_WIDE) != 0;
@@ -1030,6 +1034,12 @@ __global__ __launch_bounds__(256, KC <= 4 ? MISO_FLAT_WGS_4 : (KC <= 8 ? MISO_FL
     ChainStats *st = reinterpret_cast<ChainStats *>(a.out_pool + LE_.off_stats) + lchain;
     st->counts_hash = hash; st->accepted = accepted;
     st->hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+#ifdef MISO_FLAT_WAVETIME
+    uint64_t wt_t1;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wt_t1) : : "memory");
+    st->hw_id = static_cast<uint32_t>(wt_t1 - wt_t0);
+    st->counts_hash = wt_t0;   // when it started
+#endif
   }
 #undef FD
 #undef FI
