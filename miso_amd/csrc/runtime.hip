@@ -1009,12 +1009,18 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       const bool forced = std::getenv("MISO_FLAT_NC") != nullptr;
       const long n_waves = pack_with(std::max(64.0, per_chain * (forced ? nc : cap)));
       if (!forced && n_waves < 3 * resident / 2) {
-        const double want = 0.95 * static_cast<double>(n_waves <= resident ? resident : 2 * resident);
+        // (round 6) ... and TWO rounds are aimed at from further below than one: the second round's workgroups start as the
+        // first round's end, staggered, and a count within a few per cent of two full rounds runs into a third (hg19-like read
+        // counts, K = 5, 2048 resident wavefronts: 4029 wavefronts 71.7 ms, 3793 64.6 ms, 3541 66.2 ms, 2956 -- the fullest
+        // packing -- 67.7 ms; profiles/r06_flat_pack_rounds.txt).  MISO_FLAT_ROUNDS_FRAC: the fraction of two rounds (experiments).
+        const bool two = n_waves > resident;
+        const double frac2 = std::getenv("MISO_FLAT_ROUNDS_FRAC") ? std::atof(std::getenv("MISO_FLAT_ROUNDS_FRAC")) : 0.85;
+        const double want = (two ? frac2 : 0.95) * static_cast<double>(two ? 2 * resident : resident);
         if (static_cast<double>(n_waves) < want) {
           // (round 5) ... and not a few wavefronts MORE than the round(s): the packing's bound is a target, the count it
           // makes lands some per cent off, and 3110 wavefronts on 3072 slots cost a second round for 38 of them
           // (K = 3, hg19-like read counts: 154 k events/s there, 212 k at 2960; profiles/r05_flat_chunks.txt)
-          const long target = n_waves <= resident ? resident : 2 * resident;
+          const long target = two ? static_cast<long>((frac2 + 0.04) * 2.0 * static_cast<double>(resident)) : resident;
           double U2 = std::max(64.0, static_cast<double>(total) / want);
           long n2 = pack_with(U2);
           for (int it = 0; it < 8 && n2 > target; it++) {
