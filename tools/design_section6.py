@@ -36,8 +36,8 @@ cycles at a measured %.3f GHz; the committed profile's launch: %.1f M cycles).  
 clock (model: %.1f VALU wave-instructions per chain-iteration x %.3f cycles / kernel time; `floor_frac` %.2f; the profiled launch's
 own counters: busy 0.90, wave-slot occupancy 0.94 -- 0.81 / 0.78 in round 5); measured HBM %.2f GB per launch = %.4f of the peak
 (the compulsory 4.9 GB of samples); SURVEY section 8(d)'s figure: %.0f TB/s = `bytes_frac_8d` %.1f (the reference algorithm's
-traffic; the event is register-resident).  CPU baseline %.0f events/s on %d host cores (the real reference) => ~ %.0f x.  |delta psi|
-two-sample test: p_row %s, largest |z| %s, 0 of 768 cells beyond 4.""" % (
+traffic; the event is register-resident).  CPU baseline %.0f events/s on %d host cores (the real reference) => ~ %.0f x.
+|delta psi| two-sample test: p_row %s, largest |z| %s, 0 of 768 cells beyond 4.""" % (
     k(new["value"]), k(old.get("value", 0)), r["kernel_ms"], r.get("kernel_Mcycles", 0) / 1e3, r.get("clock_ghz") or 0,
     (r.get("profile_kernel_Mcycles") or 0) / 1e3, r["frac"], r["model"]["valu_per_chain_iteration"], r["model"]["issue_cycles_per_valu"],
     r["floor_frac"], r["traffic"] / 1e9, r["hbm_measured_frac"], r["algorithmic_GBs"] / 1e3, r["bytes_frac_8d"],
