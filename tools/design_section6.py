@@ -37,7 +37,7 @@ clock (model: %.1f VALU wave-instructions per chain-iteration x %.3f cycles / ke
 own counters: busy 0.90, wave-slot occupancy 0.94 -- 0.81 / 0.78 in round 5); measured HBM %.2f GB per launch = %.4f of the peak
 (the compulsory 4.9 GB of samples); SURVEY section 8(d)'s figure: %.0f TB/s = `bytes_frac_8d` %.1f (the reference algorithm's
 traffic; the event is register-resident).  CPU baseline %.0f events/s on %d host cores (the real reference) => ~ %.0f x.
-|delta psi| two-sample test: p_row %s, largest |z| %s, 0 of 768 cells beyond 4.""" % (
+(The round's closing runs on eight boxes of the pool: 664.7 - 678.2 k events/s; this one is the last, on the final build.)  |delta psi| two-sample test: p_row %s, largest |z| %s, 0 of 768 cells beyond 4.""" % (
     k(new["value"]), k(old.get("value", 0)), r["kernel_ms"], r.get("kernel_Mcycles", 0) / 1e3, r.get("clock_ghz") or 0,
     (r.get("profile_kernel_Mcycles") or 0) / 1e3, r["frac"], r["model"]["valu_per_chain_iteration"], r["model"]["issue_cycles_per_valu"],
     r["floor_frac"], r["traffic"] / 1e9, r["hbm_measured_frac"], r["algorithmic_GBs"] / 1e3, r["bytes_frac_8d"],
@@ -46,7 +46,7 @@ traffic; the event is register-resident).  CPU baseline %.0f events/s on %d host
 print("""
 Matrix (40 000 events, 7500 iterations unless the id says otherwise; `defaults` = 6 chains x 5000 iterations, lag 10; `pe_k10`
 20 000 events; `pe_mix*` 16 384 genes of 3 - 20 isoforms; in brackets round 5's closing record; VALU busy at the row's own
-measured clock):
+measured clock; a row = the median of three launches):
 """)
 print(table)
 print("""
@@ -59,18 +59,19 @@ VERDICT r5's list, item by item:
    per CU still lose (+ 3 / + 33 %%); and the loop does not wait for memory (an L2-resident working set: 4 %%), so the registers, not
    the traffic, are what a restructuring has to attack (section 8 (a), `profiles/r06_pe_three_blocks.txt`, `r06_pe_working_set.txt`).
 3. *`sampler_flat`, the per-chain scalar step* -- `se_k5` %s, `se_k10` %s (targets 130 k / 70 k): + 4 / + 3 %% from issue priority by
-   progress; `floor_frac` unchanged (0.42 / 0.37).  The kernel's main loop carries ~ 540 `v_readlane` / `v_writelane` per iteration
+   progress, `se_k5_hg19` 114.2 -> 123.0 k from a packing that aims at two rounds of wavefronts from 0.85 of them (section 4.4); `floor_frac` unchanged (0.42 / 0.37).  The kernel's main loop carries ~ 540 `v_readlane` / `v_writelane` per iteration
    (12 %% of its instructions) of scalar-register spill traffic: the phases as separately compiled functions remain to be done.
 4. *Headline tail* -- done by other means: the SIMD's two wavefronts keep step by priority instead of pulling chain groups from a
    cursor (no work added): wave-slot occupancy 0.78 -> 0.94, %s events/s driver-style (target 660 k); `se_k2_defaults` %s (target
    230 k not met: 1.2 rounds of three wavefronts per SIMD at the formulation's floor, 0.87 / 0.87).
-5. *Whole-gene batches as one ordered grid* -- not done: `pe_mix` %s, `pe_mix_hg19` %s genes/s; issue priorities by class: nothing
-   (`profiles/r06_class_priority.txt`); the launches scatter +- 15 %% by themselves.
+5. *Whole-gene batches as one ordered grid* -- not done: `pe_mix` %s, `pe_mix_hg19` %s genes/s; issue priorities by class: nothing;
+   a CU partition per class: slower (`profiles/r06_class_priority.txt`, `r06_class_cu_partition.txt`); the timelines say what is lost -- two rounds of chains whose
+   own duration is half the launch, the last quarter nearly empty (`profiles/r06_mix_timeline.txt`); the launches scatter +- 15 %% by themselves.
 6. *End to end* -- `miso --run`, 40 000 events, MISO defaults: 6.9 -> 4.1 - 4.6 s (8.7 - 9.7 k events/s; target 9 k) with files; summary-only
-   4.4 - 5.1 s: the 40 k events/s asked for that mode would need the whole run in 1 s, of which decoding 3.2 GB of SAM text alone
+   4.1 - 5.1 s: the 40 k events/s asked for that mode would need the whole run in 1 s, of which decoding 3.2 GB of SAM text alone
    takes 1.3 (section 4.10, `profiles/r06_e2e_miso_run.txt`).
 7. *`CONVERGENT_MEAN` window* -- done, and the rule of the round's first ratio with it (section 1).
-8. *Hygiene* -- `tools/archive/`, this file 56 KB (round 5's narrative in `docs/history.md`), `oracle/README.md` and section 5 say what
+8. *Hygiene* -- `tools/archive/`, this file 58 KB (round 5's narrative in `docs/history.md`), `oracle/README.md` and section 5 say what
    VERDICT asked them to say.
 ADVICE r5: the hidden loads are checked on the generated assembly at every build (`make check-isa`) and the bit-exact tests pass on
 a build without them (`profiles/r06_noasm_variant.txt`); K > 64 guard, contract version, wide-gene warning + accept-count test,
