@@ -400,14 +400,14 @@ __global__ __launch_bounds__(256, KC <= 4 ? MISO_FLAT_WGS_4 : (KC <= 8 ? MISO_FL
   const int PR = ks;
 
   // ---- set-up: every chain's constants and class table into its slice ----
-  int Kw = 0;
+  int Kw_rt = 0;
   for (int s = 0; s < ncw; s++) {
     const long slot = first_slot + s;
     const int ev = a.slot_event[slot / a.C];
     const uint32_t chain = static_cast<uint32_t>(slot % a.C);
     const DevEvent E = a.events[ev];
     const int K = E.K;
-    Kw = max(Kw, K);
+    Kw_rt = max(Kw_rt, K);
     const double *consts = reinterpret_cast<const double *>(a.in_pool + E.off_consts);
     const int *base = reinterpret_cast<const int *>(a.in_pool + E.off_base);
     const uint32_t *gt = reinterpret_cast<const uint32_t *>(a.in_pool + E.off_cls);
@@ -445,7 +445,11 @@ __global__ __launch_bounds__(256, KC <= 4 ? MISO_FLAT_WGS_4 : (KC <= 8 ? MISO_FL
       sx[SX_SIGMA] = consts[3 * K + 2]; sx[SX_SD] = consts[3 * K + 3]; sx[SX_COVAR] = consts[3 * K + 4];
     }
   }
-  Kw = __builtin_amdgcn_readfirstlane(Kw);
+  Kw_rt = __builtin_amdgcn_readfirstlane(Kw_rt);
+  // bound of the isoform loops: the wavefront's largest isoform count -- in a kernel of one isoform count (KS) that count itself:
+  // every `k < Kw` is then decided at compile time instead of living in a scalar register pair as a loop-invariant mask (the
+  // entries beyond a chain's own K are zeros in its slice and switched off by the chain's `k < lK` as before)
+  const int Kw = KS > 0 ? KB : Kw_rt;
   fsync();
   // the wavefront's unit list: chain s owns units [ustart_s, ustart_s + n_units_s); MI_NEXT = the next
   // chain that has units at all
@@ -773,7 +777,7 @@ __global__ __launch_bounds__(256, KC <= 4 ? MISO_FLAT_WGS_4 : (KC <= 8 ? MISO_FL
       fsync();
       return;
     }
-    const int tww = Kw - 1;
+    const int tww = Kw_rt - 1;
 #ifdef MISO_FLAT_SKIP_LOOP   // instruction accounting (tools/flat_phase_valu.sh): results are wrong
     if (a.M >= 0) return;
 #endif
