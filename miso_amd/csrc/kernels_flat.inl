@@ -364,9 +364,11 @@ __device__ __attribute__((noinline)) void flat_units_desc(const FlatUnitsArgs A,
 // instructions), and the unrolled isoform loops end at KS instead of at the class's KC.  Up to twenty isoforms every count has
 // its kernel (kernels_flat_c*.hip); KS = 0: the layout at run time (21 - 32 isoforms).  K = 5 110.0 -> 113.5 k,
 // K = 10 58.0 -> 60.7 k events/s with the layout alone (profiles/r05_flat_chunks.txt).
-template <int KC, int KS = 0>
+template <int KC, int KS = 0, bool UNI = false>
 __global__ __launch_bounds__(256, KC <= 4 ? MISO_FLAT_WGS_4 : (KC <= 8 ? MISO_FLAT_WGS_SMALL : (KC <= 12 ? MISO_FLAT_WGS_12 : MISO_FLAT_WGS_LARGE))) void sampler_flat(const KernelArgs a) {
   static_assert(KS == 0 || (KS <= KC && KS >= 2), "KS: an isoform count of the class KC");
+  static_assert(!UNI || KS > 0, "UNI: every event of the launch has KS isoforms");
+#define KOF(x) (UNI ? KB : (x))   // a chain's isoform count
   constexpr int KB = KS > 0 ? KS : KC;   // bound of the unrolled isoform loops
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int ks = KS > 0 ? KS : a.kstride;
@@ -521,7 +523,7 @@ __global__ __launch_bounds__(256, KC <= 4 ? MISO_FLAT_WGS_4 : (KC <= 8 ? MISO_FL
   // ---- the leader of chain s is lane s: the chain's sequential sums and its scalars ----
   const bool leader = lane < ncw;
   const int ls = leader ? lane : 0;
-  const int lK = FI(ls, L.misc)[MI_K];
+  const int lK = KOF(FI(ls, L.misc)[MI_K]);
   const DevEvent LE_ = a.events[FI(ls, L.misc)[MI_EV]];
   const uint32_t lchain = static_cast<uint32_t>(FI(ls, L.misc)[MI_CHAIN]);
   double l_lg_sum = 0.0, l_lg_each = 0.0, l_covar = 0.0;
@@ -575,10 +577,10 @@ __global__ __launch_bounds__(256, KC <= 4 ? MISO_FLAT_WGS_4 : (KC <= 8 ? MISO_FL
   // ---- alpha' = alpha + sd z ; psi' = logit_inv(alpha') (miso.c:449-471), then the psi-only parts of
   // both scores of the new point: lp = log x, tb = lp + cst, lr = log(x_k / x_K'), jacobian.
   // SRC / DST: buffer offsets (0 = current, PR = proposal) of alpha read / everything written. ----
-  auto propose_and_logs = [&](uint32_t iter, int SRC, int DST, double &jac_out) {
+  auto propose_and_logs = [&](uint32_t iter, int SRC, int DST, double &jac_out) __attribute__((always_inline)) {
     FLAT_BEGIN(tws, inv_k1)   // pass 1 (qnorm) + pass 2 (exp), one normal per lane
       const int *mi = FI(s, L.misc);
-      const int K = mi[MI_K];
+      const int K = KOF(mi[MI_K]);
       const uint32_t evid = static_cast<uint32_t>(mi[MI_EVID]), chain = static_cast<uint32_t>(mi[MI_CHAIN]);
       const double al = FD(s, L.alpha)[SRC + j], sd = FD(s, L.sx)[SX_SD];
       const int w = 2 + 2 * j;
@@ -604,7 +606,7 @@ __global__ __launch_bounds__(256, KC <= 4 ? MISO_FLAT_WGS_4 : (KC <= 8 ? MISO_FL
     }
     fsync();
     FLAT_BEGIN(tws, inv_k1)
-      const int K = FI(s, L.misc)[MI_K];
+      const int K = KOF(FI(s, L.misc)[MI_K]);
       const double q = FD(s, L.tc)[j] / FD(s, L.sx)[SX_SUMEXP];
       if (on && j < K - 1) FD(s, L.psi)[DST + j] = q;
     FLAT_END
@@ -625,7 +627,7 @@ __global__ __launch_bounds__(256, KC <= 4 ? MISO_FLAT_WGS_4 : (KC <= 8 ? MISO_FL
     }
     fsync();
     FLAT_BEGIN(2 * ks - 1, inv_2k)   // pass 3 (log): 2K - 1 arguments per chain
-      const int K = FI(s, L.misc)[MI_K];
+      const int K = KOF(FI(s, L.misc)[MI_K]);
       const bool firsthalf = j < ks;
       const int k = firsthalf ? j : j - ks;
       const double xv = FD(s, L.psi)[DST + k], lt = FD(s, L.sx)[SX_LTHETA], cst = FD(s, L.cst)[k];
@@ -647,7 +649,7 @@ __global__ __launch_bounds__(256, KC <= 4 ? MISO_FLAT_WGS_4 : (KC <= 8 ? MISO_FL
     FLAT_END
     fsync();
   };
-  auto leader_max = [&](int BUF) {   // miso.c:137-140: maxv starts at entry 0
+  auto leader_max = [&](int BUF) __attribute__((always_inline)) {   // miso.c:137-140: maxv starts at entry 0
     double maxv = 0.0;
     if (leader) {
       maxv = (FD(ls, L.tb) + BUF)[0];
@@ -659,13 +661,15 @@ __global__ __launch_bounds__(256, KC <= 4 ? MISO_FLAT_WGS_4 : (KC <= 8 ? MISO_FL
     }
     return maxv;
   };
-  auto count_of = [&](int s, int k) { return FI(s, L.bas)[k] + FI(s, L.cnt)[k]; };
+  auto count_of = [&](int s, int k) __attribute__((always_inline)) { return FI(s, L.bas)[k] + FI(s, L.cnt)[k]; };
 
   // ---- per-read picks by direct evaluation of the reference's scan (miso.c:11-22, 69-80): the final
   // assignment of chain 0 (miso.c:943-946) and the fallback when a threshold does not fit 32 bits ----
-  auto direct_chain = [&](int s, uint32_t iter, bool count, bool write) {
+  // (always_inline, all of them: outlined -- as the K = 10 kernel of one isoform count did with direct_chain -- a lambda reaches the
+  // kernel's locals through its capture block in scratch and the slices through generic pointers: 541 -> 733 ms)
+  auto direct_chain = [&](int s, uint32_t iter, bool count, bool write) __attribute__((always_inline)) {
     const int *mi = FI(s, L.misc);
-    const int K = mi[MI_K], n_draw = mi[MI_NDRAW];
+    const int K = KOF(mi[MI_K]), n_draw = mi[MI_NDRAW];
     const DevEvent E = a.events[mi[MI_EV]];
     const uint32_t *masks = reinterpret_cast<const uint32_t *>(a.in_pool + E.off_draw);
     uint8_t *drawass = a.out_pool + E.off_drawass;
@@ -698,7 +702,7 @@ __global__ __launch_bounds__(256, KC <= 4 ? MISO_FLAT_WGS_4 : (KC <= 8 ? MISO_FL
   };
 
   // ---- Gibbs step for every chain's current psi ----
-  auto gibbs = [&](uint32_t iter) {
+  auto gibbs = [&](uint32_t iter) __attribute__((always_inline)) {
     FPROF_T(t0);
     // thresholds: one lane per (chain, class) -- of the chains whose psi CHANGED.  The thresholds are a function of psi
     // alone, and the Metropolis-Hastings step keeps psi in 45 % (ten isoforms) to 65 % (three to five) of the iterations
@@ -724,7 +728,7 @@ __global__ __launch_bounds__(256, KC <= 4 ? MISO_FLAT_WGS_4 : (KC <= 8 ? MISO_FL
         s = on ? static_cast<int>(__builtin_ctzll(rest | (1ull << 63))) : 0;
       }
       const int *mi = FI(s, L.misc);
-      const int K = mi[MI_K], ncls = mi[MI_NCLS];
+      const int K = KOF(mi[MI_K]), ncls = mi[MI_NCLS];
       const uint32_t m = FU(s, L.ctab)[CLS_WORDS * j];
       const double *psi = FD(s, L.psi);
       double ps[KB];
@@ -808,7 +812,7 @@ __global__ __launch_bounds__(256, KC <= 4 ? MISO_FLAT_WGS_4 : (KC <= 8 ? MISO_FL
     // D_k (+ the reads of classes that end at or before k) -> picks per isoform
     FLAT_BEGIN(ks, inv_k)
       const int *mi = FI(s, L.misc);
-      const int K = mi[MI_K], nd = mi[MI_NDRAW];
+      const int K = KOF(mi[MI_K]), nd = mi[MI_NDRAW];
       const uint32_t *A = FU(s, L.ctab) + CLS_WORDS * (cs + 1);
       const int *dl = FI(s, L.dl);
       const int jm = max(j - 1, 0);
@@ -831,7 +835,7 @@ __global__ __launch_bounds__(256, KC <= 4 ? MISO_FLAT_WGS_4 : (KC <= 8 ? MISO_FL
     const double maxv = leader_max(0);
     fsync();
     FLAT_BEGIN(ks, inv_k)
-      const int K = FI(s, L.misc)[MI_K];
+      const int K = KOF(FI(s, L.misc)[MI_K]);
       const double r = miso_det_exp(FD(s, L.tb)[j] - FD(s, L.sx)[SX_MAXV]);
       if (on && j < K) FD(s, L.tc)[j] = r;
     FLAT_END
@@ -866,7 +870,7 @@ __global__ __launch_bounds__(256, KC <= 4 ? MISO_FLAT_WGS_4 : (KC <= 8 ? MISO_FL
     if (tracing) {
       FLAT_BEGIN(ks, inv_k)
         const int *mi = FI(s, L.misc);
-        const int K = mi[MI_K];
+        const int K = KOF(mi[MI_K]);
         if (on && j < K) {
           const uint64_t to = (static_cast<uint64_t>(static_cast<uint32_t>(mi[MI_TRACE_HI])) << 32) | static_cast<uint32_t>(mi[MI_TRACE_LO]);
           if (writes) reinterpret_cast<int32_t *>(a.out_pool + to)[(static_cast<size_t>(m) * a.C + mi[MI_CHAIN]) * K + j] = count_of(s, j);
@@ -888,7 +892,7 @@ __global__ __launch_bounds__(256, KC <= 4 ? MISO_FLAT_WGS_4 : (KC <= 8 ? MISO_FL
     }
     fsync();
     FLAT_BEGIN(ks + 2, inv_k2)                                                         // pass 4: exp
-      const int K = FI(s, L.misc)[MI_K];
+      const int K = KOF(FI(s, L.misc)[MI_K]);
       const bool iso = j < ks;
       const double *sx = FD(s, L.sx);
       const double tbv = FD(s, L.tb)[PR + (iso ? j : 0)], mx = sx[SX_MAXV], e1 = sx[SX_E1], e2 = sx[SX_E2];
@@ -966,7 +970,7 @@ __global__ __launch_bounds__(256, KC <= 4 ? MISO_FLAT_WGS_4 : (KC <= 8 ? MISO_FL
     const bool rec = m >= a.B && lagCounter == a.lag - 1;
     FLAT_BEGIN(ks, inv_k)
       const int *mi = FI(s, L.misc);
-      const int acc = mi[MI_ACC], K = mi[MI_K];
+      const int acc = mi[MI_ACC], K = KOF(mi[MI_K]);
       const double v0 = FD(s, L.psi)[PR + j], v1 = FD(s, L.alpha)[PR + j], v2 = FD(s, L.lp)[PR + j],
                    v3 = FD(s, L.tb)[PR + j], v4 = FD(s, L.lr)[PR + j];
       const double c0 = FD(s, L.psi)[j];
@@ -1001,7 +1005,7 @@ __global__ __launch_bounds__(256, KC <= 4 ? MISO_FLAT_WGS_4 : (KC <= 8 ? MISO_FL
     if (MISO_FLAT_STORE_AFTER && rec) {
       FLAT_BEGIN(ks, inv_k)
         const int *mi = FI(s, L.misc);
-        const int K = mi[MI_K];
+        const int K = KOF(mi[MI_K]);
         if (on && j < K && writes) {
           const uint64_t so = (static_cast<uint64_t>(static_cast<uint32_t>(mi[MI_SAMP_HI])) << 32) | static_cast<uint32_t>(mi[MI_SAMP_LO]);
           const size_t col = static_cast<size_t>(rec_col) + mi[MI_CHAIN];
@@ -1017,7 +1021,7 @@ __global__ __launch_bounds__(256, KC <= 4 ? MISO_FLAT_WGS_4 : (KC <= 8 ? MISO_FL
   if (tracing) {
     FLAT_BEGIN(ks, inv_k)
       const int *mi = FI(s, L.misc);
-      const int K = mi[MI_K];
+      const int K = KOF(mi[MI_K]);
       if (on && j < K) {
         const uint64_t to = (static_cast<uint64_t>(static_cast<uint32_t>(mi[MI_TRACE_HI])) << 32) | static_cast<uint32_t>(mi[MI_TRACE_LO]);
         if (writes) reinterpret_cast<int32_t *>(a.out_pool + to)[(static_cast<size_t>(a.M) * a.C + mi[MI_CHAIN]) * K + j] = count_of(s, j);
@@ -1045,6 +1049,7 @@ __global__ __launch_bounds__(256, KC <= 4 ? MISO_FLAT_WGS_4 : (KC <= 8 ? MISO_FL
     st->counts_hash = wt_t0;   // when it started
 #endif
   }
+#undef KOF
 #undef FD
 #undef FI
 #undef FU

@@ -7,4 +7,8 @@ template __global__ void sampler_flat<12, 9>(const KernelArgs);   // ... of 9 is
 template __global__ void sampler_flat<12, 10>(const KernelArgs);   // ... of 10 isoforms at compile time
 template __global__ void sampler_flat<12, 11>(const KernelArgs);   // ... of 11 isoforms at compile time
 template __global__ void sampler_flat<12, 12>(const KernelArgs);   // ... of 12 isoforms at compile time
+template __global__ void sampler_flat<12, 9, true>(const KernelArgs);   // ... and every event of the launch has 9
+template __global__ void sampler_flat<12, 10, true>(const KernelArgs);   // ... and every event of the launch has 10
+template __global__ void sampler_flat<12, 11, true>(const KernelArgs);   // ... and every event of the launch has 11
+template __global__ void sampler_flat<12, 12, true>(const KernelArgs);   // ... and every event of the launch has 12
 }  // namespace miso

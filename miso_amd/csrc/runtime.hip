@@ -42,7 +42,7 @@ __global__ void match_kernel(const MatchEvent *, const int2 *, const int *, cons
 __global__ void summarize_kernel(const DevEvent *, const unsigned char *, int, int, int, int, const uint64_t *, double *, int);
 template <int G, bool PE, int KC, bool WIDE = false> __global__ void sampler_grp(const KernelArgs a);
 template <int KC> __global__ void sampler_grp_multi(const KernelArgs a);
-template <int KC, int KS> __global__ void sampler_flat(const KernelArgs a);   // KS: the launch's largest isoform count at compile time (0: at run time)
+template <int KC, int KS, bool UNI> __global__ void sampler_flat(const KernelArgs a);   // KS: the launch's largest isoform count at compile time (0: at run time)
 __global__ void selftest_detmath_kernel(const double *, int, double *, double *, double *, double *);
 __global__ void selftest_philox_kernel(const uint32_t *, int, uint32_t *);
 
@@ -939,7 +939,11 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     const int lo = run.kc == 4 ? 3 : (run.kc == 8 ? 5 : (run.kc == 12 ? 9 : (run.kc == 16 ? 13 : 17)));
     return (run.kc <= 32 && run.kmax >= lo && run.kmax <= std::min(run.kc, 20) && std::getenv("MISO_FLAT_NO_KS") == nullptr) ? run.kmax : 0;
   };
-  auto flat_name = [&](const GenRun &run) { return "sampler_flat<" + std::to_string(run.kc) + ", " + std::to_string(flat_ks(run)) + ">"; };
+  // ... and, when every event of the launch has that count, the kernel that knows it (UNI: no per-chain `k < K` masks)
+  auto flat_uni = [&](const GenRun &run) { return flat_ks(run) > 0 && run.kmin == run.kmax && std::getenv("MISO_FLAT_NO_UNI") == nullptr; };
+  auto flat_name = [&](const GenRun &run) {
+    return "sampler_flat<" + std::to_string(run.kc) + ", " + std::to_string(flat_ks(run)) + (flat_uni(run) ? ", true>" : ">");
+  };
   // Which chains a wavefront of sampler_flat owns (kernels_flat.inl: a.wave_tab).  Uniform batches: `nc` consecutive
   // chains each.  When the batch's events differ widely in size -- the heaviest wavefront of the uniform rule would
   // carry more than twice the average wavefront's work units -- the wavefronts are packed by UNITS instead: as many
@@ -1083,11 +1087,15 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     if (std::getenv("MISO_PRIO_QUARTILES") == nullptr && !run.wave_packed && run.wave_wide == 0 &&
         static_cast<long>(grid) * 4 > static_cast<long>(slots_for(static_cast<long>(run.count) * p.noChains)) * flat_wgs_for(run.kc) / 2)
       ka.balance = 2;
+#define MISO_FLAT_LAUNCH_(KC, KS, UNI)                                                                  \
+  {                                                                                                     \
+    HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sampler_flat<KC, KS, UNI>),              \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));     \
+    hipLaunchKernelGGL((sampler_flat<KC, KS, UNI>), dim3(grid), dim3(256), lds, st, ka);                \
+  }
 #define MISO_FLAT_LAUNCH(KC, KS)                                                                        \
   {                                                                                                     \
-    HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sampler_flat<KC, KS>),                   \
-                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));     \
-    hipLaunchKernelGGL((sampler_flat<KC, KS>), dim3(grid), dim3(256), lds, st, ka);                     \
+    if (KS > 0 && flat_uni(run)) MISO_FLAT_LAUNCH_(KC, KS, (KS > 0)) else MISO_FLAT_LAUNCH_(KC, KS, false)  \
   }
     const int ksel = flat_ks(run);   // (== ka.kstride or 0)
     switch (run.kc) {
@@ -1112,6 +1120,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       break;
     }
 #undef MISO_FLAT_LAUNCH
+#undef MISO_FLAT_LAUNCH_
     HIP_OK(hipGetLastError());
   };
   std::vector<int> grp_G(gen_runs.size(), 64);
@@ -1572,7 +1581,11 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     const int lo = run.kc == 4 ? 3 : (run.kc == 8 ? 5 : (run.kc == 12 ? 9 : (run.kc == 16 ? 13 : 17)));
     return (run.kc <= 32 && run.kmax >= lo && run.kmax <= std::min(run.kc, 20) && std::getenv("MISO_FLAT_NO_KS") == nullptr) ? run.kmax : 0;
   };
-  auto flat_name = [&](const GenRun &run) { return "sampler_flat<" + std::to_string(run.kc) + ", " + std::to_string(flat_ks(run)) + ">"; };
+  // ... and, when every event of the launch has that count, the kernel that knows it (UNI: no per-chain `k < K` masks)
+  auto flat_uni = [&](const GenRun &run) { return flat_ks(run) > 0 && run.kmin == run.kmax && std::getenv("MISO_FLAT_NO_UNI") == nullptr; };
+  auto flat_name = [&](const GenRun &run) {
+    return "sampler_flat<" + std::to_string(run.kc) + ", " + std::to_string(flat_ks(run)) + (flat_uni(run) ? ", true>" : ">");
+  };
   for (int part = 0; part < 2; part++) {
     const bool wpart = part == 0;
     const int count = wpart ? n_k2w : n_k2 - n_k2w, k2G = wpart ? k2w_G : k2_G;

@@ -47,23 +47,27 @@ def test_single_end_bit_exact(orc, K, N, chains, iters, burn, lag):
 
 @pytest.mark.parametrize("K", list(range(3, 22)))
 def test_single_end_kernel_of_every_isoform_count(orc, K, monkeypatch):
-    """sampler_flat<KC, KS>: up to twenty isoforms the launch's largest isoform count is a compile-time constant of the
-    kernel (slice layout, loop bounds -- kernels_flat.inl); beyond, and under MISO_FLAT_NO_KS=1, the run-time layout.
-    Both bit-exact against the checker, three chains of different events in one wavefront."""
+    """sampler_flat<KC, KS, UNI>: up to twenty isoforms the launch's largest isoform count is a compile-time constant of the
+    kernel (slice layout, loop bounds -- kernels_flat.inl), and when every event of the launch has that count the kernel
+    knows it (UNI: no per-chain `k < K` masks); MISO_FLAT_NO_UNI=1: the kernel for mixed counts; beyond twenty, and under
+    MISO_FLAT_NO_KS=1, the run-time layout.  All bit-exact against the checker, three chains of different events in one
+    wavefront."""
     iters, burn, lag, chains = 60, 10, 2, 2
     cases = []
     for e in range(3):
         exons, isoforms, g, pos, cig = simulate_se(orc, K, 250 + 40 * e, seed=700 + 10 * K + e)
         cases.append((miso_amd.Gene(exons, isoforms), g, pos, cig))
     kc = 4 if K <= 4 else 8 if K <= 8 else 12 if K <= 12 else 16 if K <= 16 else 32
-    for no_ks in (False, True):
-        if no_ks:
-            monkeypatch.setenv("MISO_FLAT_NO_KS", "1")
+    for env, name in ((None, "sampler_flat<%d, %d, true>" % (kc, K) if K <= 20 else "sampler_flat<%d, 0>" % kc),
+                      ("MISO_FLAT_NO_UNI", "sampler_flat<%d, %d>" % (kc, K if K <= 20 else 0)),
+                      ("MISO_FLAT_NO_KS", "sampler_flat<%d, 0>" % kc)):
+        if env:
+            monkeypatch.setenv(env, "1")
         b = miso_amd.Batch(36, iters=iters, burn=burn, lag=lag, chains=chains, counts_trace=True)
         for G, g, pos, cig in cases:
             b.add_event(G, pos, cig)
         b.run(seed=SEED, first_event_id=40)
-        assert "sampler_flat<%d, %d>" % (kc, 0 if (no_ks or K > 20) else K) in b.last_kernels(), b.last_kernels()
+        assert name in b.last_kernels(), b.last_kernels()
         for e, (G, g, pos, cig) in enumerate(cases):
             cpu = orc.miso(g, pos, cig, 36, iters=iters, burn=burn, lag=lag, chains=chains,
                            mode=OrcLib.COUNTER, seed=SEED, event_id=40 + e, trace=True)
@@ -106,6 +110,27 @@ def test_many_events_one_launch(orc):
         assert (gpu.samples == cpu.samples).all(), i
         assert np.array_equal(gpu.loglik, cpu.loglik, equal_nan=True), i
         assert (gpu.assignment == cpu.assignment).all(), i
+
+
+@pytest.mark.parametrize("counts", [(3, 4, 3), (5, 8, 6, 7, 5), (9, 12, 10), (13, 16), (17, 20, 18)])
+def test_single_end_class_of_mixed_isoform_counts(orc, counts):
+    """Events of different isoform counts of one class in one launch share wavefronts: the kernel of the largest count,
+    NOT the one that takes every chain's count for that constant (kernels_flat.inl UNI)."""
+    iters, burn, lag, chains = 50, 10, 2, 2
+    b = miso_amd.Batch(36, iters=iters, burn=burn, lag=lag, chains=chains, counts_trace=True)
+    keep = []
+    for e, K in enumerate(counts):
+        exons, isoforms, g, pos, cig = simulate_se(orc, K, 200 + 30 * e, seed=9100 + 10 * K + e)
+        b.add_event(miso_amd.Gene(exons, isoforms), pos, cig)
+        keep.append((g, pos, cig))
+    b.run(seed=SEED, first_event_id=70)
+    kc = 4 if max(counts) <= 4 else 8 if max(counts) <= 8 else 12 if max(counts) <= 12 else 16 if max(counts) <= 16 else 32
+    assert b.last_kernels() == "sampler_flat<%d, %d>" % (kc, max(counts)), b.last_kernels()
+    for e, (g, pos, cig) in enumerate(keep):
+        cpu = orc.miso(g, pos, cig, 36, iters=iters, burn=burn, lag=lag, chains=chains,
+                       mode=OrcLib.COUNTER, seed=SEED, event_id=70 + e, trace=True)
+        assert cpu.rc == 0
+        _compare(b.result(e, trace=True), cpu, chains)
 
 
 @pytest.mark.parametrize("paired", [False, True])
