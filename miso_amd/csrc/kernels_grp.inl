@@ -774,17 +774,21 @@ __device__ __forceinline__ void pe_dense(const uint32_t *fq, const double *psi, 
       if constexpr (NR >= 2) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(r2) : "v"(src + 4 * NQ) : "memory");
       if constexpr (NR & 1) asm volatile("global_load_dword %0, %1, off" : "=v"(r1) : "v"(src + 4 * NQ + (NR & 2)) : "memory");
     };
-    auto landed = [&](auto cnt) __attribute__((always_inline)) {
-      // (every piece is named: nothing may read or move it before this point)
-#pragma unroll
-      for (int i = 0; i < NQ; i++) asm volatile("" : "+v"(r4[i]) : : "memory");
-      if constexpr (decltype(cnt)::value == 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(r2), "+v"(r1) : : "memory");
-      else asm volatile("s_waitcnt vmcnt(4)" : "+v"(r2), "+v"(r1) : : "memory");
-#pragma unroll
-      for (int i = 0; i < NQ; i++) asm volatile("" : "+v"(r4[i]) : : "memory");
+    // (every piece is named IN the wait: nothing may read or move it before this point.  Round 6: with the 16-byte pieces named
+    // by empty statements around the wait instead, a build without machine-level hoisting put a register copy of one between
+    // the statement in front and the wait -- a read before the data has landed; `make check-isa` stopped that build)
+    static_assert(NQ == 1 || NQ == 2, "records of five to eight isoforms");
+    auto landed = [&](bool everything) __attribute__((always_inline)) {   // (a constant at both call sites)
+      if constexpr (NQ == 2) {
+        if (everything) asm volatile("s_waitcnt vmcnt(0)" : "+v"(r4[0]), "+v"(r4[1]), "+v"(r2), "+v"(r1) : : "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" : "+v"(r4[0]), "+v"(r4[1]), "+v"(r2), "+v"(r1) : : "memory");
+      } else {
+        if (everything) asm volatile("s_waitcnt vmcnt(0)" : "+v"(r4[0]), "+v"(r2), "+v"(r1) : : "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" : "+v"(r4[0]), "+v"(r2), "+v"(r1) : : "memory");
+      }
     };
     issue(sub);
-    landed(std::integral_constant<int, 0>{});
+    landed(true);
     for (int q0 = 0; q0 < nqw; q0 += G) {
       uint32_t cur[ND];
 #pragma unroll
@@ -793,7 +797,7 @@ __device__ __forceinline__ void pe_dense(const uint32_t *fq, const double *psi, 
       if constexpr (NR & 1) cur[ND - 1] = r1;
       issue(q0 + sub + G);
       process(cur, q0 + sub);
-      landed(std::integral_constant<int, 4>{});
+      landed(false);
     }
   } else {
     // wider records: one loop body, the next quad fetched into a second set of registers and copied over

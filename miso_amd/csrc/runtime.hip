@@ -956,11 +956,11 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   // resident slots, or a second round that is less than half full (K = 3: 3349 wavefronts on 3072 slots 286 ms,
   // 5704 wavefronts 270 ms); then the wavefront count goes to 0.95 x one or two rounds
   // (profiles/r03_flat_pack_sweep.txt).  A forced MISO_FLAT_NC sets the average chains per wavefront instead.
-  auto flat_waves = [&](GenRun &run, int nc, int nc_max, long resident) {
+  auto flat_waves = [&](GenRun &run, int nc, int nc_max_u, long resident_u, int nc_max_p, long resident_p) {
     const long chains = static_cast<long>(run.count) * p.noChains;
     const int C = p.noChains;
     const char *env = std::getenv("MISO_FLAT_PACK");
-    const long key = ((static_cast<long>(nc) * 4 + (env ? 1 + (std::atoi(env) != 0) : 0)) * 128 + nc_max) * 1024 + (std::getenv("MISO_FLAT_PACK_OV") ? 1 + std::atol(std::getenv("MISO_FLAT_PACK_OV")) % 1000 : 0);
+    const long key = (((static_cast<long>(nc) * 4 + (env ? 1 + (std::atoi(env) != 0) : 0)) * 128 + nc_max_u) * 128 + nc_max_p) * 1024 + (std::getenv("MISO_FLAT_PACK_OV") ? 1 + std::atol(std::getenv("MISO_FLAT_PACK_OV")) % 1000 : 0);
     if (run.wave_key == key && run.d_wave_tab) return;
     // (round 5) what a chain costs its wavefront, in work units: its units + the scalar step and thresholds, which do not
     // depend on the reads.  Measured per chain-iteration at eight / five chains per wavefront (profiles/r05_flat_chunks.txt):
@@ -990,6 +990,8 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       for (long c = 0; c < chains; c += nc) waves.push_back(W{static_cast<int32_t>(c), static_cast<int32_t>(std::min<long>(nc, chains - c)), 0});
       run.wave_nc = nc;
     } else {
+      // (packed launches have their own sizing: launch_flat)
+      const int nc_max = nc_max_p; const long resident = resident_p;
       const int cap = std::min(nc_max, 255);
       int most = 1;
       auto pack_with = [&](double U) {
@@ -1058,7 +1060,18 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
     {
       const long chains = static_cast<long>(run.count) * p.noChains;
       const int wgs = std::getenv("MISO_FLAT_WGS") ? std::max(1, std::atoi(std::getenv("MISO_FLAT_WGS"))) : flat_wgs_for(run.kc);
-      flat_waves(run, nc, nc_max, std::max<long>(1, static_cast<long>(slots_for(chains)) * wgs / 2));
+      // Five to eight isoforms: the kernel's registers allow three workgroups per CU; launches of like-sized events are sized for
+      // two (fuller wavefronts: K = 6 312 against 333 ms, K = 7 347 / 366), launches packed by cost for three -- more, smaller
+      // wavefronts level the heavy tail better than fuller ones amortise the scalar step (hg19-like read counts, 40 000 events:
+      // K = 5 276 -> 252 ms, K = 6 332 -> 278, K = 7 379 -> 339, K = 8 415 -> 393; profiles/r06_flat_licm.txt)
+      int wgs_p = wgs, nc_max_p = nc_max;
+      if (run.kc == 8 && std::getenv("MISO_FLAT_WGS") == nullptr && std::getenv("MISO_LDS_MAX_KB") == nullptr && std::getenv("MISO_FLAT_PACK_WGS2") == nullptr) {
+        wgs_p = 3;
+        const int slice = flat_layout(run.kmax, std::max(run.maxcls, 1)).bytes;
+        nc_max_p = std::max(1, std::min<int>(64, static_cast<int>(160 * 1024 / (4 * wgs_p) - 64) / slice));
+      }
+      flat_waves(run, nc, nc_max, std::max<long>(1, static_cast<long>(slots_for(chains)) * wgs / 2),
+                 nc_max_p, std::max<long>(1, static_cast<long>(slots_for(chains)) * wgs_p / 2));
     }
     ka.slot_event = d_slots + n_k2 + run.first; ka.n_slots = run.count;
     ka.kstride = run.kmax; ka.cstride = std::max(run.maxcls, 1); ka.tstride = 0; ka.nc = run.wave_nc;
