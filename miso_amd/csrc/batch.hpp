@@ -47,6 +47,8 @@ struct miso_batch {
   // rounds after the first open (KernelArgs::round_tab)
   int round_iters = 0, round_burn = 0;
   std::vector<int> round_starts;
+  miso::GrpSeg *d_grp_segs = nullptr;     // sampler_grp_all's segment table on the device (KernelArgs::grp_segs), h_grp_segs its host copy
+  std::vector<miso::GrpSeg> h_grp_segs;
   int32_t *d_round_tab = nullptr;   // ... on the device (KernelArgs::round_tab)
   std::vector<char> went_on;      // per event: it ran a further round in the last launch's converge_rounds
   bool event_went_on(int i) const { return i < static_cast<int>(went_on.size()) && went_on[i] != 0; }
@@ -139,7 +141,7 @@ struct miso_batch {
   std::vector<int32_t> k2_pair_tab;
   int32_t *d_k2_pair_tab = nullptr;
   int k2_pair_wide_blocks = 0, k2_pair_grid = 0;
-  std::vector<char> run_in_multi;                 // gen_runs launched as a segment of sampler_grp_multi (last launch)
+  std::vector<char> run_in_multi;                 // gen_runs launched as a segment of sampler_grp_multi (1) or sampler_grp_all (2) (last launch)
   std::function<void()> stats_builder;            // set by launch(): the walk over events and wavefronts is not part of a launch
   int wave_slots = 2048;          // resident sampler_k2 wavefronts on the device
   std::vector<miso::DevEvent> h_events;

@@ -87,6 +87,18 @@ constexpr int MISO_MAX_ROUNDS = 8;   // stop = CONVERGENT_MEAN: rounds a device 
 constexpr int K2_WIDE = 512;   // seg_lanes value: one chain per workgroup
 constexpr int K2_RED_BYTES = 2 * 8 * 16 + 16 + 16;   // two buffers x (up to) 8 wavefronts x {int64 score sum, int count, int bad} + the barrier's flag + the psi a workgroup-wide chain's first four wavefronts publish (kernels_k2.inl)
 
+// sampler_grp_all (kernels_grp_all.hip): one segment of the launch -- a run of one isoform-count class and one size bucket
+struct GrpSeg {
+  int32_t block0;           // the segment's first workgroup (the table ends with a sentinel entry: block0 = the grid)
+  int32_t slot0, n_slots;   // its events in the launch's list
+  int32_t lanes;            // per chain: 16, 32, 64 or K2_WIDE (a workgroup, or several: coop_tab)
+  int32_t kc;               // the class: 4, 8, 12, 16, 32
+  int32_t kstride, tstride; // the run's slice layout (KernelArgs::kstride, tstride)
+  int32_t red_off;          // workgroup-wide chains: KernelArgs::red_off
+  const int32_t *coop_tab;  // ... KernelArgs::coop_tab, coop_mem
+  uint32_t *coop_mem;
+};
+
 struct KernelArgs {
   const DevEvent *events;
   const unsigned char *in_pool;
@@ -130,6 +142,8 @@ struct KernelArgs {
   // sampler_k2_multi<0, 8>, one round: the two wavefronts of a SIMD keep step by priority (kernels_k2.inl k2_balance)
   int32_t balance;
   int32_t wide_dedup;       // sampler_k2 WIDE with eight wavefronts: the Metropolis-Hastings step on the first four only (kernels_k2.inl)
+  const GrpSeg *grp_segs;   // sampler_grp_all: n_grp_segs segments + the sentinel, in global memory
+  int32_t n_grp_segs;
   int32_t n_segs;
   int32_t seg_block[K2_MAX_SEGS + 1];
   int32_t seg_slot[K2_MAX_SEGS + 1];

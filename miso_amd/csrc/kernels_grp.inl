@@ -1533,6 +1533,15 @@ __global__ __launch_bounds__(256, PE ? MISO_GRP_PE_BLOCKS : (KC <= 8 ? MISO_GRP_
 // the launch's list, seg_lanes[s] lanes per chain (K2_WIDE = a workgroup).  One kernel in the hardware queue instead of
 // four, the workgroups start longest chains first across the buckets (docs/history.md 4.3 (iv)).
 template <int KC>
+__device__ __forceinline__ void grp_lanes(const KernelArgs &b, unsigned blk, int lanes) {
+  switch (lanes) {
+  case K2_WIDE: grp_body<64, true, KC, true>(b, blk); break;
+  case 64: grp_body<64, true, KC, false>(b, blk); break;
+  case 32: grp_body<32, true, KC, false>(b, blk); break;
+  default: grp_body<16, true, KC, false>(b, blk); break;
+  }
+}
+template <int KC>
 __global__ __launch_bounds__(256, MISO_GRP_PE_BLOCKS) void sampler_grp_multi(const KernelArgs a) {
   int s = 0;
   while (s + 1 < a.n_segs && static_cast<int>(blockIdx.x) >= a.seg_block[s + 1]) s++;
@@ -1541,12 +1550,43 @@ __global__ __launch_bounds__(256, MISO_GRP_PE_BLOCKS) void sampler_grp_multi(con
   b.slot_event = a.slot_event + a.seg_slot[s];
   b.n_slots = a.seg_slot[s + 1] - a.seg_slot[s];
   const unsigned blk = blockIdx.x - static_cast<unsigned>(a.seg_block[s]);
-  switch (a.seg_lanes[s]) {
-  case K2_WIDE: grp_body<64, true, KC, true>(b, blk); break;
-  case 64: grp_body<64, true, KC, false>(b, blk); break;
-  case 32: grp_body<32, true, KC, false>(b, blk); break;
-  default: grp_body<16, true, KC, false>(b, blk); break;
+  grp_lanes<KC>(b, blk, a.seg_lanes[s]);
+}
+
+#ifdef MISO_GRP_ALL_CLASSES
+// Paired-end, EVERY isoform-count class of the batch with its size buckets in one launch (runtime.hip; VERDICT r5 item 5: a
+// whole-gene batch as one ordered grid).  The segments (a.grp_segs, in global memory: a run-time index into the by-value
+// arguments would cost a scratch copy of them) are ordered by what a workgroup of theirs costs, the chains on several
+// workgroups in front: the hardware starts workgroups in index order, so the 17 - 20 isoform genes all start in the first round
+// of resident wavefronts and the three-isoform genes fill the slots they free -- instead of five kernels in five hardware
+// queues whose workgroups the dispatcher interleaves as it likes (profiles/r06_mix_timeline.txt: the last quarter of such a
+// launch ran nearly empty).
+__global__ __launch_bounds__(256, MISO_GRP_PE_BLOCKS) void sampler_grp_all(const KernelArgs a) {
+  int s = 0;
+  while (s + 1 < a.n_grp_segs && static_cast<int>(blockIdx.x) >= a.grp_segs[s + 1].block0) s++;
+  s = __builtin_amdgcn_readfirstlane(s);
+  // (the table is read by vector loads -- nothing tells the compiler that it is not written meanwhile --: every field is made a
+  // scalar by hand, or the slice layout and the loop bounds of the body would count as different from lane to lane)
+  const GrpSeg *gp = a.grp_segs + s;
+  GrpSeg g{};
+  g.block0 = __builtin_amdgcn_readfirstlane(gp->block0); g.slot0 = __builtin_amdgcn_readfirstlane(gp->slot0);
+  g.n_slots = __builtin_amdgcn_readfirstlane(gp->n_slots); g.kc = __builtin_amdgcn_readfirstlane(gp->kc);
+  g.kstride = __builtin_amdgcn_readfirstlane(gp->kstride); g.tstride = __builtin_amdgcn_readfirstlane(gp->tstride);
+  KernelArgs b = a;
+  b.slot_event = a.slot_event + g.slot0;
+  b.n_slots = g.n_slots;
+  b.kstride = g.kstride; b.tstride = g.tstride;
+  const unsigned blk = blockIdx.x - static_cast<unsigned>(g.block0);
+  // (sixteen lanes per chain only: with the four kinds of segment of all five classes -- twenty bodies in one function -- the
+  // unit took 28 minutes to compile and spilled 802 registers, round 5)
+  switch (g.kc) {
+  case 4: grp_body<16, true, 4, false>(b, blk); break;
+  case 8: grp_body<16, true, 8, false>(b, blk); break;
+  case 12: grp_body<16, true, 12, false>(b, blk); break;
+  case 16: grp_body<16, true, 16, false>(b, blk); break;
+  default: grp_body<16, true, 32, false>(b, blk); break;
   }
 }
+#endif
 
 }  // namespace miso

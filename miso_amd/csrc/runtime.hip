@@ -42,6 +42,7 @@ __global__ void match_kernel(const MatchEvent *, const int2 *, const int *, cons
 __global__ void summarize_kernel(const DevEvent *, const unsigned char *, int, int, int, int, const uint64_t *, double *, int);
 template <int G, bool PE, int KC, bool WIDE = false> __global__ void sampler_grp(const KernelArgs a);
 template <int KC> __global__ void sampler_grp_multi(const KernelArgs a);
+__global__ void sampler_grp_all(const KernelArgs a);   // kernels_grp_all.hip
 template <int KC, int KS, bool UNI> __global__ void sampler_flat(const KernelArgs a);   // KS: the launch's largest isoform count at compile time (0: at run time)
 __global__ void selftest_detmath_kernel(const double *, int, double *, double *, double *, double *);
 __global__ void selftest_philox_kernel(const uint32_t *, int, uint32_t *);
@@ -135,6 +136,7 @@ void miso_batch::release() {
   if (probe_stream) { (void) hipStreamSynchronize(probe_stream); (void) hipStreamDestroy(probe_stream); probe_stream = nullptr; }
   if (d_probe) { (void) hipFree(d_probe); d_probe = nullptr; }
   if (d_round_tab) { (void) hipFree(d_round_tab); d_round_tab = nullptr; }
+  if (d_grp_segs) { (void) hipFree(d_grp_segs); d_grp_segs = nullptr; }
   probe_armed = false;
   if (ev0) (void) hipEventDestroy(ev0);
   if (ev1) (void) hipEventDestroy(ev1);
@@ -1701,7 +1703,8 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       trips = 0; waves = 0;
       for (long sl = 0; sl < chains; sl++) { trips += 4 * ((((evs[sl / C]->n_draw + 3) / 4) + 255) / 256); waves += 4; }
     }
-    const std::string name = (ri < run_in_multi.size() && run_in_multi[ri]) ? "sampler_grp_multi<" + std::to_string(run.kc) + ">" :
+    const std::string name = (ri < run_in_multi.size() && run_in_multi[ri] == 2) ? std::string("sampler_grp_all") :
+                             (ri < run_in_multi.size() && run_in_multi[ri]) ? "sampler_grp_multi<" + std::to_string(run.kc) + ">" :
                              run.wide ? "sampler_grp<64, true, " + std::to_string(run.kc) + ", true>" :
                              flat ? flat_name(run) : ((G == 64 && !w64) ? std::string(run.kc > 64 ? "sampler_big<" : "sampler_wave<") : "sampler_grp<" + std::to_string(G) + ", ") +
                              (p.paired ? "true" : "false") + ((G == 64 && !w64) ? std::string(">") : ", " + std::to_string(run.kc) + ">");
@@ -1808,12 +1811,92 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   // segments = the class's runs in list order -- workgroup-wide chains (those on several workgroups in front), a
   // wavefront per chain, 32 lanes, 16 lanes.  MISO_NO_PE_MULTI=1: every run its own launch (A/B, tests).
   std::vector<char> in_multi(gen_runs.size(), 0);
+  bool all_launched = false;
+  // Paired-end, two classes or more, every run on dense records with sixteen lanes per chain (a whole-gene batch of like-sized
+  // genes): ALL of them in one launch (sampler_grp_all, kernels_grp.inl), the segments ordered by what a workgroup costs --
+  // (quads per lane + the scalar step) x isoforms, descending: longest first across the classes.  Every segment keeps the run's
+  // own slice layout (launch_grp's).  Batches with size buckets (real pair counts) keep a launch per class
+  // (sampler_grp_multi): twenty bodies in one kernel do not compile in reasonable time (round 5: 28 minutes, 802 spilled registers).
+  // MISO_NO_PE_ALL=1: the launches per run below (A/B, tests).
+  {
+    bool all_ok = p.paired && !lane_gen && gen_runs.size() >= 2 && gen_runs.size() < 127 && std::getenv("MISO_NO_PE_ALL") == nullptr &&
+                  std::getenv("MISO_NO_PE_MULTI") == nullptr && std::getenv("MISO_SERIAL_KERNELS") == nullptr &&
+                  (std::getenv("MISO_GENERAL_LANES") == nullptr || std::getenv("MISO_PE_ALL") != nullptr);   // (MISO_PE_ALL=1 with MISO_GENERAL_LANES=16: tests on small batches)
+    bool two_classes = false;
+    for (size_t ri = 0; ri < gen_runs.size() && all_ok; ri++) {
+      const GenRun &run = gen_runs[ri];
+      const int G = grp_G[ri];
+      all_ok = !run_lane[ri] && flat_nc[ri] == 0 && fp_rows(run) && run.kc <= 32 && !run.wide && G == 16;
+      two_classes |= run.kc != gen_runs[0].kc;
+    }
+    if (all_ok && two_classes) {
+      struct Seg { size_t ri; int lanes; double cost; };
+      std::vector<Seg> segs;
+      for (size_t ri = 0; ri < gen_runs.size(); ri++) {
+        const GenRun &run = gen_runs[ri];
+        const int lanes = run.wide ? K2_WIDE : grp_G[ri];
+        const double per_lane = static_cast<double>(run.maxq) / (run.wide ? 256.0 : lanes);
+        segs.push_back(Seg{ri, lanes, (per_lane + 8.0) * (run.kmax + 2)});
+      }
+      std::stable_sort(segs.begin(), segs.end(), [&](const Seg &x, const Seg &y) {
+        const bool wx = x.lanes == K2_WIDE, wy = y.lanes == K2_WIDE;
+        return wx != wy ? wx : x.cost > y.cost;
+      });
+      KernelArgs ka = a;
+      hipStream_t st = stream_for_next();
+      ka.slot_event = d_slots + n_k2; ka.n_slots = n_gen;
+      ka.cstride = 0; ka.pe_dense = 1; ka.pe_force_exact = std::getenv("MISO_PE_FORCE_EXACT") != nullptr;
+      size_t lds = 0; int blocks = 0;
+      std::vector<GrpSeg> tab;
+      for (const Seg &sg : segs) {
+        GenRun &run = gen_runs[sg.ri];
+        const GrpShape &sh = grp_sh[sg.ri];
+        const long chains = static_cast<long>(run.count) * p.noChains;
+        const size_t fp_bytes = fp_bytes_of(run);
+        const size_t slice = grp_slice_bytes(run.kmax, 0, sh.ts);
+        GrpSeg g{};
+        g.block0 = blocks; g.slot0 = run.first; g.n_slots = run.count; g.lanes = sg.lanes; g.kc = run.kc;
+        g.kstride = run.kmax; g.tstride = sh.ts;
+        if (run.wide) {
+          const size_t lds0 = align_up(fp_bytes + 4 * slice, 16);
+          g.red_off = static_cast<int32_t>(lds0);
+          lds = std::max(lds, lds0 + 96);
+          blocks += static_cast<int>(wide_setup(run, chains, st));
+          g.coop_tab = run.d_coop_tab; g.coop_mem = run.d_coop_mem;
+        } else {
+          const int cpw = 64 / sg.lanes;
+          lds = std::max(lds, fp_bytes + 4 * static_cast<size_t>(cpw) * slice);
+          blocks += static_cast<int>(((chains + cpw - 1) / cpw + 3) / 4);
+        }
+        tab.push_back(g);
+        in_multi[sg.ri] = 2;
+      }
+      GrpSeg sentinel{}; sentinel.block0 = blocks;
+      tab.push_back(sentinel);
+      if (lds > LDS_MAX) MISO_FAIL(MISO_EINTERNAL, "sampler_grp_all: a segment's slices exceed the workgroup's LDS");
+      // (uploaded when it changed: the batch's first launch, or another upload's events; the launch that read the old one has
+      // been waited for by then)
+      constexpr size_t GRP_SEGS_CAP = 128;
+      if (tab.size() > GRP_SEGS_CAP) MISO_FAIL(MISO_EINTERNAL, "sampler_grp_all: too many segments");
+      if (!d_grp_segs) HIP_OK(hipMalloc(reinterpret_cast<void **>(&d_grp_segs), GRP_SEGS_CAP * sizeof(GrpSeg)));
+      if (tab.size() != h_grp_segs.size() || std::memcmp(tab.data(), h_grp_segs.data(), tab.size() * sizeof(GrpSeg)) != 0) {
+        h_grp_segs = tab;
+        HIP_OK(hipMemcpy(d_grp_segs, h_grp_segs.data(), h_grp_segs.size() * sizeof(GrpSeg), hipMemcpyHostToDevice));
+      }
+      ka.grp_segs = d_grp_segs; ka.n_grp_segs = static_cast<int32_t>(segs.size());
+      last_kernels += std::string(last_kernels.empty() ? "" : ",") + "sampler_grp_all";
+      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sampler_grp_all), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+      hipLaunchKernelGGL(sampler_grp_all, dim3(static_cast<unsigned>(blocks)), dim3(256), lds, st, ka);
+      HIP_OK(hipGetLastError());
+      all_launched = true;
+    }
+  }
   // When: the batch's launches outnumber the hardware queues (a whole-gene mix with real read counts: ~20 launches, 243 ->
   // 180 ms per 1500 iterations; a single class's three or four buckets run 3 % faster side by side: 149 vs 155 ms at K = 5;
   // profiles/r03_pe_buckets.txt).  MISO_PE_MULTI=1 forces (tests).
   const bool multi_on = p.paired && !lane_gen && std::getenv("MISO_NO_PE_MULTI") == nullptr && std::getenv("MISO_GENERAL_LANES") == nullptr &&
                         (std::getenv("MISO_PE_MULTI") != nullptr || gen_runs.size() + (n_k2 > 0 ? 1 : 0) > 8);
-  for (size_t r0 = 0; multi_on && r0 < gen_runs.size();) {
+  for (size_t r0 = 0; multi_on && !all_launched && r0 < gen_runs.size();) {
     size_t r1 = r0 + 1;
     while (r1 < gen_runs.size() && gen_runs[r1].kc == gen_runs[r0].kc) r1++;
     bool ok = r1 - r0 >= 2 && r1 - r0 <= static_cast<size_t>(K2_MAX_SEGS);

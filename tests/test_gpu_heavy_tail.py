@@ -224,6 +224,65 @@ def test_mixed_pair_counts_three_or_more_isoforms_paired_end_bit_exact(orc, K, c
     assert "sampler_grp<64, true, %d>" % kc in names[6] and "sampler_grp<64, true, %d, true>" % kc in names[6], names
 
 
+def test_whole_gene_batch_of_several_classes_in_one_launch_bit_exact(orc):
+    """sampler_grp_all (kernels_grp.inl): a paired-end batch of like-sized genes of several isoform-count classes (sixteen lanes
+    per chain everywhere) is ONE launch, its classes segments ordered by cost.  Against the oracle, with every read through the
+    exact scan, and against the launch per class (MISO_NO_PE_ALL=1), which must give the same bits; a batch with size buckets
+    (one gene of 9000 pairs among them) keeps the launches per class."""
+    counts = [3, 18, 5, 10, 14, 4, 7, 12, 20, 9, 3, 5, 16, 8, 11, 6, 13, 17, 19, 15]
+    sizes = [300, 260, 200, 350, 220, 180, 0, 260, 400, 320, 290, 200, 235, 400, 250, 380, 310, 270, 330, 240]
+    evs = []
+    for j, (K, n) in enumerate(zip(counts, sizes)):
+        exons, isoforms = se_gene(K, exlen=500 + 11 * j, gap=300)
+        g = orc.gene(flat(exons), isoforms)
+        orc.rng_seed(7100 + j)
+        rc, _, pos, cig = orc.simulate_paired_reads(g, expr_for(K), max(n, 1), 36, 250.0, 900.0)
+        assert rc == 0
+        evs.append((exons, isoforms, g, pos[:2 * n], cig[:2 * n]))
+    kw = dict(iters=40, burn=10, lag=2, chains=2)
+    cpu = []
+    for i, (exons, isoforms, g, pos, cig) in enumerate(evs):
+        r = orc.miso_paired(g, pos, cig, 36, 250.0, 900.0, mode=OrcLib.COUNTER, seed=23, event_id=900 + i, trace=True, **kw)
+        assert r.rc == 0
+        cpu.append(r)
+    names = []
+    # (a batch this small would get 32 lanes per chain and size buckets: sixteen everywhere is what 16 384 genes get by themselves)
+    lanes16 = dict(MISO_GENERAL_LANES="16", MISO_NO_PE_BUCKETS="1", MISO_PE_ALL="1")
+    for v in (lanes16, dict(lanes16, MISO_PE_FORCE_EXACT="1"), dict(lanes16, MISO_NO_PE_ALL="1")):
+        with _env(**v):
+            b = miso_amd.Batch(36, paired=True, mean=250.0, var=900.0, device_match=True, **kw)
+            for exons, isoforms, g, pos, cig in evs:
+                b.add_event(miso_amd.Gene(exons, isoforms), pos, cig)
+            b.run(seed=23, first_event_id=900)
+            names.append(b.last_kernels())
+            b.run(seed=23, first_event_id=900)   # (the segment table is kept between launches)
+            assert b.last_kernels() == names[-1]
+            for i, r in enumerate(cpu):
+                gpu = b.result(i)
+                where = (v, counts[i], sizes[i], b.last_kernels())
+                assert (gpu.counts_hash == r.trace["counts_hash"]).all(), where
+                assert np.array_equal(gpu.samples, r.samples, equal_nan=True), where
+                assert np.array_equal(gpu.loglik, r.loglik, equal_nan=True), where
+                assert (gpu.assignment == r.assignment).all(), where
+                assert gpu.rundata.noAccepted == r.accepted, where
+    assert names[0] == "sampler_grp_all" and names[1] == "sampler_grp_all", names
+    assert "sampler_grp_all" not in names[2] and names[2].count("sampler_grp<16, true, ") == 5, names
+    # one large gene: size buckets, a launch per class (or per run) as before
+    exons, isoforms = se_gene(6, exlen=700, gap=300)
+    g = orc.gene(flat(exons), isoforms)
+    orc.rng_seed(7177)
+    rc, _, pos, cig = orc.simulate_paired_reads(g, expr_for(6), 9000, 36, 250.0, 900.0)
+    assert rc == 0
+    b = miso_amd.Batch(36, paired=True, mean=250.0, var=900.0, device_match=True, **kw)
+    for exons_, isoforms_, g_, pos_, cig_ in evs:
+        b.add_event(miso_amd.Gene(exons_, isoforms_), pos_, cig_)
+    b.add_event(miso_amd.Gene(exons, isoforms), pos, cig)
+    b.run(seed=23, first_event_id=900)
+    assert "sampler_grp_all" not in b.last_kernels(), b.last_kernels()
+    for i, r in enumerate(cpu):
+        assert np.array_equal(b.result(i).samples, r.samples, equal_nan=True), i
+
+
 def _worker(paired, K, rounds, **env):
     import subprocess
     import sys
