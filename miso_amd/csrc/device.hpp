@@ -87,16 +87,12 @@ constexpr int MISO_MAX_ROUNDS = 8;   // stop = CONVERGENT_MEAN: rounds a device 
 constexpr int K2_WIDE = 512;   // seg_lanes value: one chain per workgroup
 constexpr int K2_RED_BYTES = 2 * 8 * 16 + 16 + 16;   // two buffers x (up to) 8 wavefronts x {int64 score sum, int count, int bad} + the barrier's flag + the psi a workgroup-wide chain's first four wavefronts publish (kernels_k2.inl)
 
-// sampler_grp_all (kernels_grp_all.hip): one segment of the launch -- a run of one isoform-count class and one size bucket
+// sampler_grp_all (kernels_grp_all.hip): one segment of the launch -- the run of one isoform-count class, sixteen lanes per chain
 struct GrpSeg {
   int32_t block0;           // the segment's first workgroup (the table ends with a sentinel entry: block0 = the grid)
   int32_t slot0, n_slots;   // its events in the launch's list
-  int32_t lanes;            // per chain: 16, 32, 64 or K2_WIDE (a workgroup, or several: coop_tab)
   int32_t kc;               // the class: 4, 8, 12, 16, 32
   int32_t kstride, tstride; // the run's slice layout (KernelArgs::kstride, tstride)
-  int32_t red_off;          // workgroup-wide chains: KernelArgs::red_off
-  const int32_t *coop_tab;  // ... KernelArgs::coop_tab, coop_mem
-  uint32_t *coop_mem;
 };
 
 struct KernelArgs {

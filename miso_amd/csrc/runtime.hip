@@ -1830,18 +1830,11 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       two_classes |= run.kc != gen_runs[0].kc;
     }
     if (all_ok && two_classes) {
-      struct Seg { size_t ri; int lanes; double cost; };
+      struct Seg { size_t ri; double cost; };
       std::vector<Seg> segs;
-      for (size_t ri = 0; ri < gen_runs.size(); ri++) {
-        const GenRun &run = gen_runs[ri];
-        const int lanes = run.wide ? K2_WIDE : grp_G[ri];
-        const double per_lane = static_cast<double>(run.maxq) / (run.wide ? 256.0 : lanes);
-        segs.push_back(Seg{ri, lanes, (per_lane + 8.0) * (run.kmax + 2)});
-      }
-      std::stable_sort(segs.begin(), segs.end(), [&](const Seg &x, const Seg &y) {
-        const bool wx = x.lanes == K2_WIDE, wy = y.lanes == K2_WIDE;
-        return wx != wy ? wx : x.cost > y.cost;
-      });
+      for (size_t ri = 0; ri < gen_runs.size(); ri++)
+        segs.push_back(Seg{ri, (static_cast<double>(gen_runs[ri].maxq) / 16.0 + 8.0) * (gen_runs[ri].kmax + 2)});
+      std::stable_sort(segs.begin(), segs.end(), [&](const Seg &x, const Seg &y) { return x.cost > y.cost; });
       KernelArgs ka = a;
       hipStream_t st = stream_for_next();
       ka.slot_event = d_slots + n_k2; ka.n_slots = n_gen;
@@ -1849,25 +1842,14 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       size_t lds = 0; int blocks = 0;
       std::vector<GrpSeg> tab;
       for (const Seg &sg : segs) {
-        GenRun &run = gen_runs[sg.ri];
+        const GenRun &run = gen_runs[sg.ri];
         const GrpShape &sh = grp_sh[sg.ri];
         const long chains = static_cast<long>(run.count) * p.noChains;
-        const size_t fp_bytes = fp_bytes_of(run);
-        const size_t slice = grp_slice_bytes(run.kmax, 0, sh.ts);
         GrpSeg g{};
-        g.block0 = blocks; g.slot0 = run.first; g.n_slots = run.count; g.lanes = sg.lanes; g.kc = run.kc;
+        g.block0 = blocks; g.slot0 = run.first; g.n_slots = run.count; g.kc = run.kc;
         g.kstride = run.kmax; g.tstride = sh.ts;
-        if (run.wide) {
-          const size_t lds0 = align_up(fp_bytes + 4 * slice, 16);
-          g.red_off = static_cast<int32_t>(lds0);
-          lds = std::max(lds, lds0 + 96);
-          blocks += static_cast<int>(wide_setup(run, chains, st));
-          g.coop_tab = run.d_coop_tab; g.coop_mem = run.d_coop_mem;
-        } else {
-          const int cpw = 64 / sg.lanes;
-          lds = std::max(lds, fp_bytes + 4 * static_cast<size_t>(cpw) * slice);
-          blocks += static_cast<int>(((chains + cpw - 1) / cpw + 3) / 4);
-        }
+        lds = std::max(lds, fp_bytes_of(run) + 4 * 4 * static_cast<size_t>(grp_slice_bytes(run.kmax, 0, sh.ts)));
+        blocks += static_cast<int>(((chains + 3) / 4 + 3) / 4);
         tab.push_back(g);
         in_multi[sg.ri] = 2;
       }
