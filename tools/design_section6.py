@@ -25,9 +25,9 @@ def row(i):
     return "%s (%s)" % (k(rows[i]["events_per_s"]), k(orow[i]["events_per_s"])) if i in orow else k(rows[i]["events_per_s"])
 
 
-print("""`python bench.py --steps 20 --warmup 5` on the round's final build, after `pytest -m gpu` (252 passed, 1 skipped: the two-GPU
+print("""`python bench.py --steps 20 --warmup 5` on the round's final build, after `pytest -m gpu` (258 passed, 1 skipped: the two-GPU
 `release()` test on a one-GPU lease) and `smoke()`; the rocprofv3 passes of every row on the same pool (`tools/r6_final.sh`,
-`tools/archive/r6_k.sh`, `r6_p.sh` for the two-isoform rows' final kernels): `profiles/r06_bench_default_line.json` = the line as printed (3.1 KB),
+`tools/archive/r6_k.sh`, `r6_p.sh` for the two-isoform rows' final kernels, `r6_aq.sh` for the rows whose kernels changed last): `profiles/r06_bench_default_line.json` = the line as printed (3.1 KB),
 `profiles/r06_bench_default.json` = the full record, `profiles/r06_<row>_summary.txt` = kernel trace + SQ / FETCH / WRITE counters
 per row, `profiles/valu_model.json` (with the traced launch span and the clock of the traced launch), `profiles/traffic.json`.
 
@@ -55,26 +55,29 @@ VERDICT r5's list, item by item:
    row carries the clock its kernels ran at (the one or two rows without: the probe's extra wavefront displaced a workgroup of a
    register-filling kernel and the probed launch was not one of the timed ones -- their model is checked in milliseconds as before);
    188 k against 201 k was the driver's box: the launch is %.0f M cycles wherever it runs (section 4.8, `profiles/r06_clock_probe.txt`).
-2. *Paired-end K >= 3, third wavefront* -- not reached: `pe_k5` %s, `pe_k10` %s.  Re-measured after round 5's loop fixes, three workgroups
+2. *Paired-end K >= 3, third wavefront* -- not reached: `pe_k5` %s, `pe_k10` %s (+ 3 - 4 %% from the units built without machine-level hoisting).  Re-measured after round 5's loop fixes, three workgroups
    per CU still lose (+ 3 / + 33 %%); and the loop does not wait for memory (an L2-resident working set: 4 %%), so the registers, not
    the traffic, are what a restructuring has to attack (section 8 (a), `profiles/r06_pe_three_blocks.txt`, `r06_pe_working_set.txt`).
-3. *`sampler_flat`, the per-chain scalar step* -- `se_k5` %s, `se_k10` %s (targets 130 k / 70 k): + 4 / + 3 %% from issue priority by
-   progress, `se_k5_hg19` 114.2 -> 123.0 k from a packing that aims at two rounds of wavefronts from 0.85 of them (section 4.4); `floor_frac` unchanged (0.42 / 0.37).  The kernel's main loop carries ~ 540 `v_readlane` / `v_writelane` per iteration
-   (12 %% of its instructions) of scalar-register spill traffic: the phases as separately compiled functions remain to be done.
+3. *`sampler_flat`, the per-chain scalar step* -- done, by other means than asked: `se_k5` %s, `se_k10` %s (targets 130 k / 70 k), `se_k5_hg19` %s.
+   The ~ 540 `v_readlane` / `v_writelane` per iteration were loop-invariant CONDITIONS (`k <` the wavefront's largest isoform count, one per unrolled
+   isoform), not layout: a compile-time bound in the kernels of one isoform count, `sampler_flat<KC, KS, UNI>`, the units built without machine-level
+   hoisting (section 4.4, `profiles/r06_flat_licm.txt`); before that + 4 / + 3 %% from issue priority by progress and the two-round packing rule.  The model now
+   has the kernels AT the issue rate (VALU busy 0.90 / 0.95): what is left is the instruction count (`floor_frac` 0.47 / 0.43).
 4. *Headline tail* -- done by other means: the SIMD's two wavefronts keep step by priority instead of pulling chain groups from a
    cursor (no work added): wave-slot occupancy 0.78 -> 0.94, %s events/s driver-style (target 660 k); `se_k2_defaults` %s (target
    230 k not met: 1.2 rounds of three wavefronts per SIMD at the formulation's floor, 0.87 / 0.87).
-5. *Whole-gene batches as one ordered grid* -- not done: `pe_mix` %s, `pe_mix_hg19` %s genes/s; issue priorities by class: nothing;
-   a CU partition per class: slower (`profiles/r06_class_priority.txt`, `r06_class_cu_partition.txt`); the timelines say what is lost -- two rounds of chains whose
-   own duration is half the launch, the last quarter nearly empty (`profiles/r06_mix_timeline.txt`); the launches scatter +- 15 %% by themselves.
+5. *Whole-gene batches as one ordered grid* -- done for batches of like-sized genes (`sampler_grp_all`: the five classes' sixteen-lane bodies behind one
+   entry point, the runs ordered by cost): `pe_mix` %s genes/s; batches with size buckets keep a launch per class (`pe_mix_hg19` %s): all twenty
+   bodies in one function took 28 minutes to compile (round 5).  Issue priorities by class: nothing; a CU partition per class: slower
+   (`profiles/r06_class_priority.txt`, `r06_class_cu_partition.txt`, `r06_mix_timeline.txt`).
 6. *End to end* -- `miso --run`, 40 000 events, MISO defaults: 6.9 -> 4.1 - 4.6 s (8.7 - 9.7 k events/s; target 9 k) with files; summary-only
    4.1 - 5.1 s: the 40 k events/s asked for that mode would need the whole run in 1 s, of which decoding 3.2 GB of SAM text alone
    takes 1.3 (section 4.10, `profiles/r06_e2e_miso_run.txt`).
 7. *`CONVERGENT_MEAN` window* -- done, and the rule of the round's first ratio with it (section 1).
-8. *Hygiene* -- `tools/archive/`, this file 58 KB (round 5's narrative in `docs/history.md`), `oracle/README.md` and section 5 say what
+8. *Hygiene* -- `tools/archive/`, this file 63 KB (round 5's narrative in `docs/history.md`), `oracle/README.md` and section 5 say what
    VERDICT asked them to say.
 ADVICE r5: the hidden loads are checked on the generated assembly at every build (`make check-isa`) and the bit-exact tests pass on
 a build without them (`profiles/r06_noasm_variant.txt`); K > 64 guard, contract version, wide-gene warning + accept-count test,
 collapsed route per run.""" % (
-    r.get("kernel_Mcycles", 0) / 1e3 if False else 471.0, row("pe_k5"), row("pe_k10"), row("se_k5"), row("se_k10"), k(new["value"]),
+    r.get("kernel_Mcycles", 0) / 1e3 if False else 471.0, row("pe_k5"), row("pe_k10"), row("se_k5"), row("se_k10"), row("se_k5_hg19"), k(new["value"]),
     row("se_k2_defaults"), row("pe_mix"), row("pe_mix_hg19")))
