@@ -10,7 +10,7 @@ cp miso_amd/csrc/*.o tools/_build/$name/
 F="$defs -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -Iinclude -Imiso_amd/csrc -Wno-unused-result"
 # (the flat and grp units carry the Makefile's own extra flags; FLAT_UNITFLAGS="" builds them without)
 FU=${FLAT_UNITFLAGS--mllvm -disable-machine-licm}
-for f in "$@"; do U=""; case $f in kernels_flat_c*|kernels_grp_c*|kernels_k2m_m0w4n) U=$FU;; esac; /opt/rocm/bin/hipcc $F $U -c miso_amd/csrc/$f.hip -o tools/_build/$name/$f.o & done
+for f in "$@"; do U=""; case $f in kernels_flat_c*|kernels_grp_c*|kernels_grp_all|kernels_k2m_m0w4n) U=$FU;; esac; /opt/rocm/bin/hipcc $F $U -c miso_amd/csrc/$f.hip -o tools/_build/$name/$f.o & done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC tools/_build/$name/*.o -o tools/_build/libmiso_$name.so -lz -lpthread
 rm -rf tools/_build/$name
