@@ -1553,14 +1553,17 @@ __global__ __launch_bounds__(256, MISO_GRP_PE_BLOCKS) void sampler_grp_multi(con
   grp_lanes<KC>(b, blk, a.seg_lanes[s]);
 }
 
+// Paired-end, EVERY isoform-count class of a batch of like-sized genes (sixteen lanes per chain everywhere) in one launch
+// (runtime.hip; VERDICT r5 item 5: a whole-gene batch as one ordered grid).  The segments (a.grp_segs, in global memory: a run-time
+// index into the by-value arguments would cost a scratch copy of them) are the classes' runs ordered by what a workgroup of
+// theirs costs: the hardware starts workgroups in index order, so the 17 - 20 isoform genes all start in the first round of
+// resident wavefronts and the three-isoform genes fill the slots they free -- instead of five kernels in five hardware queues
+// whose workgroups the dispatcher interleaves as it likes (profiles/r06_mix_timeline.txt).
+// Sixteen lanes only.  The other kinds of run (32 lanes, a wavefront, a workgroup or several per chain: the size buckets of real
+// pair counts) were built the same way, a kernel per kind with every class's runs cut into pieces ordered by cost: 825 -> 1010 ms
+// on hg19-like pair counts, with whole runs or pieces alike -- the launch per class (sampler_grp_multi) stays there; and all
+// twenty bodies in ONE function took 28 minutes to compile and spilled 802 registers (round 5).
 #ifdef MISO_GRP_ALL_CLASSES
-// Paired-end, EVERY isoform-count class of the batch with its size buckets in one launch (runtime.hip; VERDICT r5 item 5: a
-// whole-gene batch as one ordered grid).  The segments (a.grp_segs, in global memory: a run-time index into the by-value
-// arguments would cost a scratch copy of them) are ordered by what a workgroup of theirs costs, the chains on several
-// workgroups in front: the hardware starts workgroups in index order, so the 17 - 20 isoform genes all start in the first round
-// of resident wavefronts and the three-isoform genes fill the slots they free -- instead of five kernels in five hardware
-// queues whose workgroups the dispatcher interleaves as it likes (profiles/r06_mix_timeline.txt: the last quarter of such a
-// launch ran nearly empty).
 __global__ __launch_bounds__(256, MISO_GRP_PE_BLOCKS) void sampler_grp_all(const KernelArgs a) {
   int s = 0;
   while (s + 1 < a.n_grp_segs && static_cast<int>(blockIdx.x) >= a.grp_segs[s + 1].block0) s++;
@@ -1568,18 +1571,13 @@ __global__ __launch_bounds__(256, MISO_GRP_PE_BLOCKS) void sampler_grp_all(const
   // (the table is read by vector loads -- nothing tells the compiler that it is not written meanwhile --: every field is made a
   // scalar by hand, or the slice layout and the loop bounds of the body would count as different from lane to lane)
   const GrpSeg *gp = a.grp_segs + s;
-  GrpSeg g{};
-  g.block0 = __builtin_amdgcn_readfirstlane(gp->block0); g.slot0 = __builtin_amdgcn_readfirstlane(gp->slot0);
-  g.n_slots = __builtin_amdgcn_readfirstlane(gp->n_slots); g.kc = __builtin_amdgcn_readfirstlane(gp->kc);
-  g.kstride = __builtin_amdgcn_readfirstlane(gp->kstride); g.tstride = __builtin_amdgcn_readfirstlane(gp->tstride);
+  const int block0 = __builtin_amdgcn_readfirstlane(gp->block0), kc = __builtin_amdgcn_readfirstlane(gp->kc);
   KernelArgs b = a;
-  b.slot_event = a.slot_event + g.slot0;
-  b.n_slots = g.n_slots;
-  b.kstride = g.kstride; b.tstride = g.tstride;
-  const unsigned blk = blockIdx.x - static_cast<unsigned>(g.block0);
-  // (sixteen lanes per chain only: with the four kinds of segment of all five classes -- twenty bodies in one function -- the
-  // unit took 28 minutes to compile and spilled 802 registers, round 5)
-  switch (g.kc) {
+  b.slot_event = a.slot_event + __builtin_amdgcn_readfirstlane(gp->slot0);
+  b.n_slots = __builtin_amdgcn_readfirstlane(gp->n_slots);
+  b.kstride = __builtin_amdgcn_readfirstlane(gp->kstride); b.tstride = __builtin_amdgcn_readfirstlane(gp->tstride);
+  const unsigned blk = blockIdx.x - static_cast<unsigned>(block0);
+  switch (kc) {
   case 4: grp_body<16, true, 4, false>(b, blk); break;
   case 8: grp_body<16, true, 8, false>(b, blk); break;
   case 12: grp_body<16, true, 12, false>(b, blk); break;
