@@ -1830,11 +1830,29 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       two_classes |= run.kc != gen_runs[0].kc;
     }
     if (all_ok && two_classes) {
-      struct Seg { size_t ri; double cost; };
+      struct Seg { size_t ri; int e0, e1; double cost; };
       std::vector<Seg> segs;
-      for (size_t ri = 0; ri < gen_runs.size(); ri++)
-        segs.push_back(Seg{ri, (static_cast<double>(gen_runs[ri].maxq) / 16.0 + 8.0) * (gen_runs[ri].kmax + 2)});
+      // (a segment per isoform count, so that no wavefront carries two -- see sampler_grp_multi below; MISO_PE_ALL_ORDER=0: a segment per
+      // run, 2: heaviest / lightest alternating, 3: lightest first (A/B: 777 / 705 / 767 / 851 ms for 0 / 1 / 2 / 3))
+      const int order = std::getenv("MISO_PE_ALL_ORDER") ? std::atoi(std::getenv("MISO_PE_ALL_ORDER")) : 1;
+      for (size_t ri = 0; ri < gen_runs.size(); ri++) {
+        const GenRun &run = gen_runs[ri];
+        if (order == 0) { segs.push_back(Seg{ri, 0, run.count, (static_cast<double>(run.maxq) / 16.0 + 8.0) * (run.kmax + 2)}); continue; }
+        auto cost_at = [&](int e) {
+          const PackedEvent &ev = events[h_slots[n_k2 + run.first + e]];
+          return (static_cast<double>((ev.n_draw + 3) / 4) / 16.0 + 8.0) * (ev.K + 2);
+        };
+        int e0 = 0;   // pieces: one per isoform count
+        for (int e = 1; e <= run.count; e++)
+          if (e == run.count || events[h_slots[n_k2 + run.first + e]].K != events[h_slots[n_k2 + run.first + e0]].K) { segs.push_back(Seg{ri, e0, e, cost_at(e0)}); e0 = e; }
+      }
       std::stable_sort(segs.begin(), segs.end(), [&](const Seg &x, const Seg &y) { return x.cost > y.cost; });
+      if (order == 2) {   // heaviest, lightest, second heaviest, second lightest, ...
+        std::vector<Seg> t;
+        for (size_t i = 0, j = segs.size(); i < j;) { t.push_back(segs[i++]); if (i < j) t.push_back(segs[--j]); }
+        segs = t;
+      }
+      if (order == 3) std::reverse(segs.begin(), segs.end());   // lightest first
       KernelArgs ka = a;
       hipStream_t st = stream_for_next();
       ka.slot_event = d_slots + n_k2; ka.n_slots = n_gen;
@@ -1844,9 +1862,9 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       for (const Seg &sg : segs) {
         const GenRun &run = gen_runs[sg.ri];
         const GrpShape &sh = grp_sh[sg.ri];
-        const long chains = static_cast<long>(run.count) * p.noChains;
+        const long chains = static_cast<long>(sg.e1 - sg.e0) * p.noChains;
         GrpSeg g{};
-        g.block0 = blocks; g.slot0 = run.first; g.n_slots = run.count; g.kc = run.kc;
+        g.block0 = blocks; g.slot0 = run.first + sg.e0; g.n_slots = sg.e1 - sg.e0; g.kc = run.kc;
         g.kstride = run.kmax; g.tstride = sh.ts;
         lds = std::max(lds, fp_bytes_of(run) + 4 * 4 * static_cast<size_t>(grp_slice_bytes(run.kmax, 0, sh.ts)));
         blocks += static_cast<int>(((chains + 3) / 4 + 3) / 4);
@@ -1858,7 +1876,7 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       if (lds > LDS_MAX) MISO_FAIL(MISO_EINTERNAL, "sampler_grp_all: a segment's slices exceed the workgroup's LDS");
       // (uploaded when it changed: the batch's first launch, or another upload's events; the launch that read the old one has
       // been waited for by then)
-      constexpr size_t GRP_SEGS_CAP = 128;
+      constexpr size_t GRP_SEGS_CAP = 256;
       if (tab.size() > GRP_SEGS_CAP) MISO_FAIL(MISO_EINTERNAL, "sampler_grp_all: too many segments");
       if (!d_grp_segs) HIP_OK(hipMalloc(reinterpret_cast<void **>(&d_grp_segs), GRP_SEGS_CAP * sizeof(GrpSeg)));
       if (tab.size() != h_grp_segs.size() || std::memcmp(tab.data(), h_grp_segs.data(), tab.size() * sizeof(GrpSeg)) != 0) {
@@ -1876,12 +1894,17 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   // When: the batch's launches outnumber the hardware queues (a whole-gene mix with real read counts: ~20 launches, 243 ->
   // 180 ms per 1500 iterations; a single class's three or four buckets run 3 % faster side by side: 149 vs 155 ms at K = 5;
   // profiles/r03_pe_buckets.txt).  MISO_PE_MULTI=1 forces (tests).
+  // ... or some run on 16 / 32 lanes holds several isoform counts: the multi kernel's segments keep them in wavefronts of their own
+  bool any_mixed = false;
+  for (size_t ri = 0; ri < gen_runs.size(); ri++)
+    any_mixed |= p.paired && !gen_runs[ri].wide && (grp_G[ri] == 16 || grp_G[ri] == 32) && fp_rows(gen_runs[ri]) && flat_nc[ri] == 0 && gen_runs[ri].kmin != gen_runs[ri].kmax;
   const bool multi_on = p.paired && !lane_gen && std::getenv("MISO_NO_PE_MULTI") == nullptr && std::getenv("MISO_GENERAL_LANES") == nullptr &&
-                        (std::getenv("MISO_PE_MULTI") != nullptr || gen_runs.size() + (n_k2 > 0 ? 1 : 0) > 8);
+                        (std::getenv("MISO_PE_MULTI") != nullptr || gen_runs.size() + (n_k2 > 0 ? 1 : 0) > 8 || any_mixed);
   for (size_t r0 = 0; multi_on && !all_launched && r0 < gen_runs.size();) {
     size_t r1 = r0 + 1;
     while (r1 < gen_runs.size() && gen_runs[r1].kc == gen_runs[r0].kc) r1++;
-    bool ok = r1 - r0 >= 2 && r1 - r0 <= static_cast<size_t>(K2_MAX_SEGS);
+    bool ok = (r1 - r0 >= 2 || (r1 - r0 == 1 && gen_runs[r0].kmin != gen_runs[r0].kmax && (grp_G[r0] == 16 || grp_G[r0] == 32))) &&
+              r1 - r0 <= static_cast<size_t>(K2_MAX_SEGS);
     GenRun m;
     m.first = gen_runs[r0].first; m.count = 0; m.kc = gen_runs[r0].kc;
     for (size_t ri = r0; ri < r1 && ok; ri++) {
@@ -1904,22 +1927,42 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       ka.kstride = m.kmax; ka.cstride = 0; ka.tstride = msh.ts;
       ka.pe_dense = 1; ka.pe_force_exact = std::getenv("MISO_PE_FORCE_EXACT") != nullptr;
       size_t lds = 0; int blocks = 0, segs = 0;
-      for (size_t ri = r0; ri < r1; ri++, segs++) {
+      // A run on 16 or 32 lanes per chain is one segment PER ISOFORM COUNT (the run's events are ordered by it): every segment starts
+      // a new workgroup, so no wavefront carries chains of two isoform counts -- such a wavefront runs both counts' read loops one after
+      // the other (kernels_grp.inl pe_fast), twice a chain's own time, and with the class's longest chains that was the launch's length
+      // (round 6, profiles/r06_mix_timeline.txt).  As far as the segments suffice; MISO_PE_NO_KSPLIT=1: a segment per run (A/B).
+      auto k_pieces = [&](const GenRun &run) {
+        std::vector<int> cuts{0};
+        for (int e = 1; e < run.count; e++)
+          if (events[h_slots[n_k2 + run.first + e]].K != events[h_slots[n_k2 + run.first + e - 1]].K) cuts.push_back(e);
+        cuts.push_back(run.count);
+        return cuts;
+      };
+      size_t want_segs = 0;
+      for (size_t ri = r0; ri < r1; ri++)
+        want_segs += (gen_runs[ri].wide || grp_G[ri] == 64) ? 1 : k_pieces(gen_runs[ri]).size() - 1;
+      const bool ksplit = want_segs <= static_cast<size_t>(K2_MAX_SEGS) && std::getenv("MISO_PE_NO_KSPLIT") == nullptr;
+      for (size_t ri = r0; ri < r1; ri++) {
         GenRun &run = gen_runs[ri];
         const long chains = static_cast<long>(run.count) * p.noChains;
-        ka.seg_slot[segs] = run.first - m.first; ka.seg_block[segs] = blocks;
         if (run.wide) {
+          ka.seg_slot[segs] = run.first - m.first; ka.seg_block[segs] = blocks;
           const size_t lds0 = align_up(fp_bytes + 4 * slice, 16);
           ka.red_off = static_cast<int32_t>(lds0);
           lds = std::max(lds, lds0 + 96);
           blocks += static_cast<int>(wide_setup(run, chains, st));
           ka.coop_tab = run.d_coop_tab; ka.coop_mem = run.d_coop_mem;
-          ka.seg_lanes[segs] = K2_WIDE;
+          ka.seg_lanes[segs++] = K2_WIDE;
         } else {
           const int G = grp_G[ri], cpw = 64 / G;
           lds = std::max(lds, fp_bytes + 4 * static_cast<size_t>(cpw) * slice);
-          blocks += static_cast<int>(((chains + cpw - 1) / cpw + 3) / 4);
-          ka.seg_lanes[segs] = G;
+          const std::vector<int> cuts = (ksplit && G != 64) ? k_pieces(run) : std::vector<int>{0, run.count};
+          for (size_t c = 0; c + 1 < cuts.size(); c++) {
+            const long pc = static_cast<long>(cuts[c + 1] - cuts[c]) * p.noChains;
+            ka.seg_slot[segs] = run.first - m.first + cuts[c]; ka.seg_block[segs] = blocks;
+            blocks += static_cast<int>(((pc + cpw - 1) / cpw + 3) / 4);
+            ka.seg_lanes[segs++] = G;
+          }
         }
         in_multi[ri] = 1;
       }
