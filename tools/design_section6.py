@@ -67,9 +67,10 @@ VERDICT r5's list, item by item:
    cursor (no work added): wave-slot occupancy 0.78 -> 0.94, %s events/s driver-style (target 660 k); `se_k2_defaults` %s (target
    230 k not met: 1.2 rounds of three wavefronts per SIMD at the formulation's floor, 0.87 / 0.87).
 5. *Whole-gene batches as one ordered grid* -- done for batches of like-sized genes (`sampler_grp_all`: the five classes' sixteen-lane bodies behind one
-   entry point, the runs ordered by cost): `pe_mix` %s genes/s; batches with size buckets keep a launch per class (`pe_mix_hg19` %s): all twenty
-   bodies in one function took 28 minutes to compile (round 5).  Issue priorities by class: nothing; a CU partition per class: slower
-   (`profiles/r06_class_priority.txt`, `r06_class_cu_partition.txt`, `r06_mix_timeline.txt`).
+   entry point), and what the order experiments found on the way did more: a wavefront with chains of TWO isoform counts ran both counts' read loops one after
+   the other, and at the boundary 20 | 19 of the longest class that one wavefront was the launch's length; a segment (a new workgroup) per isoform count:
+   `pe_mix` %s, `pe_mix_hg19` %s genes/s.  For batches with size buckets a kernel per kind of run, and a cost-ordered grid of the sixteen-lane runs,
+   were built and measured slower (825 -> 1010 / 1033 ms): they keep a launch per class (section 4.3, `profiles/r06_mix_timeline.txt`).
 6. *End to end* -- `miso --run`, 40 000 events, MISO defaults: 6.9 -> 4.1 - 4.6 s (8.7 - 9.7 k events/s; target 9 k) with files; summary-only
    4.1 - 5.1 s: the 40 k events/s asked for that mode would need the whole run in 1 s, of which decoding 3.2 GB of SAM text alone
    takes 1.3 (section 4.10, `profiles/r06_e2e_miso_run.txt`).
