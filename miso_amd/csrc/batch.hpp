@@ -100,6 +100,7 @@ struct miso_batch {
     int maxcls = 0;               // most drawing-read classes (single-end)
     bool nocls = false;           // some single-end event has no class table (> MAX_DRAW_CLASSES classes)
     bool dense = true;            // paired-end: every event has dense quad records (pe_dense)
+    bool small = false;           // paired-end size bucket: genes of few pairs in a batch of several classes -- eight lanes per chain (runtime.hip upload)
     int force_G = 0;              // paired-end size bucket: at least this many lanes per chain (events several times the class's mean size)
     bool wide = false;            // paired-end size bucket: one chain per workgroup (sampler_grp<64, true, KC, true>)
     bool wave64 = false;          // paired-end size bucket: one chain per wavefront (sampler_grp<64, true, KC>)

@@ -144,6 +144,7 @@ struct KernelArgs {
   int32_t seg_block[K2_MAX_SEGS + 1];
   int32_t seg_slot[K2_MAX_SEGS + 1];
   int32_t seg_lanes[K2_MAX_SEGS];
+  int32_t seg_ts[K2_MAX_SEGS];   // sampler_grp_multi: the segment's tstride (eight chains of a wavefront keep their score tables in global memory)
 };
 
 #ifdef __HIPCC__

@@ -1538,6 +1538,7 @@ __device__ __forceinline__ void grp_lanes(const KernelArgs &b, unsigned blk, int
   case K2_WIDE: grp_body<64, true, KC, true>(b, blk); break;
   case 64: grp_body<64, true, KC, false>(b, blk); break;
   case 32: grp_body<32, true, KC, false>(b, blk); break;
+  case 8: grp_body<8, true, KC, false>(b, blk); break;   // the class's small genes (round 6)
   default: grp_body<16, true, KC, false>(b, blk); break;
   }
 }
@@ -1549,6 +1550,7 @@ __global__ __launch_bounds__(256, MISO_GRP_PE_BLOCKS) void sampler_grp_multi(con
   KernelArgs b = a;
   b.slot_event = a.slot_event + a.seg_slot[s];
   b.n_slots = a.seg_slot[s + 1] - a.seg_slot[s];
+  b.tstride = a.seg_ts[s];
   const unsigned blk = blockIdx.x - static_cast<unsigned>(a.seg_block[s]);
   grp_lanes<KC>(b, blk, a.seg_lanes[s]);
 }

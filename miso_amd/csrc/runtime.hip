@@ -495,6 +495,18 @@ void miso_batch::upload(int dev) {
       } else if (can_wide && need > t_wave && nq >= 128) bucket[i] = 2;
       else if (need > t_32 && nq >= 64) bucket[i] = 1;
     }
+    // (round 6) ... and the SMALL genes of a batch of several classes: eight lanes per chain -- a gene of a hundred pairs is all
+    // scalar step, which eight chains of a wavefront share instead of four (16 384 genes of 3 - 8 isoforms x 100 / 250 / 500 pairs:
+    // 198.5 -> 147.4, 237.3 -> 190.3, 306.2 -> 291.8 ms; profiles/r06_small_genes.txt).  MISO_PE_T_SMALL: drawing quads up to which
+    // (0: none; experiments, tests).
+    const int t_small = std::getenv("MISO_PE_T_SMALL") ? std::atoi(std::getenv("MISO_PE_T_SMALL")) : 96;
+    bool classes2 = false;
+    for (int i : gen) classes2 |= kc_of(events[i].K) != kc_of(events[gen[0]].K);
+    if (classes2 && t_small > 0 && dense_ok)
+      for (int i : gen) {
+        const PackedEvent &e = events[i];
+        if (bucket[i] == 0 && !e.draw_dense.empty() && e.K >= 3 && e.K <= PE_DENSE_KMAX && (e.n_draw + 3) / 4 <= t_small) bucket[i] = -1;
+      }
   }
   std::stable_sort(gen.begin(), gen.end(), [&](int x, int y) {
     const int kx = kc_of(events[x].K), ky = kc_of(events[y].K);
@@ -505,8 +517,8 @@ void miso_batch::upload(int dev) {
   for (size_t j = 0; j < gen.size(); j++) {
     const PackedEvent &e = events[gen[j]];
     const int kc = kc_of(e.K), bk = bucket[gen[j]];
-    if (gen_runs.empty() || gen_runs.back().kc != kc || (gen_runs.back().wide ? 3 : (gen_runs.back().wave64 ? 2 : (gen_runs.back().force_G ? 1 : 0))) != bk) {
-      GenRun r; r.first = static_cast<int>(j); r.kc = kc; r.wide = bk == 3; r.wave64 = bk == 2; r.force_G = bk == 1 ? 32 : (bk == 2 ? 64 : 0);
+    if (gen_runs.empty() || gen_runs.back().kc != kc || (gen_runs.back().wide ? 3 : (gen_runs.back().wave64 ? 2 : (gen_runs.back().force_G ? 1 : (gen_runs.back().small ? -1 : 0)))) != bk) {
+      GenRun r; r.first = static_cast<int>(j); r.kc = kc; r.wide = bk == 3; r.wave64 = bk == 2; r.force_G = bk == 1 ? 32 : (bk == 2 ? 64 : 0); r.small = bk == -1;
       gen_runs.push_back(r);
     }
     GenRun &r = gen_runs.back();
@@ -1249,6 +1261,11 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       }
     }
     if (run.force_G && G < run.force_G && std::getenv("MISO_GENERAL_LANES") == nullptr) G = run.force_G;   // size bucket (upload)
+    if (run.small && p.paired && std::getenv("MISO_GENERAL_LANES") == nullptr && std::getenv("MISO_GENERAL_LANES_BY_CLASS") == nullptr) {   // the small genes' bucket: eight chains per wavefront, score tables in global memory
+      GrpShape sh8 = sh;
+      sh8.ts = 0;
+      if (grp_fits(run, sh8, 8)) { sh = grp_sh[ri] = sh8; G = 8; }
+    }
     // a forced (or odd) choice never exceeds the LDS budget: fewer chains per wavefront instead
     while (G < 64 && !grp_fits(run, sh, G)) G = (G < 2) ? 2 : ((G & (G - 1)) ? 64 : G * 2);
     grp_G[ri] = G;
@@ -1897,13 +1914,13 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
   // ... or some run on 16 / 32 lanes holds several isoform counts: the multi kernel's segments keep them in wavefronts of their own
   bool any_mixed = false;
   for (size_t ri = 0; ri < gen_runs.size(); ri++)
-    any_mixed |= p.paired && !gen_runs[ri].wide && (grp_G[ri] == 16 || grp_G[ri] == 32) && fp_rows(gen_runs[ri]) && flat_nc[ri] == 0 && gen_runs[ri].kmin != gen_runs[ri].kmax;
+    any_mixed |= p.paired && !gen_runs[ri].wide && (grp_G[ri] == 16 || grp_G[ri] == 32 || (grp_G[ri] == 8 && gen_runs[ri].small)) && fp_rows(gen_runs[ri]) && flat_nc[ri] == 0 && gen_runs[ri].kmin != gen_runs[ri].kmax;
   const bool multi_on = p.paired && !lane_gen && std::getenv("MISO_NO_PE_MULTI") == nullptr && std::getenv("MISO_GENERAL_LANES") == nullptr &&
                         (std::getenv("MISO_PE_MULTI") != nullptr || gen_runs.size() + (n_k2 > 0 ? 1 : 0) > 8 || any_mixed);
   for (size_t r0 = 0; multi_on && !all_launched && r0 < gen_runs.size();) {
     size_t r1 = r0 + 1;
     while (r1 < gen_runs.size() && gen_runs[r1].kc == gen_runs[r0].kc) r1++;
-    bool ok = (r1 - r0 >= 2 || (r1 - r0 == 1 && gen_runs[r0].kmin != gen_runs[r0].kmax && (grp_G[r0] == 16 || grp_G[r0] == 32))) &&
+    bool ok = (r1 - r0 >= 2 || (r1 - r0 == 1 && gen_runs[r0].kmin != gen_runs[r0].kmax && (grp_G[r0] == 16 || grp_G[r0] == 32 || (grp_G[r0] == 8 && gen_runs[r0].small)))) &&
               r1 - r0 <= static_cast<size_t>(K2_MAX_SEGS);
     GenRun m;
     m.first = gen_runs[r0].first; m.count = 0; m.kc = gen_runs[r0].kc;
@@ -1911,15 +1928,17 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
       const GenRun &run = gen_runs[ri];
       const int G = grp_G[ri];
       ok = flat_nc[ri] == 0 && fp_rows(run) && run.first == m.first + m.count &&
-           (run.wide || G == 16 || G == 32 || (G == 64 && run.wave64));
+           (run.wide || G == 16 || G == 32 || (G == 64 && run.wave64) || (G == 8 && run.small));
       m.count += run.count; m.kmax = std::max(m.kmax, run.kmax); m.kmin = std::min(m.kmin, run.kmin);
       m.maxq = std::max(m.maxq, run.maxq);
     }
     const GrpShape msh = ok ? grp_shape(m) : GrpShape{0, 0};
     const size_t fp_bytes = fp_bytes_of(m);
     const size_t slice = ok ? grp_slice_bytes(m.kmax, 0, msh.ts) : 0;
+    // (the small genes' segment: eight chains per wavefront, their score tables in global memory -- a tstride of its own)
+    const size_t slice8 = ok ? grp_slice_bytes(m.kmax, 0, 0) : 0;
     for (size_t ri = r0; ri < r1 && ok; ri++)
-      if (!gen_runs[ri].wide) ok = fp_bytes + 4 * static_cast<size_t>(64 / grp_G[ri]) * slice <= LDS_MAX;
+      if (!gen_runs[ri].wide) ok = fp_bytes + 4 * static_cast<size_t>(64 / grp_G[ri]) * (grp_G[ri] == 8 ? slice8 : slice) <= LDS_MAX;
     if (ok) {
       KernelArgs ka = a;
       hipStream_t st = stream_for_next();
@@ -1952,15 +1971,17 @@ void miso_batch::launch(uint64_t seed, uint32_t first_event_id) {
           lds = std::max(lds, lds0 + 96);
           blocks += static_cast<int>(wide_setup(run, chains, st));
           ka.coop_tab = run.d_coop_tab; ka.coop_mem = run.d_coop_mem;
+          ka.seg_ts[segs] = msh.ts;
           ka.seg_lanes[segs++] = K2_WIDE;
         } else {
           const int G = grp_G[ri], cpw = 64 / G;
-          lds = std::max(lds, fp_bytes + 4 * static_cast<size_t>(cpw) * slice);
+          lds = std::max(lds, fp_bytes + 4 * static_cast<size_t>(cpw) * (G == 8 ? slice8 : slice));
           const std::vector<int> cuts = (ksplit && G != 64) ? k_pieces(run) : std::vector<int>{0, run.count};
           for (size_t c = 0; c + 1 < cuts.size(); c++) {
             const long pc = static_cast<long>(cuts[c + 1] - cuts[c]) * p.noChains;
             ka.seg_slot[segs] = run.first - m.first + cuts[c]; ka.seg_block[segs] = blocks;
             blocks += static_cast<int>(((pc + cpw - 1) / cpw + 3) / 4);
+            ka.seg_ts[segs] = G == 8 ? 0 : msh.ts;
             ka.seg_lanes[segs++] = G;
           }
         }

@@ -283,6 +283,47 @@ def test_whole_gene_batch_of_several_classes_in_one_launch_bit_exact(orc):
         assert np.array_equal(b.result(i).samples, r.samples, equal_nan=True), i
 
 
+def test_small_genes_of_a_whole_gene_batch_on_eight_lanes_bit_exact(orc):
+    """runtime.hip upload, bucket -1: in a paired-end batch of several isoform-count classes the genes of few pairs (up to
+    MISO_PE_T_SMALL drawing quads, default 96) run on EIGHT lanes per chain, eight chains of a wavefront sharing the scalar step,
+    their score tables in global memory -- a segment of the class's sampler_grp_multi launch with a tstride of its own.  Against
+    the oracle with the bucket on (two thresholds), off, and with every read through the exact scan."""
+    counts = [3, 18, 5, 10, 14, 4, 7, 12, 20, 9, 3, 5, 16, 8, 11, 6, 5, 5, 9, 13]
+    sizes = [30, 60, 200, 5, 120, 1800, 0, 60, 700, 90, 90, 200, 35, 400, 150, 80, 40, 45, 55, 65]
+    evs = []
+    for j, (K, n) in enumerate(zip(counts, sizes)):
+        exons, isoforms = se_gene(K, exlen=500 + 11 * j, gap=300)
+        g = orc.gene(flat(exons), isoforms)
+        orc.rng_seed(7300 + j)
+        rc, _, pos, cig = orc.simulate_paired_reads(g, expr_for(K), max(n, 1), 36, 250.0, 900.0)
+        assert rc == 0
+        evs.append((exons, isoforms, g, pos[:2 * n], cig[:2 * n]))
+    kw = dict(iters=40, burn=10, lag=2, chains=2)
+    cpu = []
+    for i, (exons, isoforms, g, pos, cig) in enumerate(evs):
+        r = orc.miso_paired(g, pos, cig, 36, 250.0, 900.0, mode=OrcLib.COUNTER, seed=29, event_id=500 + i, trace=True, **kw)
+        assert r.rc == 0
+        cpu.append(r)
+    names = []
+    for v in (dict(), dict(MISO_PE_T_SMALL="20"), dict(MISO_PE_T_SMALL="0"), dict(MISO_PE_FORCE_EXACT="1"), dict(MISO_NO_PE_MULTI="1")):
+        with _env(**v):
+            b = miso_amd.Batch(36, paired=True, mean=250.0, var=900.0, device_match=True, **kw)
+            for exons, isoforms, g, pos, cig in evs:
+                b.add_event(miso_amd.Gene(exons, isoforms), pos, cig)
+            b.run(seed=29, first_event_id=500)
+            names.append(b.last_kernels())
+            for i, r in enumerate(cpu):
+                gpu = b.result(i)
+                where = (v, counts[i], sizes[i], b.last_kernels())
+                assert (gpu.counts_hash == r.trace["counts_hash"]).all(), where
+                assert np.array_equal(gpu.samples, r.samples, equal_nan=True), where
+                assert np.array_equal(gpu.loglik, r.loglik, equal_nan=True), where
+                assert (gpu.assignment == r.assignment).all(), where
+                assert gpu.rundata.noAccepted == r.accepted, where
+    assert "sampler_grp_multi<" in names[0], names
+    assert "sampler_grp<8, true, " in names[4], names   # without the multi kernel the small genes' runs are eight-lane launches of their own
+
+
 def _worker(paired, K, rounds, **env):
     import subprocess
     import sys

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Kernel time of an arbitrary single-class shape (not only the bench matrix rows):
-    python tools/archive/r6_shape.py K=6 K=7,reads=hg19 K=8,paired=1 [--reps 2] [--events 40000]"""
+    python tools/archive/r6_shape.py K=6 K=7,reads=hg19 K=8,paired=1 K=3-20,paired=1,reads=250 [--reps 2] [--events 40000]"""
 import argparse
 import os
 import sys
@@ -23,7 +23,12 @@ def main():
         ov = {}
         for kv in spec.split(","):
             k, v = kv.split("=")
-            ov[k] = v if k == "reads" else (bool(int(v)) if k == "paired" else int(v))
+            if k == "K" and "-" in v:
+                ov[k] = tuple(int(x) for x in v.split("-"))   # K=3-20: a whole-gene mix
+            elif k == "reads":
+                ov[k] = v if v == "hg19" else int(v)
+            else:
+                ov[k] = bool(int(v)) if k == "paired" else int(v)
         b = bench.build(0, a.events, dict(bench.BASE_SHAPE, **ov))
         b.upload(0)
         ms = []
