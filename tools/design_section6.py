@@ -25,7 +25,7 @@ def row(i):
     return "%s (%s)" % (k(rows[i]["events_per_s"]), k(orow[i]["events_per_s"])) if i in orow else k(rows[i]["events_per_s"])
 
 
-print("""`python bench.py --steps 20 --warmup 5` on the round's final build, after `pytest -m gpu` (258 passed, 1 skipped: the two-GPU
+print("""`python bench.py --steps 20 --warmup 5` on the round's final build, after `pytest -m gpu` (259 passed, 1 skipped: the two-GPU
 `release()` test on a one-GPU lease) and `smoke()`; the rocprofv3 passes of every row on the same pool (`tools/r6_final.sh`,
 `tools/archive/r6_k.sh`, `r6_p.sh` for the two-isoform rows' final kernels, `r6_aq.sh` for the rows whose kernels changed last): `profiles/r06_bench_default_line.json` = the line as printed (3.1 KB),
 `profiles/r06_bench_default.json` = the full record, `profiles/r06_<row>_summary.txt` = kernel trace + SQ / FETCH / WRITE counters
