@@ -440,11 +440,16 @@ class Batch:
         """{"kernels": [{name, waves, trips, iterations, chains, words}], "uniforms": Philox words the
         read loops consume per launch} of the last launch (miso_batch_launch_stats)."""
         n = C.c_int(0)
-        arr = (KernelStat * 16)()
-        check(lib().miso_batch_launch_stats(self.handle, arr, 16, C.byref(n)))
+        cap = 16
+        while True:   # (one record per run: a whole-gene batch with size buckets has two dozen; the call reports how many there are)
+            arr = (KernelStat * cap)()
+            check(lib().miso_batch_launch_stats(self.handle, arr, cap, C.byref(n)))
+            if n.value <= cap:
+                break
+            cap = n.value
         ks = [{"name": arr[i].name.decode(), "waves": arr[i].waves, "trips": arr[i].trips,
                "iterations": arr[i].iterations, "chains": arr[i].chains, "words": arr[i].words}
-              for i in range(min(n.value, 16))]
+              for i in range(n.value)]
         return {"kernels": ks, "uniforms": sum(k["words"] * k["iterations"] for k in ks)}
 
     def placement(self, i):

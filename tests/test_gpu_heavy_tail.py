@@ -322,6 +322,9 @@ def test_small_genes_of_a_whole_gene_batch_on_eight_lanes_bit_exact(orc):
                 assert gpu.rundata.noAccepted == r.accepted, where
     assert "sampler_grp_multi<" in names[0], names
     assert "sampler_grp<8, true, " in names[4], names   # without the multi kernel the small genes' runs are eight-lane launches of their own
+    # (round 6: the launch's statistics have a record per run -- more than the sixteen the binding used to ask for -- and cover every chain)
+    st = b.launch_stats()
+    assert sum(k["chains"] for k in st["kernels"]) == len(evs) * kw["chains"], st
 
 
 def _worker(paired, K, rounds, **env):
