@@ -7,9 +7,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from miso_amd import workload
 
-E = 16384
+E = int(os.environ.get("WT_E", "16384"))
 nr = 1000 if "uniform" in sys.argv else workload.HG19_LIKE
-b = workload.build_batch(0, E, K=(3, 20), paired=True, n_reads=nr, device_match=True, iters=1500, burn=500)
+KK = int(os.environ["WT_K"]) if os.environ.get("WT_K") else (3, 20)   # WT_K=5 WT_E=40000: one isoform count
+b = workload.build_batch(0, E, K=KK, paired=True, n_reads=nr, device_match=True, iters=1500, burn=500)
 b.upload(0)
 b.launch(seed=42); ms = b.sync()
 b.launch(seed=42); ms = b.sync()
@@ -29,10 +30,11 @@ if "timeline" in sys.argv:   # how many chains of every class are running over t
     t1 = t0 + dur
     end = t1.max()
     print("# wavefront-chains running at t (ms): per class, 32 lanes => 2 chains per wavefront")
-    print("   t   " + " ".join("kc%-4d" % c for c in (32, 16, 12, 8, 4)) + "  all")
+    print("   t   " + " ".join("kc%-4d" % c for c in (32, 16, 12, 8, 4)) + "  all   pairs of the chains running: median / max")
     for t in np.arange(0, end, end / 24):
         row = [int(((t0 <= t) & (t1 > t) & (kc == c)).sum()) for c in (32, 16, 12, 8, 4)]
-        print("%6.1f " % t + " ".join("%6d" % r for r in row) + " %6d" % sum(row))
+        on = (t0 <= t) & (t1 > t)
+        print("%6.1f " % t + " ".join("%6d" % r for r in row) + " %6d" % sum(row) + ("   %8d %8d" % (np.median(nd[on]), nd[on].max()) if on.any() else ""))
 print("class  draws from..to   genes | chain time ms: min mean max")
 for c in (32, 16, 12, 8, 4):
     idx = np.where(kc == c)[0]
